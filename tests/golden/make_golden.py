@@ -1,0 +1,267 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in tests/golden/*.npz by running the REFERENCE
+(Shwai-He/VLM-Compression, mounted read-only at /root/reference) on small seeded
+inputs.  Runs only in the build container; the GPU box and the test-suite never
+import the reference -- they read the committed .npz files.
+
+Import recipe: SURVEY.md Appendix C (namespace stub for `lavis`, stubs for the
+missing `lavis.datasets.data_utils`, `omegaconf`, `bitsandbytes`).  No reference
+source is copied; only inputs and outputs are stored.
+
+    python tests/golden/make_golden.py            # all groups
+    python tests/golden/make_golden.py wanda      # one group
+"""
+import copy
+import importlib.machinery
+import os
+import sys
+import types
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.dont_write_bytecode = True          # never leave __pycache__ inside /root/reference
+
+
+def import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference not mounted; golden fixtures can only be regenerated in the build container")
+
+    def stub(name, **a):
+        m = types.ModuleType(name)
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        m.__dict__.update(a)
+        sys.modules[name] = m
+        return m
+
+    stub("lavis").__path__ = [REF + "/lavis"]
+    stub("lavis.datasets").__path__ = []
+    stub("lavis.datasets.data_utils", prepare_sample=lambda s, cuda_enabled=True: s)
+    stub("omegaconf", OmegaConf=type("OmegaConf", (), {}))
+    b = stub("bitsandbytes")
+    b.nn = stub("bitsandbytes.nn", Linear8bitLt=type("Linear8bitLt", (nn.Linear,), {}))
+    import lavis.compression  # noqa: F401  (registers the pruners)
+    torch.cuda.synchronize = lambda *a, **k: None      # sparsegpt_pruner.py:212 on a CPU-only box
+    torch.cuda.empty_cache = lambda *a, **k: None
+
+
+import golden_io  # noqa: E402
+import toy_models  # noqa: E402
+
+
+# --------------------------------------------------------------------------- #
+# single-linear towers: the block input IS the linear input
+# --------------------------------------------------------------------------- #
+class OneLinearT5Block(nn.Module):
+    def __init__(self, W):
+        super().__init__()
+        self.fc = nn.Linear(W.shape[1], W.shape[0], bias=False)
+        self.fc.weight.data = W.clone()
+
+    def forward(self, x, dense=False, **kw):
+        return (self.fc(x),)
+
+
+class OneLinearViTBlock(nn.Module):
+    def __init__(self, W):
+        super().__init__()
+        self.fc = nn.Linear(W.shape[1], W.shape[0], bias=False)
+        self.fc.weight.data = W.clone()
+
+    def forward(self, x, rel_pos_bias=None, dense=False):
+        return self.fc(x)
+
+
+class OneLinearModel(nn.Module):
+    def __init__(self, W, tower):
+        super().__init__()
+        import contextlib
+        self._ctx = contextlib.nullcontext
+        if tower == "t5":
+            self.t5_model = nn.Module()
+            self.t5_model.config = types.SimpleNamespace(use_cache=True)
+            self.t5_model.encoder = nn.Module()
+            self.t5_model.encoder.block = nn.ModuleList([OneLinearT5Block(W)])
+        else:
+            self.visual_encoder = nn.Module()
+            self.visual_encoder.blocks = nn.ModuleList([OneLinearViTBlock(W)])
+        self.tower = tower
+
+    def maybe_autocast(self, dtype=None):
+        return self._ctx()
+
+    def forward(self, samples):
+        if self.tower == "t5":
+            kw = dict(attention_mask=None, position_bias=None, encoder_hidden_states=None,
+                      encoder_attention_mask=None, encoder_decoder_position_bias=None, layer_head_mask=None,
+                      cross_attn_layer_head_mask=None)
+            return self.t5_model.encoder.block[0](samples["x"], **kw)
+        return self.visual_encoder.blocks[0](samples["x"], None)
+
+
+def ref_prune_one_linear(W, xs, tower, ratio=0.5, n=0, m=0):
+    """Run the reference Wanda loop body on one linear with hook inputs `xs`."""
+    from lavis.compression.pruners import wanda_pruner as R
+    model = OneLinearModel(W, tower)
+    loader = [{"x": x, "image": x, "text_input": [0] * x.shape[0]} for x in xs]
+    pr = R.BLIPT5LayerWandaPruner(model=model, data_loader=loader, t5_prune_spec="1-%r-1.0-1.0" % (1 - ratio),
+                                  vit_prune_spec="1-%r-1.0-1.0" % (1 - ratio), t5_pruning_method="wanda",
+                                  vit_pruning_method="wanda", num_samples=len(xs), prune_n=n, prune_m=m,
+                                  max_sparsity_per_layer=1.01)
+    sd = pr.get_sparsity(ratio, sparsity_ratio_granularity=None)
+    cls = R.T5LayerWandaPruner if tower == "t5" else R.VITLayerWandaPruner
+    pr.prepare_calibration_input_encoder = partial(cls.prepare_calibration_input_encoder, pr)
+    if tower == "t5":
+        cls._prune(pr, model, loader, model_prefix="t5_model", module_to_process="t5_model.encoder.block",
+                   n_samples=len(xs), sparsity_ratio=sd, lora_model=False)
+        fc = model.t5_model.encoder.block[0].fc
+    else:
+        cls._prune(pr, model, loader, model_prefix="visual_encoder", module_to_process="visual_encoder.blocks",
+                   n_samples=len(xs), sparsity_ratio=sd, lora_model=False)
+        fc = model.visual_encoder.blocks[0].fc
+    return fc.mask.clone(), fc.weight.data.clone(), float(fc.weight.importance_score)
+
+
+def craft_weight(out_f, in_f, dtype, seed, ties=True):
+    g = torch.Generator().manual_seed(seed)
+    W = (torch.randn(out_f, in_f, generator=g) * 0.02).to(dtype)
+    if ties:
+        W[0, :] = W[0, 0]                         # whole row of equal |w| (ties decided by scale)
+        W[1, ::3] = 0                             # exact zeros -> zero scores, index-ordered ties
+        W[2, :] = 0                               # all-zero row
+        W[3, 1::2] = -W[3, 0::2]                  # +/- pairs
+        W[5:9, 4:12] = W[5:9, 4:5]                # equal blocks
+    return W
+
+
+def make_xs(n, T, in_f, dtype, seed, mean=0.1, equal_cols=True):
+    g = torch.Generator().manual_seed(seed)
+    xs = []
+    for _ in range(n):
+        x = (torch.randn(1, T, in_f, generator=g) + mean).to(dtype)
+        if equal_cols:
+            x[..., 8:16] = x[..., 8:9]            # identical channels -> identical scales -> ties across columns
+        xs.append(x)
+    return xs
+
+
+# --------------------------------------------------------------------------- #
+def gen_wanda():
+    from lavis.compression.pruners import wanda_pruner as R
+    out = {}
+    # ---- G1: WrappedGPT.add_batch recurrence -----------------------------
+    cases = [("bf16", torch.bfloat16, 16, 128, 8, 1), ("fp16", torch.float16, 5, 64, 6, 1),
+             ("fp32", torch.float32, 16, 64, 8, 1), ("bf16_b2", torch.bfloat16, 7, 64, 4, 2),
+             ("fp32_b3", torch.float32, 9, 32, 3, 3)]
+    for name, dt, T, in_f, n, b in cases:
+        g = torch.Generator().manual_seed(100 + len(out))
+        layer = nn.Linear(in_f, 4, bias=False)
+        w = R.WrappedGPT(layer)
+        states = []
+        for j in range(n):
+            x = ((torch.randn(b, T, in_f, generator=g) * (1 + j % 3)) + 0.1).to(dt)
+            out[f"g1/{name}/x{j}"] = x
+            w.add_batch(x, None)
+            states.append(w.scaler_row.clone())
+        out[f"g1/{name}/states"] = torch.stack(states)
+        out[f"g1/{name}/n"] = n
+        out[f"g1/{name}/b"] = b
+    # ---- G2: per-row select (T5/LLM rule) --------------------------------
+    k = 0
+    for name, dt, ratio in [("bf16_r50", torch.bfloat16, 0.5), ("bf16_r30", torch.bfloat16, 0.3),
+                            ("fp16_r50", torch.float16, 0.5), ("fp32_r37", torch.float32, 0.37)]:
+        W = craft_weight(48, 128, dt, seed=200 + k)
+        xs = make_xs(8, 16, 128, dt, seed=300 + k)
+        mask, Wn, imp = ref_prune_one_linear(W, xs, "t5", ratio=ratio)
+        out.update({f"g2/{name}/W": W, f"g2/{name}/xs": torch.cat(xs), f"g2/{name}/ratio": ratio,
+                    f"g2/{name}/mask": mask, f"g2/{name}/Wn": Wn, f"g2/{name}/imp": imp})
+        k += 1
+    # ---- G3: matrix-wide select (ViT rule) -------------------------------
+    for name, dt, ratio in [("fp16_r50", torch.float16, 0.5), ("bf16_r25", torch.bfloat16, 0.25),
+                            ("fp32_r60", torch.float32, 0.6)]:
+        W = craft_weight(40, 96, dt, seed=400 + k)
+        xs = make_xs(6, 9, 96, dt, seed=500 + k)
+        mask, Wn, imp = ref_prune_one_linear(W, xs, "vit", ratio=ratio)
+        out.update({f"g3/{name}/W": W, f"g3/{name}/xs": torch.cat(xs), f"g3/{name}/ratio": ratio,
+                    f"g3/{name}/mask": mask, f"g3/{name}/Wn": Wn, f"g3/{name}/imp": imp})
+        k += 1
+    # ---- G4: n:m (tie-free weights; torch.topk tie order is implementation-defined)
+    for name, dt, n, m, tower in [("bf16_2_4_t5", torch.bfloat16, 2, 4, "t5"), ("fp16_4_8_vit", torch.float16, 4, 8, "vit"),
+                                  ("fp32_2_4_vit", torch.float32, 2, 4, "vit"), ("bf16_4_8_t5", torch.bfloat16, 4, 8, "t5")]:
+        W = craft_weight(32, 64, dt, seed=600 + k, ties=False)
+        xs = make_xs(5, 11, 64, dt, seed=700 + k, equal_cols=False)
+        mask, Wn, imp = ref_prune_one_linear(W, xs, tower, n=n, m=m)
+        out.update({f"g4/{name}/W": W, f"g4/{name}/xs": torch.cat(xs), f"g4/{name}/n": n, f"g4/{name}/m": m,
+                    f"g4/{name}/mask": mask, f"g4/{name}/Wn": Wn, f"g4/{name}/imp": imp})
+        k += 1
+    golden_io.save("wanda_unit", out)
+    print("wanda_unit.npz:", len(out), "arrays")
+
+
+def _wrap_lora_reference(model, r=4, alpha=16):
+    """Swap every prunable nn.Linear for the reference SparseLoRA Linear sharing the
+    weight, like LoraModel._replace_module (lora.py:190-208)."""
+    from lavis.peft.src.peft.tuners.lora import Linear as RefLoraLinear
+    g = torch.Generator().manual_seed(4242)
+    for parent in list(model.modules()):
+        for cname, child in list(parent.named_children()):
+            if type(child) is nn.Linear and cname != "t5_proj":
+                new = RefLoraLinear(child.in_features, child.out_features, r=r, lora_alpha=alpha,
+                                    bias=child.bias is not None)
+                new.weight = child.weight
+                if child.bias is not None:
+                    new.bias = child.bias
+                new.mask = torch.ones_like(child.weight.data).bool()
+                with torch.no_grad():
+                    new.lora_A.weight.copy_(torch.randn(new.lora_A.weight.shape, generator=g) * 0.05)
+                    new.lora_B.weight.copy_(torch.randn(new.lora_B.weight.shape, generator=g) * 0.05)
+                new.to(child.weight.dtype)
+                setattr(parent, cname, new)
+    return model
+
+
+def gen_wanda_e2e():
+    """G8: whole-pruner runs on the toy InstructBLIP (ViT -> encoder -> decoder)."""
+    from lavis.compression.pruners import wanda_pruner as R
+    variants = {
+        "fp32_r50": dict(vit_dtype=torch.float32, t5_dtype=torch.float32, ratio=0.5, n=0, m=0, lora=False),
+        "mixed_2_4": dict(vit_dtype=torch.float32, t5_dtype=torch.bfloat16, ratio=0.5, n=2, m=4, lora=False),
+        "fp32_r40_lora": dict(vit_dtype=torch.float32, t5_dtype=torch.float32, ratio=0.4, n=0, m=0, lora=True),
+    }
+    out = {}
+    for name, v in variants.items():
+        model = toy_models.init_toy(toy_models.ToyBlipT5(vit_dtype=v["vit_dtype"], t5_dtype=v["t5_dtype"]), seed=7)
+        if v["lora"]:
+            _wrap_lora_reference(model)
+        model.eval()
+        batches = toy_models.make_batches(6, seed=11)
+        spec = "2-%r-1.0-1.0" % (1 - v["ratio"])
+        pr = R.BLIPT5LayerWandaPruner(model=model, data_loader=batches, t5_prune_spec=spec, vit_prune_spec=spec,
+                                      t5_pruning_method="wanda", vit_pruning_method="wanda", num_samples=6,
+                                      prune_n=v["n"], prune_m=v["m"], max_sparsity_per_layer=1.01)
+        pruned, _ = pr.prune(lora_model=True) if v["lora"] else pr.prune()
+        for k_, t in pruned.state_dict().items():
+            out[f"{name}/sd/{k_}"] = t
+        for mn, mod in pruned.named_modules():
+            if hasattr(mod, "mask") and "mask" not in dict(mod.named_buffers(recurse=False)):
+                out[f"{name}/mask/{mn}"] = mod.mask
+            if hasattr(mod, "weight") and hasattr(mod.weight, "importance_score"):
+                out[f"{name}/imp/{mn}"] = float(mod.weight.importance_score)
+        out[f"{name}/ratio"] = v["ratio"]
+    golden_io.save("wanda_e2e", out)
+    print("wanda_e2e.npz:", len(out), "arrays")
+
+
+GROUPS = {"wanda": gen_wanda, "wanda_e2e": gen_wanda_e2e}
+
+if __name__ == "__main__":
+    import_reference()
+    torch.set_num_threads(1)
+    todo = sys.argv[1:] or list(GROUPS)
+    for gname in todo:
+        GROUPS[gname]()
