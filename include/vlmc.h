@@ -1,0 +1,90 @@
+/* vlmc.h -- C ABI of the MI355X (gfx950) pruning / SparseLoRA kernels.
+ *
+ * Drop-in boundary for the hot path of Shwai-He/VLM-Compression
+ * (lavis/compression/pruners/ and lavis/peft/src/peft/tuners/lora.py).  The
+ * reference is pure Python on PyTorch ops, so the "FFI" a maintainer binds is a
+ * ctypes stub; every entry point below names the reference
+ * op sequence (file:line under /root/reference) it replaces.
+ *
+ * Conventions
+ *  - plain pointers + sizes; no torch types.  All tensor pointers are DEVICE
+ *    pointers owned by the caller; the library borrows them for the call,
+ *    allocates nothing, frees nothing, and enqueues on `stream` (a hipStream_t
+ *    passed as void*; NULL = default stream).  It never synchronises.
+ *  - scratch comes from a caller-provided workspace: ask `*_workspace()` for
+ *    the size, pass a device buffer of at least that many bytes (256-B aligned).
+ *  - every function returns 0 on success or a negative VLMC_E* code;
+ *    `vlmc_last_error()` returns a thread-local message for the last failure.
+ *  - matrices are row-major `[out, in]` like `nn.Linear.weight`; `ld*` is the
+ *    row stride in ELEMENTS.
+ *  - masks are `torch.bool` storage: one byte per element, 1 = keep, 0 = pruned
+ *    (the reference's `module.mask`, wanda_pruner.py:339).
+ */
+#ifndef VLMC_H
+#define VLMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VLMC_ABI_VERSION 1
+
+#define VLMC_OK 0
+#define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
+#define VLMC_EHIP (-2)       /* HIP runtime error (launch failure, no device)        */
+#define VLMC_EWORKSPACE (-3) /* workspace too small                                  */
+#define VLMC_ENOTPD (-4)     /* Hessian not positive definite after max damping      */
+
+/* element types of weights / activations */
+#define VLMC_F32 0
+#define VLMC_F16 1
+#define VLMC_BF16 2
+
+/* Wanda selection rules */
+#define VLMC_SEL_ROW 0    /* per output row, k smallest, stable (wanda_pruner.py:332-337) */
+#define VLMC_SEL_MATRIX 1 /* matrix-wide strict threshold (wanda_pruner.py:682-683)      */
+#define VLMC_SEL_NM 2     /* n of every m consecutive columns (wanda_pruner.py:326-329)  */
+
+int vlmc_abi_version(void);
+const char *vlmc_last_error(void);
+
+/* ---- K1: activation statistics ------------------------------------------------
+ * Replaces the body of WrappedGPT.add_batch, wanda_pruner.py:68-81
+ *     inp = inp.reshape(-1, in).t().float();  torch.norm(inp, p=2, dim=1) ** 2
+ * for `n_calls` hook calls at once.  Call c reads `tokens` rows of `in_features`
+ * elements starting at x + c*call_stride, rows `row_stride` elements apart.
+ * normsq[c, ch] = square(sqrtf(chain_t fmaf(x, x, acc)))  -- the token reduction
+ * is the sequential fused-multiply-add chain torch's CPU kernel performs, so the
+ * result is bit-identical to the reference's CPU path.                           */
+int vlmc_act_sqnorm(const void *x, int dtype, int64_t n_calls, int64_t tokens, int64_t in_features,
+                    int64_t row_stride, int64_t call_stride, float *normsq /* [n_calls, in] */, void *stream);
+
+/* Running mean of wanda_pruner.py:77-81 applied for `n_calls` further calls of
+ * `batch` samples each, in call order:
+ *     s *= float(n / (n + batch));  n += batch;  s += normsq[c] / float(n)          */
+int vlmc_wanda_scaler_update(float *scaler_row /* [in], in/out */, int64_t in_features, int64_t nsamples_before,
+                             const float *normsq /* [n_calls, in] */, int64_t n_calls, int64_t batch, void *stream);
+
+/* ---- K2-K7: fused score + select + apply ----------------------------------------
+ * Replaces wanda_pruner.py:318-341 (T5/LLM) and :666-687 (ViT) for one linear:
+ *     score = |W| * sqrt(scaler_row)            (fp32, never materialised)
+ *     SEL_ROW:    prune the `k` lowest-score columns of every row, ties -> lowest column
+ *     SEL_MATRIX: thr = sort(score.flatten())[k]; prune score < thr   (ties with thr kept)
+ *     SEL_NM:     prune the n lowest of every m consecutive columns, ties -> lowest column
+ *     mask = keep (1 byte/elt);  if apply_zero: W[pruned] = 0 in place
+ *     *score_sum = sum(score) as double  (importance_score = score_sum / (out*in))
+ * `k` is computed by the caller exactly like the reference (int(in*ratio) or
+ * int(out*in*ratio)).  score_sum may be NULL.                                     */
+size_t vlmc_wanda_select_workspace(int mode, int64_t out_features, int64_t in_features);
+int vlmc_wanda_select(void *W, int dtype, int64_t out_features, int64_t in_features, int64_t ldw,
+                      const float *scaler_row, int mode, int64_t k, int n, int m, int apply_zero,
+                      uint8_t *mask /* [out, in] */, double *score_sum /* device, 1 elt */, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLMC_H */

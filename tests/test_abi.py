@@ -1,0 +1,46 @@
+"""CPU-only: the C-ABI library loads and exports exactly what include/vlmc.h declares."""
+import ctypes
+
+import pytest
+
+from vlmc import _lib
+
+
+def test_library_exports_every_header_symbol():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _lib.header_functions()
+    assert declared, "no functions parsed from include/vlmc.h"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/vlmc.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared, "vlmc/_lib.py SIGNATURES out of sync with include/vlmc.h"
+
+
+def test_abi_version_and_error_string():
+    lib = _lib.load()
+    assert lib.vlmc_abi_version() == _lib.header_abi_version()
+    assert isinstance(lib.vlmc_last_error(), bytes)
+
+
+def test_workspace_query_needs_no_gpu():
+    lib = _lib.load()
+    assert lib.vlmc_wanda_select_workspace(_lib.SEL_ROW, 5120, 2048) >= 2048 * 4 + 5120 * 8
+    assert lib.vlmc_wanda_select_workspace(_lib.SEL_MATRIX, 6144, 1408) >= 1408 * 4 + (4096 + 2048) * 4
+    assert lib.vlmc_wanda_select_workspace(7, 1, 1) == 0
+
+
+def test_argument_validation_fails_loudly_without_touching_the_gpu():
+    lib = _lib.load()
+    rc = lib.vlmc_act_sqnorm(None, _lib.BF16, 1, 1, 8, 8, 8, None, None)
+    assert rc == _lib.VLMC_EINVAL and b"null pointer" in lib.vlmc_last_error()
+    with pytest.raises(_lib.VlmcError):
+        _lib.check(rc)
+
+
+def test_ops_refuse_cpu_tensors():
+    """No CPU fallback: the product path raises instead of computing on the host."""
+    import torch
+    from vlmc import ops
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.act_sqnorm(torch.zeros(1, 4, 8))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.wanda_select(torch.zeros(4, 8), torch.zeros(8), "row", k=2)

@@ -1,0 +1,15 @@
+// Error plumbing and ABI version for the C-ABI library (include/vlmc.h).
+#include "common.hpp"
+
+namespace vlmc {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace vlmc
+
+extern "C" int vlmc_abi_version(void) { return VLMC_ABI_VERSION; }
+extern "C" const char *vlmc_last_error(void) { return vlmc::g_err; }

@@ -1,0 +1,115 @@
+// Shared device/host helpers for the gfx950 kernels.  Built with -ffp-contract=off:
+// every fp32 operation below is a single correctly rounded IEEE op, which is what
+// makes mask indices bit-identical to the reference's PyTorch path.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/vlmc.h"
+
+namespace vlmc {
+
+// ---- error plumbing ---------------------------------------------------------------
+void set_error(const char *fmt, ...);
+#define VLMC_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            ::vlmc::set_error(__VA_ARGS__); \
+            return VLMC_EINVAL;            \
+        }                                  \
+    } while (0)
+#define VLMC_HIP_CHECK_LAUNCH(what)                                                  \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) {                                                      \
+            ::vlmc::set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e_)); \
+            return VLMC_EHIP;                                                        \
+        }                                                                            \
+    } while (0)
+
+// ---- element types ----------------------------------------------------------------
+struct f32_t { using raw = float; };
+struct f16_t { using raw = uint16_t; };
+struct bf16_t { using raw = uint16_t; };
+
+template <typename T> __device__ __forceinline__ float to_f32(typename T::raw v);
+template <> __device__ __forceinline__ float to_f32<f32_t>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(uint16_t v) { return __uint_as_float(uint32_t(v) << 16); }
+template <> __device__ __forceinline__ float to_f32<f16_t>(uint16_t v) {
+    _Float16 h;
+    __builtin_memcpy(&h, &v, 2);
+    return float(h);
+}
+
+// 8 consecutive elements of a row, as loaded by one lane (16 B for 16-bit types, 32 B for f32).
+template <typename T> struct Chunk8;
+template <> struct Chunk8<f32_t> { float v[8]; };
+template <> struct Chunk8<f16_t> { uint16_t v[8]; };
+template <> struct Chunk8<bf16_t> { uint16_t v[8]; };
+
+template <typename T> __device__ __forceinline__ Chunk8<T> load_chunk8(const typename T::raw *p) {
+    Chunk8<T> c;
+    if constexpr (sizeof(typename T::raw) == 2) {
+        uint4 q = *reinterpret_cast<const uint4 *>(p);
+        __builtin_memcpy(c.v, &q, 16);
+    } else {
+        float4 a = reinterpret_cast<const float4 *>(p)[0];
+        float4 b = reinterpret_cast<const float4 *>(p)[1];
+        __builtin_memcpy(c.v, &a, 16);
+        __builtin_memcpy(c.v + 4, &b, 16);
+    }
+    return c;
+}
+template <typename T> __device__ __forceinline__ void store_chunk8(typename T::raw *p, const Chunk8<T> &c) {
+    if constexpr (sizeof(typename T::raw) == 2) {
+        uint4 q;
+        __builtin_memcpy(&q, c.v, 16);
+        *reinterpret_cast<uint4 *>(p) = q;
+    } else {
+        float4 a, b;
+        __builtin_memcpy(&a, c.v, 16);
+        __builtin_memcpy(&b, c.v + 4, 16);
+        reinterpret_cast<float4 *>(p)[0] = a;
+        reinterpret_cast<float4 *>(p)[1] = b;
+    }
+}
+
+// Wanda score -> order-preserving unsigned key.  score = |w| * sqrt(s) >= +0 or NaN.
+// NaN sorts last (torch.sort semantics) -> 0xFFFFFFFF; -0 (impossible, but harmless) == +0.
+__device__ __forceinline__ uint32_t score_key(float sc) {
+    return (sc != sc) ? 0xFFFFFFFFu : (__float_as_uint(sc) & 0x7FFFFFFFu);
+}
+
+// Correctly rounded fp32 primitives.  NOTE: HIP's __fsqrt_rn / __fdiv_rn are NOT the IEEE
+// operations (they lower to the approximate native instructions unless OCML rounded ops are
+// enabled); plain sqrtf and `/` are, under -fhip-fp32-correctly-rounded-divide-sqrt (hipcc's
+// default, also passed explicitly by the Makefile).  With -ffp-contract=off `a*b` and `a+b`
+// are never fused.  tests/test_wanda_gpu.py::test_ieee_sqrt_div_fma_on_device checks all of
+// them against the host's IEEE arithmetic.
+__device__ __forceinline__ float ieee_sqrt(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ float ieee_div(float a, float b) { return a / b; }
+__device__ __forceinline__ float ieee_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float ieee_add(float a, float b) { return a + b; }
+
+constexpr int kWave = 64;
+
+// wave-wide sum of a 32-bit integer (result valid in every lane)
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace vlmc

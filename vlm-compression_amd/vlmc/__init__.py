@@ -1,0 +1,10 @@
+"""vlmc -- host-side binding of the gfx950 pruning / SparseLoRA kernels.
+
+`vlmc._lib` loads the C-ABI shared library (include/vlmc.h) with ctypes;
+`vlmc.ops` wraps its entry points for torch tensors (device pointers, current HIP
+stream, caller-owned workspace).  There is NO CPU fallback: every op raises if the
+library is missing or the tensors are not on a GPU.
+"""
+from . import _lib, ops  # noqa: F401
+
+__all__ = ["_lib", "ops"]
