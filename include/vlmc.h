@@ -64,24 +64,34 @@ int vlmc_act_sqnorm(const void *x, int dtype, int64_t n_calls, int64_t tokens, i
 
 /* Running mean of wanda_pruner.py:77-81 applied for `n_calls` further calls of
  * `batch` samples each, in call order:
- *     s *= float(n / (n + batch));  n += batch;  s += normsq[c] / float(n)          */
+ *     s *= float(n / (n + batch));  n += batch;  s += normsq[c] / float(n)
+ * If `sqrt_out` is not NULL it also receives sqrtf(s) -- the `torch.sqrt(scaler_row)`
+ * factor of the score (wanda_pruner.py:318) that vlmc_wanda_select consumes.
+ * n_calls may be 0 (only the square roots are produced).                           */
 int vlmc_wanda_scaler_update(float *scaler_row /* [in], in/out */, int64_t in_features, int64_t nsamples_before,
-                             const float *normsq /* [n_calls, in] */, int64_t n_calls, int64_t batch, void *stream);
+                             const float *normsq /* [n_calls, in] */, int64_t n_calls, int64_t batch,
+                             float *sqrt_out /* [in] or NULL */, void *stream);
 
 /* ---- K2-K7: fused score + select + apply ----------------------------------------
  * Replaces wanda_pruner.py:318-341 (T5/LLM) and :666-687 (ViT) for one linear:
- *     score = |W| * sqrt(scaler_row)            (fp32, never materialised)
+ *     score = |W| * sqrt_scaler                 (fp32, never materialised; sqrt_scaler =
+ *                                                sqrtf(scaler_row) from vlmc_wanda_scaler_update)
  *     SEL_ROW:    prune the `k` lowest-score columns of every row, ties -> lowest column
  *     SEL_MATRIX: thr = sort(score.flatten())[k]; prune score < thr   (ties with thr kept)
  *     SEL_NM:     prune the n lowest of every m consecutive columns, ties -> lowest column
  *     mask = keep (1 byte/elt);  if apply_zero: W[pruned] = 0 in place
- *     *score_sum = sum(score) as double  (importance_score = score_sum / (out*in))
+ *     score_partials[i] = partial sums of score as double; their sum is sum(score)
+ *                         (importance_score = sum / (out*in), wanda_pruner.py:320).  The
+ *                         caller adds them (fixed count and order => deterministic) -- one
+ *                         device reduction per transformer block instead of one launch per
+ *                         linear.  `vlmc_wanda_select_partials()` gives the count; may be NULL.
  * `k` is computed by the caller exactly like the reference (int(in*ratio) or
- * int(out*in*ratio)).  score_sum may be NULL.                                     */
+ * int(out*in*ratio)).  Only SEL_MATRIX needs a workspace (else size 0, NULL is fine). */
 size_t vlmc_wanda_select_workspace(int mode, int64_t out_features, int64_t in_features);
+int64_t vlmc_wanda_select_partials(int mode, int64_t out_features, int64_t in_features);
 int vlmc_wanda_select(void *W, int dtype, int64_t out_features, int64_t in_features, int64_t ldw,
-                      const float *scaler_row, int mode, int64_t k, int n, int m, int apply_zero,
-                      uint8_t *mask /* [out, in] */, double *score_sum /* device, 1 elt */, void *workspace,
+                      const float *sqrt_scaler, int mode, int64_t k, int n, int m, int apply_zero,
+                      uint8_t *mask /* [out, in] */, double *score_partials /* device */, void *workspace,
                       size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus

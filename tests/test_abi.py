@@ -23,8 +23,9 @@ def test_abi_version_and_error_string():
 
 def test_workspace_query_needs_no_gpu():
     lib = _lib.load()
-    assert lib.vlmc_wanda_select_workspace(_lib.SEL_ROW, 5120, 2048) >= 2048 * 4 + 5120 * 8
-    assert lib.vlmc_wanda_select_workspace(_lib.SEL_MATRIX, 6144, 1408) >= 1408 * 4 + (4096 + 2048) * 4
+    assert lib.vlmc_wanda_select_workspace(_lib.SEL_ROW, 5120, 2048) == 0
+    assert lib.vlmc_wanda_select_partials(_lib.SEL_ROW, 5120, 2048) == 5120
+    assert lib.vlmc_wanda_select_workspace(_lib.SEL_MATRIX, 6144, 1408) >= (4096 + 2048) * 4
     assert lib.vlmc_wanda_select_workspace(7, 1, 1) == 0
 
 

@@ -87,8 +87,8 @@ def test_sqnorm_strided_rows_and_misaligned_base():
 def _run_select(W, s, mode, **kw):
     ops = _ops()
     Wd = W.clone().to(DEV)
-    mask, ssum = ops.wanda_select(Wd, torch.from_numpy(s).to(DEV), mode, **kw)
-    return mask.cpu().numpy(), Wd.cpu(), float(ssum.item()) / W.numel()
+    mask, ssum = ops.wanda_select(Wd, ops.sqrt_scaler(torch.from_numpy(s).to(DEV)), mode, **kw)
+    return mask.cpu().numpy(), Wd.cpu(), float(ssum.sum().item()) / W.numel()
 
 
 def _check_vs_oracle(W, s, mode, ratio=None, n=0, m=0, apply_zero=True):
@@ -220,6 +220,7 @@ def test_bad_arguments_raise():
     ops = _ops()
     W = torch.zeros(4, 16, dtype=torch.bfloat16, device=DEV)
     s = torch.ones(16, device=DEV)
+    s = ops.sqrt_scaler(s)
     with pytest.raises(_lib.VlmcError):
         ops.wanda_select(W, s, "row", k=17)
     with pytest.raises(_lib.VlmcError):

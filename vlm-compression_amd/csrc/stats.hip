@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void act_sqnorm_kernel(const typename T::raw *
 
 // s *= float(n/(n+b)); n += b; s += normsq[c] / float(n)   (wanda_pruner.py:77-81)
 __global__ void scaler_update_kernel(float *__restrict__ s, int64_t in_f, int64_t n0, const float *__restrict__ normsq,
-                                     int64_t n_calls, int64_t batch) {
+                                     int64_t n_calls, int64_t batch, float *__restrict__ sqrt_out) {
     const int64_t ch = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (ch >= in_f) return;
     float acc = s[ch];
@@ -75,6 +75,7 @@ __global__ void scaler_update_kernel(float *__restrict__ s, int64_t in_f, int64_
         acc = ieee_add(acc, ieee_div(normsq[c * in_f + ch], float(n)));
     }
     s[ch] = acc;
+    if (sqrt_out) sqrt_out[ch] = ieee_sqrt(acc);   // torch.sqrt(scaler_row), wanda_pruner.py:318
 }
 
 template <typename T>
@@ -147,15 +148,16 @@ extern "C" int vlmc_act_sqnorm(const void *x, int dtype, int64_t n_calls, int64_
 }
 
 extern "C" int vlmc_wanda_scaler_update(float *scaler_row, int64_t in_features, int64_t nsamples_before,
-                                        const float *normsq, int64_t n_calls, int64_t batch, void *stream) {
-    VLMC_REQUIRE(scaler_row && normsq, "vlmc_wanda_scaler_update: null pointer");
+                                        const float *normsq, int64_t n_calls, int64_t batch, float *sqrt_out,
+                                        void *stream) {
+    VLMC_REQUIRE(scaler_row && (normsq || n_calls == 0), "vlmc_wanda_scaler_update: null pointer");
     VLMC_REQUIRE(in_features > 0 && n_calls >= 0 && batch > 0 && nsamples_before >= 0,
                  "vlmc_wanda_scaler_update: bad arguments in=%lld calls=%lld batch=%lld n0=%lld", (long long)in_features,
                  (long long)n_calls, (long long)batch, (long long)nsamples_before);
-    if (n_calls == 0) return VLMC_OK;
+    if (n_calls == 0 && !sqrt_out) return VLMC_OK;
     const int threads = 256;
     hipLaunchKernelGGL(scaler_update_kernel, dim3(unsigned((in_features + threads - 1) / threads)), dim3(threads), 0,
-                       as_stream(stream), scaler_row, in_features, nsamples_before, normsq, n_calls, batch);
+                       as_stream(stream), scaler_row, in_features, nsamples_before, normsq, n_calls, batch, sqrt_out);
     VLMC_HIP_CHECK_LAUNCH("vlmc_wanda_scaler_update");
     return VLMC_OK;
 }

@@ -10,7 +10,10 @@
 //             coalesced).  The k-th smallest key is found by bisection on the key bits with
 //             wave-wide counting (DPP reduction), switching to an exact all-pairs rank over the
 //             few keys left in the bracket; ties are broken by column index exactly like the
-//             reference's stable sort.  A persistent grid walks the rows.
+//             reference's stable sort.  A persistent grid walks the rows: each wave seeds the
+//             bracket of its next row with the threshold of its previous one (rows of one
+//             matrix share the column scales, so thresholds differ by a few percent) and
+//             prefetches the next row while it works on the current one.
 //  SEL_MATRIX three global radix-histogram passes (12+10+10 key bits, LDS histograms flushed with
 //             integer atomics), then an elementwise apply pass.  W (<= 17 MB for ViT-g) is
 //             re-read from L2/Infinity Cache, not HBM.
@@ -35,6 +38,28 @@ __device__ __forceinline__ uint32_t wave_sum_u32_dpp(uint32_t v) {
            uint32_t(__builtin_amdgcn_readlane(int(v), 32)) + uint32_t(__builtin_amdgcn_readlane(int(v), 48));
 }
 
+// f32 sum over the 64 lanes with DPP; every lane of the result row holds the total of its 16-lane
+// row, the four row totals are combined through readlane (fixed order => deterministic).
+__device__ __forceinline__ float wave_sum_f32_dpp(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for
+// outstanding global loads (vmcnt), so the next row's prefetch stays in flight across it.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // inclusive prefix sum over lanes (rare tie path; shuffles are fine)
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
     const int lane = threadIdx.x & 63;
@@ -44,26 +69,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
         if (lane >= off) v += o;
     }
     return v;
-}
-
-__global__ void sqrt_scaler_kernel(const float *__restrict__ s, float *__restrict__ sq, int64_t n) {
-    int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < n) sq[i] = ieee_sqrt(s[i]);   // torch.sqrt(scaler_row), wanda_pruner.py:318
-}
-
-// deterministic final reduction of per-row / per-block partial sums
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__restrict__ part, int64_t n,
-                                                              double *__restrict__ out) {
-    __shared__ double sm[256];
-    double a = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) a += part[i];
-    sm[threadIdx.x] = a;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (int(threadIdx.x) < s) sm[threadIdx.x] += sm[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = sm[0];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -122,23 +127,55 @@ constexpr int kCap = 32;   // bracket population at which bisection hands over t
 
 template <int NW> struct RowSmem {
     uint32_t cnt[2][NW];       // double-buffered per-wave counts
+    uint32_t cnt2[2][NW];
     uint32_t scan[NW];
     double dsum[NW];
-    unsigned long long cand[kCap];
+    unsigned long long seg[NW * kCap];   // per-wave candidate segments
+    unsigned long long cand[kCap];       // dense candidate list
     unsigned long long cut;
-    uint32_t ncand;
+    uint32_t segcnt[NW];
 };
 
-template <int E, int NW>
-__device__ __forceinline__ uint32_t block_count_le(const uint32_t (&key)[E], uint32_t mid, RowSmem<NW> &sm, int &phase) {
+#ifndef VLMC_COUNT_MODE
+#define VLMC_COUNT_MODE 0
+#endif
+// wave-wide count(key <= mid).  Three codegen variants (VLMC_COUNT_MODE) for tuning:
+//  0: per-lane counters (v_cmp + v_addc) reduced with DPP
+//  1: ballot + scalar popcount (v_cmp -> SGPR pair, s_bcnt1, s_add): no cross-lane reduce
+//  2: half of the keys each way, so the vector and the scalar unit share the work
+template <int E> __device__ __forceinline__ uint32_t wave_count_le(const uint32_t (&key)[E], uint32_t mid) {
+#if VLMC_COUNT_MODE == 1
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < E; ++i) c += uint32_t(__popcll(__ballot(key[i] <= mid)));
+    return c;
+#elif VLMC_COUNT_MODE == 2
+    constexpr int H = (E * 3) / 8;   // share counted on the scalar unit
+    uint32_t cs = 0, c0 = 0, c1 = 0;
+#pragma unroll
+    for (int i = 0; i < H; ++i) cs += uint32_t(__popcll(__ballot(key[i] <= mid)));
+#pragma unroll
+    for (int i = H; i + 1 < E; i += 2) {
+        c0 += (key[i] <= mid) ? 1u : 0u;
+        c1 += (key[i + 1] <= mid) ? 1u : 0u;
+    }
+    if ((E - H) & 1) c0 += (key[E - 1] <= mid) ? 1u : 0u;
+    return cs + wave_sum_u32_dpp(c0 + c1);
+#else
     uint32_t c = 0;
 #pragma unroll
     for (int i = 0; i < E; ++i) c += (key[i] <= mid) ? 1u : 0u;
-    c = wave_sum_u32_dpp(c);
+    return wave_sum_u32_dpp(c);
+#endif
+}
+
+template <int E, int NW>
+__device__ __forceinline__ uint32_t block_count_le(const uint32_t (&key)[E], uint32_t mid, RowSmem<NW> &sm, int &phase) {
+    uint32_t c = wave_count_le<E>(key, mid);
     if constexpr (NW > 1) {
         const int wave = threadIdx.x >> 6;
         if ((threadIdx.x & 63) == 0) sm.cnt[phase][wave] = c;
-        __syncthreads();
+        lds_barrier();
         uint32_t t = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) t += sm.cnt[phase][w];
@@ -148,10 +185,30 @@ __device__ __forceinline__ uint32_t block_count_le(const uint32_t (&key)[E], uin
     return c;
 }
 
+// count(key <= a) and count(key <= b) in one sweep (bracket verification)
+template <int E, int NW>
+__device__ __forceinline__ void block_count_le2(const uint32_t (&key)[E], uint32_t a, uint32_t b, RowSmem<NW> &sm,
+                                                int &phase, uint32_t &ca, uint32_t &cb) {
+    uint32_t x = wave_count_le<E>(key, a);
+    uint32_t y = wave_count_le<E>(key, b);
+    if constexpr (NW > 1) {
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sm.cnt[phase][wave] = x; sm.cnt2[phase][wave] = y; }
+        lds_barrier();
+        uint32_t tx = 0, ty = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { tx += sm.cnt[phase][w]; ty += sm.cnt2[phase][w]; }
+        phase ^= 1;
+        x = tx; y = ty;
+    }
+    ca = x; cb = y;
+}
+
 template <typename T, int CH, int NW, bool ALIGNED>
-__global__ __launch_bounds__(64 * NW) void select_rows_kernel(typename T::raw *__restrict__ W, int64_t out_f,
-                                                              int64_t in_f, int64_t ldw, const float *__restrict__ sq,
-                                                              uint32_t k, int apply_zero, uint8_t *__restrict__ mask,
+__global__ __launch_bounds__(64 * NW, 4) void select_rows_kernel(typename T::raw *__restrict__ W, int64_t out_f,
+                                                              int64_t in_f, int64_t ldw,
+                                                              const float *__restrict__ sqrt_scaler, uint32_t k,
+                                                              int apply_zero, uint8_t *__restrict__ mask,
                                                               double *__restrict__ row_sums) {
     constexpr int NT = 64 * NW;
     constexpr int E = CH * 8;
@@ -159,7 +216,8 @@ __global__ __launch_bounds__(64 * NW) void select_rows_kernel(typename T::raw *_
     const int tid = threadIdx.x;
     const int64_t nchunks = (in_f + 7) / 8;
 
-    // per-column sqrt(scaler_row), loaded once and reused for every row this workgroup handles
+    // per-column sqrt(scaler_row) (wanda_pruner.py:318), loaded once per workgroup and kept in
+    // registers for every row it handles
     float sqv[E];
     bool valid[CH];
 #pragma unroll
@@ -167,22 +225,40 @@ __global__ __launch_bounds__(64 * NW) void select_rows_kernel(typename T::raw *_
         const int64_t c = int64_t(s) * NT + tid;
         valid[s] = c < nchunks;
         if (valid[s]) {
-            load_sq_chunk<ALIGNED>(sq, c * 8, in_f, &sqv[s * 8]);
+            load_sq_chunk<ALIGNED>(sqrt_scaler, c * 8, in_f, &sqv[s * 8]);
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) sqv[s * 8 + j] = 0.f;
         }
     }
 
-    for (int64_t row = blockIdx.x; row < out_f; row += gridDim.x) {
+    // software prefetch: the next row's chunks are in flight while the current row is processed
+    Chunk8<T> nxt[CH];
+    int64_t row = blockIdx.x;
+    if (row < out_f) {
+#pragma unroll
+        for (int s = 0; s < CH; ++s)
+            if (valid[s]) nxt[s] = load_row_chunk<T, ALIGNED>(W + row * ldw, (int64_t(s) * NT + tid) * 8, in_f);
+    }
+    bool have_prev = false;
+    uint32_t prev_key = 0;
+
+    for (; row < out_f; row += gridDim.x) {
         typename T::raw *wrow = W + row * ldw;
         Chunk8<T> raw[CH];
+#pragma unroll
+        for (int s = 0; s < CH; ++s) raw[s] = nxt[s];
+        const int64_t nrow = row + gridDim.x;
+        if (nrow < out_f) {
+#pragma unroll
+            for (int s = 0; s < CH; ++s)
+                if (valid[s]) nxt[s] = load_row_chunk<T, ALIGNED>(W + nrow * ldw, (int64_t(s) * NT + tid) * 8, in_f);
+        }
         uint32_t key[E];
         float fsum = 0.f;
 #pragma unroll
         for (int s = 0; s < CH; ++s) {
             const int64_t col0 = (int64_t(s) * NT + tid) * 8;
-            if (valid[s]) raw[s] = load_row_chunk<T, ALIGNED>(wrow, col0, in_f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const bool live = valid[s] && (ALIGNED || col0 + j < in_f);
@@ -208,6 +284,22 @@ __global__ __launch_bounds__(64 * NW) void select_rows_kernel(typename T::raw *_
             uint32_t lo = 0, hi = 0xFFFFFFFFu;
             uint32_t cb = 0;                    // count(key <  lo)
             uint32_t ca = uint32_t(NT) * E;     // count(key <= hi)
+            if (have_prev) {
+                // guess: this row's threshold lies within +-2^20 key units (6..12 % in value) of the
+                // previous row's.  Verified by counting, so a wrong guess only costs time.
+                constexpr uint32_t D = 1u << 20;
+                const uint32_t glo = prev_key > D ? prev_key - D : 0u;
+                const uint32_t ghi = prev_key < 0xFFFFFFFFu - D ? prev_key + D : 0xFFFFFFFFu;
+                uint32_t c_below = 0, c_upto = 0;   // count(key < glo), count(key <= ghi)
+                if (glo > 0) {
+                    block_count_le2<E, NW>(key, glo - 1, ghi, sm, phase, c_below, c_upto);
+                } else {
+                    c_upto = block_count_le<E, NW>(key, ghi, sm, phase);
+                }
+                if (c_below >= k) { hi = glo - 1; ca = c_below; }
+                else if (c_upto < k) { lo = ghi + 1; cb = c_upto; }
+                else { lo = glo; hi = ghi; cb = c_below; ca = c_upto; }
+            }
             while (ca - cb > uint32_t(kCap) && lo != hi) {
                 const uint32_t mid = lo + ((hi - lo) >> 1);
                 const uint32_t c = block_count_le<E, NW>(key, mid, sm, phase);
@@ -216,32 +308,56 @@ __global__ __launch_bounds__(64 * NW) void select_rows_kernel(typename T::raw *_
             const uint32_t need = k - cb;       // how many keys inside [lo,hi] are pruned (1..pop)
             const uint32_t pop = ca - cb;
             if (pop <= uint32_t(kCap)) {
-                // exact rank among the <= kCap bracket keys, composite (key<<32 | col) is unique
-                __syncthreads();
-                if (tid == 0) sm.ncand = 0;
-                __syncthreads();
+                // exact rank among the <= kCap bracket keys; composite (key<<32 | col) is unique.
+                // Compaction: ballot prefix inside the wave (no atomics), waves own LDS segments.
+                const int wave = tid >> 6, lane = tid & 63;
+                uint32_t base = 0;
 #pragma unroll
                 for (int i = 0; i < E; ++i) {
-                    if (key[i] >= lo && key[i] <= hi) {
-                        const uint32_t col = uint32_t((i / 8) * NT * 8 + (i % 8)) + tid8;
-                        const uint32_t pos = atomicAdd(&sm.ncand, 1u);
-                        sm.cand[pos] = (static_cast<unsigned long long>(key[i]) << 32) | col;
+                    const bool inb = key[i] >= lo && key[i] <= hi;
+                    const unsigned long long b = __ballot(inb);
+                    if (b) {
+                        if (inb) {
+                            const uint32_t pos = base + uint32_t(__popcll(b & ((1ull << lane) - 1ull)));
+                            const uint32_t col = uint32_t((i / 8) * NT * 8 + (i % 8)) + tid8;
+                            sm.seg[wave * kCap + pos] = (static_cast<unsigned long long>(key[i]) << 32) | col;
+                        }
+                        base += uint32_t(__popcll(b));
                     }
                 }
-                __syncthreads();
-                if (tid < int(pop)) {
-                    const unsigned long long mine = sm.cand[tid];
-                    uint32_t rank = 0;
-                    for (uint32_t j = 0; j < pop; ++j) rank += (sm.cand[j] < mine) ? 1u : 0u;
-                    if (rank == need - 1) sm.cut = mine;
+                if constexpr (NW > 1) {
+                    if (lane == 0) sm.segcnt[wave] = base;
+                    lds_barrier();
+                    if (tid < int(pop)) {          // gather the segments into one dense list
+                        uint32_t t = uint32_t(tid);
+                        int w = 0;
+                        for (; w < NW - 1; ++w) {
+                            const uint32_t c = sm.segcnt[w];
+                            if (t < c) break;
+                            t -= c;
+                        }
+                        sm.cand[tid] = sm.seg[w * kCap + t];
+                    }
                 }
-                __syncthreads();
+                lds_barrier();
+                if (tid < kWave) {
+                    const unsigned long long *list = NW > 1 ? sm.cand : sm.seg;
+                    const unsigned long long mine = tid < int(pop) ? list[tid] : ~0ull;
+                    uint32_t rank = 0;
+#pragma unroll
+                    for (int j = 0; j < kCap; ++j) {
+                        const unsigned long long other = list[j];            // wave-uniform address: broadcast
+                        rank += (uint32_t(j) < pop && other < mine) ? 1u : 0u;
+                    }
+                    if (tid < int(pop) && rank == need - 1) sm.cut = mine;
+                }
+                lds_barrier();
                 cut = sm.cut;
             } else {
                 // lo == hi: more than kCap keys tie at the threshold value -> take the first `need`
                 // of them in column order (stable sort semantics).
                 uint32_t running = 0;
-                if constexpr (NW > 1) __syncthreads();
+                if constexpr (NW > 1) lds_barrier();
 #pragma unroll
                 for (int s = 0; s < CH; ++s) {
                     uint32_t cnt = 0;
@@ -252,7 +368,7 @@ __global__ __launch_bounds__(64 * NW) void select_rows_kernel(typename T::raw *_
                     if constexpr (NW > 1) {
                         const int wave = tid >> 6;
                         if ((tid & 63) == 63) sm.scan[wave] = incl;
-                        __syncthreads();
+                        lds_barrier();
                         uint32_t before = 0, all = 0;
 #pragma unroll
                         for (int w = 0; w < NW; ++w) {
@@ -262,7 +378,7 @@ __global__ __launch_bounds__(64 * NW) void select_rows_kernel(typename T::raw *_
                         }
                         incl += before;
                         total = all;
-                        __syncthreads();
+                        lds_barrier();
                     }
                     const uint32_t excl = incl - cnt;
                     if (running + excl < need && need <= running + incl) {
@@ -278,9 +394,11 @@ __global__ __launch_bounds__(64 * NW) void select_rows_kernel(typename T::raw *_
                     }
                     running += total;
                 }
-                __syncthreads();
+                lds_barrier();
                 cut = sm.cut;
             }
+            have_prev = true;
+            prev_key = uint32_t(cut >> 32);
         }
 
         // ---- apply -----------------------------------------------------------------------
@@ -307,18 +425,18 @@ __global__ __launch_bounds__(64 * NW) void select_rows_kernel(typename T::raw *_
 
         // ---- row score sum (importance_score numerator) ------------------------------------
         if (row_sums) {
-            double d = wave_sum_f64(double(fsum));
+            double d = double(wave_sum_f32_dpp(fsum));
             if constexpr (NW > 1) {
                 const int wave = tid >> 6;
                 if ((tid & 63) == 0) sm.dsum[wave] = d;
-                __syncthreads();
+                lds_barrier();
                 d = 0.0;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) d += sm.dsum[w];
             }
             if (tid == 0) row_sums[row] = d;
         }
-        if constexpr (NW > 1) __syncthreads();   // smem reuse by the next row
+        if constexpr (NW > 1) lds_barrier();   // smem reuse by the next row
     }
 }
 
@@ -535,17 +653,16 @@ constexpr int kMatrixGrid = 512;     // persistent 1024-thread workgroups (2 per
 constexpr int kNmGrid = 2048;        // 256-thread workgroups (8 per CU)
 
 struct WsLayout {
-    size_t sq_off, part_off, hist_off, total;
-    int64_t nparts;
+    size_t hist_off, total;
 };
 static WsLayout ws_layout(int mode, int64_t out_f, int64_t in_f) {
     WsLayout l{};
-    l.sq_off = 0;
-    l.part_off = round_up(size_t(in_f) * 4, 256);
-    l.nparts = mode == VLMC_SEL_ROW ? out_f : (mode == VLMC_SEL_MATRIX ? kMatrixGrid : kNmGrid);
-    l.hist_off = l.part_off + round_up(size_t(l.nparts) * 8, 256);
-    l.total = l.hist_off + (mode == VLMC_SEL_MATRIX ? round_up(size_t(kHistTotal) * 4, 256) : 0);
+    (void)out_f; (void)in_f;
+    if (mode == VLMC_SEL_MATRIX) l.total = round_up(size_t(kHistTotal) * 4, 256);   // radix histograms
     return l;
+}
+static int64_t n_partials(int mode, int64_t out_f) {
+    return mode == VLMC_SEL_ROW ? out_f : (mode == VLMC_SEL_MATRIX ? kMatrixGrid : kNmGrid);
 }
 
 static int env_int(const char *name, int dflt) {
@@ -554,22 +671,23 @@ static int env_int(const char *name, int dflt) {
 }
 
 template <typename T, int CH, int NW, bool ALIGNED>
-static void launch_rows(void *W, int64_t out_f, int64_t in_f, int64_t ldw, const float *sq, uint32_t k, int apply_zero,
-                        uint8_t *mask, double *row_sums, hipStream_t st) {
-    // persistent grid: enough workgroups to fill the chip (~16 waves per CU), each walks rows
+static void launch_rows(void *W, int64_t out_f, int64_t in_f, int64_t ldw, const float *sqrt_scaler, uint32_t k,
+                        int apply_zero, uint8_t *mask, double *row_sums, hipStream_t st) {
+    // persistent grid: ~16 waves per CU, every workgroup walks the same number of rows (+-1)
     const int waves_per_cu = env_int("VLMC_SELECT_WAVES_PER_CU", 16);
-    int64_t grid = int64_t(256) * waves_per_cu / NW;
-    if (grid > out_f) grid = out_f;
-    if (grid < 1) grid = 1;
+    int64_t max_grid = int64_t(256) * waves_per_cu / NW;
+    if (max_grid < 1) max_grid = 1;
+    const int64_t rows_per_wg = (out_f + max_grid - 1) / max_grid;
+    const int64_t grid = (out_f + rows_per_wg - 1) / rows_per_wg;
     hipLaunchKernelGGL((select_rows_kernel<T, CH, NW, ALIGNED>), dim3(unsigned(grid)), dim3(64 * NW), 0, st,
-                       static_cast<typename T::raw *>(W), out_f, in_f, ldw, sq, k, apply_zero, mask, row_sums);
+                       static_cast<typename T::raw *>(W), out_f, in_f, ldw, sqrt_scaler, k, apply_zero, mask, row_sums);
 }
 
 template <typename T>
-static int dispatch_rows(void *W, int64_t out_f, int64_t in_f, int64_t ldw, const float *sq, uint32_t k, int apply_zero,
+static int dispatch_rows(void *W, int64_t out_f, int64_t in_f, int64_t ldw, const float *sqrt_scaler, uint32_t k, int apply_zero,
                          uint8_t *mask, double *row_sums, bool aligned, hipStream_t st) {
     const int64_t nchunks = (in_f + 7) / 8;
-#define VLMC_ROWS(CH, NW, AL) launch_rows<T, CH, NW, AL>(W, out_f, in_f, ldw, sq, k, apply_zero, mask, row_sums, st)
+#define VLMC_ROWS(CH, NW, AL) launch_rows<T, CH, NW, AL>(W, out_f, in_f, ldw, sqrt_scaler, k, apply_zero, mask, row_sums, st)
     if (!aligned) {
         if (nchunks <= 256) VLMC_ROWS(4, 1, false);
         else if (nchunks <= 2048) VLMC_ROWS(4, 8, false);
@@ -631,27 +749,26 @@ static int launch_nm(void *W, int64_t out_f, int64_t in_f, int64_t ldw, const fl
 }
 
 template <typename T>
-static int select_typed(void *W, int64_t out_f, int64_t in_f, int64_t ldw, const float *scaler_row, int mode, int64_t k,
-                        int n, int m, int apply_zero, uint8_t *mask, double *score_sum, char *ws, hipStream_t st) {
+static int select_typed(void *W, int64_t out_f, int64_t in_f, int64_t ldw, const float *sqrt_scaler, int mode, int64_t k,
+                        int n, int m, int apply_zero, uint8_t *mask, double *parts, char *ws, hipStream_t st) {
     const WsLayout l = ws_layout(mode, out_f, in_f);
-    float *sq = reinterpret_cast<float *>(ws + l.sq_off);
-    double *parts = reinterpret_cast<double *>(ws + l.part_off);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(ws + l.hist_off);
-    const bool aligned = in_f % 8 == 0 && ldw % 8 == 0 && aligned16(W) && (reinterpret_cast<uintptr_t>(mask) % 8) == 0;
-    hipLaunchKernelGGL(sqrt_scaler_kernel, dim3(unsigned((in_f + 255) / 256)), dim3(256), 0, st, scaler_row, sq, in_f);
+    const bool aligned = in_f % 8 == 0 && ldw % 8 == 0 && aligned16(W) && aligned16(sqrt_scaler) &&
+                         (reinterpret_cast<uintptr_t>(mask) % 8) == 0;
     int rc = VLMC_OK;
     if (mode == VLMC_SEL_ROW) {
-        rc = dispatch_rows<T>(W, out_f, in_f, ldw, sq, uint32_t(k), apply_zero, mask, score_sum ? parts : nullptr, aligned, st);
-    } else if (mode == VLMC_SEL_MATRIX) {
-        if (aligned) launch_matrix<T, true>(W, out_f, in_f, ldw, sq, uint64_t(k), apply_zero, mask, score_sum ? parts : nullptr, hist, st);
-        else launch_matrix<T, false>(W, out_f, in_f, ldw, sq, uint64_t(k), apply_zero, mask, score_sum ? parts : nullptr, hist, st);
+        rc = dispatch_rows<T>(W, out_f, in_f, ldw, sqrt_scaler, uint32_t(k), apply_zero, mask, parts, aligned, st);
     } else {
-        rc = aligned ? launch_nm<T, true>(W, out_f, in_f, ldw, sq, n, m, apply_zero, mask, score_sum ? parts : nullptr, st)
-                     : launch_nm<T, false>(W, out_f, in_f, ldw, sq, n, m, apply_zero, mask, score_sum ? parts : nullptr, st);
+        const float *sq = sqrt_scaler;
+        uint32_t *hist = reinterpret_cast<uint32_t *>(ws + l.hist_off);
+        if (mode == VLMC_SEL_MATRIX) {
+            if (aligned) launch_matrix<T, true>(W, out_f, in_f, ldw, sq, uint64_t(k), apply_zero, mask, parts, hist, st);
+            else launch_matrix<T, false>(W, out_f, in_f, ldw, sq, uint64_t(k), apply_zero, mask, parts, hist, st);
+        } else {
+            rc = aligned ? launch_nm<T, true>(W, out_f, in_f, ldw, sq, n, m, apply_zero, mask, parts, st)
+                         : launch_nm<T, false>(W, out_f, in_f, ldw, sq, n, m, apply_zero, mask, parts, st);
+        }
     }
     if (rc != VLMC_OK) return rc;
-    if (score_sum)
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, parts, l.nparts, score_sum);
     VLMC_HIP_CHECK_LAUNCH("vlmc_wanda_select");
     return VLMC_OK;
 }
@@ -665,11 +782,16 @@ extern "C" size_t vlmc_wanda_select_workspace(int mode, int64_t out_features, in
     return ws_layout(mode, out_features, in_features).total;
 }
 
+extern "C" int64_t vlmc_wanda_select_partials(int mode, int64_t out_features, int64_t in_features) {
+    if (out_features <= 0 || in_features <= 0 || mode < 0 || mode > 2) return 0;
+    return n_partials(mode, out_features);
+}
+
 extern "C" int vlmc_wanda_select(void *W, int dtype, int64_t out_features, int64_t in_features, int64_t ldw,
-                                 const float *scaler_row, int mode, int64_t k, int n, int m, int apply_zero,
-                                 uint8_t *mask, double *score_sum, void *workspace, size_t workspace_bytes,
+                                 const float *sqrt_scaler, int mode, int64_t k, int n, int m, int apply_zero,
+                                 uint8_t *mask, double *score_partials, void *workspace, size_t workspace_bytes,
                                  void *stream) {
-    VLMC_REQUIRE(W && scaler_row && mask && workspace, "vlmc_wanda_select: null pointer");
+    VLMC_REQUIRE(W && sqrt_scaler && mask, "vlmc_wanda_select: null pointer");
     VLMC_REQUIRE(out_features > 0 && in_features > 0 && ldw >= in_features,
                  "vlmc_wanda_select: bad shape out=%lld in=%lld ldw=%lld", (long long)out_features, (long long)in_features,
                  (long long)ldw);
@@ -685,18 +807,21 @@ extern "C" int vlmc_wanda_select(void *W, int dtype, int64_t out_features, int64
         VLMC_REQUIRE(m > 0 && n >= 0 && n <= m && in_features % m == 0,
                      "vlmc_wanda_select: bad n:m = %d:%d for in_features %lld", n, m, (long long)in_features);
     }
-    VLMC_REQUIRE((reinterpret_cast<uintptr_t>(workspace) % 256) == 0, "vlmc_wanda_select: workspace not 256-B aligned");
     const size_t need = vlmc_wanda_select_workspace(mode, out_features, in_features);
-    if (workspace_bytes < need) {
-        set_error("vlmc_wanda_select: workspace %zu B < required %zu B", workspace_bytes, need);
-        return VLMC_EWORKSPACE;
+    if (need) {
+        VLMC_REQUIRE(workspace, "vlmc_wanda_select: null workspace");
+        VLMC_REQUIRE((reinterpret_cast<uintptr_t>(workspace) % 256) == 0, "vlmc_wanda_select: workspace not 256-B aligned");
+        if (workspace_bytes < need) {
+            set_error("vlmc_wanda_select: workspace %zu B < required %zu B", workspace_bytes, need);
+            return VLMC_EWORKSPACE;
+        }
     }
     hipStream_t st = as_stream(stream);
     char *ws = static_cast<char *>(workspace);
     switch (dtype) {
-        case VLMC_F32: return select_typed<f32_t>(W, out_features, in_features, ldw, scaler_row, mode, k, n, m, apply_zero, mask, score_sum, ws, st);
-        case VLMC_F16: return select_typed<f16_t>(W, out_features, in_features, ldw, scaler_row, mode, k, n, m, apply_zero, mask, score_sum, ws, st);
-        case VLMC_BF16: return select_typed<bf16_t>(W, out_features, in_features, ldw, scaler_row, mode, k, n, m, apply_zero, mask, score_sum, ws, st);
+        case VLMC_F32: return select_typed<f32_t>(W, out_features, in_features, ldw, sqrt_scaler, mode, k, n, m, apply_zero, mask, score_partials, ws, st);
+        case VLMC_F16: return select_typed<f16_t>(W, out_features, in_features, ldw, sqrt_scaler, mode, k, n, m, apply_zero, mask, score_partials, ws, st);
+        case VLMC_BF16: return select_typed<bf16_t>(W, out_features, in_features, ldw, sqrt_scaler, mode, k, n, m, apply_zero, mask, score_partials, ws, st);
     }
     set_error("vlmc_wanda_select: unknown dtype %d", dtype);
     return VLMC_EINVAL;

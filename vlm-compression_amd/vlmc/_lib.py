@@ -6,7 +6,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvlmc_hip.so")
+LIB_PATH = os.environ.get("VLMC_LIB", os.path.join(_HERE, "libvlmc_hip.so"))   # VLMC_LIB: tuning builds
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "vlmc.h")
 
 VLMC_OK, VLMC_EINVAL, VLMC_EHIP, VLMC_EWORKSPACE, VLMC_ENOTPD = 0, -1, -2, -3, -4
@@ -22,8 +22,9 @@ SIGNATURES = {
     "vlmc_abi_version": (_i, []),
     "vlmc_last_error": (_c.c_char_p, []),
     "vlmc_act_sqnorm": (_i, [_p, _i, _i64, _i64, _i64, _i64, _i64, _p, _p]),
-    "vlmc_wanda_scaler_update": (_i, [_p, _i64, _i64, _p, _i64, _i64, _p]),
+    "vlmc_wanda_scaler_update": (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _p]),
     "vlmc_wanda_select_workspace": (_sz, [_i, _i64, _i64]),
+    "vlmc_wanda_select_partials": (_i64, [_i, _i64, _i64]),
     "vlmc_wanda_select": (_i, [_p, _i, _i64, _i64, _i64, _p, _i, _i64, _i, _i, _i, _p, _p, _p, _sz, _p]),
 }
 

@@ -43,6 +43,7 @@ class Workspace:
 
 
 _select_ws = Workspace()
+_MODES = {"row": _lib.SEL_ROW, "matrix": _lib.SEL_MATRIX, "nm": _lib.SEL_NM}
 
 
 def act_sqnorm(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
@@ -66,43 +67,69 @@ def act_sqnorm(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor
     return out
 
 
-def wanda_scaler_update(scaler_row: torch.Tensor, nsamples_before: int, normsq: torch.Tensor, batch: int = 1) -> int:
+def wanda_scaler_update(scaler_row: torch.Tensor, nsamples_before: int, normsq: torch.Tensor | None, batch: int = 1,
+                        sqrt_out: torch.Tensor | None = None) -> int:
     """Apply the running-mean recurrence of wanda_pruner.py:77-81 in place for every
-    row of `normsq` ([calls, in], in call order).  Returns the new sample count."""
-    _need_gpu(scaler_row, normsq)
+    row of `normsq` ([calls, in], in call order); optionally also write
+    sqrt(scaler_row) (the score factor of wanda_pruner.py:318) into `sqrt_out`.
+    Returns the new sample count."""
+    _need_gpu(scaler_row, normsq, sqrt_out)
     assert scaler_row.dtype == torch.float32 and scaler_row.is_contiguous()
-    assert normsq.dtype == torch.float32 and normsq.is_contiguous() and normsq.shape[-1] == scaler_row.numel()
-    calls = normsq.shape[0] if normsq.dim() == 2 else 1
-    _lib.check(_lib.load().vlmc_wanda_scaler_update(scaler_row.data_ptr(), scaler_row.numel(), nsamples_before,
-                                                    normsq.data_ptr(), calls, batch, _stream()))
+    calls = 0
+    if normsq is not None:
+        assert normsq.dtype == torch.float32 and normsq.is_contiguous() and normsq.shape[-1] == scaler_row.numel()
+        calls = normsq.shape[0] if normsq.dim() == 2 else 1
+    if sqrt_out is not None:
+        assert sqrt_out.dtype == torch.float32 and sqrt_out.is_contiguous() and sqrt_out.numel() == scaler_row.numel()
+    _lib.check(_lib.load().vlmc_wanda_scaler_update(
+        scaler_row.data_ptr(), scaler_row.numel(), nsamples_before, normsq.data_ptr() if calls else None, calls, batch,
+        sqrt_out.data_ptr() if sqrt_out is not None else None, _stream()))
     return nsamples_before + calls * batch
 
 
-def wanda_select(weight: torch.Tensor, scaler_row: torch.Tensor, mode: str, *, k: int = 0, n: int = 0, m: int = 0,
-                 apply_zero: bool = True, mask: torch.Tensor | None = None, score_sum: torch.Tensor | None = None):
+def sqrt_scaler(scaler_row: torch.Tensor) -> torch.Tensor:
+    """IEEE sqrt(scaler_row) on the device (torch.sqrt(scaler_row), wanda_pruner.py:318)."""
+    out = torch.empty_like(scaler_row)
+    wanda_scaler_update(scaler_row, 0, None, 1, sqrt_out=out)
+    return out
+
+
+def wanda_select(weight: torch.Tensor, sqrt_scaler_row: torch.Tensor, mode: str, *, k: int = 0, n: int = 0, m: int = 0,
+                 apply_zero: bool = True, mask: torch.Tensor | None = None, partials: torch.Tensor | None = None):
     """Fused score + select + apply for one linear (wanda_pruner.py:318-341 / :666-687).
+    `sqrt_scaler_row` = sqrt(scaler_row) as produced by wanda_scaler_update(sqrt_out=...).
 
     mode "row": prune the k lowest-score columns of every row (stable);
     mode "matrix": prune score < sort(score.flatten())[k];  mode "nm": n of every m.
     Writes `mask` (torch.bool [out,in], True = keep), zeroes pruned weights in place
-    when apply_zero, writes sum(score) into `score_sum` (float64 [1]).
-    Returns (mask, score_sum).
+    when apply_zero, writes partial sums of the scores into `partials` (float64
+    [select_partials(...)]; `partials.sum() / weight.numel()` is the importance_score).
+    Returns (mask, partials).
     """
-    _need_gpu(weight, scaler_row, mask, score_sum)
+    _need_gpu(weight, sqrt_scaler_row, mask, partials)
     if weight.dim() != 2 or weight.stride(1) != 1:
         raise ValueError("wanda_select expects a row-major 2-D weight")
     out_f, in_f = weight.shape
-    assert scaler_row.dtype == torch.float32 and scaler_row.is_contiguous() and scaler_row.numel() == in_f
+    assert (sqrt_scaler_row.dtype == torch.float32 and sqrt_scaler_row.is_contiguous()
+            and sqrt_scaler_row.numel() == in_f)
     if mask is None:
         mask = torch.empty((out_f, in_f), dtype=torch.bool, device=weight.device)
     assert mask.dtype == torch.bool and mask.is_contiguous() and mask.shape == weight.shape
-    if score_sum is None:
-        score_sum = torch.empty(1, dtype=torch.float64, device=weight.device)
-    code = {"row": _lib.SEL_ROW, "matrix": _lib.SEL_MATRIX, "nm": _lib.SEL_NM}[mode]
+    code = _MODES[mode]
     lib = _lib.load()
+    nparts = lib.vlmc_wanda_select_partials(code, out_f, in_f)
+    if partials is None:
+        partials = torch.empty(nparts, dtype=torch.float64, device=weight.device)
+    assert partials.dtype == torch.float64 and partials.is_contiguous() and partials.numel() >= nparts
     nbytes = lib.vlmc_wanda_select_workspace(code, out_f, in_f)
-    ws = _select_ws.get(nbytes, weight.device)
+    ws = _select_ws.get(nbytes, weight.device) if nbytes else None
     _lib.check(lib.vlmc_wanda_select(weight.data_ptr(), _dtype_code(weight), out_f, in_f, weight.stride(0),
-                                     scaler_row.data_ptr(), code, int(k), int(n), int(m), int(bool(apply_zero)),
-                                     mask.data_ptr(), score_sum.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
-    return mask, score_sum
+                                     sqrt_scaler_row.data_ptr(), code, int(k), int(n), int(m), int(bool(apply_zero)),
+                                     mask.data_ptr(), partials.data_ptr(), ws.data_ptr() if nbytes else None,
+                                     ws.numel() if nbytes else 0, _stream()))
+    return mask, partials[:nparts]
+
+
+def select_partials(mode: str, out_f: int, in_f: int) -> int:
+    """Number of float64 partial sums `wanda_select` writes for this shape."""
+    return int(_lib.load().vlmc_wanda_select_partials(_MODES[mode], out_f, in_f))
