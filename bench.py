@@ -1,0 +1,293 @@
+#!/usr/bin/env python
+"""bench.py -- Wanda 50 % unstructured prune of InstructBLIP-FlanT5-XL on MI355X.
+
+Metric (BASELINE.json): layers/sec (layer = one pruned nn.Linear) and total prune
+wall-clock for configs[1]: all 588 prunable linears (39 ViT-g blocks fp16 with the
+matrix-wide rule, 24+24 T5 blocks bf16 with the per-row rule), 128 calibration
+samples, synthetic weights N(0, 0.02) and synthetic activations N(0.1, 1) of the
+model's shapes (257 / 64 / 16 tokens), all resident in HBM before the timed region.
+
+One "step" = one pass of the hot path over the whole model: per transformer block,
+activation statistics of every distinct linear input over the 128 samples
+(vlmc_act_sqnorm), the running-mean recurrence + sqrt (vlmc_wanda_scaler_update),
+and the fused score + select + apply of every linear (vlmc_wanda_select) -- i.e.
+SURVEY.md §8 rows a3-a8 without the block forward (row (f)1, not built yet).  Each
+timed step prunes a fresh copy of the dense weights.
+
+N GPUs (`torchrun`, one rank per GPU): the 128 calibration samples are sharded in
+contiguous ranges, one RCCL all-gather of per-sample squared norms per block, select
+replicated on every rank -> total work fixed => "scaling": "strong".
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "vlm-compression_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+N_CALIB = 128
+RATIO = 0.5
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline leg (0 = skip)")
+    ap.add_argument("--weight-sets", type=int, default=0, help="dense weight copies kept in HBM (0 = steps+warmup, capped by memory)")
+    return ap.parse_args()
+
+
+def build_workload(dev, rank, world, n_sets_wanted):
+    from vlmc import workload as wl
+    blocks = wl.flan_t5_xl()
+    n_local = N_CALIB // world
+    # ---- activations: rank r holds samples [r*n_local, (r+1)*n_local) of every distinct input
+    acts = []
+    for bi, b in enumerate(blocks):
+        per_in = []
+        for ii, inp in enumerate(b.inputs):
+            g = torch.Generator(device=dev)
+            g.manual_seed(1_000_003 * bi + 1009 * ii + rank)
+            x = torch.empty((n_local, inp.tokens, inp.in_features), dtype=b.dtype, device=dev)
+            x.normal_(0.1, 1.0, generator=g)
+            per_in.append(x)
+        acts.append(per_in)
+    # ---- weights: as many dense copies as fit (each timed step prunes a fresh one)
+    bytes_per_set = sum(l.out_features * l.in_features * 2 for b in blocks for l in b.linears)
+    free, _ = torch.cuda.mem_get_info(dev)
+    mask_bytes = bytes_per_set // 2
+    fit = int((free - mask_bytes - (8 << 30)) // bytes_per_set)
+    n_sets = max(1, min(n_sets_wanted, fit))
+    sets = []
+    for s in range(n_sets):
+        ws, gi = [], 0
+        for b in blocks:
+            wb = []
+            for lin in b.linears:
+                if s == 0:
+                    g = torch.Generator(device=dev)
+                    g.manual_seed(gi)
+                    w = torch.empty((lin.out_features, lin.in_features), dtype=b.dtype, device=dev)
+                    w.normal_(0.0, 0.02, generator=g)
+                else:
+                    w = sets[0][len(ws)][len(wb)].clone()
+                wb.append(w)
+                gi += 1
+            ws.append(wb)
+        sets.append(ws)
+    return blocks, acts, sets, n_local
+
+
+def build_plans(blocks, acts, weights, n_local, world, dev, state):
+    """Pre-bind every launch of one step for one weight set.  Returns a list of per-block
+    (stat_plans, exchange, update_plans, select_plans) and the list of select launches that
+    carry roofline events."""
+    from vlmc import ops, workload as wl
+    steps = []
+    for bi, b in enumerate(blocks):
+        st_plans, upd_plans, sel_plans = [], [], []
+        ins = state["blocks"][bi]
+        for ii, inp in enumerate(b.inputs):
+            s = ins[ii]
+            st_plans.append(ops.plan_act_sqnorm(acts[bi][ii], s["normsq_local"]))
+            upd_plans.append((s["scaler"], ops.plan_scaler_update(s["scaler"], 0, s["normsq_all"], 1, s["sqrt"])))
+        li = 0
+        for ii, inp in enumerate(b.inputs):
+            s = ins[ii]
+            for lin in inp.linears:
+                w = weights[bi][li]
+                k = int(lin.in_features * RATIO) if b.mode == "row" else int(lin.out_features * lin.in_features * RATIO)
+                plan = ops.plan_select(w, s["sqrt"], b.mode, k=k, apply_zero=True, mask=state["masks"][bi][li],
+                                       partials=state["partials"][bi][li])
+                sel_plans.append((plan, b.mode == "row", wl.select_bytes(lin, w.element_size(), True)))
+                li += 1
+        steps.append((st_plans, upd_plans, sel_plans))
+    return steps
+
+
+def alloc_state(blocks, n_local, world, dev):
+    from vlmc import ops
+    st = {"blocks": [], "masks": [], "partials": []}
+    for b in blocks:
+        ins = []
+        tot = sum(i.in_features for i in b.inputs)
+        # one flat buffer per block so that the multi-GPU exchange is a single all-gather
+        flat_local = torch.empty((n_local, tot), dtype=torch.float32, device=dev) if world > 1 else None
+        flat_all = torch.empty((N_CALIB, tot), dtype=torch.float32, device=dev) if world > 1 else None
+        off = 0
+        for inp in b.inputs:
+            d = {"scaler": torch.zeros(inp.in_features, dtype=torch.float32, device=dev),
+                 "sqrt": torch.empty(inp.in_features, dtype=torch.float32, device=dev)}
+            if world > 1:
+                d["normsq_local"] = torch.empty((n_local, inp.in_features), dtype=torch.float32, device=dev)
+                d["normsq_all"] = torch.empty((N_CALIB, inp.in_features), dtype=torch.float32, device=dev)
+                d["slice"] = (off, off + inp.in_features)
+            else:
+                d["normsq_local"] = torch.empty((N_CALIB, inp.in_features), dtype=torch.float32, device=dev)
+                d["normsq_all"] = d["normsq_local"]
+            off += inp.in_features
+            ins.append(d)
+        st["blocks"].append(ins)
+        if world > 1:
+            ins[0]["flat_local"], ins[0]["flat_all"] = flat_local, flat_all
+        st["masks"].append([torch.empty((l.out_features, l.in_features), dtype=torch.bool, device=dev) for l in b.linears])
+        st["partials"].append([torch.empty(ops.select_partials(b.mode, l.out_features, l.in_features), dtype=torch.float64,
+                                           device=dev) for l in b.linears])
+    return st
+
+
+def run_step(plans, state, world, events=None):
+    for bi, (st_plans, upd_plans, sel_plans) in enumerate(plans):
+        for p in st_plans:
+            p()
+        if world > 1:          # ONE all-gather per block: [n_local, sum(in)] -> [128, sum(in)] in sample order
+            ins = state["blocks"][bi]
+            flat_local, flat_all = ins[0]["flat_local"], ins[0]["flat_all"]
+            torch.cat([d["normsq_local"] for d in ins], dim=1, out=flat_local)
+            dist.all_gather_into_tensor(flat_all, flat_local)
+            for d in ins:
+                d["normsq_all"].copy_(flat_all[:, d["slice"][0]:d["slice"][1]])
+        for _scaler, p in upd_plans:
+            p()
+        for p, is_row, nbytes in sel_plans:
+            if events is not None and is_row:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                p()
+                b.record()
+                events.append((a, b, nbytes))
+            else:
+                p()
+
+
+def cpu_baseline(blocks, budget_s):
+    """Time the oracle (the reference's PyTorch-CPU op sequence, oracle/wanda_torch.py) on a
+    bounded sample of the same workload: whole blocks taken round-robin from the three towers
+    until the time budget is used.  Checker code timed as a baseline, never shipped."""
+    from oracle import wanda_torch as OT
+    order = [0, 39, 63]                      # first ViT block, first encoder block, first decoder block
+    order += [1, 40, 64, 2, 41, 65]
+    t0 = time.perf_counter()
+    done, names = 0, []
+    for bi in order:
+        b = blocks[bi]
+        g = torch.Generator().manual_seed(bi)
+        for inp in b.inputs:
+            st = OT.WandaStat(inp.in_features)
+            for j in range(N_CALIB):
+                x = (torch.randn((1, inp.tokens, inp.in_features), generator=g) + 0.1).to(b.dtype)
+                st.add_batch(x)
+            for lin in inp.linears:
+                w = (torch.randn((lin.out_features, lin.in_features), generator=g) * 0.02).to(b.dtype)
+                OT.prune_linear(w, st.scaler_row, b.mode, ratio=RATIO, apply_zero=True)
+                done += 1
+        names.append(b.name)
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "layers/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{done} linears of {len(names)} blocks ({', '.join(names)}), {N_CALIB} calib samples each, "
+                      f"synthetic data generation included, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback of the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    assert N_CALIB % world == 0
+
+    from vlmc import _lib
+    _lib.load()                                   # fail loudly if the HIP library is missing
+
+    want_sets = args.weight_sets or (args.steps + args.warmup)
+    blocks, acts, sets, n_local = build_workload(dev, rank, world, want_sets)
+    state = alloc_state(blocks, n_local, world, dev)
+    plans = [build_plans(blocks, acts, w, n_local, world, dev, state) for w in sets]
+    n_lin = sum(len(b.linears) for b in blocks)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        run_step(plans[i % len(plans)], state, world)
+    sync()
+    events = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        run_step(plans[(args.warmup + i) % len(plans)], state, world, events)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel: the per-row score+select kernel (T5 tower) -----------
+    tot_ms = sum(a.elapsed_time(b) for a, b, _ in events)
+    tot_bytes = sum(nb for _, _, nb in events)
+    ach = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("select_rows_kernel_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roof = {"bound": "hbm", "kernel": "vlmc::select_rows_kernel (score+select+apply, per-row rule)",
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "launches": len(events),
+            "avg_launch_us": round(tot_ms * 1e3 / max(1, len(events)), 2),
+            "bytes_per_launch": round(tot_bytes / max(1, len(events)))}
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "layers/sec, Wanda@50% unstructured, InstructBLIP-FlanT5-XL (588 linears, 128 calib samples)",
+            "value": round(n_lin * args.steps / elapsed, 1), "unit": "layers/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: Wanda 50% unstructured, full InstructBLIP-FlanT5-XL shapes "
+                                   "(39 ViT-g blocks fp16 matrix-wide rule + 24/24 T5 blocks bf16 per-row rule), "
+                                   "128 calib samples, tokens 257/64/16; statistics + score/select/apply of every linear",
+                       "linears": n_lin, "blocks": len(blocks), "calib_samples": N_CALIB, "ratio": RATIO,
+                       "weight_sets": len(sets), "total_prune_wall_clock_s": round(elapsed / args.steps, 5),
+                       "parallelism": f"calib-dp{world}"},
+            "roofline": roof,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(blocks, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

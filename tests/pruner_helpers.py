@@ -1,0 +1,94 @@
+"""Shared by the CPU host-logic test and the GPU end-to-end test of the drop-in pruners."""
+import torch
+import torch.nn as nn
+
+import golden_io
+import toy_models
+
+E2E = None
+
+VARIANTS = {
+    "fp32_r50": dict(vit_dtype=torch.float32, t5_dtype=torch.float32, ratio=0.5, n=0, m=0, lora=False),
+    "mixed_2_4": dict(vit_dtype=torch.float32, t5_dtype=torch.bfloat16, ratio=0.5, n=2, m=4, lora=False),
+    "fp32_r40_lora": dict(vit_dtype=torch.float32, t5_dtype=torch.float32, ratio=0.4, n=0, m=0, lora=True),
+}
+
+
+def golden():
+    global E2E
+    if E2E is None:
+        E2E = golden_io.load("wanda_e2e")
+    return E2E
+
+
+def wrap_lora(model, r=4, alpha=16):
+    """Same replacement the golden generator did with the reference's Linear (weights shared,
+    A/B from the same seeded stream)."""
+    from lavis.peft.src.peft.tuners.lora import Linear
+    g = torch.Generator().manual_seed(4242)
+    for parent in list(model.modules()):
+        for cname, child in list(parent.named_children()):
+            if type(child) is nn.Linear and cname != "t5_proj":
+                new = Linear(child.in_features, child.out_features, r=r, lora_alpha=alpha, bias=child.bias is not None)
+                new.weight = child.weight
+                if child.bias is not None:
+                    new.bias = child.bias
+                new.mask = torch.ones_like(child.weight.data).bool()
+                with torch.no_grad():
+                    new.lora_A.weight.copy_(torch.randn(new.lora_A.weight.shape, generator=g) * 0.05)
+                    new.lora_B.weight.copy_(torch.randn(new.lora_B.weight.shape, generator=g) * 0.05)
+                new.to(child.weight.dtype)
+                setattr(parent, cname, new)
+    return model
+
+
+def build(name, device="cpu"):
+    v = VARIANTS[name]
+    model = toy_models.init_toy(toy_models.ToyBlipT5(vit_dtype=v["vit_dtype"], t5_dtype=v["t5_dtype"]), seed=7)
+    if v["lora"]:
+        wrap_lora(model)
+    model.eval().to(device)
+    batches = [{k: t.to(device) for k, t in b.items()} for b in toy_models.make_batches(6, seed=11)]
+    return model, batches, v
+
+
+def run_pruner(name, device="cpu"):
+    from lavis.compression import load_pruner
+    model, batches, v = build(name, device)
+    spec = "2-%r-1.0-1.0" % (1 - v["ratio"])
+    cfg = dict(t5_prune_spec=spec, vit_prune_spec=spec, t5_pruning_method="wanda", vit_pruning_method="wanda",
+               num_samples=6, prune_n=v["n"], prune_m=v["m"], max_sparsity_per_layer=1.01)
+    pruner = load_pruner("blipt5_wanda_pruner", model, batches, cfg=cfg)
+    pruned, sd = pruner.prune(lora_model=True) if v["lora"] else pruner.prune()
+    return pruned, sd
+
+
+def compare_with_golden(name, pruned, exact=True, min_mask_agreement=1.0, weight_rtol=0.0):
+    G = golden()
+    stats = {"masks": 0, "mask_elems": 0, "mask_diff": 0}
+    sd = pruned.state_dict()
+    for key in [k for k in G if k.startswith(f"{name}/sd/")]:
+        k = key[len(name) + 4:]
+        got, ref = sd[k].cpu(), G[key]
+        if k.endswith("mask"):
+            continue
+        if exact:
+            assert torch.equal(got, ref), f"{name}: state tensor {k} differs"
+    for mn, mod in pruned.named_modules():
+        gk = f"{name}/mask/{mn}"
+        sk = f"{name}/sd/{mn}.mask"
+        ref = G.get(gk, G.get(sk) if hasattr(mod, "lora_A") else None)
+        if ref is None:
+            continue
+        got = mod.mask.cpu()
+        stats["masks"] += 1
+        stats["mask_elems"] += ref.numel()
+        stats["mask_diff"] += int((got != ref).sum())
+        ik = f"{name}/imp/{mn}"
+        if ik in G:
+            ref_imp = float(G[ik])
+            assert abs(mod.weight.importance_score - ref_imp) <= 2e-3 * abs(ref_imp) + 1e-12, (mn, mod.weight.importance_score, ref_imp)
+    assert stats["masks"] > 0
+    agree = 1 - stats["mask_diff"] / stats["mask_elems"]
+    assert agree >= min_mask_agreement, f"{name}: mask agreement {agree:.5f} < {min_mask_agreement}"
+    return stats

@@ -66,7 +66,7 @@ __global__ void scaler_update_kernel(float *__restrict__ s, int64_t in_f, int64_
                                      int64_t n_calls, int64_t batch, float *__restrict__ sqrt_out) {
     const int64_t ch = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (ch >= in_f) return;
-    float acc = s[ch];
+    float acc = n0 == 0 ? 0.f : s[ch];   // a fresh statistic starts from zeros (WrappedGPT.__init__, :62)
     int64_t n = n0;
     for (int64_t c = 0; c < n_calls; ++c) {
         const float f = float(double(n) / double(n + batch));   // python float -> fp32 scalar

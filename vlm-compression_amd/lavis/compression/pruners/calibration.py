@@ -1,0 +1,167 @@
+"""Calibration capture and the per-block walk shared by the layer-wise pruners.
+
+Behavioural restatement (not a copy) of the machinery every reference pruner repeats:
+`get_module_recursive` / `find_layers` (wanda_pruner.py:16-48),
+`prepare_calibration_input_encoder` with its `Catcher` (T5/LLM :213-273, ViT :583-625)
+and the block loop skeleton of `_prune` (:275-354, :627-699): run the block on every
+captured sample with forward hooks on its linears, let the method prune the linears,
+run the block again with the pruned weights, swap inputs/outputs.
+
+Quirks kept on purpose:
+* the block-0 kwargs are replayed for every block, so T5 blocks 1.. run with
+  `position_bias=None`;
+* `find_layers` matches types exactly (a LoRA-wrapped linear is found as ONE module);
+* the sample count is taken from `batch["image"]` / `batch["text_input"]`, and the
+  loop stops only when a batch BEGINS at or past `n_samples`.
+
+Multi-GPU extension (not in the reference): under an initialised
+`torch.distributed` group each rank captures and replays only its contiguous share
+of the calibration samples; the pruning method exchanges statistics
+(`vlmc.wanda.gather_stats`) so that results are bit-identical on every rank and for
+every world size.  `VLMC_SHARD_CALIB=0` restores the reference's replica behaviour.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+
+T5_KEYS = ["attention_mask", "position_bias", "encoder_attention_mask", "encoder_decoder_position_bias",
+           "layer_head_mask", "cross_attn_layer_head_mask", "encoder_hidden_states"]      # wanda_pruner.py:225-228
+OPT_KEYS = ["attention_mask", "layer_head_mask"]                                         # :230-232
+LLM_KEYS = ["attention_mask", "position_ids"]                                            # :234-236
+
+
+def get_module_recursive(base, module_to_process):
+    for part in [p for p in module_to_process.split(".") if p != ""]:
+        base = getattr(base, part)
+    return base
+
+
+def prunable_layer_types():
+    from lavis.peft.src.peft.tuners.lora import Linear, LoraLayer, Linear8bitLt
+    return [nn.Linear, Linear, LoraLayer, Linear8bitLt]
+
+
+def find_layers(module, layers=None, name=""):
+    """{qualified name: module} for every sub-module whose type is EXACTLY one of `layers`."""
+    layers = prunable_layer_types() if layers is None else layers
+    if type(module) in layers:
+        return {name: module}
+    res = {}
+    for child_name, child in module.named_children():
+        res.update(find_layers(child, layers=layers, name=name + "." + child_name if name != "" else child_name))
+    return res
+
+
+class _Stop(ValueError):
+    """Raised by the catcher to abort the model forward (the reference raises ValueError)."""
+
+
+def calibration_shard():
+    """(rank, world) for sample sharding, or (0, 1) when running as replicas."""
+    import torch.distributed as dist
+    if os.environ.get("VLMC_SHARD_CALIB", "1") == "0":
+        return 0, 1
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _keys_for(model_prefix):
+    if "t5_model" in model_prefix:
+        return T5_KEYS
+    if "opt_model" in model_prefix:
+        return OPT_KEYS
+    if "llm_model" in model_prefix:
+        return LLM_KEYS
+    raise ValueError(f"no calibration cache keys known for model prefix {model_prefix!r}")
+
+
+def capture_block_inputs(model, dataloader, n_samples, module_to_process, forward_to_cache, lora_model, *, vit,
+                         model_prefix=None):
+    """Run the model until block 0 of `module_to_process` is reached, for the first
+    `n_samples` calibration samples; return (inps, outs, caches) like the reference.
+
+    vit=True  -> catcher signature (inp, rel_pos_bias, dense=True)         (:595-608)
+    vit=False -> catcher signature (inp, dense=True, **kwargs), caching the
+                 family's kwargs (:238-253)
+    """
+    layers = get_module_recursive(model, module_to_process)
+    keys = None if vit else _keys_for(model_prefix)
+    inps, caches = [], []
+    rank, world = calibration_shard()
+
+    class Catcher(nn.Module):
+        def __init__(self, module):
+            super().__init__()
+            self.module = module
+
+        def forward(self, inp, *args, **kwargs):
+            if vit:
+                rel_pos_bias = args[0] if args else kwargs.get("rel_pos_bias")
+                dense = args[1] if len(args) > 1 else kwargs.get("dense", True)
+                cache = {"rel_pos_bias": rel_pos_bias}
+            else:
+                dense = kwargs.pop("dense", True)
+                cache = {k: kwargs[k] for k in keys}
+            inps.append(inp)
+            inps[-1].requires_grad = False
+            if lora_model:
+                cache["dense"] = dense
+            caches.append(cache)
+            raise _Stop
+
+    layers[0] = Catcher(layers[0])
+    try:
+        total = 0
+        batches = []
+        for batch in dataloader:                       # which batches the reference would consume
+            if total >= n_samples:
+                break
+            if vit or "image" in batch:
+                total += batch["image"].shape[0]
+            else:
+                total += len(batch["text_input"])
+            batches.append(batch)
+        if world > 1 and len(batches) % world != 0:
+            raise RuntimeError(f"calibration sharding needs the {len(batches)} calibration batches to divide evenly "
+                               f"over {world} ranks (set VLMC_SHARD_CALIB=0 to run as replicas)")
+        per = len(batches) // world
+        for batch in batches[rank * per:(rank + 1) * per] if world > 1 else batches:
+            try:
+                forward_to_cache(model, batch, lora_model)
+            except ValueError:                         # _Stop, or the reference's bare ValueError
+                pass
+    finally:
+        layers[0] = layers[0].module
+    return inps, [None] * len(inps), caches
+
+
+def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocast, prune_block, tuple_output):
+    """The block loop of `_prune`: for every block, `prune_block(i, layer, subset, run)`
+    is called with `run()` = one pass of the block over all samples (filling `outs`);
+    afterwards the block runs again with whatever weights `prune_block` left, and
+    inputs/outputs swap (wanda_pruner.py:287-347)."""
+    layers = get_module_recursive(model, module_to_process)
+    n_samples = min(n_samples, len(inps))
+    state = {"inps": inps, "outs": outs}
+
+    def run_pass(before_sample=None):
+        cur_in, cur_out = state["inps"], state["outs"]
+        for j in range(n_samples):
+            if before_sample is not None:
+                before_sample(j)
+            with torch.no_grad():
+                with autocast():
+                    y = layer(cur_in[j], **caches[j])
+                    cur_out[j] = y[0] if tuple_output else y
+
+    for i in range(len(layers)):
+        layer = layers[i]
+        subset = find_layers(layer)
+        prune_block(i, layer, subset, run_pass, state)
+        run_pass()
+        state["inps"], state["outs"] = state["outs"], state["inps"]
+    return model

@@ -1,0 +1,365 @@
+"""Wanda pruners behind the reference's `lavis.compression` API, running on the
+gfx950 kernels (`vlmc.ops`): `t5_wanda_pruner`, `vit_wanda_pruner`, `blipt5_wanda_pruner`.
+
+Reference: lavis/compression/pruners/wanda_pruner.py (T5LayerWandaPruner :84-494,
+VITLayerWandaPruner :497-793, BLIPT5LayerWandaPruner :796-1052).  Same registry names,
+constructor kwargs, `prune(importance_scores=None, keep_indices_or_masks=None,
+lora_model=False) -> (model, sparsity_dict | None)` contract and side effects
+(`module.mask` bool [out,in] True = keep, `weight.importance_score` float, weights
+zeroed in place unless `lora_model`).  What differs is where the arithmetic runs:
+
+  reference op sequence (per linear)                    here
+  ---------------------------------------------------  ---------------------------------
+  hook: norm(x.t().float(), dim=1)**2, running mean     vlmc_act_sqnorm (per hook call,
+  (:68-81)                                               shared by linears with the same
+                                                         input) + vlmc_wanda_scaler_update
+  |W| * sqrt(scaler_row); .cpu().abs().mean().item()    fused in vlmc_wanda_select; the
+  (:318-320, full [out,in] D2H copy)                     score is never materialised, one
+  sort / topk loop / threshold; scatter_; W[mask]=0      8-byte readback per BLOCK
+  (:322-341, :670-687)
+
+There is no CPU fallback: without the HIP library or a GPU model the pruner raises.
+"""
+from __future__ import annotations
+
+import gc
+import os
+
+import torch
+
+from lavis.common.registry import registry
+from lavis.compression.pruners import calibration as cal
+from lavis.compression.pruners.layer_single_base_pruner import LayerSparsity, LayerWiseBasePruner
+from lavis.compression.pruners.utils import print_time
+
+_VERBOSE = os.environ.get("VLMC_VERBOSE", "0") != "0"
+
+
+# --------------------------------------------------------------------------------------
+# statistics collection through forward hooks
+# --------------------------------------------------------------------------------------
+class WandaStatCollector:
+    """Forward hooks on the linears of one block (wanda_pruner.py:295-314).  Linears that
+    receive the very same tensor (q/k/v, wi_0/wi_1) share one squared-norm launch and one
+    statistic."""
+
+    def __init__(self, subset):
+        from vlmc import ops
+        self._ops = ops
+        self.subset = subset
+        self.rows = {n: [] for n in subset}
+        self.batches = {n: [] for n in subset}
+        self._cache = {}
+        self.handles = [m.register_forward_hook(self._make_hook(n)) for n, m in subset.items()]
+
+    def _make_hook(self, name):
+        def hook(_module, inp, _out):
+            x = inp[0].data
+            if x.dim() == 2:
+                x = x.unsqueeze(0)
+            key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, x._version)
+            hit = self._cache.get(key)
+            if hit is None:
+                row = self._ops.act_sqnorm(x.reshape(1, -1, x.shape[-1]))
+                # keep `x` referenced until the next sample so its memory cannot be recycled
+                # for a different activation with the same address/shape during this forward
+                hit = (x, row)
+                self._cache[key] = hit
+            self.rows[name].append(hit[1])
+            self.batches[name].append(x.shape[0])
+        return hook
+
+    def next_sample(self, _j=None):
+        self._cache.clear()
+
+    def close(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []
+        self._cache.clear()
+
+    def finalize(self):
+        """{name: InputStat}; linears whose hooks saw identical tensors share the object."""
+        from vlmc import wanda
+        shared, out, order = {}, {}, []
+        for name, rows in self.rows.items():
+            sig = tuple(id(r) for r in rows)
+            st = shared.get(sig)
+            if st is None:
+                in_f = self.subset[name].weight.shape[1]
+                st = wanda.InputStat(in_f, self.subset[name].weight.device)
+                st.rows = list(rows)
+                st.batches = list(self.batches[name])
+                shared[sig] = st
+                order.append(st)
+            out[name] = st
+        wanda.gather_stats(order)
+        return out
+
+
+def _importance_readback(subset, names, partial_rows, numels):
+    """weight.importance_score for every linear of the block with ONE device->host copy
+    (the reference copies each fp32 [out,in] metric to the host, wanda_pruner.py:320)."""
+    sums = partial_rows.sum(dim=1).cpu().tolist()
+    for name, s, numel in zip(names, sums, numels):
+        setattr(subset[name].weight, "importance_score", s / numel)
+
+
+class _WandaBlockMixin:
+    """Per-block Wanda step shared by the T5/LLM and ViT variants."""
+
+    def _wanda_block(self, i, subset, run_pass, n_inps, batch0, *, unstructured_mode, module_to_process, model_prefix,
+                     sparsity_ratio, lora_model):
+        from vlmc import ops, wanda
+        col = WandaStatCollector(subset)
+        try:
+            run_pass(col.next_sample)
+        finally:
+            col.close()
+        stats = col.finalize()
+
+        names = list(subset)
+        nparts = [ops.select_partials(unstructured_mode if self.prune_n == 0 else "nm", *subset[n].weight.shape)
+                  for n in names]
+        dev = subset[names[0]].weight.device
+        partial_rows = torch.zeros((len(names), max(nparts)), dtype=torch.float64, device=dev)
+        for li, name in enumerate(names):
+            mod, st = subset[name], stats[name]
+            assert st.nsamples == n_inps * batch0                      # wanda_pruner.py:317
+            W = mod.weight.data
+            if not W.is_contiguous():
+                raise RuntimeError(f"{name}: weight must be contiguous")
+            if self.prune_n != 0:
+                if _VERBOSE:
+                    print(f"pruning {model_prefix} layer {i} {name} at structured {self.prune_n}:{self.prune_m} sparsity")
+                mask, _ = wanda.prune_linear(W, st, "nm", n=self.prune_n, m=self.prune_m, apply_zero=not lora_model,
+                                             partials=partial_rows[li])
+            else:
+                key = f"{module_to_process}.{i}.{name}.weight"
+                ratio = sparsity_ratio[key]
+                if _VERBOSE:
+                    print(f"pruning {model_prefix} layer {i} {name} at unstructured {ratio} sparsity")
+                mask, _ = wanda.prune_linear(W, st, unstructured_mode, ratio=ratio, apply_zero=not lora_model,
+                                             partials=partial_rows[li])
+            setattr(mod, "mask", mask)                                  # True = keep (:339)
+        _importance_readback(subset, names, partial_rows, [subset[n].weight.numel() for n in names])
+
+
+# --------------------------------------------------------------------------------------
+@registry.register_pruner("t5_wanda_pruner")
+class T5LayerWandaPruner(LayerWiseBasePruner, _WandaBlockMixin):
+    """T5 / OPT / LLaMA tower: per-output-row selection (wanda_pruner.py:84-494)."""
+    pruner_name = "t5_wanda_pruner"
+
+    def __init__(self, model, data_loader, prune_spec=None, importance_scores_cache=None,
+                 keep_indices_or_masks_cache=None, is_strct_pruning=False, num_samples=64, is_global=False,
+                 model_prefix="t5_model", sparsity_ratio_granularity=None, max_sparsity_per_layer=0.8,
+                 score_method="obd_avg", num_data_first_stage=128, num_noise=1, sparsity_dict=None, noise_eps=1e-3,
+                 prune_per_model=False, prune_n=0, prune_m=0, **kwargs):
+        super().__init__(model=model, data_loader=data_loader, prune_spec=prune_spec,
+                         is_strct_pruning=is_strct_pruning, importance_scores_cache=importance_scores_cache,
+                         keep_indices_or_masks_cache=keep_indices_or_masks_cache, is_global=is_global,
+                         num_samples=num_samples, model_prefix=model_prefix,
+                         sparsity_ratio_granularity=sparsity_ratio_granularity,
+                         max_sparsity_per_layer=max_sparsity_per_layer, score_method=score_method,
+                         num_data_first_stage=num_data_first_stage, num_noise=num_noise, sparsity_dict=sparsity_dict,
+                         noise_eps=noise_eps, prune_per_model=prune_per_model, prune_n=prune_n, prune_m=prune_m)
+
+    def forward_to_cache(self, model, batch, lora_model=False):
+        return model(batch)
+
+    def check_sparsity(self, model, module_to_process="encoder.block"):
+        layers = cal.get_module_recursive(model, module_to_process)
+        zeros = total = 0
+        for layer in layers:
+            for mod in cal.find_layers(layer).values():
+                zeros += (mod.weight.data == 0).sum().item()
+                total += mod.weight.numel()
+        return float(zeros) / total
+
+    def prepare_calibration_input_encoder(self, model, dataloader, model_prefix, n_samples,
+                                          module_to_process="encoder.block", lora_model=False):
+        cfg = getattr(model, model_prefix).config
+        use_cache, cfg.use_cache = cfg.use_cache, False
+        try:
+            return cal.capture_block_inputs(model, dataloader, n_samples, module_to_process, self.forward_to_cache,
+                                            lora_model, vit=False, model_prefix=self.model_prefix)
+        finally:
+            cfg.use_cache = use_cache
+
+    @print_time
+    def _prune(self, model, dataloader, model_prefix, module_to_process="encoder.block", n_samples=64,
+               sparsity_ratio=0.5, lora_model=False):
+        cfg = getattr(model, model_prefix).config
+        use_cache, cfg.use_cache = cfg.use_cache, False
+        with torch.no_grad():
+            inps, outs, caches = self.prepare_calibration_input_encoder(model, dataloader, model_prefix, n_samples,
+                                                                        module_to_process, lora_model)
+        n_inps, batch0 = len(inps), inps[0].shape[0]
+
+        def prune_block(i, layer, subset, run_pass, state):
+            self._wanda_block(i, subset, run_pass, n_inps, batch0, unstructured_mode="row",
+                              module_to_process=module_to_process, model_prefix=model_prefix,
+                              sparsity_ratio=sparsity_ratio, lora_model=lora_model)
+
+        cal.walk_blocks(model, inps, outs, caches, module_to_process, n_samples,
+                        lambda: model.maybe_autocast(dtype=torch.bfloat16), prune_block, tuple_output=True)
+        cfg.use_cache = use_cache
+        torch.cuda.empty_cache()
+        gc.collect()
+        return model
+
+
+@registry.register_pruner("vit_wanda_pruner")
+class VITLayerWandaPruner(LayerWiseBasePruner, _WandaBlockMixin):
+    """EVA ViT tower: ONE matrix-wide threshold per linear (wanda_pruner.py:497-793)."""
+    pruner_name = "vit_wanda_pruner"
+
+    def __init__(self, model, data_loader, prune_spec=None, importance_scores_cache=None,
+                 keep_indices_or_masks_cache=None, is_strct_pruning=False, num_samples=64, is_global=False,
+                 model_prefix="visual", sparsity_ratio_granularity=None, max_sparsity_per_layer=0.8,
+                 score_method="obd_avg", num_data_first_stage=128, num_noise=1, sparsity_dict=None, noise_eps=1e-3,
+                 prune_per_model=False, prune_n=0, prune_m=0, **kwargs):
+        super().__init__(model=model, data_loader=data_loader, prune_spec=prune_spec,
+                         is_strct_pruning=is_strct_pruning, importance_scores_cache=importance_scores_cache,
+                         keep_indices_or_masks_cache=keep_indices_or_masks_cache, is_global=is_global,
+                         num_samples=num_samples, model_prefix=model_prefix,
+                         sparsity_ratio_granularity=sparsity_ratio_granularity,
+                         max_sparsity_per_layer=max_sparsity_per_layer, score_method=score_method,
+                         num_data_first_stage=num_data_first_stage, num_noise=num_noise, sparsity_dict=sparsity_dict,
+                         noise_eps=noise_eps, prune_per_model=prune_per_model, prune_n=prune_n, prune_m=prune_m)
+
+    def forward_to_cache(self, model, batch, lora_model=False):
+        return model.encode_image(batch["image"])
+
+    check_sparsity = T5LayerWandaPruner.check_sparsity
+
+    def prepare_calibration_input_encoder(self, model, dataloader, model_prefix, n_samples,
+                                          module_to_process="encoder.block", lora_model=False):
+        return cal.capture_block_inputs(model, dataloader, n_samples, module_to_process, self.forward_to_cache,
+                                        lora_model, vit=True)
+
+    @print_time
+    def _prune(self, model, dataloader, model_prefix, module_to_process="encoder.block", n_samples=64,
+               sparsity_ratio=0.5, lora_model=False):
+        with torch.no_grad():
+            inps, outs, caches = self.prepare_calibration_input_encoder(model, dataloader, model_prefix, n_samples,
+                                                                        module_to_process, lora_model)
+        n_inps, batch0 = len(inps), inps[0].shape[0]
+
+        def prune_block(i, layer, subset, run_pass, state):
+            self._wanda_block(i, subset, run_pass, n_inps, batch0, unstructured_mode="matrix",
+                              module_to_process=module_to_process, model_prefix=model_prefix,
+                              sparsity_ratio=sparsity_ratio, lora_model=lora_model)
+
+        cal.walk_blocks(model, inps, outs, caches, module_to_process, n_samples, lambda: model.maybe_autocast(),
+                        prune_block, tuple_output=False)
+        torch.cuda.empty_cache()
+        gc.collect()
+        return model
+
+
+def uniform_or_layer_sparsity(pruner, original_sparsity, granularity, loss_func=None):
+    """`get_sparsity` of the BLIP pruners (wanda_pruner.py:866-939): a yaml override, the
+    uniform module, or (not built) the ECoFLaP allocation."""
+    if pruner.sparsity_dict is not None:
+        import yaml
+        with open(pruner.sparsity_dict, "r") as f:
+            return yaml.load(f, Loader=yaml.FullLoader)
+    if granularity is None or granularity == "none":
+        mapping = {}
+    else:
+        raise NotImplementedError("sparsity_ratio_granularity other than None/'none' needs LayerSparsity's "
+                                  "first-order scoring (layer_single_base_pruner.py:257-729), not built yet")
+    return LayerSparsity(pruner.model, pruner.data_loader, loss_func, pruner.num_data_first_stage, original_sparsity,
+                         pruner.max_sparsity_per_layer, pruner.score_method, pruner.num_noise, pruner.noise_eps,
+                         mapping).return_sparsity()
+
+
+@registry.register_pruner("blipt5_wanda_pruner")
+class BLIPT5LayerWandaPruner(LayerWiseBasePruner):
+    """ViT tower, then T5 encoder, then T5 decoder (or the LLaMA/OPT stack) --
+    wanda_pruner.py:796-1052."""
+    pruner_name = "blipt5_wanda_pruner"
+
+    def __init__(self, model, data_loader, t5_prune_spec=None, vit_prune_spec=None, t5_pruning_method=None,
+                 vit_pruning_method=None, t5_importance_scores_cache=None, t5_keep_indices_or_masks_cache=None,
+                 vit_importance_scores_cache=None, vit_keep_indices_or_masks_cache=None, importance_scores_cache=None,
+                 keep_indices_or_masks_cache=None, is_strct_pruning=False, num_samples=64, is_global=False,
+                 t5_model_prefix="t5_model", vit_model_prefix="visual_encoder", sparsity_ratio_granularity=None,
+                 max_sparsity_per_layer=0.8, score_method="obd_avg", num_data_first_stage=128, num_noise=1,
+                 sparsity_dict=None, noise_eps=1e-3, prune_per_model=False, peft_postfix="", prune_n=0, prune_m=0,
+                 **kwargs):
+        super().__init__(model=model, data_loader=data_loader, prune_spec=None, is_strct_pruning=is_strct_pruning,
+                         importance_scores_cache=importance_scores_cache,
+                         keep_indices_or_masks_cache=keep_indices_or_masks_cache, is_global=is_global,
+                         num_samples=num_samples, model_prefix=f"{vit_model_prefix}+{t5_model_prefix}",
+                         sparsity_ratio_granularity=sparsity_ratio_granularity,
+                         max_sparsity_per_layer=max_sparsity_per_layer, score_method=score_method,
+                         num_data_first_stage=num_data_first_stage, num_noise=num_noise, sparsity_dict=sparsity_dict,
+                         noise_eps=noise_eps, prune_per_model=prune_per_model, prune_n=prune_n, prune_m=prune_m)
+        self.t5_prune_spec = t5_prune_spec
+        self.vit_prune_spec = vit_prune_spec
+        self.peft_postfix = peft_postfix
+        self.vit_dense = True
+        self.llm_dense = True
+        assert t5_pruning_method is not None
+        assert vit_pruning_method is not None
+        self.t5_model_prefix = t5_model_prefix
+        self.vit_model_prefix = vit_model_prefix
+
+    # the tower implementations are borrowed as unbound methods, like the reference does with
+    # functools.partial (:983-988, :1011-1015)
+    _wanda_block = _WandaBlockMixin._wanda_block
+
+    def get_sparsity(self, original_sparsity, sparsity_ratio_granularity=None):
+        return uniform_or_layer_sparsity(self, original_sparsity, sparsity_ratio_granularity)
+
+    def forward_to_cache(self, model, batch, lora_model=False):
+        if lora_model:
+            return model(batch, vit_dense=self.vit_dense, llm_dense=self.llm_dense)      # :941-945
+        return model(batch)
+
+    def _tower(self, cls, **kw):
+        self.prepare_calibration_input_encoder = lambda *a, **k: cls.prepare_calibration_input_encoder(self, *a, **k)
+        return cls._prune(self, self.model, self.data_loader, **kw)
+
+    @print_time
+    def prune(self, importance_scores=None, keep_indices_or_masks=None, lora_model=False):
+        dtype_record, requires_grad_record, device = self.model_setup_and_record_attributes(self.model)
+        global_sparsity_dict = None
+        _, vit_keep_ratio, _, _ = self.convert_spec_to_list(self.vit_prune_spec)
+        _, t5_keep_ratio, _, _ = self.convert_spec_to_list(self.t5_prune_spec)
+        if self.sparsity_ratio_granularity not in [None, "none"]:
+            global_sparsity_dict = self.get_sparsity(1 - t5_keep_ratio,
+                                                     sparsity_ratio_granularity=self.sparsity_ratio_granularity)
+        # the calibration forward of a tower is DENSE exactly when that tower is pruned (:966-967)
+        self.vit_dense = True if float(vit_keep_ratio) < 1. else False
+        self.llm_dense = True if float(t5_keep_ratio) < 1. else False
+
+        if self.vit_prune_spec is not None and float(vit_keep_ratio) < 1.:
+            sd = global_sparsity_dict if global_sparsity_dict not in [None, "none"] else \
+                self.get_sparsity(1 - vit_keep_ratio, sparsity_ratio_granularity=None)
+            self.model = self._tower(VITLayerWandaPruner, model_prefix=self.vit_model_prefix,
+                                     module_to_process=f"{self.vit_model_prefix}.blocks",
+                                     n_samples=self.num_samples, sparsity_ratio=sd, lora_model=lora_model)
+
+        if self.t5_prune_spec is not None and float(t5_keep_ratio) < 1.:
+            sd = global_sparsity_dict if global_sparsity_dict is not None else \
+                self.get_sparsity(1 - t5_keep_ratio, sparsity_ratio_granularity=None)
+            if "t5_model" in self.t5_model_prefix:
+                for side in ("encoder", "decoder"):
+                    self.model = self._tower(T5LayerWandaPruner, model_prefix=self.t5_model_prefix,
+                                             module_to_process=f"{self.t5_model_prefix}.{side}.block",
+                                             n_samples=self.num_samples, sparsity_ratio=sd, lora_model=lora_model)
+            else:
+                self.model = self._tower(T5LayerWandaPruner, model_prefix=self.t5_model_prefix,
+                                         module_to_process=f"{self.t5_model_prefix}{self.peft_postfix}.model.layers",
+                                         n_samples=self.num_samples, sparsity_ratio=sd, lora_model=lora_model)
+
+        self.model_reset(self.model, dtype_record, requires_grad_record, device)
+        return self.model, global_sparsity_dict
+
+    def check(self, name, v, model_prefix):
+        return len(v.shape) == 2 and ".block" in name and "relative_attention_bias.weight" not in name \
+            and name.startswith(model_prefix)

@@ -133,3 +133,50 @@ def wanda_select(weight: torch.Tensor, sqrt_scaler_row: torch.Tensor, mode: str,
 def select_partials(mode: str, out_f: int, in_f: int) -> int:
     """Number of float64 partial sums `wanda_select` writes for this shape."""
     return int(_lib.load().vlmc_wanda_select_partials(_MODES[mode], out_f, in_f))
+
+
+# ---------------------------------------------------------------------------------------
+# Launch plans: pre-validated, pre-bound C-ABI calls for hot loops that issue thousands of
+# launches per step (bench.py, the per-block pruner loop).  A plan is a zero-argument
+# callable; tensors referenced by a plan must stay alive and must not be reallocated.
+# ---------------------------------------------------------------------------------------
+def _bind(fn, args):
+    check = _lib.check
+
+    def run():
+        rc = fn(*args)
+        if rc:
+            check(rc)
+    return run
+
+
+def plan_act_sqnorm(x: torch.Tensor, out: torch.Tensor):
+    _need_gpu(x, out)
+    assert x.dim() == 3 and x.is_contiguous() and out.is_contiguous() and out.shape == (x.shape[0], x.shape[2])
+    calls, tokens, in_f = x.shape
+    return _bind(_lib.load().vlmc_act_sqnorm, (x.data_ptr(), _dtype_code(x), calls, tokens, in_f, in_f, tokens * in_f,
+                                               out.data_ptr(), _stream()))
+
+
+def plan_scaler_update(scaler_row: torch.Tensor, nsamples_before: int, normsq: torch.Tensor, batch: int,
+                       sqrt_out: torch.Tensor):
+    _need_gpu(scaler_row, normsq, sqrt_out)
+    assert normsq.is_contiguous() and normsq.dtype == torch.float32
+    return _bind(_lib.load().vlmc_wanda_scaler_update, (scaler_row.data_ptr(), scaler_row.numel(), nsamples_before,
+                                                        normsq.data_ptr(), normsq.shape[0], batch, sqrt_out.data_ptr(),
+                                                        _stream()))
+
+
+def plan_select(weight: torch.Tensor, sqrt_scaler_row: torch.Tensor, mode: str, *, k=0, n=0, m=0, apply_zero=True,
+                mask: torch.Tensor, partials: torch.Tensor):
+    _need_gpu(weight, sqrt_scaler_row, mask, partials)
+    out_f, in_f = weight.shape
+    code = _MODES[mode]
+    lib = _lib.load()
+    assert partials.numel() >= lib.vlmc_wanda_select_partials(code, out_f, in_f)
+    nbytes = lib.vlmc_wanda_select_workspace(code, out_f, in_f)
+    ws = _select_ws.get(nbytes, weight.device) if nbytes else None
+    return _bind(lib.vlmc_wanda_select, (weight.data_ptr(), _dtype_code(weight), out_f, in_f, weight.stride(0),
+                                         sqrt_scaler_row.data_ptr(), code, int(k), int(n), int(m), int(bool(apply_zero)),
+                                         mask.data_ptr(), partials.data_ptr(), ws.data_ptr() if nbytes else None,
+                                         ws.numel() if nbytes else 0, _stream()))

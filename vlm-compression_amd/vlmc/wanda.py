@@ -1,0 +1,124 @@
+"""Wanda pruning engine pieces shared by the drop-in pruner (`lavis.compression`) and
+bench.py: per-input activation statistics, the multi-GPU statistics exchange, and the
+per-linear fused select.  Everything numeric runs in the HIP kernels behind `vlmc.ops`;
+this module only sequences launches and owns the small state tensors.
+
+Multi-GPU: calibration samples are sharded over ranks in contiguous
+ranges (rank r owns samples [r*n, (r+1)*n)).  Each rank reduces its own samples to
+per-sample squared norms ([n, in] fp32); ONE all-gather per transformer block (RCCL
+over xGMI, or gloo on CPU in the tests) concatenates them in sample order, and every
+rank then runs the reference's running-mean recurrence over all samples in order --
+so scaler_row, and therefore every mask, is bit-identical for any number of GPUs.
+The select itself (<= 125 MB of traffic per linear) is replicated, because every rank
+needs the pruned weights for the next block's forward.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class InputStat:
+    """Statistics of ONE distinct linear input over the calibration set
+    (the state of `WrappedGPT`, wanda_pruner.py:51-81, for every linear sharing it)."""
+
+    def __init__(self, in_features: int, device, capacity: int = 0):
+        self.in_features = in_features
+        self.device = device
+        self.rows = []                 # per-call squared norms, [calls_i, in] tensors in call order
+        self.batches = []              # samples per call (the reference's `tmp`)
+        self.scaler_row = None
+        self.sqrt_row = None
+        self.nsamples = 0
+        self._buf = torch.empty((capacity, in_features), dtype=torch.float32, device=device) if capacity else None
+        self._used = 0
+
+    # -- accumulation ---------------------------------------------------------------
+    def add_call(self, x: torch.Tensor):
+        """One forward-hook call with input x [b, T, in] (or [T, in])."""
+        b = x.shape[0] if x.dim() == 3 else 1
+        x = x.reshape(1, -1, x.shape[-1])
+        out = None
+        if self._buf is not None and self._used < self._buf.shape[0]:
+            out = self._buf[self._used:self._used + 1]
+            self._used += 1
+        self.rows.append(ops.act_sqnorm(x, out=out))
+        self.batches.append(b)
+
+    def add_samples(self, x: torch.Tensor, out: torch.Tensor | None = None):
+        """Many batch-1 calls at once: x [samples, T, in] -> one launch."""
+        self.rows.append(ops.act_sqnorm(x, out=out))
+        self.batches.extend([1] * x.shape[0])
+
+    def local_normsq(self) -> torch.Tensor:
+        if len(self.rows) == 1:
+            return self.rows[0]
+        if self._buf is not None and self._used == len(self.rows):
+            return self._buf[:self._used]
+        return torch.cat(self.rows, dim=0)
+
+    # -- finalisation ---------------------------------------------------------------
+    def finalize(self, normsq: torch.Tensor | None = None, batches=None):
+        """Run the running-mean recurrence over `normsq` (default: the local calls) in
+        order and produce scaler_row and sqrt(scaler_row)."""
+        normsq = self.local_normsq() if normsq is None else normsq
+        batches = self.batches if batches is None else batches
+        self.scaler_row = torch.zeros(self.in_features, dtype=torch.float32, device=self.device)
+        self.sqrt_row = torch.empty_like(self.scaler_row)
+        n, start = 0, 0
+        # consecutive calls with the same batch size go to the device in one launch
+        while start < len(batches):
+            end = start
+            while end < len(batches) and batches[end] == batches[start]:
+                end += 1
+            last = end == len(batches)
+            n = ops.wanda_scaler_update(self.scaler_row, n, normsq[start:end], batches[start],
+                                        sqrt_out=self.sqrt_row if last else None)
+            start = end
+        if not batches:
+            ops.wanda_scaler_update(self.scaler_row, 0, None, 1, sqrt_out=self.sqrt_row)
+        self.nsamples = n
+        return self
+
+
+def gather_stats(stats, group=None):
+    """Multi-GPU exchange for one transformer block: all-gather the per-sample squared
+    norms of every distinct input in ONE collective, then finalise each statistic over
+    the full, ordered sample set.  With no process group this is just `finalize()`."""
+    import torch.distributed as dist
+    if group is None and not (dist.is_available() and dist.is_initialized()):
+        for st in stats:
+            st.finalize()
+        return stats
+    world = dist.get_world_size(group)
+    if world == 1:
+        for st in stats:
+            st.finalize()
+        return stats
+    local = [st.local_normsq() for st in stats]
+    n_local = local[0].shape[0]
+    assert all(t.shape[0] == n_local for t in local), "every input must see the same number of calls"
+    flat = torch.cat(local, dim=1).contiguous()                        # [n_local, sum(in)]
+    gathered = torch.empty((world * n_local, flat.shape[1]), dtype=flat.dtype, device=flat.device)
+    dist.all_gather_into_tensor(gathered, flat, group=group)           # rank-major == sample order
+    off = 0
+    for st in stats:
+        part = gathered[:, off:off + st.in_features].contiguous()
+        off += st.in_features
+        st.finalize(part, st.batches * world)
+    return stats
+
+
+def prune_linear(weight: torch.Tensor, stat: InputStat, mode: str, *, ratio=None, n=0, m=0, apply_zero=True,
+                 mask: torch.Tensor | None = None, partials: torch.Tensor | None = None):
+    """Loop body of wanda_pruner.py:316-341 / :664-687 for one linear."""
+    if mode == "nm":
+        return ops.wanda_select(weight, stat.sqrt_row, "nm", n=n, m=m, apply_zero=apply_zero, mask=mask, partials=partials)
+    if mode == "row":
+        k = int(weight.shape[1] * ratio)                               # :336
+    elif mode == "matrix":
+        k = int(weight.numel() * ratio)                                # :682
+    else:
+        raise ValueError(mode)
+    return ops.wanda_select(weight, stat.sqrt_row, mode, k=k, apply_zero=apply_zero, mask=mask, partials=partials)
