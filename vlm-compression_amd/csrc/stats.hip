@@ -62,20 +62,53 @@ __global__ __launch_bounds__(256) void act_sqnorm_kernel(const typename T::raw *
 }
 
 // s *= float(n/(n+b)); n += b; s += normsq[c] / float(n)   (wanda_pruner.py:77-81)
-__global__ void scaler_update_kernel(float *__restrict__ s, int64_t in_f, int64_t n0, const float *__restrict__ normsq,
-                                     int64_t n_calls, int64_t batch, float *__restrict__ sqrt_out) {
-    const int64_t ch = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (ch >= in_f) return;
-    float acc = n0 == 0 ? 0.f : s[ch];   // a fresh statistic starts from zeros (WrappedGPT.__init__, :62)
-    int64_t n = n0;
-    for (int64_t c = 0; c < n_calls; ++c) {
-        const float f = float(double(n) / double(n + batch));   // python float -> fp32 scalar
-        acc = ieee_mul(acc, f);
-        n += batch;
-        acc = ieee_add(acc, ieee_div(normsq[c * in_f + ch], float(n)));
+// One lane per channel walks the calls in order.  The scale factors float(n/(n+b)) (a python
+// double division rounded to fp32) are the same for every channel: they are computed once per
+// workgroup into LDS, off the dependent chain, which is then one multiply and one add per call;
+// the per-call divisions normsq/float(n) do not depend on the accumulator and pipeline freely.
+constexpr int kUpdChannels = 64;    // channels per workgroup
+constexpr int kUpdGroups = 4;       // call groups (256 threads = 64 channels x 4 groups)
+constexpr int kUpdChunk = 128;      // calls staged in LDS at a time (32 KB)
+__global__ __launch_bounds__(256) void scaler_update_kernel(float *__restrict__ s, int64_t in_f, int64_t n0,
+                                                            const float *__restrict__ normsq, int64_t n_calls,
+                                                            int64_t batch, float *__restrict__ sqrt_out) {
+    // The normsq loads are the latency problem of this tiny kernel (calls x in fp32, read once):
+    // 256 threads fetch and pre-divide a [128 calls x 64 channels] panel into LDS with all loads in
+    // flight at once, then 64 lanes run the short dependent chain (one mul + one add per call).
+    __shared__ float q[kUpdChunk][kUpdChannels];
+    __shared__ float fac[kUpdChunk];
+    const int chl = threadIdx.x % kUpdChannels, grp = threadIdx.x / kUpdChannels;
+    const int64_t ch = int64_t(blockIdx.x) * kUpdChannels + chl;
+    const bool live = ch < in_f;
+    // a fresh statistic starts from zeros (WrappedGPT.__init__, wanda_pruner.py:62)
+    float acc = (live && !(n0 == 0 && n_calls > 0)) ? s[ch] : 0.f;
+    for (int64_t c0 = 0; c0 < n_calls; c0 += kUpdChunk) {
+        const int cn = int((n_calls - c0 < kUpdChunk) ? (n_calls - c0) : kUpdChunk);
+        __syncthreads();
+        if (int(threadIdx.x) < cn) {
+            const int64_t n = n0 + (c0 + threadIdx.x) * batch;
+            fac[threadIdx.x] = float(double(n) / double(n + batch));   // python float -> fp32 scalar
+        }
+        float v[kUpdChunk / kUpdGroups];
+#pragma unroll
+        for (int i = 0; i < kUpdChunk / kUpdGroups; ++i) {
+            const int c = i * kUpdGroups + grp;
+            v[i] = (live && c < cn) ? normsq[(c0 + c) * in_f + ch] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < kUpdChunk / kUpdGroups; ++i) {
+            const int c = i * kUpdGroups + grp;
+            if (c < cn) q[c][chl] = ieee_div(v[i], float(n0 + (c0 + c + 1) * batch));
+        }
+        __syncthreads();
+        if (grp == 0) {
+            for (int c = 0; c < cn; ++c) acc = ieee_add(ieee_mul(acc, fac[c]), q[c][chl]);
+        }
     }
-    s[ch] = acc;
-    if (sqrt_out) sqrt_out[ch] = ieee_sqrt(acc);   // torch.sqrt(scaler_row), wanda_pruner.py:318
+    if (live && grp == 0) {
+        s[ch] = acc;
+        if (sqrt_out) sqrt_out[ch] = ieee_sqrt(acc);   // torch.sqrt(scaler_row), wanda_pruner.py:318
+    }
 }
 
 template <typename T>
@@ -155,8 +188,7 @@ extern "C" int vlmc_wanda_scaler_update(float *scaler_row, int64_t in_features, 
                  "vlmc_wanda_scaler_update: bad arguments in=%lld calls=%lld batch=%lld n0=%lld", (long long)in_features,
                  (long long)n_calls, (long long)batch, (long long)nsamples_before);
     if (n_calls == 0 && !sqrt_out) return VLMC_OK;
-    const int threads = 256;
-    hipLaunchKernelGGL(scaler_update_kernel, dim3(unsigned((in_features + threads - 1) / threads)), dim3(threads), 0,
+    hipLaunchKernelGGL(scaler_update_kernel, dim3(unsigned((in_features + kUpdChannels - 1) / kUpdChannels)), dim3(256), 0,
                        as_stream(stream), scaler_row, in_features, nsamples_before, normsq, n_calls, batch, sqrt_out);
     VLMC_HIP_CHECK_LAUNCH("vlmc_wanda_scaler_update");
     return VLMC_OK;
