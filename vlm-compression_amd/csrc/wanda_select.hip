@@ -5,15 +5,11 @@
 // write the zeroed W back (2 B) => 5 B/weight (3 B under lora_model=True).  The fp32 score
 // |W|*sqrt(s) is never materialised; it lives in registers as an order-preserving u32 key.
 //
-//  SEL_ROW    one workgroup (NW waves, usually ONE wave => no barriers) per row; the row's keys
-//             stay in VGPRs (8*CH per lane, lanes own 16-byte column chunks so loads/stores are
-//             coalesced).  The k-th smallest key is found by bisection on the key bits with
-//             wave-wide counting (DPP reduction), switching to an exact all-pairs rank over the
-//             few keys left in the bracket; ties are broken by column index exactly like the
-//             reference's stable sort.  A persistent grid walks the rows: each wave seeds the
-//             bracket of its next row with the threshold of its previous one (rows of one
-//             matrix share the column scales, so thresholds differ by a few percent) and
-//             prefetches the next row while it works on the current one.
+//  SEL_ROW    one workgroup (1..8 waves) per row, grid = rows; the row's keys stay in VGPRs
+//             (lanes own 16-byte column chunks, so loads/stores are coalesced).  The k-th smallest
+//             key is found by radix-64 refinement of a bracket with 64 LDS counters (6 key bits
+//             per sweep), seeded by a 32-key sample of the row; ties are broken by column index
+//             exactly like the reference's stable sort.  See the kernel's header comment.
 //  SEL_MATRIX three global radix-histogram passes (12+10+10 key bits, LDS histograms flushed with
 //             integer atomics), then an elementwise apply pass.  W (<= 17 MB for ViT-g) is
 //             re-read from L2/Infinity Cache, not HBM.
@@ -98,11 +94,11 @@ __device__ __forceinline__ void store_row_chunk(typename T::raw *row, int64_t co
 template <bool ALIGNED>
 __device__ __forceinline__ void store_mask_chunk(uint8_t *mrow, int64_t col0, int64_t in_f, uint32_t keepbits) {
     if constexpr (ALIGNED) {
-        // spread bit j to byte j
-        uint64_t m = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) m |= uint64_t((keepbits >> j) & 1u) << (8 * j);
-        *reinterpret_cast<uint64_t *>(mrow + col0) = m;
+        // spread bit j to byte j: (nibble * 0x204081) & 0x01010101 puts bits 0..3 into bytes 0..3
+        uint2 m;
+        m.x = ((keepbits & 0xFu) * 0x00204081u) & 0x01010101u;
+        m.y = (((keepbits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u;
+        *reinterpret_cast<uint2 *>(mrow + col0) = m;
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -121,323 +117,335 @@ __device__ __forceinline__ void load_sq_chunk(const float *sq, int64_t col0, int
 }
 
 // ------------------------------------------------------------------------------------------
-// SEL_ROW
+// SEL_ROW: one workgroup of NW waves per row, grid = rows (the hardware dispatcher overlaps
+// rows that are loading, searching and storing on every SIMD).
+//
+//   1. keys in registers (8*CH per lane, 64*NW lanes; lanes own 16-byte column chunks).
+//   2. threshold search = radix-64 refinement of a bracket [lo, lo + 64*2^shift): every key
+//      inside the bracket bumps one of 64 LDS counters (bin = (key-lo) >> shift; keys outside
+//      go to a private per-thread sink slot, so there is no bank conflict and no divergence),
+//      a DPP prefix scan over 64 lanes finds the bin holding rank k, and that bin becomes the
+//      next bracket -- 6 key bits per sweep instead of 1 per bisection step.
+//      First bracket: two order statistics of a 32-key sample of the row (all-pairs ranks via
+//      readlane) bound the threshold to ~45 % of the keys, which spreads the first sweep's
+//      atomics over the bins; the sweep itself verifies the guess by exact counting and falls
+//      back to the whole key range if it was wrong.
+//      The refinement stops when every key left in the bracket is pruned (need == pop) or the
+//      bracket is a single value (ties, resolved in column order like the reference's stable sort).
+//   3. apply: one compare per key -> bool mask bytes + zeroed weights.
+// All decisions rest on exact counts: the sample only affects speed, never the result.
 // ------------------------------------------------------------------------------------------
-constexpr int kCap = 32;   // bracket population at which bisection hands over to the exact all-pairs rank
+#ifdef VLMC_STAMPS
+// diagnostic build only (never shipped): per-phase cycle totals, summed over waves into row_sums[0..7]
+#define VLMC_STAMP(i)                                                                   \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        unsigned long long t_;                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        stamp_acc[i] += t_ - stamp_last;                                                \
+        stamp_last = t_;                                                                \
+    } while (0)
+#else
+#define VLMC_STAMP(i) do {} while (0)
+#endif
+
+// inclusive prefix sum across the 64 lanes with DPP row shifts + row broadcasts
+__device__ __forceinline__ uint32_t wave_incl_scan_u32_dpp(uint32_t v) {
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xF, 0xF, false));   // row_shr:1
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xF, 0xF, false));   // row_shr:2
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xF, 0xF, false));   // row_shr:4
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xF, 0xF, false));   // row_shr:8
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1,3
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2,3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32_dpp(uint32_t v) {
+    v = max(v, uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0xB1, 0xF, 0xF, true)));
+    v = max(v, uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x4E, 0xF, 0xF, true)));
+    v = max(v, uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x141, 0xF, 0xF, true)));
+    v = max(v, uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x140, 0xF, 0xF, true)));
+    return max(max(uint32_t(__builtin_amdgcn_readlane(int(v), 0)), uint32_t(__builtin_amdgcn_readlane(int(v), 16))),
+               max(uint32_t(__builtin_amdgcn_readlane(int(v), 32)), uint32_t(__builtin_amdgcn_readlane(int(v), 48))));
+}
+__device__ __forceinline__ uint32_t wave_min_u32_dpp(uint32_t v) { return ~wave_max_u32_dpp(~v); }
+
+constexpr int kBins = 64;
+constexpr int kSample = 32;
 
 template <int NW> struct RowSmem {
-    uint32_t cnt[2][NW];       // double-buffered per-wave counts
-    uint32_t cnt2[2][NW];
+    uint32_t hist[kBins + 64 * NW];   // [0,64): bins; [64, 64+NT): per-thread sinks
+    uint32_t sample[kSample];
+    uint32_t below[NW];               // per-wave count(key < lo) of the guessed sweep
     uint32_t scan[NW];
-    double dsum[NW];
-    unsigned long long seg[NW * kCap];   // per-wave candidate segments
-    unsigned long long cand[kCap];       // dense candidate list
-    unsigned long long cut;
-    uint32_t segcnt[NW];
+    float fsum[NW];
+    uint32_t cut_col;
 };
 
-#ifndef VLMC_COUNT_MODE
-#define VLMC_COUNT_MODE 0
-#endif
-// wave-wide count(key <= mid).  Three codegen variants (VLMC_COUNT_MODE) for tuning:
-//  0: per-lane counters (v_cmp + v_addc) reduced with DPP
-//  1: ballot + scalar popcount (v_cmp -> SGPR pair, s_bcnt1, s_add): no cross-lane reduce
-//  2: half of the keys each way, so the vector and the scalar unit share the work
-template <int E> __device__ __forceinline__ uint32_t wave_count_le(const uint32_t (&key)[E], uint32_t mid) {
-#if VLMC_COUNT_MODE == 1
-    uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < E; ++i) c += uint32_t(__popcll(__ballot(key[i] <= mid)));
-    return c;
-#elif VLMC_COUNT_MODE == 2
-    constexpr int H = (E * 3) / 8;   // share counted on the scalar unit
-    uint32_t cs = 0, c0 = 0, c1 = 0;
-#pragma unroll
-    for (int i = 0; i < H; ++i) cs += uint32_t(__popcll(__ballot(key[i] <= mid)));
-#pragma unroll
-    for (int i = H; i + 1 < E; i += 2) {
-        c0 += (key[i] <= mid) ? 1u : 0u;
-        c1 += (key[i + 1] <= mid) ? 1u : 0u;
-    }
-    if ((E - H) & 1) c0 += (key[E - 1] <= mid) ? 1u : 0u;
-    return cs + wave_sum_u32_dpp(c0 + c1);
-#else
-    uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < E; ++i) c += (key[i] <= mid) ? 1u : 0u;
-    return wave_sum_u32_dpp(c);
-#endif
-}
-
-template <int E, int NW>
-__device__ __forceinline__ uint32_t block_count_le(const uint32_t (&key)[E], uint32_t mid, RowSmem<NW> &sm, int &phase) {
-    uint32_t c = wave_count_le<E>(key, mid);
+// workgroup-wide sync of LDS traffic; a single-wave workgroup only needs program order
+template <int NW> __device__ __forceinline__ void row_sync() {
     if constexpr (NW > 1) {
-        const int wave = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) sm.cnt[phase][wave] = c;
         lds_barrier();
-        uint32_t t = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) t += sm.cnt[phase][w];
-        phase ^= 1;
-        c = t;
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
-    return c;
-}
-
-// count(key <= a) and count(key <= b) in one sweep (bracket verification)
-template <int E, int NW>
-__device__ __forceinline__ void block_count_le2(const uint32_t (&key)[E], uint32_t a, uint32_t b, RowSmem<NW> &sm,
-                                                int &phase, uint32_t &ca, uint32_t &cb) {
-    uint32_t x = wave_count_le<E>(key, a);
-    uint32_t y = wave_count_le<E>(key, b);
-    if constexpr (NW > 1) {
-        const int wave = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) { sm.cnt[phase][wave] = x; sm.cnt2[phase][wave] = y; }
-        lds_barrier();
-        uint32_t tx = 0, ty = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { tx += sm.cnt[phase][w]; ty += sm.cnt2[phase][w]; }
-        phase ^= 1;
-        x = tx; y = ty;
-    }
-    ca = x; cb = y;
 }
 
 template <typename T, int CH, int NW, bool ALIGNED>
-__global__ __launch_bounds__(64 * NW, 4) void select_rows_kernel(typename T::raw *__restrict__ W, int64_t out_f,
-                                                              int64_t in_f, int64_t ldw,
-                                                              const float *__restrict__ sqrt_scaler, uint32_t k,
-                                                              int apply_zero, uint8_t *__restrict__ mask,
-                                                              double *__restrict__ row_sums) {
+__global__ __launch_bounds__(64 * NW, (NW * CH >= 4 && CH >= 3) ? 5 : 8)
+void select_rows_kernel(typename T::raw *__restrict__ W, int64_t out_f, int64_t in_f, int64_t ldw,
+                        const float *__restrict__ sqrt_scaler, uint32_t k, int apply_zero, uint8_t *__restrict__ mask,
+                        double *__restrict__ row_sums, uint32_t sample_margin, uint32_t frac_q16) {
     constexpr int NT = 64 * NW;
     constexpr int E = CH * 8;
     __shared__ RowSmem<NW> sm;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t nchunks = (in_f + 7) / 8;
+    const int64_t row = blockIdx.x;
+    typename T::raw *wrow = W + row * ldw;
+    const uint32_t sink = uint32_t(kBins + tid);
+    const uint32_t tid8 = uint32_t(tid) * 8u;
+#ifdef VLMC_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
 
-    // per-column sqrt(scaler_row) (wanda_pruner.py:318), loaded once per workgroup and kept in
-    // registers for every row it handles
-    float sqv[E];
+    // ---- 1. load the row, build the keys ------------------------------------------------------
     bool valid[CH];
+    Chunk8<T> raw[CH];
 #pragma unroll
     for (int s = 0; s < CH; ++s) {
-        const int64_t c = int64_t(s) * NT + tid;
-        valid[s] = c < nchunks;
-        if (valid[s]) {
-            load_sq_chunk<ALIGNED>(sqrt_scaler, c * 8, in_f, &sqv[s * 8]);
-        } else {
+        valid[s] = int64_t(s) * NT + tid < nchunks;
+        if (valid[s]) raw[s] = load_row_chunk<T, ALIGNED>(wrow, (int64_t(s) * NT + tid) * 8, in_f);
+    }
+    VLMC_STAMP(0);
+    uint32_t key[E];
+    float fsum = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sqv[s * 8 + j] = 0.f;
+    for (int s = 0; s < CH; ++s) {
+        const int64_t col0 = (int64_t(s) * NT + tid) * 8;
+        float sq[8];
+        if (valid[s]) load_sq_chunk<ALIGNED>(sqrt_scaler, col0, in_f, sq);     // <= 64 KB table, L2-resident
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool live = valid[s] && (ALIGNED || col0 + j < in_f);
+            if (live) {
+                const float sc = ieee_mul(fabsf(to_f32<T>(raw[s].v[j])), sq[j]);
+                // score >= +0 or NaN; every NaN -> one key above +inf (torch.sort puts NaN last)
+                const uint32_t b = __float_as_uint(sc);
+                key[s * 8 + j] = b < 0x7F800001u ? b : 0x7F800001u;
+                fsum += sc;
+            } else {
+                key[s * 8 + j] = 0xFFFFFFFFu;   // padding sorts after every real column
+            }
         }
     }
+    VLMC_STAMP(1);
 
-    // software prefetch: the next row's chunks are in flight while the current row is processed
-    Chunk8<T> nxt[CH];
-    int64_t row = blockIdx.x;
-    if (row < out_f) {
+    uint32_t cut_key = 0, cut_col = 0;
+    if (k > 0) {
+        // ---- 2a. bracket guess from a 32-key sample ------------------------------------------------
+        uint32_t lo = 0, cb = 0, shift = 26;          // default: whole key range, 64 * 2^26 = 2^32
+        bool guessed = false;
+        {
+            // sample = first key of slot (lane mod CH) of the first 32 threads: spread over the columns
+            uint32_t v = key[0];
 #pragma unroll
-        for (int s = 0; s < CH; ++s)
-            if (valid[s]) nxt[s] = load_row_chunk<T, ALIGNED>(W + row * ldw, (int64_t(s) * NT + tid) * 8, in_f);
-    }
-    bool have_prev = false;
-    uint32_t prev_key = 0;
-
-    for (; row < out_f; row += gridDim.x) {
-        typename T::raw *wrow = W + row * ldw;
-        Chunk8<T> raw[CH];
+            for (int s = 1; s < CH; ++s) v = (lane % CH == s) ? key[s * 8] : v;
+            if constexpr (NW > 1) {
+                if (tid < kSample) sm.sample[tid] = v;
+                lds_barrier();
+                v = sm.sample[lane & (kSample - 1)];
+            }
+            const bool in_sample = lane < kSample && v != 0xFFFFFFFFu;
+            const uint32_t nsample = uint32_t(__popcll(__ballot(in_sample)));
+            if (!in_sample) v = 0xFFFFFFFFu;
+            uint32_t rank = 0, rank2 = 0;
 #pragma unroll
-        for (int s = 0; s < CH; ++s) raw[s] = nxt[s];
-        const int64_t nrow = row + gridDim.x;
-        if (nrow < out_f) {
-#pragma unroll
-            for (int s = 0; s < CH; ++s)
-                if (valid[s]) nxt[s] = load_row_chunk<T, ALIGNED>(W + nrow * ldw, (int64_t(s) * NT + tid) * 8, in_f);
-        }
-        uint32_t key[E];
-        float fsum = 0.f;
-#pragma unroll
-        for (int s = 0; s < CH; ++s) {
-            const int64_t col0 = (int64_t(s) * NT + tid) * 8;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const bool live = valid[s] && (ALIGNED || col0 + j < in_f);
-                if (live) {
-                    const float sc = ieee_mul(fabsf(to_f32<T>(raw[s].v[j])), sqv[s * 8 + j]);
-                    key[s * 8 + j] = score_key(sc);
-                    fsum += sc;
+            for (int j = 0; j < kSample; j += 2) {
+                rank += (uint32_t(__builtin_amdgcn_readlane(int(v), j)) < v) ? 1u : 0u;
+                rank2 += (uint32_t(__builtin_amdgcn_readlane(int(v), j + 1)) < v) ? 1u : 0u;
+            }
+            rank += rank2;
+            const uint32_t rs = (frac_q16 * nsample) >> 16;                            // sample rank of the target
+            const uint32_t r_lo = rs > sample_margin ? rs - sample_margin : 0u;
+            const uint32_t r_hi = rs + sample_margin;
+            const uint32_t glo = r_lo == 0 ? 0u : wave_max_u32_dpp((rank <= r_lo && in_sample) ? v : 0u);
+            uint32_t ghi = wave_min_u32_dpp((rank >= r_hi && in_sample) ? v : 0xFFFFFFFFu);
+            if (ghi > 0x7F800001u) ghi = 0x7F800001u;                                 // largest real key
+            if (ghi > glo) {
+                const uint32_t w = (ghi - glo) >> 6;                                  // 64 bins must cover [glo, ghi]
+                shift = w ? 32u - uint32_t(__builtin_clz(w)) : 0u;
+                lo = glo;
+                if (shift < 26u) {
+                    const uint64_t end = uint64_t(lo) + (uint64_t(64) << shift);
+                    if (end > 0x100000000ull) lo = uint32_t(0x100000000ull - (uint64_t(64) << shift));
+                    guessed = true;
                 } else {
-                    key[s * 8 + j] = 0xFFFFFFFFu;   // padding sorts after every real column
+                    lo = 0; shift = 26;
                 }
             }
         }
-
-        // column of this lane's first element; opaque to the optimiser so that the 8*CH per-key
-        // column indices derived from it are not hoisted out of the row loop into registers
-        uint32_t tid8 = uint32_t(tid) * 8u;
-        asm volatile("" : "+v"(tid8));
-
-        // ---- find the cut: the (key, column) pair of rank k-1 in stable order ----------
-        unsigned long long cut = 0;   // prune (key,col) <= cut
-        if (k > 0) {
-            int phase = 0;
-            uint32_t lo = 0, hi = 0xFFFFFFFFu;
-            uint32_t cb = 0;                    // count(key <  lo)
-            uint32_t ca = uint32_t(NT) * E;     // count(key <= hi)
-            if (have_prev) {
-                // guess: this row's threshold lies within +-2^20 key units (6..12 % in value) of the
-                // previous row's.  Verified by counting, so a wrong guess only costs time.
-                constexpr uint32_t D = 1u << 20;
-                const uint32_t glo = prev_key > D ? prev_key - D : 0u;
-                const uint32_t ghi = prev_key < 0xFFFFFFFFu - D ? prev_key + D : 0xFFFFFFFFu;
-                uint32_t c_below = 0, c_upto = 0;   // count(key < glo), count(key <= ghi)
-                if (glo > 0) {
-                    block_count_le2<E, NW>(key, glo - 1, ghi, sm, phase, c_below, c_upto);
-                } else {
-                    c_upto = block_count_le<E, NW>(key, ghi, sm, phase);
-                }
-                if (c_below >= k) { hi = glo - 1; ca = c_below; }
-                else if (c_upto < k) { lo = ghi + 1; cb = c_upto; }
-                else { lo = glo; hi = ghi; cb = c_below; ca = c_upto; }
-            }
-            while (ca - cb > uint32_t(kCap) && lo != hi) {
-                const uint32_t mid = lo + ((hi - lo) >> 1);
-                const uint32_t c = block_count_le<E, NW>(key, mid, sm, phase);
-                if (c >= k) { hi = mid; ca = c; } else { lo = mid + 1; cb = c; }
-            }
-            const uint32_t need = k - cb;       // how many keys inside [lo,hi] are pruned (1..pop)
-            const uint32_t pop = ca - cb;
-            if (pop <= uint32_t(kCap)) {
-                // exact rank among the <= kCap bracket keys; composite (key<<32 | col) is unique.
-                // Compaction: ballot prefix inside the wave (no atomics), waves own LDS segments.
-                const int wave = tid >> 6, lane = tid & 63;
-                uint32_t base = 0;
+        VLMC_STAMP(2);
+        // ---- 2b. radix-64 bracket refinement ------------------------------------------------------
+        // invariant: cb = count(key < lo) < k <= count(key < lo + 64*2^shift)
+        uint32_t need = 0, pop = 0;
+        for (;;) {
+            if (tid < kBins) sm.hist[tid] = 0;
+            uint32_t below = 0, below2 = 0;
+            if (guessed) {
 #pragma unroll
-                for (int i = 0; i < E; ++i) {
-                    const bool inb = key[i] >= lo && key[i] <= hi;
-                    const unsigned long long b = __ballot(inb);
-                    if (b) {
-                        if (inb) {
-                            const uint32_t pos = base + uint32_t(__popcll(b & ((1ull << lane) - 1ull)));
-                            const uint32_t col = uint32_t((i / 8) * NT * 8 + (i % 8)) + tid8;
-                            sm.seg[wave * kCap + pos] = (static_cast<unsigned long long>(key[i]) << 32) | col;
-                        }
-                        base += uint32_t(__popcll(b));
-                    }
+                for (int i = 0; i < E; i += 2) {
+                    below += (key[i] < lo) ? 1u : 0u;
+                    below2 += (key[i + 1] < lo) ? 1u : 0u;
                 }
                 if constexpr (NW > 1) {
-                    if (lane == 0) sm.segcnt[wave] = base;
-                    lds_barrier();
-                    if (tid < int(pop)) {          // gather the segments into one dense list
-                        uint32_t t = uint32_t(tid);
-                        int w = 0;
-                        for (; w < NW - 1; ++w) {
-                            const uint32_t c = sm.segcnt[w];
-                            if (t < c) break;
-                            t -= c;
-                        }
-                        sm.cand[tid] = sm.seg[w * kCap + t];
-                    }
+                    const uint32_t wsum = wave_sum_u32_dpp(below + below2);
+                    if (lane == 0) sm.below[wave] = wsum;
                 }
-                lds_barrier();
-                if (tid < kWave) {
-                    const unsigned long long *list = NW > 1 ? sm.cand : sm.seg;
-                    const unsigned long long mine = tid < int(pop) ? list[tid] : ~0ull;
-                    uint32_t rank = 0;
-#pragma unroll
-                    for (int j = 0; j < kCap; ++j) {
-                        const unsigned long long other = list[j];            // wave-uniform address: broadcast
-                        rank += (uint32_t(j) < pop && other < mine) ? 1u : 0u;
-                    }
-                    if (tid < int(pop) && rank == need - 1) sm.cut = mine;
-                }
-                lds_barrier();
-                cut = sm.cut;
-            } else {
-                // lo == hi: more than kCap keys tie at the threshold value -> take the first `need`
-                // of them in column order (stable sort semantics).
-                uint32_t running = 0;
-                if constexpr (NW > 1) lds_barrier();
-#pragma unroll
-                for (int s = 0; s < CH; ++s) {
-                    uint32_t cnt = 0;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) cnt += (key[s * 8 + j] == lo) ? 1u : 0u;
-                    uint32_t incl = wave_incl_scan_u32(cnt);
-                    uint32_t total = __shfl(incl, 63, kWave);
-                    if constexpr (NW > 1) {
-                        const int wave = tid >> 6;
-                        if ((tid & 63) == 63) sm.scan[wave] = incl;
-                        lds_barrier();
-                        uint32_t before = 0, all = 0;
-#pragma unroll
-                        for (int w = 0; w < NW; ++w) {
-                            const uint32_t v = sm.scan[w];
-                            before += (w < wave) ? v : 0u;
-                            all += v;
-                        }
-                        incl += before;
-                        total = all;
-                        lds_barrier();
-                    }
-                    const uint32_t excl = incl - cnt;
-                    if (running + excl < need && need <= running + incl) {
-                        uint32_t target = need - running - excl;   // 1-based among this lane's equal keys
-                        uint32_t colsel = 0;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            if (key[s * 8 + j] == lo) {
-                                if (--target == 0) colsel = uint32_t(s * NT * 8 + j) + tid8;
-                            }
-                        }
-                        sm.cut = (static_cast<unsigned long long>(lo) << 32) | colsel;
-                    }
-                    running += total;
-                }
-                lds_barrier();
-                cut = sm.cut;
             }
-            have_prev = true;
-            prev_key = uint32_t(cut >> 32);
-        }
-
-        // ---- apply -----------------------------------------------------------------------
-        uint8_t *mrow = mask + row * in_f;
-        const uint32_t cut_key = uint32_t(cut >> 32), cut_col = uint32_t(cut);
+            if constexpr (NW > 1) lds_barrier();          // bins cleared before anybody adds
+            // bin = (key - lo) >> shift; anything outside the bracket (including wrapped key < lo)
+            // is >= 64 and lands in this thread's private sink slot
 #pragma unroll
-        for (int s = 0; s < CH; ++s) {
-            if (!valid[s]) continue;
-            const uint32_t c0 = uint32_t(s * NT * 8) + tid8;
-            // column test `c0 + j <= cut_col` as `j <= rel`: keeps per-key column indices out of registers
-            const int rel = (cut_col >= c0) ? int(cut_col - c0 > 8u ? 8u : cut_col - c0) : -1;
-            uint32_t keepbits = 0;
+            for (int i = 0; i < E; i += 4) {
+                uint32_t a0 = (key[i] - lo) >> shift, a1 = (key[i + 1] - lo) >> shift;
+                uint32_t a2 = (key[i + 2] - lo) >> shift, a3 = (key[i + 3] - lo) >> shift;
+                a0 = min(a0, sink); a1 = min(a1, sink); a2 = min(a2, sink); a3 = min(a3, sink);
+                atomicAdd(&sm.hist[a0], 1u); atomicAdd(&sm.hist[a1], 1u);
+                atomicAdd(&sm.hist[a2], 1u); atomicAdd(&sm.hist[a3], 1u);
+            }
+            row_sync<NW>();
+            if (guessed) {
+                if constexpr (NW > 1) {
+                    cb = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) cb += sm.below[w];
+                } else {
+                    cb = wave_sum_u32_dpp(below + below2);
+                }
+            }
+            const uint32_t h = sm.hist[lane];                        // every wave scans the 64 bins itself
+            const uint32_t incl = wave_incl_scan_u32_dpp(h);
+            const unsigned long long hit = __ballot(cb + incl >= k);
+            if constexpr (NW > 1) lds_barrier();                     // bins read before the next sweep clears them
+            if (guessed) {
+                guessed = false;
+                if (cb >= k || hit == 0) {                          // wrong guess: start over on the full range
+                    lo = 0; cb = 0; shift = 26;
+                    continue;
+                }
+            }
+            const int b = __builtin_ctzll(hit);                     // bin that holds rank k
+            const uint32_t incl_b = uint32_t(__builtin_amdgcn_readlane(int(incl), b));
+            pop = uint32_t(__builtin_amdgcn_readlane(int(h), b));
+            cb += incl_b - pop;
+            need = k - cb;                                           // 1..pop
+            lo += uint32_t(b) << shift;
+            if (need == pop || shift == 0) break;
+            shift = shift >= 6 ? shift - 6 : 0;
+        }
+        VLMC_STAMP(3);
+        // bracket is now [lo, lo + 2^shift): all `pop` keys inside it are pruned, or shift == 0
+        // and `need` of the `pop` keys equal to lo are pruned (first by column).
+        cut_key = lo + ((1u << shift) - 1u);
+        if (need == pop) {
+            cut_col = 0xFFFFFFFFu;
+        } else {
+            // columns grow with (slot, thread, j): ordered count of the keys equal to lo
+            uint32_t running = 0;
+#pragma unroll
+            for (int s = 0; s < CH; ++s) {
+                uint32_t cnt = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cnt += (key[s * 8 + j] == lo) ? 1u : 0u;
+                uint32_t incl = wave_incl_scan_u32_dpp(cnt);
+                uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+                if constexpr (NW > 1) {
+                    if (lane == 63) sm.scan[wave] = incl;
+                    lds_barrier();
+                    uint32_t before = 0, all = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        const uint32_t t = sm.scan[w];
+                        before += (w < wave) ? t : 0u;
+                        all += t;
+                    }
+                    incl += before;
+                    total = all;
+                    lds_barrier();
+                }
+                const uint32_t excl = incl - cnt;
+                if (running + excl < need && need <= running + incl) {
+                    uint32_t target = need - running - excl;
+                    uint32_t colsel = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (key[s * 8 + j] == lo && --target == 0) colsel = uint32_t(s * NT * 8 + j) + tid8;
+                    sm.cut_col = colsel;
+                }
+                running += total;
+            }
+            row_sync<NW>();
+            cut_col = sm.cut_col;
+        }
+    }
+    VLMC_STAMP(4);
+
+    // ---- 3. apply -------------------------------------------------------------------------------
+    uint8_t *mrow = mask + row * in_f;
+#pragma unroll
+    for (int s = 0; s < CH; ++s) {
+        if (!valid[s]) continue;
+        const uint32_t c0 = uint32_t(s * NT * 8) + tid8;
+        uint32_t keepbits = 0;
+        if (k == 0) {
+            keepbits = 0xFFu;
+        } else if (cut_key < 0xFFFFFFFFu && !(c0 <= cut_col && cut_col < c0 + 7u)) {
+            // whole chunk on one side of the tie column: one compare per key
+            const uint32_t t = cut_key + ((c0 + 7u <= cut_col) ? 1u : 0u);    // prune key < t
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool keep = key[s * 8 + j] >= t;
+                keepbits |= (keep ? 1u : 0u) << j;
+                raw[s].v[j] = keep ? raw[s].v[j] : typename T::raw(0);
+            }
+        } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const uint32_t kk = key[s * 8 + j];
-                // (key, col) <= (cut_key, cut_col) in lexicographic order
-                const bool pruned = (k > 0) && (kk < cut_key || (kk == cut_key && rel >= j));
-                keepbits |= (pruned ? 0u : 1u) << j;
-                if (pruned) raw[s].v[j] = typename T::raw(0);
+                const bool keep = !(kk < cut_key || (kk == cut_key && c0 + uint32_t(j) <= cut_col));
+                keepbits |= (keep ? 1u : 0u) << j;
+                raw[s].v[j] = keep ? raw[s].v[j] : typename T::raw(0);
             }
-            store_mask_chunk<ALIGNED>(mrow, c0, in_f, keepbits);
-            if (apply_zero && keepbits != 0xFFu) store_row_chunk<T, ALIGNED>(wrow, c0, in_f, raw[s]);
         }
-
-        // ---- row score sum (importance_score numerator) ------------------------------------
-        if (row_sums) {
-            double d = double(wave_sum_f32_dpp(fsum));
-            if constexpr (NW > 1) {
-                const int wave = tid >> 6;
-                if ((tid & 63) == 0) sm.dsum[wave] = d;
-                lds_barrier();
-                d = 0.0;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) d += sm.dsum[w];
-            }
-            if (tid == 0) row_sums[row] = d;
-        }
-        if constexpr (NW > 1) lds_barrier();   // smem reuse by the next row
+        store_mask_chunk<ALIGNED>(mrow, c0, in_f, keepbits);
+        if (apply_zero && keepbits != 0xFFu) store_row_chunk<T, ALIGNED>(wrow, c0, in_f, raw[s]);
     }
+    VLMC_STAMP(5);
+#ifndef VLMC_STAMPS
+    if (row_sums) {
+        const float tot = wave_sum_f32_dpp(fsum);
+        if constexpr (NW > 1) {
+            if (lane == 0) sm.fsum[wave] = tot;
+            lds_barrier();
+            if (tid == 0) {
+                double d = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) d += double(sm.fsum[w]);
+                row_sums[row] = d;
+            }
+        } else {
+            if (lane == 0) row_sums[row] = double(tot);
+        }
+    }
+#else
+    if (tid == 0 && row_sums) {
+        for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(row_sums) + i, stamp_acc[i]);
+        atomicAdd(reinterpret_cast<unsigned long long *>(row_sums) + 8, 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -673,32 +681,35 @@ static int env_int(const char *name, int dflt) {
 template <typename T, int CH, int NW, bool ALIGNED>
 static void launch_rows(void *W, int64_t out_f, int64_t in_f, int64_t ldw, const float *sqrt_scaler, uint32_t k,
                         int apply_zero, uint8_t *mask, double *row_sums, hipStream_t st) {
-    // persistent grid: ~16 waves per CU, every workgroup walks the same number of rows (+-1)
-    const int waves_per_cu = env_int("VLMC_SELECT_WAVES_PER_CU", 16);
-    int64_t max_grid = int64_t(256) * waves_per_cu / NW;
-    if (max_grid < 1) max_grid = 1;
-    const int64_t rows_per_wg = (out_f + max_grid - 1) / max_grid;
-    const int64_t grid = (out_f + rows_per_wg - 1) / rows_per_wg;
-    hipLaunchKernelGGL((select_rows_kernel<T, CH, NW, ALIGNED>), dim3(unsigned(grid)), dim3(64 * NW), 0, st,
-                       static_cast<typename T::raw *>(W), out_f, in_f, ldw, sqrt_scaler, k, apply_zero, mask, row_sums);
+    const uint32_t margin = uint32_t(env_int("VLMC_SELECT_SAMPLE_MARGIN", 9));   // ~ +-3 sigma of a 32-sample rank
+    const uint32_t frac_q16 = uint32_t((uint64_t(k) << 16) / uint64_t(in_f));
+    hipLaunchKernelGGL((select_rows_kernel<T, CH, NW, ALIGNED>), dim3(unsigned(out_f)), dim3(64 * NW), 0, st,
+                       static_cast<typename T::raw *>(W), out_f, in_f, ldw, sqrt_scaler, k, apply_zero, mask, row_sums,
+                       margin, frac_q16);
 }
 
+// (NW waves) x (CH chunks of 8 columns per lane) must cover the row: 64*NW*CH >= in/8.
+// Few rows -> more waves per row (parallelism); many rows -> one wave per row (no barriers).
 template <typename T>
 static int dispatch_rows(void *W, int64_t out_f, int64_t in_f, int64_t ldw, const float *sqrt_scaler, uint32_t k, int apply_zero,
                          uint8_t *mask, double *row_sums, bool aligned, hipStream_t st) {
     const int64_t nchunks = (in_f + 7) / 8;
+    if (nchunks > 2048) {
+        set_error("vlmc_wanda_select: in_features %lld too large (max 16384)", (long long)in_f);
+        return VLMC_EINVAL;
+    }
 #define VLMC_ROWS(CH, NW, AL) launch_rows<T, CH, NW, AL>(W, out_f, in_f, ldw, sqrt_scaler, k, apply_zero, mask, row_sums, st)
     if (!aligned) {
         if (nchunks <= 256) VLMC_ROWS(4, 1, false);
-        else if (nchunks <= 2048) VLMC_ROWS(4, 8, false);
-        else { set_error("vlmc_wanda_select: in_features %lld too large (max 16384)", (long long)in_f); return VLMC_EINVAL; }
+        else VLMC_ROWS(4, 8, false);
         return VLMC_OK;
     }
     int nw = 1;
-    while (nw < 8 && nchunks > int64_t(64) * nw * 4) nw *= 2;
-    if (nchunks > int64_t(64) * nw * 4) {
-        set_error("vlmc_wanda_select: in_features %lld too large (max 16384)", (long long)in_f);
-        return VLMC_EINVAL;
+    while (nw < 8 && nchunks > int64_t(64) * nw * 4) nw *= 2;               // CH <= 4
+    const int64_t want_waves = env_int("VLMC_SELECT_WANT_WAVES", 4096);      // ~4 waves per SIMD
+    while (nw < 8 && out_f * nw < want_waves && nchunks > int64_t(64) * nw) nw *= 2;
+    if (const int f = env_int("VLMC_SELECT_NW", 0)) {
+        if ((f == 1 || f == 2 || f == 4 || f == 8) && nchunks <= int64_t(64) * f * 4) nw = f;
     }
     const int ch = int((nchunks + 64 * nw - 1) / (64 * nw));
 #define VLMC_ROWS_NW(NW)                          \
