@@ -1,0 +1,103 @@
+"""CPU, world_size 2, gloo: the multi-GPU statistics exchange (vlmc.wanda.gather_stats) and the
+sample-sharded calibration of the drop-in pruner give bit-identical results to a single process.
+
+The numeric ops are the oracle-backed stand-ins (tests/oracle_ops.py); what is under test is the
+sharding/collective logic that runs unchanged on RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup(rank, world, port):
+    for p in (ROOT, os.path.join(ROOT, "vlm-compression_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_ops
+    from vlmc import ops
+
+    class MP:
+        @staticmethod
+        def setattr(obj, name, val):
+            setattr(obj, name, val)
+    oracle_ops.install(MP)
+    return ops
+
+
+def _worker_gather(rank, world, port, out_dir):
+    _setup(rank, world, port)
+    from vlmc import wanda
+    g = torch.Generator().manual_seed(123)
+    xs_a = [(torch.randn(1, 7, 48, generator=g) + 0.1).to(torch.bfloat16) for _ in range(8)]
+    xs_b = [(torch.randn(1, 5, 80, generator=g) * 2).to(torch.float32) for _ in range(8)]
+    n_local = 8 // world
+    stats = []
+    for xs in (xs_a, xs_b):
+        st = wanda.InputStat(xs[0].shape[-1], "cpu")
+        for x in xs[rank * n_local:(rank + 1) * n_local]:          # this rank's contiguous share
+            st.add_call(x)
+        stats.append(st)
+    wanda.gather_stats(stats)
+    np.savez(os.path.join(out_dir, f"gather_{rank}.npz"), a=stats[0].scaler_row.numpy(), b=stats[1].scaler_row.numpy(),
+             na=stats[0].nsamples, nb=stats[1].nsamples)
+    dist.destroy_process_group()
+
+
+def _worker_pruner(rank, world, port, out_dir):
+    _setup(rank, world, port)
+    import pruner_helpers as H
+    pruned, _ = H.run_pruner("fp32_r50", "cpu")
+    torch.save({k: v for k, v in pruned.state_dict().items()}, os.path.join(out_dir, f"pruned_{rank}.pt"))
+    masks = {n: m.mask.clone() for n, m in pruned.named_modules() if hasattr(m, "mask")}
+    torch.save(masks, os.path.join(out_dir, f"masks_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gather_stats_world2_equals_single_process(tmp_path):
+    from oracle import wanda as OW
+    port = _free_port()
+    mp.spawn(_worker_gather, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g = torch.Generator().manual_seed(123)
+    xs_a = [(torch.randn(1, 7, 48, generator=g) + 0.1).to(torch.bfloat16) for _ in range(8)]
+    xs_b = [(torch.randn(1, 5, 80, generator=g) * 2).to(torch.float32) for _ in range(8)]
+    want_a, want_b = OW.wanda_stats(xs_a), OW.wanda_stats(xs_b)
+    for r in range(2):
+        z = np.load(tmp_path / f"gather_{r}.npz")
+        assert int(z["na"]) == 8 and int(z["nb"]) == 8
+        assert np.array_equal(z["a"].view(np.uint32), want_a.view(np.uint32))
+        assert np.array_equal(z["b"].view(np.uint32), want_b.view(np.uint32))
+
+
+@pytest.mark.timeout(600)
+def test_sample_sharded_pruner_world2_matches_reference_golden(tmp_path):
+    """6 calibration samples over 2 ranks: every rank ends with the reference's masks and weights."""
+    import pruner_helpers as H
+    port = _free_port()
+    mp.spawn(_worker_pruner, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    G = H.golden()
+    for r in range(2):
+        sd = torch.load(tmp_path / f"pruned_{r}.pt")
+        for key in [k for k in G if k.startswith("fp32_r50/sd/")]:
+            assert torch.equal(sd[key[len("fp32_r50/sd/"):]], G[key]), (r, key)
+        masks = torch.load(tmp_path / f"masks_{r}.pt")
+        for mn, m in masks.items():
+            assert torch.equal(m, G[f"fp32_r50/mask/{mn}"]), (r, mn)

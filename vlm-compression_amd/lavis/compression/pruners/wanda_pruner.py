@@ -195,7 +195,8 @@ class T5LayerWandaPruner(LayerWiseBasePruner, _WandaBlockMixin):
         with torch.no_grad():
             inps, outs, caches = self.prepare_calibration_input_encoder(model, dataloader, model_prefix, n_samples,
                                                                         module_to_process, lora_model)
-        n_inps, batch0 = len(inps), inps[0].shape[0]
+        # under calibration sharding every rank holds 1/world of the samples; statistics are global
+        n_inps, batch0 = len(inps) * cal.calibration_shard()[1], inps[0].shape[0]
 
         def prune_block(i, layer, subset, run_pass, state):
             self._wanda_block(i, subset, run_pass, n_inps, batch0, unstructured_mode="row",
@@ -245,7 +246,8 @@ class VITLayerWandaPruner(LayerWiseBasePruner, _WandaBlockMixin):
         with torch.no_grad():
             inps, outs, caches = self.prepare_calibration_input_encoder(model, dataloader, model_prefix, n_samples,
                                                                         module_to_process, lora_model)
-        n_inps, batch0 = len(inps), inps[0].shape[0]
+        # under calibration sharding every rank holds 1/world of the samples; statistics are global
+        n_inps, batch0 = len(inps) * cal.calibration_shard()[1], inps[0].shape[0]
 
         def prune_block(i, layer, subset, run_pass, state):
             self._wanda_block(i, subset, run_pass, n_inps, batch0, unstructured_mode="matrix",
