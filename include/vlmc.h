@@ -94,6 +94,37 @@ int vlmc_wanda_select(void *W, int dtype, int64_t out_features, int64_t in_featu
                       uint8_t *mask /* [out, in] */, double *score_partials /* device */, void *workspace,
                       size_t workspace_bytes, void *stream);
 
+/* ---- K14-K16: SparseLoRA --------------------------------------------------------------
+ * Replaces the tensor algebra of lavis/peft/src/peft/tuners/lora.py:359-394.
+ * A = lora_A.weight [r, in] fp32, B = lora_B.weight [out, r] fp32, M = mask, s = alpha/r.
+ * The rank-r contraction runs on the matrix cores (f32-input MFMA), the [out,in] delta is
+ * never written to memory.
+ *
+ * vlmc_lora_effective_weight: W_out (may alias W) =
+ *   VLMC_LORA_FWD_SPARSE   wd(W + d2) * M,  d2 = wd(wd(B@A) * s)        (forward, sparse=True,  :362-368)
+ *   VLMC_LORA_FWD_MASKED   wd(W * M + d2)                               (forward, sparse=False, :369-375)
+ *   VLMC_LORA_MERGE_SPARSE wd(W + (s*(B@A)) * M)                        (merge(), sparse=True,  :385-387)
+ *   VLMC_LORA_MERGE_MASKED wd(W * M + s*(B@A))                          (merge(), sparse=False, :388-391)
+ * wd() = rounding to the weight dtype, i.e. exactly the reference's chain of tensor ops;
+ * autocast = dtype code of an active torch.autocast (0 none, VLMC_F16, VLMC_BF16): A, B and
+ * B@A are rounded to it like the reference's autocast matmul does.                       */
+#define VLMC_LORA_FWD_SPARSE 0
+#define VLMC_LORA_FWD_MASKED 1
+#define VLMC_LORA_MERGE_SPARSE 2
+#define VLMC_LORA_MERGE_MASKED 3
+int vlmc_lora_effective_weight(const void *W, int dtype, int64_t out_features, int64_t in_features, int64_t ldw,
+                               const float *A, const float *B, int r, float scaling, const uint8_t *mask, int mode,
+                               int autocast, void *W_out, int64_t ldo, void *stream);
+
+/* Gradients of the adapters from G = dL/dW_eff ([out,in], weight dtype; the library GEMM dY^T x):
+ *   Gm = wd((sparse ? G . M : G) * s), then rounded to the autocast dtype (as the reference's autograd)
+ *   dB[out, r] = Gm @ A^T,  dA[r, in] = B^T @ Gm     (fp32 accumulate; rounded to the autocast dtype)
+ * dA or dB may be NULL.  dA needs a workspace of vlmc_lora_grad_workspace() bytes.               */
+size_t vlmc_lora_grad_workspace(int64_t out_features, int64_t in_features, int r);
+int vlmc_lora_grad(const void *G, int dtype, int64_t out_features, int64_t in_features, int64_t ldg, const float *A,
+                   const float *B, int r, float scaling, const uint8_t *mask, int sparse, int autocast, float *dA,
+                   float *dB, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

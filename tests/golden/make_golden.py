@@ -257,7 +257,65 @@ def gen_wanda_e2e():
     print("wanda_e2e.npz:", len(out), "arrays")
 
 
-GROUPS = {"wanda": gen_wanda, "wanda_e2e": gen_wanda_e2e}
+def gen_sparse_lora():
+    """G7: the reference's SparseLoRA Linear -- forward (dense / sparse=True / sparse=False), the
+    weight it hands to F.linear (captured by wrapping F.linear), grads of x, A, B, and merge()."""
+    import contextlib
+    from lavis.peft.src.peft.tuners import lora as RL
+    out = {}
+    in_f, out_f, r, alpha = 96, 80, 4, 16
+    g = torch.Generator().manual_seed(77)
+    base_W = torch.randn(out_f, in_f, generator=g) * 0.05
+    base_b = torch.randn(out_f, generator=g) * 0.01
+    A0 = torch.randn(r, in_f, generator=g) * 0.1
+    B0 = torch.randn(out_f, r, generator=g) * 0.1
+    M0 = torch.rand(out_f, in_f, generator=g) > 0.5
+    X0 = torch.randn(2, 5, in_f, generator=g)
+    GY = torch.randn(2, 5, out_f, generator=g)
+    out.update({"W": base_W, "b": base_b, "A": A0, "B": B0, "M": M0, "X": X0, "GY": GY, "r": r, "alpha": alpha})
+    cases = {"fp32": (torch.float32, None), "bf16": (torch.bfloat16, None), "bf16_autocast": (torch.bfloat16, torch.bfloat16),
+             "fp32_autocast_bf16": (torch.float32, torch.bfloat16)}
+    for cname, (wd, ac) in cases.items():
+        for sparse in (True, False):
+            lin = RL.Linear(in_f, out_f, r=r, lora_alpha=alpha, bias=True)
+            with torch.no_grad():
+                lin.weight.copy_(base_W); lin.bias.copy_(base_b)
+                lin.lora_A.weight.copy_(A0); lin.lora_B.weight.copy_(B0)
+            lin.weight.data = lin.weight.data.to(wd)
+            lin.bias.data = lin.bias.data.to(wd)
+            lin.mask = M0.clone()
+            lin.sparse = sparse
+            captured = {}
+            real_linear = RL.F.linear
+
+            def spy(x, w, bias=None):
+                captured["w"] = w.detach().clone()
+                return real_linear(x, w, bias)
+            RL.F.linear = spy
+            ctx = torch.autocast("cpu", dtype=ac) if ac is not None else contextlib.nullcontext()
+            x = X0.to(wd if ac is None else torch.float32).clone().requires_grad_(True)
+            with ctx:
+                y = lin(x)
+            RL.F.linear = real_linear
+            y.backward(GY.to(y.dtype))
+            key = f"{cname}/sparse{int(sparse)}"
+            out.update({f"{key}/y": y.detach(), f"{key}/weff": captured["w"], f"{key}/gx": x.grad,
+                        f"{key}/gA": lin.lora_A.weight.grad, f"{key}/gB": lin.lora_B.weight.grad})
+            if ac is None:
+                with torch.no_grad():
+                    yd = lin(X0.to(wd), dense=True)
+                out[f"{key}/y_dense"] = yd
+                lin.merge()
+                out[f"{key}/merged"] = lin.weight.data.clone()
+                out[f"{key}/A_after_merge_is_reinit"] = int(not torch.equal(lin.lora_A.weight.data, A0))
+                out[f"{key}/B_after_merge_is_zero"] = int(bool((lin.lora_B.weight.data == 0).all()))
+        lin = RL.Linear(in_f, out_f, r=r, lora_alpha=alpha, bias=True)
+        out["state_dict_keys"] = np.array(sorted(lin.state_dict().keys()))
+    golden_io.save("sparse_lora", out)
+    print("sparse_lora.npz:", len(out), "arrays")
+
+
+GROUPS = {"wanda": gen_wanda, "wanda_e2e": gen_wanda_e2e, "sparse_lora": gen_sparse_lora}
 
 if __name__ == "__main__":
     import_reference()

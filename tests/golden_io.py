@@ -30,6 +30,8 @@ def unpack(npz) -> dict:
         a = npz[k]
         if k.endswith("::bf16"):
             out[k[:-6]] = torch.from_numpy(a.copy()).view(torch.bfloat16)
+        elif a.dtype.kind in "US":
+            out[k] = a
         elif a.dtype.kind in "fiub" and a.ndim > 0:
             out[k] = torch.from_numpy(a.copy())
         else:

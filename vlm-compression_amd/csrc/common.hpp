@@ -110,6 +110,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+__device__ __forceinline__ bool aligned16_dev(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace vlmc
