@@ -125,6 +125,23 @@ int vlmc_lora_grad(const void *G, int dtype, int64_t out_features, int64_t in_fe
                    const float *B, int r, float scaling, const uint8_t *mask, int sparse, int autocast, float *dA,
                    float *dB, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- K10: SparseGPT blocked OBS sweep ----------------------------------------------------
+ * Replaces the per-column Python loop of sparsegpt_pruner.py:186-205 for ONE block of
+ * `count` <= 128 columns (fp32 working copy W, pointer at the block's first column):
+ *     for i in 0..count-1:
+ *         [n:m: if i % m == 0: prune the n smallest w^2/U[j,j]^2 of columns i..i+m-1, ties ->
+ *          lowest column, evaluated on the compensated weights]
+ *         q = pruned(i) ? 0 : w[:, i];  err = (w[:, i] - q) / U1[i, i];  w[:, i:] -= err (x) U1[i, i:]
+ *     W[:, block] = Q;  Err1 = the err columns
+ * U1 = the block of the upper Cholesky factor of H^-1 (`Hinv1`), mask1 = the block's
+ * unstructured mask (1 = prune; sparsegpt_pruner.py:180-185; ignored for n:m), mask_out
+ * (optional) receives the final pruned mask of the block.  Elementwise IEEE fp32 in the
+ * reference's operation order: bit-exact given the same factor.  The caller applies the
+ * trailing update W[:, i2:] -= Err1 @ U[i1:i2, i2:] (:210) with a library GEMM.            */
+int vlmc_sparsegpt_sweep(float *W, int64_t out_features, int64_t count, int64_t ldw, const float *U1, int64_t ldu,
+                         const uint8_t *mask1, int64_t ldm, int prune_n, int prune_m, float *Err1, int64_t lde,
+                         uint8_t *mask_out, int64_t ldmo, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

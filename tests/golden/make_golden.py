@@ -315,7 +315,68 @@ def gen_sparse_lora():
     print("sparse_lora.npz:", len(out), "arrays")
 
 
-GROUPS = {"wanda": gen_wanda, "wanda_e2e": gen_wanda_e2e, "sparse_lora": gen_sparse_lora}
+def gen_sparsegpt():
+    """G5: the reference's SparseGPT class -- Hessian after add_batch, fasterprune() for
+    unstructured 0.5 / 0.3 and 2:4 / 4:8 on [32,256] (two 128-column blocks), a dead input
+    channel, and a rank-deficient Hessian that exercises the damping loop."""
+    from lavis.compression.pruners import sparsegpt_pruner as RS
+    out = {}
+    # 6 samples x 48 tokens = 288 > 256 columns: positive definite Hessians, except `rankdef`
+    cases = [("fp32_u50", torch.float32, 0.5, 0, 0, 48, False), ("bf16_u30", torch.bfloat16, 0.3, 0, 0, 48, False),
+             ("fp32_2_4", torch.float32, 0.5, 2, 4, 48, False), ("fp16_4_8", torch.float16, 0.5, 4, 8, 48, False),
+             ("fp32_dead", torch.float32, 0.5, 0, 0, 48, True), ("fp32_rankdef", torch.float32, 0.5, 0, 0, 3, False)]
+    for i, (name, dt, sparsity, n, m, T, dead) in enumerate(cases):
+        g = torch.Generator().manual_seed(900 + i)
+        lin = nn.Linear(256, 32, bias=False)
+        W = (torch.randn(32, 256, generator=g) * 0.05).to(dt)
+        lin.weight.data = W.clone()
+        sg = RS.SparseGPT(lin)
+        xs = []
+        for j in range(6):
+            # activations are fp16-representable so that the fixture stores them in 2 bytes
+            x = ((torch.randn(1, T, 256, generator=g) + 0.1) * (1 + 0.2 * j)).half().to(dt)
+            if dead:
+                x[..., 17] = 0
+                x[..., 200] = 0
+            xs.append(x if dt != torch.float32 else x.half())
+            sg.add_batch(x, None)
+        if name in ("fp32_u50", "fp32_rankdef"):          # the others are re-derived (and verified) by the oracle
+            out[f"{name}/H"] = sg.H.clone()
+        out[f"{name}/W"] = W
+        out[f"{name}/xs"] = torch.cat(xs)
+        sg.fasterprune(sparsity, prune_n=n, prune_m=m, percdamp=0.01, blocksize=128)
+        out[f"{name}/Wn"] = lin.weight.data.clone()
+        out[f"{name}/imp"] = float(lin.weight.importance_score)
+        out[f"{name}/sparsity"] = sparsity
+        out[f"{name}/n"] = n
+        out[f"{name}/m"] = m
+    golden_io.save("sparsegpt", out)
+    print("sparsegpt.npz:", len(out), "arrays")
+
+
+def gen_sparsegpt_e2e():
+    """Whole-pruner run of the reference's blipt5_sparsegpt_pruner on the toy InstructBLIP."""
+    from lavis.compression.pruners import sparsegpt_pruner as RS
+    out = {}
+    for name, v in {"fp32_u50": dict(ratio=0.5, n=0, m=0), "fp32_2_4": dict(ratio=0.5, n=2, m=4)}.items():
+        model = toy_models.init_toy(toy_models.ToyBlipT5(), seed=7).eval()
+        batches = toy_models.make_batches(6, seed=11)
+        spec = "2-%r-1.0-1.0" % (1 - v["ratio"])
+        pr = RS.BLIPT5LayerSparseGPTPruner(model=model, data_loader=batches, t5_prune_spec=spec, vit_prune_spec=spec,
+                                           t5_pruning_method="sparsegpt", vit_pruning_method="sparsegpt", num_samples=6,
+                                           prune_n=v["n"], prune_m=v["m"], max_sparsity_per_layer=1.01)
+        pruned, _ = pr.prune()
+        for k_, t in pruned.state_dict().items():
+            out[f"{name}/sd/{k_}"] = t
+        for mn, mod in pruned.named_modules():
+            if hasattr(mod, "weight") and hasattr(mod.weight, "importance_score"):
+                out[f"{name}/imp/{mn}"] = float(mod.weight.importance_score)
+    golden_io.save("sparsegpt_e2e", out)
+    print("sparsegpt_e2e.npz:", len(out), "arrays")
+
+
+GROUPS = {"wanda": gen_wanda, "wanda_e2e": gen_wanda_e2e, "sparse_lora": gen_sparse_lora, "sparsegpt": gen_sparsegpt,
+          "sparsegpt_e2e": gen_sparsegpt_e2e}
 
 if __name__ == "__main__":
     import_reference()

@@ -72,3 +72,34 @@ def install(monkeypatch):
     from vlmc import ops
     for name in ("act_sqnorm", "wanda_scaler_update", "sqrt_scaler", "select_partials", "wanda_select"):
         monkeypatch.setattr(ops, name, globals()[name])
+
+
+# ---- SparseGPT stand-ins (for vlmc.sparsegpt) ----------------------------------------------
+class OracleSparseGPT:
+    def __init__(self, layer):
+        from oracle import sparsegpt as OS
+        self._os = OS
+        self.layer = layer
+        self.rows, self.columns = layer.weight.shape
+        self.H = torch.zeros((self.columns, self.columns))
+        self.nsamples = 0
+
+    def add_batch(self, inp, out=None):
+        self.nsamples = self._os.hessian_update(self.H, self.nsamples, inp)
+
+    def free(self):
+        self.H = None
+
+
+def oracle_fasterprune(layer, H, sparsity, prune_n=0, prune_m=0, blocksize=128, percdamp=0.01, return_mask=False):
+    from oracle import sparsegpt as OS
+    Wn, imp, pruned = OS.prune(layer.weight.data, H, sparsity, prune_n, prune_m, blocksize, percdamp)
+    setattr(layer.weight, "importance_score", imp)
+    layer.weight.data = Wn
+    return pruned if return_mask else None
+
+
+def install_sparsegpt(monkeypatch):
+    from vlmc import sparsegpt
+    monkeypatch.setattr(sparsegpt, "SparseGPT", OracleSparseGPT)
+    monkeypatch.setattr(sparsegpt, "fasterprune", oracle_fasterprune)

@@ -62,3 +62,32 @@ def test_pruner_is_deterministic_on_gpu():
     b, _ = H.run_pruner("fp32_r50", "cuda:0")
     for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
         assert ka == kb and torch.equal(va, vb), ka
+
+
+@pytest.mark.parametrize("name", ["fp32_u50", "fp32_2_4"])
+def test_sparsegpt_pruner_on_gpu_tracks_reference_run(name):
+    """Whole blipt5_sparsegpt_pruner on the GPU (library Cholesky/GEMMs + fused sweep kernel) vs the
+    reference's CPU run: same zero pattern up to near-ties, weights close, 2:4 structure exact."""
+    import golden_io
+    import test_pruner_host_logic as T
+    E = golden_io.load("sparsegpt_e2e")
+    pruned, _ = T._run_sparsegpt_pruner(name, "cuda:0")
+    got = pruned.state_dict()
+    tot = agree = 0
+    num = den = 0.0
+    for key in [k for k in E if k.startswith(f"{name}/sd/")]:
+        k = key[len(name) + 4:]
+        ref = E[key]
+        g = got[k].cpu()
+        if ref.dim() != 2 or ".block" not in k or "shared" in k:
+            continue
+        same = (g == 0) == (ref == 0)
+        tot += same.numel()
+        agree += int(same.sum())
+        clean = same.all(dim=1)
+        num += float((g[clean] - ref[clean]).pow(2).sum())
+        den += float(ref[clean].pow(2).sum())
+        if name == "fp32_2_4" and ("blocks." in k or "block." in k) and g.shape[1] % 4 == 0 and (g == 0).any():
+            assert bool(((g == 0).view(g.shape[0], -1, 4).sum(-1) >= 2).all()), k
+    assert tot > 0 and agree / tot >= 0.97, agree / tot
+    assert (num / den) ** 0.5 < 2e-2

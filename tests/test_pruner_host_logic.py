@@ -49,3 +49,45 @@ def test_pruner_has_no_cpu_fallback():
     """Without the test stand-ins a CPU model must raise, not silently compute on the host."""
     with pytest.raises(RuntimeError, match="GPU only"):
         H.run_pruner("fp32_r50", "cpu")
+
+
+# ---- SparseGPT pruner host logic ---------------------------------------------------------
+import golden_io  # noqa: E402
+
+SG_E2E = golden_io.load("sparsegpt_e2e")
+
+
+def _run_sparsegpt_pruner(name, device="cpu"):
+    import toy_models
+    from lavis.compression import load_pruner
+    v = {"fp32_u50": dict(ratio=0.5, n=0, m=0), "fp32_2_4": dict(ratio=0.5, n=2, m=4)}[name]
+    model = toy_models.init_toy(toy_models.ToyBlipT5(), seed=7).eval().to(device)
+    batches = [{k: t.to(device) for k, t in b.items()} for b in toy_models.make_batches(6, seed=11)]
+    spec = "2-%r-1.0-1.0" % (1 - v["ratio"])
+    cfg = dict(t5_prune_spec=spec, vit_prune_spec=spec, t5_pruning_method="sparsegpt", vit_pruning_method="sparsegpt",
+               num_samples=6, prune_n=v["n"], prune_m=v["m"], max_sparsity_per_layer=1.01)
+    pruner = load_pruner("blipt5_sparsegpt_pruner", model, batches, cfg=cfg)
+    return pruner.prune()
+
+
+@pytest.mark.parametrize("name", ["fp32_u50", "fp32_2_4"])
+def test_blipt5_sparsegpt_pruner_matches_reference_run(name, monkeypatch):
+    oracle_ops.install_sparsegpt(monkeypatch)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)                      # the goldens' BLAS configuration (see test_oracle_golden.py)
+    try:
+        pruned, sd = _run_sparsegpt_pruner(name)
+    finally:
+        torch.set_num_threads(nthreads)
+    assert sd is None
+    got = pruned.state_dict()
+    n_checked = 0
+    for key in [k for k in SG_E2E if k.startswith(f"{name}/sd/")]:
+        assert torch.equal(got[key[len(name) + 4:]], SG_E2E[key]), key
+        n_checked += 1
+    assert n_checked > 40
+    for mn, mod in pruned.named_modules():
+        ik = f"{name}/imp/{mn}"
+        if ik in SG_E2E:
+            assert mod.weight.importance_score == pytest.approx(float(SG_E2E[ik]), rel=1e-6)
+            assert not hasattr(mod, "mask")       # SparseGPT attaches no mask (sparsegpt_pruner.py:215)

@@ -5,6 +5,9 @@ from lavis.compression.pruners.base_pruner import BasePruner
 from lavis.compression.pruners.wanda_pruner import (  # noqa: F401  (registration)
     BLIPT5LayerWandaPruner, T5LayerWandaPruner, VITLayerWandaPruner,
 )
+from lavis.compression.pruners.sparsegpt_pruner import (  # noqa: F401  (registration)
+    BLIPT5LayerSparseGPTPruner, T5LayerSparseGPTPruner, VITLayerSparseGPTPruner,
+)
 
 __all__ = ["BasePruner"]
 

@@ -80,13 +80,15 @@ def _keys_for(model_prefix):
 
 
 def capture_block_inputs(model, dataloader, n_samples, module_to_process, forward_to_cache, lora_model, *, vit,
-                         model_prefix=None):
+                         model_prefix=None, count_batches=False):
     """Run the model until block 0 of `module_to_process` is reached, for the first
     `n_samples` calibration samples; return (inps, outs, caches) like the reference.
 
     vit=True  -> catcher signature (inp, rel_pos_bias, dense=True)         (:595-608)
     vit=False -> catcher signature (inp, dense=True, **kwargs), caching the
                  family's kwargs (:238-253)
+    count_batches=True reproduces the SparseGPT pruners' stop rule (`i >= n_samples` on the
+    batch index, sparsegpt_pruner.py:391-393) instead of Wanda's sample count.
     """
     layers = get_module_recursive(model, module_to_process)
     keys = None if vit else _keys_for(model_prefix)
@@ -120,7 +122,9 @@ def capture_block_inputs(model, dataloader, n_samples, module_to_process, forwar
         for batch in dataloader:                       # which batches the reference would consume
             if total >= n_samples:
                 break
-            if vit or "image" in batch:
+            if count_batches:
+                total += 1
+            elif vit or "image" in batch:
                 total += batch["image"].shape[0]
             else:
                 total += len(batch["text_input"])

@@ -1,0 +1,183 @@
+"""SparseGPT pruners behind the reference's `lavis.compression` API: `t5_sparsegpt_pruner`,
+`vit_sparsegpt_pruner`, `blipt5_sparsegpt_pruner`
+(reference: lavis/compression/pruners/sparsegpt_pruner.py:222-497, :500-867, :870-1090).
+
+Same registry names, constructor kwargs and `prune(importance_scores=None,
+keep_indices_or_masks=None) -> (model, sparsity_dict | None)` contract (no `lora_model`
+argument, like the reference).  Quirks kept: calibration stops by BATCH index (`i >= n_samples`,
+:391-393), both towers are pruned whenever their spec is not None (no keep-ratio < 1 test,
+:1021,:1044), the LLM branch walks `...model.decoder.layers` (OPT layout, :1084), no `module.mask`
+is attached (SparseGPT only rewrites the weights).  The arithmetic lives in `vlmc.sparsegpt`.
+"""
+from __future__ import annotations
+
+import torch
+
+from lavis.common.registry import registry
+from lavis.compression.pruners import calibration as cal
+from lavis.compression.pruners.layer_single_base_pruner import LayerWiseBasePruner
+from lavis.compression.pruners.utils import print_time
+from lavis.compression.pruners.wanda_pruner import uniform_or_layer_sparsity
+
+_KW = dict(prune_spec=None, importance_scores_cache=None, keep_indices_or_masks_cache=None, is_strct_pruning=False,
+           num_samples=64, is_global=False, sparsity_ratio_granularity=None, max_sparsity_per_layer=0.8,
+           score_method="obd_avg", num_data_first_stage=128, num_noise=1, sparsity_dict=None, noise_eps=1e-3,
+           prune_per_model=False, prune_n=0, prune_m=0)
+
+
+class _SparseGPTBlockMixin:
+    def _capture(self, model, dataloader, n_samples, module_to_process, vit, model_prefix=None):
+        return cal.capture_block_inputs(model, dataloader, n_samples, module_to_process,
+                                        lambda m, b, _lora=False: self.forward_to_cache(m, b), False, vit=vit,
+                                        model_prefix=model_prefix, count_batches=True)
+
+    def _sparsegpt_block(self, i, subset, run_pass, n_inps, module_to_process, sparsity_ratio):
+        from vlmc import sparsegpt
+        wrapped = {name: sparsegpt.SparseGPT(mod) for name, mod in subset.items()}
+        handles = [mod.register_forward_hook(lambda _m, inp, out, name=name: wrapped[name].add_batch(inp[0].data, out.data))
+                   for name, mod in subset.items()]
+        try:
+            run_pass()
+        finally:
+            for h in handles:
+                h.remove()
+        _allreduce_hessians(wrapped)
+        for name, mod in subset.items():
+            assert wrapped[name].nsamples == n_inps                                  # :442
+            key = f"{module_to_process}.{i}.{name}.weight"
+            sparsegpt.fasterprune(mod, wrapped[name].H, sparsity_ratio[key], prune_n=self.prune_n, prune_m=self.prune_m,
+                                  percdamp=0.01, blocksize=128)
+            wrapped[name].free()
+
+
+def _allreduce_hessians(wrapped):
+    """Multi-GPU: every rank accumulated H over its share of the samples; the global running mean
+    is the sample-weighted average.  (Not in the reference, which runs replicas.)"""
+    import torch.distributed as dist
+    rank, world = cal.calibration_shard()
+    if world == 1:
+        return
+    for w in wrapped.values():
+        total = torch.tensor([float(w.nsamples)], device=w.H.device)
+        w.H.mul_(w.nsamples)
+        dist.all_reduce(w.H)
+        dist.all_reduce(total)
+        w.nsamples = int(total.item())
+        w.H.div_(w.nsamples)
+
+
+@registry.register_pruner("t5_sparsegpt_pruner")
+class T5LayerSparseGPTPruner(LayerWiseBasePruner, _SparseGPTBlockMixin):
+    pruner_name = "t5_sparsegpt_pruner"
+
+    def __init__(self, model, data_loader, model_prefix="t5_model", **kwargs):
+        kw = dict(_KW); kw.update({k: v for k, v in kwargs.items() if k in _KW})
+        super().__init__(model=model, data_loader=data_loader, model_prefix=model_prefix, **kw)
+
+    def forward_to_cache(self, model, batch):
+        return model(batch)
+
+    @print_time
+    def _prune(self, model, dataloader, device, model_prefix, module_to_process="encoder.block", n_samples=64,
+               sparsity_ratio=0.5):
+        cfg = getattr(model, model_prefix).config
+        use_cache, cfg.use_cache = cfg.use_cache, False
+        print("loading calibdation data")
+        with torch.no_grad():
+            inps, outs, caches = self._capture(model, dataloader, n_samples, module_to_process, vit=False,
+                                               model_prefix=self.model_prefix)
+        n_inps = len(inps) * cal.calibration_shard()[1]
+
+        def prune_block(i, layer, subset, run_pass, state):
+            self._sparsegpt_block(i, subset, run_pass, n_inps, module_to_process, sparsity_ratio)
+
+        cal.walk_blocks(model, inps, outs, caches, module_to_process, n_samples,
+                        lambda: model.maybe_autocast(dtype=torch.bfloat16), prune_block, tuple_output=True)
+        cfg.use_cache = use_cache
+        torch.cuda.empty_cache()
+        return model
+
+
+@registry.register_pruner("vit_sparsegpt_pruner")
+class VITLayerSparseGPTPruner(LayerWiseBasePruner, _SparseGPTBlockMixin):
+    pruner_name = "vit_sparsegpt_pruner"
+
+    def __init__(self, model, data_loader, model_prefix="visual", **kwargs):
+        kw = dict(_KW); kw.update({k: v for k, v in kwargs.items() if k in _KW})
+        super().__init__(model=model, data_loader=data_loader, model_prefix=model_prefix, **kw)
+
+    def forward_to_cache(self, model, batch):
+        return model.encode_image(batch["image"])
+
+    @print_time
+    def _prune(self, model, dataloader, device, model_prefix, module_to_process="encoder.block", n_samples=64,
+               sparsity_ratio=0.5):
+        with torch.no_grad():
+            inps, outs, caches = self._capture(model, dataloader, n_samples, module_to_process, vit=True)
+        n_inps = len(inps) * cal.calibration_shard()[1]
+
+        def prune_block(i, layer, subset, run_pass, state):
+            self._sparsegpt_block(i, subset, run_pass, n_inps, module_to_process, sparsity_ratio)
+
+        cal.walk_blocks(model, inps, outs, caches, module_to_process, n_samples, lambda: model.maybe_autocast(),
+                        prune_block, tuple_output=False)
+        torch.cuda.empty_cache()
+        return model
+
+
+@registry.register_pruner("blipt5_sparsegpt_pruner")
+class BLIPT5LayerSparseGPTPruner(LayerWiseBasePruner, _SparseGPTBlockMixin):
+    pruner_name = "blipt5_sparsegpt_pruner"
+
+    def __init__(self, model, data_loader, t5_prune_spec=None, vit_prune_spec=None, t5_pruning_method=None,
+                 vit_pruning_method=None, t5_model_prefix="t5_model", vit_model_prefix="visual_encoder", **kwargs):
+        kw = dict(_KW); kw.update({k: v for k, v in kwargs.items() if k in _KW})
+        kw["prune_spec"] = None
+        super().__init__(model=model, data_loader=data_loader, model_prefix=f"{vit_model_prefix}+{t5_model_prefix}", **kw)
+        self.t5_prune_spec = t5_prune_spec
+        self.vit_prune_spec = vit_prune_spec
+        assert t5_pruning_method is not None
+        assert vit_pruning_method is not None
+        self.t5_model_prefix = t5_model_prefix
+        self.vit_model_prefix = vit_model_prefix
+
+    def get_sparsity(self, original_sparsity, sparsity_ratio_granularity=None):
+        return uniform_or_layer_sparsity(self, original_sparsity, sparsity_ratio_granularity)
+
+    def forward_to_cache(self, model, batch):
+        return model(batch)
+
+    @print_time
+    def prune(self, importance_scores=None, keep_indices_or_masks=None):
+        print("In: ", self.pruner_name)
+        dtype_record, requires_grad_record, device = self.model_setup_and_record_attributes(self.model)
+        global_sparsity_dict = None
+        if self.sparsity_ratio_granularity is not None:
+            _, vit_keep_ratio, _, _ = self.convert_spec_to_list(self.vit_prune_spec)
+            _, t5_keep_ratio, _, _ = self.convert_spec_to_list(self.t5_prune_spec)
+            assert vit_keep_ratio == t5_keep_ratio
+            global_sparsity_dict = self.get_sparsity(1 - vit_keep_ratio,
+                                                     sparsity_ratio_granularity=self.sparsity_ratio_granularity)
+        if self.vit_prune_spec is not None:
+            _, keep_ratio, _, _ = self.convert_spec_to_list(self.vit_prune_spec)
+            sd = global_sparsity_dict if global_sparsity_dict is not None else self.get_sparsity(1 - keep_ratio, None)
+            self.model = VITLayerSparseGPTPruner._prune(self, self.model, self.data_loader, device,
+                                                        model_prefix=self.vit_model_prefix,
+                                                        module_to_process=f"{self.vit_model_prefix}.blocks",
+                                                        n_samples=self.num_samples, sparsity_ratio=sd)
+        if self.t5_prune_spec is not None:
+            _, keep_ratio, _, _ = self.convert_spec_to_list(self.t5_prune_spec)
+            sd = global_sparsity_dict if global_sparsity_dict is not None else self.get_sparsity(1 - keep_ratio, None)
+            if "t5_model" in self.t5_model_prefix:
+                for side in ("encoder", "decoder"):
+                    self.model = T5LayerSparseGPTPruner._prune(self, self.model, self.data_loader, device,
+                                                               model_prefix=self.t5_model_prefix,
+                                                               module_to_process=f"{self.t5_model_prefix}.{side}.block",
+                                                               n_samples=self.num_samples, sparsity_ratio=sd)
+            else:
+                self.model = T5LayerSparseGPTPruner._prune(self, self.model, self.data_loader, device,
+                                                           model_prefix=self.t5_model_prefix,
+                                                           module_to_process=f"{self.t5_model_prefix}.model.decoder.layers",
+                                                           n_samples=self.num_samples, sparsity_ratio=sd)
+        self.model_reset(self.model, dtype_record, requires_grad_record, device)
+        return self.model, global_sparsity_dict
