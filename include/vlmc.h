@@ -142,6 +142,33 @@ int vlmc_sparsegpt_sweep(float *W, int64_t out_features, int64_t count, int64_t 
                          const uint8_t *mask1, int64_t ldm, int prune_n, int prune_m, float *Err1, int64_t lde,
                          uint8_t *mask_out, int64_t ldmo, void *stream);
 
+/* ---- K11-K13: DSnoT --------------------------------------------------------------------
+ * vlmc_act_moments: per hook call and channel (layout as vlmc_act_sqnorm) the squared norm, the
+ *   plain sum over tokens and the population variance -- the three per-call quantities of the DSnoT
+ *   `WrappedGPT.add_batch` (dsnot_pruner.py:79-101).  Any output pointer may be NULL.
+ * vlmc_dsnot_stats_update: the three running means in call order (:92-101); tokens_per_call is a
+ *   device array (calls may have different token counts); also emits sqrt(scaler_row) if asked.  */
+int vlmc_act_moments(const void *x, int dtype, int64_t n_calls, int64_t tokens, int64_t in_features, int64_t row_stride,
+                     int64_t call_stride, float *normsq, float *sums, float *vars, void *stream);
+int vlmc_dsnot_stats_update(float *scaler_row, float *sum_row, float *var_row, int64_t in_features, int64_t nsamples_before,
+                            int64_t ntokens_before, const float *normsq, const float *sums, const float *vars,
+                            const int64_t *tokens_per_call, int64_t n_calls, int64_t batch, float *sqrt_out, void *stream);
+
+/* vlmc_dsnot_refine: the prune/regrow cycle loop of dsnot_pruner.py:553-751 (unstructured, prune_n == 0)
+ *   or :407-552 (n:m) for every row, starting from keep_mask0 (1 = keep: the initial mask, i.e.
+ *   vlmc_wanda_select with k = round(in*ratio) or n:m, apply_zero = 0).  Writes, per row and cycle,
+ *   events[row, t] = p | r << 14 | update << 28 for max_cycle cycles, and stop_cycle[row] = first
+ *   cycle (1-based) after which the row no longer updates (INT_MAX if it never stops).
+ * vlmc_dsnot_apply: replays the first min(*ncycles, max_cycle) events of every row into the mask
+ *   (the reference runs all rows for as long as ANY row updates: ncycles = max over rows of
+ *   stop_cycle) and zeroes the pruned weights when apply_zero.  in_features <= 16384.          */
+int vlmc_dsnot_refine(const void *W, int dtype, int64_t out_features, int64_t in_features, int64_t ldw,
+                      const uint8_t *keep_mask0, const float *sqrt_scaler, const float *sum_row, const float *var_row,
+                      int use_wanda_init, int prune_n, int prune_m, int max_cycle, float update_threshold, float pow_of_var,
+                      int without_same_sign, uint32_t *events, int32_t *stop_cycle, void *stream);
+int vlmc_dsnot_apply(void *W, int dtype, int64_t out_features, int64_t in_features, int64_t ldw, uint8_t *keep_mask,
+                     const uint32_t *events, const int32_t *ncycles, int max_cycle, int nm_mode, int apply_zero, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -375,8 +375,70 @@ def gen_sparsegpt_e2e():
     print("sparsegpt_e2e.npz:", len(out), "arrays")
 
 
+def ref_dsnot_one_linear(W, xs, tower, ratio=0.5, n=0, m=0, **dsnot_kw):
+    """Run the reference DSnoT loop body on one linear with hook inputs `xs`."""
+    from lavis.compression.pruners import dsnot_pruner as R
+    model = OneLinearModel(W, tower)
+    loader = [{"x": x, "image": x, "text_input": [0] * x.shape[0]} for x in xs]
+    pr = R.BLIPT5LayerDSnoTPruner(model=model, data_loader=loader, t5_prune_spec="1-%r-1.0-1.0" % (1 - ratio),
+                                  vit_prune_spec="1-%r-1.0-1.0" % (1 - ratio), t5_pruning_method="dsnot",
+                                  vit_pruning_method="dsnot", num_samples=len(xs), prune_n=n, prune_m=m,
+                                  max_sparsity_per_layer=1.01, **dsnot_kw)
+    sd = pr.get_sparsity(ratio, ratio, sparsity_ratio_granularity=None)
+    cls = R.T5LayerDSnoTPruner if tower == "t5" else R.VITLayerDSnoTPruner
+    pr.prepare_calibration_input_encoder = partial(cls.prepare_calibration_input_encoder, pr)
+    if tower == "t5":
+        cls._prune(pr, model, loader, "cpu", model_prefix="t5_model", module_to_process="t5_model.encoder.block",
+                   n_samples=len(xs), sparsity_ratio=sd, lora_model=False)
+        fc = model.t5_model.encoder.block[0].fc
+    else:
+        cls._prune(pr, model, loader, "cpu", model_prefix="visual_encoder", module_to_process="visual_encoder.blocks",
+                   n_samples=len(xs), sparsity_ratio=sd, lora_model=False)
+        fc = model.visual_encoder.blocks[0].fc
+    return fc.mask.clone(), fc.weight.data.clone()
+
+
+def gen_dsnot():
+    from lavis.compression.pruners import dsnot_pruner as R
+    out = {}
+    # ---- statistics (DSnoT WrappedGPT.add_batch) ------------------------------------------
+    for name, dt, T, in_f, ncalls, b in [("bf16", torch.bfloat16, 16, 128, 6, 1), ("fp16_b2", torch.float16, 7, 64, 4, 2),
+                                         ("fp32", torch.float32, 12, 64, 5, 1)]:
+        g = torch.Generator().manual_seed(40 + len(out))
+        w = R.WrappedGPT(nn.Linear(in_f, 4, bias=False))
+        for j in range(ncalls):
+            x = ((torch.randn(b, T + j, in_f, generator=g) * (1 + j % 3)) + 0.2).to(dt)
+            out[f"stat/{name}/x{j}"] = x
+            w.add_batch(x, None)
+            out[f"stat/{name}/scaler{j}"] = w.scaler_row.clone()
+            out[f"stat/{name}/sum{j}"] = w.sum_metric_row.clone()
+            out[f"stat/{name}/var{j}"] = w.var.flatten().clone()
+        out[f"stat/{name}/n"] = ncalls
+    # ---- per-linear pruning ----------------------------------------------------------------
+    cases = [
+        ("t5_bf16_r50", "t5", torch.bfloat16, 40, 256, 0.5, 0, 0, {}),
+        ("t5_fp32_r30_mag", "t5", torch.float32, 24, 256, 0.3, 0, 0, dict(initial_method="magnitude")),
+        ("t5_bf16_plain", "t5", torch.bfloat16, 24, 256, 0.5, 0, 0, dict(without_DSnoT=True)),
+        ("t5_fp16_walk", "t5", torch.float16, 32, 64, 0.5, 0, 0, dict(max_cycle_time=24)),
+        ("t5_fp32_samesign", "t5", torch.float32, 24, 256, 0.4, 0, 0, dict(without_same_sign=False, update_threshold=0.02)),
+        ("vit_fp16_r50", "vit", torch.float16, 32, 256, 0.5, 0, 0, {}),
+        ("t5_bf16_2_4", "t5", torch.bfloat16, 32, 256, 0.5, 2, 4, {}),
+        ("vit_fp32_4_8", "vit", torch.float32, 24, 256, 0.5, 4, 8, dict(max_cycle_time=40)),
+    ]
+    for i, (name, tower, dt, out_f, in_f, ratio, n, m, kw) in enumerate(cases):
+        W = craft_weight(out_f, in_f, dt, seed=1200 + i, ties=(n == 0))
+        xs = make_xs(6, 12, in_f, dt, seed=1300 + i, mean=0.3, equal_cols=(n == 0))
+        mask, Wn = ref_dsnot_one_linear(W, xs, tower, ratio=ratio, n=n, m=m, **kw)
+        out.update({f"{name}/W": W, f"{name}/xs": torch.cat(xs), f"{name}/mask": mask, f"{name}/Wn": Wn,
+                    f"{name}/ratio": ratio, f"{name}/n": n, f"{name}/m": m, f"{name}/tower": np.array(tower)})
+        for k_, v_ in kw.items():
+            out[f"{name}/kw/{k_}"] = np.array(v_)
+    golden_io.save("dsnot", out)
+    print("dsnot.npz:", len(out), "arrays")
+
+
 GROUPS = {"wanda": gen_wanda, "wanda_e2e": gen_wanda_e2e, "sparse_lora": gen_sparse_lora, "sparsegpt": gen_sparsegpt,
-          "sparsegpt_e2e": gen_sparsegpt_e2e}
+          "sparsegpt_e2e": gen_sparsegpt_e2e, "dsnot": gen_dsnot}
 
 if __name__ == "__main__":
     import_reference()

@@ -1,0 +1,122 @@
+"""DSnoT on the GPU: per-input statistics and the training-free prune/regrow refinement.
+
+Mirrors the DSnoT `WrappedGPT` state (dsnot_pruner.py:53-105) and the per-linear body of
+`_prune` (:378-751).  Per linear:
+    initial mask   vlmc_wanda_select (row rule with k = round(in*ratio), or n:m; magnitude init =
+                   the same kernel with a unit scale) -- no weights touched
+    refinement     vlmc_dsnot_refine: every row's whole cycle loop in ONE launch (the reference
+                   issues ~20 small kernels per cycle for up to 100 cycles after three full-row sorts)
+    replay/apply   vlmc_dsnot_apply with C = min(max_cycle, max over rows of the stop cycle)
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib, ops
+from .ops import _dtype_code, _need_gpu, _stream
+
+
+class DsnotInputStat:
+    """Statistics of ONE distinct linear input (shared by the linears that receive it)."""
+
+    def __init__(self, in_features: int, device):
+        self.in_features, self.device = in_features, device
+        self.normsq, self.sums, self.vars, self.tokens, self.batches = [], [], [], [], []
+        self.scaler_row = self.sum_row = self.var_row = self.sqrt_row = None
+        self.nsamples = self.ntokens = 0
+
+    def add_call(self, x: torch.Tensor):
+        b = x.shape[0] if x.dim() == 3 else 1
+        x = x.reshape(1, -1, x.shape[-1])
+        if x.stride(-1) != 1:
+            x = x.contiguous()
+        _need_gpu(x)
+        out = torch.empty((3, self.in_features), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().vlmc_act_moments(x.data_ptr(), _dtype_code(x), 1, x.shape[1], x.shape[2], x.stride(1), 0,
+                                                out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), _stream()))
+        self.normsq.append(out[0]); self.sums.append(out[1]); self.vars.append(out[2])
+        self.tokens.append(x.shape[1]); self.batches.append(b)
+
+    def _stacked(self):
+        return torch.stack(self.normsq), torch.stack(self.sums), torch.stack(self.vars)
+
+    def finalize(self, gathered=None):
+        nsq, sm, vr = self._stacked() if gathered is None else gathered[:3]
+        tokens = self.tokens if gathered is None else gathered[3]
+        batches = self.batches if gathered is None else gathered[4]
+        assert len(set(batches)) <= 1, "DSnoT statistics expect a constant calibration batch size"
+        dev = self.device
+        self.scaler_row = torch.zeros(self.in_features, dtype=torch.float32, device=dev)
+        self.sum_row = torch.zeros_like(self.scaler_row)
+        self.var_row = torch.zeros_like(self.scaler_row)
+        self.sqrt_row = torch.empty_like(self.scaler_row)
+        tok = torch.tensor(list(tokens), dtype=torch.int64, device=dev)
+        b = batches[0] if batches else 1
+        _lib.check(_lib.load().vlmc_dsnot_stats_update(
+            self.scaler_row.data_ptr(), self.sum_row.data_ptr(), self.var_row.data_ptr(), self.in_features, 0, 0,
+            nsq.contiguous().data_ptr(), sm.contiguous().data_ptr(), vr.contiguous().data_ptr(), tok.data_ptr(), len(tokens), b,
+            self.sqrt_row.data_ptr(), _stream()))
+        self.nsamples = len(tokens) * b
+        self.ntokens = int(sum(tokens))
+        self._keep = (nsq, sm, vr, tok)             # keep the inputs alive until the stream has consumed them
+        return self
+
+
+def gather_stats(stats):
+    """Multi-GPU: all-gather the per-call moments (rank-major = sample order), then finalise."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if world == 1:
+        for st in stats:
+            st.finalize()
+        return stats
+    for st in stats:
+        nsq, sm, vr = st._stacked()
+        local = torch.cat([nsq, sm, vr], dim=1).contiguous()
+        allm = torch.empty((world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(allm, local)
+        tok = torch.tensor(st.tokens, dtype=torch.int64, device=local.device)
+        allt = torch.empty(world * tok.numel(), dtype=torch.int64, device=local.device)
+        dist.all_gather_into_tensor(allt, tok)
+        f = st.in_features
+        st.finalize((allm[:, :f], allm[:, f:2 * f], allm[:, 2 * f:], allt.cpu().tolist(), st.batches * world))
+    return stats
+
+
+@torch.no_grad()
+def prune_linear(weight: torch.Tensor, stat: DsnotInputStat, ratio, *, prune_n=0, prune_m=0, initial_method="wanda",
+                 without_DSnoT=False, max_cycle_time=100, update_threshold=0.1, pow_of_var_regrowing=1.0,
+                 without_same_sign=True, apply_zero=True):
+    """Per-linear body of the DSnoT `_prune` loops.  Returns the keep mask (torch.bool, True = keep),
+    or None when ratio == 0 in the unstructured branch (the reference skips the linear, :560-561)."""
+    _need_gpu(weight)
+    if initial_method not in ("wanda", "magnitude"):
+        raise ValueError("initial_method must be 'wanda' or 'magnitude' (the reference's 'sparsegpt' branch cannot run: "
+                         "its Hessian is never allocated, dsnot_pruner.py:340,386)")
+    out_f, in_f = weight.shape
+    init_scale = stat.sqrt_row if initial_method == "wanda" else torch.ones_like(stat.sqrt_row)
+    max_cycle = int(max_cycle_time)
+    if prune_n != 0:
+        keep, _ = ops.wanda_select(weight, init_scale, "nm", n=prune_n, m=prune_m, apply_zero=False)
+    else:
+        if ratio == 0.:
+            return None
+        keep, _ = ops.wanda_select(weight, init_scale, "row", k=round(in_f * ratio), apply_zero=False)     # :562 round()
+    lib = _lib.load()
+    ncyc = torch.zeros(1, dtype=torch.int32, device=weight.device)
+    events = torch.empty((out_f, max(max_cycle, 1)), dtype=torch.int32, device=weight.device)
+    if not (prune_n == 0 and without_DSnoT):
+        if max_cycle >= in_f:
+            raise RuntimeError(f"DSnoT needs in_features ({in_f}) > max_cycle_time ({max_cycle}); the reference's pointers "
+                               "run out of range in that case (SURVEY.md Appendix B.1)")
+        stop = torch.empty(out_f, dtype=torch.int32, device=weight.device)
+        _lib.check(lib.vlmc_dsnot_refine(
+            weight.data_ptr(), _dtype_code(weight), out_f, in_f, weight.stride(0), keep.data_ptr(), stat.sqrt_row.data_ptr(),
+            stat.sum_row.data_ptr(), stat.var_row.data_ptr(), int(initial_method == "wanda"), int(prune_n), int(prune_m),
+            max_cycle, float(update_threshold), float(pow_of_var_regrowing or 0.0), int(bool(without_same_sign)),
+            events.data_ptr(), stop.data_ptr(), _stream()))
+        ncyc = stop.max().clamp(max=max_cycle).to(torch.int32).reshape(1)
+    _lib.check(lib.vlmc_dsnot_apply(weight.data_ptr(), _dtype_code(weight), out_f, in_f, weight.stride(0), keep.data_ptr(),
+                                    events.data_ptr(), ncyc.data_ptr(), max(max_cycle, 1), int(prune_n != 0),
+                                    int(bool(apply_zero)), _stream()))
+    return keep
