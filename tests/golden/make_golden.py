@@ -437,8 +437,40 @@ def gen_dsnot():
     print("dsnot.npz:", len(out), "arrays")
 
 
+def gen_dsnot_e2e():
+    """Whole-pruner run of the reference's blipt5_dsnot_pruner on the toy InstructBLIP."""
+    from lavis.compression.pruners import dsnot_pruner as RD
+    variants = {
+        "fp32_r50": dict(t5_dtype=torch.float32, ratio=0.5, n=0, m=0, lora=False, kw=dict(max_cycle_time=20)),
+        "mixed_2_4": dict(t5_dtype=torch.bfloat16, ratio=0.5, n=2, m=4, lora=False, kw=dict(max_cycle_time=4)),
+        "fp32_r40_lora_mag": dict(t5_dtype=torch.float32, ratio=0.4, n=0, m=0, lora=True,
+                                  kw=dict(max_cycle_time=16, initial_method="magnitude", update_threshold=0.02)),
+    }
+    out = {}
+    for name, v in variants.items():
+        model = toy_models.init_toy(toy_models.ToyBlipT5(vit_dtype=torch.float32, t5_dtype=v["t5_dtype"]), seed=7)
+        if v["lora"]:
+            _wrap_lora_reference(model)
+        model.eval()
+        batches = toy_models.make_batches(6, seed=11)
+        spec = "2-%r-1.0-1.0" % (1 - v["ratio"])
+        pr = RD.BLIPT5LayerDSnoTPruner(model=model, data_loader=batches, t5_prune_spec=spec, vit_prune_spec=spec,
+                                       t5_pruning_method="dsnot", vit_pruning_method="dsnot", num_samples=6,
+                                       prune_n=v["n"], prune_m=v["m"], max_sparsity_per_layer=1.01, **v["kw"])
+        pruned, _ = pr.prune(lora_model=True) if v["lora"] else pr.prune()
+        for k_, t in pruned.state_dict().items():
+            out[f"{name}/sd/{k_}"] = t
+        for mn, mod in pruned.named_modules():
+            if hasattr(mod, "mask") and "mask" not in dict(mod.named_buffers(recurse=False)):
+                out[f"{name}/mask/{mn}"] = mod.mask
+        out[f"{name}/ratio"] = v["ratio"]
+    golden_io.save("dsnot_e2e", out)
+    print("dsnot_e2e.npz:", len(out), "arrays")
+
+
 GROUPS = {"wanda": gen_wanda, "wanda_e2e": gen_wanda_e2e, "sparse_lora": gen_sparse_lora, "sparsegpt": gen_sparsegpt,
-          "sparsegpt_e2e": gen_sparsegpt_e2e, "dsnot": gen_dsnot}
+          "sparsegpt_e2e": gen_sparsegpt_e2e, "dsnot": gen_dsnot,
+          "dsnot_e2e": gen_dsnot_e2e}
 
 if __name__ == "__main__":
     import_reference()

@@ -103,3 +103,59 @@ def install_sparsegpt(monkeypatch):
     from vlmc import sparsegpt
     monkeypatch.setattr(sparsegpt, "SparseGPT", OracleSparseGPT)
     monkeypatch.setattr(sparsegpt, "fasterprune", oracle_fasterprune)
+
+
+# ---- DSnoT stand-ins (for vlmc.dsnot) -------------------------------------------------------
+def dsnot_act_moments(x):
+    """Per-call moments exactly as the reference's hook forms them (dsnot_pruner.py:88-100)."""
+    xt = x.reshape(-1, x.shape[-1]).t().type(torch.float32)
+    return torch.stack([torch.norm(xt, p=2, dim=1) ** 2, torch.sum(xt, dim=1), torch.var(xt, dim=1, unbiased=False)])
+
+
+def dsnot_stats_update(in_features, device, normsq, sums, vars_, tokens, batch):
+    """oracle.dsnot.DSnoTStat.add_batch restated over per-call moments (same op order and scalar types)."""
+    scaler, sum_row, var, n, ntok = torch.zeros(in_features), torch.zeros(in_features), None, 0, 0
+    for c, num in enumerate(tokens):
+        var = vars_[c].clone() if ntok == 0 else (var * ntok + vars_[c] * num) / (ntok + num)
+        ntok += num
+        scaler *= n / (n + batch)
+        sum_row *= n / (n + batch)
+        n += batch
+        scaler += normsq[c] / n
+        sum_row += sums[c] / n
+    if var is None:
+        var = torch.zeros(in_features)
+    return scaler, sum_row, var, torch.sqrt(scaler), None
+
+
+def _ostat(stat):
+    from types import SimpleNamespace
+    return SimpleNamespace(scaler_row=stat.scaler_row, sum_metric_row=stat.sum_row, var=stat.var_row.reshape(-1, 1))
+
+
+def oracle_dsnot_prune_linear(weight, stat, ratio, *, prune_n=0, prune_m=0, initial_method="wanda", without_DSnoT=False,
+                              max_cycle_time=100, update_threshold=0.1, pow_of_var_regrowing=1.0, without_same_sign=True,
+                              apply_zero=True):
+    from oracle import dsnot as OD
+    if prune_n != 0:
+        pruned = OD.prune_nm(weight.data, _ostat(stat), prune_n, prune_m, initial_method=initial_method,
+                             max_cycle_time=max_cycle_time, update_threshold=update_threshold,
+                             pow_of_var_regrowing=pow_of_var_regrowing)
+    else:
+        pruned = OD.prune_unstructured(weight.data, _ostat(stat), ratio, initial_method=initial_method,
+                                       without_DSnoT=without_DSnoT, max_cycle_time=max_cycle_time,
+                                       update_threshold=update_threshold, pow_of_var_regrowing=pow_of_var_regrowing,
+                                       without_same_sign=without_same_sign)
+        if pruned is None:
+            return None
+    if apply_zero:
+        weight[pruned] = 0
+    return ~pruned
+
+
+def install_dsnot(monkeypatch):
+    """vlmc.dsnot's three C-ABI entry points replaced; DsnotInputStat / gather_stats stay the product's."""
+    from vlmc import dsnot
+    monkeypatch.setattr(dsnot, "act_moments", dsnot_act_moments)
+    monkeypatch.setattr(dsnot, "stats_update", dsnot_stats_update)
+    monkeypatch.setattr(dsnot, "prune_linear", oracle_dsnot_prune_linear)

@@ -5,7 +5,7 @@ import torch.nn as nn
 import golden_io
 import toy_models
 
-E2E = None
+E2E = {}
 
 VARIANTS = {
     "fp32_r50": dict(vit_dtype=torch.float32, t5_dtype=torch.float32, ratio=0.5, n=0, m=0, lora=False),
@@ -14,11 +14,20 @@ VARIANTS = {
 }
 
 
-def golden():
-    global E2E
-    if E2E is None:
-        E2E = golden_io.load("wanda_e2e")
-    return E2E
+DSNOT_VARIANTS = {
+    "fp32_r50": dict(vit_dtype=torch.float32, t5_dtype=torch.float32, ratio=0.5, n=0, m=0, lora=False,
+                     kw=dict(max_cycle_time=20)),
+    "mixed_2_4": dict(vit_dtype=torch.float32, t5_dtype=torch.bfloat16, ratio=0.5, n=2, m=4, lora=False,
+                      kw=dict(max_cycle_time=4)),
+    "fp32_r40_lora_mag": dict(vit_dtype=torch.float32, t5_dtype=torch.float32, ratio=0.4, n=0, m=0, lora=True,
+                              kw=dict(max_cycle_time=16, initial_method="magnitude", update_threshold=0.02)),
+}
+
+
+def golden(which="wanda_e2e"):
+    if which not in E2E:
+        E2E[which] = golden_io.load(which)
+    return E2E[which]
 
 
 def wrap_lora(model, r=4, alpha=16):
@@ -42,8 +51,8 @@ def wrap_lora(model, r=4, alpha=16):
     return model
 
 
-def build(name, device="cpu"):
-    v = VARIANTS[name]
+def build(name, device="cpu", variants=None):
+    v = (variants or VARIANTS)[name]
     model = toy_models.init_toy(toy_models.ToyBlipT5(vit_dtype=v["vit_dtype"], t5_dtype=v["t5_dtype"]), seed=7)
     if v["lora"]:
         wrap_lora(model)
@@ -63,8 +72,19 @@ def run_pruner(name, device="cpu"):
     return pruned, sd
 
 
-def compare_with_golden(name, pruned, exact=True, min_mask_agreement=1.0, weight_rtol=0.0):
-    G = golden()
+def run_dsnot_pruner(name, device="cpu"):
+    from lavis.compression import load_pruner
+    model, batches, v = build(name, device, DSNOT_VARIANTS)
+    spec = "2-%r-1.0-1.0" % (1 - v["ratio"])
+    cfg = dict(t5_prune_spec=spec, vit_prune_spec=spec, t5_pruning_method="dsnot", vit_pruning_method="dsnot",
+               num_samples=6, prune_n=v["n"], prune_m=v["m"], max_sparsity_per_layer=1.01, **v["kw"])
+    pruner = load_pruner("blipt5_dsnot_pruner", model, batches, cfg=cfg)
+    pruned, sd = pruner.prune(lora_model=True) if v["lora"] else pruner.prune()
+    return pruned, sd
+
+
+def compare_with_golden(name, pruned, exact=True, min_mask_agreement=1.0, weight_rtol=0.0, which="wanda_e2e"):
+    G = golden(which)
     stats = {"masks": 0, "mask_elems": 0, "mask_diff": 0}
     sd = pruned.state_dict()
     for key in [k for k in G if k.startswith(f"{name}/sd/")]:

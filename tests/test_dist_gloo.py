@@ -39,6 +39,7 @@ def _setup(rank, world, port):
         def setattr(obj, name, val):
             setattr(obj, name, val)
     oracle_ops.install(MP)
+    oracle_ops.install_dsnot(MP)
     return ops
 
 
@@ -99,5 +100,33 @@ def test_sample_sharded_pruner_world2_matches_reference_golden(tmp_path):
         for key in [k for k in G if k.startswith("fp32_r50/sd/")]:
             assert torch.equal(sd[key[len("fp32_r50/sd/"):]], G[key]), (r, key)
         masks = torch.load(tmp_path / f"masks_{r}.pt")
+        for mn, m in masks.items():
+            assert torch.equal(m, G[f"fp32_r50/mask/{mn}"]), (r, mn)
+
+
+def _worker_dsnot_pruner(rank, world, port, out_dir):
+    _setup(rank, world, port)
+    import pruner_helpers as H
+    pruned, _ = H.run_dsnot_pruner("fp32_r50", "cpu")
+    torch.save({k: v for k, v in pruned.state_dict().items()}, os.path.join(out_dir, f"dsnot_pruned_{rank}.pt"))
+    masks = {n: m.mask.clone() for n, m in pruned.named_modules() if hasattr(m, "mask")}
+    torch.save(masks, os.path.join(out_dir, f"dsnot_masks_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sample_sharded_dsnot_pruner_world2_matches_reference_golden(tmp_path):
+    """DSnoT statistics (norm, sum, token-weighted variance) gathered per call over 2 ranks
+    (vlmc.dsnot.gather_stats): every rank ends with the reference's masks and weights."""
+    import pruner_helpers as H
+    port = _free_port()
+    mp.spawn(_worker_dsnot_pruner, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    G = H.golden("dsnot_e2e")
+    for r in range(2):
+        sd = torch.load(tmp_path / f"dsnot_pruned_{r}.pt")
+        for key in [k for k in G if k.startswith("fp32_r50/sd/")]:
+            assert torch.equal(sd[key[len("fp32_r50/sd/"):]], G[key]), (r, key)
+        masks = torch.load(tmp_path / f"dsnot_masks_{r}.pt")
+        assert len(masks) == 2 * 4 + 2 * 7 + 2 * 11
         for mn, m in masks.items():
             assert torch.equal(m, G[f"fp32_r50/mask/{mn}"]), (r, mn)

@@ -1,4 +1,4 @@
-"""GPU end-to-end: the drop-in `blipt5_wanda_pruner` running on the HIP kernels.
+"""GPU end-to-end: the drop-in `blipt5_*_pruner`s running on the HIP kernels (Wanda first).
 
 (a) every statistics launch and every per-linear select that the pruner issues is
     re-checked bit-for-bit against the CPU oracle on the very tensors it saw (the GPU
@@ -91,3 +91,46 @@ def test_sparsegpt_pruner_on_gpu_tracks_reference_run(name):
             assert bool(((g == 0).view(g.shape[0], -1, 4).sum(-1) >= 2).all()), k
     assert tot > 0 and agree / tot >= 0.97, agree / tot
     assert (num / den) ** 0.5 < 2e-2
+
+
+@pytest.mark.parametrize("name", list(H.DSNOT_VARIANTS))
+def test_dsnot_pruner_on_gpu_every_linear_matches_oracle(name, monkeypatch):
+    """Whole blipt5_dsnot_pruner on the GPU: every per-linear refinement is re-checked bit-for-bit against
+    the CPU oracle fed with the statistics the GPU produced; the final masks track the reference's run."""
+    from types import SimpleNamespace
+    from oracle import dsnot as OD
+    from vlmc import dsnot
+    real = dsnot.prune_linear
+    counts = {"linears": 0, "moments": 0}
+    real_add = dsnot.DsnotInputStat.add_call
+
+    def counted_add(self, x):
+        counts["moments"] += 1
+        return real_add(self, x)
+
+    def checked(weight, stat, ratio, **kw):
+        W0 = weight.detach().clone().cpu()
+        ostat = SimpleNamespace(scaler_row=stat.scaler_row.cpu(), sum_metric_row=stat.sum_row.cpu(),
+                                var=stat.var_row.cpu().reshape(-1, 1))
+        keep = real(weight, stat, ratio, **kw)
+        okw = {k: kw[k] for k in ("initial_method", "max_cycle_time", "update_threshold", "pow_of_var_regrowing")}
+        if kw["prune_n"]:
+            pruned = OD.prune_nm(W0, ostat, kw["prune_n"], kw["prune_m"], **okw)
+        else:
+            pruned = OD.prune_unstructured(W0, ostat, ratio, without_DSnoT=kw["without_DSnoT"],
+                                           without_same_sign=kw["without_same_sign"], **okw)
+        assert torch.equal(keep.cpu(), ~pruned), "refined mask differs from the oracle"
+        want_w = W0.clone()
+        if kw["apply_zero"]:
+            want_w[pruned] = 0
+        assert torch.equal(weight.detach().cpu(), want_w)
+        counts["linears"] += 1
+        return keep
+
+    monkeypatch.setattr(dsnot, "prune_linear", checked)
+    monkeypatch.setattr(dsnot.DsnotInputStat, "add_call", counted_add)
+    pruned, _ = H.run_dsnot_pruner(name, "cuda:0")
+    assert counts["linears"] == 2 * 4 + 2 * 7 + 2 * 11
+    assert counts["moments"] == 6 * (2 * 4 + 2 * 4 + 2 * 7)        # one launch per distinct input tensor
+    st = H.compare_with_golden(name, pruned, exact=False, min_mask_agreement=0.99, which="dsnot_e2e")
+    print(name, st)

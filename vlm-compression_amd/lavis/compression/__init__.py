@@ -8,6 +8,9 @@ from lavis.compression.pruners.wanda_pruner import (  # noqa: F401  (registratio
 from lavis.compression.pruners.sparsegpt_pruner import (  # noqa: F401  (registration)
     BLIPT5LayerSparseGPTPruner, T5LayerSparseGPTPruner, VITLayerSparseGPTPruner,
 )
+from lavis.compression.pruners.dsnot_pruner import (  # noqa: F401  (registration)
+    BLIPT5LayerDSnoTPruner, T5LayerDSnoTPruner, VITLayerDSnoTPruner,
+)
 
 __all__ = ["BasePruner"]
 

@@ -16,49 +16,63 @@ from . import _lib, ops
 from .ops import _dtype_code, _need_gpu, _stream
 
 
+def act_moments(x: torch.Tensor) -> torch.Tensor:
+    """[3, in] fp32 for ONE hook call x [1, tokens, in]: (||x||_2)^2, sum and biased variance over the tokens,
+    per input channel, in one pass (dsnot_pruner.py:88-100)."""
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    _need_gpu(x)
+    out = torch.empty((3, x.shape[-1]), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().vlmc_act_moments(x.data_ptr(), _dtype_code(x), 1, x.shape[1], x.shape[2], x.stride(1), 0,
+                                            out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), _stream()))
+    return out
+
+
+def stats_update(in_features, device, normsq, sums, vars_, tokens, batch):
+    """Fold the per-call moments ([n_calls, in] each, sample order) into the running statistics from a zero
+    state.  Returns (scaler_row, sum_row, var_row, sqrt(scaler_row)), all [in] fp32."""
+    scaler = torch.zeros(in_features, dtype=torch.float32, device=device)
+    _need_gpu(scaler)
+    sum_row, var_row, sqrt_row = torch.zeros_like(scaler), torch.zeros_like(scaler), torch.empty_like(scaler)
+    tok = torch.tensor(list(tokens), dtype=torch.int64, device=device)
+    normsq, sums, vars_ = normsq.contiguous(), sums.contiguous(), vars_.contiguous()
+    _lib.check(_lib.load().vlmc_dsnot_stats_update(
+        scaler.data_ptr(), sum_row.data_ptr(), var_row.data_ptr(), in_features, 0, 0, normsq.data_ptr(), sums.data_ptr(),
+        vars_.data_ptr(), tok.data_ptr(), len(tokens), batch, sqrt_row.data_ptr(), _stream()))
+    # the inputs must outlive the launch: callers keep them referenced through DsnotInputStat._keep
+    return scaler, sum_row, var_row, sqrt_row, (normsq, sums, vars_, tok)
+
+
 class DsnotInputStat:
     """Statistics of ONE distinct linear input (shared by the linears that receive it)."""
 
     def __init__(self, in_features: int, device):
         self.in_features, self.device = in_features, device
-        self.normsq, self.sums, self.vars, self.tokens, self.batches = [], [], [], [], []
+        self.moments, self.tokens, self.batches = [], [], []           # per hook call: [3, in] tensor, #tokens, batch
         self.scaler_row = self.sum_row = self.var_row = self.sqrt_row = None
         self.nsamples = self.ntokens = 0
 
     def add_call(self, x: torch.Tensor):
         b = x.shape[0] if x.dim() == 3 else 1
         x = x.reshape(1, -1, x.shape[-1])
-        if x.stride(-1) != 1:
-            x = x.contiguous()
-        _need_gpu(x)
-        out = torch.empty((3, self.in_features), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.load().vlmc_act_moments(x.data_ptr(), _dtype_code(x), 1, x.shape[1], x.shape[2], x.stride(1), 0,
-                                                out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), _stream()))
-        self.normsq.append(out[0]); self.sums.append(out[1]); self.vars.append(out[2])
+        self.moments.append(act_moments(x))
         self.tokens.append(x.shape[1]); self.batches.append(b)
 
-    def _stacked(self):
-        return torch.stack(self.normsq), torch.stack(self.sums), torch.stack(self.vars)
+    def extend(self, other: "DsnotInputStat"):
+        """Append the call records of `other` (used when hook-level records are merged per linear input)."""
+        self.moments += other.moments; self.tokens += other.tokens; self.batches += other.batches
 
     def finalize(self, gathered=None):
-        nsq, sm, vr = self._stacked() if gathered is None else gathered[:3]
-        tokens = self.tokens if gathered is None else gathered[3]
-        batches = self.batches if gathered is None else gathered[4]
+        """gathered = (moments [n_calls, 3, in], tokens list, batches list) replaces the local records."""
+        mom = torch.stack(self.moments) if gathered is None else gathered[0]
+        tokens = self.tokens if gathered is None else gathered[1]
+        batches = self.batches if gathered is None else gathered[2]
         assert len(set(batches)) <= 1, "DSnoT statistics expect a constant calibration batch size"
-        dev = self.device
-        self.scaler_row = torch.zeros(self.in_features, dtype=torch.float32, device=dev)
-        self.sum_row = torch.zeros_like(self.scaler_row)
-        self.var_row = torch.zeros_like(self.scaler_row)
-        self.sqrt_row = torch.empty_like(self.scaler_row)
-        tok = torch.tensor(list(tokens), dtype=torch.int64, device=dev)
         b = batches[0] if batches else 1
-        _lib.check(_lib.load().vlmc_dsnot_stats_update(
-            self.scaler_row.data_ptr(), self.sum_row.data_ptr(), self.var_row.data_ptr(), self.in_features, 0, 0,
-            nsq.contiguous().data_ptr(), sm.contiguous().data_ptr(), vr.contiguous().data_ptr(), tok.data_ptr(), len(tokens), b,
-            self.sqrt_row.data_ptr(), _stream()))
+        self.scaler_row, self.sum_row, self.var_row, self.sqrt_row, self._keep = stats_update(
+            self.in_features, self.device, mom[:, 0], mom[:, 1], mom[:, 2], tokens, b)
         self.nsamples = len(tokens) * b
         self.ntokens = int(sum(tokens))
-        self._keep = (nsq, sm, vr, tok)             # keep the inputs alive until the stream has consumed them
         return self
 
 
@@ -71,15 +85,13 @@ def gather_stats(stats):
             st.finalize()
         return stats
     for st in stats:
-        nsq, sm, vr = st._stacked()
-        local = torch.cat([nsq, sm, vr], dim=1).contiguous()
-        allm = torch.empty((world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
+        local = torch.stack(st.moments).contiguous()                      # [calls, 3, in]
+        allm = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(allm, local)
         tok = torch.tensor(st.tokens, dtype=torch.int64, device=local.device)
         allt = torch.empty(world * tok.numel(), dtype=torch.int64, device=local.device)
         dist.all_gather_into_tensor(allt, tok)
-        f = st.in_features
-        st.finalize((allm[:, :f], allm[:, f:2 * f], allm[:, 2 * f:], allt.cpu().tolist(), st.batches * world))
+        st.finalize((allm, allt.cpu().tolist(), st.batches * world))
     return stats
 
 
