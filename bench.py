@@ -90,57 +90,52 @@ def build_workload(dev, rank, world, n_sets_wanted):
 
 
 def build_plans(blocks, acts, weights, n_local, world, dev, state):
-    """Pre-bind every launch of one step for one weight set.  Returns a list of per-block
-    (stat_plans, exchange, update_plans, select_plans) and the list of select launches that
-    carry roofline events."""
+    """Pre-bind every launch of one step for one weight set: per block ONE batched statistics launch
+    (all distinct linear inputs), ONE batched running-mean launch, and one batched select call (the
+    library issues one launch per distinct (in_features, k) for the per-row rule, one launch sequence
+    for the matrix-wide rule)."""
     from vlmc import ops, workload as wl
     steps = []
     for bi, b in enumerate(blocks):
-        st_plans, upd_plans, sel_plans = [], [], []
         ins = state["blocks"][bi]
+        stat = ops.plan_act_sqnorm_batch(acts[bi], [s["normsq_local"] for s in ins])
+        upd = ops.plan_scaler_update_batch([s["scaler"] for s in ins], 0, [s["normsq_all"] for s in ins], 1,
+                                           [s["sqrt"] for s in ins])
+        ws, sqs, ks, nbytes, li = [], [], [], 0, 0
         for ii, inp in enumerate(b.inputs):
-            s = ins[ii]
-            st_plans.append(ops.plan_act_sqnorm(acts[bi][ii], s["normsq_local"]))
-            upd_plans.append((s["scaler"], ops.plan_scaler_update(s["scaler"], 0, s["normsq_all"], 1, s["sqrt"])))
-        li = 0
-        for ii, inp in enumerate(b.inputs):
-            s = ins[ii]
             for lin in inp.linears:
                 w = weights[bi][li]
-                k = int(lin.in_features * RATIO) if b.mode == "row" else int(lin.out_features * lin.in_features * RATIO)
-                plan = ops.plan_select(w, s["sqrt"], b.mode, k=k, apply_zero=True, mask=state["masks"][bi][li],
-                                       partials=state["partials"][bi][li])
-                sel_plans.append((plan, b.mode == "row", wl.select_bytes(lin, w.element_size(), True)))
+                ws.append(w)
+                sqs.append(ins[ii]["sqrt"])
+                ks.append(int(lin.in_features * RATIO) if b.mode == "row" else int(lin.out_features * lin.in_features * RATIO))
+                nbytes += wl.select_bytes(lin, w.element_size(), True)
                 li += 1
-        steps.append((st_plans, upd_plans, sel_plans))
+        sel = ops.plan_select_batch(ws, sqs, b.mode, ks=ks, apply_zero=True, masks=state["masks"][bi],
+                                    partials=state["partials"][bi])
+        n_launch = len({(w.shape[1], k) for w, k in zip(ws, ks)}) if b.mode == "row" else 0
+        steps.append((stat, upd, sel, b.mode == "row", nbytes, n_launch))
     return steps
 
 
 def alloc_state(blocks, n_local, world, dev):
     from vlmc import ops
-    st = {"blocks": [], "masks": [], "partials": []}
+    st = {"blocks": [], "masks": [], "partials": [], "flat": []}
     for b in blocks:
         ins = []
         tot = sum(i.in_features for i in b.inputs)
-        # one flat buffer per block so that the multi-GPU exchange is a single all-gather
-        flat_local = torch.empty((n_local, tot), dtype=torch.float32, device=dev) if world > 1 else None
-        flat_all = torch.empty((N_CALIB, tot), dtype=torch.float32, device=dev) if world > 1 else None
+        # one flat [samples, sum(in)] buffer per block: the statistics kernel writes column slices of it, the
+        # multi-GPU exchange is a single all-gather of it, the running-mean kernel reads column slices of it
+        flat_local = torch.empty((n_local, tot), dtype=torch.float32, device=dev)
+        flat_all = torch.empty((N_CALIB, tot), dtype=torch.float32, device=dev) if world > 1 else flat_local
         off = 0
         for inp in b.inputs:
-            d = {"scaler": torch.zeros(inp.in_features, dtype=torch.float32, device=dev),
-                 "sqrt": torch.empty(inp.in_features, dtype=torch.float32, device=dev)}
-            if world > 1:
-                d["normsq_local"] = torch.empty((n_local, inp.in_features), dtype=torch.float32, device=dev)
-                d["normsq_all"] = torch.empty((N_CALIB, inp.in_features), dtype=torch.float32, device=dev)
-                d["slice"] = (off, off + inp.in_features)
-            else:
-                d["normsq_local"] = torch.empty((N_CALIB, inp.in_features), dtype=torch.float32, device=dev)
-                d["normsq_all"] = d["normsq_local"]
+            ins.append({"scaler": torch.zeros(inp.in_features, dtype=torch.float32, device=dev),
+                        "sqrt": torch.empty(inp.in_features, dtype=torch.float32, device=dev),
+                        "normsq_local": flat_local[:, off:off + inp.in_features],
+                        "normsq_all": flat_all[:, off:off + inp.in_features]})
             off += inp.in_features
-            ins.append(d)
         st["blocks"].append(ins)
-        if world > 1:
-            ins[0]["flat_local"], ins[0]["flat_all"] = flat_local, flat_all
+        st["flat"].append((flat_local, flat_all))
         st["masks"].append([torch.empty((l.out_features, l.in_features), dtype=torch.bool, device=dev) for l in b.linears])
         st["partials"].append([torch.empty(ops.select_partials(b.mode, l.out_features, l.in_features), dtype=torch.float64,
                                            device=dev) for l in b.linears])
@@ -148,27 +143,20 @@ def alloc_state(blocks, n_local, world, dev):
 
 
 def run_step(plans, state, world, events=None):
-    for bi, (st_plans, upd_plans, sel_plans) in enumerate(plans):
-        for p in st_plans:
-            p()
+    for bi, (stat, upd, sel, is_row, nbytes, n_launch) in enumerate(plans):
+        stat()
         if world > 1:          # ONE all-gather per block: [n_local, sum(in)] -> [128, sum(in)] in sample order
-            ins = state["blocks"][bi]
-            flat_local, flat_all = ins[0]["flat_local"], ins[0]["flat_all"]
-            torch.cat([d["normsq_local"] for d in ins], dim=1, out=flat_local)
+            flat_local, flat_all = state["flat"][bi]
             dist.all_gather_into_tensor(flat_all, flat_local)
-            for d in ins:
-                d["normsq_all"].copy_(flat_all[:, d["slice"][0]:d["slice"][1]])
-        for _scaler, p in upd_plans:
-            p()
-        for p, is_row, nbytes in sel_plans:
-            if events is not None and is_row:
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                p()
-                b.record()
-                events.append((a, b, nbytes))
-            else:
-                p()
+        upd()
+        if events is not None and is_row:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            sel()
+            b.record()
+            events.append((a, b, nbytes, n_launch))
+        else:
+            sel()
 
 
 def cpu_baseline(blocks, budget_s):
@@ -247,8 +235,9 @@ def main():
         elapsed = float(t.item())
 
     # ---- roofline of the dominant kernel: the per-row score+select kernel (T5 tower) -----------
-    tot_ms = sum(a.elapsed_time(b) for a, b, _ in events)
-    tot_bytes = sum(nb for _, _, nb in events)
+    tot_ms = sum(a.elapsed_time(b) for a, b, _, _ in events)
+    tot_bytes = sum(nb for _, _, nb, _ in events)
+    n_launches = sum(nl for _, _, _, nl in events)
     ach = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -259,9 +248,9 @@ def main():
             traffic = None
     roof = {"bound": "hbm", "kernel": "vlmc::select_rows_kernel (score+select+apply, per-row rule)",
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "launches": len(events),
-            "avg_launch_us": round(tot_ms * 1e3 / max(1, len(events)), 2),
-            "bytes_per_launch": round(tot_bytes / max(1, len(events)))}
+            "traffic": traffic, "launches": n_launches,
+            "avg_launch_us": round(tot_ms * 1e3 / max(1, n_launches), 2),
+            "bytes_per_launch": round(tot_bytes / max(1, n_launches))}
 
     out = None
     if rank == 0:

@@ -62,6 +62,17 @@ const char *vlmc_last_error(void);
 int vlmc_act_sqnorm(const void *x, int dtype, int64_t n_calls, int64_t tokens, int64_t in_features,
                     int64_t row_stride, int64_t call_stride, float *normsq /* [n_calls, in] */, void *stream);
 
+/* The same for several hook inputs in ONE launch -- the hooks of one transformer block fire
+ * in one dense pass (wanda_pruner.py:304-314), so their reductions are independent.  All jobs
+ * share dtype and n_calls; output row c of job j starts at normsq + c*normsq_stride.          */
+typedef struct vlmc_stat_job {
+    const void *x;
+    float *normsq;
+    int64_t in_features, tokens, row_stride, call_stride, normsq_stride;
+} vlmc_stat_job;
+int vlmc_act_sqnorm_batch(const vlmc_stat_job *jobs /* host array */, int n_jobs, int dtype, int64_t n_calls,
+                          void *stream);
+
 /* Running mean of wanda_pruner.py:77-81 applied for `n_calls` further calls of
  * `batch` samples each, in call order:
  *     s *= float(n / (n + batch));  n += batch;  s += normsq[c] / float(n)
@@ -71,6 +82,17 @@ int vlmc_act_sqnorm(const void *x, int dtype, int64_t n_calls, int64_t tokens, i
 int vlmc_wanda_scaler_update(float *scaler_row /* [in], in/out */, int64_t in_features, int64_t nsamples_before,
                              const float *normsq /* [n_calls, in] */, int64_t n_calls, int64_t batch,
                              float *sqrt_out /* [in] or NULL */, void *stream);
+
+/* The same recurrence for several statistics in ONE launch (one per distinct linear input of a
+ * block); row c of job j's normsq starts at normsq + c*normsq_stride.                         */
+typedef struct vlmc_update_job {
+    float *scaler_row;
+    const float *normsq;
+    float *sqrt_out;
+    int64_t in_features, normsq_stride;
+} vlmc_update_job;
+int vlmc_wanda_scaler_update_batch(const vlmc_update_job *jobs /* host array */, int n_jobs, int64_t nsamples_before,
+                                   int64_t n_calls, int64_t batch, void *stream);
 
 /* ---- K2-K7: fused score + select + apply ----------------------------------------
  * Replaces wanda_pruner.py:318-341 (T5/LLM) and :666-687 (ViT) for one linear:
@@ -86,7 +108,24 @@ int vlmc_wanda_scaler_update(float *scaler_row /* [in], in/out */, int64_t in_fe
  *                         device reduction per transformer block instead of one launch per
  *                         linear.  `vlmc_wanda_select_partials()` gives the count; may be NULL.
  * `k` is computed by the caller exactly like the reference (int(in*ratio) or
- * int(out*in*ratio)).  Only SEL_MATRIX needs a workspace (else size 0, NULL is fine). */
+ * int(out*in*ratio)).  Only SEL_MATRIX needs a workspace (else size 0, NULL is fine).
+ *
+ * vlmc_wanda_select_batch does the same for several linears -- the `for name in subset` loop of
+ * wanda_pruner.py:316-341 -- with as few launches as the shapes allow (SEL_ROW: one per distinct
+ * (in_features, k); SEL_MATRIX / SEL_NM: one launch sequence per 12 linears).  All jobs share
+ * dtype, mode, n:m and apply_zero; SEL_MATRIX jobs need DISTINCT workspaces.                   */
+typedef struct vlmc_select_job {
+    void *W;
+    int64_t out_features, in_features, ldw;
+    const float *sqrt_scaler;
+    int64_t k;
+    uint8_t *mask;
+    double *score_partials;
+    void *workspace;
+    size_t workspace_bytes;
+} vlmc_select_job;
+int vlmc_wanda_select_batch(const vlmc_select_job *jobs /* host array */, int n_jobs, int dtype, int mode, int n, int m,
+                            int apply_zero, void *stream);
 size_t vlmc_wanda_select_workspace(int mode, int64_t out_features, int64_t in_features);
 int64_t vlmc_wanda_select_partials(int mode, int64_t out_features, int64_t in_features);
 int vlmc_wanda_select(void *W, int dtype, int64_t out_features, int64_t in_features, int64_t ldw,

@@ -68,9 +68,38 @@ def wanda_select(weight, sqrt_scaler_row, mode, *, k=0, n=0, m=0, apply_zero=Tru
     return mask, partials[:nparts]
 
 
+def act_sqnorm_batch(xs, outs=None):
+    rows = [act_sqnorm(x) for x in xs]
+    if outs is not None:
+        for o, r in zip(outs, rows):
+            o.copy_(r)
+        return outs
+    return rows
+
+
+def wanda_scaler_update_batch(scalers, nsamples_before, normsqs, batch=1, sqrt_outs=None):
+    sqrt_outs = [None] * len(scalers) if sqrt_outs is None else sqrt_outs
+    n = nsamples_before
+    for s, nsq, sq in zip(scalers, normsqs, sqrt_outs):
+        n = wanda_scaler_update(s, nsamples_before, nsq.contiguous(), batch, sqrt_out=sq)
+    return n
+
+
+def wanda_select_batch(weights, sqrt_rows, mode, *, ks=None, n=0, m=0, apply_zero=True, masks=None, partials=None):
+    ks = [0] * len(weights) if ks is None else ks
+    out_m, out_p = [], []
+    for i, (w, sq) in enumerate(zip(weights, sqrt_rows)):
+        mk, pt = wanda_select(w, sq, mode, k=ks[i], n=n, m=m, apply_zero=apply_zero,
+                              mask=None if masks is None else masks[i], partials=None if partials is None else partials[i])
+        out_m.append(mk)
+        out_p.append(pt)
+    return out_m, out_p
+
+
 def install(monkeypatch):
     from vlmc import ops
-    for name in ("act_sqnorm", "wanda_scaler_update", "sqrt_scaler", "select_partials", "wanda_select"):
+    for name in ("act_sqnorm", "wanda_scaler_update", "sqrt_scaler", "select_partials", "wanda_select", "act_sqnorm_batch",
+                 "wanda_scaler_update_batch", "wanda_select_batch"):
         monkeypatch.setattr(ops, name, globals()[name])
 
 

@@ -1,0 +1,180 @@
+"""GPU: the batched C-ABI entry points (all hook inputs / statistics / linears of one transformer
+block per launch) against the single-job entry points and the CPU oracle, bit for bit; plus the
+SEL_MATRIX selection's fast path (sample bracket + two counting passes) and its exact fallback."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import wanda as OW
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ops():
+    from vlmc import ops
+    return ops
+
+
+def _w(out_f, in_f, dtype, seed, zero_frac=0.0):
+    g = torch.Generator().manual_seed(seed)
+    W = (torch.randn(out_f, in_f, generator=g) * 0.02).to(dtype)
+    if zero_frac:
+        W[torch.rand(out_f, in_f, generator=g) < zero_frac] = 0
+    s = (torch.rand(in_f, generator=g) * 4 + 0.01).numpy().astype(np.float32)
+    return W, s
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+def test_sqnorm_batch_equals_single_calls_and_oracle(dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(5, 37, 1408), (5, 37, 6144), (5, 9, 2048), (5, 37, 100), (5, 1, 8)]
+    xs = [((torch.randn(s, generator=g) * 2) + 0.1).to(dtype).to(DEV) for s in shapes]
+    flat = torch.full((5, sum(s[2] for s in shapes) + 3), -1.0, dtype=torch.float32, device=DEV)
+    outs, off = [], 0
+    for s in shapes:
+        outs.append(flat[:, off:off + s[2]])
+        off += s[2]
+    ops.act_sqnorm_batch(xs, outs)
+    for x, o in zip(xs, outs):
+        single = ops.act_sqnorm(x)
+        assert torch.equal(o, single)
+        want = np.stack([OW.act_sqnorm(x[c].cpu()) for c in range(x.shape[0])])
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert bool((flat[:, off:] == -1.0).all())                   # nothing written past the jobs' columns
+    auto = ops.act_sqnorm_batch(xs)                              # library-allocated outputs
+    assert all(torch.equal(a, o) for a, o in zip(auto, outs))
+
+
+def test_sqnorm_batch_more_jobs_than_one_launch_holds():
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    xs = [torch.randn((3, 5, 64 + 8 * j), generator=g).to(torch.bfloat16).to(DEV) for j in range(15)]
+    outs = ops.act_sqnorm_batch(xs)
+    for x, o in zip(xs, outs):
+        assert torch.equal(o, ops.act_sqnorm(x))
+
+
+def test_scaler_update_batch_equals_single_calls():
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    widths = [1408, 6144, 2048, 100, 8]
+    calls = 130                                                  # > one LDS panel of 128 calls
+    flat = (torch.rand((calls, sum(widths)), generator=g) * 50).to(DEV)
+    nsqs, off = [], 0
+    for w in widths:
+        nsqs.append(flat[:, off:off + w])
+        off += w
+    scal = [torch.zeros(w, dtype=torch.float32, device=DEV) for w in widths]
+    sq = [torch.empty(w, dtype=torch.float32, device=DEV) for w in widths]
+    n = ops.wanda_scaler_update_batch(scal, 0, nsqs, 1, sq)
+    assert n == calls
+    for w, nsq, s_b, q_b in zip(widths, nsqs, scal, sq):
+        s1 = torch.zeros(w, dtype=torch.float32, device=DEV)
+        q1 = torch.empty_like(s1)
+        ops.wanda_scaler_update(s1, 0, nsq.contiguous(), 1, sqrt_out=q1)
+        assert torch.equal(s1, s_b) and torch.equal(q1, q_b)
+        ref, nn = np.zeros(w, np.float32), 0
+        for c in range(calls):
+            ref, nn = OW.scaler_update(ref, nn, nsq[c].cpu().numpy(), 1)
+        assert np.array_equal(ref.view(np.uint32), s_b.cpu().numpy().view(np.uint32))
+    # continuing from a non-zero sample count with batch 2
+    n2 = ops.wanda_scaler_update_batch(scal[:2], n, [nsqs[0][:3], nsqs[1][:3]], 2, None)
+    assert n2 == calls + 6
+
+
+def _single(W, s, mode, **kw):
+    ops = _ops()
+    Wd = W.clone().to(DEV)
+    mask, parts = ops.wanda_select(Wd, ops.sqrt_scaler(torch.from_numpy(s).to(DEV)), mode, **kw)
+    return mask, Wd, parts
+
+
+@pytest.mark.parametrize("mode", ["row", "matrix", "nm"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_select_batch_equals_single_calls(mode, dtype):
+    ops = _ops()
+    shapes = [(64, 256), (64, 256), (96, 512), (40, 256), (33, 104), (96, 512), (8, 256)]
+    cases = [_w(o, i, dtype, 100 + j, zero_frac=0.1 if j == 3 else 0.0) for j, (o, i) in enumerate(shapes)]
+    Ws = [c[0].clone().to(DEV) for c in cases]
+    sqs = [ops.sqrt_scaler(torch.from_numpy(c[1]).to(DEV)) for c in cases]
+    if mode == "row":
+        kw, ks = {}, [int(i * 0.5) for _, i in shapes]
+    elif mode == "matrix":
+        kw, ks = {}, [int(o * i * 0.45) for o, i in shapes]
+    else:
+        kw, ks = dict(n=2, m=4), None
+    masks, parts = ops.wanda_select_batch(Ws, sqs, mode, ks=ks, apply_zero=True, **kw)
+    for j, (W, s) in enumerate(cases):
+        skw = dict(kw) if mode == "nm" else dict(k=ks[j])
+        m1, W1, p1 = _single(W, s, mode, **skw)
+        assert torch.equal(masks[j], m1), (mode, j)
+        assert torch.equal(Ws[j], W1), (mode, j)
+        assert float(parts[j].sum()) == pytest.approx(float(p1.sum()), rel=1e-12)
+        want = OW.prune_linear(W, s, mode, ratio=0.5 if mode == "row" else 0.45, n=2 if mode == "nm" else 0,
+                               m=4 if mode == "nm" else 0)
+        assert np.array_equal(masks[j].cpu().numpy(), want["mask"]), (mode, j)
+
+
+def _check_matrix(W, s, k):
+    mask, Wd, parts = _single(W, s, "matrix", k=k)
+    score = OW.wanda_score(W, s)
+    pruned = OW.select_matrix(score, k)
+    assert np.array_equal(mask.cpu().numpy(), ~pruned)
+    want_w = W.clone()
+    want_w[torch.from_numpy(pruned)] = 0
+    assert torch.equal(Wd.cpu(), want_w)
+    return int(pruned.sum())
+
+
+@pytest.mark.parametrize("shape", [(4224, 1408), (1408, 6144), (1000, 1001)])
+@pytest.mark.parametrize("ratio", [0.5, 0.02, 0.97])
+def test_matrix_select_model_shapes_vs_oracle(shape, ratio):
+    W, s = _w(shape[0], shape[1], torch.float16, 11)
+    n = _check_matrix(W, s, int(W.numel() * ratio))
+    assert abs(n - int(W.numel() * ratio)) <= 64                 # strict '<' may drop a few tied elements only
+
+
+def test_matrix_select_fallback_path_is_exact(monkeypatch):
+    W, s = _w(512, 1408, torch.float16, 12)
+    monkeypatch.setenv("VLMC_MATRIX_FORCE_SLOW", "1")
+    _check_matrix(W, s, int(W.numel() * 0.5))
+    _check_matrix(W, s, 0)
+    _check_matrix(W, s, W.numel() - 1)
+
+
+@pytest.mark.parametrize("zero_frac,ratio", [(0.5, 0.5), (0.5, 0.25), (0.5, 0.75), (0.9, 0.95)])
+def test_matrix_select_already_sparse_weights(zero_frac, ratio):
+    """Half the scores are exactly 0: the sample bracket spans from key 0 to a normal float (wider than
+    the two counting passes resolve) or sits inside the tie run -- both must still be exact."""
+    W, s = _w(600, 1408, torch.bfloat16, 13, zero_frac=zero_frac)
+    _check_matrix(W, s, int(W.numel() * ratio))
+
+
+def test_matrix_select_extreme_ranks_and_nan():
+    W, s = _w(300, 704, torch.float16, 14)
+    for k in (0, 1, W.numel() // 2, W.numel() - 2, W.numel() - 1):
+        _check_matrix(W, s, k)
+    s2 = s.copy()
+    s2[5] = np.nan                                               # NaN scores sort last; a NaN threshold prunes nothing
+    mask, _, _ = _single(W, s2, "matrix", k=W.numel() - 1)
+    assert bool(mask.all())
+    _check_matrix(W, s2, W.numel() // 3)
+
+
+def test_select_batch_rejects_shared_workspace_and_bad_args():
+    from vlmc import _lib
+    ops = _ops()
+    W, s = _w(16, 64, torch.float16, 15)
+    Wd = W.to(DEV)
+    sq = ops.sqrt_scaler(torch.from_numpy(s).to(DEV))
+    mk = torch.empty((16, 64), dtype=torch.bool, device=DEV)
+    ws = torch.empty(1 << 16, dtype=torch.uint8, device=DEV)
+    jobs = (_lib.SelectJob * 2)()
+    for j in range(2):
+        jobs[j] = _lib.SelectJob(Wd.data_ptr(), 16, 64, 64, sq.data_ptr(), 10, mk.data_ptr(), None, ws.data_ptr(), ws.numel())
+    lib = _lib.load()
+    assert lib.vlmc_wanda_select_batch(jobs, 2, _lib.F16, _lib.SEL_MATRIX, 0, 0, 1, None) == _lib.VLMC_EINVAL
+    assert b"share a workspace" in lib.vlmc_last_error()
+    assert lib.vlmc_wanda_select_batch(jobs, 0, _lib.F16, _lib.SEL_ROW, 0, 0, 1, None) == _lib.VLMC_EINVAL

@@ -19,35 +19,39 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("name", list(H.VARIANTS))
 def test_pruner_on_gpu_every_launch_matches_oracle(name, monkeypatch):
     from vlmc import ops, wanda
-    real_sq, real_prune = ops.act_sqnorm, wanda.prune_linear
-    counts = {"sqnorm": 0, "select": 0}
+    real_sq, real_prune = ops.act_sqnorm_batch, wanda.prune_block
+    counts = {"sqnorm_launches": 0, "sqnorm_inputs": 0, "select": 0, "blocks": 0}
 
-    def checked_sqnorm(x, out=None):
-        r = real_sq(x, out=out)
-        got = r.cpu().numpy()
-        for c in range(x.shape[0]):
-            want = OW.act_sqnorm(x[c].cpu())
-            assert np.array_equal(got[c].view(np.uint32), want.view(np.uint32))
-        counts["sqnorm"] += 1
-        return r
+    def checked_sqnorm(xs, outs=None):
+        rows = real_sq(xs, outs)
+        for x, r in zip(xs, rows):
+            got = r.cpu().numpy()
+            for c in range(x.shape[0]):
+                want = OW.act_sqnorm(x[c].cpu())
+                assert np.array_equal(got[c].view(np.uint32), want.view(np.uint32))
+        counts["sqnorm_launches"] += 1
+        counts["sqnorm_inputs"] += len(xs)
+        return rows
 
-    def checked_prune(weight, stat, mode, *, ratio=None, n=0, m=0, apply_zero=True, mask=None, partials=None):
-        W0 = weight.detach().clone().cpu()
-        s = stat.scaler_row.cpu().numpy()
-        mask, parts = real_prune(weight, stat, mode, ratio=ratio, n=n, m=m, apply_zero=apply_zero, mask=mask,
-                                 partials=partials)
-        want = OW.prune_linear(W0, s, mode, ratio=ratio, n=n, m=m, apply_zero=apply_zero)
-        assert np.array_equal(mask.cpu().numpy(), want["mask"]), f"{mode} mask differs from oracle"
-        assert torch.equal(weight.detach().cpu(), want["weight"])
-        counts["select"] += 1
-        return mask, parts
+    def checked_block(weights, stats, mode, *, ratios=None, n=0, m=0, apply_zero=True, partials=None):
+        W0 = [w.detach().clone().cpu() for w in weights]
+        masks = real_prune(weights, stats, mode, ratios=ratios, n=n, m=m, apply_zero=apply_zero, partials=partials)
+        for w0, w, st, mk, ratio in zip(W0, weights, stats, masks, ratios):
+            want = OW.prune_linear(w0, st.scaler_row.cpu().numpy(), mode, ratio=ratio, n=n, m=m, apply_zero=apply_zero)
+            assert np.array_equal(mk.cpu().numpy(), want["mask"]), f"{mode} mask differs from oracle"
+            assert torch.equal(w.detach().cpu(), want["weight"])
+            counts["select"] += 1
+        counts["blocks"] += 1
+        return masks
 
-    monkeypatch.setattr(ops, "act_sqnorm", checked_sqnorm)
-    monkeypatch.setattr(wanda, "prune_linear", checked_prune)
+    monkeypatch.setattr(ops, "act_sqnorm_batch", checked_sqnorm)
+    monkeypatch.setattr(wanda, "prune_block", checked_block)
     pruned, _ = H.run_pruner(name, "cuda:0")
-    assert counts["select"] == 2 * 4 + 2 * 7 + 2 * 11
-    # shared inputs are reduced once: per sample 4 (ViT) / 4 (enc) / 7 (dec) distinct tensors, not 4 / 7 / 11
-    assert counts["sqnorm"] == 6 * (2 * 4 + 2 * 4 + 2 * 7)
+    assert counts["select"] == 2 * 4 + 2 * 7 + 2 * 11 and counts["blocks"] == 6
+    # shared inputs are reduced once: per sample 4 (ViT) / 4 (enc) / 7 (dec) distinct tensors, not 4 / 7 / 11,
+    # and all distinct inputs of one sample's block forward go in one launch
+    assert counts["sqnorm_inputs"] == 6 * (2 * 4 + 2 * 4 + 2 * 7)
+    assert counts["sqnorm_launches"] == 6 * 6
     st = H.compare_with_golden(name, pruned, exact=False, min_mask_agreement=0.99)
     print(name, st)
     for mn, mod in pruned.named_modules():

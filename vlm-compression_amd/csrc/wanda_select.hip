@@ -10,10 +10,12 @@
 //             key is found by radix-64 refinement of a bracket with 64 LDS counters (6 key bits
 //             per sweep), seeded by a 32-key sample of the row; ties are broken by column index
 //             exactly like the reference's stable sort.  See the kernel's header comment.
-//  SEL_MATRIX three global radix-histogram passes (12+10+10 key bits, LDS histograms flushed with
-//             integer atomics), then an elementwise apply pass.  W (<= 17 MB for ViT-g) is
-//             re-read from L2/Infinity Cache, not HBM.
+//  SEL_MATRIX sample -> bracket, two counting passes (4096 LDS bins inside the bracket, then inside
+//             the bin that holds rank k), one elementwise apply pass; a one-workgroup exact radix
+//             select is the (normally idle) fallback.  See the section comment below.
 //  SEL_NM     elementwise: each lane ranks the columns of its m-groups in registers.
+// Every kernel takes a table of up to 12 linears ("jobs") by value, so all linears of a transformer
+// block that share a launch shape go to the GPU in ONE launch.
 #include <cstdlib>
 
 #include "common.hpp"
@@ -117,6 +119,35 @@ __device__ __forceinline__ void load_sq_chunk(const float *sq, int64_t col0, int
 }
 
 // ------------------------------------------------------------------------------------------
+// job table (kernel argument, passed by value)
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxSelJobs = 12;
+constexpr int kMatrixParts = 512;   // score partial sums per SEL_MATRIX job (= max workgroups per job)
+constexpr int kNmParts = 2048;      // ... per SEL_NM job
+struct SelJob {
+    void *W;
+    const float *sq;          // sqrt(scaler_row) [in]
+    uint8_t *mask;            // [out, in]
+    double *parts;            // score partial sums (may be null)
+    uint32_t *ws;             // SEL_MATRIX workspace
+    uint32_t out_f, in_f, ldw;
+    uint32_t k;               // SEL_ROW: columns pruned per row; SEL_MATRIX: flat rank of the threshold
+    uint32_t unit_end;        // exclusive prefix end of this job's grid units (rows or workgroups)
+    uint32_t nwg;             // workgroups of this job in the elementwise passes
+};
+struct SelBatch {
+    SelJob job[kMaxSelJobs];
+    int32_t n, apply_zero;
+    uint32_t p0, p1;          // SEL_ROW: sample margin, k/in as Q16; SEL_NM: n; SEL_MATRIX: force-slow flag
+};
+__device__ __forceinline__ int find_job(const SelBatch &b, uint32_t unit, uint32_t &local) {
+    int j = 0;
+    while (j + 1 < b.n && unit >= b.job[j].unit_end) ++j;
+    local = unit - (j ? b.job[j - 1].unit_end : 0u);
+    return j;
+}
+
+// ------------------------------------------------------------------------------------------
 // SEL_ROW: one workgroup of NW waves per row, grid = rows (the hardware dispatcher overlaps
 // rows that are loading, searching and storing on every SIMD).
 //
@@ -194,16 +225,21 @@ template <int NW> __device__ __forceinline__ void row_sync() {
 
 template <typename T, int CH, int NW, bool ALIGNED>
 __global__ __launch_bounds__(64 * NW, (NW * CH >= 4 && CH >= 3) ? 5 : 8)
-void select_rows_kernel(typename T::raw *__restrict__ W, int64_t out_f, int64_t in_f, int64_t ldw,
-                        const float *__restrict__ sqrt_scaler, uint32_t k, int apply_zero, uint8_t *__restrict__ mask,
-                        double *__restrict__ row_sums, uint32_t sample_margin, uint32_t frac_q16) {
+void select_rows_kernel(const SelBatch b) {
     constexpr int NT = 64 * NW;
     constexpr int E = CH * 8;
     __shared__ RowSmem<NW> sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t row32;
+    const SelJob &jb = b.job[find_job(b, blockIdx.x, row32)];
+    const int64_t in_f = jb.in_f, row = row32;
+    const float *__restrict__ sqrt_scaler = jb.sq;
+    uint8_t *__restrict__ mask = jb.mask;
+    double *__restrict__ row_sums = jb.parts;
+    const uint32_t k = jb.k, sample_margin = b.p0, frac_q16 = b.p1;
+    const int apply_zero = b.apply_zero;
     const int64_t nchunks = (in_f + 7) / 8;
-    const int64_t row = blockIdx.x;
-    typename T::raw *wrow = W + row * ldw;
+    typename T::raw *wrow = static_cast<typename T::raw *>(jb.W) + row * int64_t(jb.ldw);
     const uint32_t sink = uint32_t(kBins + tid);
     const uint32_t tid8 = uint32_t(tid) * 8u;
 #ifdef VLMC_STAMPS
@@ -449,122 +485,308 @@ void select_rows_kernel(typename T::raw *__restrict__ W, int64_t out_f, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------
-// SEL_MATRIX : global radix select (12 + 10 + 10 bits)
+// SEL_MATRIX: thr = sort(score.flatten())[k]; prune score < thr  (wanda_pruner.py:682-683)
+//
+//   sample   one workgroup per linear: 2048 random samples -> two order statistics
+//            (coarse LDS histogram) bracket the threshold to ~15 % of the elements with a 6-sigma
+//            margin; also clears the job's workspace (no memset launches).
+//   pass A   streams W once: count(key < lo) in registers, keys inside the bracket bump one of
+//            4096 LDS counters ((key-lo) >> shift; ~15 % of the elements, spread over the bins, so
+//            the LDS atomics are cheap).  The LAST workgroup to finish (device-scope counter)
+//            scans the merged histogram and publishes the bin that holds rank k.
+//   pass B   streams W again (<= 17 MB per ViT-g linear: served by the Infinity Cache), counting
+//            per key inside that one bin (~100 elements) -> the exact threshold key.
+//   apply    elementwise mask + zeroing + score partial sums.
+//   slow     one workgroup per linear, idle unless the bracket missed rank k or was wider than
+//            2^24 keys (then an exact 4 x 8-bit radix select over the whole matrix).  Every decision
+//            rests on exact counts; sampling only affects speed.
+// Workspace per job (u32 words): histA[4096] | histB[4096] | ctrl[16].
 // ------------------------------------------------------------------------------------------
-constexpr int kBits0 = 12, kBits1 = 10, kBits2 = 10;
-constexpr int kBins0 = 1 << kBits0, kBins1 = 1 << kBits1, kBins2 = 1 << kBits2;
-constexpr int kHistTotal = kBins0 + kBins1 + kBins2;
+constexpr int kMatBins = 4096;
+constexpr int kMatSample = 2048;   // one CU issues every sample load: the sample size is what its kernel costs
+constexpr int kCtrl = 2 * kMatBins;
+constexpr int kWsWords = 2 * kMatBins + 16;
+enum { C_LO = 0, C_SHIFT, C_BELOW, C_DONE_A, C_LOB, C_SHIFTB, C_RANKB, C_DONE_B, C_THR, C_FAIL, C_SKIPB };
 
-__device__ __forceinline__ int pass_bins(int p) { return p == 0 ? kBins0 : (p == 1 ? kBins1 : kBins2); }
-__device__ __forceinline__ int pass_shift(int p) { return p == 0 ? 20 : (p == 1 ? 10 : 0); }
-__device__ __forceinline__ int pass_off(int p) { return p == 0 ? 0 : (p == 1 ? kBins0 : kBins0 + kBins1); }
+__device__ __forceinline__ uint32_t ld_dev(const uint32_t *p) {       // device-scope load (bypasses the CU's L1)
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
-// Walk the finished histograms of passes [0, npass): returns the key prefix (bits above the next
-// pass's digit) that contains rank `r`, and the rank left inside it.  Every workgroup recomputes
-// this from the global histograms (a few KB from L2) instead of a separate tiny launch.
-__device__ void resolve_prefix(const uint32_t *__restrict__ hist, int npass, uint64_t r, uint32_t *sh /*>=258 u32*/,
-                               uint32_t &prefix, uint64_t &rank) {
-    prefix = 0;
-    rank = r;
+// Rank search over a histogram held 4 bins per thread by the first nthreads*4 bins of a 1024-thread
+// workgroup: finds the bin with cum <= need < cum + h.  Returns false if need >= total.
+__device__ bool block_find_rank(const uint32_t (&h)[4], uint32_t need, uint32_t *red /*>= 20 u32 of LDS*/, uint32_t &bin,
+                                uint32_t &before) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t s = h[0] + h[1] + h[2] + h[3];
+    const uint32_t incl = wave_incl_scan_u32_dpp(s);
+    if (lane == 63) red[wave] = incl;
+    if (tid == 0) red[16] = 0xFFFFFFFFu;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int w = 0; w < wave; ++w) off += red[w];
+    const uint32_t hi = off + incl, lo = hi - s;
+    if (lo <= need && need < hi) {
+        uint32_t cum = lo;
+        int i = 0;
+        for (; i < 3; ++i) {
+            if (cum + h[i] > need) break;
+            cum += h[i];
+        }
+        red[16] = uint32_t(tid * 4 + i);
+        red[17] = cum;
+    }
+    __syncthreads();
+    bin = red[16];
+    before = red[17];
+    __syncthreads();
+    return bin != 0xFFFFFFFFu;
+}
+
+template <typename T>
+__device__ __forceinline__ uint32_t element_key(const SelJob &jb, uint32_t e) {
+    const uint32_t row = e / jb.in_f, col = e - row * jb.in_f;
+    const typename T::raw w = static_cast<const typename T::raw *>(jb.W)[int64_t(row) * jb.ldw + col];
+    return score_key(ieee_mul(fabsf(to_f32<T>(w)), jb.sq[col]));
+}
+
+// Coarse bin of a key for the sample histogram: sign/exponent + 4 mantissa bits (2^19 keys per bin).
+constexpr int kCoarseShift = 19;
+__device__ __forceinline__ uint32_t coarse_bin(uint32_t key) {
+    const uint32_t b = key >> kCoarseShift;
+    return b < uint32_t(kMatBins) ? b : uint32_t(kMatBins - 1);   // NaN keys (0xFFFFFFFF) -> last bin
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void matrix_sample_kernel(const SelBatch b) {
+    __shared__ uint32_t hist[kMatBins];
+    __shared__ uint32_t red[20];
+    const SelJob &jb = b.job[blockIdx.x];
     const int tid = threadIdx.x;
-    for (int p = 0; p < npass; ++p) {
-        const uint32_t *h = hist + pass_off(p);
-        const int per = pass_bins(p) / 256;              // 16 or 4 bins per scanning thread
-        if (tid < 256) {
-            uint32_t a = 0;
-            for (int i = 0; i < per; ++i) a += h[tid * per + i];
-            sh[tid] = a;
-        }
-        __syncthreads();
-        if (tid < 64) {                                   // wave 0: scan 64 groups of 4 partials
-            const uint32_t a = sh[4 * tid] + sh[4 * tid + 1] + sh[4 * tid + 2] + sh[4 * tid + 3];
-            const uint64_t incl = wave_incl_scan_u32(a);  // numel < 2^32
-            const unsigned long long hit = __ballot(incl > rank);
-            const int owner = hit ? __ffsll((long long)hit) - 1 : 63;
-            if (tid == owner) {
-                uint64_t cum = incl - a;
-                int t = 4 * tid;
-                for (; t < 4 * tid + 3; ++t) {
-                    if (cum + sh[t] > rank) break;
-                    cum += sh[t];
-                }
-                int b = t * per;
-                for (; b < t * per + per - 1; ++b) {
-                    const uint32_t c = h[b];
-                    if (cum + c > rank) break;
-                    cum += c;
-                }
-                sh[256] = uint32_t(b);
-                sh[257] = uint32_t(rank - cum);
-            }
-        }
-        __syncthreads();
-        prefix |= sh[256] << pass_shift(p);
-        rank = sh[257];
-        __syncthreads();
+    uint32_t *ws = jb.ws;
+    for (int i = tid; i < kWsWords; i += 1024) ws[i] = 0;
+    for (int i = tid; i < kMatBins; i += 1024) hist[i] = 0;
+    __syncthreads();                                             // ctrl words are rewritten below
+    const uint32_t numel = jb.out_f * jb.in_f;
+    const uint32_t S = numel < uint32_t(kMatSample) ? numel : uint32_t(kMatSample);
+    // uniform sampling with replacement: (row, col) = two multiplicative hashes scaled by mul-high (no integer
+    // division: this single workgroup is instruction-bound); all 16 loads of a lane are issued before the first use
+    const typename T::raw *W = static_cast<const typename T::raw *>(jb.W);
+    constexpr int SPT = kMatSample / 1024;                       // samples per thread
+    uint32_t col[SPT];
+    typename T::raw wv[SPT];
+    float sv[SPT];
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+        const uint32_t i = uint32_t(tid) + 1024u * j;
+        uint32_t h = (i + 1u) * 2654435761u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const uint32_t row = __umulhi(h, jb.out_f);
+        h *= 3266489917u; h ^= h >> 16;
+        col[j] = __umulhi(h, jb.in_f);
+        const bool on = i < S;
+        col[j] = on ? col[j] : 0u;
+        wv[j] = W[on ? int64_t(row) * jb.ldw + col[j] : 0];
+    }
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) sv[j] = jb.sq[col[j]];
+#pragma unroll
+    for (int j = 0; j < SPT; ++j)
+        if (uint32_t(tid) + 1024u * j < S)
+            atomicAdd(&hist[coarse_bin(score_key(ieee_mul(fabsf(to_f32<T>(wv[j])), sv[j])))], 1u);
+    __syncthreads();
+    // sample ranks that bracket flat rank k with a 6-sigma margin, resolved to whole coarse bins
+    const uint32_t rs = uint32_t((uint64_t(jb.k) * S) / numel);
+    const float pr = float(jb.k) / float(numel);
+    const uint32_t margin = uint32_t(6.f * sqrtf(float(S) * pr * (1.f - pr))) + 8u;
+    uint32_t h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = hist[tid * 4 + i];
+    uint32_t lo = 0, hi = 0xFFFFFFFFu, bin, before;
+    if (rs > margin) {
+        block_find_rank(h, rs - margin, red, bin, before);
+        lo = bin << kCoarseShift;
+    }
+    if (rs + margin < S) {
+        block_find_rank(h, rs + margin, red, bin, before);
+        if (bin < uint32_t(kMatBins - 1)) hi = ((bin + 1u) << kCoarseShift) - 1u;
+    }
+    uint32_t shift = 0;
+    while (((hi - lo) >> shift) >= uint32_t(kMatBins)) ++shift;
+    if (tid == 0) {
+        ws[kCtrl + C_LO] = lo;
+        ws[kCtrl + C_SHIFT] = shift;
+        if (b.p0) ws[kCtrl + C_FAIL] = 1;            // test hook: force the slow path
     }
 }
 
+// One streaming pass over a job's matrix.  PASS 0: bracket histogram (+ below count); PASS 1: per-key
+// histogram inside the bin found by pass 0.
 template <typename T, bool ALIGNED, int PASS>
-__global__ __launch_bounds__(1024) void matrix_hist_kernel(const typename T::raw *__restrict__ W, int64_t out_f,
-                                                           int64_t in_f, int64_t ldw, const float *__restrict__ sq,
-                                                           uint64_t k_index, uint32_t *__restrict__ hist) {
-    constexpr int BINS = PASS == 0 ? kBins0 : (PASS == 1 ? kBins1 : kBins2);
-    constexpr int SHIFT = PASS == 0 ? 20 : (PASS == 1 ? 10 : 0);
-    __shared__ uint32_t lh[BINS];
-    __shared__ uint32_t sh[260];
-    for (int i = threadIdx.x; i < BINS; i += blockDim.x) lh[i] = 0;
-    uint32_t prefix = 0;
-    uint64_t rank = 0;
-    resolve_prefix(hist, PASS, k_index, sh, prefix, rank);   // also the barrier after zeroing lh
-    if constexpr (PASS == 0) __syncthreads();
-    const uint32_t pmask = PASS == 0 ? 0u : (PASS == 1 ? 0xFFF00000u : 0xFFFFFC00u);
-
-    const int64_t cpr = (in_f + 7) / 8;                     // chunks per row
-    const int64_t total = out_f * cpr;
-    for (int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; c < total; c += int64_t(gridDim.x) * blockDim.x) {
-        const int64_t row = c / cpr, col0 = (c - row * cpr) * 8;
-        Chunk8<T> raw = load_row_chunk<T, ALIGNED>(W + row * ldw, col0, in_f);
-        float sqv[8];
-        load_sq_chunk<ALIGNED>(sq, col0, in_f, sqv);
+__global__ __launch_bounds__(1024) void matrix_count_kernel(const SelBatch b) {
+    __shared__ uint32_t lh[kMatBins];
+    __shared__ uint32_t red[20];
+    uint32_t wg;
+    const SelJob &jb = b.job[find_job(b, blockIdx.x, wg)];
+    const int tid = threadIdx.x;
+    uint32_t *ws = jb.ws;
+    // the control block, written by earlier launches only: fetched with three 16-byte loads issued together
+    const uint4 c0 = reinterpret_cast<const uint4 *>(ws + kCtrl)[0], c1 = reinterpret_cast<const uint4 *>(ws + kCtrl)[1],
+                c2 = reinterpret_cast<const uint4 *>(ws + kCtrl)[2];
+    if (c2.y /* C_FAIL */) return;
+    if (PASS == 1 && c2.z /* C_SKIPB */) return;
+    for (int i = tid; i < kMatBins; i += 1024) lh[i] = 0;
+    const uint32_t lo = PASS == 0 ? c0.x /* C_LO */ : c1.x /* C_LOB */;
+    const uint32_t wshift = c0.y /* C_SHIFT */;                  // PASS 1: window = one pass-0 bin = 2^wshift keys
+    const uint32_t shift = PASS == 0 ? wshift : c1.y /* C_SHIFTB */;
+    const uint32_t rankb = c1.z /* C_RANKB */;
+    const uint32_t span = PASS == 0 ? uint32_t(kMatBins) : ((1u << wshift) >> shift);   // bins in use
+    __syncthreads();
+    const uint32_t in_f = jb.in_f, cpr = (in_f + 7) / 8, total = jb.out_f * cpr;
+    const typename T::raw *W = static_cast<const typename T::raw *>(jb.W);
+    uint32_t below = 0;
+    const uint32_t step = jb.nwg * 1024u, step_rows = step / cpr, step_cir = step - step_rows * cpr;
+    constexpr int NCH = 4;                                       // chunks in flight per lane
+    for (uint32_t cb = wg * 1024u + uint32_t(tid); cb < total; cb += NCH * step) {
+        Chunk8<T> raw[NCH];
+        float sqv[NCH][8];
+        uint32_t col0[NCH];
+        bool has[NCH];
+        // (row, chunk-in-row) of cb by one division, of cb + u*step by carry arithmetic
+        uint32_t row = cb / cpr, cir = cb - row * cpr;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (ALIGNED || col0 + j < in_f) {
-                const uint32_t key = score_key(ieee_mul(fabsf(to_f32<T>(raw.v[j])), sqv[j]));
-                if ((key & pmask) == prefix) atomicAdd(&lh[(key >> SHIFT) & (BINS - 1)], 1u);
+        for (int u = 0; u < NCH; ++u) {
+            has[u] = cb + uint32_t(u) * step < total;
+            col0[u] = cir * 8;
+            raw[u] = load_row_chunk<T, ALIGNED>(W + int64_t(has[u] ? row : 0u) * jb.ldw, has[u] ? col0[u] : 0u, in_f);
+            row += step_rows;
+            cir += step_cir;
+            if (cir >= cpr) { cir -= cpr; ++row; }
+        }
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) load_sq_chunk<ALIGNED>(jb.sq, col0[u], in_f, sqv[u]);
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            if (!has[u]) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (ALIGNED || col0[u] + j < in_f) {
+                    const uint32_t key = score_key(ieee_mul(fabsf(to_f32<T>(raw[u].v[j])), sqv[u][j]));
+                    if (PASS == 0) below += key < lo ? 1u : 0u;
+                    const uint32_t d = (key - lo) >> shift;
+                    if (key >= lo && d < span) atomicAdd(&lh[d], 1u);
+                }
             }
         }
     }
+    uint32_t *gh = ws + (PASS == 0 ? 0 : kMatBins);
+    if (PASS == 0) {
+        const uint32_t wsum = wave_sum_u32_dpp(below);
+        if ((tid & 63) == 0) red[tid >> 6] = wsum;
+    }
     __syncthreads();
-    uint32_t *gh = hist + (PASS == 0 ? 0 : (PASS == 1 ? kBins0 : kBins0 + kBins1));
-    for (int i = threadIdx.x; i < BINS; i += blockDim.x) {
+    for (int i = tid; i < kMatBins; i += 1024) {
         const uint32_t v = lh[i];
         if (v) atomicAdd(&gh[i], v);
+    }
+    if (PASS == 0 && tid == 0) {
+        uint32_t bsum = 0;
+        for (int w = 0; w < 16; ++w) bsum += red[w];
+        if (bsum) atomicAdd(&ws[kCtrl + C_BELOW], bsum);
+    }
+    // ---- last workgroup of this job resolves the merged histogram ---------------------------------
+    // Everything exchanged between workgroups here goes through device-scope atomics (performed at the
+    // memory side, not in the per-XCD L2), so ordering only needs "my atomics have been performed" before
+    // the done-counter increment: wait for their acknowledgements.  A __threadfence() would write back and
+    // invalidate the XCD's whole L2 in every workgroup (measured: 0.5 ms per launch).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) red[18] = atomicAdd(&ws[kCtrl + (PASS == 0 ? C_DONE_A : C_DONE_B)], 1u);
+    __syncthreads();
+    if (red[18] != jb.nwg - 1) return;
+    uint32_t h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = ld_dev(&gh[tid * 4 + i]);
+    uint32_t need, bin, before;
+    bool ok = true;
+    if (PASS == 0) {
+        const uint32_t bel = ld_dev(&ws[kCtrl + C_BELOW]);
+        ok = bel <= jb.k;
+        need = jb.k - bel;
+    } else {
+        need = rankb;
+    }
+    ok = block_find_rank(h, need, red, bin, before) && ok;
+    if (tid == 0) {
+        if (!ok) {
+            ws[kCtrl + C_FAIL] = 1;
+        } else if (PASS == 0) {
+            const uint32_t lob = lo + (bin << shift);
+            ws[kCtrl + C_LOB] = lob;
+            ws[kCtrl + C_RANKB] = need - before;
+            ws[kCtrl + C_SHIFTB] = shift > 12u ? shift - 12u : 0u;
+            if (shift == 0) { ws[kCtrl + C_THR] = lob; ws[kCtrl + C_SKIPB] = 1; }
+        } else {
+            if (shift != 0) ws[kCtrl + C_FAIL] = 1;              // window wider than 4096 keys: not exact
+            else ws[kCtrl + C_THR] = lo + bin;
+        }
+    }
+}
+
+// Fallback: exact radix select by ONE workgroup per failed job (4 streaming passes of 8 key bits).
+template <typename T>
+__global__ __launch_bounds__(1024) void matrix_slow_kernel(const SelBatch b) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t red[20];
+    const SelJob &jb = b.job[blockIdx.x];
+    uint32_t *ws = jb.ws;
+    if (!ws[kCtrl + C_FAIL]) return;
+    const int tid = threadIdx.x;
+    const uint32_t numel = jb.out_f * jb.in_f;
+    uint32_t prefix = 0, pmask = 0, r = jb.k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (uint32_t e = tid; e < numel; e += 1024u) {
+            const uint32_t key = element_key<T>(jb, e);
+            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        uint32_t h[4] = {0, 0, 0, 0};
+        if (tid < 64) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[i] = hist[tid * 4 + i];
+        }
+        uint32_t bin, before;
+        block_find_rank(h, r, red, bin, before);
+        prefix |= bin << shift;
+        pmask |= 0xFFu << shift;
+        r -= before;
+    }
+    if (tid == 0) {
+        ws[kCtrl + C_THR] = prefix;
+        ws[kCtrl + C_FAIL] = 2;                                  // 2 = resolved by the slow path
     }
 }
 
 template <typename T, bool ALIGNED>
-__global__ __launch_bounds__(1024) void matrix_apply_kernel(typename T::raw *__restrict__ W, int64_t out_f, int64_t in_f,
-                                                            int64_t ldw, const float *__restrict__ sq, uint64_t k_index,
-                                                            const uint32_t *__restrict__ hist, int apply_zero,
-                                                            uint8_t *__restrict__ mask, double *__restrict__ block_sums) {
-    __shared__ uint32_t sh[260];
+__global__ __launch_bounds__(1024) void matrix_apply_kernel(const SelBatch b) {
     __shared__ double dsm[16];
-    uint32_t thr = 0;
-    uint64_t rank = 0;
-    resolve_prefix(hist, 3, k_index, sh, thr, rank);
-    // thr is the key of flat rank k_index; prune strictly below it.  A NaN threshold prunes nothing
+    uint32_t wg;
+    const SelJob &jb = b.job[find_job(b, blockIdx.x, wg)];
+    const int tid = threadIdx.x;
+    // thr is the key of flat rank k; prune strictly below it.  A NaN threshold prunes nothing
     // (`score < nan` is False everywhere, wanda_pruner.py:683).
+    const uint32_t thr = jb.ws[kCtrl + C_THR];
     const bool none = thr == 0xFFFFFFFFu;
-    const int64_t cpr = (in_f + 7) / 8;
-    const int64_t total = out_f * cpr;
+    const uint32_t in_f = jb.in_f, cpr = (in_f + 7) / 8, total = jb.out_f * cpr;
+    typename T::raw *W = static_cast<typename T::raw *>(jb.W);
     double dsum = 0.0;
-    for (int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; c < total; c += int64_t(gridDim.x) * blockDim.x) {
-        const int64_t row = c / cpr, col0 = (c - row * cpr) * 8;
-        typename T::raw *wrow = W + row * ldw;
+    for (uint32_t c = wg * 1024u + uint32_t(tid); c < total; c += jb.nwg * 1024u) {
+        const uint32_t row = c / cpr, col0 = (c - row * cpr) * 8;
+        typename T::raw *wrow = W + int64_t(row) * jb.ldw;
         Chunk8<T> raw = load_row_chunk<T, ALIGNED>(wrow, col0, in_f);
         float sqv[8];
-        load_sq_chunk<ALIGNED>(sq, col0, in_f, sqv);
+        load_sq_chunk<ALIGNED>(jb.sq, col0, in_f, sqv);
         uint32_t keepbits = 0;
         float fs = 0.f;
 #pragma unroll
@@ -579,18 +801,20 @@ __global__ __launch_bounds__(1024) void matrix_apply_kernel(typename T::raw *__r
             if (pruned) raw.v[j] = typename T::raw(0);
         }
         dsum += double(fs);
-        store_mask_chunk<ALIGNED>(mask + row * in_f, col0, in_f, keepbits);
-        if (apply_zero && keepbits != 0xFFu) store_row_chunk<T, ALIGNED>(wrow, col0, in_f, raw);
+        store_mask_chunk<ALIGNED>(jb.mask + int64_t(row) * in_f, col0, in_f, keepbits);
+        if (b.apply_zero && keepbits != 0xFFu) store_row_chunk<T, ALIGNED>(wrow, col0, in_f, raw);
     }
-    if (block_sums) {
+    if (jb.parts) {
         dsum = wave_sum_f64(dsum);
-        const int wave = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) dsm[wave] = dsum;
+        if ((tid & 63) == 0) dsm[tid >> 6] = dsum;
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             double a = 0.0;
-            for (int w = 0; w < int(blockDim.x >> 6); ++w) a += dsm[w];
-            block_sums[blockIdx.x] = a;
+            for (int w = 0; w < 16; ++w) a += dsm[w];
+            jb.parts[wg] = a;
+        }
+        if (wg == 0) {                                           // slots of workgroups this job does not have
+            for (uint32_t i = jb.nwg + uint32_t(tid); i < uint32_t(kMatrixParts); i += 1024u) jb.parts[i] = 0.0;
         }
     }
 }
@@ -599,19 +823,20 @@ __global__ __launch_bounds__(1024) void matrix_apply_kernel(typename T::raw *__r
 // SEL_NM
 // ------------------------------------------------------------------------------------------
 template <typename T, bool ALIGNED, int M>
-__global__ __launch_bounds__(256) void nm_kernel(typename T::raw *__restrict__ W, int64_t out_f, int64_t in_f, int64_t ldw,
-                                                 const float *__restrict__ sq, int n, int apply_zero,
-                                                 uint8_t *__restrict__ mask, double *__restrict__ block_sums) {
+__global__ __launch_bounds__(256) void nm_kernel(const SelBatch b) {
     __shared__ double dsm[4];
-    const int64_t cpr = (in_f + 7) / 8;
-    const int64_t total = out_f * cpr;
+    uint32_t wg;
+    const SelJob &jb = b.job[find_job(b, blockIdx.x, wg)];
+    const int n = int(b.p0);
+    const uint32_t in_f = jb.in_f, cpr = (in_f + 7) / 8, total = jb.out_f * cpr;
+    typename T::raw *W = static_cast<typename T::raw *>(jb.W);
     double dsum = 0.0;
-    for (int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; c < total; c += int64_t(gridDim.x) * blockDim.x) {
-        const int64_t row = c / cpr, col0 = (c - row * cpr) * 8;
-        typename T::raw *wrow = W + row * ldw;
+    for (uint32_t c = wg * 256u + threadIdx.x; c < total; c += jb.nwg * 256u) {
+        const uint32_t row = c / cpr, col0 = (c - row * cpr) * 8;
+        typename T::raw *wrow = W + int64_t(row) * jb.ldw;
         Chunk8<T> raw = load_row_chunk<T, ALIGNED>(wrow, col0, in_f);
         float sqv[8];
-        load_sq_chunk<ALIGNED>(sq, col0, in_f, sqv);
+        load_sq_chunk<ALIGNED>(jb.sq, col0, in_f, sqv);
         uint32_t key[8];
         float fs = 0.f;
 #pragma unroll
@@ -642,35 +867,27 @@ __global__ __launch_bounds__(256) void nm_kernel(typename T::raw *__restrict__ W
                 if (pruned) raw.v[g * M + i] = typename T::raw(0);
             }
         }
-        store_mask_chunk<ALIGNED>(mask + row * in_f, col0, in_f, keepbits);
-        if (apply_zero && keepbits != 0xFFu) store_row_chunk<T, ALIGNED>(wrow, col0, in_f, raw);
+        store_mask_chunk<ALIGNED>(jb.mask + int64_t(row) * in_f, col0, in_f, keepbits);
+        if (b.apply_zero && keepbits != 0xFFu) store_row_chunk<T, ALIGNED>(wrow, col0, in_f, raw);
     }
-    if (block_sums) {
+    if (jb.parts) {
         dsum = wave_sum_f64(dsum);
         const int wave = threadIdx.x >> 6;
         if ((threadIdx.x & 63) == 0) dsm[wave] = dsum;
         __syncthreads();
-        if (threadIdx.x == 0) block_sums[blockIdx.x] = dsm[0] + dsm[1] + dsm[2] + dsm[3];
+        if (threadIdx.x == 0) jb.parts[wg] = dsm[0] + dsm[1] + dsm[2] + dsm[3];
+        if (wg == 0) {
+            for (uint32_t i = jb.nwg + threadIdx.x; i < uint32_t(kNmParts); i += 256u) jb.parts[i] = 0.0;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-constexpr int kMatrixGrid = 512;     // persistent 1024-thread workgroups (2 per CU)
-constexpr int kNmGrid = 2048;        // 256-thread workgroups (8 per CU)
-
-struct WsLayout {
-    size_t hist_off, total;
-};
-static WsLayout ws_layout(int mode, int64_t out_f, int64_t in_f) {
-    WsLayout l{};
-    (void)out_f; (void)in_f;
-    if (mode == VLMC_SEL_MATRIX) l.total = round_up(size_t(kHistTotal) * 4, 256);   // radix histograms
-    return l;
-}
+static size_t ws_bytes(int mode) { return mode == VLMC_SEL_MATRIX ? round_up(size_t(kWsWords) * 4, 256) : 0; }
 static int64_t n_partials(int mode, int64_t out_f) {
-    return mode == VLMC_SEL_ROW ? out_f : (mode == VLMC_SEL_MATRIX ? kMatrixGrid : kNmGrid);
+    return mode == VLMC_SEL_ROW ? out_f : (mode == VLMC_SEL_MATRIX ? kMatrixParts : kNmParts);
 }
 
 static int env_int(const char *name, int dflt) {
@@ -678,27 +895,41 @@ static int env_int(const char *name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-template <typename T, int CH, int NW, bool ALIGNED>
-static void launch_rows(void *W, int64_t out_f, int64_t in_f, int64_t ldw, const float *sqrt_scaler, uint32_t k,
-                        int apply_zero, uint8_t *mask, double *row_sums, hipStream_t st) {
-    const uint32_t margin = uint32_t(env_int("VLMC_SELECT_SAMPLE_MARGIN", 9));   // ~ +-3 sigma of a 32-sample rank
-    const uint32_t frac_q16 = uint32_t((uint64_t(k) << 16) / uint64_t(in_f));
-    hipLaunchKernelGGL((select_rows_kernel<T, CH, NW, ALIGNED>), dim3(unsigned(out_f)), dim3(64 * NW), 0, st,
-                       static_cast<typename T::raw *>(W), out_f, in_f, ldw, sqrt_scaler, k, apply_zero, mask, row_sums,
-                       margin, frac_q16);
+static bool job_aligned(const vlmc_select_job &j) {
+    return j.in_features % 8 == 0 && j.ldw % 8 == 0 && aligned16(j.W) && aligned16(j.sqrt_scaler) &&
+           (reinterpret_cast<uintptr_t>(j.mask) % 8) == 0;
+}
+
+static void fill_job(SelJob &d, const vlmc_select_job &j) {
+    d.W = j.W; d.sq = j.sqrt_scaler; d.mask = j.mask; d.parts = j.score_partials;
+    d.ws = static_cast<uint32_t *>(j.workspace);
+    d.out_f = uint32_t(j.out_features); d.in_f = uint32_t(j.in_features); d.ldw = uint32_t(j.ldw);
+    d.k = uint32_t(j.k); d.unit_end = 0; d.nwg = 0;
 }
 
 // (NW waves) x (CH chunks of 8 columns per lane) must cover the row: 64*NW*CH >= in/8.
 // Few rows -> more waves per row (parallelism); many rows -> one wave per row (no barriers).
 template <typename T>
-static int dispatch_rows(void *W, int64_t out_f, int64_t in_f, int64_t ldw, const float *sqrt_scaler, uint32_t k, int apply_zero,
-                         uint8_t *mask, double *row_sums, bool aligned, hipStream_t st) {
-    const int64_t nchunks = (in_f + 7) / 8;
+static int launch_rows(const vlmc_select_job *jobs, const int *idx, int n, int apply_zero, hipStream_t st) {
+    const vlmc_select_job &j0 = jobs[idx[0]];
+    const int64_t in_f = j0.in_features, nchunks = (in_f + 7) / 8;
     if (nchunks > 2048) {
         set_error("vlmc_wanda_select: in_features %lld too large (max 16384)", (long long)in_f);
         return VLMC_EINVAL;
     }
-#define VLMC_ROWS(CH, NW, AL) launch_rows<T, CH, NW, AL>(W, out_f, in_f, ldw, sqrt_scaler, k, apply_zero, mask, row_sums, st)
+    SelBatch b;
+    b.n = n; b.apply_zero = apply_zero;
+    b.p0 = uint32_t(env_int("VLMC_SELECT_SAMPLE_MARGIN", 9));          // ~ +-3 sigma of a 32-sample rank
+    b.p1 = uint32_t((uint64_t(j0.k) << 16) / uint64_t(in_f));
+    int64_t rows = 0;
+    for (int i = 0; i < n; ++i) {
+        fill_job(b.job[i], jobs[idx[i]]);
+        rows += jobs[idx[i]].out_features;
+        b.job[i].unit_end = uint32_t(rows);
+    }
+    const bool aligned = job_aligned(j0);
+#define VLMC_ROWS(CH, NW, AL) \
+    hipLaunchKernelGGL((select_rows_kernel<T, CH, NW, AL>), dim3(unsigned(rows)), dim3(64 * NW), 0, st, b)
     if (!aligned) {
         if (nchunks <= 256) VLMC_ROWS(4, 1, false);
         else VLMC_ROWS(4, 8, false);
@@ -707,7 +938,7 @@ static int dispatch_rows(void *W, int64_t out_f, int64_t in_f, int64_t ldw, cons
     int nw = 1;
     while (nw < 8 && nchunks > int64_t(64) * nw * 4) nw *= 2;               // CH <= 4
     const int64_t want_waves = env_int("VLMC_SELECT_WANT_WAVES", 4096);      // ~4 waves per SIMD
-    while (nw < 8 && out_f * nw < want_waves && nchunks > int64_t(64) * nw) nw *= 2;
+    while (nw < 8 && rows * nw < want_waves && nchunks > int64_t(64) * nw) nw *= 2;
     if (const int f = env_int("VLMC_SELECT_NW", 0)) {
         if ((f == 1 || f == 2 || f == 4 || f == 8) && nchunks <= int64_t(64) * f * 4) nw = f;
     }
@@ -730,56 +961,102 @@ static int dispatch_rows(void *W, int64_t out_f, int64_t in_f, int64_t ldw, cons
     return VLMC_OK;
 }
 
-template <typename T, bool AL>
-static void launch_matrix(void *W, int64_t out_f, int64_t in_f, int64_t ldw, const float *sq, uint64_t k_index,
-                          int apply_zero, uint8_t *mask, double *parts, uint32_t *hist, hipStream_t st) {
-    using raw = typename T::raw;
-    raw *w = static_cast<raw *>(W);
-    (void)hipMemsetAsync(hist, 0, size_t(kHistTotal) * 4, st);
-    hipLaunchKernelGGL((matrix_hist_kernel<T, AL, 0>), dim3(kMatrixGrid), dim3(1024), 0, st, w, out_f, in_f, ldw, sq, k_index, hist);
-    hipLaunchKernelGGL((matrix_hist_kernel<T, AL, 1>), dim3(kMatrixGrid), dim3(1024), 0, st, w, out_f, in_f, ldw, sq, k_index, hist);
-    hipLaunchKernelGGL((matrix_hist_kernel<T, AL, 2>), dim3(kMatrixGrid), dim3(1024), 0, st, w, out_f, in_f, ldw, sq, k_index, hist);
-    hipLaunchKernelGGL((matrix_apply_kernel<T, AL>), dim3(kMatrixGrid), dim3(1024), 0, st, w, out_f, in_f, ldw, sq, k_index,
-                       hist, apply_zero, mask, parts);
+// elementwise passes: workgroups of `threads` lanes, 8 columns per lane, at most `cap` workgroups per job
+static uint32_t job_wgs(const vlmc_select_job &j, int threads, int cap) {
+    const int64_t chunks = j.out_features * ((j.in_features + 7) / 8);
+    int64_t n = (chunks + threads - 1) / threads;
+    return uint32_t(n < 1 ? 1 : (n > cap ? cap : n));
 }
 
-template <typename T, bool AL>
-static int launch_nm(void *W, int64_t out_f, int64_t in_f, int64_t ldw, const float *sq, int n, int m, int apply_zero,
-                     uint8_t *mask, double *parts, hipStream_t st) {
-    using raw = typename T::raw;
-    raw *w = static_cast<raw *>(W);
-#define VLMC_NM(M) hipLaunchKernelGGL((nm_kernel<T, AL, M>), dim3(kNmGrid), dim3(256), 0, st, w, out_f, in_f, ldw, sq, n, apply_zero, mask, parts)
-    switch (m) {
+template <typename T>
+static int launch_matrix(const vlmc_select_job *jobs, const int *idx, int n, int apply_zero, hipStream_t st) {
+    SelBatch b;
+    b.n = n; b.apply_zero = apply_zero;
+    b.p0 = uint32_t(env_int("VLMC_MATRIX_FORCE_SLOW", 0)); b.p1 = 0;
+    bool aligned = true;
+    uint32_t wgs = 0;
+    // persistent workgroups: 2 x 1024 lanes per CU over the whole launch, shared out by matrix size, so the
+    // fixed per-workgroup latencies (control loads, LDS clear/flush, done-counter atomic) are paid once
+    const int budget = env_int("VLMC_MATRIX_WGS", 512);
+    int64_t all_chunks = 0;
+    for (int i = 0; i < n; ++i) all_chunks += jobs[idx[i]].out_features * ((jobs[idx[i]].in_features + 7) / 8);
+    for (int i = 0; i < n; ++i) {
+        fill_job(b.job[i], jobs[idx[i]]);
+        const int64_t chunks = jobs[idx[i]].out_features * ((jobs[idx[i]].in_features + 7) / 8);
+        int64_t share = (chunks * budget + all_chunks - 1) / all_chunks;
+        const uint32_t cap = job_wgs(jobs[idx[i]], 1024, kMatrixParts);
+        b.job[i].nwg = uint32_t(share < 1 ? 1 : (share > cap ? cap : share));
+        wgs += b.job[i].nwg;
+        b.job[i].unit_end = wgs;
+        aligned = aligned && job_aligned(jobs[idx[i]]);
+    }
+    hipLaunchKernelGGL((matrix_sample_kernel<T>), dim3(unsigned(n)), dim3(1024), 0, st, b);
+    if (aligned) {
+        hipLaunchKernelGGL((matrix_count_kernel<T, true, 0>), dim3(wgs), dim3(1024), 0, st, b);
+        hipLaunchKernelGGL((matrix_count_kernel<T, true, 1>), dim3(wgs), dim3(1024), 0, st, b);
+    } else {
+        hipLaunchKernelGGL((matrix_count_kernel<T, false, 0>), dim3(wgs), dim3(1024), 0, st, b);
+        hipLaunchKernelGGL((matrix_count_kernel<T, false, 1>), dim3(wgs), dim3(1024), 0, st, b);
+    }
+    hipLaunchKernelGGL((matrix_slow_kernel<T>), dim3(unsigned(n)), dim3(1024), 0, st, b);
+    if (aligned) hipLaunchKernelGGL((matrix_apply_kernel<T, true>), dim3(wgs), dim3(1024), 0, st, b);
+    else hipLaunchKernelGGL((matrix_apply_kernel<T, false>), dim3(wgs), dim3(1024), 0, st, b);
+    return VLMC_OK;
+}
+
+template <typename T>
+static int launch_nm(const vlmc_select_job *jobs, const int *idx, int n, int prune_n, int prune_m, int apply_zero,
+                     hipStream_t st) {
+    SelBatch b;
+    b.n = n; b.apply_zero = apply_zero;
+    b.p0 = uint32_t(prune_n); b.p1 = 0;
+    bool aligned = true;
+    uint32_t wgs = 0;
+    for (int i = 0; i < n; ++i) {
+        fill_job(b.job[i], jobs[idx[i]]);
+        b.job[i].nwg = job_wgs(jobs[idx[i]], 256, kNmParts);
+        wgs += b.job[i].nwg;
+        b.job[i].unit_end = wgs;
+        aligned = aligned && job_aligned(jobs[idx[i]]);
+    }
+#define VLMC_NM(M)                                                                                         \
+    do {                                                                                                   \
+        if (aligned) hipLaunchKernelGGL((nm_kernel<T, true, M>), dim3(wgs), dim3(256), 0, st, b);          \
+        else hipLaunchKernelGGL((nm_kernel<T, false, M>), dim3(wgs), dim3(256), 0, st, b);                 \
+    } while (0)
+    switch (prune_m) {
         case 2: VLMC_NM(2); break;
         case 4: VLMC_NM(4); break;
         case 8: VLMC_NM(8); break;
-        default: set_error("vlmc_wanda_select: n:m with m=%d unsupported (m must be 2, 4 or 8)", m); return VLMC_EINVAL;
+        default: set_error("vlmc_wanda_select: n:m with m=%d unsupported (m must be 2, 4 or 8)", prune_m); return VLMC_EINVAL;
     }
 #undef VLMC_NM
     return VLMC_OK;
 }
 
 template <typename T>
-static int select_typed(void *W, int64_t out_f, int64_t in_f, int64_t ldw, const float *sqrt_scaler, int mode, int64_t k,
-                        int n, int m, int apply_zero, uint8_t *mask, double *parts, char *ws, hipStream_t st) {
-    const WsLayout l = ws_layout(mode, out_f, in_f);
-    const bool aligned = in_f % 8 == 0 && ldw % 8 == 0 && aligned16(W) && aligned16(sqrt_scaler) &&
-                         (reinterpret_cast<uintptr_t>(mask) % 8) == 0;
-    int rc = VLMC_OK;
-    if (mode == VLMC_SEL_ROW) {
-        rc = dispatch_rows<T>(W, out_f, in_f, ldw, sqrt_scaler, uint32_t(k), apply_zero, mask, parts, aligned, st);
-    } else {
-        const float *sq = sqrt_scaler;
-        uint32_t *hist = reinterpret_cast<uint32_t *>(ws + l.hist_off);
-        if (mode == VLMC_SEL_MATRIX) {
-            if (aligned) launch_matrix<T, true>(W, out_f, in_f, ldw, sq, uint64_t(k), apply_zero, mask, parts, hist, st);
-            else launch_matrix<T, false>(W, out_f, in_f, ldw, sq, uint64_t(k), apply_zero, mask, parts, hist, st);
-        } else {
-            rc = aligned ? launch_nm<T, true>(W, out_f, in_f, ldw, sq, n, m, apply_zero, mask, parts, st)
-                         : launch_nm<T, false>(W, out_f, in_f, ldw, sq, n, m, apply_zero, mask, parts, st);
+static int select_typed(const vlmc_select_job *jobs, int n_jobs, int mode, int prune_n, int prune_m, int apply_zero,
+                        hipStream_t st) {
+    // launch groups: consecutive runs of <= kMaxSelJobs jobs; SEL_ROW additionally needs equal (in, k, alignment)
+    int idx[kMaxSelJobs];
+    bool done[256] = {false};
+    for (int s0 = 0; s0 < n_jobs; ++s0) {
+        if (done[s0]) continue;
+        int n = 0;
+        for (int i = s0; i < n_jobs && n < kMaxSelJobs; ++i) {
+            if (done[i]) continue;
+            if (mode == VLMC_SEL_ROW && (jobs[i].in_features != jobs[s0].in_features || jobs[i].k != jobs[s0].k ||
+                                         job_aligned(jobs[i]) != job_aligned(jobs[s0])))
+                continue;
+            idx[n++] = i;
+            done[i] = true;
         }
+        int rc;
+        if (mode == VLMC_SEL_ROW) rc = launch_rows<T>(jobs, idx, n, apply_zero, st);
+        else if (mode == VLMC_SEL_MATRIX) rc = launch_matrix<T>(jobs, idx, n, apply_zero, st);
+        else rc = launch_nm<T>(jobs, idx, n, prune_n, prune_m, apply_zero, st);
+        if (rc != VLMC_OK) return rc;
     }
-    if (rc != VLMC_OK) return rc;
     VLMC_HIP_CHECK_LAUNCH("vlmc_wanda_select");
     return VLMC_OK;
 }
@@ -790,7 +1067,7 @@ using namespace vlmc;
 
 extern "C" size_t vlmc_wanda_select_workspace(int mode, int64_t out_features, int64_t in_features) {
     if (out_features <= 0 || in_features <= 0 || mode < 0 || mode > 2) return 0;
-    return ws_layout(mode, out_features, in_features).total;
+    return ws_bytes(mode);
 }
 
 extern "C" int64_t vlmc_wanda_select_partials(int mode, int64_t out_features, int64_t in_features) {
@@ -798,42 +1075,52 @@ extern "C" int64_t vlmc_wanda_select_partials(int mode, int64_t out_features, in
     return n_partials(mode, out_features);
 }
 
+extern "C" int vlmc_wanda_select_batch(const vlmc_select_job *jobs, int n_jobs, int dtype, int mode, int n, int m,
+                                       int apply_zero, void *stream) {
+    VLMC_REQUIRE(jobs && n_jobs > 0 && n_jobs <= 256, "vlmc_wanda_select_batch: 1..256 jobs expected (got %d)", n_jobs);
+    VLMC_REQUIRE(mode >= 0 && mode <= 2, "vlmc_wanda_select: unknown mode %d", mode);
+    for (int i = 0; i < n_jobs; ++i) {
+        const vlmc_select_job &j = jobs[i];
+        VLMC_REQUIRE(j.W && j.sqrt_scaler && j.mask, "vlmc_wanda_select: null pointer (job %d)", i);
+        VLMC_REQUIRE(j.out_features > 0 && j.in_features > 0 && j.ldw >= j.in_features && j.ldw < (int64_t(1) << 32),
+                     "vlmc_wanda_select: bad shape out=%lld in=%lld ldw=%lld", (long long)j.out_features,
+                     (long long)j.in_features, (long long)j.ldw);
+        VLMC_REQUIRE(j.out_features * j.in_features < (int64_t(1) << 32), "vlmc_wanda_select: more than 2^32 weights");
+        if (mode == VLMC_SEL_ROW) {
+            VLMC_REQUIRE(j.k >= 0 && j.k <= j.in_features, "vlmc_wanda_select: row k=%lld outside [0,%lld]", (long long)j.k,
+                         (long long)j.in_features);
+        } else if (mode == VLMC_SEL_MATRIX) {
+            VLMC_REQUIRE(j.k >= 0 && j.k < j.out_features * j.in_features, "vlmc_wanda_select: matrix k=%lld outside [0,%lld)",
+                         (long long)j.k, (long long)(j.out_features * j.in_features));
+            const size_t need = ws_bytes(mode);
+            VLMC_REQUIRE(j.workspace, "vlmc_wanda_select: null workspace");
+            VLMC_REQUIRE((reinterpret_cast<uintptr_t>(j.workspace) % 256) == 0, "vlmc_wanda_select: workspace not 256-B aligned");
+            if (j.workspace_bytes < need) {
+                set_error("vlmc_wanda_select: workspace %zu B < required %zu B", j.workspace_bytes, need);
+                return VLMC_EWORKSPACE;
+            }
+            for (int p = 0; p < i; ++p)
+                VLMC_REQUIRE(jobs[p].workspace != j.workspace, "vlmc_wanda_select_batch: jobs %d and %d share a workspace", p, i);
+        } else {
+            VLMC_REQUIRE(m > 0 && n >= 0 && n <= m && j.in_features % m == 0,
+                         "vlmc_wanda_select: bad n:m = %d:%d for in_features %lld", n, m, (long long)j.in_features);
+        }
+    }
+    hipStream_t st = as_stream(stream);
+    switch (dtype) {
+        case VLMC_F32: return select_typed<f32_t>(jobs, n_jobs, mode, n, m, apply_zero, st);
+        case VLMC_F16: return select_typed<f16_t>(jobs, n_jobs, mode, n, m, apply_zero, st);
+        case VLMC_BF16: return select_typed<bf16_t>(jobs, n_jobs, mode, n, m, apply_zero, st);
+    }
+    set_error("vlmc_wanda_select: unknown dtype %d", dtype);
+    return VLMC_EINVAL;
+}
+
 extern "C" int vlmc_wanda_select(void *W, int dtype, int64_t out_features, int64_t in_features, int64_t ldw,
                                  const float *sqrt_scaler, int mode, int64_t k, int n, int m, int apply_zero,
                                  uint8_t *mask, double *score_partials, void *workspace, size_t workspace_bytes,
                                  void *stream) {
-    VLMC_REQUIRE(W && sqrt_scaler && mask, "vlmc_wanda_select: null pointer");
-    VLMC_REQUIRE(out_features > 0 && in_features > 0 && ldw >= in_features,
-                 "vlmc_wanda_select: bad shape out=%lld in=%lld ldw=%lld", (long long)out_features, (long long)in_features,
-                 (long long)ldw);
-    VLMC_REQUIRE(out_features * in_features < (int64_t(1) << 32), "vlmc_wanda_select: more than 2^32 weights");
-    VLMC_REQUIRE(mode >= 0 && mode <= 2, "vlmc_wanda_select: unknown mode %d", mode);
-    if (mode == VLMC_SEL_ROW) {
-        VLMC_REQUIRE(k >= 0 && k <= in_features, "vlmc_wanda_select: row k=%lld outside [0,%lld]", (long long)k,
-                     (long long)in_features);
-    } else if (mode == VLMC_SEL_MATRIX) {
-        VLMC_REQUIRE(k >= 0 && k < out_features * in_features, "vlmc_wanda_select: matrix k=%lld outside [0,%lld)",
-                     (long long)k, (long long)(out_features * in_features));
-    } else {
-        VLMC_REQUIRE(m > 0 && n >= 0 && n <= m && in_features % m == 0,
-                     "vlmc_wanda_select: bad n:m = %d:%d for in_features %lld", n, m, (long long)in_features);
-    }
-    const size_t need = vlmc_wanda_select_workspace(mode, out_features, in_features);
-    if (need) {
-        VLMC_REQUIRE(workspace, "vlmc_wanda_select: null workspace");
-        VLMC_REQUIRE((reinterpret_cast<uintptr_t>(workspace) % 256) == 0, "vlmc_wanda_select: workspace not 256-B aligned");
-        if (workspace_bytes < need) {
-            set_error("vlmc_wanda_select: workspace %zu B < required %zu B", workspace_bytes, need);
-            return VLMC_EWORKSPACE;
-        }
-    }
-    hipStream_t st = as_stream(stream);
-    char *ws = static_cast<char *>(workspace);
-    switch (dtype) {
-        case VLMC_F32: return select_typed<f32_t>(W, out_features, in_features, ldw, sqrt_scaler, mode, k, n, m, apply_zero, mask, score_partials, ws, st);
-        case VLMC_F16: return select_typed<f16_t>(W, out_features, in_features, ldw, sqrt_scaler, mode, k, n, m, apply_zero, mask, score_partials, ws, st);
-        case VLMC_BF16: return select_typed<bf16_t>(W, out_features, in_features, ldw, sqrt_scaler, mode, k, n, m, apply_zero, mask, score_partials, ws, st);
-    }
-    set_error("vlmc_wanda_select: unknown dtype %d", dtype);
-    return VLMC_EINVAL;
+    const vlmc_select_job j{W, out_features, in_features, ldw, sqrt_scaler, k, mask, score_partials, workspace,
+                            workspace_bytes};
+    return vlmc_wanda_select_batch(&j, 1, dtype, mode, n, m, apply_zero, stream);
 }

@@ -40,16 +40,18 @@ _VERBOSE = os.environ.get("VLMC_VERBOSE", "0") != "0"
 # --------------------------------------------------------------------------------------
 class WandaStatCollector:
     """Forward hooks on the linears of one block (wanda_pruner.py:295-314).  Linears that
-    receive the very same tensor (q/k/v, wi_0/wi_1) share one squared-norm launch and one
-    statistic."""
+    receive the very same tensor (q/k/v, wi_0/wi_1) share one statistic, and all distinct
+    inputs of one sample's block forward are reduced by ONE batched launch (issued when the
+    next sample starts, or at close)."""
 
     def __init__(self, subset):
         from vlmc import ops
         self._ops = ops
         self.subset = subset
-        self.rows = {n: [] for n in subset}
+        self.rows = {n: [] for n in subset}          # per linear: holders [row tensor | None], one per hook call
         self.batches = {n: [] for n in subset}
-        self._cache = {}
+        self._cache = {}                              # input signature -> (x kept alive, holder)
+        self._pending = []                            # (x [1, tokens, in], holder) not yet reduced
         self.handles = [m.register_forward_hook(self._make_hook(n)) for n, m in subset.items()]
 
     def _make_hook(self, name):
@@ -60,35 +62,47 @@ class WandaStatCollector:
             key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, x._version)
             hit = self._cache.get(key)
             if hit is None:
-                row = self._ops.act_sqnorm(x.reshape(1, -1, x.shape[-1]))
-                # keep `x` referenced until the next sample so its memory cannot be recycled
-                # for a different activation with the same address/shape during this forward
-                hit = (x, row)
+                # `x` stays referenced until it has been reduced, so its memory cannot be recycled for a
+                # different activation with the same address/shape in the meantime
+                hit = (x, [None])
                 self._cache[key] = hit
+                self._pending.append((x.reshape(1, -1, x.shape[-1]), hit[1]))
             self.rows[name].append(hit[1])
             self.batches[name].append(x.shape[0])
         return hook
 
+    def _flush(self):
+        by_dtype = {}
+        for x, holder in self._pending:
+            by_dtype.setdefault(x.dtype, []).append((x, holder))
+        for items in by_dtype.values():
+            outs = self._ops.act_sqnorm_batch([x for x, _ in items])
+            for (_, holder), row in zip(items, outs):
+                holder[0] = row
+        self._pending = []
+
     def next_sample(self, _j=None):
+        self._flush()
         self._cache.clear()
 
     def close(self):
         for h in self.handles:
             h.remove()
         self.handles = []
+        self._flush()
         self._cache.clear()
 
     def finalize(self):
         """{name: InputStat}; linears whose hooks saw identical tensors share the object."""
         from vlmc import wanda
         shared, out, order = {}, {}, []
-        for name, rows in self.rows.items():
-            sig = tuple(id(r) for r in rows)
+        for name, holders in self.rows.items():
+            sig = tuple(id(h) for h in holders)
             st = shared.get(sig)
             if st is None:
                 in_f = self.subset[name].weight.shape[1]
                 st = wanda.InputStat(in_f, self.subset[name].weight.device)
-                st.rows = list(rows)
+                st.rows = [h[0] for h in holders]
                 st.batches = list(self.batches[name])
                 shared[sig] = st
                 order.append(st)
@@ -119,29 +133,30 @@ class _WandaBlockMixin:
         stats = col.finalize()
 
         names = list(subset)
-        nparts = [ops.select_partials(unstructured_mode if self.prune_n == 0 else "nm", *subset[n].weight.shape)
-                  for n in names]
+        mode = unstructured_mode if self.prune_n == 0 else "nm"
+        nparts = [ops.select_partials(mode, *subset[n].weight.shape) for n in names]
         dev = subset[names[0]].weight.device
         partial_rows = torch.zeros((len(names), max(nparts)), dtype=torch.float64, device=dev)
-        for li, name in enumerate(names):
+        weights, ratios = [], []
+        for name in names:
             mod, st = subset[name], stats[name]
             assert st.nsamples == n_inps * batch0                      # wanda_pruner.py:317
-            W = mod.weight.data
-            if not W.is_contiguous():
+            if not mod.weight.data.is_contiguous():
                 raise RuntimeError(f"{name}: weight must be contiguous")
+            weights.append(mod.weight.data)
             if self.prune_n != 0:
+                ratios.append(None)
                 if _VERBOSE:
                     print(f"pruning {model_prefix} layer {i} {name} at structured {self.prune_n}:{self.prune_m} sparsity")
-                mask, _ = wanda.prune_linear(W, st, "nm", n=self.prune_n, m=self.prune_m, apply_zero=not lora_model,
-                                             partials=partial_rows[li])
             else:
-                key = f"{module_to_process}.{i}.{name}.weight"
-                ratio = sparsity_ratio[key]
+                ratios.append(sparsity_ratio[f"{module_to_process}.{i}.{name}.weight"])
                 if _VERBOSE:
-                    print(f"pruning {model_prefix} layer {i} {name} at unstructured {ratio} sparsity")
-                mask, _ = wanda.prune_linear(W, st, unstructured_mode, ratio=ratio, apply_zero=not lora_model,
-                                             partials=partial_rows[li])
-            setattr(mod, "mask", mask)                                  # True = keep (:339)
+                    print(f"pruning {model_prefix} layer {i} {name} at unstructured {ratios[-1]} sparsity")
+        # every linear of the block in batched launches (the reference's per-linear loop, :316-341)
+        masks = wanda.prune_block(weights, [stats[n] for n in names], mode, ratios=ratios, n=self.prune_n, m=self.prune_m,
+                                  apply_zero=not lora_model, partials=[partial_rows[li] for li in range(len(names))])
+        for name, mask in zip(names, masks):
+            setattr(subset[name], "mask", mask)                         # True = keep (:339)
         _importance_readback(subset, names, partial_rows, [subset[n].weight.numel() for n in names])
 
 

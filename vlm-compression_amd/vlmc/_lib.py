@@ -16,6 +16,22 @@ SEL_ROW, SEL_MATRIX, SEL_NM = 0, 1, 2
 _c = ctypes
 _p, _i, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
 
+
+
+class StatJob(_c.Structure):          # vlmc_stat_job
+    _fields_ = [("x", _p), ("normsq", _p), ("in_features", _i64), ("tokens", _i64), ("row_stride", _i64),
+                ("call_stride", _i64), ("normsq_stride", _i64)]
+
+
+class UpdateJob(_c.Structure):        # vlmc_update_job
+    _fields_ = [("scaler_row", _p), ("normsq", _p), ("sqrt_out", _p), ("in_features", _i64), ("normsq_stride", _i64)]
+
+
+class SelectJob(_c.Structure):        # vlmc_select_job
+    _fields_ = [("W", _p), ("out_features", _i64), ("in_features", _i64), ("ldw", _i64), ("sqrt_scaler", _p), ("k", _i64),
+                ("mask", _p), ("score_partials", _p), ("workspace", _p), ("workspace_bytes", _sz)]
+
+
 # name -> (restype, argtypes); must list every function include/vlmc.h declares
 # (tests/test_abi.py parses the header and checks both directions).
 SIGNATURES = {
@@ -23,6 +39,9 @@ SIGNATURES = {
     "vlmc_last_error": (_c.c_char_p, []),
     "vlmc_act_sqnorm": (_i, [_p, _i, _i64, _i64, _i64, _i64, _i64, _p, _p]),
     "vlmc_wanda_scaler_update": (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _p]),
+    "vlmc_act_sqnorm_batch": (_i, [_p, _i, _i, _i64, _p]),
+    "vlmc_wanda_scaler_update_batch": (_i, [_p, _i, _i64, _i64, _i64, _p]),
+    "vlmc_wanda_select_batch": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
     "vlmc_wanda_select_workspace": (_sz, [_i, _i64, _i64]),
     "vlmc_wanda_select_partials": (_i64, [_i, _i64, _i64]),
     "vlmc_lora_effective_weight": (_i, [_p, _i, _i64, _i64, _i64, _p, _p, _i, _c.c_float, _p, _i, _i, _p, _i64, _p]),

@@ -136,6 +136,101 @@ def select_partials(mode: str, out_f: int, in_f: int) -> int:
 
 
 # ---------------------------------------------------------------------------------------
+# Batched entry points: all hook inputs / statistics / linears of one transformer block per launch
+# ---------------------------------------------------------------------------------------
+def _stat_jobs(xs, outs):
+    jobs = (_lib.StatJob * len(xs))()
+    calls = xs[0].shape[0]
+    for j, (x, out) in enumerate(zip(xs, outs)):
+        _need_gpu(x, out)
+        assert x.dim() == 3 and x.stride(2) == 1 and x.shape[0] == calls and x.dtype == xs[0].dtype
+        assert out.dtype == torch.float32 and out.shape == (calls, x.shape[2]) and out.stride(1) == 1
+        tokens, in_f = x.shape[1], x.shape[2]
+        row_stride = x.stride(1) if tokens > 1 else in_f
+        call_stride = x.stride(0) if calls > 1 else tokens * row_stride
+        assert row_stride >= in_f
+        jobs[j] = _lib.StatJob(x.data_ptr(), out.data_ptr(), in_f, tokens, row_stride, call_stride,
+                               out.stride(0) if calls > 1 else in_f)
+    return jobs, calls
+
+
+def act_sqnorm_batch(xs, outs=None):
+    """`act_sqnorm` for several hook inputs ([calls, tokens, in_j], same dtype and calls) in one launch.
+    `outs[j]` may be a column slice of a wider fp32 buffer (row stride = the buffer's width)."""
+    xs = [x if x.stride(-1) == 1 else x.contiguous() for x in xs]
+    if outs is None:
+        outs = [torch.empty((x.shape[0], x.shape[2]), dtype=torch.float32, device=x.device) for x in xs]
+    jobs, calls = _stat_jobs(xs, outs)
+    _lib.check(_lib.load().vlmc_act_sqnorm_batch(jobs, len(xs), _dtype_code(xs[0]), calls, _stream()))
+    return outs
+
+
+def _update_jobs(scalers, normsqs, sqrt_outs):
+    jobs = (_lib.UpdateJob * len(scalers))()
+    calls = normsqs[0].shape[0]
+    for j, (s, nsq, sq) in enumerate(zip(scalers, normsqs, sqrt_outs)):
+        _need_gpu(s, nsq, sq)
+        assert s.dtype == torch.float32 and s.is_contiguous() and nsq.dtype == torch.float32
+        assert nsq.shape == (calls, s.numel()) and nsq.stride(1) == 1
+        assert sq is None or (sq.dtype == torch.float32 and sq.is_contiguous() and sq.numel() == s.numel())
+        jobs[j] = _lib.UpdateJob(s.data_ptr(), nsq.data_ptr(), sq.data_ptr() if sq is not None else None, s.numel(),
+                                 nsq.stride(0) if calls > 1 else s.numel())
+    return jobs, calls
+
+
+def wanda_scaler_update_batch(scalers, nsamples_before: int, normsqs, batch: int = 1, sqrt_outs=None) -> int:
+    """`wanda_scaler_update` for several statistics that saw the same calls, in one launch."""
+    sqrt_outs = [None] * len(scalers) if sqrt_outs is None else sqrt_outs
+    jobs, calls = _update_jobs(scalers, normsqs, sqrt_outs)
+    _lib.check(_lib.load().vlmc_wanda_scaler_update_batch(jobs, len(scalers), nsamples_before, calls, batch, _stream()))
+    return nsamples_before + calls * batch
+
+
+_batch_ws = Workspace()
+
+
+def _select_jobs(weights, sqrt_rows, code, ks, masks, partials, ws_holder):
+    lib = _lib.load()
+    n = len(weights)
+    jobs = (_lib.SelectJob * n)()
+    nbytes = lib.vlmc_wanda_select_workspace(code, *weights[0].shape)
+    ws = ws_holder.get(nbytes * n, weights[0].device) if nbytes else None
+    for j, (w, sq, k, mk, pt) in enumerate(zip(weights, sqrt_rows, ks, masks, partials)):
+        _need_gpu(w, sq, mk, pt)
+        if w.dim() != 2 or w.stride(1) != 1:
+            raise ValueError("wanda_select expects a row-major 2-D weight")
+        assert w.dtype == weights[0].dtype
+        out_f, in_f = w.shape
+        assert sq.dtype == torch.float32 and sq.is_contiguous() and sq.numel() == in_f
+        assert mk.dtype == torch.bool and mk.is_contiguous() and mk.shape == w.shape
+        assert pt is None or (pt.dtype == torch.float64 and pt.is_contiguous()
+                              and pt.numel() >= lib.vlmc_wanda_select_partials(code, out_f, in_f))
+        jobs[j] = _lib.SelectJob(w.data_ptr(), out_f, in_f, w.stride(0), sq.data_ptr(), int(k), mk.data_ptr(),
+                                 pt.data_ptr() if pt is not None else None,
+                                 ws.data_ptr() + j * nbytes if nbytes else None, nbytes)
+    return jobs
+
+
+def wanda_select_batch(weights, sqrt_rows, mode: str, *, ks=None, n: int = 0, m: int = 0, apply_zero: bool = True,
+                       masks=None, partials=None):
+    """`wanda_select` for all linears of a block (same dtype, mode, n:m) with as few launches as the shapes
+    allow.  Returns (masks, partials) as lists."""
+    code = _MODES[mode]
+    lib = _lib.load()
+    ks = [0] * len(weights) if ks is None else ks
+    if masks is None:
+        masks = [torch.empty(tuple(w.shape), dtype=torch.bool, device=w.device) for w in weights]
+    if partials is None:
+        partials = [torch.empty(lib.vlmc_wanda_select_partials(code, *w.shape), dtype=torch.float64, device=w.device)
+                    for w in weights]
+    jobs = _select_jobs(weights, sqrt_rows, code, ks, masks, partials, _batch_ws)
+    _lib.check(lib.vlmc_wanda_select_batch(jobs, len(weights), _dtype_code(weights[0]), code, int(n), int(m),
+                                           int(bool(apply_zero)), _stream()))
+    return masks, [p[:lib.vlmc_wanda_select_partials(code, *w.shape)] if p is not None else None
+                   for p, w in zip(partials, weights)]
+
+
+# ---------------------------------------------------------------------------------------
 # Launch plans: pre-validated, pre-bound C-ABI calls for hot loops that issue thousands of
 # launches per step (bench.py, the per-block pruner loop).  A plan is a zero-argument
 # callable; tensors referenced by a plan must stay alive and must not be reallocated.
@@ -180,3 +275,25 @@ def plan_select(weight: torch.Tensor, sqrt_scaler_row: torch.Tensor, mode: str, 
                                          sqrt_scaler_row.data_ptr(), code, int(k), int(n), int(m), int(bool(apply_zero)),
                                          mask.data_ptr(), partials.data_ptr(), ws.data_ptr() if nbytes else None,
                                          ws.numel() if nbytes else 0, _stream()))
+
+
+def plan_act_sqnorm_batch(xs, outs):
+    jobs, calls = _stat_jobs(xs, outs)
+    return _bind(_lib.load().vlmc_act_sqnorm_batch, (jobs, len(xs), _dtype_code(xs[0]), calls, _stream()))
+
+
+def plan_scaler_update_batch(scalers, nsamples_before: int, normsqs, batch: int, sqrt_outs):
+    jobs, calls = _update_jobs(scalers, normsqs, sqrt_outs)
+    return _bind(_lib.load().vlmc_wanda_scaler_update_batch, (jobs, len(scalers), nsamples_before, calls, batch, _stream()))
+
+
+def plan_select_batch(weights, sqrt_rows, mode: str, *, ks=None, n=0, m=0, apply_zero=True, masks, partials):
+    """Pre-bound batched select.  The plan owns its SEL_MATRIX workspace (plans may be replayed in any order)."""
+    code = _MODES[mode]
+    ks = [0] * len(weights) if ks is None else ks
+    holder = Workspace()
+    jobs = _select_jobs(weights, sqrt_rows, code, ks, masks, partials, holder)
+    run = _bind(_lib.load().vlmc_wanda_select_batch, (jobs, len(weights), _dtype_code(weights[0]), code, int(n), int(m),
+                                                     int(bool(apply_zero)), _stream()))
+    run.workspace = holder
+    return run

@@ -62,52 +62,59 @@ class InputStat:
     def finalize(self, normsq: torch.Tensor | None = None, batches=None):
         """Run the running-mean recurrence over `normsq` (default: the local calls) in
         order and produce scaler_row and sqrt(scaler_row)."""
-        normsq = self.local_normsq() if normsq is None else normsq
-        batches = self.batches if batches is None else batches
-        self.scaler_row = torch.zeros(self.in_features, dtype=torch.float32, device=self.device)
-        self.sqrt_row = torch.empty_like(self.scaler_row)
-        n, start = 0, 0
-        # consecutive calls with the same batch size go to the device in one launch
-        while start < len(batches):
-            end = start
-            while end < len(batches) and batches[end] == batches[start]:
-                end += 1
-            last = end == len(batches)
-            n = ops.wanda_scaler_update(self.scaler_row, n, normsq[start:end], batches[start],
-                                        sqrt_out=self.sqrt_row if last else None)
-            start = end
-        if not batches:
-            ops.wanda_scaler_update(self.scaler_row, 0, None, 1, sqrt_out=self.sqrt_row)
-        self.nsamples = n
+        finalize_stats([self], [self.local_normsq() if normsq is None else normsq], [batches or self.batches])
         return self
+
+
+def finalize_stats(stats, normsqs, batches_list):
+    """Running-mean recurrence for several statistics.  Statistics that saw the same call pattern (the
+    inputs of one transformer block) share ONE launch per run of equal batch sizes."""
+    for st in stats:
+        st.scaler_row = torch.zeros(st.in_features, dtype=torch.float32, device=st.device)
+        st.sqrt_row = torch.empty_like(st.scaler_row)
+    groups = {}
+    for st, nsq, bt in zip(stats, normsqs, batches_list):
+        groups.setdefault(tuple(bt), []).append((st, nsq))
+    for bt, members in groups.items():
+        n, start = 0, 0
+        while start < len(bt):                 # consecutive calls with the same batch size: one launch
+            end = start
+            while end < len(bt) and bt[end] == bt[start]:
+                end += 1
+            last = end == len(bt)
+            n = ops.wanda_scaler_update_batch([st.scaler_row for st, _ in members], n,
+                                              [nsq[start:end] for _, nsq in members], bt[start],
+                                              [st.sqrt_row if last else None for st, _ in members])
+            start = end
+        if not bt:
+            for st, _ in members:
+                ops.wanda_scaler_update(st.scaler_row, 0, None, 1, sqrt_out=st.sqrt_row)
+        for st, _ in members:
+            st.nsamples = n
+    return stats
 
 
 def gather_stats(stats, group=None):
     """Multi-GPU exchange for one transformer block: all-gather the per-sample squared
     norms of every distinct input in ONE collective, then finalise each statistic over
-    the full, ordered sample set.  With no process group this is just `finalize()`."""
+    the full, ordered sample set.  With no process group this is just the finalisation."""
     import torch.distributed as dist
-    if group is None and not (dist.is_available() and dist.is_initialized()):
-        for st in stats:
-            st.finalize()
-        return stats
-    world = dist.get_world_size(group)
+    world = 1
+    if group is not None or (dist.is_available() and dist.is_initialized()):
+        world = dist.get_world_size(group)
     if world == 1:
-        for st in stats:
-            st.finalize()
-        return stats
+        return finalize_stats(stats, [st.local_normsq() for st in stats], [st.batches for st in stats])
     local = [st.local_normsq() for st in stats]
     n_local = local[0].shape[0]
     assert all(t.shape[0] == n_local for t in local), "every input must see the same number of calls"
     flat = torch.cat(local, dim=1).contiguous()                        # [n_local, sum(in)]
     gathered = torch.empty((world * n_local, flat.shape[1]), dtype=flat.dtype, device=flat.device)
     dist.all_gather_into_tensor(gathered, flat, group=group)           # rank-major == sample order
-    off = 0
+    parts, off = [], 0
     for st in stats:
-        part = gathered[:, off:off + st.in_features].contiguous()
+        parts.append(gathered[:, off:off + st.in_features])            # column slices: the kernel takes a row stride
         off += st.in_features
-        st.finalize(part, st.batches * world)
-    return stats
+    return finalize_stats(stats, parts, [st.batches * world for st in stats])
 
 
 def prune_linear(weight: torch.Tensor, stat: InputStat, mode: str, *, ratio=None, n=0, m=0, apply_zero=True,
@@ -122,3 +129,27 @@ def prune_linear(weight: torch.Tensor, stat: InputStat, mode: str, *, ratio=None
     else:
         raise ValueError(mode)
     return ops.wanda_select(weight, stat.sqrt_row, mode, k=k, apply_zero=apply_zero, mask=mask, partials=partials)
+
+
+def prune_block(weights, stats, mode: str, *, ratios=None, n=0, m=0, apply_zero=True, partials=None):
+    """`for name in subset:` of wanda_pruner.py:316-341 / :664-687 for ALL linears of a block with batched
+    launches.  Linears of different dtypes go in separate batches.  Returns the list of keep masks."""
+    masks = [None] * len(weights)
+    by_dtype = {}
+    for i, w in enumerate(weights):
+        by_dtype.setdefault(w.dtype, []).append(i)
+    for idx in by_dtype.values():
+        ws = [weights[i] for i in idx]
+        if mode == "nm":
+            ks = None
+        elif mode == "row":
+            ks = [int(w.shape[1] * ratios[i]) for w, i in zip(ws, idx)]                     # :336
+        elif mode == "matrix":
+            ks = [int(w.numel() * ratios[i]) for w, i in zip(ws, idx)]                      # :682
+        else:
+            raise ValueError(mode)
+        out, _ = ops.wanda_select_batch(ws, [stats[i].sqrt_row for i in idx], mode, ks=ks, n=n, m=m, apply_zero=apply_zero,
+                                        partials=None if partials is None else [partials[i] for i in idx])
+        for i, mk in zip(idx, out):
+            masks[i] = mk
+    return masks
