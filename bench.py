@@ -113,7 +113,8 @@ def build_plans(blocks, acts, weights, n_local, world, dev, state):
         sel = ops.plan_select_batch(ws, sqs, b.mode, ks=ks, apply_zero=True, masks=state["masks"][bi],
                                     partials=state["partials"][bi])
         n_launch = len({(w.shape[1], k) for w, k in zip(ws, ks)}) if b.mode == "row" else 0
-        steps.append((stat, upd, sel, b.mode == "row", nbytes, n_launch))
+        sbytes = sum(wl.stat_bytes(inp, n_local, acts[bi][ii].element_size()) for ii, inp in enumerate(b.inputs))
+        steps.append((stat, upd, sel, b.mode == "row", nbytes, n_launch, sbytes))
     return steps
 
 
@@ -143,18 +144,28 @@ def alloc_state(blocks, n_local, world, dev):
 
 
 def run_step(plans, state, world, events=None):
-    for bi, (stat, upd, sel, is_row, nbytes, n_launch) in enumerate(plans):
-        stat()
+    """events = {"stat": [...], "rows": [...]} collects (start, stop, algorithmic bytes, launches) on the
+    launch stream around the statistics launch of every block and the per-row select launches of the T5 blocks."""
+    ev = torch.cuda.Event
+    for bi, (stat, upd, sel, is_row, nbytes, n_launch, sbytes) in enumerate(plans):
+        if events is not None:
+            a, b = ev(enable_timing=True), ev(enable_timing=True)
+            a.record()
+            stat()
+            b.record()
+            events["stat"].append((a, b, sbytes, 1))
+        else:
+            stat()
         if world > 1:          # ONE all-gather per block: [n_local, sum(in)] -> [128, sum(in)] in sample order
             flat_local, flat_all = state["flat"][bi]
             dist.all_gather_into_tensor(flat_all, flat_local)
         upd()
         if events is not None and is_row:
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a, b = ev(enable_timing=True), ev(enable_timing=True)
             a.record()
             sel()
             b.record()
-            events.append((a, b, nbytes, n_launch))
+            events["rows"].append((a, b, nbytes, n_launch))
         else:
             sel()
 
@@ -223,7 +234,7 @@ def main():
     for i in range(args.warmup):
         run_step(plans[i % len(plans)], state, world)
     sync()
-    events = []
+    events = {"stat": [], "rows": []}
     t0 = time.perf_counter()
     for i in range(args.steps):
         run_step(plans[(args.warmup + i) % len(plans)], state, world, events)
@@ -234,23 +245,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline of the dominant kernel: the per-row score+select kernel (T5 tower) -----------
-    tot_ms = sum(a.elapsed_time(b) for a, b, _, _ in events)
-    tot_bytes = sum(nb for _, _, nb, _ in events)
-    n_launches = sum(nl for _, _, _, nl in events)
-    ach = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
-    traffic = None
+    # ---- roofline of the dominant kernel (largest share of the step's GPU time): the activation
+    # ---- statistics kernel; the per-row score+select kernel is reported beside it ----------------
+    traffic = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("select_rows_kernel_bytes_per_launch")
+            traffic = json.load(open(tpath))
         except Exception:
-            traffic = None
-    roof = {"bound": "hbm", "kernel": "vlmc::select_rows_kernel (score+select+apply, per-row rule)",
-            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "launches": n_launches,
-            "avg_launch_us": round(tot_ms * 1e3 / max(1, n_launches), 2),
-            "bytes_per_launch": round(tot_bytes / max(1, n_launches))}
+            traffic = {}
+
+    def roof(kind, kernel, tkey):
+        evs = events[kind]
+        tot_ms = sum(a.elapsed_time(b) for a, b, _, _ in evs)
+        tot_bytes = sum(nb for _, _, nb, _ in evs)
+        n_launches = sum(nl for _, _, _, nl in evs)
+        ach = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+        return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(tkey), "launches": n_launches,
+                "avg_launch_us": round(tot_ms * 1e3 / max(1, n_launches), 2),
+                "bytes_per_launch": round(tot_bytes / max(1, n_launches))}
+
+    roofline = roof("stat", "vlmc::act_sqnorm_kernel (per-sample squared column norms of every distinct linear input "
+                            "of a block, one launch per block)", "act_sqnorm_kernel_bytes_per_launch")
+    roofline["other"] = [roof("rows", "vlmc::select_rows_kernel (score+select+apply, per-row rule; one launch per distinct "
+                                      "in_features of a T5 block)", "select_rows_kernel_bytes_per_launch")]
 
     out = None
     if rank == 0:
@@ -265,7 +284,7 @@ def main():
                        "linears": n_lin, "blocks": len(blocks), "calib_samples": N_CALIB, "ratio": RATIO,
                        "weight_sets": len(sets), "total_prune_wall_clock_s": round(elapsed / args.steps, 5),
                        "parallelism": f"calib-dp{world}"},
-            "roofline": roof,
+            "roofline": roofline,
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(blocks, args.cpu_seconds)

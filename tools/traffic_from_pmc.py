@@ -23,14 +23,16 @@ fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1",
        "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950 FETCH_SIZE counts 64 B per 128-B request)",
        "kernels": {}}
-rows_f = rows_w = rows_n = 0
+agg = collections.defaultdict(lambda: [0.0, 0])
 for k in sorted(fetch):
     f, w = fetch[k], write.get(k, [0])
     fb, wb = 2 * sum(f) / len(f) * 1024, sum(w) / len(w) * 1024
     out["kernels"][k] = {"dispatches": len(f), "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
                          "hbm_bytes_per_launch": round(fb + wb)}
-    if "select_rows_kernel" in k:
-        rows_f += 2 * sum(f) * 1024; rows_w += sum(w) / len(w) * 1024 * len(f); rows_n += len(f)
-out["select_rows_kernel_bytes_per_launch"] = round((rows_f + rows_w) / rows_n)
+    base = k.split("<")[0].split("::")[-1]                       # all instantiations of one kernel template together
+    agg[base][0] += (fb + wb) * len(f)
+    agg[base][1] += len(f)
+for base, (tot, n) in agg.items():
+    out[f"{base}_bytes_per_launch"] = round(tot / n)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
