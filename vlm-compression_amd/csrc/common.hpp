@@ -50,30 +50,37 @@ template <> struct Chunk8<f32_t> { float v[8]; };
 template <> struct Chunk8<f16_t> { uint16_t v[8]; };
 template <> struct Chunk8<bf16_t> { uint16_t v[8]; };
 
-template <typename T> __device__ __forceinline__ Chunk8<T> load_chunk8(const typename T::raw *p) {
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+// NT = non-temporal (streaming) access: for data touched exactly once by the kernel and not re-read by the
+// next one, so that it does not displace re-used lines in L2 / Infinity Cache.
+template <typename T, bool NT = false> __device__ __forceinline__ Chunk8<T> load_chunk8(const typename T::raw *p) {
     Chunk8<T> c;
+    const u32x4_t *q = reinterpret_cast<const u32x4_t *>(p);
     if constexpr (sizeof(typename T::raw) == 2) {
-        uint4 q = *reinterpret_cast<const uint4 *>(p);
-        __builtin_memcpy(c.v, &q, 16);
+        const u32x4_t a = NT ? __builtin_nontemporal_load(q) : *q;
+        __builtin_memcpy(c.v, &a, 16);
     } else {
-        float4 a = reinterpret_cast<const float4 *>(p)[0];
-        float4 b = reinterpret_cast<const float4 *>(p)[1];
+        const u32x4_t a = NT ? __builtin_nontemporal_load(q) : q[0];
+        const u32x4_t b = NT ? __builtin_nontemporal_load(q + 1) : q[1];
         __builtin_memcpy(c.v, &a, 16);
         __builtin_memcpy(c.v + 4, &b, 16);
     }
     return c;
 }
-template <typename T> __device__ __forceinline__ void store_chunk8(typename T::raw *p, const Chunk8<T> &c) {
+template <typename T, bool NT = false> __device__ __forceinline__ void store_chunk8(typename T::raw *p, const Chunk8<T> &c) {
+    u32x4_t *q = reinterpret_cast<u32x4_t *>(p);
     if constexpr (sizeof(typename T::raw) == 2) {
-        uint4 q;
-        __builtin_memcpy(&q, c.v, 16);
-        *reinterpret_cast<uint4 *>(p) = q;
+        u32x4_t a;
+        __builtin_memcpy(&a, c.v, 16);
+        if constexpr (NT) __builtin_nontemporal_store(a, q); else *q = a;
     } else {
-        float4 a, b;
+        u32x4_t a, b;
         __builtin_memcpy(&a, c.v, 16);
         __builtin_memcpy(&b, c.v + 4, 16);
-        reinterpret_cast<float4 *>(p)[0] = a;
-        reinterpret_cast<float4 *>(p)[1] = b;
+        if constexpr (NT) { __builtin_nontemporal_store(a, q); __builtin_nontemporal_store(b, q + 1); }
+        else { q[0] = a; q[1] = b; }
     }
 }
 

@@ -13,17 +13,21 @@
 
 namespace vlmc {
 
-// VEC consecutive elements per lane as ONE naturally aligned vector load (<= 16 B; 32 B = 2 loads).
+// VEC consecutive elements per lane as ONE naturally aligned vector load (<= 16 B), non-temporal: the
+// activations are read exactly once, so they should not displace the weights in L2 / Infinity Cache.
+template <int BYTES> struct NtWord;
+template <> struct NtWord<2> { using type = uint16_t; };
+template <> struct NtWord<4> { using type = uint32_t; };
+template <> struct NtWord<8> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct NtWord<16> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
 template <typename T, int VEC> __device__ __forceinline__ void vec_load(const typename T::raw *p, float *o) {
     using raw = typename T::raw;
-    if constexpr (VEC == 1) {
-        o[0] = to_f32<T>(p[0]);
-    } else {
-        struct alignas((sizeof(raw) * VEC > 16) ? 16 : sizeof(raw) * VEC) Pack { raw r[VEC]; };
-        const Pack q = *reinterpret_cast<const Pack *>(p);
+    using word = typename NtWord<sizeof(raw) * VEC>::type;
+    const word w = __builtin_nontemporal_load(reinterpret_cast<const word *>(p));
+    raw r[VEC];
+    __builtin_memcpy(r, &w, sizeof(w));
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) o[i] = to_f32<T>(q.r[i]);
-    }
+    for (int i = 0; i < VEC; ++i) o[i] = to_f32<T>(r[i]);
 }
 
 // One hook input of a batched launch (all jobs share dtype and the number of calls).

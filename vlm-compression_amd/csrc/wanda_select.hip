@@ -72,10 +72,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
 // ------------------------------------------------------------------------------------------
 // chunk access: 8 consecutive columns per lane
 // ------------------------------------------------------------------------------------------
-template <typename T, bool ALIGNED>
+template <typename T, bool ALIGNED, bool NT = false>
 __device__ __forceinline__ Chunk8<T> load_row_chunk(const typename T::raw *row, int64_t col0, int64_t in_f) {
     if constexpr (ALIGNED) {
-        return load_chunk8<T>(row + col0);
+        return load_chunk8<T, NT>(row + col0);
     } else {
         Chunk8<T> c;
 #pragma unroll
@@ -83,24 +83,25 @@ __device__ __forceinline__ Chunk8<T> load_row_chunk(const typename T::raw *row, 
         return c;
     }
 }
-template <typename T, bool ALIGNED>
+template <typename T, bool ALIGNED, bool NT = false>
 __device__ __forceinline__ void store_row_chunk(typename T::raw *row, int64_t col0, int64_t in_f, const Chunk8<T> &c) {
     if constexpr (ALIGNED) {
-        store_chunk8<T>(row + col0, c);
+        store_chunk8<T, NT>(row + col0, c);
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             if (col0 + j < in_f) row[col0 + j] = c.v[j];
     }
 }
-template <bool ALIGNED>
+template <bool ALIGNED, bool NT = false>
 __device__ __forceinline__ void store_mask_chunk(uint8_t *mrow, int64_t col0, int64_t in_f, uint32_t keepbits) {
     if constexpr (ALIGNED) {
         // spread bit j to byte j: (nibble * 0x204081) & 0x01010101 puts bits 0..3 into bytes 0..3
-        uint2 m;
+        u32x2_t m;
         m.x = ((keepbits & 0xFu) * 0x00204081u) & 0x01010101u;
         m.y = (((keepbits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u;
-        *reinterpret_cast<uint2 *>(mrow + col0) = m;
+        u32x2_t *q = reinterpret_cast<u32x2_t *>(mrow + col0);
+        if constexpr (NT) __builtin_nontemporal_store(m, q); else *q = m;
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -253,7 +254,7 @@ void select_rows_kernel(const SelBatch b) {
 #pragma unroll
     for (int s = 0; s < CH; ++s) {
         valid[s] = int64_t(s) * NT + tid < nchunks;
-        if (valid[s]) raw[s] = load_row_chunk<T, ALIGNED>(wrow, (int64_t(s) * NT + tid) * 8, in_f);
+        if (valid[s]) raw[s] = load_row_chunk<T, ALIGNED, true>(wrow, (int64_t(s) * NT + tid) * 8, in_f);
     }
     VLMC_STAMP(0);
     uint32_t key[E];
@@ -456,8 +457,8 @@ void select_rows_kernel(const SelBatch b) {
                 raw[s].v[j] = keep ? raw[s].v[j] : typename T::raw(0);
             }
         }
-        store_mask_chunk<ALIGNED>(mrow, c0, in_f, keepbits);
-        if (apply_zero && keepbits != 0xFFu) store_row_chunk<T, ALIGNED>(wrow, c0, in_f, raw[s]);
+        store_mask_chunk<ALIGNED, true>(mrow, c0, in_f, keepbits);
+        if (apply_zero && keepbits != 0xFFu) store_row_chunk<T, ALIGNED, true>(wrow, c0, in_f, raw[s]);
     }
     VLMC_STAMP(5);
 #ifndef VLMC_STAMPS
@@ -784,7 +785,7 @@ __global__ __launch_bounds__(1024) void matrix_apply_kernel(const SelBatch b) {
     for (uint32_t c = wg * 1024u + uint32_t(tid); c < total; c += jb.nwg * 1024u) {
         const uint32_t row = c / cpr, col0 = (c - row * cpr) * 8;
         typename T::raw *wrow = W + int64_t(row) * jb.ldw;
-        Chunk8<T> raw = load_row_chunk<T, ALIGNED>(wrow, col0, in_f);
+        Chunk8<T> raw = load_row_chunk<T, ALIGNED, true>(wrow, col0, in_f);
         float sqv[8];
         load_sq_chunk<ALIGNED>(jb.sq, col0, in_f, sqv);
         uint32_t keepbits = 0;
@@ -801,8 +802,8 @@ __global__ __launch_bounds__(1024) void matrix_apply_kernel(const SelBatch b) {
             if (pruned) raw.v[j] = typename T::raw(0);
         }
         dsum += double(fs);
-        store_mask_chunk<ALIGNED>(jb.mask + int64_t(row) * in_f, col0, in_f, keepbits);
-        if (b.apply_zero && keepbits != 0xFFu) store_row_chunk<T, ALIGNED>(wrow, col0, in_f, raw);
+        store_mask_chunk<ALIGNED, true>(jb.mask + int64_t(row) * in_f, col0, in_f, keepbits);
+        if (b.apply_zero && keepbits != 0xFFu) store_row_chunk<T, ALIGNED, true>(wrow, col0, in_f, raw);
     }
     if (jb.parts) {
         dsum = wave_sum_f64(dsum);
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(256) void nm_kernel(const SelBatch b) {
     for (uint32_t c = wg * 256u + threadIdx.x; c < total; c += jb.nwg * 256u) {
         const uint32_t row = c / cpr, col0 = (c - row * cpr) * 8;
         typename T::raw *wrow = W + int64_t(row) * jb.ldw;
-        Chunk8<T> raw = load_row_chunk<T, ALIGNED>(wrow, col0, in_f);
+        Chunk8<T> raw = load_row_chunk<T, ALIGNED, true>(wrow, col0, in_f);
         float sqv[8];
         load_sq_chunk<ALIGNED>(jb.sq, col0, in_f, sqv);
         uint32_t key[8];
@@ -867,8 +868,8 @@ __global__ __launch_bounds__(256) void nm_kernel(const SelBatch b) {
                 if (pruned) raw.v[g * M + i] = typename T::raw(0);
             }
         }
-        store_mask_chunk<ALIGNED>(jb.mask + int64_t(row) * in_f, col0, in_f, keepbits);
-        if (b.apply_zero && keepbits != 0xFFu) store_row_chunk<T, ALIGNED>(wrow, col0, in_f, raw);
+        store_mask_chunk<ALIGNED, true>(jb.mask + int64_t(row) * in_f, col0, in_f, keepbits);
+        if (b.apply_zero && keepbits != 0xFFu) store_row_chunk<T, ALIGNED, true>(wrow, col0, in_f, raw);
     }
     if (jb.parts) {
         dsum = wave_sum_f64(dsum);
