@@ -40,6 +40,7 @@ def _setup(rank, world, port):
             setattr(obj, name, val)
     oracle_ops.install(MP)
     oracle_ops.install_dsnot(MP)
+    oracle_ops.install_sparsegpt(MP)
     return ops
 
 
@@ -130,3 +131,41 @@ def test_sample_sharded_dsnot_pruner_world2_matches_reference_golden(tmp_path):
         assert len(masks) == 2 * 4 + 2 * 7 + 2 * 11
         for mn, m in masks.items():
             assert torch.equal(m, G[f"fp32_r50/mask/{mn}"]), (r, mn)
+
+
+def _worker_sparsegpt_pruner(rank, world, port, out_dir):
+    _setup(rank, world, port)
+    torch.set_num_threads(1)
+    import test_pruner_host_logic as T
+    pruned, _ = T._run_sparsegpt_pruner("fp32_u50", "cpu")
+    torch.save({k: v for k, v in pruned.state_dict().items()}, os.path.join(out_dir, f"sgpt_pruned_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sample_sharded_sparsegpt_pruner_world2_tracks_reference_golden(tmp_path):
+    """SparseGPT under sample sharding: every rank accumulates the Hessian of its samples, ONE all-reduce per
+    linear forms the sample-weighted mean (lavis/compression/pruners/sparsegpt_pruner.py here: _allreduce_hessians).
+    The sum order differs from the sequential running mean, so parity is the SparseGPT tolerance: both ranks
+    identical to each other, zero pattern and weights close to the reference's single-process run."""
+    import golden_io
+    port = _free_port()
+    mp.spawn(_worker_sparsegpt_pruner, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    E = golden_io.load("sparsegpt_e2e")
+    sd0, sd1 = torch.load(tmp_path / "sgpt_pruned_0.pt"), torch.load(tmp_path / "sgpt_pruned_1.pt")
+    tot = agree = 0
+    num = den = 0.0
+    for key in [k for k in E if k.startswith("fp32_u50/sd/")]:
+        k = key[len("fp32_u50/sd/"):]
+        assert torch.equal(sd0[k], sd1[k]), k                       # ranks agree bit for bit
+        ref, g = E[key], sd0[k]
+        if ref.dim() != 2 or ".block" not in k or "shared" in k:
+            continue
+        same = (g == 0) == (ref == 0)
+        tot += same.numel()
+        agree += int(same.sum())
+        clean = same.all(dim=1)
+        num += float((g[clean] - ref[clean]).pow(2).sum())
+        den += float(ref[clean].pow(2).sum())
+    assert tot > 0 and agree / tot >= 0.97, agree / tot
+    assert (num / den) ** 0.5 < 2e-2
