@@ -468,9 +468,71 @@ def gen_dsnot_e2e():
     print("dsnot_e2e.npz:", len(out), "arrays")
 
 
+def gen_ressa():
+    """RESSA retraining (image_text_retrain.py:95-203) on the toy InstructBLIP: Wanda masks under lora_model,
+    then the reference task's `_train_inner_loop` for a few AdamW steps on CPU, fp32, no AMP."""
+    from lavis.compression.pruners import wanda_pruner as R
+
+    def stub(name, **a):
+        m = types.ModuleType(name)
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        m.__dict__.update(a)
+        sys.modules[name] = m
+        return m
+    # import the task module without lavis/tasks/__init__.py (which pulls in every task and dataset) and without timm
+    stub("timm"); stub("timm.models"); stub("timm.models.hub")
+    stub("lavis.tasks").__path__ = [REF + "/lavis/tasks"]
+    from lavis.tasks.image_text_retrain import ImageTextRetrainTask
+    from lavis.peft.src.peft.tuners.lora import mark_only_lora_as_trainable
+    out = {}
+    model = toy_models.init_toy(toy_models.ToyBlipT5(), seed=7)
+    _wrap_lora_reference(model)
+    for m in model.modules():
+        if hasattr(m, "lora_A"):
+            m.merge_weights = False                      # LoraConfig default (lora.py:68-71)
+            m.sparse = True                              # train.py:607-609 with --sparse
+    model.eval()
+    batches = toy_models.make_batches(6, seed=11)
+    spec = "2-0.5-1.0-1.0"
+    pr = R.BLIPT5LayerWandaPruner(model=model, data_loader=batches, t5_prune_spec=spec, vit_prune_spec=spec,
+                                  t5_pruning_method="wanda", vit_pruning_method="wanda", num_samples=6,
+                                  max_sparsity_per_layer=1.01)
+    model, _ = pr.prune(lora_model=True)
+    mark_only_lora_as_trainable(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-2, weight_decay=0.05)
+
+    class Sched:
+        def step(self, cur_epoch, cur_step):
+            for gparam in opt.param_groups:
+                gparam["lr"] = 1e-2 * (0.9 ** cur_step)
+
+    task = ImageTextRetrainTask()
+    task.kl_weight = 0.1
+    losses = []
+    orig_backward = torch.Tensor.backward
+
+    def spy(self, *a, **k):
+        losses.append(float(self.detach()))
+        return orig_backward(self, *a, **k)
+    torch.Tensor.backward = spy
+    try:
+        stats = task._train_inner_loop(epoch=0, iters_per_epoch=5, model=model, data_loader=iter(batches), optimizer=opt,
+                                       lr_scheduler=Sched(), scaler=None, log_freq=1, cuda_enabled=False,
+                                       accum_grad_iters=2)
+    finally:
+        torch.Tensor.backward = orig_backward
+    out["losses"] = torch.tensor(losses, dtype=torch.float64)
+    out["stats_loss"] = np.array(stats["loss"])
+    for k_, t in model.state_dict().items():
+        out[f"sd/{k_}"] = t
+    golden_io.save("ressa", out)
+    print("ressa.npz:", len(out), "arrays; losses", losses)
+
+
 GROUPS = {"wanda": gen_wanda, "wanda_e2e": gen_wanda_e2e, "sparse_lora": gen_sparse_lora, "sparsegpt": gen_sparsegpt,
           "sparsegpt_e2e": gen_sparsegpt_e2e, "dsnot": gen_dsnot,
-          "dsnot_e2e": gen_dsnot_e2e}
+          "dsnot_e2e": gen_dsnot_e2e, "ressa": gen_ressa}
 
 if __name__ == "__main__":
     import_reference()

@@ -112,3 +112,37 @@ def compare_with_golden(name, pruned, exact=True, min_mask_agreement=1.0, weight
     agree = 1 - stats["mask_diff"] / stats["mask_elems"]
     assert agree >= min_mask_agreement, f"{name}: mask agreement {agree:.5f} < {min_mask_agreement}"
     return stats
+
+
+# ---- RESSA retraining --------------------------------------------------------------
+def run_ressa(device="cpu", iters=5):
+    """Toy InstructBLIP + SparseLoRA (sparse=True) -> Wanda masks under lora_model -> the drop-in task's
+    `_train_inner_loop`; the same script the golden generator ran with the reference's modules."""
+    from lavis.compression import load_pruner
+    from lavis.peft.src.peft.tuners.lora import mark_only_lora_as_trainable
+    from lavis.tasks.image_text_retrain import ImageTextRetrainTask
+    model = toy_models.init_toy(toy_models.ToyBlipT5(), seed=7)
+    wrap_lora(model)
+    for m in model.modules():
+        if hasattr(m, "lora_A"):
+            m.merge_weights = False
+            m.sparse = True
+    model.eval().to(device)
+    batches = [{k: t.to(device) for k, t in b.items()} for b in toy_models.make_batches(6, seed=11)]
+    spec = "2-0.5-1.0-1.0"
+    cfg = dict(t5_prune_spec=spec, vit_prune_spec=spec, t5_pruning_method="wanda", vit_pruning_method="wanda",
+               num_samples=6, max_sparsity_per_layer=1.01)
+    model, _ = load_pruner("blipt5_wanda_pruner", model, batches, cfg=cfg).prune(lora_model=True)
+    mark_only_lora_as_trainable(model)
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-2, weight_decay=0.05)
+
+    class Sched:
+        def step(self, cur_epoch, cur_step):
+            for g in opt.param_groups:
+                g["lr"] = 1e-2 * (0.9 ** cur_step)
+
+    task = ImageTextRetrainTask()
+    task.kl_weight = 0.1
+    stats = task._train_inner_loop(epoch=0, iters_per_epoch=iters, model=model, data_loader=iter(batches), optimizer=opt,
+                                   lr_scheduler=Sched(), scaler=None, log_freq=1, cuda_enabled=False, accum_grad_iters=2)
+    return model, task, stats

@@ -161,7 +161,8 @@ class ToyBlipT5(nn.Module):
         kw["encoder_hidden_states"] = h
         for blk in t5.decoder.block:
             d = blk(d, dense=llm_dense, **kw)[0]
-        return {"loss": d.float().pow(2).mean()}
+        logits = d.float() @ t5.shared.weight.float().t()            # tied lm head, [B, out_len, vocab]
+        return {"loss": d.float().pow(2).mean(), "logits": logits}
 
 
 def make_batches(n, vit_tokens=9, vit_dim=32, txt_len=5, out_len=4, vocab=50, seed=0, image_mean=0.1):
