@@ -170,7 +170,7 @@ def test_select_batch_rejects_shared_workspace_and_bad_args():
     Wd = W.to(DEV)
     sq = ops.sqrt_scaler(torch.from_numpy(s).to(DEV))
     mk = torch.empty((16, 64), dtype=torch.bool, device=DEV)
-    ws = torch.empty(1 << 16, dtype=torch.uint8, device=DEV)
+    ws = torch.empty(1 << 18, dtype=torch.uint8, device=DEV)
     jobs = (_lib.SelectJob * 2)()
     for j in range(2):
         jobs[j] = _lib.SelectJob(Wd.data_ptr(), 16, 64, 64, sq.data_ptr(), 10, mk.data_ptr(), None, ws.data_ptr(), ws.numel())

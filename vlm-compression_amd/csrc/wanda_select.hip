@@ -10,9 +10,9 @@
 //             key is found by radix-64 refinement of a bracket with 64 LDS counters (6 key bits
 //             per sweep), seeded by a 32-key sample of the row; ties are broken by column index
 //             exactly like the reference's stable sort.  See the kernel's header comment.
-//  SEL_MATRIX sample -> bracket, two counting passes (4096 LDS bins inside the bracket, then inside
-//             the bin that holds rank k), one elementwise apply pass; a one-workgroup exact radix
-//             select is the (normally idle) fallback.  See the section comment below.
+//  SEL_MATRIX sample -> bracket, one counting pass (2048 LDS bins inside the bracket), one apply pass that
+//             leaves the few hundred elements of the threshold's bin to a one-workgroup resolve kernel
+//             (which is also the exact fallback).  See the section comment below.
 //  SEL_NM     elementwise: each lane ranks the columns of its m-groups in registers.
 // Every kernel takes a table of up to 12 linears ("jobs") by value, so all linears of a transformer
 // block that share a launch shape go to the GPU in ONE launch.
@@ -488,33 +488,39 @@ void select_rows_kernel(const SelBatch b) {
 // ------------------------------------------------------------------------------------------
 // SEL_MATRIX: thr = sort(score.flatten())[k]; prune score < thr  (wanda_pruner.py:682-683)
 //
-//   sample   one workgroup per linear: 2048 random samples -> two order statistics
-//            (coarse LDS histogram) bracket the threshold to ~15 % of the elements with a 6-sigma
-//            margin; also clears the job's workspace (no memset launches).
-//   pass A   streams W once: count(key < lo) in registers, keys inside the bracket bump one of
-//            4096 LDS counters ((key-lo) >> shift; ~15 % of the elements, spread over the bins, so
-//            the LDS atomics are cheap).  The LAST workgroup to finish (device-scope counter)
-//            scans the merged histogram and publishes the bin that holds rank k.
-//   pass B   streams W again (<= 17 MB per ViT-g linear: served by the Infinity Cache), counting
-//            per key inside that one bin (~100 elements) -> the exact threshold key.
-//   apply    elementwise mask + zeroing + score partial sums.
-//   slow     one workgroup per linear, idle unless the bracket missed rank k or was wider than
-//            2^24 keys (then an exact 4 x 8-bit radix select over the whole matrix).  Every decision
-//            rests on exact counts; sampling only affects speed.
-// Workspace per job (u32 words): histA[4096] | histB[4096] | ctrl[16].
+//   sample   one workgroup per linear: 2048 random samples -> coarse LDS histogram -> a bracket around
+//            rank k with a 6-sigma margin (~15 % of the elements); also clears the job's control words
+//            and histogram (no memset launches).  One CU issues every sample load, so the sample size
+//            is what this kernel costs.
+//   count    streams W once: count(key < lo) and the NaN count in registers, keys inside the bracket bump
+//            one of 2048 LDS counters ((key-lo) >> shift).  The LAST workgroup to finish (device-scope
+//            counter) scans the merged histogram and publishes the bin [lob, lob + 2^shift) that holds
+//            rank k and the rank left inside it.
+//   apply    streams W again: key < lob -> pruned, key >= lob + 2^shift -> kept, and the few hundred
+//            elements inside the bin are kept PROVISIONALLY and appended to a candidate list (index, key).
+//            Writes the whole mask, the zeroed weights and the score partial sums: 5 B / weight.
+//   resolve  one workgroup per linear: exact rank select among the candidates (LDS radix), then clears
+//            the mask byte and the weight of the candidates below the threshold.  The same kernel is the
+//            fallback when the bracket missed rank k or the bin overflowed the list (heavy ties, e.g.
+//            re-pruning weights that are already half zero): it then selects by streaming the matrix itself.
+// Every decision rests on exact counts; sampling only affects speed.  No device-wide fences: everything
+// exchanged between workgroups inside a launch goes through device-scope atomics.
+// Workspace per job (u32 words): hist[2048] | ctrl[32] | candidates[2 x 8192].
 // ------------------------------------------------------------------------------------------
-constexpr int kMatBins = 4096;
+constexpr int kMatBins = 2048;
 constexpr int kMatSample = 2048;   // one CU issues every sample load: the sample size is what its kernel costs
-constexpr int kCtrl = 2 * kMatBins;
-constexpr int kWsWords = 2 * kMatBins + 16;
-enum { C_LO = 0, C_SHIFT, C_BELOW, C_DONE_A, C_LOB, C_SHIFTB, C_RANKB, C_DONE_B, C_THR, C_FAIL, C_SKIPB };
+constexpr int kCandCap = 8192;
+constexpr int kCtrl = kMatBins;
+constexpr int kCand = kMatBins + 32;
+constexpr int kWsWords = kCand + 2 * kCandCap;
+enum { C_LO = 0, C_SHIFT, C_BELOW, C_NANC, C_LOB, C_RANKB, C_NONE, C_FAIL, C_DONE, C_NCAND };
 
 __device__ __forceinline__ uint32_t ld_dev(const uint32_t *p) {       // device-scope load (bypasses the CU's L1)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Rank search over a histogram held 4 bins per thread by the first nthreads*4 bins of a 1024-thread
-// workgroup: finds the bin with cum <= need < cum + h.  Returns false if need >= total.
+// Rank search over a histogram held 4 bins per thread by a 1024-thread workgroup (bins past the histogram's
+// end are passed as 0): finds the bin with cum <= need < cum + h.  Returns false if need >= total.
 __device__ bool block_find_rank(const uint32_t (&h)[4], uint32_t need, uint32_t *red /*>= 20 u32 of LDS*/, uint32_t &bin,
                                 uint32_t &before) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -550,8 +556,8 @@ __device__ __forceinline__ uint32_t element_key(const SelJob &jb, uint32_t e) {
     return score_key(ieee_mul(fabsf(to_f32<T>(w)), jb.sq[col]));
 }
 
-// Coarse bin of a key for the sample histogram: sign/exponent + 4 mantissa bits (2^19 keys per bin).
-constexpr int kCoarseShift = 19;
+// Coarse bin of a key for the sample histogram: sign/exponent + 3 mantissa bits (2^20 keys per bin).
+constexpr int kCoarseShift = 20;
 __device__ __forceinline__ uint32_t coarse_bin(uint32_t key) {
     const uint32_t b = key >> kCoarseShift;
     return b < uint32_t(kMatBins) ? b : uint32_t(kMatBins - 1);   // NaN keys (0xFFFFFFFF) -> last bin
@@ -564,13 +570,13 @@ __global__ __launch_bounds__(1024) void matrix_sample_kernel(const SelBatch b) {
     const SelJob &jb = b.job[blockIdx.x];
     const int tid = threadIdx.x;
     uint32_t *ws = jb.ws;
-    for (int i = tid; i < kWsWords; i += 1024) ws[i] = 0;
+    for (int i = tid; i < kCand; i += 1024) ws[i] = 0;           // histogram + control words
     for (int i = tid; i < kMatBins; i += 1024) hist[i] = 0;
     __syncthreads();                                             // ctrl words are rewritten below
     const uint32_t numel = jb.out_f * jb.in_f;
     const uint32_t S = numel < uint32_t(kMatSample) ? numel : uint32_t(kMatSample);
     // uniform sampling with replacement: (row, col) = two multiplicative hashes scaled by mul-high (no integer
-    // division: this single workgroup is instruction-bound); all 16 loads of a lane are issued before the first use
+    // division: this single workgroup is instruction-bound); all loads of a lane are issued before the first use
     const typename T::raw *W = static_cast<const typename T::raw *>(jb.W);
     constexpr int SPT = kMatSample / 1024;                       // samples per thread
     uint32_t col[SPT];
@@ -599,9 +605,11 @@ __global__ __launch_bounds__(1024) void matrix_sample_kernel(const SelBatch b) {
     const uint32_t rs = uint32_t((uint64_t(jb.k) * S) / numel);
     const float pr = float(jb.k) / float(numel);
     const uint32_t margin = uint32_t(6.f * sqrtf(float(S) * pr * (1.f - pr))) + 8u;
-    uint32_t h[4];
+    uint32_t h[4] = {0, 0, 0, 0};
+    if (tid < kMatBins / 4) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) h[i] = hist[tid * 4 + i];
+        for (int i = 0; i < 4; ++i) h[i] = hist[tid * 4 + i];
+    }
     uint32_t lo = 0, hi = 0xFFFFFFFFu, bin, before;
     if (rs > margin) {
         block_find_rank(h, rs - margin, red, bin, before);
@@ -616,52 +624,55 @@ __global__ __launch_bounds__(1024) void matrix_sample_kernel(const SelBatch b) {
     if (tid == 0) {
         ws[kCtrl + C_LO] = lo;
         ws[kCtrl + C_SHIFT] = shift;
-        if (b.p0) ws[kCtrl + C_FAIL] = 1;            // test hook: force the slow path
+        if (b.p0) ws[kCtrl + C_FAIL] = 1;            // test hook: force the fallback
     }
 }
 
-// One streaming pass over a job's matrix.  PASS 0: bracket histogram (+ below count); PASS 1: per-key
-// histogram inside the bin found by pass 0.
-template <typename T, bool ALIGNED, int PASS>
+// (row, chunk-in-row) walker over a job's chunks: workgroup `wg` of `nwg`, NCH chunks in flight per lane.
+struct ChunkWalk {
+    uint32_t cpr, total, step, step_rows, step_cir;
+    __device__ ChunkWalk(const SelJob &jb) {
+        cpr = (jb.in_f + 7) / 8;
+        total = jb.out_f * cpr;
+        step = jb.nwg * 1024u;
+        step_rows = step / cpr;
+        step_cir = step - step_rows * cpr;
+    }
+};
+
+template <typename T, bool ALIGNED>
 __global__ __launch_bounds__(1024) void matrix_count_kernel(const SelBatch b) {
     __shared__ uint32_t lh[kMatBins];
-    __shared__ uint32_t red[20];
+    __shared__ uint32_t red[36];
     uint32_t wg;
     const SelJob &jb = b.job[find_job(b, blockIdx.x, wg)];
     const int tid = threadIdx.x;
     uint32_t *ws = jb.ws;
-    // the control block, written by earlier launches only: fetched with three 16-byte loads issued together
-    const uint4 c0 = reinterpret_cast<const uint4 *>(ws + kCtrl)[0], c1 = reinterpret_cast<const uint4 *>(ws + kCtrl)[1],
-                c2 = reinterpret_cast<const uint4 *>(ws + kCtrl)[2];
-    if (c2.y /* C_FAIL */) return;
-    if (PASS == 1 && c2.z /* C_SKIPB */) return;
+    // the control block, written by the sample launch: two 16-byte loads issued together
+    const uint4 c0 = reinterpret_cast<const uint4 *>(ws + kCtrl)[0], c1 = reinterpret_cast<const uint4 *>(ws + kCtrl)[1];
+    if (c1.w /* C_FAIL */) return;
     for (int i = tid; i < kMatBins; i += 1024) lh[i] = 0;
-    const uint32_t lo = PASS == 0 ? c0.x /* C_LO */ : c1.x /* C_LOB */;
-    const uint32_t wshift = c0.y /* C_SHIFT */;                  // PASS 1: window = one pass-0 bin = 2^wshift keys
-    const uint32_t shift = PASS == 0 ? wshift : c1.y /* C_SHIFTB */;
-    const uint32_t rankb = c1.z /* C_RANKB */;
-    const uint32_t span = PASS == 0 ? uint32_t(kMatBins) : ((1u << wshift) >> shift);   // bins in use
+    const uint32_t lo = c0.x /* C_LO */, shift = c0.y /* C_SHIFT */;
     __syncthreads();
-    const uint32_t in_f = jb.in_f, cpr = (in_f + 7) / 8, total = jb.out_f * cpr;
+    const uint32_t in_f = jb.in_f;
     const typename T::raw *W = static_cast<const typename T::raw *>(jb.W);
-    uint32_t below = 0;
-    const uint32_t step = jb.nwg * 1024u, step_rows = step / cpr, step_cir = step - step_rows * cpr;
+    const ChunkWalk cw(jb);
+    uint32_t below = 0, nanc = 0;
     constexpr int NCH = 4;                                       // chunks in flight per lane
-    for (uint32_t cb = wg * 1024u + uint32_t(tid); cb < total; cb += NCH * step) {
+    for (uint32_t cb = wg * 1024u + uint32_t(tid); cb < cw.total; cb += NCH * cw.step) {
         Chunk8<T> raw[NCH];
         float sqv[NCH][8];
         uint32_t col0[NCH];
         bool has[NCH];
-        // (row, chunk-in-row) of cb by one division, of cb + u*step by carry arithmetic
-        uint32_t row = cb / cpr, cir = cb - row * cpr;
+        uint32_t row = cb / cw.cpr, cir = cb - row * cw.cpr;     // one division, then carry arithmetic
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
-            has[u] = cb + uint32_t(u) * step < total;
+            has[u] = cb + uint32_t(u) * cw.step < cw.total;
             col0[u] = cir * 8;
             raw[u] = load_row_chunk<T, ALIGNED>(W + int64_t(has[u] ? row : 0u) * jb.ldw, has[u] ? col0[u] : 0u, in_f);
-            row += step_rows;
-            cir += step_cir;
-            if (cir >= cpr) { cir -= cpr; ++row; }
+            row += cw.step_rows;
+            cir += cw.step_cir;
+            if (cir >= cw.cpr) { cir -= cw.cpr; ++row; }
         }
 #pragma unroll
         for (int u = 0; u < NCH; ++u) load_sq_chunk<ALIGNED>(jb.sq, col0[u], in_f, sqv[u]);
@@ -672,27 +683,28 @@ __global__ __launch_bounds__(1024) void matrix_count_kernel(const SelBatch b) {
             for (int j = 0; j < 8; ++j) {
                 if (ALIGNED || col0[u] + j < in_f) {
                     const uint32_t key = score_key(ieee_mul(fabsf(to_f32<T>(raw[u].v[j])), sqv[u][j]));
-                    if (PASS == 0) below += key < lo ? 1u : 0u;
+                    below += key < lo ? 1u : 0u;
+                    nanc += key == 0xFFFFFFFFu ? 1u : 0u;
                     const uint32_t d = (key - lo) >> shift;
-                    if (key >= lo && d < span) atomicAdd(&lh[d], 1u);
+                    if (key >= lo && d < uint32_t(kMatBins)) atomicAdd(&lh[d], 1u);
                 }
             }
         }
     }
-    uint32_t *gh = ws + (PASS == 0 ? 0 : kMatBins);
-    if (PASS == 0) {
-        const uint32_t wsum = wave_sum_u32_dpp(below);
-        if ((tid & 63) == 0) red[tid >> 6] = wsum;
+    {
+        const uint32_t wsum = wave_sum_u32_dpp(below), nsum = wave_sum_u32_dpp(nanc);
+        if ((tid & 63) == 0) { red[tid >> 6] = wsum; red[16 + (tid >> 6)] = nsum; }
     }
     __syncthreads();
     for (int i = tid; i < kMatBins; i += 1024) {
         const uint32_t v = lh[i];
-        if (v) atomicAdd(&gh[i], v);
+        if (v) atomicAdd(&ws[i], v);
     }
-    if (PASS == 0 && tid == 0) {
-        uint32_t bsum = 0;
-        for (int w = 0; w < 16; ++w) bsum += red[w];
+    if (tid == 0) {
+        uint32_t bsum = 0, nsum = 0;
+        for (int w = 0; w < 16; ++w) { bsum += red[w]; nsum += red[16 + w]; }
         if (bsum) atomicAdd(&ws[kCtrl + C_BELOW], bsum);
+        if (nsum) atomicAdd(&ws[kCtrl + C_NANC], nsum);
     }
     // ---- last workgroup of this job resolves the merged histogram ---------------------------------
     // Everything exchanged between workgroups here goes through device-scope atomics (performed at the
@@ -701,71 +713,27 @@ __global__ __launch_bounds__(1024) void matrix_count_kernel(const SelBatch b) {
     // invalidate the XCD's whole L2 in every workgroup (measured: 0.5 ms per launch).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) red[18] = atomicAdd(&ws[kCtrl + (PASS == 0 ? C_DONE_A : C_DONE_B)], 1u);
+    if (tid == 0) red[34] = atomicAdd(&ws[kCtrl + C_DONE], 1u);
     __syncthreads();
-    if (red[18] != jb.nwg - 1) return;
-    uint32_t h[4];
+    if (red[34] != jb.nwg - 1) return;
+    uint32_t h[4] = {0, 0, 0, 0};
+    if (tid < kMatBins / 4) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) h[i] = ld_dev(&gh[tid * 4 + i]);
-    uint32_t need, bin, before;
-    bool ok = true;
-    if (PASS == 0) {
-        const uint32_t bel = ld_dev(&ws[kCtrl + C_BELOW]);
-        ok = bel <= jb.k;
-        need = jb.k - bel;
-    } else {
-        need = rankb;
+        for (int i = 0; i < 4; ++i) h[i] = ld_dev(&ws[tid * 4 + i]);
     }
-    ok = block_find_rank(h, need, red, bin, before) && ok;
-    if (tid == 0) {
-        if (!ok) {
-            ws[kCtrl + C_FAIL] = 1;
-        } else if (PASS == 0) {
-            const uint32_t lob = lo + (bin << shift);
-            ws[kCtrl + C_LOB] = lob;
-            ws[kCtrl + C_RANKB] = need - before;
-            ws[kCtrl + C_SHIFTB] = shift > 12u ? shift - 12u : 0u;
-            if (shift == 0) { ws[kCtrl + C_THR] = lob; ws[kCtrl + C_SKIPB] = 1; }
-        } else {
-            if (shift != 0) ws[kCtrl + C_FAIL] = 1;              // window wider than 4096 keys: not exact
-            else ws[kCtrl + C_THR] = lo + bin;
-        }
-    }
-}
-
-// Fallback: exact radix select by ONE workgroup per failed job (4 streaming passes of 8 key bits).
-template <typename T>
-__global__ __launch_bounds__(1024) void matrix_slow_kernel(const SelBatch b) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t red[20];
-    const SelJob &jb = b.job[blockIdx.x];
-    uint32_t *ws = jb.ws;
-    if (!ws[kCtrl + C_FAIL]) return;
-    const int tid = threadIdx.x;
+    const uint32_t bel = ld_dev(&ws[kCtrl + C_BELOW]), nans = ld_dev(&ws[kCtrl + C_NANC]);
     const uint32_t numel = jb.out_f * jb.in_f;
-    uint32_t prefix = 0, pmask = 0, r = jb.k;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
-        for (uint32_t e = tid; e < numel; e += 1024u) {
-            const uint32_t key = element_key<T>(jb, e);
-            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        uint32_t h[4] = {0, 0, 0, 0};
-        if (tid < 64) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) h[i] = hist[tid * 4 + i];
-        }
-        uint32_t bin, before;
-        block_find_rank(h, r, red, bin, before);
-        prefix |= bin << shift;
-        pmask |= 0xFFu << shift;
-        r -= before;
-    }
+    uint32_t bin, before;
+    const bool found = block_find_rank(h, jb.k - bel, red, bin, before);   // (wraps harmlessly when bel > k: checked below)
     if (tid == 0) {
-        ws[kCtrl + C_THR] = prefix;
-        ws[kCtrl + C_FAIL] = 2;                                  // 2 = resolved by the slow path
+        if (jb.k >= numel - nans) {
+            ws[kCtrl + C_NONE] = 1;                  // the threshold is a NaN score: `score < nan` prunes nothing
+        } else if (bel > jb.k || !found) {
+            ws[kCtrl + C_FAIL] = 1;                  // the sampled bracket missed rank k
+        } else {
+            ws[kCtrl + C_LOB] = lo + (bin << shift);
+            ws[kCtrl + C_RANKB] = jb.k - bel - before;
+        }
     }
 }
 
@@ -775,35 +743,65 @@ __global__ __launch_bounds__(1024) void matrix_apply_kernel(const SelBatch b) {
     uint32_t wg;
     const SelJob &jb = b.job[find_job(b, blockIdx.x, wg)];
     const int tid = threadIdx.x;
-    // thr is the key of flat rank k; prune strictly below it.  A NaN threshold prunes nothing
-    // (`score < nan` is False everywhere, wanda_pruner.py:683).
-    const uint32_t thr = jb.ws[kCtrl + C_THR];
-    const bool none = thr == 0xFFFFFFFFu;
-    const uint32_t in_f = jb.in_f, cpr = (in_f + 7) / 8, total = jb.out_f * cpr;
+    uint32_t *ws = jb.ws;
+    const uint4 c0 = reinterpret_cast<const uint4 *>(ws + kCtrl)[0], c1 = reinterpret_cast<const uint4 *>(ws + kCtrl)[1];
+    // undecided = nothing is pruned here (fallback: the resolve kernel prunes; NaN threshold: nobody does)
+    const bool undecided = c1.w /* C_FAIL */ || c1.z /* C_NONE */;
+    const uint32_t shift = c0.y /* C_SHIFT */, lob = c1.x /* C_LOB */;
+    // bin = [lob, lob + 2^shift): a one-key bin (shift 0) needs no candidates -- ties with the threshold are kept
+    const uint32_t width = shift ? (1u << shift) : 0u;
+    const uint32_t in_f = jb.in_f;
     typename T::raw *W = static_cast<typename T::raw *>(jb.W);
+    const ChunkWalk cw(jb);
     double dsum = 0.0;
-    for (uint32_t c = wg * 1024u + uint32_t(tid); c < total; c += jb.nwg * 1024u) {
-        const uint32_t row = c / cpr, col0 = (c - row * cpr) * 8;
-        typename T::raw *wrow = W + int64_t(row) * jb.ldw;
-        Chunk8<T> raw = load_row_chunk<T, ALIGNED, true>(wrow, col0, in_f);
-        float sqv[8];
-        load_sq_chunk<ALIGNED>(jb.sq, col0, in_f, sqv);
-        uint32_t keepbits = 0;
-        float fs = 0.f;
+    constexpr int NCH = 2;
+    for (uint32_t cb = wg * 1024u + uint32_t(tid); cb < cw.total; cb += NCH * cw.step) {
+        Chunk8<T> raw[NCH];
+        float sqv[NCH][8];
+        uint32_t col0[NCH], rowu[NCH];
+        bool has[NCH];
+        uint32_t row = cb / cw.cpr, cir = cb - row * cw.cpr;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            bool pruned = false;
-            if (ALIGNED || col0 + j < in_f) {
-                const float sc = ieee_mul(fabsf(to_f32<T>(raw.v[j])), sqv[j]);
-                fs += sc;
-                pruned = !none && score_key(sc) < thr;
-            }
-            keepbits |= (pruned ? 0u : 1u) << j;
-            if (pruned) raw.v[j] = typename T::raw(0);
+        for (int u = 0; u < NCH; ++u) {
+            has[u] = cb + uint32_t(u) * cw.step < cw.total;
+            col0[u] = has[u] ? cir * 8 : 0u;
+            rowu[u] = has[u] ? row : 0u;
+            raw[u] = load_row_chunk<T, ALIGNED, true>(W + int64_t(rowu[u]) * jb.ldw, col0[u], in_f);
+            row += cw.step_rows;
+            cir += cw.step_cir;
+            if (cir >= cw.cpr) { cir -= cw.cpr; ++row; }
         }
-        dsum += double(fs);
-        store_mask_chunk<ALIGNED, true>(jb.mask + int64_t(row) * in_f, col0, in_f, keepbits);
-        if (b.apply_zero && keepbits != 0xFFu) store_row_chunk<T, ALIGNED, true>(wrow, col0, in_f, raw);
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) load_sq_chunk<ALIGNED>(jb.sq, col0[u], in_f, sqv[u]);
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            if (!has[u]) continue;
+            uint32_t keepbits = 0;
+            float fs = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bool pruned = false;
+                if (ALIGNED || col0[u] + j < in_f) {
+                    const float sc = ieee_mul(fabsf(to_f32<T>(raw[u].v[j])), sqv[u][j]);
+                    fs += sc;
+                    const uint32_t key = score_key(sc);
+                    pruned = !undecided && key < lob;
+                    if (!undecided && key - lob < width && key >= lob) {          // inside the bin: decide later
+                        const uint32_t pos = atomicAdd(&ws[kCtrl + C_NCAND], 1u);
+                        if (pos < uint32_t(kCandCap)) {
+                            ws[kCand + 2 * pos] = rowu[u] * in_f + col0[u] + uint32_t(j);
+                            ws[kCand + 2 * pos + 1] = key;
+                        }
+                    }
+                }
+                keepbits |= (pruned ? 0u : 1u) << j;
+                if (pruned) raw[u].v[j] = typename T::raw(0);
+            }
+            dsum += double(fs);
+            store_mask_chunk<ALIGNED, true>(jb.mask + int64_t(rowu[u]) * in_f, col0[u], in_f, keepbits);
+            if (b.apply_zero && keepbits != 0xFFu)
+                store_row_chunk<T, ALIGNED, true>(W + int64_t(rowu[u]) * jb.ldw, col0[u], in_f, raw[u]);
+        }
     }
     if (jb.parts) {
         dsum = wave_sum_f64(dsum);
@@ -816,6 +814,63 @@ __global__ __launch_bounds__(1024) void matrix_apply_kernel(const SelBatch b) {
         }
         if (wg == 0) {                                           // slots of workgroups this job does not have
             for (uint32_t i = jb.nwg + uint32_t(tid); i < uint32_t(kMatrixParts); i += 1024u) jb.parts[i] = 0.0;
+        }
+    }
+}
+
+// One workgroup per job, after the apply pass: decide the elements the apply pass left undecided.
+//   normal    the <= 8192 candidates of the final bin: exact rank select in LDS, prune those below the threshold
+//   fallback  the bracket missed rank k (everything is undecided) or the bin overflowed the list: the same
+//             select, but streaming the matrix (4 x 8-bit radix over the keys inside [lob, lob + width))
+template <typename T>
+__global__ __launch_bounds__(1024) void matrix_resolve_kernel(const SelBatch b) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t red[20];
+    const SelJob &jb = b.job[blockIdx.x];
+    uint32_t *ws = jb.ws;
+    const int tid = threadIdx.x;
+    if (ws[kCtrl + C_NONE]) return;
+    const uint32_t fail = ws[kCtrl + C_FAIL], ncand = ws[kCtrl + C_NCAND], shift = ws[kCtrl + C_SHIFT];
+    const bool from_list = !fail && ncand <= uint32_t(kCandCap);
+    if (!fail && (shift == 0 || ncand == 0)) return;            // nothing was left undecided
+    const uint32_t lob = fail ? 0u : ws[kCtrl + C_LOB];
+    const uint32_t width = fail ? 0xFFFFFFFFu : (1u << shift);  // undecided keys: lob <= key, key - lob < width (or all)
+    uint32_t r = fail ? jb.k : ws[kCtrl + C_RANKB];
+    const uint32_t numel = jb.out_f * jb.in_f;
+    const uint32_t n_items = from_list ? ncand : numel;
+    typename T::raw *W = static_cast<typename T::raw *>(jb.W);
+    auto key_of = [&](uint32_t i) -> uint32_t { return from_list ? ws[kCand + 2 * i + 1] : element_key<T>(jb, i); };
+    auto undecided = [&](uint32_t key) -> bool { return fail || (key >= lob && key - lob < width); };
+    // rank-r key among the undecided keys: MSD radix, 8 bits per pass
+    uint32_t prefix = 0, pmask = 0;
+    for (int sh = 24; sh >= 0; sh -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n_items; i += 1024u) {
+            const uint32_t key = key_of(i);
+            if (undecided(key) && (key & pmask) == prefix) atomicAdd(&hist[(key >> sh) & 255u], 1u);
+        }
+        __syncthreads();
+        uint32_t h[4] = {0, 0, 0, 0};
+        if (tid < 64) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[i] = hist[tid * 4 + i];
+        }
+        uint32_t bin, before;
+        block_find_rank(h, r, red, bin, before);                 // r < number of matching keys by construction
+        prefix |= bin << sh;
+        pmask |= 0xFFu << sh;
+        r -= before;
+    }
+    const uint32_t thr = prefix;
+    if (thr == 0xFFFFFFFFu) return;                              // NaN threshold (fallback path): prunes nothing
+    for (uint32_t i = tid; i < n_items; i += 1024u) {
+        const uint32_t key = key_of(i);
+        if (undecided(key) && key < thr) {
+            const uint32_t e = from_list ? ws[kCand + 2 * i] : i;
+            const uint32_t row = e / jb.in_f, col = e - row * jb.in_f;
+            jb.mask[e] = 0;
+            if (b.apply_zero) W[int64_t(row) * jb.ldw + col] = typename T::raw(0);
         }
     }
 }
@@ -993,15 +1048,13 @@ static int launch_matrix(const vlmc_select_job *jobs, const int *idx, int n, int
     }
     hipLaunchKernelGGL((matrix_sample_kernel<T>), dim3(unsigned(n)), dim3(1024), 0, st, b);
     if (aligned) {
-        hipLaunchKernelGGL((matrix_count_kernel<T, true, 0>), dim3(wgs), dim3(1024), 0, st, b);
-        hipLaunchKernelGGL((matrix_count_kernel<T, true, 1>), dim3(wgs), dim3(1024), 0, st, b);
+        hipLaunchKernelGGL((matrix_count_kernel<T, true>), dim3(wgs), dim3(1024), 0, st, b);
+        hipLaunchKernelGGL((matrix_apply_kernel<T, true>), dim3(wgs), dim3(1024), 0, st, b);
     } else {
-        hipLaunchKernelGGL((matrix_count_kernel<T, false, 0>), dim3(wgs), dim3(1024), 0, st, b);
-        hipLaunchKernelGGL((matrix_count_kernel<T, false, 1>), dim3(wgs), dim3(1024), 0, st, b);
+        hipLaunchKernelGGL((matrix_count_kernel<T, false>), dim3(wgs), dim3(1024), 0, st, b);
+        hipLaunchKernelGGL((matrix_apply_kernel<T, false>), dim3(wgs), dim3(1024), 0, st, b);
     }
-    hipLaunchKernelGGL((matrix_slow_kernel<T>), dim3(unsigned(n)), dim3(1024), 0, st, b);
-    if (aligned) hipLaunchKernelGGL((matrix_apply_kernel<T, true>), dim3(wgs), dim3(1024), 0, st, b);
-    else hipLaunchKernelGGL((matrix_apply_kernel<T, false>), dim3(wgs), dim3(1024), 0, st, b);
+    hipLaunchKernelGGL((matrix_resolve_kernel<T>), dim3(unsigned(n)), dim3(1024), 0, st, b);
     return VLMC_OK;
 }
 
