@@ -549,6 +549,11 @@ __device__ bool block_find_rank(const uint32_t (&h)[4], uint32_t need, uint32_t 
     return bin != 0xFFFFFFFFu;
 }
 
+// Key used inside the streaming passes: score >= +0 or NaN, so clearing the sign bit orders every finite score
+// and +inf like score_key() and leaves NaNs above +inf (0x7F800001..0x7FFFFFFF) -- one instruction.  A bin that
+// reaches above +inf is handed to the fallback, which uses score_key()'s single NaN key.
+__device__ __forceinline__ uint32_t stream_key(float sc) { return __float_as_uint(sc) & 0x7FFFFFFFu; }
+
 template <typename T>
 __device__ __forceinline__ uint32_t element_key(const SelJob &jb, uint32_t e) {
     const uint32_t row = e / jb.in_f, col = e - row * jb.in_f;
@@ -657,7 +662,7 @@ __global__ __launch_bounds__(1024) void matrix_count_kernel(const SelBatch b) {
     const uint32_t in_f = jb.in_f;
     const typename T::raw *W = static_cast<const typename T::raw *>(jb.W);
     const ChunkWalk cw(jb);
-    uint32_t below = 0, nanc = 0;
+    uint32_t below = 0;
     constexpr int NCH = 4;                                       // chunks in flight per lane
     for (uint32_t cb = wg * 1024u + uint32_t(tid); cb < cw.total; cb += NCH * cw.step) {
         Chunk8<T> raw[NCH];
@@ -682,9 +687,8 @@ __global__ __launch_bounds__(1024) void matrix_count_kernel(const SelBatch b) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (ALIGNED || col0[u] + j < in_f) {
-                    const uint32_t key = score_key(ieee_mul(fabsf(to_f32<T>(raw[u].v[j])), sqv[u][j]));
+                    const uint32_t key = stream_key(ieee_mul(fabsf(to_f32<T>(raw[u].v[j])), sqv[u][j]));
                     below += key < lo ? 1u : 0u;
-                    nanc += key == 0xFFFFFFFFu ? 1u : 0u;
                     const uint32_t d = (key - lo) >> shift;
                     if (key >= lo && d < uint32_t(kMatBins)) atomicAdd(&lh[d], 1u);
                 }
@@ -692,8 +696,8 @@ __global__ __launch_bounds__(1024) void matrix_count_kernel(const SelBatch b) {
         }
     }
     {
-        const uint32_t wsum = wave_sum_u32_dpp(below), nsum = wave_sum_u32_dpp(nanc);
-        if ((tid & 63) == 0) { red[tid >> 6] = wsum; red[16 + (tid >> 6)] = nsum; }
+        const uint32_t wsum = wave_sum_u32_dpp(below);
+        if ((tid & 63) == 0) red[tid >> 6] = wsum;
     }
     __syncthreads();
     for (int i = tid; i < kMatBins; i += 1024) {
@@ -701,10 +705,9 @@ __global__ __launch_bounds__(1024) void matrix_count_kernel(const SelBatch b) {
         if (v) atomicAdd(&ws[i], v);
     }
     if (tid == 0) {
-        uint32_t bsum = 0, nsum = 0;
-        for (int w = 0; w < 16; ++w) { bsum += red[w]; nsum += red[16 + w]; }
+        uint32_t bsum = 0;
+        for (int w = 0; w < 16; ++w) bsum += red[w];
         if (bsum) atomicAdd(&ws[kCtrl + C_BELOW], bsum);
-        if (nsum) atomicAdd(&ws[kCtrl + C_NANC], nsum);
     }
     // ---- last workgroup of this job resolves the merged histogram ---------------------------------
     // Everything exchanged between workgroups here goes through device-scope atomics (performed at the
@@ -721,15 +724,15 @@ __global__ __launch_bounds__(1024) void matrix_count_kernel(const SelBatch b) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) h[i] = ld_dev(&ws[tid * 4 + i]);
     }
-    const uint32_t bel = ld_dev(&ws[kCtrl + C_BELOW]), nans = ld_dev(&ws[kCtrl + C_NANC]);
-    const uint32_t numel = jb.out_f * jb.in_f;
+    const uint32_t bel = ld_dev(&ws[kCtrl + C_BELOW]);
     uint32_t bin, before;
     const bool found = block_find_rank(h, jb.k - bel, red, bin, before);   // (wraps harmlessly when bel > k: checked below)
     if (tid == 0) {
-        if (jb.k >= numel - nans) {
-            ws[kCtrl + C_NONE] = 1;                  // the threshold is a NaN score: `score < nan` prunes nothing
-        } else if (bel > jb.k || !found) {
-            ws[kCtrl + C_FAIL] = 1;                  // the sampled bracket missed rank k
+        const uint64_t bin_end = uint64_t(lo) + (uint64_t(bin + 1u) << shift);      // one past the bin's last key
+        if (bel > jb.k || !found || bin_end > 0x7F800001ull) {
+            // the sampled bracket missed rank k, or the bin reaches the NaN keys (a NaN threshold prunes
+            // nothing, wanda_pruner.py:683): exact fallback in the resolve kernel
+            ws[kCtrl + C_FAIL] = 1;
         } else {
             ws[kCtrl + C_LOB] = lo + (bin << shift);
             ws[kCtrl + C_RANKB] = jb.k - bel - before;
@@ -784,7 +787,7 @@ __global__ __launch_bounds__(1024) void matrix_apply_kernel(const SelBatch b) {
                 if (ALIGNED || col0[u] + j < in_f) {
                     const float sc = ieee_mul(fabsf(to_f32<T>(raw[u].v[j])), sqv[u][j]);
                     fs += sc;
-                    const uint32_t key = score_key(sc);
+                    const uint32_t key = stream_key(sc);
                     pruned = !undecided && key < lob;
                     if (!undecided && key - lob < width && key >= lob) {          // inside the bin: decide later
                         const uint32_t pos = atomicAdd(&ws[kCtrl + C_NCAND], 1u);
@@ -1091,7 +1094,9 @@ static int launch_nm(const vlmc_select_job *jobs, const int *idx, int n, int pru
 template <typename T>
 static int select_typed(const vlmc_select_job *jobs, int n_jobs, int mode, int prune_n, int prune_m, int apply_zero,
                         hipStream_t st) {
-    // launch groups: consecutive runs of <= kMaxSelJobs jobs; SEL_ROW additionally needs equal (in, k, alignment)
+    // launch groups: consecutive runs of <= kMaxSelJobs jobs; SEL_ROW additionally needs equal (in, k, alignment).
+    // (Running the groups of one call side by side on a second stream was measured: the event fork/join costs
+    // more than the overlap of T5's small `wo` group with the large one gains -- 46 vs 35 us per block.)
     int idx[kMaxSelJobs];
     bool done[256] = {false};
     for (int s0 = 0; s0 < n_jobs; ++s0) {
