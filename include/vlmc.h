@@ -158,7 +158,8 @@ int vlmc_lora_effective_weight(const void *W, int dtype, int64_t out_features, i
 /* Gradients of the adapters from G = dL/dW_eff ([out,in], weight dtype; the library GEMM dY^T x):
  *   Gm = wd((sparse ? G . M : G) * s), then rounded to the autocast dtype (as the reference's autograd)
  *   dB[out, r] = Gm @ A^T,  dA[r, in] = B^T @ Gm     (fp32 accumulate; rounded to the autocast dtype)
- * dA or dB may be NULL.  dA needs a workspace of vlmc_lora_grad_workspace() bytes.               */
+ * dA or dB may be NULL.  Needs a workspace of vlmc_lora_grad_workspace() bytes (partial sums, combined in
+ * a fixed order: deterministic).                                                                 */
 size_t vlmc_lora_grad_workspace(int64_t out_features, int64_t in_features, int r);
 int vlmc_lora_grad(const void *G, int dtype, int64_t out_features, int64_t in_features, int64_t ldg, const float *A,
                    const float *B, int r, float scaling, const uint8_t *mask, int sparse, int autocast, float *dA,

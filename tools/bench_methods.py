@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 from vlmc import dsnot, ops, sparse_lora, sparsegpt
 
-ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=10)
+ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=10); ap.add_argument("--only", default="")
 args = ap.parse_args()
 dev = "cuda:0"
 rows = []
@@ -36,7 +36,7 @@ def emit(kernel, shape, us, note):
 
 
 # ---- SparseLoRA (config 5: Vicuna-7B linears, r = 16, fp16 weights) ------------------------------------
-for out_f, in_f in [(4096, 4096), (11008, 4096), (4096, 11008)]:
+for out_f, in_f in ([(4096, 4096), (11008, 4096), (4096, 11008)] if args.only in ('', 'lora') else []):
     r = 16
     pool = [(torch.randn(out_f, in_f, device=dev) * 0.02).to(torch.float16) for _ in range(6)]
     A = torch.randn(r, in_f, device=dev) * 0.05
@@ -51,12 +51,13 @@ for out_f, in_f in [(4096, 4096), (11008, 4096), (4096, 11008)]:
     G = [(torch.randn(out_f, in_f, device=dev) * 0.01).to(torch.float16) for _ in range(6)]
     us = timeit(lambda: sparse_lora.lora_grads(G[next(it) % len(G)], A, B, M, 1.0, True, 0))
     nbytes = out_f * in_f * 3
-    emit("`lora_grad_{a,b}_kernel` (+ reduce)", f"{out_f}x{in_f} r16 fp16", us,
-         f"{2 * nbytes / us / 1e3:.0f} GB/s (G and mask are read by both kernels: 2 x 3 B/weight); {4 * out_f * in_f * r / us / 1e6:.2f} TFLOP/s")
+    emit("`lora_grad_fused_kernel` + 2 x `lora_grad_reduce_kernel` (dA and dB)", f"{out_f}x{in_f} r16 fp16", us,
+         f"{nbytes / us / 1e3:.0f} GB/s of 3 B/weight (G + mask read once); {4 * out_f * in_f * r / us / 1e6:.2f} TFLOP/s f32 MFMA; "
+         "event-timed from an idle stream, i.e. including 3 launch latencies")
     del pool, G
 
 # ---- SparseGPT (config 3: FlanT5-XL shapes, 2:4 and unstructured 50 %) -----------------------------------
-for out_f, in_f in [(2048, 2048), (5120, 2048), (2048, 5120)]:
+for out_f, in_f in ([(2048, 2048), (5120, 2048), (2048, 5120)] if args.only in ('', 'sparsegpt') else []):
     lin = nn.Linear(in_f, out_f, bias=False).to(dev).to(torch.bfloat16)
     g = sparsegpt.SparseGPT(lin)
     xs = [(torch.randn(1, 64, in_f, device=dev) + 0.1).to(torch.bfloat16) for _ in range(128)]
@@ -81,8 +82,8 @@ for out_f, in_f in [(2048, 2048), (5120, 2048), (2048, 5120)]:
     del g, xs, H0
 
 # ---- DSnoT (config 4: Vicuna-7B + ViT shapes, wanda init, 100 cycles) -----------------------------------
-for out_f, in_f, dt in [(4096, 4096, torch.float16), (11008, 4096, torch.float16), (4096, 11008, torch.float16),
-                        (6144, 1408, torch.float16)]:
+for out_f, in_f, dt in ([(4096, 4096, torch.float16), (11008, 4096, torch.float16), (4096, 11008, torch.float16),
+                         (6144, 1408, torch.float16)] if args.only in ('', 'dsnot') else []):
     xs = [(torch.randn(1, 96, in_f, device=dev) + 0.2).to(dt) for _ in range(16)]
     st = dsnot.DsnotInputStat(in_f, dev)
     for x in xs:

@@ -18,6 +18,8 @@
 // the first C = min(max_cycle, max_row stop) events into the mask.  Literal semantics kept: in
 // the unstructured branch every cycle ends with mask[p] = keep, mask[r] = pruned whatever the
 // update flag says.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace vlmc {
@@ -276,36 +278,56 @@ __global__ __launch_bounds__(64 * NW) void dsnot_simulate_kernel(
         k0col = k0.col; k0d = k0.d;
     }
 
+    // Every lane caches its own best candidate of each sorted list the cycles walk (smallest / largest unvisited G;
+    // smallest / largest unconsumed wanda metric among its negative-D and positive-D kept columns).  A cycle is then
+    // two workgroup-wide arg-min reductions over the cached candidates; only the ONE lane whose candidate was taken
+    // rescans its <= 32 columns.  (Rescanning every column in every lane cost 40-70 x more per cycle.)
+    auto scan = [&](const uint32_t (&keys)[E], uint32_t pool, bool take_min) -> Best {
+        Best bst{0, 0xFFFFFFFFu, 0.f};
+#pragma unroll
+        for (int i = 0; i < E; ++i)
+            if ((pool >> i) & 1u) {
+                const Best c2{keys[i], uint32_t((i / 8) * NT * 8 + tid * 8 + (i % 8)), D[i]};
+                if (better(c2, bst, take_min)) bst = c2;
+            }
+        return bst;
+    };
+    Best c_rlo = scan(gk, live, true), c_rhi = scan(gk, live, false);
+    Best c_nlo{0, 0xFFFFFFFFu, 0.f}, c_nhi = c_nlo, c_plo = c_nlo, c_phi = c_nlo;
+    if constexpr (!NM) {
+        c_nlo = scan(wk, negm, true); c_nhi = scan(wk, negm, false);
+        c_plo = scan(wk, posm, true); c_phi = scan(wk, posm, false);
+    }
+
     bool u = true;
     int stop = 0x7FFFFFFF;
     uint32_t hpos = 0, tpos = 0;                             // prune-list positions consumed from head / tail
     for (int t = 0; t < max_cycle; ++t) {
         // ---- regrow candidate: next from the tail (err > 0) or the head of the ascending G order ----
         const bool r_tail = err > 0.f;
-        Best rb{0, 0xFFFFFFFFu, 0.f};
-#pragma unroll
-        for (int i = 0; i < E; ++i)
-            if (((live & ~seen_r) >> i) & 1u) {
-                const Best c2{gk[i], uint32_t((i / 8) * NT * 8 + tid * 8 + (i % 8)), D[i]};
-                if (better(c2, rb, !r_tail)) rb = c2;
-            }
-        rb = block_best<NW>(rb, !r_tail, sm, phase);
+        Best rb = block_best<NW>(r_tail ? c_rhi : c_rlo, !r_tail, sm, phase);
         const uint32_t rcol = rb.col;
-        {   // the owner marks it visited
+        {   // the owner marks it visited and refreshes its cached candidates
             const uint32_t c = rcol / 8, own = c % NT, slot = c / NT;
-            if (uint32_t(tid) == own) seen_r |= 1u << (slot * 8 + rcol % 8);
+            if (uint32_t(tid) == own) {
+                seen_r |= 1u << (slot * 8 + rcol % 8);
+                if (c_rlo.col == rcol) c_rlo = scan(gk, live & ~seen_r, true);     // only the list(s) that lost their head
+                if (c_rhi.col == rcol) c_rhi = scan(gk, live & ~seen_r, false);
+            }
         }
         // ---- prune candidate ---------------------------------------------------------------------
         Best pb{0, 0xFFFFFFFFu, 0.f};
         if constexpr (NM) {
             // smallest metric among the currently kept columns of r's m-group (ties -> lowest column)
             const uint32_t g0 = rcol - rcol % uint32_t(prune_m);
+            if (uint32_t(tid) == (rcol / 8) % NT) {          // the m-group lies inside one lane's 8-column chunk
 #pragma unroll
-            for (int i = 0; i < E; ++i) {
-                const uint32_t col = uint32_t((i / 8) * NT * 8 + tid * 8 + (i % 8));
-                if (((kept_now >> i) & 1u) && col >= g0 && col < g0 + uint32_t(prune_m)) {
-                    const Best c2{wk[i], col, D[i]};
-                    if (better(c2, pb, true)) pb = c2;
+                for (int i = 0; i < E; ++i) {
+                    const uint32_t col = uint32_t((i / 8) * NT * 8 + tid * 8 + (i % 8));
+                    if (((kept_now >> i) & 1u) && col >= g0 && col < g0 + uint32_t(prune_m)) {
+                        const Best c2{wk[i], col, D[i]};
+                        if (better(c2, pb, true)) pb = c2;
+                    }
                 }
             }
             pb = block_best<NW>(pb, true, sm, phase);
@@ -335,19 +357,19 @@ __global__ __launch_bounds__(64 * NW) void dsnot_simulate_kernel(
                 // head&low: negatives ascending (neg_lo); head&high: positives descending (pos_hi)
                 // tail&low: positives ascending (pos_lo); tail&high: negatives descending (neg_hi)
                 const bool use_neg = p_tail ? !from_low : from_low;
-                const uint32_t pool = use_neg ? (negm & ~(neg_lo | neg_hi)) : (posm & ~(pos_lo | pos_hi));
-#pragma unroll
-                for (int i = 0; i < E; ++i)
-                    if ((pool >> i) & 1u) {
-                        const Best c2{wk[i], uint32_t((i / 8) * NT * 8 + tid * 8 + (i % 8)), D[i]};
-                        if (better(c2, pb, from_low)) pb = c2;
-                    }
-                pb = block_best<NW>(pb, from_low, sm, phase);
+                pb = block_best<NW>(use_neg ? (from_low ? c_nlo : c_nhi) : (from_low ? c_plo : c_phi), from_low, sm, phase);
                 const uint32_t c = pb.col / 8, own = c % NT, slot = c / NT;
                 if (pb.col != 0xFFFFFFFFu && uint32_t(tid) == own) {
                     const uint32_t bit = 1u << (slot * 8 + pb.col % 8);
-                    if (use_neg) { if (from_low) neg_lo |= bit; else neg_hi |= bit; }
-                    else { if (from_low) pos_lo |= bit; else pos_hi |= bit; }
+                    if (use_neg) {
+                        if (from_low) neg_lo |= bit; else neg_hi |= bit;
+                        if (c_nlo.col == pb.col) c_nlo = scan(wk, negm & ~(neg_lo | neg_hi), true);
+                        if (c_nhi.col == pb.col) c_nhi = scan(wk, negm & ~(neg_lo | neg_hi), false);
+                    } else {
+                        if (from_low) pos_lo |= bit; else pos_hi |= bit;
+                        if (c_plo.col == pb.col) c_plo = scan(wk, posm & ~(pos_lo | pos_hi), true);
+                        if (c_phi.col == pb.col) c_phi = scan(wk, posm & ~(pos_lo | pos_hi), false);
+                    }
                 }
             }
             if (p_tail) ++tpos; else ++hpos;
@@ -415,8 +437,15 @@ static int simulate_dispatch(const void *W, int64_t out_f, int64_t in_f, int64_t
                              float thr, float pow_var, int without_same_sign, uint32_t *events, int32_t *t_row, hipStream_t st) {
     using raw = typename T::raw;
     const int64_t nchunks = in_f / 8;
-    int nw = 1;
-    while (nw < 8 && nchunks > int64_t(64) * nw * 4) nw *= 2;
+    // A cycle costs the rescan of ONE lane's columns plus two workgroup-wide reductions (with a barrier each when the
+    // row spans several waves).  Measured (100 cycles, fp16): rows of 1408 columns are fastest in one wave (1.2 ms per
+    // 6144x1408 linear vs 1.5 / 2.0 / 4.9 ms with 2 / 4 / 8 waves), rows of 4096 columns with four (2.2 ms vs 3.2 ms
+    // with two and 4.0 ms with eight).
+    int nw = nchunks <= 256 ? 1 : (nchunks <= 768 ? 4 : 8);
+    if (const char *e = getenv("VLMC_DSNOT_NW")) {                    // tuning override
+        const int f = atoi(e);
+        if ((f == 1 || f == 2 || f == 4 || f == 8) && nchunks <= int64_t(64) * f * 4) nw = f;
+    }
     if (nchunks > int64_t(64) * nw * 4) {
         set_error("vlmc_dsnot_refine: in_features %lld too large (max 16384)", (long long)in_f);
         return VLMC_EINVAL;

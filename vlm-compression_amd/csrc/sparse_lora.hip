@@ -56,7 +56,7 @@ enum { LORA_FWD_SPARSE = 0, LORA_FWD_MASKED = 1, LORA_MERGE_SPARSE = 2, LORA_MER
 
 constexpr int kTM = 32;        // tile rows
 constexpr int kTN = 256;       // tile columns (4 waves x 64)
-constexpr int kLd = kTN + 1;   // LDS row stride in floats (odd => conflict-free column walks)
+constexpr int kLd = kTN + 4;   // LDS row stride in floats: rows stay 16-byte aligned (ds_read_b128), +4 skews the banks
 
 // ------------------------------------------------------------------------------------------
 // effective weight / merge
@@ -67,9 +67,26 @@ __global__ __launch_bounds__(256) void lora_weff_kernel(const typename T::raw *_
                                                         int r, float scaling, const uint8_t *__restrict__ mask, int ab_code,
                                                         typename T::raw *__restrict__ Wout, int64_t ldo) {
     using raw = typename T::raw;
-    __shared__ float dl[kTM * kLd];
+    __shared__ __attribute__((aligned(16))) float dl[kTM * kLd];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int64_t row0 = int64_t(blockIdx.y) * kTM, colb = int64_t(blockIdx.x) * kTN;
+
+    // ---- the tile's W / mask chunks are requested first: their latency hides behind the MFMA phase -------------
+    const bool vec = (in_f % 8 == 0) && (ldw % 8 == 0) && (ldo % 8 == 0) && aligned16_dev(W) && aligned16_dev(Wout) &&
+                     (reinterpret_cast<uintptr_t>(mask) % 8 == 0);
+    constexpr int NQ = (kTM * kTN / 8) / 256;
+    Chunk8<T> wpre[NQ];
+    uint2 mpre[NQ];
+    if (vec) {
+#pragma unroll
+        for (int q4 = 0; q4 < NQ; ++q4) {
+            const int q = tid + 256 * q4;
+            const int64_t row = row0 + (q >> 5), col = colb + (q & 31) * 8;
+            const bool in = row < out_f && col < in_f;
+            wpre[q4] = load_chunk8<T>(W + (in ? row * ldw + col : 0));
+            mpre[q4] = *reinterpret_cast<const uint2 *>(mask + (in ? row * in_f + col : 0));
+        }
+    }
 
     // ---- delta tile on the matrix cores: D[o, i] = sum_k B[o, k] * A[k, i] -------------------------
     // v_mfma_f32_32x32x2_f32: A-operand lane l = Bm[o = l&31][k = l>>5], B-operand = Am[k = l>>5][i = l&31],
@@ -80,16 +97,25 @@ __global__ __launch_bounds__(256) void lora_weff_kernel(const typename T::raw *_
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
     const int64_t orow = row0 + l31;
-    for (int k = 0; k < r; k += 2) {
-        const int kk = k + h;
-        float b = (orow < out_f && kk < r) ? B[orow * r + kk] : 0.f;
-        b = round_code(b, ab_code);
+    // operands of 16 rank steps are fetched before the first MFMA (a load -> MFMA chain per step is pure latency)
+    constexpr int KC = 16;
+    for (int k0 = 0; k0 < r; k0 += KC) {
+        float bv[KC / 2], av[KC / 2][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int64_t c = colb + wave * 64 + t * 32 + l31;
-            float a = (c < in_f && kk < r) ? A[int64_t(kk) * in_f + c] : 0.f;
-            a = round_code(a, ab_code);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[t], 0, 0, 0);
+        for (int s2 = 0; s2 < KC / 2; ++s2) {
+            const int kk = k0 + 2 * s2 + h;
+            bv[s2] = (orow < out_f && kk < r) ? B[orow * r + kk] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int64_t c = colb + wave * 64 + t * 32 + l31;
+                av[s2][t] = (c < in_f && kk < r) ? A[int64_t(kk) * in_f + c] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < KC / 2; ++s2) {
+            const float b = round_code(bv[s2], ab_code);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, round_code(av[s2][t], ab_code), acc[t], 0, 0, 0);
         }
     }
     constexpr bool kMerge = MODE == LORA_MERGE_SPARSE || MODE == LORA_MERGE_MASKED;
@@ -110,10 +136,8 @@ __global__ __launch_bounds__(256) void lora_weff_kernel(const typename T::raw *_
     __syncthreads();
 
     // ---- elementwise combine, 16-byte chunks ----------------------------------------------------------
-    const bool vec = (in_f % 8 == 0) && (ldw % 8 == 0) && (ldo % 8 == 0) && aligned16_dev(W) && aligned16_dev(Wout) &&
-                     (reinterpret_cast<uintptr_t>(mask) % 8 == 0);
 #pragma unroll
-    for (int q4 = 0; q4 < (kTM * kTN / 8) / 256; ++q4) {
+    for (int q4 = 0; q4 < NQ; ++q4) {
         const int q = tid + 256 * q4;
         const int o = q >> 5, cc = (q & 31) * 8;
         const int64_t row = row0 + o, col = colb + cc;
@@ -121,10 +145,8 @@ __global__ __launch_bounds__(256) void lora_weff_kernel(const typename T::raw *_
         raw w[8];
         uint8_t m[8];
         if (vec) {
-            Chunk8<T> c8 = load_chunk8<T>(W + row * ldw + col);
-            __builtin_memcpy(w, c8.v, sizeof(w));
-            const uint2 mm = *reinterpret_cast<const uint2 *>(mask + row * in_f + col);
-            __builtin_memcpy(m, &mm, 8);
+            __builtin_memcpy(w, wpre[q4].v, sizeof(w));
+            __builtin_memcpy(m, &mpre[q4], 8);
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -134,10 +156,16 @@ __global__ __launch_bounds__(256) void lora_weff_kernel(const typename T::raw *_
             }
         }
         Chunk8<T> res;
+        float dv[8];
+        {
+            const float4 d0 = *reinterpret_cast<const float4 *>(&dl[o * kLd + cc]);
+            const float4 d1 = *reinterpret_cast<const float4 *>(&dl[o * kLd + cc + 4]);
+            dv[0] = d0.x; dv[1] = d0.y; dv[2] = d0.z; dv[3] = d0.w; dv[4] = d1.x; dv[5] = d1.y; dv[6] = d1.z; dv[7] = d1.w;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float wf = to_f32<T>(w[j]);
-            const float d = dl[o * kLd + cc + j];
+            const float d = dv[j];
             const bool keep = m[j] != 0;
             float v;
             if constexpr (MODE == LORA_FWD_SPARSE) v = keep ? round_to<T>(ieee_add(wf, d)) : 0.f;
@@ -162,164 +190,217 @@ __global__ __launch_bounds__(256) void lora_weff_kernel(const typename T::raw *_
 // v_mfma_f32_16x16x4_f32: A-operand lane l = X[i = l&15][k = l>>4], B-operand = Y[k = l>>4][j = l&15],
 // D register g of lane l = D[row 4*(l>>4) + g][col l&15].
 // ------------------------------------------------------------------------------------------
+// A 32 x 256 tile of G and of the mask in registers (4 chunks of 8 columns per thread), so that the NEXT tile's
+// global loads are in flight while the current tile is consumed from LDS.
+template <typename T> struct GmRegs {
+    Chunk8<T> g[(kTM * kTN / 8) / 256];
+    uint2 m[(kTM * kTN / 8) / 256];
+};
 template <typename T>
-__device__ __forceinline__ void stage_gm_tile(const typename T::raw *__restrict__ G, int64_t out_f, int64_t in_f, int64_t ldg,
-                                              const uint8_t *__restrict__ mask, int sparse, float scaling, int ab_code,
-                                              int64_t row0, int64_t colb, float *gm, bool vec) {
+__device__ __forceinline__ void load_gm_tile(const typename T::raw *__restrict__ G, int64_t row_end, int64_t in_f, int64_t ldg,
+                                             const uint8_t *__restrict__ mask, int64_t row0, int64_t colb, bool vec,
+                                             GmRegs<T> &rg) {
     using raw = typename T::raw;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q4 = 0; q4 < (kTM * kTN / 8) / 256; ++q4) {
+        const int q = tid + 256 * q4;
+        const int64_t row = row0 + (q >> 5), col = colb + (q & 31) * 8;
+        const bool in = row < row_end && col < in_f;
+        if (vec) {
+            rg.g[q4] = load_chunk8<T>(G + (in ? row * ldg + col : 0));
+            rg.m[q4] = *reinterpret_cast<const uint2 *>(mask + (in ? row * in_f + col : 0));
+        } else {
+            uint8_t m[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool inj = in && col + j < in_f;
+                rg.g[q4].v[j] = inj ? G[row * ldg + col + j] : raw(0);
+                m[j] = inj ? mask[row * in_f + col + j] : uint8_t(0);
+            }
+            __builtin_memcpy(&rg.m[q4], m, 8);
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store_gm_tile(const GmRegs<T> &rg, int64_t row_end, int64_t in_f, int sparse, float scaling,
+                                              int ab_code, int64_t row0, int64_t colb, float *gm) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int q4 = 0; q4 < (kTM * kTN / 8) / 256; ++q4) {
         const int q = tid + 256 * q4;
         const int o = q >> 5, cc = (q & 31) * 8;
         const int64_t row = row0 + o, col = colb + cc;
+        uint8_t m[8];
+        __builtin_memcpy(m, &rg.m[q4], 8);
         float v[8];
-        if (row < out_f && col < in_f) {
-            raw g[8];
-            uint8_t m[8];
-            if (vec) {
-                Chunk8<T> c8 = load_chunk8<T>(G + row * ldg + col);
-                __builtin_memcpy(g, c8.v, sizeof(g));
-                const uint2 mm = *reinterpret_cast<const uint2 *>(mask + row * in_f + col);
-                __builtin_memcpy(m, &mm, 8);
-            } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bool in = col + j < in_f;
-                    g[j] = in ? G[row * ldg + col + j] : raw(0);
-                    m[j] = in ? mask[row * in_f + col + j] : uint8_t(0);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float x = to_f32<T>(g[j]);
-                if (sparse && !m[j]) x = 0.f;
-                // autograd of `d1 * s` rounds to wd, the cast back to the matmul's dtype rounds to it
-                v[j] = round_code(round_to<T>(ieee_mul(x, scaling)), ab_code);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        for (int j = 0; j < 8; ++j) {
+            float x = to_f32<T>(rg.g[q4].v[j]);
+            if (sparse && !m[j]) x = 0.f;
+            // autograd of `d1 * s` rounds to wd, the cast back to the matmul's dtype rounds to it
+            v[j] = (row < row_end && col + j < in_f) ? round_code(round_to<T>(ieee_mul(x, scaling)), ab_code) : 0.f;
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) gm[o * kLd + cc + j] = v[j];
+        *reinterpret_cast<float4 *>(&gm[o * kLd + cc]) = float4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<float4 *>(&gm[o * kLd + cc + 4]) = float4{v[4], v[5], v[6], v[7]};
     }
 }
 
-// dB[o, k] = sum_i Gm[o, i] * A[k, i]: one workgroup per 32-row strip, loops over the columns.
-// Wave w: rows (w&1)*16.., column half (w>>1)*128.. of each tile; NT16 = ceil(r/16) n-tiles.
+// One pass over G for both gradients.  Workgroup (strip j, split s) walks the 32-row tiles of rows
+// [s*rows_per_split, ...) of the 256-column strip j; per tile (staged once in LDS as Gm):
+//   dB tile [32, r] = Gm[32, 256] @ A_strip^T   -> part_b[j][row][k]   (summed over the strips by the reduce kernel)
+//   dA strip [r, 256] += B_tile^T[r, 32] @ Gm   -> registers, written once as part_a[s][k][col]
+// The A strip panel is staged in LDS once, the B tile per row tile: no global load sits inside an MFMA chain.
+// Partial sums are combined in a fixed order (no float atomics) => deterministic.
 template <typename T, int NT16>
-__global__ __launch_bounds__(256) void lora_grad_b_kernel(const typename T::raw *__restrict__ G, int64_t out_f, int64_t in_f,
-                                                          int64_t ldg, const float *__restrict__ A, int r, float scaling,
-                                                          const uint8_t *__restrict__ mask, int sparse, int ab_code,
-                                                          float *__restrict__ dB) {
-    __shared__ float gm[kTM * kLd];
-    __shared__ float red[2][kTM * 16 * NT16];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
-    const int64_t row0 = int64_t(blockIdx.x) * kTM;
-    const bool vec = (in_f % 8 == 0) && (ldg % 8 == 0) && aligned16_dev(G) && (reinterpret_cast<uintptr_t>(mask) % 8 == 0);
-    const int rh = wave & 1, chalf = wave >> 1;
-    f32x4 acc[NT16];
-#pragma unroll
-    for (int n = 0; n < NT16; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int64_t colb = 0; colb < in_f; colb += kTN) {
-        __syncthreads();
-        stage_gm_tile<T>(G, out_f, in_f, ldg, mask, sparse, scaling, ab_code, row0, colb, gm, vec);
-        __syncthreads();
-        for (int i0 = chalf * 128; i0 < chalf * 128 + 128; i0 += 4) {
-            const float x = gm[(rh * 16 + l15) * kLd + i0 + q];                 // Gm[o = l&15][i = i0 + (l>>4)]
-            const int64_t ci = colb + i0 + q;
-#pragma unroll
-            for (int n = 0; n < NT16; ++n) {
-                const int kk = n * 16 + l15;
-                float a = (kk < r && ci < in_f) ? A[int64_t(kk) * in_f + ci] : 0.f;   // A^T[i][k]
-                a = round_code(a, ab_code);
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, a, acc[n], 0, 0, 0);
-            }
-        }
-    }
-    // combine the two column halves (fixed order => deterministic), write dB
-    __syncthreads();
-#pragma unroll
-    for (int n = 0; n < NT16; ++n)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) red[chalf][(rh * 16 + 4 * q + g) * (16 * NT16) + n * 16 + l15] = acc[n][g];
-    __syncthreads();
-    for (int e = tid; e < kTM * 16 * NT16; e += 256) {
-        const int o = e / (16 * NT16), kk = e % (16 * NT16);
-        if (row0 + o < out_f && kk < r) {
-            dB[(row0 + o) * r + kk] = round_code(ieee_add(red[0][e], red[1][e]), ab_code);
-        }
-    }
-}
-
-// dA[k, i] = sum_o B[o, k] * Gm[o, i]: one workgroup per 256-column strip, loops over the rows.
-template <typename T, int NT16>
-__global__ __launch_bounds__(256) void lora_grad_a_kernel(const typename T::raw *__restrict__ G, int64_t out_f, int64_t in_f,
-                                                          int64_t ldg, const float *__restrict__ B, int r, float scaling,
-                                                          const uint8_t *__restrict__ mask, int sparse, int ab_code,
-                                                          int64_t rows_per_split, float *__restrict__ part) {
-    // grid = (column strips, row splits); split s accumulates rows [s*rows_per_split, ...) into part[s][k][i]
-    __shared__ float gm[kTM * kLd];
+__global__ __launch_bounds__(256) void lora_grad_fused_kernel(const typename T::raw *__restrict__ G, int64_t out_f, int64_t in_f,
+                                                              int64_t ldg, const float *__restrict__ A,
+                                                              const float *__restrict__ B, int r, float scaling,
+                                                              const uint8_t *__restrict__ mask, int sparse, int ab_code,
+                                                              int64_t rows_per_split, float *__restrict__ part_a,
+                                                              float *__restrict__ part_b) {
+    constexpr int RK = NT16 * 16;                    // padded rank
+    __shared__ __attribute__((aligned(16))) float gm[kTM * kLd];
+    __shared__ float As[RK * kLd];
+    __shared__ float Bs[kTM * (RK + 1)];
+    __shared__ float red[2][kTM * RK];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
     const int64_t colb = int64_t(blockIdx.x) * kTN;
     const int64_t rbeg = int64_t(blockIdx.y) * rows_per_split;
     const int64_t rend = rbeg + rows_per_split < out_f ? rbeg + rows_per_split : out_f;
-    float *dA = part + int64_t(blockIdx.y) * r * in_f;
     const bool vec = (in_f % 8 == 0) && (ldg % 8 == 0) && aligned16_dev(G) && (reinterpret_cast<uintptr_t>(mask) % 8 == 0);
-    f32x4 acc[NT16][4];        // [k-tile][16-column tile of this wave's 64 columns]
+    const int rh = wave & 1, chalf = wave >> 1;
+    for (int e = tid; e < RK * kTN; e += 256) {
+        const int kk = e / kTN, c = e % kTN;
+        const int64_t ci = colb + c;
+        As[kk * kLd + c] = (kk < r && ci < in_f) ? round_code(A[int64_t(kk) * in_f + ci], ab_code) : 0.f;
+    }
+    f32x4 acc_a[NT16][4];        // [k-tile][16-column tile of this wave's 64 columns]
 #pragma unroll
     for (int n = 0; n < NT16; ++n)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[n][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < 4; ++c) acc_a[n][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float *pb = part_b ? part_b + int64_t(blockIdx.x) * out_f * r : nullptr;
+    GmRegs<T> rg;
+    float breg[(kTM * RK + 255) / 256];
+    auto load_b_tile = [&](int64_t row0) {
+#pragma unroll
+        for (int i = 0; i < (kTM * RK + 255) / 256; ++i) {
+            const int e = tid + 256 * i, o = e / RK, kk = e % RK;
+            breg[i] = (e < kTM * RK && row0 + o < rend && kk < r) ? B[(row0 + o) * r + kk] : 0.f;
+        }
+    };
+    load_gm_tile<T>(G, rend, in_f, ldg, mask, rbeg, colb, vec, rg);
+    load_b_tile(rbeg);
     for (int64_t row0 = rbeg; row0 < rend; row0 += kTM) {
+        __syncthreads();                                                     // the previous tile has been consumed
+        store_gm_tile<T>(rg, rend, in_f, sparse, scaling, ab_code, row0, colb, gm);
+#pragma unroll
+        for (int i = 0; i < (kTM * RK + 255) / 256; ++i) {
+            const int e = tid + 256 * i;
+            if (e < kTM * RK) Bs[(e / RK) * (RK + 1) + e % RK] = round_code(breg[i], ab_code);
+        }
         __syncthreads();
-        stage_gm_tile<T>(G, rend, in_f, ldg, mask, sparse, scaling, ab_code, row0, colb, gm, vec);
-        __syncthreads();
-        for (int o0 = 0; o0 < kTM; o0 += 4) {
-            const int64_t orow = row0 + o0 + q;
-            float y[4];
+        if (row0 + kTM < rend) {                                             // next tile's loads fly during the MFMAs
+            load_gm_tile<T>(G, rend, in_f, ldg, mask, row0 + kTM, colb, vec, rg);
+            load_b_tile(row0 + kTM);
+        }
+        if (pb) {
+            // wave: rows (w&1)*16.., column half (w>>1)*128.. of the tile
+            f32x4 acc_b[NT16];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) y[c] = gm[(o0 + q) * kLd + wave * 64 + c * 16 + l15];   // Gm[o = o0+(l>>4)][i]
+            for (int n = 0; n < NT16; ++n) acc_b[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // 8 rank-4 steps per batch: all LDS operands of a batch are requested before its first MFMA
+            for (int i0 = chalf * 128; i0 < chalf * 128 + 128; i0 += 32) {
+                float x[8], av[NT16][8];
 #pragma unroll
-            for (int n = 0; n < NT16; ++n) {
-                const int kk = n * 16 + l15;
-                float b = (kk < r && orow < rend) ? B[orow * r + kk] : 0.f;                      // B^T[k][o]
-                b = round_code(b, ab_code);
+                for (int u = 0; u < 8; ++u) {
+                    x[u] = gm[(rh * 16 + l15) * kLd + i0 + 4 * u + q];          // Gm[o = l&15][i = i0 + 4u + (l>>4)]
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[n][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, y[c], acc[n][c], 0, 0, 0);
+                    for (int n = 0; n < NT16; ++n) av[n][u] = As[(n * 16 + l15) * kLd + i0 + 4 * u + q];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int n = 0; n < NT16; ++n) acc_b[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u], av[n][u], acc_b[n], 0, 0, 0);
+            }
+#pragma unroll
+            for (int n = 0; n < NT16; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) red[chalf][(rh * 16 + 4 * q + g) * RK + n * 16 + l15] = acc_b[n][g];
+        }
+        if (part_a) {
+            for (int o0 = 0; o0 < kTM; o0 += 8) {
+                float y[2][4], bq[2][NT16];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) y[u][c] = gm[(o0 + 4 * u + q) * kLd + wave * 64 + c * 16 + l15];   // Gm[o][i]
+#pragma unroll
+                    for (int n = 0; n < NT16; ++n) bq[u][n] = Bs[(o0 + 4 * u + q) * (RK + 1) + n * 16 + l15];      // B^T[k][o]
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int n = 0; n < NT16; ++n)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc_a[n][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[u][n], y[u][c], acc_a[n][c], 0, 0, 0);
+            }
+        }
+        if (pb) {
+            __syncthreads();
+            for (int e = tid; e < kTM * RK; e += 256) {          // two column halves, fixed order
+                const int o = e / RK, kk = e % RK;
+                if (row0 + o < rend && kk < r) pb[(row0 + o) * r + kk] = ieee_add(red[0][e], red[1][e]);
             }
         }
     }
+    if (part_a) {
+        float *dA = part_a + int64_t(blockIdx.y) * r * in_f;
 #pragma unroll
-    for (int n = 0; n < NT16; ++n)
+        for (int n = 0; n < NT16; ++n)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int kk = n * 16 + 4 * q + g;
-                const int64_t ci = colb + wave * 64 + c * 16 + l15;
-                if (kk < r && ci < in_f) dA[int64_t(kk) * in_f + ci] = acc[n][c][g];
-            }
+                for (int g = 0; g < 4; ++g) {
+                    const int kk = n * 16 + 4 * q + g;
+                    const int64_t ci = colb + wave * 64 + c * 16 + l15;
+                    if (kk < r && ci < in_f) dA[int64_t(kk) * in_f + ci] = acc_a[n][c][g];
+                }
+    }
 }
 
-// dA = sum over the row splits, in split order (deterministic)
-template <typename T>
-__global__ void lora_grad_a_reduce_kernel(const float *__restrict__ part, int splits, int64_t n, int ab_code,
-                                          float *__restrict__ dA) {
+// out[i] = sum over the partial slabs, in slab order (deterministic), rounded to the autocast dtype
+__global__ void lora_grad_reduce_kernel(const float *__restrict__ part, int slabs, int64_t n, int ab_code,
+                                        float *__restrict__ out) {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float v = 0.f;
-    for (int s = 0; s < splits; ++s) v = ieee_add(v, part[int64_t(s) * n + i]);
-    dA[i] = round_code(v, ab_code);
+    int s = 0;
+    for (; s + 8 <= slabs; s += 8) {                 // 8 loads in flight, summed in slab order
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = part[int64_t(s + u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v = ieee_add(v, t[u]);
+    }
+    for (; s < slabs; ++s) v = ieee_add(v, part[int64_t(s) * n + i]);
+    out[i] = round_code(v, ab_code);
 }
 
 static int64_t grad_row_splits(int64_t out_f, int64_t in_f) {
     const int64_t strips = (in_f + kTN - 1) / kTN, tiles = (out_f + kTM - 1) / kTM;
-    int64_t s = (512 + strips - 1) / strips;          // aim at >= 512 workgroups
+    int64_t s = (768 + strips - 1) / strips;          // aim at >= 768 workgroups (3 per CU)
     if (s > tiles) s = tiles;
     if (s < 1) s = 1;
     return s;
+}
+static size_t grad_ws_a(int64_t out_f, int64_t in_f, int r) {
+    return round_up(size_t(grad_row_splits(out_f, in_f)) * size_t(r) * size_t(in_f) * 4, 256);
+}
+static size_t grad_ws_b(int64_t out_f, int64_t in_f, int r) {
+    return round_up(size_t((in_f + kTN - 1) / kTN) * size_t(out_f) * size_t(r) * 4, 256);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -346,21 +427,19 @@ static int weff_typed(const void *W, int64_t out_f, int64_t in_f, int64_t ldw, c
 
 template <typename T>
 static int grad_typed(const void *G, int64_t out_f, int64_t in_f, int64_t ldg, const float *A, const float *B, int r,
-                      float scaling, const uint8_t *mask, int sparse, int ab_code, float *dA, float *dB, float *ws,
+                      float scaling, const uint8_t *mask, int sparse, int ab_code, float *dA, float *dB, char *ws,
                       hipStream_t st) {
     using raw = typename T::raw;
     const raw *g = static_cast<const raw *>(G);
-    const unsigned gb = unsigned((out_f + kTM - 1) / kTM), ga = unsigned((in_f + kTN - 1) / kTN);
+    const unsigned strips = unsigned((in_f + kTN - 1) / kTN);
     const int64_t splits = grad_row_splits(out_f, in_f);
     const int64_t tiles = (out_f + kTM - 1) / kTM;
     const int64_t rows_per_split = (tiles + splits - 1) / splits * kTM;
-#define VLMC_GRAD(NT)                                                                                                       \
-    do {                                                                                                                    \
-        if (dB) hipLaunchKernelGGL((lora_grad_b_kernel<T, NT>), dim3(gb), dim3(256), 0, st, g, out_f, in_f, ldg, A, r, scaling, \
-                                   mask, sparse, ab_code, dB);                                        \
-        if (dA) hipLaunchKernelGGL((lora_grad_a_kernel<T, NT>), dim3(ga, unsigned(splits)), dim3(256), 0, st, g, out_f, in_f, \
-                                   ldg, B, r, scaling, mask, sparse, ab_code, rows_per_split, ws);               \
-    } while (0)
+    float *part_a = dA ? reinterpret_cast<float *>(ws) : nullptr;
+    float *part_b = dB ? reinterpret_cast<float *>(ws + grad_ws_a(out_f, in_f, r)) : nullptr;
+#define VLMC_GRAD(NT)                                                                                                          \
+    hipLaunchKernelGGL((lora_grad_fused_kernel<T, NT>), dim3(strips, unsigned(splits)), dim3(256), 0, st, g, out_f, in_f, ldg, A, \
+                       B, r, scaling, mask, sparse, ab_code, rows_per_split, part_a, part_b)
     const int nt = (r + 15) / 16;
     switch (nt) {
         case 1: VLMC_GRAD(1); break;
@@ -371,8 +450,13 @@ static int grad_typed(const void *G, int64_t out_f, int64_t in_f, int64_t ldg, c
 #undef VLMC_GRAD
     if (dA) {
         const int64_t n = int64_t(r) * in_f;
-        hipLaunchKernelGGL((lora_grad_a_reduce_kernel<T>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, ws, int(splits), n,
+        hipLaunchKernelGGL(lora_grad_reduce_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, part_a, int(splits), n,
                            ab_code, dA);
+    }
+    if (dB) {
+        const int64_t n = out_f * int64_t(r);
+        hipLaunchKernelGGL(lora_grad_reduce_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, part_b, int(strips), n,
+                           ab_code, dB);
     }
     VLMC_HIP_CHECK_LAUNCH("vlmc_lora_grad");
     return VLMC_OK;
@@ -404,7 +488,7 @@ extern "C" int vlmc_lora_effective_weight(const void *W, int dtype, int64_t out_
 
 extern "C" size_t vlmc_lora_grad_workspace(int64_t out_features, int64_t in_features, int r) {
     if (out_features <= 0 || in_features <= 0 || r <= 0) return 0;
-    return round_up(size_t(grad_row_splits(out_features, in_features)) * size_t(r) * size_t(in_features) * 4, 256);
+    return grad_ws_a(out_features, in_features, r) + grad_ws_b(out_features, in_features, r);
 }
 
 extern "C" int vlmc_lora_grad(const void *G, int dtype, int64_t out_features, int64_t in_features, int64_t ldg, const float *A,
@@ -413,7 +497,7 @@ extern "C" int vlmc_lora_grad(const void *G, int dtype, int64_t out_features, in
     VLMC_REQUIRE(G && A && B && mask, "vlmc_lora_grad: null pointer");
     VLMC_REQUIRE(out_features > 0 && in_features > 0 && ldg >= in_features && r > 0 && r <= 64,
                  "vlmc_lora_grad: bad shape out=%lld in=%lld r=%d (r <= 64)", (long long)out_features, (long long)in_features, r);
-    if (dA) {
+    if (dA || dB) {
         const size_t need = vlmc_lora_grad_workspace(out_features, in_features, r);
         VLMC_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) % 256) == 0, "vlmc_lora_grad: workspace missing or not 256-B aligned");
         if (workspace_bytes < need) {
@@ -422,7 +506,7 @@ extern "C" int vlmc_lora_grad(const void *G, int dtype, int64_t out_features, in
         }
     }
     hipStream_t st = as_stream(stream);
-    float *ws = static_cast<float *>(workspace);
+    char *ws = static_cast<char *>(workspace);
     switch (dtype) {
         case VLMC_F32: return grad_typed<f32_t>(G, out_features, in_features, ldg, A, B, r, scaling, mask, sparse, ab_code, dA, dB, ws, st);
         case VLMC_F16: return grad_typed<f16_t>(G, out_features, in_features, ldg, A, B, r, scaling, mask, sparse, ab_code, dA, dB, ws, st);
