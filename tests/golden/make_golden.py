@@ -530,9 +530,44 @@ def gen_ressa():
     print("ressa.npz:", len(out), "arrays; losses", losses)
 
 
+def gen_ecoflap():
+    """ECoFLaP first stage (LayerSparsity, layer_single_base_pruner.py:111-728) + the Wanda / DSnoT prune it steers,
+    on the toy InstructBLIP: the sparsity dict and the final masks of the reference."""
+    import numpy.random as npr
+    from lavis.compression.pruners import dsnot_pruner as RD
+    from lavis.compression.pruners import wanda_pruner as R
+    variants = {
+        "wanda_block_aobd_sum": dict(cls="wanda", gran="block", score="aobd_sum", kw={}),
+        "wanda_layer_obd_avg": dict(cls="wanda", gran="layer", score="obd_avg", kw={}),
+        "wanda_model_gradient_sum": dict(cls="wanda", gran="model", score="gradient_sum", kw={}),
+        "wanda_block_olmezo": dict(cls="wanda", gran="block", score="olmezo-gradient_sum", kw=dict(num_noise=2)),
+        "dsnot_block_per_model": dict(cls="dsnot", gran="block", score="aobd_sum", kw=dict(prune_per_model=True, max_cycle_time=4)),
+    }
+    out = {}
+    for name, v in variants.items():
+        torch.manual_seed(0)
+        npr.seed(1234)
+        model = toy_models.init_toy(toy_models.ToyBlipT5(), seed=7).eval()
+        batches = toy_models.make_batches(6, seed=11)
+        spec = "2-0.5-1.0-1.0"
+        cls = R.BLIPT5LayerWandaPruner if v["cls"] == "wanda" else RD.BLIPT5LayerDSnoTPruner
+        pr = cls(model=model, data_loader=batches, t5_prune_spec=spec, vit_prune_spec=spec, t5_pruning_method=v["cls"],
+                 vit_pruning_method=v["cls"], num_samples=6, max_sparsity_per_layer=0.8, score_method=v["score"],
+                 sparsity_ratio_granularity=v["gran"], num_data_first_stage=4, **v["kw"])
+        pruned, sd = pr.prune()
+        keys = sorted(sd.keys())
+        out[f"{name}/keys"] = np.array(keys)
+        out[f"{name}/sparsity"] = torch.tensor([float(sd[k]) for k in keys], dtype=torch.float64)
+        for mn, mod in pruned.named_modules():
+            if hasattr(mod, "mask") and "mask" not in dict(mod.named_buffers(recurse=False)):
+                out[f"{name}/mask/{mn}"] = mod.mask
+    golden_io.save("ecoflap", out)
+    print("ecoflap.npz:", len(out), "arrays")
+
+
 GROUPS = {"wanda": gen_wanda, "wanda_e2e": gen_wanda_e2e, "sparse_lora": gen_sparse_lora, "sparsegpt": gen_sparsegpt,
           "sparsegpt_e2e": gen_sparsegpt_e2e, "dsnot": gen_dsnot,
-          "dsnot_e2e": gen_dsnot_e2e, "ressa": gen_ressa}
+          "dsnot_e2e": gen_dsnot_e2e, "ressa": gen_ressa, "ecoflap": gen_ecoflap}
 
 if __name__ == "__main__":
     import_reference()

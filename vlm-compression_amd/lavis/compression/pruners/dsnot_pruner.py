@@ -316,17 +316,19 @@ class BLIPT5LayerDSnoTPruner(LayerWiseBasePruner, _DsnotBlockMixin):
         self.vit_model_prefix = vit_model_prefix
 
     def get_sparsity(self, t5_sparsity, vit_sparsity, sparsity_ratio_granularity=None):
-        """(:1683-1757): a yaml override, else the uniform module at the MEAN of both sparsities."""
+        """(:1683-1757): a yaml override, else LayerSparsity at the MEAN of both sparsities (per-tower budgets
+        under `prune_per_model`)."""
         original_sparsity = 0.5 * (t5_sparsity + vit_sparsity)
         if self.sparsity_dict is not None:
             import yaml
             with open(self.sparsity_dict, "r") as f:
                 return yaml.load(f, Loader=yaml.FullLoader)
-        if sparsity_ratio_granularity is not None and sparsity_ratio_granularity != "none":
-            raise NotImplementedError("sparsity_ratio_granularity other than None/'none' needs LayerSparsity's "
-                                      "first-order scoring (layer_single_base_pruner.py:257-729), not built yet")
-        return LayerSparsity(self.model, self.data_loader, None, self.num_data_first_stage, original_sparsity,
-                             self.max_sparsity_per_layer, self.score_method, self.num_noise, self.noise_eps, {},
+        from lavis.compression.pruners.utils import loss_vision_language
+        from lavis.compression.pruners.wanda_pruner import layer_to_group_mapping
+        # same grouping rule as the Wanda pruner's get_sparsity (:1693-1740)
+        mapping = layer_to_group_mapping(self, sparsity_ratio_granularity)
+        return LayerSparsity(self.model, self.data_loader, loss_vision_language, self.num_data_first_stage, original_sparsity,
+                             self.max_sparsity_per_layer, self.score_method, self.num_noise, self.noise_eps, mapping,
                              prune_per_model=self.prune_per_model,
                              per_model_group=[self.t5_model_prefix, self.vit_model_prefix],
                              per_model_sparsity=[t5_sparsity, vit_sparsity]).return_sparsity()

@@ -276,21 +276,41 @@ class VITLayerWandaPruner(LayerWiseBasePruner, _WandaBlockMixin):
         return model
 
 
-def uniform_or_layer_sparsity(pruner, original_sparsity, granularity, loss_func=None):
-    """`get_sparsity` of the BLIP pruners (wanda_pruner.py:866-939): a yaml override, the
-    uniform module, or (not built) the ECoFLaP allocation."""
+def layer_to_group_mapping(pruner, granularity):
+    """Parameter name -> group name for `sparsity_ratio_granularity` in {None, "none", "model", "layer", "block"}
+    (wanda_pruner.py:872-919): 2-D weights of the transformer blocks of both towers."""
+    if granularity is None or granularity == "none":
+        return {}
+    t5, vit = pruner.t5_model_prefix, pruner.vit_model_prefix
+
+    def prunable(name, v):
+        return len(v.shape) == 2 and ".block" in name and "relative_attention_bias.weight" not in name and \
+            (name.startswith(t5) or name.startswith(vit))
+    names = [k for k, v in pruner.model.named_parameters() if prunable(k, v)]
+    if granularity == "layer":
+        return {k: k for k in names}
+    if granularity == "model":
+        return {k: (t5 if k.startswith(t5) else vit if k.startswith(vit) else "other") for k in names}
+    if granularity == "block":
+        # "<t5 prefix>.encoder.block.<i>" (4 name parts) / "<vit prefix>.blocks.<i>" (3 parts)
+        return {k: ".".join(k.split(".")[:4 if k.startswith(t5) else 3]) if (k.startswith(t5) or k.startswith(vit)) else "other"
+                for k in names}
+    raise NotImplementedError
+
+
+def uniform_or_layer_sparsity(pruner, original_sparsity, granularity, loss_func=None, **per_model):
+    """`get_sparsity` of the BLIP pruners (wanda_pruner.py:866-939): a yaml override, else LayerSparsity --
+    uniform without a grouping, ECoFLaP's score-proportional allocation with one."""
     if pruner.sparsity_dict is not None:
         import yaml
         with open(pruner.sparsity_dict, "r") as f:
             return yaml.load(f, Loader=yaml.FullLoader)
-    if granularity is None or granularity == "none":
-        mapping = {}
-    else:
-        raise NotImplementedError("sparsity_ratio_granularity other than None/'none' needs LayerSparsity's "
-                                  "first-order scoring (layer_single_base_pruner.py:257-729), not built yet")
+    if loss_func is None:
+        from lavis.compression.pruners.utils import loss_vision_language as loss_func
+    mapping = layer_to_group_mapping(pruner, granularity) if hasattr(pruner, "t5_model_prefix") else {}
     return LayerSparsity(pruner.model, pruner.data_loader, loss_func, pruner.num_data_first_stage, original_sparsity,
                          pruner.max_sparsity_per_layer, pruner.score_method, pruner.num_noise, pruner.noise_eps,
-                         mapping).return_sparsity()
+                         mapping, **per_model).return_sparsity()
 
 
 @registry.register_pruner("blipt5_wanda_pruner")
