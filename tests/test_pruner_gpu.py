@@ -138,3 +138,26 @@ def test_dsnot_pruner_on_gpu_every_linear_matches_oracle(name, monkeypatch):
     assert counts["moments"] == 6 * (2 * 4 + 2 * 4 + 2 * 7)        # one launch per distinct input tensor
     st = H.compare_with_golden(name, pruned, exact=False, min_mask_agreement=0.99, which="dsnot_e2e")
     print(name, st)
+
+
+@pytest.mark.parametrize("method", ["wanda", "dsnot"])
+def test_batched_replay_on_gpu_tracks_reference_run(method, monkeypatch):
+    """VLMC_BATCH_REPLAY=4: 4 samples per block forward, per-sample statistics kept; the final masks
+    track the reference's per-sample golden run (activations differ in the last bits only)."""
+    monkeypatch.setenv("VLMC_BATCH_REPLAY", "4")
+    if method == "wanda":
+        from vlmc import ops
+        real_sq = ops.act_sqnorm_batch
+        seen = {"calls": 0}
+
+        def counting(xs, outs=None):
+            seen["calls"] += sum(x.shape[0] for x in xs)
+            return real_sq(xs, outs)
+        monkeypatch.setattr(ops, "act_sqnorm_batch", counting)
+        pruned, _ = H.run_pruner("fp32_r50", "cuda:0")
+        assert seen["calls"] == 6 * (2 * 4 + 2 * 4 + 2 * 7)          # still one statistics row per sample and distinct input
+        st = H.compare_with_golden("fp32_r50", pruned, exact=False, min_mask_agreement=0.99)
+    else:
+        pruned, _ = H.run_dsnot_pruner("fp32_r50", "cuda:0")
+        st = H.compare_with_golden("fp32_r50", pruned, exact=False, min_mask_agreement=0.99, which="dsnot_e2e")
+    print(method, st)

@@ -62,11 +62,16 @@ class DsnotStatCollector:
             key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, x._version)
             hit = self._cache.get(key)
             if hit is None:
-                st = self._dsnot.DsnotInputStat(x.shape[-1], x.device)
-                st.add_call(x)                               # one launch: sum of squares, sum, variance over tokens
-                hit = (x, st)                                # `x` stays referenced until the next sample (see wanda collector)
+                stacked = cal.stacked_samples()              # batched replay: one record per stacked calibration sample
+                calls, b0 = stacked if stacked and stacked[0] * stacked[1] == x.shape[0] else (1, x.shape[0])
+                recs = []
+                for c in range(calls):
+                    st = self._dsnot.DsnotInputStat(x.shape[-1], x.device)
+                    st.add_call(x[c * b0:(c + 1) * b0])      # one launch: sum of squares, sum, variance over tokens
+                    recs.append(st)
+                hit = (x, recs)                              # `x` stays referenced until the next sample (see wanda collector)
                 self._cache[key] = hit
-            self.calls[name].append(hit[1])
+            self.calls[name].extend(hit[1])
         return hook
 
     def next_sample(self, _j=None):

@@ -61,14 +61,16 @@ class WandaStatCollector:
                 x = x.unsqueeze(0)
             key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, x._version)
             hit = self._cache.get(key)
+            stacked = cal.stacked_samples()                    # (samples, batch per sample) of a batched replay call
+            calls, b0 = stacked if stacked and stacked[0] * stacked[1] == x.shape[0] else (1, x.shape[0])
             if hit is None:
                 # `x` stays referenced until it has been reduced, so its memory cannot be recycled for a
                 # different activation with the same address/shape in the meantime
-                hit = (x, [None])
+                hit = (x, [[None] for _ in range(calls)])
                 self._cache[key] = hit
-                self._pending.append((x.reshape(1, -1, x.shape[-1]), hit[1]))
-            self.rows[name].append(hit[1])
-            self.batches[name].append(x.shape[0])
+                self._pending.append((x.reshape(calls, -1, x.shape[-1]), hit[1]))
+            self.rows[name].extend(hit[1])                     # one record per calibration sample, as in the reference
+            self.batches[name].extend([b0] * calls)
         return hook
 
     def _flush(self):
@@ -76,9 +78,14 @@ class WandaStatCollector:
         for x, holder in self._pending:
             by_dtype.setdefault(x.dtype, []).append((x, holder))
         for items in by_dtype.values():
-            outs = self._ops.act_sqnorm_batch([x for x, _ in items])
-            for (_, holder), row in zip(items, outs):
-                holder[0] = row
+            by_calls = {}
+            for x, holders in items:
+                by_calls.setdefault(x.shape[0], []).append((x, holders))
+            for same in by_calls.values():                     # one launch per group of inputs with equally many calls
+                outs = self._ops.act_sqnorm_batch([x for x, _ in same])
+                for (_, holders), rows in zip(same, outs):
+                    for c, holder in enumerate(holders):
+                        holder[0] = rows[c:c + 1]
         self._pending = []
 
     def next_sample(self, _j=None):
