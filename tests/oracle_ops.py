@@ -112,6 +112,7 @@ class OracleSparseGPT:
         self.rows, self.columns = layer.weight.shape
         self.H = torch.zeros((self.columns, self.columns))
         self.nsamples = 0
+        self.factor_cache = {}
 
     def add_batch(self, inp, out=None):
         self.nsamples = self._os.hessian_update(self.H, self.nsamples, inp)
@@ -120,9 +121,11 @@ class OracleSparseGPT:
         self.H = None
 
 
-def oracle_fasterprune(layer, H, sparsity, prune_n=0, prune_m=0, blocksize=128, percdamp=0.01, return_mask=False):
+def oracle_fasterprune(layer, H, sparsity, prune_n=0, prune_m=0, blocksize=128, percdamp=0.01, return_mask=False,
+                       factor_cache=None):
     from oracle import sparsegpt as OS
-    Wn, imp, pruned = OS.prune(layer.weight.data, H, sparsity, prune_n, prune_m, blocksize, percdamp)
+    # the reference factorizes per linear; a shared Hessian must survive for the next linear that uses it
+    Wn, imp, pruned = OS.prune(layer.weight.data, H.clone(), sparsity, prune_n, prune_m, blocksize, percdamp)
     setattr(layer.weight, "importance_score", imp)
     layer.weight.data = Wn
     return pruned if return_mask else None

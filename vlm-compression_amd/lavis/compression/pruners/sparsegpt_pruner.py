@@ -32,22 +32,48 @@ class _SparseGPTBlockMixin:
                                         model_prefix=model_prefix, count_batches=True)
 
     def _sparsegpt_block(self, i, subset, run_pass, n_inps, module_to_process, sparsity_ratio):
+        """Hooks -> one dense pass -> prune every linear (sparsegpt_pruner.py:405-459).  Linears that receive the
+        very same tensor (q/k/v, wi_0/wi_1, cross-attention k/v) have bit-identical Hessians: they share ONE
+        accumulator (one GEMM per hook input instead of one per linear) and ONE Cholesky chain."""
         from vlmc import sparsegpt
-        wrapped = {name: sparsegpt.SparseGPT(mod) for name, mod in subset.items()}
-        handles = [mod.register_forward_hook(lambda _m, inp, out, name=name: wrapped[name].add_batch(inp[0].data, out.data))
-                   for name, mod in subset.items()]
+        wrapped, fed = {}, {}            # linear name -> accumulator; input signature -> accumulator fed in this forward
+
+        def make_hook(name):
+            def hook(_m, inp, out):
+                x = inp[0].data
+                key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, x._version)
+                acc = wrapped.get(name)
+                if acc is None:                                       # first sample: discover who shares what
+                    acc = fed.get(key)
+                    if acc is None:
+                        acc = sparsegpt.SparseGPT(subset[name])
+                        acc.add_batch(x, out.data)
+                        fed[key] = acc
+                    wrapped[name] = acc
+                elif fed.get(key) is not acc:
+                    if key in fed:
+                        raise RuntimeError(f"{name}: the linears sharing an input changed between calibration samples")
+                    acc.add_batch(x, out.data)
+                    fed[key] = acc
+                acc._keep_alive = x                                   # the signature holds only while `x` lives
+            return hook
+
+        handles = [mod.register_forward_hook(make_hook(name)) for name, mod in subset.items()]
         try:
-            run_pass()
+            run_pass(lambda _j: fed.clear())
         finally:
             for h in handles:
                 h.remove()
-        _allreduce_hessians(wrapped)
+        unique = list({id(a): a for a in wrapped.values()}.values())
+        _allreduce_hessians(unique)
         for name, mod in subset.items():
-            assert wrapped[name].nsamples == n_inps                                  # :442
+            acc = wrapped[name]
+            assert acc.nsamples == n_inps                                          # :442
             key = f"{module_to_process}.{i}.{name}.weight"
-            sparsegpt.fasterprune(mod, wrapped[name].H, sparsity_ratio[key], prune_n=self.prune_n, prune_m=self.prune_m,
-                                  percdamp=0.01, blocksize=128)
-            wrapped[name].free()
+            sparsegpt.fasterprune(mod, acc.H, sparsity_ratio[key], prune_n=self.prune_n, prune_m=self.prune_m,
+                                  percdamp=0.01, blocksize=128, factor_cache=acc.factor_cache)
+        for acc in unique:
+            acc.free()
 
 
 def _allreduce_hessians(wrapped):
@@ -57,7 +83,7 @@ def _allreduce_hessians(wrapped):
     rank, world = cal.calibration_shard()
     if world == 1:
         return
-    for w in wrapped.values():
+    for w in wrapped:
         total = torch.tensor([float(w.nsamples)], device=w.H.device)
         w.H.mul_(w.nsamples)
         dist.all_reduce(w.H)

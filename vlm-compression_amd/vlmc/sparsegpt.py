@@ -36,6 +36,7 @@ class SparseGPT:
         self.rows, self.columns = layer.weight.shape
         self.H = torch.zeros((self.columns, self.columns), device=self.dev)
         self.nsamples = 0
+        self.factor_cache = {}
 
     @torch.no_grad()
     def add_batch(self, inp, out=None):
@@ -50,6 +51,7 @@ class SparseGPT:
 
     def free(self):
         self.H = None
+        self.factor_cache = {}
 
 
 def _clamp_inf(H):
@@ -71,16 +73,25 @@ def _chol_with_damping(H, damp, upper, max_tries=100):
 
 
 @torch.no_grad()
-def inverse_factor(H: torch.Tensor, W: torch.Tensor, percdamp=0.01) -> torch.Tensor:
-    """Upper Cholesky factor of H^-1 (`Hinv`); consumes H, zeroes W's dead columns (:92-160)."""
+def factorize(H: torch.Tensor, percdamp=0.01):
+    """(U, dead): upper Cholesky factor of H^-1 (`Hinv`, :92-160) and the dead-column mask; consumes H.
+    Depends on H only, so linears fed by the same tensor (q/k/v, wi_0/wi_1) share one factorization."""
     dead = torch.diag(H) == 0
     H[dead, dead] = 1
-    W[:, dead] = 0
     _clamp_inf(H)
     L = _chol_with_damping(H, percdamp * torch.mean(torch.diag(H)), upper=False)
     Hi = torch.cholesky_inverse(L)
     _clamp_inf(Hi)
-    return _chol_with_damping(Hi, percdamp * torch.mean(torch.diag(Hi).abs()), upper=True)
+    U = _chol_with_damping(Hi, percdamp * torch.mean(torch.diag(Hi).abs()), upper=True)
+    return U.contiguous(), dead                          # the solver hands back a column-major factor
+
+
+@torch.no_grad()
+def inverse_factor(H: torch.Tensor, W: torch.Tensor, percdamp=0.01) -> torch.Tensor:
+    """Upper Cholesky factor of H^-1; consumes H, zeroes W's dead columns (:92-160)."""
+    U, dead = factorize(H, percdamp)
+    W[:, dead] = 0
+    return U
 
 
 def sweep_block(W: torch.Tensor, i1: int, i2: int, U: torch.Tensor, mask1, prune_n, prune_m, err: torch.Tensor,
@@ -99,11 +110,19 @@ def sweep_block(W: torch.Tensor, i1: int, i2: int, U: torch.Tensor, mask1, prune
 
 
 @torch.no_grad()
-def fasterprune(layer, H: torch.Tensor, sparsity, prune_n=0, prune_m=0, blocksize=128, percdamp=0.01, return_mask=False):
+def fasterprune(layer, H: torch.Tensor, sparsity, prune_n=0, prune_m=0, blocksize=128, percdamp=0.01, return_mask=False,
+                factor_cache=None):
     """`SparseGPT.fasterprune` (:81-215): prunes `layer.weight` in place, sets
-    `weight.importance_score`.  H is consumed."""
+    `weight.importance_score`.  H is consumed.  `factor_cache` (a dict owned by the caller, one per distinct
+    Hessian) lets linears with the same input reuse the factorization -- bit-identical to recomputing it."""
     W = layer.weight.data.clone().float()
-    U = inverse_factor(H, W, percdamp).contiguous()      # the solver hands back a column-major factor
+    if factor_cache is not None and "U" in factor_cache:
+        U, dead = factor_cache["U"], factor_cache["dead"]
+    else:
+        U, dead = factorize(H, percdamp)
+        if factor_cache is not None:
+            factor_cache["U"], factor_cache["dead"] = U, dead
+    W[:, dead] = 0
     diag = torch.diag(U)
     score_mean = (W ** 2 / diag.reshape(1, -1) ** 2).abs().mean()
     rows, cols = W.shape
