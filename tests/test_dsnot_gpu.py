@@ -90,3 +90,70 @@ def test_lora_mode_and_zero_ratio():
     keep = dsnot.prune_linear(Wd, st, 0.5, apply_zero=False)
     assert torch.equal(Wd.cpu(), W) and torch.equal(keep.cpu(), G["t5_bf16_r50/mask"])
     assert dsnot.prune_linear(Wd, st, 0.0) is None
+
+
+# ---- list-based fast path vs the per-cycle reference kernel: identical events -------------------------
+def _refine_events(W, st, keep, n, m, mc, thr, lists, without_same_sign=1, wanda_init=1, pow_var=1.0):
+    import os
+    from vlmc import _lib
+    from vlmc.ops import _dtype_code, _stream
+    out_f, in_f = W.shape
+    events = torch.zeros((out_f, mc), dtype=torch.int32, device=DEV)
+    stop = torch.zeros(out_f, dtype=torch.int32, device=DEV)
+    os.environ["VLMC_DSNOT_LISTS"] = "1" if lists else "0"
+    try:
+        _lib.check(_lib.load().vlmc_dsnot_refine(W.data_ptr(), _dtype_code(W), out_f, in_f, W.stride(0), keep.data_ptr(),
+                                                 st.sqrt_row.data_ptr(), st.sum_row.data_ptr(), st.var_row.data_ptr(), wanda_init,
+                                                 n, m, mc, thr, pow_var, without_same_sign, events.data_ptr(), stop.data_ptr(),
+                                                 _stream()))
+    finally:
+        os.environ.pop("VLMC_DSNOT_LISTS", None)
+    torch.cuda.synchronize()
+    return events.cpu(), stop.cpu()
+
+
+@pytest.mark.parametrize("shape", [(24, 1408), (16, 2048), (12, 4096), (6, 5120), (5, 11008), (8, 256), (7, 64), (9, 16384)])
+@pytest.mark.parametrize("nm", [(0, 0), (2, 4), (4, 8), (1, 2)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_list_kernel_emits_the_same_events_as_the_cycle_kernel(shape, nm, dtype):
+    from vlmc import dsnot, ops
+    out_f, in_f = shape
+    n, m = nm
+    g = torch.Generator().manual_seed(in_f + out_f + 7 * n)
+    W = (torch.randn(out_f, in_f, generator=g) * 0.02).to(dtype)
+    W[torch.rand(out_f, in_f, generator=g) < 0.02] = 0                        # exact zeros: D == 0 columns, metric ties
+    W[:, : in_f // 16] = W[:, :1]                                             # duplicated columns: G and metric ties
+    xs = [((torch.randn(1, 9, in_f, generator=g) * 0.5) + 0.2).to(dtype) for _ in range(4)]
+    for x in xs:
+        x[..., : in_f // 16] = x[..., :1]
+    st = dsnot.DsnotInputStat(in_f, DEV)
+    for x in xs:
+        st.add_call(x.to(DEV))
+    st.finalize()
+    Wd = W.to(DEV)
+    if n:
+        keep, _ = ops.wanda_select(Wd, st.sqrt_row, "nm", n=n, m=m, apply_zero=False)
+    else:
+        keep, _ = ops.wanda_select(Wd, st.sqrt_row, "row", k=round(in_f * 0.5), apply_zero=False)
+    mc = min(100, in_f - 1)
+    for thr, wss in ((0.05, 1), (0.0, 0), (1e9, 1)):
+        ev_old, stop_old = _refine_events(Wd, st, keep, n, m, mc, thr, lists=False, without_same_sign=wss)
+        ev_new, stop_new = _refine_events(Wd, st, keep, n, m, mc, thr, lists=True, without_same_sign=wss)
+        assert torch.equal(stop_old, stop_new), (thr, wss)
+        bad = (ev_old != ev_new).nonzero()
+        assert bad.numel() == 0, (thr, wss, bad[:5].tolist(), ev_old[bad[0][0], bad[0][1]].item(), ev_new[bad[0][0], bad[0][1]].item())
+
+
+def test_list_kernel_capacity_falls_back_to_cycle_kernel():
+    """max_cycle > 128 does not fit the list heads: vlmc_dsnot_refine silently uses the per-cycle kernel."""
+    from vlmc import dsnot, ops
+    g = torch.Generator().manual_seed(3)
+    W = (torch.randn(6, 1024, generator=g) * 0.02).to(torch.float16)
+    st = dsnot.DsnotInputStat(1024, DEV)
+    st.add_call(((torch.randn(1, 9, 1024, generator=g) * 0.5) + 0.2).to(torch.float16).to(DEV))
+    st.finalize()
+    Wd = W.to(DEV)
+    keep, _ = ops.wanda_select(Wd, st.sqrt_row, "row", k=512, apply_zero=False)
+    ev_a, stop_a = _refine_events(Wd, st, keep, 0, 0, 200, 0.01, lists=True)
+    ev_b, stop_b = _refine_events(Wd, st, keep, 0, 0, 200, 0.01, lists=False)
+    assert torch.equal(ev_a, ev_b) and torch.equal(stop_a, stop_b)

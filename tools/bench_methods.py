@@ -105,7 +105,7 @@ for out_f, in_f, dt in ([(4096, 4096, torch.float16), (11008, 4096, torch.float1
         ratio = kw.pop("ratio")
         us = timeit(lambda: dsnot.prune_linear(W, st, ratio, max_cycle_time=100, update_threshold=0.1, **kw), reps=5,
                     setup=lambda: W.copy_(W0))
-        emit(f"DSnoT `prune_linear` {tag} (select + `dsnot_simulate_kernel` + `dsnot_apply_kernel`)", f"{out_f}x{in_f} fp16", us,
+        emit(f"DSnoT `prune_linear` {tag} (select + `dsnot_lists_kernel` + `dsnot_apply_kernel`)", f"{out_f}x{in_f} fp16", us,
              f"whole linear, 100-cycle budget; {out_f * in_f * 5 / us / 1e3:.0f} GB/s of the 5 B/weight a select moves")
 
 print("\n| kernel / step | shape | median us | note |\n|---|---|---|---|")

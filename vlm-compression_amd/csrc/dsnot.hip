@@ -476,6 +476,11 @@ static int simulate_dispatch(const void *W, int64_t out_f, int64_t in_f, int64_t
 
 }  // namespace vlmc
 
+namespace vlmc {
+int dsnot_refine_lists(const void *W, int dtype, int64_t out_f, int64_t in_f, int64_t ldw, const uint8_t *keep0, const float *sq,
+                       const float *sum_row, const float *var_row, int use_wanda_init, int prune_n, int prune_m, int max_cycle,
+                       float thr, float pow_var, int without_same_sign, uint32_t *events, int32_t *t_row, hipStream_t st);
+}
 using namespace vlmc;
 
 extern "C" int vlmc_act_moments(const void *x, int dtype, int64_t n_calls, int64_t tokens, int64_t in_features,
@@ -526,6 +531,17 @@ extern "C" int vlmc_dsnot_refine(const void *W, int dtype, int64_t out_features,
     if (prune_n != 0)
         VLMC_REQUIRE(prune_m == 2 || prune_m == 4 || prune_m == 8, "vlmc_dsnot_refine: n:m needs m in {2,4,8} (got %d)", prune_m);
     hipStream_t st = as_stream(stream);
+    // fast path: sorted-list heads + O(1) cycles (dsnot_lists.hip); VLMC_DSNOT_LISTS=0 keeps the per-cycle reductions
+    const char *use_lists = getenv("VLMC_DSNOT_LISTS");
+    if (!(use_lists && atoi(use_lists) == 0)) {
+        const int rc = dsnot_refine_lists(W, dtype, out_features, in_features, ldw, keep_mask0, sqrt_scaler, sum_row, var_row,
+                                          use_wanda_init, prune_n, prune_m, max_cycle, update_threshold, pow_of_var,
+                                          without_same_sign, events, stop_cycle, st);
+        if (rc == VLMC_OK) {
+            VLMC_HIP_CHECK_LAUNCH("vlmc_dsnot_refine");
+            return VLMC_OK;
+        }
+    }
 #define VLMC_DS(T)                                                                                                              \
     (prune_n != 0 ? simulate_dispatch<T, true>(W, out_features, in_features, ldw, keep_mask0, sqrt_scaler, sum_row, var_row,     \
                                                use_wanda_init, prune_m, max_cycle, update_threshold, pow_of_var,                 \
