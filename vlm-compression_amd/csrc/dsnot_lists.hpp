@@ -1,0 +1,483 @@
+// K12-K13, fast path: DSnoT refinement with the sorted lists cut to what the cycles can reach.
+//
+// The reference sorts every row three times and then walks the sorted lists for at most `max_cycle_time`
+// (100) cycles; a cycle only ever takes the NEXT element of one of six lists (regrow: ascending / descending G;
+// prune: ascending / descending wanda metric among the kept columns with negative resp. positive D).  So only
+// the first max_cycle entries of each list matter.  One workgroup per row:
+//   1. keys in registers (as in dsnot.hip)
+//   2. per list: radix select (4 x 8 key bits, LDS histogram) of the max_cycle-th smallest key, ties cut by
+//      column with two more passes, gather of those <= 128 entries into LDS, rank sort -> sorted list in LDS.
+//      n:m: each regrow entry carries its m-group's kept columns sorted by metric (the prune candidates).
+//   3. wave 0 walks the cycles reading the lists: O(1) per cycle.
+// Same events as dsnot_simulate_kernel (dsnot.hip), which remains the path for max_cycle > 128 and the
+// cross-check in tests/test_dsnot_gpu.py; 30-100 x faster at model widths.
+#pragma once
+#include <cstdlib>
+
+#include "common.hpp"
+
+namespace vlmc {
+
+__device__ __forceinline__ uint32_t dl_signed_key(float x) {          // dsnot.hip: signed_key
+    if (x != x) return 0xFFFFFFFFu;
+    x = x + 0.f;
+    const uint32_t b = __float_as_uint(x);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__device__ __forceinline__ uint32_t dl_wave_incl_scan(uint32_t v) {
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xF, 0xF, false));   // row_shr:1
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xF, 0xF, false));   // row_shr:2
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xF, 0xF, false));   // row_shr:4
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xF, 0xF, false));   // row_shr:8
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xA, 0xF, false));   // row_bcast:15
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xC, 0xF, false));   // row_bcast:31
+    return v;
+}
+
+constexpr int kListCap = 128;        // entries per list = max supported max_cycle
+constexpr int kGroupMax = 8;         // m of n:m
+
+struct ListEntry {
+    uint32_t col;
+    float d;
+};
+struct GroupInfo {                   // n:m: the kept columns of an entry's m-group, ascending (metric, column)
+    uint16_t col[kGroupMax];
+    float d[kGroupMax];
+    float d0;                        // D of the group's first column (the "all taken" fallback)
+    uint32_t n;
+};
+
+template <int NW, bool NM> struct ListSmem {
+    uint32_t hist[256];
+    uint32_t red[24];
+    uint32_t rawk[kListCap], rawc[kListCap];
+    float rawd[kListCap];
+    ListEntry list[NM ? 2 : 6][kListCap];
+    GroupInfo rawg[NM ? kListCap : 1];
+    GroupInfo grp[NM ? 2 : 1][NM ? kListCap : 1];
+    uint32_t cyc_group[NM ? kListCap : 1];
+    float fsum[NW];
+    uint32_t cnt3[3][NW];
+    uint32_t nlist[6];
+    ListEntry k0[2];
+};
+
+template <int NW> __device__ __forceinline__ void dl_sync() {
+    if constexpr (NW > 1) __syncthreads();
+    else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// rank-r (0-based) smallest value of f(i) over the elements with mask bit i; also the count of values below it.
+// f values are < 2^(8*PASSES).  All threads of the workgroup call it with the same r.
+template <int E, int NT, int NW, int PASSES, typename F, typename S>
+__device__ __forceinline__ uint32_t dl_radix_kth(F f, uint32_t mask, uint32_t r, S &sm, uint32_t &below) {
+    const int tid = threadIdx.x;
+    uint32_t prefix = 0, pmask = 0;
+    below = 0;
+    for (int sh = 8 * (PASSES - 1); sh >= 0; sh -= 8) {
+        for (int i = tid; i < 256; i += NT) sm.hist[i] = 0;
+        dl_sync<NW>();
+#pragma unroll
+        for (int i = 0; i < E; ++i)
+            if ((mask >> i) & 1u) {
+                const uint32_t v = f(i);
+                if ((v & pmask) == prefix) atomicAdd(&sm.hist[(v >> sh) & 255u], 1u);
+            }
+        dl_sync<NW>();
+        if (tid < 64) {                                              // wave 0: 4 bins per lane
+            uint32_t h[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[i] = sm.hist[tid * 4 + i];
+            const uint32_t s = h[0] + h[1] + h[2] + h[3];
+            const uint32_t incl = dl_wave_incl_scan(s);
+            const uint32_t lo = incl - s;
+            if (lo <= r && r < incl) {
+                uint32_t cum = lo;
+                int i = 0;
+                for (; i < 3; ++i) {
+                    if (cum + h[i] > r) break;
+                    cum += h[i];
+                }
+                sm.red[0] = uint32_t(tid * 4 + i);
+                sm.red[1] = cum;
+            }
+        }
+        dl_sync<NW>();
+        const uint32_t bin = sm.red[0], before = sm.red[1];
+        prefix |= bin << sh;
+        pmask |= 0xFFu << sh;
+        below += before;
+        r -= before;
+        dl_sync<NW>();
+    }
+    return prefix;
+}
+
+template <int NT, int NW, typename S> __device__ __forceinline__ uint32_t dl_block_sum(uint32_t v, S &sm, int slot) {
+    v = wave_sum_u32(v);
+    if constexpr (NW > 1) {
+        if ((threadIdx.x & 63) == 0) sm.cnt3[slot][threadIdx.x >> 6] = v;
+        __syncthreads();
+        v = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += sm.cnt3[slot][w];
+        __syncthreads();
+    }
+    return v;
+}
+
+// The K smallest (want_max: largest) (key, column) pairs among the masked elements -> out[0..n) in that order.
+// Returns n = min(K, number of masked elements).  `emit(i, pos)` is called by the lane that owns element i when it
+// is gathered to raw position pos (n:m group payload); `place(pos, rank)` moves payloads to their sorted slot.
+template <int E, int NT, int NW, typename S, typename Emit, typename Place>
+__device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], const float (&D)[E], uint32_t mask, bool want_max, uint32_t K, S &sm,
+                               ListEntry *out, Emit emit, Place place) {
+    const int tid = threadIdx.x;
+    const uint32_t avail = dl_block_sum<NT, NW>(uint32_t(__popc(mask)), sm, 0);
+    const uint32_t n = avail < K ? avail : K;
+    if (n == 0) return 0;
+    const uint32_t flip = want_max ? 0xFFFFFFFFu : 0u;
+    auto colof = [&](int i) { return uint32_t((i / 8) * NT * 8 + tid * 8 + (i % 8)); };
+    auto kf = [&](int i) { return key[i] ^ flip; };
+    auto cf = [&](int i) { return (colof(i) ^ flip) & 0x3FFFu; };
+    uint32_t c_lt;
+    const uint32_t X = dl_radix_kth<E, NT, NW, 4>(kf, mask, n - 1, sm, c_lt);
+    // ties with X: all of them, or the (n - c_lt) first by (flipped) column
+    uint32_t tie = 0;
+#pragma unroll
+    for (int i = 0; i < E; ++i)
+        if (((mask >> i) & 1u) && kf(i) == X) tie |= 1u << i;
+    const uint32_t n_tie = dl_block_sum<NT, NW>(uint32_t(__popc(tie)), sm, 1);
+    uint32_t Y = 0x3FFFu;
+    if (n_tie > n - c_lt) {
+        uint32_t dummy;
+        Y = dl_radix_kth<E, NT, NW, 2>(cf, tie, n - c_lt - 1, sm, dummy);
+    }
+    if (tid == 0) sm.red[2] = 0;
+    dl_sync<NW>();
+#pragma unroll
+    for (int i = 0; i < E; ++i)
+        if ((mask >> i) & 1u) {
+            const uint32_t kk = kf(i);
+            if (kk < X || (kk == X && cf(i) <= Y)) {
+                const uint32_t pos = atomicAdd(&sm.red[2], 1u);
+                sm.rawk[pos] = kk;
+                sm.rawc[pos] = cf(i);
+                sm.rawd[pos] = D[i];
+                emit(i, pos);
+            }
+        }
+    dl_sync<NW>();
+    // rank sort of the n <= 128 gathered entries.  One wave per row: lane l holds entries l and l + 64 in registers and
+    // the entries are broadcast one by one through v_readlane (no LDS latency in the loop: 757 -> 596 us per 6144x1408
+    // linear); several waves: every lane ranks one entry against the LDS copy (faster than serialising on wave 0).
+    if constexpr (NW > 1) {
+        for (uint32_t p = tid; p < n; p += NT) {
+            const uint32_t kp = sm.rawk[p], cp = sm.rawc[p];
+            uint32_t rank = 0;
+            for (uint32_t q = 0; q < n; ++q) {
+                const uint32_t kq = sm.rawk[q], cq = sm.rawc[q];
+                rank += (kq < kp || (kq == kp && cq < cp)) ? 1u : 0u;
+            }
+            out[rank] = ListEntry{(cp ^ flip) & 0x3FFFu, sm.rawd[p]};
+            place(p, rank);
+        }
+    } else if (tid < 64) {
+        const uint32_t p0 = uint32_t(tid), p1 = uint32_t(tid) + 64u;
+        const uint32_t k0 = p0 < n ? sm.rawk[p0] : 0xFFFFFFFFu, c0 = p0 < n ? sm.rawc[p0] : 0xFFFFFFFFu;
+        const uint32_t k1 = p1 < n ? sm.rawk[p1] : 0xFFFFFFFFu, c1 = p1 < n ? sm.rawc[p1] : 0xFFFFFFFFu;
+        uint32_t rank0 = 0, rank1 = 0;
+        const uint32_t n_lo = n < 64u ? n : 64u;
+        for (uint32_t q = 0; q < n_lo; ++q) {
+            const uint32_t kq = uint32_t(__builtin_amdgcn_readlane(int(k0), int(q))), cq = uint32_t(__builtin_amdgcn_readlane(int(c0), int(q)));
+            rank0 += (kq < k0 || (kq == k0 && cq < c0)) ? 1u : 0u;
+            rank1 += (kq < k1 || (kq == k1 && cq < c1)) ? 1u : 0u;
+        }
+        for (uint32_t q = 64; q < n; ++q) {
+            const uint32_t kq = uint32_t(__builtin_amdgcn_readlane(int(k1), int(q - 64u))), cq = uint32_t(__builtin_amdgcn_readlane(int(c1), int(q - 64u)));
+            rank0 += (kq < k0 || (kq == k0 && cq < c0)) ? 1u : 0u;
+            rank1 += (kq < k1 || (kq == k1 && cq < c1)) ? 1u : 0u;
+        }
+        if (p0 < n) { out[rank0] = ListEntry{(c0 ^ flip) & 0x3FFFu, sm.rawd[p0]}; place(p0, rank0); }
+        if (p1 < n) { out[rank1] = ListEntry{(c1 ^ flip) & 0x3FFFu, sm.rawd[p1]}; place(p1, rank1); }
+    }
+    dl_sync<NW>();
+    return n;
+}
+
+template <typename T, int CH, int NW, bool NM>
+__global__ __launch_bounds__(64 * NW) void dsnot_lists_kernel(
+    const typename T::raw *__restrict__ W, int64_t out_f, int64_t in_f, int64_t ldw, const uint8_t *__restrict__ keep0,
+    const float *__restrict__ sqrt_scaler, const float *__restrict__ sum_row, const float *__restrict__ var_row, int use_wanda_init,
+    int prune_m, int max_cycle, float thr, float pow_var, int without_same_sign, uint32_t *__restrict__ events,
+    int32_t *__restrict__ t_row) {
+    constexpr int NT = 64 * NW, E = CH * 8;
+    __shared__ ListSmem<NW, NM> sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
+    const int64_t nchunks = in_f / 8;
+    // ---- 1. keys (identical to dsnot_simulate_kernel) -------------------------------------------------------------
+    float D[E];
+    uint32_t gk[E], wk[E];
+    uint32_t live = 0, pruned0 = 0;
+    float part = 0.f;
+#pragma unroll
+    for (int s = 0; s < CH; ++s) {
+        const int64_t c = int64_t(s) * NT + tid;
+        if (c < nchunks) {
+            const int64_t col0 = c * 8;
+            Chunk8<T> raw = load_chunk8<T>(W + row * ldw + col0);
+            const uint2 mm = *reinterpret_cast<const uint2 *>(keep0 + row * in_f + col0);
+            uint8_t m[8];
+            __builtin_memcpy(m, &mm, 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = s * 8 + j;
+                const float w = to_f32<T>(raw.v[j]);
+                const float d = ieee_mul(w, sum_row[col0 + j]);
+                D[i] = d;
+                const bool pr = m[j] == 0;
+                live |= 1u << i;
+                if (pr) pruned0 |= 1u << i;
+                const float init = use_wanda_init ? ieee_mul(fabsf(w), sqrt_scaler[col0 + j]) : fabsf(w);
+                const float wanda = NM ? init : ieee_mul(fabsf(w), sqrt_scaler[col0 + j]);
+                wk[i] = score_key(wanda);
+                float g = pr ? d : 0.f;
+                if (pr) part = ieee_add(part, d);
+                if (pow_var != 0.f) {
+                    const float v = var_row[col0 + j];
+                    g = ieee_div(g, pow_var == 1.f ? v : powf(v, pow_var));
+                }
+                gk[i] = dl_signed_key(g);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { D[s * 8 + j] = 0.f; gk[s * 8 + j] = 0; wk[s * 8 + j] = 0; }
+        }
+    }
+    float err;
+    {
+        float v = part;
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+        err = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) +
+              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)) +
+              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) +
+              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+        if constexpr (NW > 1) {
+            if (lane == 0) sm.fsum[wave] = err;
+            __syncthreads();
+            err = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) err += sm.fsum[w];
+            __syncthreads();
+        }
+    }
+    const float sign0 = err > 0.f ? 1.f : (err < 0.f ? -1.f : 0.f);
+    const uint32_t kept0 = live & ~pruned0;
+    const uint32_t K = uint32_t(max_cycle);
+
+    // ---- 2. the list heads ---------------------------------------------------------------------------------------
+    auto no_emit = [](int, uint32_t) {};
+    auto no_place = [](uint32_t, uint32_t) {};
+    uint32_t n_list[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t NP = 0, PP = 0, Z = 0, k0col = 0;
+    float k0d = 0.f;
+    if constexpr (NM) {
+        const int mshift = prune_m == 8 ? 3 : (prune_m == 4 ? 2 : 1);
+        // payload of a regrow entry: its m-group's kept columns in ascending (metric, column) order
+        auto emit = [&](int i, uint32_t pos) {
+            GroupInfo gi;
+            gi.n = 0;
+            const int base = (i / 8) * 8;                      // the group lies inside the lane's 8-column chunk
+            const int gsel = (i % 8) >> mshift;
+            const uint32_t col_base = uint32_t((i / 8) * NT * 8 + tid * 8);
+#pragma unroll
+            for (int a = 0; a < 8; ++a) { gi.col[a] = 0; gi.d[a] = 0.f; }
+            gi.d0 = 0.f;
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                if ((a >> mshift) != gsel) continue;
+                if (a == (gsel << mshift)) gi.d0 = D[base + a];
+                if (!((kept0 >> (base + a)) & 1u)) continue;
+                uint32_t rank = 0;
+#pragma unroll
+                for (int b2 = 0; b2 < 8; ++b2) {
+                    if ((b2 >> mshift) != gsel || !((kept0 >> (base + b2)) & 1u)) continue;
+                    rank += (wk[base + b2] < wk[base + a] || (wk[base + b2] == wk[base + a] && b2 < a)) ? 1u : 0u;
+                }
+#pragma unroll
+                for (int slot = 0; slot < 8; ++slot)           // rank is a run-time value: select the slot by compare
+                    if (uint32_t(slot) == rank) { gi.col[slot] = uint16_t(col_base + a); gi.d[slot] = D[base + a]; }
+                ++gi.n;
+            }
+            sm.rawg[pos] = gi;
+        };
+        for (int li = 0; li < 2; ++li) {
+            auto place = [&](uint32_t p, uint32_t rank) { sm.grp[li][rank] = sm.rawg[p]; };
+            n_list[li] = dl_extract<E, NT, NW>(gk, D, live, li == 1, K, sm, sm.list[li], emit, place);
+        }
+    } else {
+        uint32_t negm = 0, posm = 0;
+#pragma unroll
+        for (int i = 0; i < E; ++i)
+            if ((kept0 >> i) & 1u) {
+                if (D[i] < 0.f) negm |= 1u << i;
+                else if (D[i] > 0.f) posm |= 1u << i;
+            }
+        NP = dl_block_sum<NT, NW>(uint32_t(__popc(negm)), sm, 0);
+        PP = dl_block_sum<NT, NW>(uint32_t(__popc(posm)), sm, 1);
+        Z = dl_block_sum<NT, NW>(uint32_t(__popc(kept0)), sm, 2) - NP - PP;
+        n_list[0] = dl_extract<E, NT, NW>(gk, D, live, false, K, sm, sm.list[0], no_emit, no_place);
+        n_list[1] = dl_extract<E, NT, NW>(gk, D, live, true, K, sm, sm.list[1], no_emit, no_place);
+        n_list[2] = dl_extract<E, NT, NW>(wk, D, negm, false, K, sm, sm.list[2], no_emit, no_place);
+        n_list[3] = dl_extract<E, NT, NW>(wk, D, negm, true, K, sm, sm.list[3], no_emit, no_place);
+        n_list[4] = dl_extract<E, NT, NW>(wk, D, posm, false, K, sm, sm.list[4], no_emit, no_place);
+        n_list[5] = dl_extract<E, NT, NW>(wk, D, posm, true, K, sm, sm.list[5], no_emit, no_place);
+        // K0: the kept column with the smallest wanda metric (head of the ascending list over ALL kept columns)
+        const uint32_t nk0 = dl_extract<E, NT, NW>(wk, D, kept0, false, 1u, sm, sm.k0, no_emit, no_place);
+        k0col = nk0 ? sm.k0[0].col : 0xFFFFFFFFu;
+        k0d = nk0 ? sm.k0[0].d : 0.f;
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sm.nlist[i] = n_list[i];
+    }
+    dl_sync<NW>();
+    if (wave != 0) return;
+
+    // ---- 3. the cycles, by wave 0 (uniform control flow) ------------------------------------------------------------
+    bool u = true;
+    int stop = 0x7FFFFFFF;
+    uint32_t hpos = 0, tpos = 0, r_lo = 0, r_hi = 0, a_nlo = 0, a_nhi = 0, a_plo = 0, a_phi = 0;
+    for (int t = 0; t < max_cycle; ++t) {
+        const bool r_tail = err > 0.f;
+        // head and tail walkers share one visited set: an entry is available while lo + hi < number of columns
+        uint32_t rcol = 0xFFFFFFFFu;
+        float rd = 0.f;
+        uint32_t ridx = 0;
+        {
+            const uint32_t idx = r_tail ? r_hi : r_lo;
+            if (idx < sm.nlist[r_tail ? 1 : 0] && r_lo + r_hi < uint32_t(in_f)) {
+                const ListEntry e = sm.list[r_tail ? 1 : 0][idx];
+                rcol = e.col; rd = e.d; ridx = idx;
+            }
+            if (r_tail) ++r_hi; else ++r_lo;
+        }
+        uint32_t pcol = 0xFFFFFFFFu;
+        float pd = 0.f;
+        if constexpr (NM) {
+            const uint32_t g0 = rcol - rcol % uint32_t(prune_m);
+            // visits of this group so far = entries of its sorted kept list already taken
+            uint32_t cnt = 0;
+            for (int base = 0; base < t; base += 64) {
+                const int q = base + lane;
+                const bool hit = q < t && sm.cyc_group[q] == g0;
+                cnt += uint32_t(__popcll(__ballot(hit)));
+            }
+            const GroupInfo &gi = sm.grp[r_tail ? 1 : 0][ridx];
+            if (cnt < gi.n) {
+                pcol = gi.col[cnt]; pd = gi.d[cnt];
+            } else {
+                pcol = g0; pd = gi.d0;                       // every kept column of the group is taken (dsnot.hip)
+            }
+            // a visit consumes a kept column only while one is left: the fallback does not
+            if (lane == 0) sm.cyc_group[t] = cnt < gi.n ? g0 : 0xFFFFFFFFu;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            const bool p_tail = err < 0.f;
+            const uint32_t pos = p_tail ? tpos : hpos;
+            const uint32_t first = p_tail ? PP : NP;
+            if (pos >= first && pos < first + Z) {
+                pcol = k0col; pd = k0d;
+            } else {
+                const bool from_low = pos < first;
+                const bool use_neg = p_tail ? !from_low : from_low;
+                const int li = use_neg ? (from_low ? 2 : 3) : (from_low ? 4 : 5);
+                const uint32_t ptr = use_neg ? (from_low ? a_nlo : a_nhi) : (from_low ? a_plo : a_phi);
+                const uint32_t taken = use_neg ? a_nlo + a_nhi : a_plo + a_phi;       // from either end of that pool
+                const uint32_t pool = use_neg ? NP : PP;
+                if (taken < pool && ptr < sm.nlist[li]) {
+                    const ListEntry e = sm.list[li][ptr];
+                    pcol = e.col; pd = e.d;
+                    a_nlo += (use_neg && from_low) ? 1u : 0u;
+                    a_nhi += (use_neg && !from_low) ? 1u : 0u;
+                    a_plo += (!use_neg && from_low) ? 1u : 0u;
+                    a_phi += (!use_neg && !from_low) ? 1u : 0u;
+                }
+            }
+            if (p_tail) ++tpos; else ++hpos;
+        }
+        const float after = ieee_add(ieee_add(err, pd), -rd);
+        const float sa = after > 0.f ? 1.f : (after < 0.f ? -1.f : 0.f);
+        bool un = u && (fabsf(err) > thr);
+        if (NM || !without_same_sign) un = un && (sign0 == sa);
+        u = un;
+        if (!u && stop == 0x7FFFFFFF) stop = t + 1;
+        if (tid == 0) events[row * max_cycle + t] = (pcol & 0x3FFFu) | ((rcol & 0x3FFFu) << 14) | (u ? 1u << 28 : 0u);
+        if (u) {
+            err = ieee_add(err, pd);
+            err = ieee_add(err, -rd);
+        }
+    }
+    if (tid == 0) t_row[row] = stop;
+}
+
+template <typename T, bool NM>
+static int lists_dispatch(const void *W, int64_t out_f, int64_t in_f, int64_t ldw, const uint8_t *keep0, const float *sq,
+                          const float *sum_row, const float *var_row, int use_wanda_init, int prune_m, int max_cycle,
+                          float thr, float pow_var, int without_same_sign, uint32_t *events, int32_t *t_row, hipStream_t st) {
+    using raw = typename T::raw;
+    const int64_t nchunks = in_f / 8;
+    // smallest workgroup that holds the row with <= 4 chunks per lane (fewest barriers per radix pass)
+    int nw = 1;
+    while (nw < 8 && nchunks > int64_t(64) * nw * 4) nw *= 2;
+    if (const char *e = getenv("VLMC_DSNOT_NW")) {
+        const int f = atoi(e);
+        if ((f == 1 || f == 2 || f == 4 || f == 8) && nchunks <= int64_t(64) * f * 4) nw = f;
+    }
+    if (nchunks > int64_t(64) * nw * 4) return VLMC_EINVAL;
+    const int ch = nchunks <= int64_t(64) * nw * 2 ? 2 : 4;
+#define VLMC_DL(CH, NW)                                                                                                    \
+    hipLaunchKernelGGL((dsnot_lists_kernel<T, CH, NW, NM>), dim3(unsigned(out_f)), dim3(64 * NW), 0, st,                    \
+                       static_cast<const raw *>(W), out_f, in_f, ldw, keep0, sq, sum_row, var_row, use_wanda_init, prune_m, \
+                       max_cycle, thr, pow_var, without_same_sign, events, t_row)
+#define VLMC_DL_NW(NW) do { if (ch == 2) VLMC_DL(2, NW); else VLMC_DL(4, NW); } while (0)
+    switch (nw) {
+        case 1: VLMC_DL_NW(1); break;
+        case 2: VLMC_DL_NW(2); break;
+        case 4: VLMC_DL_NW(4); break;
+        default: VLMC_DL_NW(8); break;
+    }
+#undef VLMC_DL_NW
+#undef VLMC_DL
+    return VLMC_OK;
+}
+
+template <bool NM>
+static int lists_dispatch_dtype(const void *W, int dtype, int64_t out_f, int64_t in_f, int64_t ldw, const uint8_t *keep0,
+                                const float *sq, const float *sum_row, const float *var_row, int use_wanda_init, int prune_m,
+                                int max_cycle, float thr, float pow_var, int without_same_sign, uint32_t *events, int32_t *t_row,
+                                hipStream_t st) {
+    switch (dtype) {
+        case VLMC_F32: return lists_dispatch<f32_t, NM>(W, out_f, in_f, ldw, keep0, sq, sum_row, var_row, use_wanda_init, prune_m,
+                                                        max_cycle, thr, pow_var, without_same_sign, events, t_row, st);
+        case VLMC_F16: return lists_dispatch<f16_t, NM>(W, out_f, in_f, ldw, keep0, sq, sum_row, var_row, use_wanda_init, prune_m,
+                                                        max_cycle, thr, pow_var, without_same_sign, events, t_row, st);
+        case VLMC_BF16: return lists_dispatch<bf16_t, NM>(W, out_f, in_f, ldw, keep0, sq, sum_row, var_row, use_wanda_init, prune_m,
+                                                          max_cycle, thr, pow_var, without_same_sign, events, t_row, st);
+    }
+    return VLMC_EINVAL;
+}
+
+}  // namespace vlmc
