@@ -10,7 +10,7 @@ plans = [bench.build_plans(blocks, acts, w, n_local, 1, dev, state) for w in set
 for i in range(2): bench.run_step(plans[i % 2], state, 1)
 torch.cuda.synchronize()
 for with_events in (False, True):
-    ev = [] if with_events else None
+    ev = {"stat": [], "rows": []} if with_events else None
     t0 = time.perf_counter(); bench.run_step(plans[0], state, 1, ev); t1 = time.perf_counter()
     torch.cuda.synchronize(); t2 = time.perf_counter()
     print(f"events={with_events}: issue {1e3*(t1-t0):.2f} ms, until done {1e3*(t2-t0):.2f} ms")
