@@ -16,12 +16,14 @@
 namespace vlmc {
 
 constexpr int kSgBlock = 128;   // max columns per block
-constexpr int kSgRows = 4;      // rows per wave in flight (independent dependency chains)
+// rows per wave in flight (independent dependency chains) is the template parameter R: few rows per wave and
+// more waves when the linear has few rows, so that every SIMD of the chip has a wave (2048 rows: 4 -> 2 rows per wave)
 
 __device__ __forceinline__ float lane_bcast(float v, int src) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
+template <int kSgRows>
 __global__ __launch_bounds__(256) void sparsegpt_sweep_kernel(float *__restrict__ W, int64_t out_f, int count, int64_t ldw,
                                                               const float *__restrict__ U1, int64_t ldu,
                                                               const uint8_t *__restrict__ mask1, int64_t ldm, int prune_n,
@@ -136,21 +138,31 @@ extern "C" int vlmc_sparsegpt_sweep(float *W, int64_t out_features, int64_t coun
     } else {
         VLMC_REQUIRE(mask1 && ldm >= count, "vlmc_sparsegpt_sweep: unstructured pruning needs the block mask");
     }
-    const int64_t groups = (out_features + kSgRows - 1) / kSgRows;
+    // rows per wave: as few as it takes to give every SIMD of the chip (1024) a wave, at most 4
+    int rows = int(out_features / 1024);
+    rows = rows < 1 ? 1 : (rows >= 4 ? 4 : (rows >= 2 ? 2 : 1));
+    const int64_t groups = (out_features + rows - 1) / rows;
     int64_t grid = (groups + 3) / 4;
     if (grid > 512) grid = 512;
     const size_t lds = size_t(count) * kSgBlock * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(sparsegpt_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kSgBlock * kSgBlock * int(sizeof(float))) != hipSuccess) {
+        const int bytes = kSgBlock * kSgBlock * int(sizeof(float));
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(sparsegpt_sweep_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(sparsegpt_sweep_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(sparsegpt_sweep_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
             set_error("vlmc_sparsegpt_sweep: cannot reserve 64 KB of LDS");
             return VLMC_EHIP;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(sparsegpt_sweep_kernel, dim3(unsigned(grid)), dim3(256), lds, as_stream(stream), W, out_features,
-                       int(count), ldw, U1, ldu, mask1, ldm, prune_n, prune_m, Err1, lde, mask_out, ldmo);
+#define VLMC_SWEEP(R)                                                                                                       \
+    hipLaunchKernelGGL(sparsegpt_sweep_kernel<R>, dim3(unsigned(grid)), dim3(256), lds, as_stream(stream), W, out_features,  \
+                       int(count), ldw, U1, ldu, mask1, ldm, prune_n, prune_m, Err1, lde, mask_out, ldmo)
+    if (rows == 1) VLMC_SWEEP(1);
+    else if (rows == 2) VLMC_SWEEP(2);
+    else VLMC_SWEEP(4);
+#undef VLMC_SWEEP
     VLMC_HIP_CHECK_LAUNCH("vlmc_sparsegpt_sweep");
     return VLMC_OK;
 }
