@@ -27,28 +27,53 @@ namespace vlmc {
 // ------------------------------------------------------------------------------------------
 // statistics
 // ------------------------------------------------------------------------------------------
+// One lane = one channel of one call, tokens in order: the squared norm is the same fp32 fma chain as
+// act_sqnorm_kernel (bit-exact scaler_row), the sum the same sequential fp32 adds; the variance comes from fp64
+// sums of x and x^2 (full-rate on CDNA, no division per token), which agrees with torch.var to ~1e-12 relative --
+// the reference's own reduction order is not reproducible to the bit anyway (tests: rtol 2e-6).
+// HBM-bound streaming: 16 tokens in flight per lane through non-temporal loads.
 template <typename T>
-__global__ __launch_bounds__(256) void act_moments_kernel(const typename T::raw *__restrict__ x, int64_t tokens, int64_t in_f,
-                                                          int64_t row_stride, int64_t call_stride, float *__restrict__ normsq,
-                                                          float *__restrict__ sums, float *__restrict__ vars) {
+__global__ __launch_bounds__(64) void act_moments_kernel(const typename T::raw *__restrict__ x, int64_t tokens, int64_t in_f,
+                                                         int64_t row_stride, int64_t call_stride, float *__restrict__ normsq,
+                                                         float *__restrict__ sums, float *__restrict__ vars) {
     const int64_t ch = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (ch >= in_f) return;
     const int64_t call = blockIdx.y;
     const typename T::raw *p = x + call * call_stride + ch;
     float sq = 0.f, s = 0.f;
-    double mean = 0.0, m2 = 0.0;
-    for (int64_t t = 0; t < tokens; ++t) {
+    double s1 = 0.0, s2 = 0.0;
+    constexpr int U = 16;
+    int64_t t = 0;
+    for (; t + U <= tokens; t += U) {
+        typename T::raw r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = __builtin_nontemporal_load(p + (t + u) * row_stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float v = to_f32<T>(r[u]);
+            sq = __builtin_fmaf(v, v, sq);
+            s = ieee_add(s, v);
+            const double d = double(v);
+            s1 += d;
+            s2 = __builtin_fma(d, d, s2);
+        }
+    }
+    for (; t < tokens; ++t) {
         const float v = to_f32<T>(p[t * row_stride]);
         sq = __builtin_fmaf(v, v, sq);
         s = ieee_add(s, v);
-        const double d = double(v) - mean;
-        mean += d / double(t + 1);
-        m2 += d * (double(v) - mean);
+        const double d = double(v);
+        s1 += d;
+        s2 = __builtin_fma(d, d, s2);
     }
     const int64_t o = call * in_f + ch;
     if (normsq) { const float r = ieee_sqrt(sq); normsq[o] = ieee_mul(r, r); }
     if (sums) sums[o] = s;
-    if (vars) vars[o] = float(m2 / double(tokens));          // torch.var(unbiased=False)
+    if (vars) {                                                   // torch.var(unbiased=False)
+        const double n = double(tokens), mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        vars[o] = float(var > 0.0 ? var : 0.0);
+    }
 }
 
 // scaler_row / sum_metric_row: *= float(n/(n+b)); += v / float(n+b)      (dsnot_pruner.py:96-101)
@@ -490,9 +515,9 @@ extern "C" int vlmc_act_moments(const void *x, int dtype, int64_t n_calls, int64
                  "vlmc_act_moments: bad shape calls=%lld tokens=%lld in=%lld", (long long)n_calls, (long long)tokens,
                  (long long)in_features);
     if (n_calls == 0) return VLMC_OK;
-    const dim3 grid(unsigned((in_features + 255) / 256), unsigned(n_calls));
+    const dim3 grid(unsigned((in_features + 63) / 64), unsigned(n_calls));
     hipStream_t st = as_stream(stream);
-#define VLMC_MOM(T) hipLaunchKernelGGL((act_moments_kernel<T>), grid, dim3(256), 0, st, static_cast<const T::raw *>(x), tokens, \
+#define VLMC_MOM(T) hipLaunchKernelGGL((act_moments_kernel<T>), grid, dim3(64), 0, st, static_cast<const T::raw *>(x), tokens, \
                                        in_features, row_stride, call_stride, normsq, sums, vars)
     switch (dtype) {
         case VLMC_F32: VLMC_MOM(f32_t); break;
