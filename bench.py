@@ -209,11 +209,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback of the product path)")
+    # VLMC_BENCH_ONE_DEVICE=1 (testing the N > 1 code path on a 1-GPU box): every rank uses cuda:0 and the
+    # collective runs over gloo -- never set by the driver
+    one_device = os.environ.get("VLMC_BENCH_ONE_DEVICE", "0") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert N_CALIB % world == 0
 
     from vlmc import _lib
