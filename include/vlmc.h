@@ -165,6 +165,16 @@ int vlmc_lora_grad(const void *G, int dtype, int64_t out_features, int64_t in_fe
                    const float *B, int r, float scaling, const uint8_t *mask, int sparse, int autocast, float *dA,
                    float *dB, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- K9: diagonal block of the blocked Cholesky factorization ------------------------------
+ * Replaces the unblocked panel step inside `torch.linalg.cholesky(H)` (sparsegpt_pruner.py:116,148):
+ * factorizes the nb x nb (nb <= 128) symmetric positive definite block A (lower part read) into its
+ * lower Cholesky factor L and also writes inv(L), so that the caller forms the panel below the block
+ * and the trailing update with library GEMMs (vlmc/sparsegpt.py: blocked_cholesky).  `*info` (device
+ * int, zero-initialised by the caller) receives col0 + j + 1 for the first column j whose pivot is not
+ * positive (LAPACK convention); it is left untouched otherwise.                                    */
+int vlmc_chol_block(const float *A, int64_t lda, int nb, float *L, int64_t ldl, float *Linv, int64_t ldi, int *info,
+                    int col0, void *stream);
+
 /* ---- K10: SparseGPT blocked OBS sweep ----------------------------------------------------
  * Replaces the per-column Python loop of sparsegpt_pruner.py:186-205 for ONE block of
  * `count` <= 128 columns (fp32 working copy W, pointer at the block's first column):

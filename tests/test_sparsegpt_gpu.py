@@ -98,3 +98,37 @@ def test_fasterprune_larger_layer_vs_oracle():
         assert clean.float().mean().item() > 0.8
         assert _rel_err(got[clean], want[clean]) < 1e-3
         assert lin.weight.importance_score == pytest.approx(imp, rel=1e-4)
+
+
+# ---- blocked Cholesky (vlmc_chol_block + library GEMMs) --------------------------------------------------
+@pytest.mark.parametrize("n", [1, 7, 128, 129, 200, 1408, 2048])
+@pytest.mark.parametrize("upper", [False, True])
+def test_blocked_cholesky_matches_library_factorization(n, upper):
+    from vlmc import sparsegpt
+    g = torch.Generator().manual_seed(n)
+    X = torch.randn(max(2 * n, 64), n, generator=g)
+    H = (X.t() @ X / X.shape[0] + 0.05 * torch.eye(n)).to("cuda:0")
+    F, info = sparsegpt.blocked_cholesky(H, upper=upper)
+    assert int(info.item()) == 0
+    ref = torch.linalg.cholesky(H.double(), upper=upper)
+    assert float((F.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    rec = (F.t() @ F) if upper else (F @ F.t())
+    assert float((rec - H).abs().max() / H.abs().max()) < 1e-5
+    tri = torch.triu(F, 1) if not upper else torch.tril(F, -1)
+    assert float(tri.abs().max()) == 0.0 if n > 1 else True
+
+
+def test_blocked_cholesky_reports_the_failing_column_like_lapack():
+    from vlmc import sparsegpt
+    n = 300
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(2 * n, n, generator=g)
+    H = (X.t() @ X / X.shape[0] + 0.05 * torch.eye(n))
+    H[200, 200] = -1.0                                       # breaks positive definiteness at column 200 (0-based)
+    _, info = sparsegpt.blocked_cholesky(H.to("cuda:0"))
+    _, ref_info = torch.linalg.cholesky_ex(H)
+    assert int(info.item()) == int(ref_info.item()) == 201
+    Hn = H.clone()
+    Hn[5, 5] = float("nan")
+    _, info = sparsegpt.blocked_cholesky(Hn.to("cuda:0"))
+    assert int(info.item()) == 6

@@ -1,0 +1,187 @@
+// K9: diagonal-block kernel of the blocked Cholesky factorization used for SparseGPT's Hessian chain
+// (replaces the unblocked panel step inside torch.linalg.cholesky, sparsegpt_pruner.py:116,148).
+//
+// rocSOLVER's potrf spends 0.3 ms per 128-column panel in a one-workgroup unblocked kernel (6 ms for a 2048^2
+// Hessian, 20 ms for 6144^2, twice per linear).  Here the 128x128 diagonal block is factorized in LDS by one
+// workgroup and its inverse is produced in the same launch, so that the panel below it becomes a GEMM
+// (L21 = A21 @ inv(L11)^T) and the trailing update another one -- both at the library's 100+ TFLOP/s fp32 rate.
+// Right-looking column sweep; every step is elementwise IEEE fp32 (sqrt, divide, multiply, subtract).
+#include "common.hpp"
+
+namespace vlmc {
+
+constexpr int kCholNb = 128;
+constexpr int kCholLd = kCholNb + 1;       // LDS row stride: column walks hit different banks
+
+constexpr int kSb = 32;                    // sub-block: factorized by ONE wave in registers (no workgroup barriers inside)
+constexpr int kCholThreads = 512;
+
+__device__ __forceinline__ float rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+// 512 lanes.  Per 32-column sub-block: (a) wave 0 factorizes the 32x32 diagonal piece with its rows in registers
+// (pivots and column entries travel by v_readlane), (b) every row below solves its 32 entries by forward substitution,
+// (c) the rest of the block gets its rank-32 update.  12 barriers per 128x128 block instead of 3 per column.
+// Then inv(L): the four 32x32 diagonal inverses by one wave each, the off-diagonal pieces block-diagonal by block-diagonal.
+__global__ __launch_bounds__(kCholThreads) void chol_block_kernel(const float *__restrict__ A, int64_t lda, int nb, float *__restrict__ L,
+                                                         int64_t ldl, float *__restrict__ Linv, int64_t ldi,
+                                                         int *__restrict__ info, int col0) {
+    extern __shared__ float sh[];
+    float *a = sh;                          // [128][kCholLd] block being factorized (lower part)
+    float *v = sh + kCholNb * kCholLd;      // [128][kCholLd] its inverse (upper pieces double as scratch)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool vec4 = nb == kCholNb && (lda % 4 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0);
+    if (vec4) {
+        for (int e = tid; e < kCholNb * kCholNb / 4; e += kCholThreads) {
+            const int i = e / (kCholNb / 4), k = (e % (kCholNb / 4)) * 4;
+            const float4 q = *reinterpret_cast<const float4 *>(A + int64_t(i) * lda + k);
+            const float r4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[i * kCholLd + k + t] = (k + t <= i) ? r4[t] : 0.f;
+                v[i * kCholLd + k + t] = 0.f;
+            }
+        }
+    } else {
+        for (int e = tid; e < kCholNb * kCholNb; e += kCholThreads) {
+            const int i = e / kCholNb, k = e % kCholNb;
+            // rows / columns past nb are padded with the identity so that every 32-piece is a full, regular one
+            a[i * kCholLd + k] = (i < nb && k <= i) ? A[int64_t(i) * lda + k] : ((i >= nb && k == i) ? 1.f : 0.f);
+            v[i * kCholLd + k] = 0.f;
+        }
+    }
+    __syncthreads();
+    for (int base = 0; base < kCholNb && base < nb; base += kSb) {
+        if (wave == 0) {
+            float row[kSb];                 // lane i < 32: row base + i of the diagonal piece
+            const int li = lane & 31;
+#pragma unroll
+            for (int k = 0; k < kSb; ++k) row[k] = (k <= li) ? a[(base + li) * kCholLd + base + k] : 0.f;
+#pragma unroll
+            for (int j = 0; j < kSb; ++j) {
+                const float d = rl(row[j], j);
+                if (lane == 0 && base + j < nb && !(d > 0.f) && *info == 0) *info = col0 + base + j + 1;   // not positive definite
+                const float r = ieee_sqrt(d);
+                const float lij = li > j ? ieee_div(row[j], r) : (li == j ? r : row[j]);
+                row[j] = lij;
+#pragma unroll
+                for (int k = j + 1; k < kSb; ++k) {
+                    const float lkj = rl(lij, k);
+                    if (li >= k) row[k] = row[k] - ieee_mul(lij, lkj);
+                }
+            }
+            if (lane < kSb) {
+#pragma unroll
+                for (int k = 0; k < kSb; ++k)
+                    if (k <= li) a[(base + li) * kCholLd + base + k] = row[k];
+            }
+        }
+        __syncthreads();
+        const int below = base + kSb;
+        for (int i = below + tid; i < kCholNb; i += kCholThreads) {      // (b) forward substitution, one row per lane
+            float x[kSb];
+#pragma unroll
+            for (int c = 0; c < kSb; ++c) {
+                float acc = a[i * kCholLd + base + c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) acc = acc - ieee_mul(x[k], a[(base + c) * kCholLd + base + k]);
+                x[c] = ieee_div(acc, a[(base + c) * kCholLd + base + c]);
+            }
+#pragma unroll
+            for (int c = 0; c < kSb; ++c) a[i * kCholLd + base + c] = x[c];
+        }
+        __syncthreads();
+        const int m2 = (kCholNb - below) / 2;                    // (c) rank-32 update of what is left, 2x2 tiles per lane
+        for (int e = tid; e < m2 * m2; e += kCholThreads) {
+            const int i = below + 2 * (e / m2), k = below + 2 * (e % m2);
+            if (k <= i) {
+                float acc00 = a[i * kCholLd + k], acc01 = a[i * kCholLd + k + 1];
+                float acc10 = a[(i + 1) * kCholLd + k], acc11 = a[(i + 1) * kCholLd + k + 1];
+#pragma unroll 8
+                for (int c = 0; c < kSb; ++c) {
+                    const float li0 = a[i * kCholLd + base + c], li1 = a[(i + 1) * kCholLd + base + c];
+                    const float lk0 = a[k * kCholLd + base + c], lk1 = a[(k + 1) * kCholLd + base + c];
+                    acc00 = acc00 - ieee_mul(li0, lk0); acc01 = acc01 - ieee_mul(li0, lk1);
+                    acc10 = acc10 - ieee_mul(li1, lk0); acc11 = acc11 - ieee_mul(li1, lk1);
+                }
+                a[i * kCholLd + k] = acc00;
+                a[(i + 1) * kCholLd + k] = acc10; a[(i + 1) * kCholLd + k + 1] = acc11;
+                if (k + 1 <= i) a[i * kCholLd + k + 1] = acc01;     // (i, i+1) lies above the diagonal of the i == k tile
+            }
+        }
+        __syncthreads();
+    }
+    // ---- inverse of the lower-triangular block ----------------------------------------------------------------
+    if (wave < kCholNb / kSb) {   // diagonal pieces: wave w inverts piece w; lane c < 32 owns column c:
+        //                           x_r = (delta_rc - sum_{k=c}^{r-1} L[r][k] x_k) / L[r][r]
+        const int base = wave * kSb, c = lane & 31;
+        float x[kSb];
+#pragma unroll
+        for (int r = 0; r < kSb; ++r) {
+            float acc = (r == c) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < r; ++k)
+                if (k >= c) acc = acc - ieee_mul(a[(base + r) * kCholLd + base + k], x[k]);
+            x[r] = (r >= c) ? ieee_div(acc, a[(base + r) * kCholLd + base + r]) : 0.f;
+        }
+        if (lane < kSb) {
+#pragma unroll
+            for (int r = 0; r < kSb; ++r) v[(base + r) * kCholLd + base + c] = x[r];
+        }
+    }
+    __syncthreads();
+    constexpr int NBLK = kCholNb / kSb;
+    for (int d = 1; d < NBLK; ++d) {
+        // pieces (rb, cb = rb - d): T = sum_{m=cb}^{rb-1} L[rb][m] V[m][cb], kept in the (cb, rb) mirror piece of v
+        const int pairs = NBLK - d;
+        for (int e = tid; e < pairs * kSb * kSb; e += kCholThreads) {
+            const int pr = e / (kSb * kSb), r = (e / kSb) % kSb, c = e % kSb;
+            const int rb = pr + d, cb = pr;
+            float acc = 0.f;
+            for (int mb = cb; mb < rb; ++mb)
+#pragma unroll 8
+                for (int k = 0; k < kSb; ++k)
+                    acc = __builtin_fmaf(a[(rb * kSb + r) * kCholLd + mb * kSb + k], v[(mb * kSb + k) * kCholLd + cb * kSb + c], acc);
+            v[(cb * kSb + r) * kCholLd + rb * kSb + c] = acc;        // scratch in the upper part
+        }
+        __syncthreads();
+        for (int e = tid; e < pairs * kSb * kSb; e += kCholThreads) {         // V[rb][cb] = -V[rb][rb] T
+            const int pr = e / (kSb * kSb), r = (e / kSb) % kSb, c = e % kSb;
+            const int rb = pr + d, cb = pr;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int k = 0; k <= r; ++k)
+                acc = __builtin_fmaf(v[(rb * kSb + r) * kCholLd + rb * kSb + k], v[(cb * kSb + k) * kCholLd + rb * kSb + c], acc);
+            v[(rb * kSb + r) * kCholLd + cb * kSb + c] = -acc;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < nb * nb; e += kCholThreads) {
+        const int i = e / nb, k = e % nb;
+        L[int64_t(i) * ldl + k] = k <= i ? a[i * kCholLd + k] : 0.f;
+        Linv[int64_t(i) * ldi + k] = k <= i ? v[i * kCholLd + k] : 0.f;      // the upper part held scratch
+    }
+}
+
+}  // namespace vlmc
+
+using namespace vlmc;
+
+extern "C" int vlmc_chol_block(const float *A, int64_t lda, int nb, float *L, int64_t ldl, float *Linv, int64_t ldi, int *info,
+                               int col0, void *stream) {
+    VLMC_REQUIRE(A && L && Linv && info, "vlmc_chol_block: null pointer");
+    VLMC_REQUIRE(nb > 0 && nb <= kCholNb && lda >= nb && ldl >= nb && ldi >= nb, "vlmc_chol_block: bad block size %d (max %d)", nb,
+                 kCholNb);
+    const size_t lds = size_t(2) * kCholNb * kCholLd * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(chol_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                int(lds)) != hipSuccess) {
+            set_error("vlmc_chol_block: cannot reserve %zu B of LDS", lds);
+            return VLMC_EHIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(chol_block_kernel, dim3(1), dim3(kCholThreads), lds, as_stream(stream), A, lda, nb, L, ldl, Linv, ldi, info, col0);
+    VLMC_HIP_CHECK_LAUNCH("vlmc_chol_block");
+    return VLMC_OK;
+}

@@ -63,9 +63,79 @@ def _clamp_inf(H):
         H[neg] = torch.quantile(H.flatten()[: 1 << 24], 0.001)
 
 
+_CHOL_NB = 128
+_CHOL_PANEL_GEMM = __import__("os").environ.get("VLMC_CHOL_PANEL_GEMM", "1") == "1"   # 0: library triangular solve for the panel
+_CHOL_GRAPH = __import__("os").environ.get("VLMC_CHOL_GRAPH", "1") == "1"
+
+
+def _chol_steps(A, L, inv, info):
+    """The right-looking sweep over 128-column blocks on row-major fp32 buffers (A is consumed)."""
+    n = A.shape[0]
+    lib = _lib.load()
+    el = A.element_size()
+    for k in range(0, n, _CHOL_NB):
+        nb = min(_CHOL_NB, n - k)
+        off = (k * n + k) * el
+        _lib.check(lib.vlmc_chol_block(A.data_ptr() + off, n, nb, L.data_ptr() + off, n, inv.data_ptr(), _CHOL_NB,
+                                       info.data_ptr(), k, _stream()))
+        if k + nb < n:
+            if _CHOL_PANEL_GEMM:
+                L21 = A[k + nb:, k:k + nb] @ inv[:nb, :nb].t()              # = A21 inv(L11)^T
+            else:
+                L21 = torch.linalg.solve_triangular(L[k:k + nb, k:k + nb], A[k + nb:, k:k + nb].t(), upper=False).t()
+            L[k + nb:, k:k + nb] = L21
+            A[k + nb:, k + nb:].addmm_(L21, L21.t(), beta=1.0, alpha=-1.0)   # trailing update (the lower part is what is read)
+
+
+_chol_graphs = {}       # (n, device index) -> (graph, A, L, inv, info): the sweep is launch-bound when issued from Python
+
+
+@torch.no_grad()
+def blocked_cholesky(H: torch.Tensor, upper=False):
+    """(factor, info) like torch.linalg.cholesky_ex(H, upper=upper) for a symmetric fp32 matrix on the GPU.
+    Right-looking, 128-column blocks: the diagonal block and its inverse in ONE one-workgroup kernel
+    (`vlmc_chol_block`), the panel below it and the trailing update as library GEMMs; the ~5 launches per block
+    are captured once per matrix size in a HIP graph (`VLMC_CHOL_GRAPH=0` issues them eagerly)."""
+    _need_gpu(H)
+    assert H.dim() == 2 and H.shape[0] == H.shape[1] and H.dtype == torch.float32
+    n = H.shape[0]
+    dev = H.device
+    if _CHOL_GRAPH and n > _CHOL_NB:
+        key = (n, dev.index)
+        ent = _chol_graphs.get(key)
+        if ent is None:
+            A = torch.empty((n, n), dtype=torch.float32, device=dev)
+            L = torch.zeros((n, n), dtype=torch.float32, device=dev)
+            inv = torch.empty((_CHOL_NB, _CHOL_NB), dtype=torch.float32, device=dev)
+            info = torch.zeros(1, dtype=torch.int32, device=dev)
+            A.copy_(H)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):                      # one eager run before capture (library workspaces)
+                _chol_steps(A, L, inv, info)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                _chol_steps(A, L, inv, info)
+            ent = _chol_graphs[key] = (graph, A, L, inv, info)
+        graph, A, L, inv, info = ent
+        A.copy_(H)                                              # also converts a column-major H
+        info.zero_()
+        graph.replay()
+        return (L.t().contiguous() if upper else L.clone()), info.clone()
+    # row-major working copy (the library hands back column-major results, e.g. cholesky_inverse); the caller's H
+    # must survive a failed attempt
+    A = H.clone(memory_format=torch.contiguous_format)
+    L = torch.zeros((n, n), dtype=torch.float32, device=dev)
+    inv = torch.empty((_CHOL_NB, _CHOL_NB), dtype=torch.float32, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    _chol_steps(A, L, inv, info)
+    return (L.t().contiguous() if upper else L), info
+
+
 def _chol_with_damping(H, damp, upper, max_tries=100):
     for _ in range(max_tries):
-        L, info = torch.linalg.cholesky_ex(H, upper=upper)
+        L, info = blocked_cholesky(H, upper=upper)
         if int(info.item()) == 0 and not bool(torch.isnan(L).any()):
             return L
         H.diagonal().add_(damp)                                        # only after a failure (:114-128)
