@@ -219,6 +219,40 @@ int vlmc_dsnot_refine(const void *W, int dtype, int64_t out_features, int64_t in
 int vlmc_dsnot_apply(void *W, int dtype, int64_t out_features, int64_t in_features, int64_t ldw, uint8_t *keep_mask,
                      const uint32_t *events, const int32_t *ncycles, int max_cycle, int nm_mode, int apply_zero, void *stream);
 
+/* ---- K17: one threshold over many score tensors (the global pruners) -----------------------
+ * Replaces `get_mask` / `get_layerwise_mask` and the weight update of global_pruner.py:107-148,
+ * :166-169, :188-190.  Every job is one parameter tensor (contiguous, numel elements); jobs with
+ * the same `scope` share ONE threshold: the scope_k[scope]-th smallest score (1-based, what
+ * `torch.topk(all_scores, k, largest=False)[0][-1]` returns) over all their elements; then
+ *     keep = score > threshold;   W *= keep   (a pruned weight becomes +-0, as `v.data *= mask`).
+ * score (fp32), by `score_mode`:
+ *     VLMC_SCORE_W       float(w)            (blipt5_mag_pruner :255 -- signed, as the reference)
+ *     VLMC_SCORE_S       S                   (blipt5_rand_pruner :262, or any precomputed score; W may be NULL)
+ *     VLMC_SCORE_ABSW_S  |float(w)| * |S|    (blipt5_aobd_pruner :311, S = mean |grad|)
+ * multiplied by prev_keep (0/1) when given (iterative pruning, :166-169).  protect_k > 0 is
+ * get_mask's per-layer cap (:111-118): scores >= the protect_k-th largest of the job count as FLT_MAX.
+ * -0 == +0; NaN scores sort last and are never kept (NaN > t is false).  scope_k[s] must lie in
+ * [1, elements of the scope] (k == 0 is an IndexError in the reference).
+ * `jobs` and `scope_k` are HOST arrays; this is the one entry point that waits on the stream (for the
+ * upload of the job table into the workspace).  Nothing is concatenated or sorted: 3 histogram passes
+ * over the operands + one apply pass.                                                            */
+typedef struct {
+    void *W;                  /* [numel] weight dtype; rewritten when apply_weights */
+    const float *S;           /* [numel] fp32 or NULL (by score_mode) */
+    const uint8_t *prev_keep; /* [numel] or NULL */
+    uint8_t *keep;            /* [numel] out, 1 = kept */
+    int64_t numel;
+    int64_t protect_k;
+    int32_t scope;
+    int32_t dtype;            /* dtype of W (jobs of one call may differ: fp16 vision tower + bf16 language model) */
+} vlmc_score_job;
+#define VLMC_SCORE_W 0
+#define VLMC_SCORE_S 1
+#define VLMC_SCORE_ABSW_S 2
+size_t vlmc_score_select_workspace(int n_jobs, int n_scopes);
+int vlmc_score_select(const vlmc_score_job *jobs, int n_jobs, const int64_t *scope_k, int n_scopes, int score_mode, int apply_weights,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -565,9 +565,53 @@ def gen_ecoflap():
     print("ecoflap.npz:", len(out), "arrays")
 
 
+def gen_global():
+    """Global pruners (global_pruner.py:49-383) on the toy InstructBLIP: final weights of the reference's
+    blipt5_{mag,rand,aobd,mezo}_pruner for the three scope layouts, iterative pruning, and `get_mask` with a
+    per-layer cap on explicit scores."""
+    import numpy.random as npr
+    from lavis.compression.pruners import global_pruner as RG
+    variants = {
+        "mag_global": dict(cls=RG.BLIPT5MagPruner, kw=dict(is_global=True)),
+        "mag_per_model_it2": dict(cls=RG.BLIPT5MagPruner, kw=dict(is_global=True, prune_per_model=True, iteration=2)),
+        "mag_layerwise_mixed": dict(cls=RG.BLIPT5MagPruner, kw=dict(is_global=False), t5_dtype=torch.bfloat16),
+        "rand_global": dict(cls=RG.BLIPT5RandPruner, kw=dict(is_global=True)),
+        "aobd_global": dict(cls=RG.BLIPT5AOBDPruner, kw=dict(is_global=True)),
+        "aobd_layerwise_it2": dict(cls=RG.BLIPT5AOBDPruner, kw=dict(is_global=False, iteration=2)),
+        "mezo_global": dict(cls=RG.BLIPT5AMeZoPruner, kw=dict(is_global=True, num_noise=2)),
+    }
+    out = {}
+    for name, v in variants.items():
+        torch.manual_seed(0)
+        npr.seed(1234)
+        model = toy_models.init_toy(toy_models.ToyBlipT5(t5_dtype=v.get("t5_dtype", torch.float32)), seed=7).eval()
+        batches = toy_models.make_batches(6, seed=11)
+        spec = "2-0.6-1.0-1.0"
+        pr = v["cls"](model=model, data_loader=batches, t5_prune_spec=spec, vit_prune_spec=spec, num_samples=4, **v["kw"])
+        pruned, _ = pr.prune()
+        for k_, p_ in pruned.named_parameters():
+            if p_.dim() == 2 and ".block" in k_:
+                out[f"{name}/{k_}"] = p_.data.clone()
+    # get_mask / get_layerwise_mask on explicit scores, with the per-layer cap active
+    g = torch.Generator().manual_seed(3)
+    scores = {f"layer{i}": torch.randn(8 + 4 * i, 16, generator=g) * (1 + i) for i in range(4)}
+    scores["layer1"] = (scores["layer1"] * 2).round() / 2                     # ties
+    pr = RG.BLIPT5MagPruner(model=toy_models.ToyBlipT5(), data_loader=[])
+    for k_, t in scores.items():
+        out[f"get_mask/scores/{k_}"] = t.clone()
+    for k_, t in pr.get_mask({a: b.clone() for a, b in scores.items()}, 0.5, 0.6).items():
+        out[f"get_mask/capped/{k_}"] = t
+    for k_, t in pr.get_mask({a: b.clone() for a, b in scores.items()}, 0.3, 1.0).items():
+        out[f"get_mask/uncapped/{k_}"] = t
+    for k_, t in pr.get_layerwise_mask({a: b.clone() for a, b in scores.items()}, 0.45).items():
+        out[f"get_mask/layerwise/{k_}"] = t
+    golden_io.save("global", out)
+    print("global.npz:", len(out), "arrays")
+
+
 GROUPS = {"wanda": gen_wanda, "wanda_e2e": gen_wanda_e2e, "sparse_lora": gen_sparse_lora, "sparsegpt": gen_sparsegpt,
           "sparsegpt_e2e": gen_sparsegpt_e2e, "dsnot": gen_dsnot,
-          "dsnot_e2e": gen_dsnot_e2e, "ressa": gen_ressa, "ecoflap": gen_ecoflap}
+          "dsnot_e2e": gen_dsnot_e2e, "ressa": gen_ressa, "ecoflap": gen_ecoflap, "global": gen_global}
 
 if __name__ == "__main__":
     import_reference()

@@ -191,3 +191,44 @@ def install_dsnot(monkeypatch):
     monkeypatch.setattr(dsnot, "act_moments", dsnot_act_moments)
     monkeypatch.setattr(dsnot, "stats_update", dsnot_stats_update)
     monkeypatch.setattr(dsnot, "prune_linear", oracle_dsnot_prune_linear)
+
+
+# ---- global pruners: oracle stand-in for ops.score_select (CPU tensors) ---------------------------------
+def score_select(weights, mode, *, scopes, scope_ks, scores=None, prev_keeps=None, protect_ks=None, apply_weights=True, keeps=None):
+    from oracle import global_select as OG
+    n = len(scopes)
+    weights = list(weights) if weights is not None else [None] * n
+    scores = list(scores) if scores is not None else [None] * n
+    prev_keeps = list(prev_keeps) if prev_keeps is not None else [None] * n
+    protect_ks = list(protect_ks) if protect_ks is not None else [0] * n
+    sc = []
+    for w, s, pk, prot in zip(weights, scores, prev_keeps, protect_ks):
+        v = {"weight": lambda: OG.score_magnitude(w), "score": lambda: s.float().clone(),
+             "absw_score": lambda: OG.score_aobd(w, s)}[mode]()
+        if pk is not None:
+            v = v * pk.to(v.dtype)
+        if prot > 0:
+            thr = torch.sort(v.flatten(), descending=True)[0][prot - 1]
+            v = v.clone()
+            v[v >= thr] = torch.finfo(v.dtype).max
+        sc.append(v)
+    out = []
+    thr_of = {}
+    for sid, k in enumerate(scope_ks):
+        flat = torch.cat([v.flatten() for v, s_ in zip(sc, scopes) if s_ == sid])
+        assert 1 <= k <= flat.numel()
+        thr_of[sid] = OG.kth_smallest(flat, int(k))
+    for i, (v, sid) in enumerate(zip(sc, scopes)):
+        keep = v > thr_of[sid]
+        if keeps is not None:
+            keeps[i].copy_(keep)
+            keep = keeps[i]
+        if apply_weights and weights[i] is not None:
+            weights[i].mul_(keep.to(weights[i].dtype))
+        out.append(keep)
+    return out
+
+
+def install_global(monkeypatch):
+    from vlmc import ops
+    monkeypatch.setattr(ops, "score_select", score_select)

@@ -11,6 +11,9 @@ from lavis.compression.pruners.sparsegpt_pruner import (  # noqa: F401  (registr
 from lavis.compression.pruners.dsnot_pruner import (  # noqa: F401  (registration)
     BLIPT5LayerDSnoTPruner, T5LayerDSnoTPruner, VITLayerDSnoTPruner,
 )
+from lavis.compression.pruners.global_pruner import (  # noqa: F401  (registration)
+    BLIPT5AMeZoPruner, BLIPT5AOBDPruner, BLIPT5MagPruner, BLIPT5RandPruner,
+)
 
 __all__ = ["BasePruner"]
 

@@ -12,6 +12,7 @@ HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "
 VLMC_OK, VLMC_EINVAL, VLMC_EHIP, VLMC_EWORKSPACE, VLMC_ENOTPD = 0, -1, -2, -3, -4
 F32, F16, BF16 = 0, 1, 2
 SEL_ROW, SEL_MATRIX, SEL_NM = 0, 1, 2
+SCORE_W, SCORE_S, SCORE_ABSW_S = 0, 1, 2
 
 _c = ctypes
 _p, _i, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
@@ -30,6 +31,11 @@ class UpdateJob(_c.Structure):        # vlmc_update_job
 class SelectJob(_c.Structure):        # vlmc_select_job
     _fields_ = [("W", _p), ("out_features", _i64), ("in_features", _i64), ("ldw", _i64), ("sqrt_scaler", _p), ("k", _i64),
                 ("mask", _p), ("score_partials", _p), ("workspace", _p), ("workspace_bytes", _sz)]
+
+
+class ScoreJob(_c.Structure):         # vlmc_score_job
+    _fields_ = [("W", _p), ("S", _p), ("prev_keep", _p), ("keep", _p), ("numel", _i64), ("protect_k", _i64),
+                ("scope", _c.c_int32), ("dtype", _c.c_int32)]
 
 
 # name -> (restype, argtypes); must list every function include/vlmc.h declares
@@ -53,6 +59,8 @@ SIGNATURES = {
     "vlmc_dsnot_apply": (_i, [_p, _i, _i64, _i64, _i64, _p, _p, _p, _i, _i, _i, _p]),
     "vlmc_chol_block": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, _p, _i, _p]),
     "vlmc_sparsegpt_sweep": (_i, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i, _i, _p, _i64, _p, _i64, _p]),
+    "vlmc_score_select_workspace": (_sz, [_i, _i]),
+    "vlmc_score_select": (_i, [_p, _i, _p, _i, _i, _i, _p, _sz, _p]),
     "vlmc_wanda_select": (_i, [_p, _i, _i64, _i64, _i64, _p, _i, _i64, _i, _i, _i, _p, _p, _p, _sz, _p]),
 }
 

@@ -6,6 +6,8 @@ pruner loop does with PyTorch ops (file:line under /root/reference cited per op)
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -235,6 +237,51 @@ def wanda_select_batch(weights, sqrt_rows, mode: str, *, ks=None, n: int = 0, m:
 # launches per step (bench.py, the per-block pruner loop).  A plan is a zero-argument
 # callable; tensors referenced by a plan must stay alive and must not be reallocated.
 # ---------------------------------------------------------------------------------------
+_c_int64 = ctypes.c_int64
+_SCORE_MODES = {"weight": _lib.SCORE_W, "score": _lib.SCORE_S, "absw_score": _lib.SCORE_ABSW_S}
+_score_ws = Workspace()
+
+
+def score_select(weights, mode: str, *, scopes, scope_ks, scores=None, prev_keeps=None, protect_ks=None, apply_weights: bool = True,
+                 keeps=None):
+    """One threshold per SCOPE over many tensors (global_pruner.py:107-148, :166-169, :188-190).
+
+    `weights[i]`: contiguous parameter tensor (any of fp32/fp16/bf16, may differ per tensor; None allowed in
+    mode "score"); `scores[i]`: fp32 tensor of the same numel (modes "score", "absw_score"); `scopes[i]`: scope id;
+    `scope_ks[s]`: rank of the threshold (the k-th smallest score of the scope, 1-based); keep = score > threshold;
+    `protect_ks[i]`: the protect_k largest scores of tensor i count as FLT_MAX; `prev_keeps[i]`: bool mask multiplied
+    into the scores.  Multiplies the weights by the masks in place when `apply_weights`.  Returns the keep masks."""
+    n = len(scopes)
+    weights = list(weights) if weights is not None else [None] * n
+    scores = list(scores) if scores is not None else [None] * n
+    prev_keeps = list(prev_keeps) if prev_keeps is not None else [None] * n
+    protect_ks = list(protect_ks) if protect_ks is not None else [0] * n
+    code = _SCORE_MODES[mode]
+    first = next(t for t in list(weights) + list(scores) if t is not None)
+    if keeps is None:
+        keeps = [torch.empty((weights[i] if weights[i] is not None else scores[i]).shape, dtype=torch.bool, device=first.device)
+                 for i in range(n)]
+    jobs = (_lib.ScoreJob * n)()
+    for i in range(n):
+        w, s, pk, kp = weights[i], scores[i], prev_keeps[i], keeps[i]
+        _need_gpu(w, s, pk, kp)
+        numel = kp.numel()
+        for t, dt in ((w, None), (s, torch.float32), (pk, torch.bool), (kp, torch.bool)):
+            if t is None:
+                continue
+            if not t.is_contiguous() or t.numel() != numel or (dt is not None and t.dtype != dt):
+                raise ValueError("score_select: operands of a job must be contiguous, of the same numel, scores fp32, masks bool")
+        jobs[i] = _lib.ScoreJob(w.data_ptr() if w is not None else None, s.data_ptr() if s is not None else None,
+                                pk.data_ptr() if pk is not None else None, kp.data_ptr(), numel, int(protect_ks[i]), int(scopes[i]),
+                                _dtype_code(w) if w is not None else _lib.F32)
+    ks = (_c_int64 * len(scope_ks))(*[int(k) for k in scope_ks])
+    lib = _lib.load()
+    nbytes = lib.vlmc_score_select_workspace(n, len(scope_ks))
+    ws = _score_ws.get(nbytes, first.device)
+    _lib.check(lib.vlmc_score_select(jobs, n, ks, len(scope_ks), code, int(bool(apply_weights)), ws.data_ptr(), ws.numel(), _stream()))
+    return keeps
+
+
 def _bind(fn, args):
     check = _lib.check
 
