@@ -161,3 +161,44 @@ def test_batched_replay_on_gpu_tracks_reference_run(method, monkeypatch):
         pruned, _ = H.run_dsnot_pruner("fp32_r50", "cuda:0")
         st = H.compare_with_golden("fp32_r50", pruned, exact=False, min_mask_agreement=0.99, which="dsnot_e2e")
     print(method, st)
+
+
+@pytest.mark.parametrize("method", ["wanda", "wanda_lora_mixed", "dsnot", "sparsegpt"])
+def test_graph_captured_replay_is_bit_identical_to_the_eager_loop(method, monkeypatch):
+    """The block forwards of the calibration replay run from HIP graphs by default (same kernels, static buffers,
+    statistics hooks fired on the captured tensors after each replay): every weight and mask equals the eager loop's."""
+    from lavis.compression.pruners import calibration as cal
+
+    def run():
+        if method == "wanda":
+            return H.run_pruner("fp32_r50", "cuda:0")[0]
+        if method == "wanda_lora_mixed":
+            return H.run_pruner("fp32_r40_lora", "cuda:0")[0], H.run_pruner("mixed_2_4", "cuda:0")[0]
+        if method == "dsnot":
+            return H.run_dsnot_pruner("fp32_r50", "cuda:0")[0]
+        import test_pruner_host_logic as T
+        return T._run_sparsegpt_pruner("fp32_u50", "cuda:0")[0]
+
+    def states(res):
+        models = res if isinstance(res, tuple) else (res,)
+        out = []
+        for m in models:
+            sd = dict(m.state_dict())
+            for n, mod in m.named_modules():
+                if hasattr(mod, "mask") and torch.is_tensor(mod.mask):
+                    sd[n + ".mask*"] = mod.mask
+            out.append(sd)
+        return out
+
+    monkeypatch.setenv("VLMC_GRAPH_REPLAY", "0")
+    before = dict(cal.graph_stats)
+    eager = states(run())
+    assert cal.graph_stats == before                                     # nothing captured when switched off
+    monkeypatch.setenv("VLMC_GRAPH_REPLAY", "1")
+    graphed = states(run())
+    assert cal.graph_stats["captured"] > before["captured"] and cal.graph_stats["replayed"] > before["replayed"]
+    assert cal.graph_stats["fallbacks"] == before["fallbacks"]
+    for a, b in zip(eager, graphed):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert torch.equal(a[k], b[k]), k

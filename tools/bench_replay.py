@@ -27,7 +27,7 @@ class Tower(nn.Module):
         return contextlib.nullcontext()
 
 
-def run(kind, group, n=128):
+def run(kind, group, n=128, graph=False):
     torch.manual_seed(0)
     if kind == "vit":
         block = toy_models.ToyViTBlock(1408, 6144, heads=16).to(torch.float16)
@@ -43,6 +43,7 @@ def run(kind, group, n=128):
         mode, tuple_out = "row", True
     model = Tower(block.to(dev).eval(), kind == "vit")
     os.environ["VLMC_BATCH_REPLAY"] = str(group)
+    os.environ["VLMC_GRAPH_REPLAY"] = "1" if graph else "0"
     helper = object.__new__(VITLayerWandaPruner if kind == "vit" else T5LayerWandaPruner)
     helper.prune_n = helper.prune_m = 0
 
@@ -64,11 +65,13 @@ def run(kind, group, n=128):
     return dt * 1e3
 
 
-print("| block | samples per forward | ms per block pass (2 x 128 forwards + statistics + select) | speed-up |")
+print("| block | replay | ms per block pass (2 x 128 forwards + statistics + select) | speed-up |")
 print("|---|---|---|---|")
 for kind, label in (("t5", "T5 encoder block 2048/5120, 64 tokens, bf16"), ("vit", "ViT-g block 1408/6144, 257 tokens, fp16")):
-    base = None
-    for g in (1, 8, 32, 128):
+    base = run(kind, 1)
+    print(f"| {label} | per sample, eager (the reference's loop) | {base:.1f} | 1.0x |", flush=True)
+    ms = run(kind, 1, graph=True)
+    print(f"| {label} | per sample, HIP graph (default; bit-identical) | {ms:.1f} | {base / ms:.1f}x |", flush=True)
+    for g in (8, 32, 128):
         ms = run(kind, g)
-        base = base or ms
-        print(f"| {label} | {g} | {ms:.1f} | {base / ms:.1f}x |", flush=True)
+        print(f"| {label} | {g} samples per forward (VLMC_BATCH_REPLAY) | {ms:.1f} | {base / ms:.1f}x |", flush=True)

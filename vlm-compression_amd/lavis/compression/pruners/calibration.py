@@ -177,6 +177,68 @@ def _stack_caches(group):
     return out
 
 
+def graph_replay_enabled():
+    """Graph-captured replay (default on for GPU tensors, `VLMC_GRAPH_REPLAY=0` turns it off)."""
+    return os.environ.get("VLMC_GRAPH_REPLAY", "1") != "0"
+
+
+GRAPH_MIN_SAMPLES = 4         # a capture costs about three eager forwards
+graph_stats = {"captured": 0, "replayed": 0, "fallbacks": 0}
+
+
+class BlockGraph:
+    """One block forward captured in a HIP graph and replayed for every calibration sample of the same shape.
+
+    A batch-1 forward of a T5 / ViT block is ~30 small kernels whose launch and Python dispatch cost dwarfs their
+    GPU time; the 2 x 128 x 87 of them are what a prune spends its time on once the statistics and select kernels
+    take milliseconds.  The graph replays the very same kernels on static buffers, so activations -- and with them
+    statistics and masks -- are bit-identical to the eager loop.
+
+    The statistics hooks on the block's linears cannot run inside a graph.  During capture they are replaced by
+    recorders that keep every linear's input / output tensor alive (so the graph's memory pool never recycles
+    them); after each replay the real hooks are called on those static tensors, exactly as a forward would."""
+
+    def __init__(self, layer, x, cache, subset, autocast, tuple_output):
+        from collections import OrderedDict
+        self.x = x.clone()
+        self.cache = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in cache.items()}
+        self.records = []
+        modules = list(subset.values())
+        saved = [m._forward_hooks for m in modules]
+
+        def recorder(mod, inp, out):
+            self.records.append((mod, inp[0], out))
+        try:
+            for m in modules:
+                m._forward_hooks = OrderedDict({0: recorder})
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side), torch.no_grad(), autocast():
+                layer(self.x, **self.cache)                   # warm-up: lazy initialisation must not land in the capture
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            self.records.clear()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph), torch.no_grad(), autocast():
+                y = layer(self.x, **self.cache)
+                self.y = y[0] if tuple_output else y
+        finally:
+            for m, h in zip(modules, saved):
+                m._forward_hooks = h
+        graph_stats["captured"] += 1
+
+    def run(self, x, cache):
+        self.x.copy_(x)
+        for k, v in cache.items():
+            if isinstance(v, torch.Tensor):
+                self.cache[k].copy_(v)
+        self.graph.replay()
+        for mod, xin, out in self.records:
+            for hook in list(mod._forward_hooks.values()):
+                hook(mod, (xin,), out)
+        graph_stats["replayed"] += 1
+        return self.y.clone()
+
+
 def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocast, prune_block, tuple_output):
     """The block loop of `_prune`: for every block, `prune_block(i, layer, subset, run)`
     is called with `run()` = one pass of the block over all samples (filling `outs`);
@@ -198,14 +260,39 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
     def run_pass(before_sample=None):
         global _STACKED
         cur_in, cur_out = state["inps"], state["outs"]
+        graphs, keys = {}, None
+        if group_max == 1 and graph_replay_enabled() and n_samples and cur_in[0].is_cuda:
+            keys = [_stack_key(cur_in[t], caches[t]) for t in range(n_samples)]
+            counts = {}
+            for k in keys:
+                counts[k] = counts.get(k, 0) + 1
         j = 0
         while j < n_samples:
+            if keys is not None and counts[keys[j]] >= GRAPH_MIN_SAMPLES and graphs.get(keys[j]) is not False:
+                if before_sample is not None:
+                    before_sample(j)
+                bg = graphs.get(keys[j])
+                if bg is None:
+                    try:
+                        bg = graphs[keys[j]] = BlockGraph(layer, cur_in[j], caches[j], subset, autocast, tuple_output)
+                    except Exception as e:          # block not capturable (host sync, data-dependent shapes): eager loop
+                        graphs[keys[j]] = False
+                        graph_stats["fallbacks"] += 1
+                        print(f"graph replay disabled for this block ({type(e).__name__}: {e})")
+                        bg = None
+                if bg is not None:
+                    cur_out[j] = bg.run(cur_in[j], caches[j])
+                    j += 1
+                    continue
+                before_sample_done = True
+            else:
+                before_sample_done = False
             g = 1
             if group_max > 1:
                 key = _stack_key(cur_in[j], caches[j])
                 while j + g < n_samples and g < group_max and _stack_key(cur_in[j + g], caches[j + g]) == key:
                     g += 1
-            if before_sample is not None:
+            if before_sample is not None and not before_sample_done:
                 before_sample(j)
             with torch.no_grad():
                 with autocast():
@@ -228,6 +315,6 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
         layer = layers[i]
         subset = find_layers(layer)
         prune_block(i, layer, subset, run_pass, state)
-        run_pass()
+        run_pass()                 # (graphs are per pass: the pruning in between may have replaced weight storage)
         state["inps"], state["outs"] = state["outs"], state["inps"]
     return model
