@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline leg (0 = skip)")
+    ap.add_argument("--e2e", default="auto", choices=["auto", "0", "1"],
+                    help="also time one whole drop-in blipt5_wanda_pruner.prune() on the synthetic InstructBLIP-FlanT5-XL "
+                         "(auto: only at N=1)")
     ap.add_argument("--weight-sets", type=int, default=0, help="dense weight copies kept in HBM (0 = steps+warmup, capped by memory)")
     return ap.parse_args()
 
@@ -200,6 +203,38 @@ def cpu_baseline(blocks, budget_s):
                       f"synthetic data generation included, {dt:.1f} s"}
 
 
+def end_to_end(dev, world):
+    """Whole-prune wall-clock through the drop-in pruner API (capture of the towers' inputs by the model's own forward,
+    block replay, statistics, score/select/apply of all 588 linears) on a random-init model of the true shapes.
+    Reported beside the timed hot path, never part of `value`."""
+    from vlmc import synthetic
+    out = {"model": "synthetic InstructBLIP-FlanT5-XL shapes (39 ViT-g fp16 + 24/24 Flan-T5-XL bf16 blocks, Q-Former replaced "
+                    "by its 32 query tokens), random init", "pruner": "blipt5_wanda_pruner", "calib_samples": N_CALIB,
+           "calib_sharded_over": world}
+    model = None
+    for key, env in (("seconds", {}), ("seconds_batched32", {"VLMC_BATCH_REPLAY": "32"})):
+        saved = {k: os.environ.get(k) for k in ("VLMC_BATCH_REPLAY", "VLMC_GRAPH_REPLAY")}
+        os.environ.update(env)
+        try:
+            dt, model, info = synthetic.time_prune(dev, "blipt5_wanda_pruner", n_samples=N_CALIB, ratio=RATIO, model=model)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        out[key] = round(dt, 3)
+        out["layers_per_s" + key[len("seconds"):]] = round(info["linears"] / dt, 1)
+        out["pruned_fraction"] = round(info["pruned_fraction"], 6)
+    out["replay"] = {"seconds": "per-sample block forwards from HIP graphs (bit-identical to the reference's loop)",
+                     "seconds_batched32": "VLMC_BATCH_REPLAY=32 (32 samples per block forward; masks agree up to near-ties)"}
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -279,6 +314,16 @@ def main():
     roofline["other"] = [roof("rows", "vlmc::select_rows_kernel (score+select+apply, per-row rule; one launch per distinct "
                                       "in_features of a T5 block)", "select_rows_kernel_bytes_per_launch")]
 
+    e2e, n_sets = None, len(sets)
+    if args.e2e == "1" or (args.e2e == "auto" and world == 1):
+        n_sets = len(sets)
+        del plans, sets, acts, state
+        torch.cuda.empty_cache()
+        try:
+            e2e = end_to_end(dev, world)
+        except Exception as e:                    # never lose the bench line to the side measurement
+            e2e = {"error": f"{type(e).__name__}: {e}"}
+
     out = None
     if rank == 0:
         out = {
@@ -290,9 +335,10 @@ def main():
                                    "(39 ViT-g blocks fp16 matrix-wide rule + 24/24 T5 blocks bf16 per-row rule), "
                                    "128 calib samples, tokens 257/64/16; statistics + score/select/apply of every linear",
                        "linears": n_lin, "blocks": len(blocks), "calib_samples": N_CALIB, "ratio": RATIO,
-                       "weight_sets": len(sets), "total_prune_wall_clock_s": round(elapsed / args.steps, 5),
+                       "weight_sets": n_sets, "total_prune_wall_clock_s": round(elapsed / args.steps, 5),
                        "parallelism": f"calib-dp{world}"},
             "roofline": roofline,
+            "end_to_end": e2e,
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(blocks, args.cpu_seconds)

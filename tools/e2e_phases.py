@@ -1,0 +1,47 @@
+"""Phase breakdown of one end-to-end Wanda prune of the synthetic InstructBLIP-FlanT5-XL (host timers with syncs)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vlm-compression_amd"))
+import torch
+from vlmc import synthetic
+from lavis.compression.pruners import calibration as cal
+
+dev = torch.device("cuda:0")
+T = {}
+
+
+def timed(name, fn):
+    def w(*a, **k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn(*a, **k)
+        torch.cuda.synchronize()
+        T[name] = T.get(name, 0.0) + time.perf_counter() - t0
+        return r
+    return w
+
+
+cal.capture_block_inputs = timed("capture (model forward up to the tower)", cal.capture_block_inputs)
+orig_walk = cal.walk_blocks
+
+
+def walk(model, inps, outs, caches, mtp, n, autocast, prune_block, tuple_output):
+    def pb(i, layer, subset, run_pass, state):
+        def rp(before_sample=None):
+            return timed("replay pass with hooks" if before_sample is not None else "replay pass plain", run_pass)(before_sample)
+        return timed("prune_block total (incl. hooked pass)", prune_block)(i, layer, subset, rp, state)
+    return orig_walk(model, inps, outs, caches, mtp, n, autocast, pb, tuple_output)
+
+
+cal.walk_blocks = timed("walk_blocks total", walk)
+import lavis.compression.pruners.wanda_pruner as wp
+wp.cal = cal
+for mode, env in (("graph", {}), ("eager", {"VLMC_GRAPH_REPLAY": "0"})):
+    os.environ.pop("VLMC_GRAPH_REPLAY", None)
+    os.environ.update(env)
+    T.clear()
+    dt, model, info = synthetic.time_prune(dev)
+    print(mode, f"total {dt:.2f} s")
+    for k, v in T.items():
+        print(f"   {k:45s} {v:7.2f} s")
+    del model

@@ -1,0 +1,231 @@
+"""Random-init model with the architecture and shapes of InstructBLIP-FlanT5-XL, for end-to-end timing of the
+drop-in pruners when no checkpoint can be downloaded (bench.py `end_to_end`, tools/).
+
+What the pruners need from the reference's model classes is kept: the module names
+(`visual_encoder.blocks[i].{attn.qkv, attn.proj, mlp.fc1, mlp.fc2}`, `t5_model.{encoder,decoder}.block[i].layer[..]`
+`.{SelfAttention,EncDecAttention}.{q,k,v,o}`, `.DenseReluDense.{wi_0,wi_1,wo}`), the block call contracts
+(eva_vit.Block: `blk(x, rel_pos_bias, dense=)`; T5Block: `blk(hidden, attention_mask=..., ..., dense=) -> (hidden,)`),
+`maybe_autocast`, `t5_model.config.use_cache` and `model(samples)["loss"]` (blip2_t5_instruct.py:136-221).
+Shapes: SURVEY.md Appendix A (ViT-g 39 x 1408/6144, 16 heads, 257 tokens, fp16; Flan-T5-XL 24 + 24 x 2048/5120,
+32 heads of 64, bf16).  The Q-Former (never pruned) is replaced by its output shape: 32 query tokens projected to the
+language model's width.
+"""
+from __future__ import annotations
+
+import contextlib
+import types
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _lin(mod, x, dense):
+    return mod(x) if type(mod) is nn.Linear else mod(x, dense=dense)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, heads, d_kv, fused_qkv):
+        super().__init__()
+        self.heads, self.d_kv, self.fused = heads, d_kv, fused_qkv
+        inner = heads * d_kv
+        if fused_qkv:
+            self.qkv = nn.Linear(dim, 3 * inner, bias=False)
+            self.proj = nn.Linear(inner, dim)
+        else:
+            self.q = nn.Linear(dim, inner, bias=False)
+            self.k = nn.Linear(dim, inner, bias=False)
+            self.v = nn.Linear(dim, inner, bias=False)
+            self.o = nn.Linear(inner, dim, bias=False)
+
+    def forward(self, x, kv=None, dense=False):
+        B, T, _ = x.shape
+        if self.fused:
+            q, k, v = _lin(self.qkv, x, dense).reshape(B, T, 3, -1).unbind(2)
+        else:
+            src = x if kv is None else kv
+            q, k, v = _lin(self.q, x, dense), _lin(self.k, src, dense), _lin(self.v, src, dense)
+        S = k.shape[1]
+        q = q.reshape(B, T, self.heads, self.d_kv).transpose(1, 2)
+        k = k.reshape(B, S, self.heads, self.d_kv).transpose(1, 2)
+        v = v.reshape(B, S, self.heads, self.d_kv).transpose(1, 2)
+        y = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, T, -1)
+        return _lin(self.proj if self.fused else self.o, y, dense)
+
+
+class ViTBlock(nn.Module):
+    def __init__(self, dim, hidden, heads):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = Attention(dim, heads, dim // heads, fused_qkv=True)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = nn.Module()
+        self.mlp.fc1 = nn.Linear(dim, hidden)
+        self.mlp.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x, rel_pos_bias=None, dense=False):
+        x = x + self.attn(self.norm1(x), dense=dense)
+        return x + _lin(self.mlp.fc2, F.gelu(_lin(self.mlp.fc1, self.norm2(x), dense)), dense)
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+
+    def forward(self, x):
+        v = x.float().pow(2).mean(-1, keepdim=True)
+        return (x.float() * torch.rsqrt(v + 1e-6)).to(x.dtype) * self.weight
+
+
+class _T5Sub(nn.Module):
+    pass
+
+
+class T5Block(nn.Module):
+    """`layer[0].SelfAttention`, (`layer[1].EncDecAttention`,) `layer[-1].DenseReluDense` with T5 v1.1's gated GELU."""
+
+    def __init__(self, dim, d_ff, heads, d_kv, is_decoder):
+        super().__init__()
+        self.is_decoder = is_decoder
+        subs = []
+        sa = _T5Sub()
+        sa.layer_norm = RMSNorm(dim)
+        sa.SelfAttention = Attention(dim, heads, d_kv, fused_qkv=False)
+        subs.append(sa)
+        if is_decoder:
+            ca = _T5Sub()
+            ca.layer_norm = RMSNorm(dim)
+            ca.EncDecAttention = Attention(dim, heads, d_kv, fused_qkv=False)
+            subs.append(ca)
+        ff = _T5Sub()
+        ff.layer_norm = RMSNorm(dim)
+        ff.DenseReluDense = nn.Module()
+        ff.DenseReluDense.wi_0 = nn.Linear(dim, d_ff, bias=False)
+        ff.DenseReluDense.wi_1 = nn.Linear(dim, d_ff, bias=False)
+        ff.DenseReluDense.wo = nn.Linear(d_ff, dim, bias=False)
+        subs.append(ff)
+        self.layer = nn.ModuleList(subs)
+
+    def forward(self, hidden_states, attention_mask=None, position_bias=None, encoder_hidden_states=None,
+                encoder_attention_mask=None, encoder_decoder_position_bias=None, layer_head_mask=None,
+                cross_attn_layer_head_mask=None, dense=False, **unused):
+        x = hidden_states
+        sa = self.layer[0]
+        x = x + sa.SelfAttention(sa.layer_norm(x), dense=dense)
+        if self.is_decoder:
+            ca = self.layer[1]
+            x = x + ca.EncDecAttention(ca.layer_norm(x), kv=encoder_hidden_states, dense=dense)
+        ff = self.layer[-1]
+        h = ff.layer_norm(x)
+        d = ff.DenseReluDense
+        x = x + _lin(d.wo, F.gelu(_lin(d.wi_0, h, dense)) * _lin(d.wi_1, h, dense), dense)
+        return (x,)
+
+
+class InstructBlipT5(nn.Module):
+    def __init__(self, vit_dim=1408, vit_hidden=6144, vit_heads=16, vit_depth=39, d_model=2048, d_ff=5120, heads=32, d_kv=64,
+                 enc_depth=24, dec_depth=24, vocab=32128, query_tokens=32, vit_dtype=torch.float16, t5_dtype=torch.bfloat16):
+        super().__init__()
+        self.visual_encoder = nn.Module()
+        self.visual_encoder.blocks = nn.ModuleList([ViTBlock(vit_dim, vit_hidden, vit_heads) for _ in range(vit_depth)])
+        self.visual_encoder.to(vit_dtype)
+        self.t5_proj = nn.Linear(vit_dim, d_model).to(t5_dtype)
+        t5 = nn.Module()
+        t5.config = types.SimpleNamespace(use_cache=True, d_model=d_model)
+        t5.shared = nn.Embedding(vocab, d_model)
+        t5.encoder = nn.Module()
+        t5.encoder.block = nn.ModuleList([T5Block(d_model, d_ff, heads, d_kv, False) for _ in range(enc_depth)])
+        t5.decoder = nn.Module()
+        t5.decoder.block = nn.ModuleList([T5Block(d_model, d_ff, heads, d_kv, True) for _ in range(dec_depth)])
+        self.t5_model = t5.to(t5_dtype)
+        self.query_tokens, self.vit_dtype, self.t5_dtype = query_tokens, vit_dtype, t5_dtype
+
+    def maybe_autocast(self, dtype=None):
+        return contextlib.nullcontext()
+
+    def encode_image(self, image):
+        x = image.to(self.vit_dtype)
+        for blk in self.visual_encoder.blocks:
+            x = blk(x, None)
+        return x
+
+    def forward(self, samples, vit_dense=False, llm_dense=False):
+        x = samples["image"].to(self.vit_dtype)
+        for blk in self.visual_encoder.blocks:
+            x = blk(x, None, dense=vit_dense)
+        t5 = self.t5_model
+        img = self.t5_proj(x[:, :self.query_tokens].to(self.t5_dtype))          # stands in for the Q-Former's 32 queries
+        h = torch.cat([img, t5.shared(samples["text_input"])], dim=1)
+        kw = dict(attention_mask=None, position_bias=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                  encoder_decoder_position_bias=None, layer_head_mask=None, cross_attn_layer_head_mask=None)
+        for blk in t5.encoder.block:
+            h = blk(h, dense=llm_dense, **kw)[0]
+        d = t5.shared(samples["text_output"])
+        kw["encoder_hidden_states"] = h
+        for blk in t5.decoder.block:
+            d = blk(d, dense=llm_dense, **kw)[0]
+        logits = d @ t5.shared.weight.t()
+        return {"loss": logits.float().logsumexp(-1).mean(), "logits": logits}
+
+
+def randomize_(model, seed=0, std=0.02):
+    """Seeded in-place N(0, std) weights (every rank builds the same model)."""
+    g = torch.Generator(device=next(model.parameters()).device).manual_seed(seed)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=g, device=p.device, dtype=torch.float32) * std)
+    return model
+
+
+def calibration_batches(n, device, vit_tokens=257, vit_dim=1408, text_len=32, out_len=16, vocab=32128, seed=1):
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = []
+    for _ in range(n):
+        out.append({"image": (torch.randn(1, vit_tokens, vit_dim, generator=g, device=device) * 0.5).half(),
+                    "text_input": torch.randint(0, vocab, (1, text_len), generator=g, device=device),
+                    "text_output": torch.randint(0, vocab, (1, out_len), generator=g, device=device)})
+    return out
+
+
+def prunable_linears(model):
+    n = 0
+    for name, mod in model.named_modules():
+        if isinstance(mod, nn.Linear) and (".blocks." in name or ".block." in name):
+            n += 1
+    return n
+
+
+def time_prune(device, pruner_name="blipt5_wanda_pruner", n_samples=128, ratio=0.5, model=None, seed=0, quiet=True, batches=None,
+               **cfg):
+    """Wall-clock of one whole `load_pruner(...).prune()` on the synthetic InstructBLIP-FlanT5-XL (capture of the three
+    towers' inputs, block replay, statistics, score/select/apply of all 588 linears).  Returns (seconds, model, info)."""
+    import contextlib
+    import io
+    import time
+
+    from lavis.compression import load_pruner
+    if model is None:
+        model = InstructBlipT5().to(device).eval()
+    randomize_(model, seed)
+    if batches is None:
+        batches = calibration_batches(n_samples, device)
+    keep = 1 - ratio
+    method = pruner_name.split("_")[1]
+    full = dict(t5_prune_spec=f"24-{keep!r}-1.0-1.0", vit_prune_spec=f"39-{keep!r}-1.0-1.0", t5_pruning_method=method,
+                vit_pruning_method=method, num_samples=n_samples, max_sparsity_per_layer=1.01)
+    full.update(cfg)
+    pruner = load_pruner(pruner_name, model, batches, cfg=full)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    with (contextlib.redirect_stdout(io.StringIO()) if quiet else contextlib.nullcontext()):
+        pruner.prune()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    zeros = total = 0
+    for name, mod in model.named_modules():
+        if isinstance(mod, nn.Linear) and (".blocks." in name or ".block." in name):
+            zeros += int((mod.weight == 0).sum())
+            total += mod.weight.numel()
+    return dt, model, {"linears": prunable_linears(model), "pruned_fraction": zeros / max(1, total), "weights": total}
