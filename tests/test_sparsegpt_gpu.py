@@ -132,3 +132,41 @@ def test_blocked_cholesky_reports_the_failing_column_like_lapack():
     Hn[5, 5] = float("nan")
     _, info = sparsegpt.blocked_cholesky(Hn.to("cuda:0"))
     assert int(info.item()) == 6
+
+
+@pytest.mark.parametrize("n", [64, 128, 200, 1408, 2048])
+def test_direct_inverse_factor_equals_the_reference_chain(n):
+    """U with U^T U = H^-1 from one factorization of the index-reversed Hessian vs the reference's
+    cholesky -> cholesky_inverse -> cholesky(upper) in fp64."""
+    from vlmc import sparsegpt
+    g = torch.Generator().manual_seed(n)
+    X = torch.randn(max(4 * n, 256), n, generator=g) + 0.2
+    H = (2 * X.t() @ X / X.shape[0]).to("cuda:0")
+    U, info = sparsegpt.inverse_upper_factor(H.clone())
+    assert int(info.item()) == 0
+    Hd = H.double()
+    ref = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(Hd)), upper=True)
+    assert float(torch.tril(U, -1).abs().max()) == 0.0 if n > 1 else True
+    assert float((U.double() - ref).abs().max() / ref.abs().max()) < 5e-4
+    eye = U.double().t() @ U.double() @ Hd
+    assert float((eye - torch.eye(n, dtype=torch.float64, device="cuda:0")).abs().max()) < 5e-3
+    # a second call reuses the captured graph and static buffers
+    U2, _ = sparsegpt.inverse_upper_factor(H.clone())
+    assert torch.equal(U, U2)
+
+
+def test_direct_inverse_factor_flags_a_non_pd_hessian_and_the_damping_loop_recovers():
+    from vlmc import sparsegpt
+    n = 256
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn(3, n, generator=g)
+    H = (X.t() @ X).to("cuda:0")                                # rank 3
+    _, info = sparsegpt.inverse_upper_factor(H.clone())
+    assert int(info.item()) != 0
+    U, dead = sparsegpt.factorize(H.clone())                   # falls back to the reference's chain and its damping loops
+    assert not bool(torch.isnan(U).any()) and not bool(dead.any())
+    Hd = H.clone()
+    ref_L = sparsegpt._chol_with_damping(Hd, 0.01 * torch.mean(torch.diag(Hd)), upper=False)
+    Hi = torch.cholesky_inverse(ref_L)
+    ref_U = sparsegpt._chol_with_damping(Hi, 0.01 * torch.mean(torch.diag(Hi).abs()), upper=True)
+    assert torch.equal(U, ref_U.contiguous())

@@ -356,6 +356,23 @@ __global__ __launch_bounds__(kThreads) void score_apply_kernel(const DevJob *__r
         });
 }
 
+// Small job tables travel as a kernel argument (no host-to-device copy, no wait): SparseGPT's per-block thresholds
+// and other few-tensor calls stay fully asynchronous.
+constexpr int kInlineJobs = 4;
+struct InlineTable {
+    DevJob jobs[kInlineJobs];
+    SelState scope_st[kInlineJobs];
+    SelState prot_st[kInlineJobs];
+};
+__global__ void score_table_kernel(InlineTable t, int n_jobs, int n_scopes, DevJob *jobs, SelState *scope_st, SelState *prot_st) {
+    const int i = threadIdx.x;
+    if (i < n_jobs) {
+        jobs[i] = t.jobs[i];
+        prot_st[i] = t.prot_st[i];
+    }
+    if (i < n_scopes) scope_st[i] = t.scope_st[i];
+}
+
 struct Layout {
     size_t jobs, scope_st, prot_st, hist, total;
 };
@@ -453,14 +470,25 @@ extern "C" int vlmc_score_select(const vlmc_score_job *jobs, int n_jobs, const i
     }
     hipStream_t st = as_stream(stream);
     char *ws = static_cast<char *>(workspace);
-    // the one place the library waits: the table lives in pageable host memory that is freed on return
-    if (hipMemcpyAsync(ws, blob.data(), l.hist, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
-        hipMemsetAsync(ws + l.hist, 0, l.total - l.hist, st) != hipSuccess) {
+    DevJob *ddj = reinterpret_cast<DevJob *>(ws + l.jobs);
+    SelState *dss = reinterpret_cast<SelState *>(ws + l.scope_st), *dps = reinterpret_cast<SelState *>(ws + l.prot_st);
+    if (n_jobs <= kInlineJobs) {
+        InlineTable t{};
+        for (int i = 0; i < n_jobs; ++i) {
+            t.jobs[i] = dj[i];
+            t.prot_st[i] = pst[i];
+        }
+        for (int i = 0; i < n_scopes; ++i) t.scope_st[i] = sst[i];
+        hipLaunchKernelGGL(score_table_kernel, dim3(1), dim3(64), 0, st, t, n_jobs, n_scopes, ddj, dss, dps);
+    } else if (hipMemcpyAsync(ws, blob.data(), l.hist, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        // the one place the library waits: the table lives in pageable host memory that is freed on return
         set_error("vlmc_score_select: uploading the job table failed: %s", hipGetErrorString(hipGetLastError()));
         return VLMC_EHIP;
     }
-    const DevJob *ddj = reinterpret_cast<const DevJob *>(ws + l.jobs);
-    SelState *dss = reinterpret_cast<SelState *>(ws + l.scope_st), *dps = reinterpret_cast<SelState *>(ws + l.prot_st);
+    if (hipMemsetAsync(ws + l.hist, 0, l.total - l.hist, st) != hipSuccess) {
+        set_error("vlmc_score_select: clearing the histograms failed: %s", hipGetErrorString(hipGetLastError()));
+        return VLMC_EHIP;
+    }
     uint32_t *hist = reinterpret_cast<uint32_t *>(ws + l.hist);
     switch (score_mode) {
         case VLMC_SCORE_W: return run<0>(ddj, n_jobs, n_scopes, chunks, dss, dps, hist, any_protect, apply_weights, st);

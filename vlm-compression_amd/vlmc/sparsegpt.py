@@ -23,6 +23,7 @@ import math
 import torch
 
 from . import _lib
+from . import ops
 from .ops import _need_gpu, _stream
 
 
@@ -69,18 +70,20 @@ _CHOL_GRAPH = __import__("os").environ.get("VLMC_CHOL_GRAPH", "1") == "1"
 
 
 def _chol_steps(A, L, inv, info):
-    """The right-looking sweep over 128-column blocks on row-major fp32 buffers (A is consumed)."""
+    """The right-looking sweep over 128-column blocks on row-major fp32 buffers (A is consumed).
+    `inv`: [128, 128] scratch, or [blocks, 128, 128] to keep the inverse of every diagonal block."""
     n = A.shape[0]
     lib = _lib.load()
     el = A.element_size()
     for k in range(0, n, _CHOL_NB):
         nb = min(_CHOL_NB, n - k)
         off = (k * n + k) * el
-        _lib.check(lib.vlmc_chol_block(A.data_ptr() + off, n, nb, L.data_ptr() + off, n, inv.data_ptr(), _CHOL_NB,
+        inv_k = inv[k // _CHOL_NB] if inv.dim() == 3 else inv
+        _lib.check(lib.vlmc_chol_block(A.data_ptr() + off, n, nb, L.data_ptr() + off, n, inv_k.data_ptr(), _CHOL_NB,
                                        info.data_ptr(), k, _stream()))
         if k + nb < n:
             if _CHOL_PANEL_GEMM:
-                L21 = A[k + nb:, k:k + nb] @ inv[:nb, :nb].t()              # = A21 inv(L11)^T
+                L21 = A[k + nb:, k:k + nb] @ inv_k[:nb, :nb].t()            # = A21 inv(L11)^T
             else:
                 L21 = torch.linalg.solve_triangular(L[k:k + nb, k:k + nb], A[k + nb:, k:k + nb].t(), upper=False).t()
             L[k + nb:, k:k + nb] = L21
@@ -133,6 +136,70 @@ def blocked_cholesky(H: torch.Tensor, upper=False):
     return (L.t().contiguous() if upper else L), info
 
 
+_SELECT_THRESHOLD = __import__("os").environ.get("VLMC_SGPT_SORT_THRESHOLD", "0") != "1"
+_DIRECT_FACTOR = __import__("os").environ.get("VLMC_SGPT_DIRECT_FACTOR", "1") == "1"
+_inv_graphs = {}        # (n, device index) -> (graph, A, L, inv, X, U, info)
+
+
+def _inverse_factor_steps(A, L, inv, X, U, info):
+    """A = H with rows and columns reversed (consumed).  M = chol(A) (lower), X = M^-1 by block rows
+    (X[i, :i] = -inv(M_ii) (M[i, :i] X[:i, :i]), the diagonal-block inverses come from vlmc_chol_block), and
+    U = X with rows and columns reversed: upper triangular with U^T U = H^-1."""
+    _chol_steps(A, L, inv, info)
+    n = A.shape[0]
+    X.zero_()
+    for k in range(0, n, _CHOL_NB):
+        nb = min(_CHOL_NB, n - k)
+        ik = inv[k // _CHOL_NB][:nb, :nb]
+        X[k:k + nb, k:k + nb] = ik
+        if k:
+            X[k:k + nb, :k] = torch.mm(ik, torch.mm(L[k:k + nb, :k], X[:k, :k])).neg_()
+    U.copy_(torch.flip(X, (0, 1)))
+
+
+@torch.no_grad()
+def inverse_upper_factor(H: torch.Tensor):
+    """(U, info): the upper triangular U with U^T U = H^-1, i.e. what `cholesky(cholesky_inverse(cholesky(H)), upper=True)`
+    (sparsegpt_pruner.py:112-150) arrives at, from ONE factorization: with J the index reversal, J H J = M M^T gives
+    H = R R^T for the upper triangular R = J M J, hence H^-1 = (R^-1)^T R^-1 and U = R^-1 = J M^-1 J (the Cholesky
+    factor is unique).  n^3/3 + n^3/3 flops instead of 4 n^3/3, one sequential sweep of diagonal blocks instead of two.
+    info != 0: H is not (numerically) positive definite."""
+    _need_gpu(H)
+    assert H.dim() == 2 and H.shape[0] == H.shape[1] and H.dtype == torch.float32
+    n = H.shape[0]
+    dev = H.device
+    key = (n, dev.index)
+    ent = _inv_graphs.get(key)
+    if ent is None:
+        nblk = (n + _CHOL_NB - 1) // _CHOL_NB
+        A = torch.empty((n, n), dtype=torch.float32, device=dev)
+        L = torch.zeros((n, n), dtype=torch.float32, device=dev)
+        X = torch.zeros((n, n), dtype=torch.float32, device=dev)
+        U = torch.zeros((n, n), dtype=torch.float32, device=dev)
+        inv = torch.zeros((nblk, _CHOL_NB, _CHOL_NB), dtype=torch.float32, device=dev)
+        info = torch.zeros(1, dtype=torch.int32, device=dev)
+        graph = None
+        if _CHOL_GRAPH and n > _CHOL_NB:
+            A.copy_(torch.flip(H, (0, 1)))
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):                      # one eager run before capture (library workspaces)
+                _inverse_factor_steps(A, L, inv, X, U, info)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                _inverse_factor_steps(A, L, inv, X, U, info)
+        ent = _inv_graphs[key] = (graph, A, L, inv, X, U, info)
+    graph, A, L, inv, X, U, info = ent
+    A.copy_(torch.flip(H, (0, 1)))
+    info.zero_()
+    if graph is not None:
+        graph.replay()
+    else:
+        _inverse_factor_steps(A, L, inv, X, U, info)
+    return U.clone(), info.clone()
+
+
 def _chol_with_damping(H, damp, upper, max_tries=100):
     for _ in range(max_tries):
         L, info = blocked_cholesky(H, upper=upper)
@@ -149,6 +216,13 @@ def factorize(H: torch.Tensor, percdamp=0.01):
     dead = torch.diag(H) == 0
     H[dead, dead] = 1
     _clamp_inf(H)
+    if _DIRECT_FACTOR:
+        # one factorization of the index-reversed Hessian instead of cholesky -> cholesky_inverse -> cholesky: the same
+        # matrix (the factor is unique) with other roundings.  A Hessian that is not positive definite takes the
+        # reference's three-step chain below with its two damping loops, unchanged.
+        U, info = inverse_upper_factor(H)
+        if int(info.item()) == 0 and not bool(torch.isnan(U).any()):
+            return U, dead
     L = _chol_with_damping(H, percdamp * torch.mean(torch.diag(H)), upper=False)
     Hi = torch.cholesky_inverse(L)
     _clamp_inf(Hi)
@@ -203,8 +277,15 @@ def fasterprune(layer, H: torch.Tensor, sparsity, prune_n=0, prune_m=0, blocksiz
         mask1 = None
         if prune_n == 0:
             tmp = W[:, i1:i2] ** 2 / diag[i1:i2].reshape(1, -1) ** 2                       # :183
-            thresh = torch.sort(tmp.flatten())[0][int(tmp.numel() * sparsity)]             # :184
-            mask1 = (tmp <= thresh).contiguous()                                            # :185
+            if _SELECT_THRESHOLD:
+                # thresh = sort(tmp)[k] is the (k+1)-th smallest score; mask1 = tmp <= thresh = not (tmp > thresh):
+                # the multi-tensor radix select (K17) on the one [rows, 128] score block, no sort, no host wait
+                keep = ops.score_select(None, "score", scopes=[0], scope_ks=[int(tmp.numel() * sparsity) + 1], scores=[tmp],
+                                        apply_weights=False)[0]
+                mask1 = torch.logical_not(keep)
+            else:
+                thresh = torch.sort(tmp.flatten())[0][int(tmp.numel() * sparsity)]         # :184
+                mask1 = (tmp <= thresh).contiguous()                                        # :185
         sweep_block(W, i1, i2, U, mask1, prune_n, prune_m, err, pruned)
         if i2 < cols:
             W[:, i2:].addmm_(err[:, :i2 - i1], U[i1:i2, i2:], beta=1.0, alpha=-1.0)        # :210
