@@ -23,7 +23,68 @@ __device__ __forceinline__ float lane_bcast(float v, int src) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
-template <int kSgRows>
+// One column step for the rows of a wave.  HI: the pivot column lives in the upper register (columns 64..127);
+// then the lower one is final and is left alone.
+template <int kSgRows, bool HI>
+__device__ __forceinline__ void sweep_step(int i, int lane, float h0, float h1, float d, float (&w0)[kSgRows], float (&w1)[kSgRows],
+                                           float (&e0)[kSgRows], float (&e1)[kSgRows], const int (&m0)[kSgRows],
+                                           const int (&m1)[kSgRows]) {
+    const int li = i & 63;
+#pragma unroll
+    for (int r = 0; r < kSgRows; ++r) {
+        const float wi = lane_bcast(HI ? w1[r] : w0[r], li);
+        const int pr = __builtin_amdgcn_readlane(HI ? m1[r] : m0[r], li);
+        const float q = pr ? 0.f : wi;
+        const float err = ieee_div(wi - q, d);
+        if (!HI) {
+            w0[r] = lane > li ? w0[r] - ieee_mul(err, h0) : (lane == li ? q : w0[r]);      // columns >= i (:204); the pivot becomes q
+            w1[r] = w1[r] - ieee_mul(err, h1);
+            if (lane == li) e0[r] = err;
+        } else {
+            w1[r] = lane > li ? w1[r] - ieee_mul(err, h1) : (lane == li ? q : w1[r]);
+            if (lane == li) e1[r] = err;
+        }
+    }
+}
+
+// n of every m columns on the COMPENSATED weights (:190-192): ranks of w^2/d^2 over columns i..i+m-1, ties -> lowest
+// column (stable), every lane computes the same ranks
+template <int kSgRows, int M>     // M: compile-time group size (4, 8) or 0 = prune_m at run time (<= 8)
+__device__ __forceinline__ void nm_decide(int i, int count, int lane, int prune_n, int prune_m_rt, const float *sU,
+                                          const float (&w0)[kSgRows], const float (&w1)[kSgRows], int (&m0)[kSgRows], int (&m1)[kSgRows]) {
+    const int prune_m = M ? M : prune_m_rt;
+    constexpr int kMax = M ? M : 8;
+#pragma unroll
+    for (int r = 0; r < kSgRows; ++r) {
+        uint32_t t[kMax];       // order-preserving keys of the metric; NaN ranks last like torch.sort
+#pragma unroll
+        for (int a = 0; a < kMax; ++a) {
+            if (a < prune_m && i + a < count) {
+                const int col = i + a;
+                const float wv = col >= 64 ? lane_bcast(w1[r], col & 63) : lane_bcast(w0[r], col & 63);
+                const float dv = sU[col * kSgBlock + col];
+                t[a] = score_key(ieee_div(ieee_mul(wv, wv), ieee_mul(dv, dv)));
+            } else {
+                t[a] = 0xFFFFFFFFu;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < kMax; ++a) {
+            if (a < prune_m && i + a < count) {
+                int rank = 0;
+#pragma unroll
+                for (int b = 0; b < kMax; ++b)
+                    if (b < prune_m) rank += (t[b] < t[a] || (t[b] == t[a] && b < a)) ? 1 : 0;
+                const int col = i + a;
+                if (rank < prune_n && lane == (col & 63)) {
+                    if (col >= 64) m1[r] = 1; else m0[r] = 1;
+                }
+            }
+        }
+    }
+}
+
+template <int kSgRows, int NM>     // NM: 0 = unstructured (block mask given), 4 / 8 = n:m with that m, 1 = n:m, m at run time
 __global__ __launch_bounds__(256) void sparsegpt_sweep_kernel(float *__restrict__ W, int64_t out_f, int count, int64_t ldw,
                                                               const float *__restrict__ U1, int64_t ldu,
                                                               const uint8_t *__restrict__ mask1, int64_t ldm, int prune_n,
@@ -31,9 +92,35 @@ __global__ __launch_bounds__(256) void sparsegpt_sweep_kernel(float *__restrict_
                                                               uint8_t *__restrict__ mask_out, int64_t ldmo) {
     extern __shared__ __attribute__((aligned(16))) float sU[];   // [count][kSgBlock]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
-    for (int e = tid; e < count * kSgBlock; e += blockDim.x) {
-        const int i = e / kSgBlock, j = e % kSgBlock;
-        sU[e] = (j < count) ? U1[int64_t(i) * ldu + j] : 0.f;
+    // stage the factor block: all of a thread's loads are issued before the first LDS store
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    if (count == kSgBlock && (ldu & 3) == 0 && aligned16_dev(U1)) {
+        constexpr int kPer = kSgBlock * (kSgBlock / 4) / 256;      // 16 float4 per thread
+        f32x4 v[kPer];
+#pragma unroll
+        for (int b = 0; b < kPer; ++b) {
+            const int e = tid + b * 256;
+            v[b] = *reinterpret_cast<const f32x4 *>(U1 + int64_t(e >> 5) * ldu + (e & 31) * 4);
+        }
+#pragma unroll
+        for (int b = 0; b < kPer; ++b) {
+            const int e = tid + b * 256;
+            *reinterpret_cast<f32x4 *>(sU + (e >> 5) * kSgBlock + (e & 31) * 4) = v[b];
+        }
+    } else {
+        for (int e0 = tid; e0 < count * kSgBlock; e0 += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int e = e0 + b * 256, i = e / kSgBlock, j = e % kSgBlock;
+                v[b] = (e < count * kSgBlock && j < count) ? U1[int64_t(i) * ldu + j] : 0.f;
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int e = e0 + b * 256;
+                if (e < count * kSgBlock) sU[e] = v[b];
+            }
+        }
     }
     __syncthreads();
     const bool c0 = lane < count, c1 = lane + 64 < count;
@@ -52,56 +139,26 @@ __global__ __launch_bounds__(256) void sparsegpt_sweep_kernel(float *__restrict_
             m1[r] = (live && c1 && mask1) ? int(mask1[row * ldm + lane + 64]) : 0;
             e0[r] = e1[r] = 0.f;
         }
-        for (int i = 0; i < count; ++i) {
-            const int li = i & 63;
-            const bool hi_slot = i >= 64;
-            if (prune_n != 0 && i % prune_m == 0) {
-                // n smallest of w^2/d^2 over columns i..i+m-1 on the COMPENSATED weights (:190-192);
-                // ties -> lowest column (stable), every lane computes the same ranks
-#pragma unroll
-                for (int r = 0; r < kSgRows; ++r) {
-                    uint32_t t[8];       // order-preserving keys of the metric; NaN ranks last like torch.sort
-#pragma unroll
-                    for (int a = 0; a < 8; ++a) {
-                        if (a < prune_m && i + a < count) {
-                            const int col = i + a;
-                            const float wv = col >= 64 ? lane_bcast(w1[r], col & 63) : lane_bcast(w0[r], col & 63);
-                            const float dv = sU[col * kSgBlock + col];
-                            t[a] = score_key(ieee_div(ieee_mul(wv, wv), ieee_mul(dv, dv)));
-                        } else {
-                            t[a] = 0xFFFFFFFFu;
-                        }
-                    }
-#pragma unroll
-                    for (int a = 0; a < 8; ++a) {
-                        if (a < prune_m && i + a < count) {
-                            int rank = 0;
-#pragma unroll
-                            for (int b = 0; b < 8; ++b)
-                                if (b < prune_m) rank += (t[b] < t[a] || (t[b] == t[a] && b < a)) ? 1 : 0;
-                            const int col = i + a;
-                            if (rank < prune_n && lane == (col & 63)) {
-                                if (col >= 64) m1[r] = 1; else m0[r] = 1;
-                            }
-                        }
-                    }
-                }
+        float h0n = sU[lane], h1n = sU[lane + 64], dn = sU[0];      // factor row of the NEXT step, read one step ahead
+        const int half = count < 64 ? count : 64;
+        for (int i = 0; i < half; ++i) {
+            if (NM && i % (NM > 1 ? NM : prune_m) == 0) nm_decide<kSgRows, (NM > 1 ? NM : 0)>(i, count, lane, prune_n, prune_m, sU, w0, w1, m0, m1);
+            const float h0 = h0n, h1 = h1n, d = dn;
+            if (i + 1 < count) {
+                h0n = sU[(i + 1) * kSgBlock + lane];
+                h1n = sU[(i + 1) * kSgBlock + lane + 64];
+                dn = sU[(i + 1) * kSgBlock + i + 1];
             }
-            const float h0 = sU[i * kSgBlock + lane], h1 = sU[i * kSgBlock + lane + 64];
-            const float d = sU[i * kSgBlock + i];
-            const bool upd0 = lane >= i, upd1 = lane + 64 >= i;       // columns >= i (:204)
-#pragma unroll
-            for (int r = 0; r < kSgRows; ++r) {
-                const float wi = hi_slot ? lane_bcast(w1[r], li) : lane_bcast(w0[r], li);
-                const int pr = hi_slot ? __builtin_amdgcn_readlane(m1[r], li) : __builtin_amdgcn_readlane(m0[r], li);
-                const float q = pr ? 0.f : wi;
-                const float err = ieee_div(wi - q, d);
-                if (upd0) w0[r] = w0[r] - ieee_mul(err, h0);
-                if (upd1) w1[r] = w1[r] - ieee_mul(err, h1);
-                if (lane == li) {
-                    if (hi_slot) { w1[r] = q; e1[r] = err; } else { w0[r] = q; e0[r] = err; }
-                }
+            sweep_step<kSgRows, false>(i, lane, h0, h1, d, w0, w1, e0, e1, m0, m1);
+        }
+        for (int i = 64; i < count; ++i) {
+            if (NM && i % (NM > 1 ? NM : prune_m) == 0) nm_decide<kSgRows, (NM > 1 ? NM : 0)>(i, count, lane, prune_n, prune_m, sU, w0, w1, m0, m1);
+            const float h1 = h1n, d = dn;
+            if (i + 1 < count) {
+                h1n = sU[(i + 1) * kSgBlock + lane + 64];
+                dn = sU[(i + 1) * kSgBlock + i + 1];
             }
+            sweep_step<kSgRows, true>(i, lane, 0.f, h1, d, w0, w1, e0, e1, m0, m1);
         }
 #pragma unroll
         for (int r = 0; r < kSgRows; ++r) {
@@ -148,20 +205,35 @@ extern "C" int vlmc_sparsegpt_sweep(float *W, int64_t out_features, int64_t coun
     static bool attr_set = false;
     if (!attr_set) {
         const int bytes = kSgBlock * kSgBlock * int(sizeof(float));
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(sparsegpt_sweep_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(sparsegpt_sweep_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(sparsegpt_sweep_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        bool ok = true;
+#define VLMC_SWEEP_ATTR(R, NMV)                                                                                          \
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(sparsegpt_sweep_kernel<R, NMV>),                         \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
+        VLMC_SWEEP_ATTR(1, 0); VLMC_SWEEP_ATTR(2, 0); VLMC_SWEEP_ATTR(4, 0);
+        VLMC_SWEEP_ATTR(1, 1); VLMC_SWEEP_ATTR(2, 1); VLMC_SWEEP_ATTR(4, 1);
+        VLMC_SWEEP_ATTR(1, 4); VLMC_SWEEP_ATTR(2, 4); VLMC_SWEEP_ATTR(4, 4);
+        VLMC_SWEEP_ATTR(1, 8); VLMC_SWEEP_ATTR(2, 8); VLMC_SWEEP_ATTR(4, 8);
+#undef VLMC_SWEEP_ATTR
+        if (!ok) {
             set_error("vlmc_sparsegpt_sweep: cannot reserve 64 KB of LDS");
             return VLMC_EHIP;
         }
         attr_set = true;
     }
-#define VLMC_SWEEP(R)                                                                                                       \
-    hipLaunchKernelGGL(sparsegpt_sweep_kernel<R>, dim3(unsigned(grid)), dim3(256), lds, as_stream(stream), W, out_features,  \
+#define VLMC_SWEEP(R, NMV)                                                                                                       \
+    hipLaunchKernelGGL((sparsegpt_sweep_kernel<R, NMV>), dim3(unsigned(grid)), dim3(256), lds, as_stream(stream), W, out_features, \
                        int(count), ldw, U1, ldu, mask1, ldm, prune_n, prune_m, Err1, lde, mask_out, ldmo)
-    if (rows == 1) VLMC_SWEEP(1);
-    else if (rows == 2) VLMC_SWEEP(2);
-    else VLMC_SWEEP(4);
+#define VLMC_SWEEP_ROWS(NMV)          \
+    do {                             \
+        if (rows == 1) VLMC_SWEEP(1, NMV);      \
+        else if (rows == 2) VLMC_SWEEP(2, NMV); \
+        else VLMC_SWEEP(4, NMV);     \
+    } while (0)
+    if (prune_n == 0) VLMC_SWEEP_ROWS(0);
+    else if (prune_m == 4) VLMC_SWEEP_ROWS(4);
+    else if (prune_m == 8) VLMC_SWEEP_ROWS(8);
+    else VLMC_SWEEP_ROWS(1);
+#undef VLMC_SWEEP_ROWS
 #undef VLMC_SWEEP
     VLMC_HIP_CHECK_LAUNCH("vlmc_sparsegpt_sweep");
     return VLMC_OK;
