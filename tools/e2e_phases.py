@@ -35,13 +35,25 @@ def walk(model, inps, outs, caches, mtp, n, autocast, prune_block, tuple_output)
 
 cal.walk_blocks = timed("walk_blocks total", walk)
 import lavis.compression.pruners.wanda_pruner as wp
-wp.cal = cal
-for mode, env in (("graph", {}), ("eager", {"VLMC_GRAPH_REPLAY": "0"})):
+import lavis.compression.pruners.sparsegpt_pruner as sp
+import lavis.compression.pruners.dsnot_pruner as dp
+wp.cal = sp.cal = dp.cal = cal
+NAME = sys.argv[1] if len(sys.argv) > 1 else "wanda"
+if NAME == "sparsegpt":
+    from vlmc import sparsegpt as SGm
+    _fp = SGm.fasterprune
+    def fp_shape(layer, *a, **k):
+        return timed(f"fasterprune {tuple(layer.weight.shape)} cached={'U' in (k.get('factor_cache') or {})}", _fp)(layer, *a, **k)
+    SGm.fasterprune = timed("fasterprune (all linears)", fp_shape)
+    SGm.SparseGPT.add_batch = timed("SparseGPT.add_batch (all calls)", SGm.SparseGPT.add_batch)
+for mode, env in (("graph", {}),):
     os.environ.pop("VLMC_GRAPH_REPLAY", None)
     os.environ.update(env)
     T.clear()
-    dt, model, info = synthetic.time_prune(dev)
+    dt, model, info = synthetic.time_prune(dev, f"blipt5_{NAME}_pruner")
     print(mode, f"total {dt:.2f} s")
+    if NAME == "sparsegpt":
+        print("   factor routes", SGm.factor_stats)
     for k, v in T.items():
         print(f"   {k:45s} {v:7.2f} s")
     del model

@@ -90,6 +90,8 @@ def _allreduce_hessians(wrapped):
         dist.all_reduce(total)
         w.nsamples = int(total.item())
         w.H.div_(w.nsamples)
+        if hasattr(w, "_folded"):
+            w._folded = w.nsamples
 
 
 @registry.register_pruner("t5_sparsegpt_pruner")

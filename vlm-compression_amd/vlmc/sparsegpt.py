@@ -27,17 +27,49 @@ from . import ops
 from .ops import _need_gpu, _stream
 
 
+_DEFER = __import__("os").environ.get("VLMC_SGPT_DEFER", "1") != "0"
+_DEFER_BYTES = 256 << 20        # staged activations (as fp32) folded into H once they exceed this
+
+
 class SparseGPT:
-    """Same surface as the reference helper: `add_batch(inp, out)`, `fasterprune(...)`, `free()`."""
+    """Same surface as the reference helper: `add_batch(inp, out)`, `fasterprune(...)`, `free()`.
+
+    The reference's recurrence (:68-79) treats a hook input of batch b as ONE update
+    `H <- H * n/(n+b) + (2/(n+b)) X^T X` over all its tokens.  With batch-1 calibration samples that is 128 tiny
+    GEMMs (+ a cast and a scale) per distinct input and block -- 54k host-bound launch triples over the model.
+    Here consecutive calls are staged and folded in with the same formula as if they had arrived as one larger batch
+    (`VLMC_SGPT_DEFER=0`: one update per call, the reference's exact sequence); `H` folds what is pending."""
 
     def __init__(self, layer):
         self.layer = layer
         self.dev = layer.weight.device
         _need_gpu(layer.weight)
         self.rows, self.columns = layer.weight.shape
-        self.H = torch.zeros((self.columns, self.columns), device=self.dev)
+        self._H = torch.zeros((self.columns, self.columns), device=self.dev)
         self.nsamples = 0
+        self._folded = 0                     # samples already inside _H
+        self._staged, self._staged_elems = [], 0
         self.factor_cache = {}
+
+    @property
+    def H(self):
+        self._fold()
+        return self._H
+
+    @H.setter
+    def H(self, value):
+        self._staged, self._staged_elems = [], 0
+        self._H = value
+
+    @torch.no_grad()
+    def _fold(self):
+        if not self._staged:
+            return
+        n = self.nsamples
+        X = torch.cat(self._staged, dim=0).float() if len(self._staged) > 1 else self._staged[0].float()
+        self._H.addmm_(X.t(), X, beta=self._folded / n, alpha=2.0 / n)       # :76-79 with b = the staged samples
+        self._folded = n
+        self._staged, self._staged_elems = [], 0
 
     @torch.no_grad()
     def add_batch(self, inp, out=None):
@@ -45,10 +77,20 @@ class SparseGPT:
             inp = inp.unsqueeze(0)
         b = inp.shape[0]
         x = inp.reshape(-1, inp.shape[-1])
+        # rows of X seen so far: X^T X of fewer rows than columns is singular, which decides the factorization route
+        self.factor_cache["rows_seen"] = self.factor_cache.get("rows_seen", 0) + x.shape[0]
+        if _DEFER:
+            self.nsamples += b
+            self._staged.append(x.clone())               # the caller may reuse the activation's memory (graph replay)
+            self._staged_elems += x.numel()
+            if self._staged_elems * 4 > _DEFER_BYTES:
+                self._fold()
+            return
         beta = self.nsamples / (self.nsamples + b)
         self.nsamples += b
+        self._folded = self.nsamples
         xs = math.sqrt(2 / self.nsamples) * x.float()                 # :78 (scaled in fp32 before the product)
-        self.H.addmm_(xs.t(), xs, beta=beta, alpha=1.0)               # H *= beta; H += xs^T xs  (:76-79)
+        self._H.addmm_(xs.t(), xs, beta=beta, alpha=1.0)              # H *= beta; H += xs^T xs  (:76-79)
 
     def free(self):
         self.H = None
@@ -137,6 +179,7 @@ def blocked_cholesky(H: torch.Tensor, upper=False):
 
 
 _SELECT_THRESHOLD = __import__("os").environ.get("VLMC_SGPT_SORT_THRESHOLD", "0") != "1"
+factor_stats = {"direct": 0, "chain": 0}     # how often each route produced the inverse factor
 _DIRECT_FACTOR = __import__("os").environ.get("VLMC_SGPT_DIRECT_FACTOR", "1") == "1"
 _inv_graphs = {}        # (n, device index) -> (graph, A, L, inv, X, U, info)
 
@@ -210,19 +253,22 @@ def _chol_with_damping(H, damp, upper, max_tries=100):
 
 
 @torch.no_grad()
-def factorize(H: torch.Tensor, percdamp=0.01):
+def factorize(H: torch.Tensor, percdamp=0.01, rows_seen=None):
     """(U, dead): upper Cholesky factor of H^-1 (`Hinv`, :92-160) and the dead-column mask; consumes H.
     Depends on H only, so linears fed by the same tensor (q/k/v, wi_0/wi_1) share one factorization."""
     dead = torch.diag(H) == 0
     H[dead, dead] = 1
     _clamp_inf(H)
-    if _DIRECT_FACTOR:
+    if _DIRECT_FACTOR and (rows_seen is None or rows_seen > H.shape[0]):
+        # (a Hessian of no more rows than columns is singular or nearly so: straight to the reference's chain)
         # one factorization of the index-reversed Hessian instead of cholesky -> cholesky_inverse -> cholesky: the same
         # matrix (the factor is unique) with other roundings.  A Hessian that is not positive definite takes the
         # reference's three-step chain below with its two damping loops, unchanged.
         U, info = inverse_upper_factor(H)
         if int(info.item()) == 0 and not bool(torch.isnan(U).any()):
+            factor_stats["direct"] += 1
             return U, dead
+    factor_stats["chain"] += 1
     L = _chol_with_damping(H, percdamp * torch.mean(torch.diag(H)), upper=False)
     Hi = torch.cholesky_inverse(L)
     _clamp_inf(Hi)
@@ -263,7 +309,7 @@ def fasterprune(layer, H: torch.Tensor, sparsity, prune_n=0, prune_m=0, blocksiz
     if factor_cache is not None and "U" in factor_cache:
         U, dead = factor_cache["U"], factor_cache["dead"]
     else:
-        U, dead = factorize(H, percdamp)
+        U, dead = factorize(H, percdamp, rows_seen=(factor_cache or {}).get("rows_seen"))
         if factor_cache is not None:
             factor_cache["U"], factor_cache["dead"] = U, dead
     W[:, dead] = 0
