@@ -7,6 +7,7 @@ pruner loop does with PyTorch ops (file:line under /root/reference cited per op)
 from __future__ import annotations
 
 import ctypes
+import threading
 
 import torch
 
@@ -33,15 +34,21 @@ def _stream():
 
 
 class Workspace:
-    """Grow-only device scratch buffer, one per (device, purpose)."""
+    """Grow-only device scratch buffers for one purpose, one per (device, stream): calls on different streams
+    or devices never share scratch memory, calls on one stream are ordered by the stream itself."""
 
     def __init__(self):
-        self.buf = None
+        self._bufs = {}
+        self._lock = threading.Lock()
 
     def get(self, nbytes: int, device) -> torch.Tensor:
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
-        return self.buf
+        device = torch.device(device)
+        key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+        with self._lock:
+            buf = self._bufs.get(key)
+            if buf is None or buf.numel() < nbytes:
+                buf = self._bufs[key] = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+            return buf
 
 
 _select_ws = Workspace()
