@@ -172,14 +172,15 @@ extern "C" int vlmc_chol_block(const float *A, int64_t lda, int nb, float *L, in
     VLMC_REQUIRE(nb > 0 && nb <= kCholNb && lda >= nb && ldl >= nb && ldi >= nb, "vlmc_chol_block: bad block size %d (max %d)", nb,
                  kCholNb);
     const size_t lds = size_t(2) * kCholNb * kCholLd * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(chol_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 int(lds)) != hipSuccess) {
             set_error("vlmc_chol_block: cannot reserve %zu B of LDS", lds);
             return VLMC_EHIP;
         }
-        attr_set = true;
+        once.mark(dev);
     }
     hipLaunchKernelGGL(chol_block_kernel, dim3(1), dim3(kCholThreads), lds, as_stream(stream), A, lda, nb, L, ldl, Linv, ldi, info, col0);
     VLMC_HIP_CHECK_LAUNCH("vlmc_chol_block");

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -114,6 +115,22 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
     return v;
 }
+
+// "done once per device" flag for per-device function attributes (the LDS carve-out of a kernel is a property of the
+// function ON a device); thread-safe, one bit per device ordinal.
+struct PerDeviceOnce {
+    std::atomic<uint64_t> done{0};
+    // returns true when the caller must perform the one-time work for the current device (and then call mark())
+    bool needed(int *dev_out) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        *dev_out = dev;
+        return dev >= 64 || !(done.load(std::memory_order_acquire) >> dev & 1);
+    }
+    void mark(int dev) {
+        if (dev < 64) done.fetch_or(uint64_t(1) << dev, std::memory_order_release);
+    }
+};
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

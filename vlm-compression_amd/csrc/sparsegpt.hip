@@ -202,8 +202,9 @@ extern "C" int vlmc_sparsegpt_sweep(float *W, int64_t out_features, int64_t coun
     int64_t grid = (groups + 3) / 4;
     if (grid > 512) grid = 512;
     const size_t lds = size_t(count) * kSgBlock * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
         const int bytes = kSgBlock * kSgBlock * int(sizeof(float));
         bool ok = true;
 #define VLMC_SWEEP_ATTR(R, NMV)                                                                                          \
@@ -218,7 +219,7 @@ extern "C" int vlmc_sparsegpt_sweep(float *W, int64_t out_features, int64_t coun
             set_error("vlmc_sparsegpt_sweep: cannot reserve 64 KB of LDS");
             return VLMC_EHIP;
         }
-        attr_set = true;
+        once.mark(dev);
     }
 #define VLMC_SWEEP(R, NMV)                                                                                                       \
     hipLaunchKernelGGL((sparsegpt_sweep_kernel<R, NMV>), dim3(unsigned(grid)), dim3(256), lds, as_stream(stream), W, out_features, \
