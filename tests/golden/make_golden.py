@@ -609,9 +609,39 @@ def gen_global():
     print("global.npz:", len(out), "arrays")
 
 
+def gen_vicuna_e2e():
+    """The `llm_model...model.layers` branch (wanda_pruner.py:233-236,1031-1038; dsnot_pruner.py likewise) on a toy
+    InstructBLIP-Vicuna: BLIPT5 Wanda (50 % per row, 2:4 on an fp16 language model) and DSnoT pruners with
+    `t5_model_prefix="llm_model"` -> final weights and masks."""
+    from lavis.compression.pruners import dsnot_pruner as RD
+    from lavis.compression.pruners import wanda_pruner as R
+    variants = {
+        "wanda_r50": dict(cls=R.BLIPT5LayerWandaPruner, method="wanda", llm_dtype=torch.float32, kw={}),
+        "wanda_2_4_bf16": dict(cls=R.BLIPT5LayerWandaPruner, method="wanda", llm_dtype=torch.bfloat16, kw=dict(prune_n=2, prune_m=4)),
+        "dsnot_r50": dict(cls=RD.BLIPT5LayerDSnoTPruner, method="dsnot", llm_dtype=torch.float32, kw=dict(max_cycle_time=12)),
+    }
+    out = {}
+    for name, v in variants.items():
+        torch.manual_seed(0)
+        model = toy_models.init_toy(toy_models.ToyBlipVicuna(llm_dtype=v["llm_dtype"]), seed=5).eval()
+        batches = toy_models.make_batches(6, seed=13)
+        spec = "2-0.5-1.0-1.0"
+        pr = v["cls"](model=model, data_loader=batches, t5_prune_spec=spec, vit_prune_spec=spec, t5_pruning_method=v["method"],
+                      vit_pruning_method=v["method"], num_samples=6, t5_model_prefix="llm_model", max_sparsity_per_layer=1.01,
+                      **v["kw"])
+        pruned, _ = pr.prune()
+        for k_, t in pruned.state_dict().items():
+            out[f"{name}/sd/{k_}"] = t
+        for mn, mod in pruned.named_modules():
+            if hasattr(mod, "mask") and torch.is_tensor(mod.mask):
+                out[f"{name}/mask/{mn}"] = mod.mask
+    golden_io.save("vicuna_e2e", out)
+    print("vicuna_e2e.npz:", len(out), "arrays")
+
+
 GROUPS = {"wanda": gen_wanda, "wanda_e2e": gen_wanda_e2e, "sparse_lora": gen_sparse_lora, "sparsegpt": gen_sparsegpt,
           "sparsegpt_e2e": gen_sparsegpt_e2e, "dsnot": gen_dsnot,
-          "dsnot_e2e": gen_dsnot_e2e, "ressa": gen_ressa, "ecoflap": gen_ecoflap, "global": gen_global}
+          "dsnot_e2e": gen_dsnot_e2e, "ressa": gen_ressa, "ecoflap": gen_ecoflap, "global": gen_global, "vicuna_e2e": gen_vicuna_e2e}
 
 if __name__ == "__main__":
     import_reference()

@@ -187,3 +187,86 @@ def init_toy(model, seed=0, std=0.05):
             elif n.endswith("bias"):
                 p.copy_((torch.randn(p.shape, generator=g) * 0.01).to(p.dtype))
     return model
+
+
+# ---- InstructBLIP-Vicuna shaped toy (BASELINE.json configs 3-4: the `llm_model...model.layers` branch) -------------------
+class ToyLlamaAttention(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.heads = heads
+        self.q_proj = nn.Linear(dim, dim, bias=False)
+        self.k_proj = nn.Linear(dim, dim, bias=False)
+        self.v_proj = nn.Linear(dim, dim, bias=False)
+        self.o_proj = nn.Linear(dim, dim, bias=False)
+
+    def forward(self, x, position_ids=None, dense=False):
+        B, T, D = x.shape
+        h = self.heads
+        q, k, v = _lin(self.q_proj, x, dense), _lin(self.k_proj, x, dense), _lin(self.v_proj, x, dense)
+        if position_ids is not None:                     # a stand-in for the rotary embedding: the kwarg must arrive
+            rot = torch.cos(position_ids.float() * 0.1)[..., None].to(x.dtype)
+            q, k = q * rot, k * rot
+        q = q.reshape(B, T, h, D // h).transpose(1, 2).float()
+        k = k.reshape(B, T, h, D // h).transpose(1, 2).float()
+        v = v.reshape(B, T, h, D // h).transpose(1, 2).float()
+        causal = torch.full((T, T), float("-inf"), device=x.device).triu(1)
+        a = torch.softmax(q @ k.transpose(-1, -2) / (D // h) ** 0.5 + causal, dim=-1)
+        return _lin(self.o_proj, (a @ v).transpose(1, 2).reshape(B, T, D).to(x.dtype), dense)
+
+
+class ToyLlamaLayer(nn.Module):
+    """7 linears: self_attn.{q,k,v,o}_proj, mlp.{gate,up,down}_proj (modeling_llama.py:160,204-206,253)."""
+
+    def __init__(self, dim, d_ff, heads=2):
+        super().__init__()
+        self.input_layernorm = ToyRMSNorm(dim)
+        self.self_attn = ToyLlamaAttention(dim, heads)
+        self.post_attention_layernorm = ToyRMSNorm(dim)
+        self.mlp = nn.Module()
+        self.mlp.gate_proj = nn.Linear(dim, d_ff, bias=False)
+        self.mlp.up_proj = nn.Linear(dim, d_ff, bias=False)
+        self.mlp.down_proj = nn.Linear(d_ff, dim, bias=False)
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, dense=False, **unused):
+        x = hidden_states
+        x = x + self.self_attn(self.input_layernorm(x), position_ids=position_ids, dense=dense)
+        h = self.post_attention_layernorm(x)
+        h = F.silu(_lin(self.mlp.gate_proj, h, dense)) * _lin(self.mlp.up_proj, h, dense)
+        return (x + _lin(self.mlp.down_proj, h, dense),)
+
+
+class ToyBlipVicuna(nn.Module):
+    def __init__(self, vit_dim=32, vit_hidden=64, vit_depth=2, dim=32, d_ff=88, depth=3, vocab=50, vit_dtype=torch.float32,
+                 llm_dtype=torch.float32):
+        super().__init__()
+        self.visual_encoder = nn.Module()
+        self.visual_encoder.blocks = nn.ModuleList([ToyViTBlock(vit_dim, vit_hidden) for _ in range(vit_depth)])
+        self.visual_encoder.to(vit_dtype)
+        self.llm_proj = nn.Linear(vit_dim, dim)
+        llm = nn.Module()
+        llm.config = types.SimpleNamespace(use_cache=True, hidden_size=dim)
+        llm.model = nn.Module()
+        llm.model.embed_tokens = nn.Embedding(vocab, dim)
+        llm.model.layers = nn.ModuleList([ToyLlamaLayer(dim, d_ff) for _ in range(depth)])
+        llm.model.norm = ToyRMSNorm(dim)
+        self.llm_model = llm
+        self.llm_proj.to(llm_dtype)
+        self.llm_model.to(llm_dtype)
+        self.vit_dtype, self.llm_dtype = vit_dtype, llm_dtype
+
+    def maybe_autocast(self, dtype=None):
+        return contextlib.nullcontext()
+
+    def forward(self, samples, vit_dense=False, llm_dense=False):
+        x = samples["image"].to(self.vit_dtype)
+        for blk in self.visual_encoder.blocks:
+            x = blk(x, None, dense=vit_dense)
+        m = self.llm_model.model
+        img = self.llm_proj(x.to(self.llm_dtype))
+        h = torch.cat([img, m.embed_tokens(samples["text_input"]), m.embed_tokens(samples["text_output"])], dim=1)
+        pos = torch.arange(h.shape[1], device=h.device)[None].expand(h.shape[0], -1)
+        for layer in m.layers:
+            h = layer(h, attention_mask=None, position_ids=pos, dense=llm_dense)[0]
+        h = m.norm(h)
+        logits = h.float() @ m.embed_tokens.weight.float().t()
+        return {"loss": h.float().pow(2).mean(), "logits": logits}
