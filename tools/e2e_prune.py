@@ -10,14 +10,20 @@ import torch  # noqa: E402
 from vlmc import synthetic  # noqa: E402
 
 dev = torch.device("cuda:0")
-names = sys.argv[1:] or ["wanda"]
+names = sys.argv[1:] or ["wanda"]          # a name ending in "@vicuna" runs on the InstructBLIP-Vicuna-7B shapes
 model = None
+last_family = None
 for name in names:
+    name, _, family = name.partition("@")
+    if family != last_family:
+        model, last_family = None, family
     for label, env in (("hip-graph replay (default)", {}), ("eager replay", {"VLMC_GRAPH_REPLAY": "0"}),
                        ("32 samples per forward", {"VLMC_BATCH_REPLAY": "32"})):
         for k in ("VLMC_GRAPH_REPLAY", "VLMC_BATCH_REPLAY"):
             os.environ.pop(k, None)
         os.environ.update(env)
         kw = dict(is_global=True) if name in ("mag", "aobd") else {}
+        if family == "vicuna":
+            kw["t5_model_prefix"] = "llm_model"
         dt, model, info = synthetic.time_prune(dev, f"blipt5_{name}_pruner", model=model, **kw)
-        print(f"{name:10s} {label:28s} {dt:8.2f} s   {info['linears'] / dt:8.1f} layers/s   pruned {info['pruned_fraction']:.4f}", flush=True)
+        print(f"{name + ('@' + family if family else ''):16s} {label:28s} {dt:8.2f} s   {info['linears'] / dt:8.1f} layers/s   pruned {info['pruned_fraction']:.4f}", flush=True)

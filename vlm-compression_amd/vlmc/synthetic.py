@@ -169,6 +169,78 @@ class InstructBlipT5(nn.Module):
         return {"loss": logits.float().logsumexp(-1).mean(), "logits": logits}
 
 
+# ---- InstructBLIP-Vicuna-7B shapes (BASELINE.json configs 3-4) -------------------------------------------------------------
+class LlamaAttention(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.heads = heads
+        self.q_proj = nn.Linear(dim, dim, bias=False)
+        self.k_proj = nn.Linear(dim, dim, bias=False)
+        self.v_proj = nn.Linear(dim, dim, bias=False)
+        self.o_proj = nn.Linear(dim, dim, bias=False)
+
+    def forward(self, x, dense=False):
+        B, T, D = x.shape
+        q, k, v = (_lin(m, x, dense).reshape(B, T, self.heads, D // self.heads).transpose(1, 2)
+                   for m in (self.q_proj, self.k_proj, self.v_proj))
+        y = F.scaled_dot_product_attention(q, k, v, is_causal=True).transpose(1, 2).reshape(B, T, D)
+        return _lin(self.o_proj, y, dense)
+
+
+class LlamaLayer(nn.Module):
+    def __init__(self, dim, d_ff, heads):
+        super().__init__()
+        self.input_layernorm = RMSNorm(dim)
+        self.self_attn = LlamaAttention(dim, heads)
+        self.post_attention_layernorm = RMSNorm(dim)
+        self.mlp = nn.Module()
+        self.mlp.gate_proj = nn.Linear(dim, d_ff, bias=False)
+        self.mlp.up_proj = nn.Linear(dim, d_ff, bias=False)
+        self.mlp.down_proj = nn.Linear(d_ff, dim, bias=False)
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, dense=False, **unused):
+        x = hidden_states
+        x = x + self.self_attn(self.input_layernorm(x), dense=dense)
+        h = self.post_attention_layernorm(x)
+        return (x + _lin(self.mlp.down_proj, F.silu(_lin(self.mlp.gate_proj, h, dense)) * _lin(self.mlp.up_proj, h, dense), dense),)
+
+
+class InstructBlipVicuna(nn.Module):
+    """ViT-g (fp16) + 32 LLaMA layers 4096 / 11008 (fp16): `llm_model.model.layers[i].{self_attn.*_proj, mlp.*_proj}`."""
+
+    def __init__(self, vit_dim=1408, vit_hidden=6144, vit_heads=16, vit_depth=39, dim=4096, d_ff=11008, heads=32, depth=32,
+                 vocab=32000, query_tokens=32, dtype=torch.float16):
+        super().__init__()
+        self.visual_encoder = nn.Module()
+        self.visual_encoder.blocks = nn.ModuleList([ViTBlock(vit_dim, vit_hidden, vit_heads) for _ in range(vit_depth)])
+        self.llm_proj = nn.Linear(vit_dim, dim)
+        llm = nn.Module()
+        llm.config = types.SimpleNamespace(use_cache=True, hidden_size=dim)
+        llm.model = nn.Module()
+        llm.model.embed_tokens = nn.Embedding(vocab, dim)
+        llm.model.layers = nn.ModuleList([LlamaLayer(dim, d_ff, heads) for _ in range(depth)])
+        llm.model.norm = RMSNorm(dim)
+        self.llm_model = llm
+        self.to(dtype)
+        self.query_tokens, self.vit_dtype, self.llm_dtype = query_tokens, dtype, dtype
+
+    def maybe_autocast(self, dtype=None):
+        return contextlib.nullcontext()
+
+    def forward(self, samples, vit_dense=False, llm_dense=False):
+        x = samples["image"].to(self.vit_dtype)
+        for blk in self.visual_encoder.blocks:
+            x = blk(x, None, dense=vit_dense)
+        m = self.llm_model.model
+        h = torch.cat([self.llm_proj(x[:, :self.query_tokens]), m.embed_tokens(samples["text_input"]),
+                       m.embed_tokens(samples["text_output"])], dim=1)
+        pos = torch.arange(h.shape[1], device=h.device)[None].expand(h.shape[0], -1)
+        for layer in m.layers:
+            h = layer(h, attention_mask=None, position_ids=pos, dense=llm_dense)[0]
+        logits = m.norm(h) @ m.embed_tokens.weight.t()
+        return {"loss": logits.float().logsumexp(-1).mean(), "logits": logits}
+
+
 def randomize_(model, seed=0, std=0.02):
     """Seeded in-place N(0, std) weights (every rank builds the same model)."""
     g = torch.Generator(device=next(model.parameters()).device).manual_seed(seed)
@@ -192,7 +264,7 @@ def calibration_batches(n, device, vit_tokens=257, vit_dim=1408, text_len=32, ou
 def prunable_linears(model):
     n = 0
     for name, mod in model.named_modules():
-        if isinstance(mod, nn.Linear) and (".blocks." in name or ".block." in name):
+        if isinstance(mod, nn.Linear) and (".blocks." in name or ".block." in name or ".layers." in name):
             n += 1
     return n
 
@@ -206,14 +278,16 @@ def time_prune(device, pruner_name="blipt5_wanda_pruner", n_samples=128, ratio=0
     import time
 
     from lavis.compression import load_pruner
+    vicuna = cfg.get("t5_model_prefix") == "llm_model"
     if model is None:
-        model = InstructBlipT5().to(device).eval()
+        model = (InstructBlipVicuna() if vicuna else InstructBlipT5()).to(device).eval()
     randomize_(model, seed)
     if batches is None:
-        batches = calibration_batches(n_samples, device)
+        emb = model.llm_model.model.embed_tokens if vicuna else model.t5_model.shared
+        batches = calibration_batches(n_samples, device, vocab=emb.num_embeddings)       # token ids must fit the embedding
     keep = 1 - ratio
     method = pruner_name.split("_")[1]
-    full = dict(t5_prune_spec=f"24-{keep!r}-1.0-1.0", vit_prune_spec=f"39-{keep!r}-1.0-1.0", t5_pruning_method=method,
+    full = dict(t5_prune_spec=f"{32 if vicuna else 24}-{keep!r}-1.0-1.0", vit_prune_spec=f"39-{keep!r}-1.0-1.0", t5_pruning_method=method,
                 vit_pruning_method=method, num_samples=n_samples, max_sparsity_per_layer=1.01)
     full.update(cfg)
     pruner = load_pruner(pruner_name, model, batches, cfg=full)
@@ -225,7 +299,7 @@ def time_prune(device, pruner_name="blipt5_wanda_pruner", n_samples=128, ratio=0
     dt = time.perf_counter() - t0
     zeros = total = 0
     for name, mod in model.named_modules():
-        if isinstance(mod, nn.Linear) and (".blocks." in name or ".block." in name):
+        if isinstance(mod, nn.Linear) and (".blocks." in name or ".block." in name or ".layers." in name):
             zeros += int((mod.weight == 0).sum())
             total += mod.weight.numel()
     return dt, model, {"linears": prunable_linears(model), "pruned_fraction": zeros / max(1, total), "weights": total}
