@@ -35,3 +35,29 @@ def test_small_synthetic_model_through_the_wanda_pruner():
     for name, mod in model.named_modules():
         if isinstance(mod, nn.Linear) and ".block." in name:
             assert bool(((mod.weight == 0).sum(dim=1) == mod.weight.shape[1] // 2).all()), name     # per-row rule on the T5 side
+
+
+def test_synthetic_vicuna_has_the_llama_linears():
+    from vlmc import synthetic
+    with torch.device("meta"):
+        model = synthetic.InstructBlipVicuna()
+    assert synthetic.prunable_linears(model) == 39 * 4 + 32 * 7
+    layer = model.llm_model.model.layers[0]
+    shapes = {n: tuple(m.weight.shape) for n, m in layer.named_modules() if isinstance(m, nn.Linear)}
+    assert shapes == {"self_attn.q_proj": (4096, 4096), "self_attn.k_proj": (4096, 4096), "self_attn.v_proj": (4096, 4096),
+                      "self_attn.o_proj": (4096, 4096), "mlp.gate_proj": (11008, 4096), "mlp.up_proj": (11008, 4096),
+                      "mlp.down_proj": (4096, 11008)}
+    assert all(p.dtype == torch.float16 for p in model.parameters())
+
+
+@pytest.mark.gpu
+def test_small_synthetic_vicuna_through_the_dsnot_pruner():
+    from vlmc import synthetic
+    dev = torch.device("cuda:0")
+    model = synthetic.InstructBlipVicuna(vit_dim=64, vit_hidden=128, vit_heads=4, vit_depth=2, dim=64, d_ff=176, heads=4, depth=2,
+                                         vocab=100, query_tokens=4).to(dev).eval()
+    batches = synthetic.calibration_batches(8, dev, vit_tokens=9, vit_dim=64, text_len=5, out_len=3, vocab=100)
+    dt, model, info = synthetic.time_prune(dev, "blipt5_dsnot_pruner", n_samples=8, model=model, batches=batches,
+                                           t5_model_prefix="llm_model", max_cycle_time=8)
+    assert info["linears"] == 2 * 4 + 2 * 7
+    assert abs(info["pruned_fraction"] - 0.5) < 0.01
