@@ -11,6 +11,8 @@ is attached (SparseGPT only rewrites the weights).  The arithmetic lives in `vlm
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from lavis.common.registry import registry
@@ -66,14 +68,65 @@ class _SparseGPTBlockMixin:
                 h.remove()
         unique = list({id(a): a for a in wrapped.values()}.values())
         _allreduce_hessians(unique)
+        owner = _shard_linears(subset, wrapped)
+        rank = cal.calibration_shard()[0]
         for name, mod in subset.items():
             acc = wrapped[name]
             assert acc.nsamples == n_inps                                          # :442
+            if owner is not None and owner[name] != rank:
+                continue
             key = f"{module_to_process}.{i}.{name}.weight"
             sparsegpt.fasterprune(mod, acc.H, sparsity_ratio[key], prune_n=self.prune_n, prune_m=self.prune_m,
                                   percdamp=0.01, blocksize=128, factor_cache=acc.factor_cache)
+        if owner is not None:
+            _exchange_pruned(subset, owner, rank)
         for acc in unique:
             acc.free()
+
+
+def _shard_linears(subset, wrapped):
+    """Multi-GPU (BASELINE.json config 3, "layers sharded"): after the Hessian all-reduce every rank holds the same H, and
+    pruning a linear is deterministic, so each linear needs to be pruned by ONE rank only.  Linears sharing an accumulator
+    (one factorization) stay together; groups go to the least loaded rank, heaviest first (n^3 for the factorization +
+    rows * n per sweep).  Returns {linear name: rank}, or None when running single / as replicas
+    (`VLMC_SGPT_SHARD_LAYERS=0`: every rank prunes everything)."""
+    rank, world = cal.calibration_shard()
+    if world == 1 or os.environ.get("VLMC_SGPT_SHARD_LAYERS", "1") == "0":
+        return None
+    groups = {}
+    for name in subset:
+        groups.setdefault(id(wrapped[name]), []).append(name)
+
+    def cost(names):
+        n = subset[names[0]].weight.shape[1]
+        return n ** 3 / 3 + sum(subset[m].weight.shape[0] * n * 128.0 for m in names)
+    load = [0.0] * world
+    owner = {}
+    for names in sorted(groups.values(), key=lambda g: (-cost(g), g[0])):
+        r = min(range(world), key=lambda k: (load[k], k))
+        load[r] += cost(names)
+        for m in names:
+            owner[m] = r
+    return owner
+
+
+def _exchange_pruned(subset, owner, rank):
+    """Every linear's pruned weights (and its importance score) travel from the rank that pruned it to all others."""
+    import torch.distributed as dist
+    names = list(subset)
+    dev = subset[names[0]].weight.device
+    scores = torch.zeros(len(names), dtype=torch.float64, device=dev)
+    for k, name in enumerate(names):
+        w = subset[name].weight
+        if owner[name] == rank:
+            scores[k] = float(getattr(w, "importance_score", 0.0))
+        data = w.data if w.data.is_contiguous() else w.data.contiguous()
+        dist.broadcast(data, src=owner[name])
+        if data is not w.data:
+            w.data.copy_(data)
+    dist.all_reduce(scores)
+    for k, name in enumerate(names):
+        setattr(subset[name].weight, "importance_score", float(scores[k].item()))
 
 
 def _allreduce_hessians(wrapped):
