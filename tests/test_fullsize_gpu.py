@@ -103,3 +103,27 @@ def test_stats_full_size_vs_c_oracle_samples(shape, dtype):
     assert ops.wanda_scaler_update(s, 0, nsq, 1) == 128
     want, _ = OC.scaler_update(np.zeros(shape[2], np.float32), 0, nsq.cpu().numpy(), 1)
     assert np.array_equal(s.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("name,shape", [("wi_0", (5120, 2048)), ("wo", (2048, 5120))])
+def test_baseline_config_0_end_to_end_vs_cpu_oracle(name, shape):
+    """BASELINE.json configs[0] exactly as SURVEY.md §8(d) writes it: one FlanT5-XL encoder FFN linear, bf16,
+    W ~ N(0, 0.02) seed 0, 8 calibration samples [1, 64, in] ~ N(0.1, 1) seeds 1..8, 50 % per row -- `scaler_row`, mask,
+    zeroed weights and importance score against the CPU oracle, bit for bit."""
+    from oracle import wanda as OW
+    from vlmc import wanda
+    out_f, in_f = shape
+    W = (torch.randn(out_f, in_f, generator=torch.Generator().manual_seed(0)) * 0.02).to(torch.bfloat16)
+    xs = [(torch.randn(1, 64, in_f, generator=torch.Generator().manual_seed(j)) + 0.1).to(torch.bfloat16) for j in range(1, 9)]
+    st = wanda.InputStat(in_f, DEV)
+    for x in xs:
+        st.add_call(x.to(DEV))
+    st.finalize()
+    s_ref = OW.wanda_stats(xs)
+    assert np.array_equal(st.scaler_row.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
+    Wd = W.clone().to(DEV)
+    mask, parts = wanda.prune_linear(Wd, st, "row", ratio=0.5)
+    want = OW.prune_linear(W, s_ref, "row", ratio=0.5)
+    assert np.array_equal(mask.cpu().numpy(), want["mask"])
+    assert torch.equal(Wd.cpu(), want["weight"])
+    assert float(parts.sum().item()) / W.numel() == pytest.approx(want["importance_score"], rel=1e-6)
