@@ -218,7 +218,7 @@ class BlockGraph:
             torch.cuda.current_stream(x.device).wait_stream(side)
             self.records.clear()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph), torch.no_grad(), autocast():
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad(), autocast():
                 y = layer(self.x, **self.cache)
                 self.y = y[0] if tuple_output else y
         finally:

@@ -160,7 +160,7 @@ def blocked_cholesky(H: torch.Tensor, upper=False):
                 _chol_steps(A, L, inv, info)
             torch.cuda.current_stream(dev).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 _chol_steps(A, L, inv, info)
             ent = _chol_graphs[key] = (graph, A, L, inv, info)
         graph, A, L, inv, info = ent
@@ -230,7 +230,7 @@ def inverse_upper_factor(H: torch.Tensor):
                 _inverse_factor_steps(A, L, inv, X, U, info)
             torch.cuda.current_stream(dev).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 _inverse_factor_steps(A, L, inv, X, U, info)
         ent = _inv_graphs[key] = (graph, A, L, inv, X, U, info)
     graph, A, L, inv, X, U, info = ent
