@@ -23,3 +23,22 @@ for seed in range(100, 160):
             except AssertionError as e:
                 fails += 1; print("FAIL score", seed, mode, layout, str(e)[:200])
 print("done, failures:", fails)
+
+# DSnoT: the list-head kernel against the per-cycle kernel (bit-identical events) and, for small rows, the CPU oracle
+import numpy as np
+import test_dsnot_gpu as D
+rng = np.random.default_rng(2024)
+dfails = 0
+for case in range(60):
+    m = int(rng.choice([0, 0, 4, 8]))
+    n = 0 if m == 0 else int(rng.integers(1, m))
+    in_f = int(rng.integers(2, 400)) * 8
+    if m:
+        in_f = (in_f // m) * m
+    out_f = int(rng.integers(1, 40))
+    dt = [torch.bfloat16, torch.float16, torch.float32][case % 3]
+    try:
+        D.test_list_kernel_emits_the_same_events_as_the_cycle_kernel((out_f, in_f), (n, m), dt)
+    except AssertionError as e:
+        dfails += 1; print("FAIL dsnot", out_f, in_f, n, m, dt, str(e)[:200])
+print("dsnot done, failures:", dfails)
