@@ -79,8 +79,101 @@ def _keys_for(model_prefix):
     raise ValueError(f"no calibration cache keys known for model prefix {model_prefix!r}")
 
 
+def graph_replay_enabled():
+    """Graph-captured replay (default on for GPU tensors, `VLMC_GRAPH_REPLAY=0` turns it off)."""
+    return os.environ.get("VLMC_GRAPH_REPLAY", "1") != "0"
+
+
+GRAPH_MIN_SAMPLES = 4         # a capture costs about three eager forwards
+graph_stats = {"captured": 0, "replayed": 0, "fallbacks": 0}
+
+
+class GraphedModule(nn.Module):
+    """Stands in for a block of an ALREADY PRUNED tower while the model's own forward runs the calibration batches up
+    to the next tower (`capture_block_inputs`): the first call with a given argument signature runs eagerly, the second
+    is captured in a HIP graph, later ones replay it -- same kernels, identical activations, about half the wall-clock
+    of a batch-1 eager block.  Anything unusual (gradients enabled, arguments that are not tensors / None / plain
+    scalars, outputs that are not tensors or flat tuples of them, a failing capture) falls through to the module."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.__dict__["_wrapped"] = module           # not registered as a sub-module: the model's structure is untouched
+        self._seen, self._graphs, self._off = {}, {}, False
+
+    def __getattr__(self, name):
+        return getattr(self.__dict__["_wrapped"], name)
+
+    @staticmethod
+    def _sig(v):
+        if isinstance(v, torch.Tensor):
+            return ("T", tuple(v.shape), v.dtype, v.device) if v.is_cuda and not v.requires_grad else NotImplemented
+        if v is None or isinstance(v, (bool, int, float, str)):
+            return ("V", v)
+        return NotImplemented
+
+    def forward(self, *args, **kwargs):
+        mod = self.__dict__["_wrapped"]
+        if self._off or torch.is_grad_enabled():
+            return mod(*args, **kwargs)
+        names = sorted(kwargs)
+        key = tuple(self._sig(a) for a in args) + tuple((k, self._sig(kwargs[k])) for k in names)
+        if any(x is NotImplemented or (isinstance(x, tuple) and len(x) == 2 and x[1] is NotImplemented) for x in key) or \
+                not any(isinstance(a, torch.Tensor) for a in list(args) + list(kwargs.values())):
+            return mod(*args, **kwargs)
+        ent = self._graphs.get(key)
+        if ent is None:
+            n = self._seen[key] = self._seen.get(key, 0) + 1
+            if n < 2:
+                return mod(*args, **kwargs)          # also the warm-up the capture needs
+            try:
+                sargs = [a.clone() if isinstance(a, torch.Tensor) else a for a in args]
+                skw = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in kwargs.items()}
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    out = mod(*sargs, **skw)
+                flat = out if isinstance(out, (tuple, list)) else (out,)
+                if not all(o is None or isinstance(o, torch.Tensor) for o in flat):
+                    raise TypeError("block output is not a tensor or a flat tuple of tensors")
+                ent = self._graphs[key] = (graph, sargs, skw, out)
+                graph_stats["captured"] += 1
+            except Exception as e:
+                self._off = True
+                graph_stats["fallbacks"] += 1
+                print(f"graph replay disabled for a block during capture ({type(e).__name__}: {e})")
+                return mod(*args, **kwargs)
+        graph, sargs, skw, out = ent
+        for s_, a in zip(sargs, args):
+            if isinstance(a, torch.Tensor):
+                s_.copy_(a)
+        for k, v in kwargs.items():
+            if isinstance(v, torch.Tensor):
+                skw[k].copy_(v)
+        graph.replay()
+        graph_stats["replayed"] += 1
+        if isinstance(out, (tuple, list)):
+            return type(out)(o.clone() if isinstance(o, torch.Tensor) else o for o in out)
+        return out.clone()
+
+
+def _wrap_towers(model, towers):
+    """Replace the blocks of the given module lists by GraphedModule proxies; returns the undo list."""
+    undo = []
+    if not (towers and graph_replay_enabled() and torch.cuda.is_available()):
+        return undo
+    for path in towers:
+        try:
+            blocks = get_module_recursive(model, path)
+        except AttributeError:
+            continue
+        for i in range(len(blocks)):
+            if not isinstance(blocks[i], GraphedModule) and next(blocks[i].parameters(), torch.empty(0)).is_cuda:
+                undo.append((blocks, i, blocks[i]))
+                blocks[i] = GraphedModule(blocks[i])
+    return undo
+
+
 def capture_block_inputs(model, dataloader, n_samples, module_to_process, forward_to_cache, lora_model, *, vit,
-                         model_prefix=None, count_batches=False):
+                         model_prefix=None, count_batches=False, done_towers=None):
     """Run the model until block 0 of `module_to_process` is reached, for the first
     `n_samples` calibration samples; return (inps, outs, caches) like the reference.
 
@@ -116,6 +209,8 @@ def capture_block_inputs(model, dataloader, n_samples, module_to_process, forwar
             raise _Stop
 
     layers[0] = Catcher(layers[0])
+    # blocks of towers that were pruned before this one (`done_towers`: their module paths) replay from HIP graphs
+    undo = _wrap_towers(model, [t for t in (done_towers or []) if t != module_to_process])
     try:
         total = 0
         batches = []
@@ -140,6 +235,8 @@ def capture_block_inputs(model, dataloader, n_samples, module_to_process, forwar
                 pass
     finally:
         layers[0] = layers[0].module
+        for blocks, i, orig in undo:
+            blocks[i] = orig
     return inps, [None] * len(inps), caches
 
 
@@ -175,15 +272,6 @@ def _stack_caches(group):
         v0 = group[0][k]
         out[k] = torch.cat([c[k] for c in group], dim=0) if isinstance(v0, torch.Tensor) else v0
     return out
-
-
-def graph_replay_enabled():
-    """Graph-captured replay (default on for GPU tensors, `VLMC_GRAPH_REPLAY=0` turns it off)."""
-    return os.environ.get("VLMC_GRAPH_REPLAY", "1") != "0"
-
-
-GRAPH_MIN_SAMPLES = 4         # a capture costs about three eager forwards
-graph_stats = {"captured": 0, "replayed": 0, "fallbacks": 0}
 
 
 class BlockGraph:

@@ -194,7 +194,7 @@ class T5LayerDSnoTPruner(LayerWiseBasePruner, _DsnotBlockMixin):
         use_cache, cfg.use_cache = cfg.use_cache, False
         try:
             return cal.capture_block_inputs(model, dataloader, n_samples, module_to_process, self.forward_to_cache,
-                                            lora_model, vit=False, model_prefix=self.model_prefix)
+                                            lora_model, vit=False, model_prefix=self.model_prefix, done_towers=getattr(self, "_done_towers", None))
         finally:
             cfg.use_cache = use_cache
 
@@ -260,7 +260,7 @@ class VITLayerDSnoTPruner(LayerWiseBasePruner, _DsnotBlockMixin):
     def prepare_calibration_input_encoder(self, model, dataloader, model_prefix, n_samples,
                                           module_to_process="encoder.block", lora_model=False):
         return cal.capture_block_inputs(model, dataloader, n_samples, module_to_process, self.forward_to_cache,
-                                        lora_model, vit=True)
+                                        lora_model, vit=True, done_towers=getattr(self, "_done_towers", None))
 
     @print_time
     def _prune(self, model, dataloader, model_prefix, module_to_process="encoder.block", n_samples=64,
@@ -345,7 +345,10 @@ class BLIPT5LayerDSnoTPruner(LayerWiseBasePruner, _DsnotBlockMixin):
 
     def _tower(self, cls, **kw):
         self.prepare_calibration_input_encoder = lambda *a, **k: cls.prepare_calibration_input_encoder(self, *a, **k)
-        return cls._prune(self, self.model, self.data_loader, **kw)
+        out = cls._prune(self, self.model, self.data_loader, **kw)
+        # the finished tower's blocks may replay from HIP graphs while the next tower's inputs are captured
+        self._done_towers = getattr(self, "_done_towers", []) + [kw["module_to_process"]]
+        return out
 
     @print_time
     def prune(self, importance_scores=None, keep_indices_or_masks=None, lora_model=False):

@@ -31,7 +31,7 @@ class _SparseGPTBlockMixin:
     def _capture(self, model, dataloader, n_samples, module_to_process, vit, model_prefix=None):
         return cal.capture_block_inputs(model, dataloader, n_samples, module_to_process,
                                         lambda m, b, _lora=False: self.forward_to_cache(m, b), False, vit=vit,
-                                        model_prefix=model_prefix, count_batches=True)
+                                        model_prefix=model_prefix, count_batches=True, done_towers=getattr(self, "_done_towers", None))
 
     def _sparsegpt_block(self, i, subset, run_pass, n_inps, module_to_process, sparsity_ratio):
         """Hooks -> one dense pass -> prune every linear (sparsegpt_pruner.py:405-459).  Linears that receive the
@@ -246,6 +246,7 @@ class BLIPT5LayerSparseGPTPruner(LayerWiseBasePruner, _SparseGPTBlockMixin):
                                                         model_prefix=self.vit_model_prefix,
                                                         module_to_process=f"{self.vit_model_prefix}.blocks",
                                                         n_samples=self.num_samples, sparsity_ratio=sd)
+            self._done_towers = getattr(self, "_done_towers", []) + [f"{self.vit_model_prefix}.blocks"]
         if self.t5_prune_spec is not None:
             _, keep_ratio, _, _ = self.convert_spec_to_list(self.t5_prune_spec)
             sd = global_sparsity_dict if global_sparsity_dict is not None else self.get_sparsity(1 - keep_ratio, None)
@@ -255,6 +256,7 @@ class BLIPT5LayerSparseGPTPruner(LayerWiseBasePruner, _SparseGPTBlockMixin):
                                                                model_prefix=self.t5_model_prefix,
                                                                module_to_process=f"{self.t5_model_prefix}.{side}.block",
                                                                n_samples=self.num_samples, sparsity_ratio=sd)
+                    self._done_towers = getattr(self, "_done_towers", []) + [f"{self.t5_model_prefix}.{side}.block"]
             else:
                 self.model = T5LayerSparseGPTPruner._prune(self, self.model, self.data_loader, device,
                                                            model_prefix=self.t5_model_prefix,
