@@ -202,3 +202,42 @@ def test_graph_captured_replay_is_bit_identical_to_the_eager_loop(method, monkey
         assert a.keys() == b.keys()
         for k in a:
             assert torch.equal(a[k], b[k]), k
+
+
+def test_graphed_module_proxy_replays_identically_and_falls_back():
+    """calibration.GraphedModule (stand-in for already pruned blocks during capture): eager first call, captured second,
+    replayed afterwards, one graph per argument signature; gradients / odd arguments go straight to the module."""
+    import toy_models
+    from lavis.compression.pruners import calibration as cal
+    torch.manual_seed(0)
+    blk = toy_models.ToyT5Block(32, 64, is_decoder=True).to("cuda:0").eval()
+    proxy = cal.GraphedModule(blk)
+    assert proxy.is_decoder is True and proxy.ln0 is blk.ln0              # attribute access reaches the block
+    before = dict(cal.graph_stats)
+    xs = [torch.randn(1, 5, 32, device="cuda:0") for _ in range(5)]
+    enc = [torch.randn(1, 7, 32, device="cuda:0") for _ in range(5)]
+    with torch.no_grad():
+        for x, e in zip(xs, enc):
+            got = proxy(x, attention_mask=None, encoder_hidden_states=e, dense=False)
+            want = blk(x, attention_mask=None, encoder_hidden_states=e, dense=False)
+            assert isinstance(got, tuple) and torch.equal(got[0], want[0])
+        assert cal.graph_stats["captured"] == before["captured"] + 1 and cal.graph_stats["replayed"] == before["replayed"] + 4
+        y = proxy(torch.randn(2, 5, 32, device="cuda:0"), attention_mask=None, encoder_hidden_states=torch.randn(2, 7, 32, device="cuda:0"))
+        assert y[0].shape == (2, 5, 32) and cal.graph_stats["captured"] == before["captured"] + 1       # new signature: eager first
+        odd = proxy(xs[0], attention_mask=None, encoder_hidden_states=enc[0], dense=False, unused_list=[1, 2])   # not graphable
+        assert torch.equal(odd[0], blk(xs[0], encoder_hidden_states=enc[0])[0])
+    x = xs[0].clone().requires_grad_()
+    out = proxy(x, encoder_hidden_states=enc[0])[0]                         # gradients enabled: the module itself
+    out.sum().backward()
+    assert x.grad is not None
+    # capture_block_inputs puts the proxies in and takes them out again
+    model = toy_models.init_toy(toy_models.ToyBlipT5(), seed=7).eval().to("cuda:0")
+    batches = [{k: t.to("cuda:0") for k, t in b.items()} for b in toy_models.make_batches(6, seed=11)]
+    vit_blocks = list(model.visual_encoder.blocks)
+    with torch.no_grad():
+        inps, _, _ = cal.capture_block_inputs(model, batches, 6, "t5_model.encoder.block", lambda m, b, _l=False: m(b), False,
+                                              vit=False, model_prefix="t5_model", done_towers=["visual_encoder.blocks"])
+        ref, _, _ = cal.capture_block_inputs(model, batches, 6, "t5_model.encoder.block", lambda m, b, _l=False: m(b), False,
+                                             vit=False, model_prefix="t5_model")
+    assert all(a is b for a, b in zip(model.visual_encoder.blocks, vit_blocks))
+    assert len(inps) == 6 and all(torch.equal(a, b) for a, b in zip(inps, ref))
