@@ -241,3 +241,26 @@ def test_graphed_module_proxy_replays_identically_and_falls_back():
                                              vit=False, model_prefix="t5_model")
     assert all(a is b for a, b in zip(model.visual_encoder.blocks, vit_blocks))
     assert len(inps) == 6 and all(torch.equal(a, b) for a, b in zip(inps, ref))
+
+
+def test_blocks_that_cannot_be_captured_fall_back_to_the_eager_loop(monkeypatch):
+    """A block whose forward synchronises with the host (HF T5's fp16 `torch.isinf(h).any()` clamp does) cannot be
+    captured: the replay engine and the capture proxies must notice, run it eagerly and produce the same result."""
+    import toy_models
+    from lavis.compression.pruners import calibration as cal
+    orig = toy_models.ToyT5Block.forward
+
+    def syncing_forward(self, hidden_states, **kw):
+        if bool(torch.isinf(hidden_states).any()):            # host sync: illegal while a stream is capturing
+            hidden_states = torch.clamp(hidden_states, -1e4, 1e4)
+        return orig(self, hidden_states, **kw)
+    monkeypatch.setenv("VLMC_GRAPH_REPLAY", "0")
+    monkeypatch.setattr(toy_models.ToyT5Block, "forward", syncing_forward)
+    eager, _ = H.run_pruner("fp32_r50", "cuda:0")
+    monkeypatch.setenv("VLMC_GRAPH_REPLAY", "1")
+    before = dict(cal.graph_stats)
+    graphed, _ = H.run_pruner("fp32_r50", "cuda:0")
+    assert cal.graph_stats["fallbacks"] > before["fallbacks"]                 # the T5 blocks were refused ...
+    assert cal.graph_stats["captured"] > before["captured"]                   # ... the ViT blocks were not
+    for (ka, va), (kb, vb) in zip(eager.state_dict().items(), graphed.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka
