@@ -349,7 +349,8 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
         global _STACKED
         cur_in, cur_out = state["inps"], state["outs"]
         graphs, keys = {}, None
-        if group_max == 1 and graph_replay_enabled() and n_samples and cur_in[0].is_cuda:
+        if group_max == 1 and graph_replay_enabled() and n_samples and cur_in[0].is_cuda and \
+                not getattr(layer, "_vlmc_no_graph", False):
             keys = [_stack_key(cur_in[t], caches[t]) for t in range(n_samples)]
             counts = {}
             for k in keys:
@@ -365,6 +366,7 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                         bg = graphs[keys[j]] = BlockGraph(layer, cur_in[j], caches[j], subset, autocast, tuple_output)
                     except Exception as e:          # block not capturable (host sync, data-dependent shapes): eager loop
                         graphs[keys[j]] = False
+                        layer._vlmc_no_graph = True             # do not try again in the second pass
                         graph_stats["fallbacks"] += 1
                         print(f"graph replay disabled for this block ({type(e).__name__}: {e})")
                         bg = None
