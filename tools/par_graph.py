@@ -42,6 +42,7 @@ for kind in ("t5", "vit"):
         n = 64
         for _ in range(n):
             g.replay()
+        enq = (time.perf_counter() - t0) / n          # host time to enqueue (the GPU may still be running)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        print(f"{kind} block, {S} parallel branch(es): {dt * 1e6:8.1f} us per replay, {dt * 1e6 / S:7.1f} us per sample, capture {cap_ms:.1f} ms", flush=True)
+        print(f"{kind} block, {S} parallel branch(es): {dt * 1e6:8.1f} us per replay, {dt * 1e6 / S:7.1f} us per sample, capture {cap_ms:.1f} ms, host enqueue {enq * 1e6:.0f} us per replay", flush=True)
