@@ -274,6 +274,12 @@ def _stack_caches(group):
     return out
 
 
+def storage_signature(layer):
+    """Addresses of every parameter and buffer of a block: a captured graph stays valid exactly as long as these do
+    (Wanda / DSnoT prune in place; SparseGPT and the LoRA masks replace tensors)."""
+    return tuple(t.data_ptr() for t in list(layer.parameters()) + list(layer.buffers()))
+
+
 class BlockGraph:
     """One block forward captured in a HIP graph and replayed for every calibration sample of the same shape.
 
@@ -291,6 +297,7 @@ class BlockGraph:
         self.x = x.clone()
         self.cache = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in cache.items()}
         self.records = []
+        self.storage = storage_signature(layer)
         modules = list(subset.values())
         saved = [m._forward_hooks for m in modules]
 
@@ -348,7 +355,12 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
     def run_pass(before_sample=None):
         global _STACKED
         cur_in, cur_out = state["inps"], state["outs"]
-        graphs, keys = {}, None
+        keys = None
+        sig = None
+        for k_ in [k_ for k_, g_ in graphs.items() if g_ is not False]:     # the first pass's graphs, if the block's
+            sig = storage_signature(layer) if sig is None else sig          # tensors are still where they were
+            if graphs[k_].storage != sig:
+                del graphs[k_]
         if group_max == 1 and graph_replay_enabled() and n_samples and cur_in[0].is_cuda and \
                 not getattr(layer, "_vlmc_no_graph", False):
             keys = [_stack_key(cur_in[t], caches[t]) for t in range(n_samples)]
@@ -401,10 +413,12 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                             cur_out[j + t] = y[t * b0:(t + 1) * b0]
             j += g
 
+    graphs = {}
     for i in range(len(layers)):
         layer = layers[i]
         subset = find_layers(layer)
+        graphs.clear()             # per block; the second pass reuses the first one's graphs when storage is unchanged
         prune_block(i, layer, subset, run_pass, state)
-        run_pass()                 # (graphs are per pass: the pruning in between may have replaced weight storage)
+        run_pass()
         state["inps"], state["outs"] = state["outs"], state["inps"]
     return model
