@@ -99,6 +99,7 @@ class GraphedModule(nn.Module):
         super().__init__()
         self.__dict__["_wrapped"] = module           # not registered as a sub-module: the model's structure is untouched
         self._seen, self._graphs, self._off = {}, {}, False
+        self._storage = storage_signature(module)
 
     def __getattr__(self, name):
         return getattr(self.__dict__["_wrapped"], name)
@@ -155,8 +156,9 @@ class GraphedModule(nn.Module):
         return out.clone()
 
 
-def _wrap_towers(model, towers):
-    """Replace the blocks of the given module lists by GraphedModule proxies; returns the undo list."""
+def _wrap_towers(model, towers, proxy_cache=None):
+    """Replace the blocks of the given module lists by GraphedModule proxies; returns the undo list.  `proxy_cache`
+    (owned by the pruner) keeps the proxies -- and their graphs -- from one capture phase to the next."""
     undo = []
     if not (towers and graph_replay_enabled() and torch.cuda.is_available()):
         return undo
@@ -167,13 +169,19 @@ def _wrap_towers(model, towers):
             continue
         for i in range(len(blocks)):
             if not isinstance(blocks[i], GraphedModule) and next(blocks[i].parameters(), torch.empty(0)).is_cuda:
-                undo.append((blocks, i, blocks[i]))
-                blocks[i] = GraphedModule(blocks[i])
+                mod = blocks[i]
+                proxy = proxy_cache.get(id(mod)) if proxy_cache is not None else None
+                if proxy is None or proxy.__dict__["_wrapped"] is not mod or proxy._storage != storage_signature(mod):
+                    proxy = GraphedModule(mod)
+                    if proxy_cache is not None:
+                        proxy_cache[id(mod)] = proxy
+                undo.append((blocks, i, mod))
+                blocks[i] = proxy
     return undo
 
 
 def capture_block_inputs(model, dataloader, n_samples, module_to_process, forward_to_cache, lora_model, *, vit,
-                         model_prefix=None, count_batches=False, done_towers=None):
+                         model_prefix=None, count_batches=False, done_towers=None, proxy_cache=None):
     """Run the model until block 0 of `module_to_process` is reached, for the first
     `n_samples` calibration samples; return (inps, outs, caches) like the reference.
 
@@ -210,7 +218,7 @@ def capture_block_inputs(model, dataloader, n_samples, module_to_process, forwar
 
     layers[0] = Catcher(layers[0])
     # blocks of towers that were pruned before this one (`done_towers`: their module paths) replay from HIP graphs
-    undo = _wrap_towers(model, [t for t in (done_towers or []) if t != module_to_process])
+    undo = _wrap_towers(model, [t for t in (done_towers or []) if t != module_to_process], proxy_cache)
     try:
         total = 0
         batches = []

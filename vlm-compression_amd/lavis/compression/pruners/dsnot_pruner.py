@@ -194,7 +194,8 @@ class T5LayerDSnoTPruner(LayerWiseBasePruner, _DsnotBlockMixin):
         use_cache, cfg.use_cache = cfg.use_cache, False
         try:
             return cal.capture_block_inputs(model, dataloader, n_samples, module_to_process, self.forward_to_cache,
-                                            lora_model, vit=False, model_prefix=self.model_prefix, done_towers=getattr(self, "_done_towers", None))
+                                            lora_model, vit=False, model_prefix=self.model_prefix, done_towers=getattr(self, "_done_towers", None),
+                                        proxy_cache=self.__dict__.setdefault("_proxy_cache", {}))
         finally:
             cfg.use_cache = use_cache
 
@@ -260,7 +261,8 @@ class VITLayerDSnoTPruner(LayerWiseBasePruner, _DsnotBlockMixin):
     def prepare_calibration_input_encoder(self, model, dataloader, model_prefix, n_samples,
                                           module_to_process="encoder.block", lora_model=False):
         return cal.capture_block_inputs(model, dataloader, n_samples, module_to_process, self.forward_to_cache,
-                                        lora_model, vit=True, done_towers=getattr(self, "_done_towers", None))
+                                        lora_model, vit=True, done_towers=getattr(self, "_done_towers", None),
+                                        proxy_cache=self.__dict__.setdefault("_proxy_cache", {}))
 
     @print_time
     def _prune(self, model, dataloader, model_prefix, module_to_process="encoder.block", n_samples=64,

@@ -31,7 +31,8 @@ class _SparseGPTBlockMixin:
     def _capture(self, model, dataloader, n_samples, module_to_process, vit, model_prefix=None):
         return cal.capture_block_inputs(model, dataloader, n_samples, module_to_process,
                                         lambda m, b, _lora=False: self.forward_to_cache(m, b), False, vit=vit,
-                                        model_prefix=model_prefix, count_batches=True, done_towers=getattr(self, "_done_towers", None))
+                                        model_prefix=model_prefix, count_batches=True, done_towers=getattr(self, "_done_towers", None),
+                                        proxy_cache=self.__dict__.setdefault("_proxy_cache", {}))
 
     def _sparsegpt_block(self, i, subset, run_pass, n_inps, module_to_process, sparsity_ratio):
         """Hooks -> one dense pass -> prune every linear (sparsegpt_pruner.py:405-459).  Linears that receive the
