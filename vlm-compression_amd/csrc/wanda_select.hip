@@ -513,7 +513,7 @@ constexpr int kCandCap = 8192;
 constexpr int kCtrl = kMatBins;
 constexpr int kCand = kMatBins + 32;
 constexpr int kWsWords = kCand + 2 * kCandCap;
-enum { C_LO = 0, C_SHIFT, C_BELOW, C_NANC, C_LOB, C_RANKB, C_NONE, C_FAIL, C_DONE, C_NCAND };
+enum { C_LO = 0, C_SHIFT, C_BELOW, C_NANC, C_LOB, C_RANKB, C_NONE, C_FAIL, C_DONE, C_NCAND, C_BAR_A, C_BAR_B, C_FUSED_OK };
 
 __device__ __forceinline__ uint32_t ld_dev(const uint32_t *p) {       // device-scope load (bypasses the CU's L1)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -834,6 +834,7 @@ __global__ __launch_bounds__(1024) void matrix_resolve_kernel(const SelBatch b) 
     const int tid = threadIdx.x;
     if (ws[kCtrl + C_NONE]) return;
     const uint32_t fail = ws[kCtrl + C_FAIL], ncand = ws[kCtrl + C_NCAND], shift = ws[kCtrl + C_SHIFT];
+    if (!fail && ws[kCtrl + C_FUSED_OK]) return;                // the fused kernel decided everything itself
     const bool from_list = !fail && ncand <= uint32_t(kCandCap);
     if (!fail && (shift == 0 || ncand == 0)) return;            // nothing was left undecided
     const uint32_t lob = fail ? 0u : ws[kCtrl + C_LOB];
@@ -874,6 +875,310 @@ __global__ __launch_bounds__(1024) void matrix_resolve_kernel(const SelBatch b) 
             const uint32_t row = e / jb.in_f, col = e - row * jb.in_f;
             jb.mask[e] = 0;
             if (b.apply_zero) W[int64_t(row) * jb.ldw + col] = typename T::raw(0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// SEL_MATRIX, fused form (default): count + candidates + apply in ONE launch of co-resident workgroups.
+//
+// The weights of a whole ViT-g block (25.2 M x 2 B = 50.5 MB) fit in the register files of the chip
+// (256 CUs x 512 KB): every lane loads its R 16-byte chunks ONCE, keeps them in VGPRs, and the threshold
+// is agreed on through two grid barriers per linear, so W is read once and mask / zeroed W written once
+// -- exactly the 5 B / weight of SURVEY 8(d) instead of 7 B, and one launch instead of three.
+//   P1  load R chunks per lane (chunks past R x grid are streamed and re-read in the later phases);
+//       count(key < lo), 2048-bin LDS histogram of the sampled bracket, score partial sums; flush the
+//       histogram with device-scope atomics                                          -- barrier A
+//   P2  every workgroup scans the merged histogram itself (same data => same decision everywhere): the bin
+//       [lob, lob + 2^shift) that holds rank k; lanes append the KEYS of their elements inside it (a few
+//       hundred per linear) to the candidate list                                    -- barrier B
+//   P3  every workgroup radix-selects the exact threshold among the candidates in LDS
+//   P4  apply from the registers: one compare per key -> mask bytes + zeroed weights.
+// Barriers: one arrival counter per barrier in the control block, device-scope atomics only (no L2
+// write-back fences, see matrix_count_kernel).  The grid never exceeds one workgroup per CU, so all
+// workgroups are resident on an otherwise idle GPU; if they are not (CUs held by another stream), the
+// bounded spin runs out, the waiters raise the fail bit, everybody leaves W untouched and writes an all-keep
+// mask, and the resolve launch that follows does the exact streaming select (its fallback mode).  Every
+// wave therefore reaches the end of the kernel whatever the residency.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kBarFail = 0x80000000u;
+constexpr int kFusedCand = 4096;                 // candidate keys a workgroup can hold (more => exact fallback)
+constexpr int kFusedMaxIn = 8192;                // in_features the LDS copy of sqrt(scaler_row) can hold
+constexpr uint32_t kSpinMax = 1u << 16;          // x (device-scope load + s_sleep) ~ 50-100 ms
+
+// tid 0 of a workgroup: arrive at the barrier word and wait for `n` arrivals.  false = fail bit seen or timed out.
+__device__ __forceinline__ bool grid_arrive_wait(uint32_t *ws, int which, uint32_t n) {
+    uint32_t *ctr = ws + kCtrl + which;
+    uint32_t v = atomicAdd(ctr, 1u) + 1u;
+    for (uint32_t it = 0; it < kSpinMax; ++it) {
+        if (v & kBarFail) return false;
+        if (v >= n) return true;
+        __builtin_amdgcn_s_sleep(8);
+        v = ld_dev(ctr);
+    }
+    atomicOr(ws + kCtrl + C_BAR_A, kBarFail);    // release everybody who is, or will be, waiting
+    atomicOr(ws + kCtrl + C_BAR_B, kBarFail);
+    return false;
+}
+
+#ifdef VLMC_FUSED_STAMPS
+// diagnostic build only (never shipped): 100 MHz wall-clock stamps of workgroup 0 / the last workgroup of each job
+#define VLMC_FSTAMP(i)                                                                               \
+    do {                                                                                             \
+        if (tid == 0 && (wg == 0 || wg == jb.nwg - 1))                                               \
+            ws[kCtrl + 16 + (wg == 0 ? 0 : 8) + 2 * 0 + (i)] = uint32_t(wall_clock64());             \
+    } while (0)
+#else
+#define VLMC_FSTAMP(i) do {} while (0)
+#endif
+
+template <typename T, bool ALIGNED, int R>
+__global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b) {
+    __shared__ uint32_t lh[kMatBins];
+    __shared__ uint32_t cand[kFusedCand];
+    __shared__ float sqs[kFusedMaxIn];                           // sqrt(scaler_row): read 3 x per element
+    __shared__ uint32_t red[40];
+    __shared__ double dsm[16];
+    uint32_t wg;
+    const SelJob &jb = b.job[find_job(b, blockIdx.x, wg)];
+    const int tid = threadIdx.x;
+    uint32_t *ws = jb.ws;
+    const uint4 c0 = reinterpret_cast<const uint4 *>(ws + kCtrl)[0], c1 = reinterpret_cast<const uint4 *>(ws + kCtrl)[1];
+    bool fail = c1.w != 0;                                       // C_FAIL: forced by the sample launch (test hook)
+    const uint32_t lo = c0.x /* C_LO */, bshift = c0.y /* C_SHIFT */;
+    const uint32_t in_f = jb.in_f;
+    typename T::raw *W = static_cast<typename T::raw *>(jb.W);
+    const ChunkWalk cw(jb);
+    const uint32_t cb0 = wg * 1024u + uint32_t(tid);
+    const uint32_t row0 = cb0 / cw.cpr, cir0 = cb0 - row0 * cw.cpr;
+    VLMC_FSTAMP(0);
+#define VLMC_WALK_NEXT(row, cir) \
+    do { row += cw.step_rows; cir += cw.step_cir; if (cir >= cw.cpr) { cir -= cw.cpr; ++row; } } while (0)
+
+    // ---- P1: load, count ------------------------------------------------------------------------------
+    Chunk8<T> raw[R];
+    {
+        uint32_t row = row0, cir = cir0;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            if (cb0 + uint32_t(u) * cw.step < cw.total)
+                raw[u] = load_row_chunk<T, ALIGNED, true>(W + int64_t(row) * jb.ldw, cir * 8, in_f);
+            VLMC_WALK_NEXT(row, cir);
+        }
+    }
+    for (int i = tid; i < kMatBins; i += 1024) lh[i] = 0;
+    for (uint32_t i = tid; i < in_f; i += 1024u) sqs[i] = jb.sq[i];
+    __syncthreads();
+    auto load_sq = [&](uint32_t col0, float *o) {
+        if constexpr (ALIGNED) {
+            const float4 a = reinterpret_cast<const float4 *>(sqs + col0)[0], c = reinterpret_cast<const float4 *>(sqs + col0)[1];
+            o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = c.x; o[5] = c.y; o[6] = c.z; o[7] = c.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (col0 + j < in_f) ? sqs[col0 + j] : 0.f;
+        }
+    };
+    uint32_t below = 0;
+    double dsum = 0.0;
+    auto count_chunk = [&](const Chunk8<T> &c, uint32_t col0) {
+        float sq[8];
+        load_sq(col0, sq);
+        float fs = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (ALIGNED || col0 + j < in_f) {
+                const float sc = ieee_mul(fabsf(to_f32<T>(c.v[j])), sq[j]);
+                fs += sc;
+                const uint32_t key = stream_key(sc);
+                below += key < lo ? 1u : 0u;
+                const uint32_t d = (key - lo) >> bshift;
+                if (key >= lo && d < uint32_t(kMatBins)) atomicAdd(&lh[d], 1u);
+            }
+        }
+        dsum += double(fs);
+    };
+    {
+        uint32_t row = row0, cir = cir0;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            if (cb0 + uint32_t(u) * cw.step < cw.total) count_chunk(raw[u], cir * 8);
+            VLMC_WALK_NEXT(row, cir);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (uint32_t cb = cb0 + uint32_t(R) * cw.step; cb < cw.total; cb += cw.step) {       // past the registers
+            count_chunk(load_row_chunk<T, ALIGNED>(W + int64_t(row) * jb.ldw, cir * 8, in_f), cir * 8);
+            VLMC_WALK_NEXT(row, cir);
+        }
+    }
+    VLMC_FSTAMP(1);
+    uint32_t thr = 0;
+    if (!fail) {
+        const uint32_t wsum = wave_sum_u32_dpp(below);
+        if ((tid & 63) == 0) red[tid >> 6] = wsum;
+        __syncthreads();
+        for (int i = tid; i < kMatBins / 2; i += 1024) {         // two bins per 64-bit atomic (no carry: counts < 2^32)
+            const unsigned long long v = (unsigned long long)(lh[2 * i]) | ((unsigned long long)(lh[2 * i + 1]) << 32);
+            if (v) atomicAdd(reinterpret_cast<unsigned long long *>(ws) + i, v);
+        }
+        if (tid == 0) {
+            uint32_t bsum = 0;
+            for (int w = 0; w < 16; ++w) bsum += red[w];
+            if (bsum) atomicAdd(&ws[kCtrl + C_BELOW], bsum);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my atomics have been performed
+        __syncthreads();
+        VLMC_FSTAMP(2);
+        if (tid == 0) red[34] = grid_arrive_wait(ws, C_BAR_A, jb.nwg) ? 1u : 0u;      // ---- barrier A
+        __syncthreads();
+        fail = red[34] == 0;
+        VLMC_FSTAMP(3);
+    }
+    // ---- P2: the bin of rank k; candidates ----------------------------------------------------------------
+    if (!fail) {
+        uint32_t h[4] = {0, 0, 0, 0};
+        if (tid < kMatBins / 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[i] = ld_dev(&ws[tid * 4 + i]);
+        }
+        const uint32_t bel = ld_dev(&ws[kCtrl + C_BELOW]);
+        uint32_t bin, before;
+        const bool found = block_find_rank(h, jb.k - bel, red, bin, before);
+        const uint64_t bin_end = uint64_t(lo) + (uint64_t(bin + 1u) << bshift);
+        // the sampled bracket missed rank k, or the bin reaches the NaN keys: exact fallback (resolve launch)
+        fail = bel > jb.k || !found || bin_end > 0x7F800001ull;
+        if (!fail) {
+            const uint32_t lob = lo + (bin << bshift), rankb = jb.k - bel - before;
+            thr = lob;                                           // one-key bin: ties with the threshold are kept
+            if (bshift) {
+                const uint32_t width = 1u << bshift;
+                if (tid == 0) red[35] = 0;
+                __syncthreads();
+                auto cand_chunk = [&](const Chunk8<T> &c, uint32_t col0) {
+                    float sq[8];
+                    load_sq(col0, sq);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (ALIGNED || col0 + j < in_f) {
+                            const uint32_t key = stream_key(ieee_mul(fabsf(to_f32<T>(c.v[j])), sq[j]));
+                            if (key >= lob && key - lob < width) {               // collected in LDS first
+                                const uint32_t pos = atomicAdd(&red[35], 1u);
+                                if (pos < uint32_t(kFusedCand)) cand[pos] = key - lob;
+                            }
+                        }
+                    }
+                };
+                uint32_t row = row0, cir = cir0;
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    if (cb0 + uint32_t(u) * cw.step < cw.total) cand_chunk(raw[u], cir * 8);
+                    VLMC_WALK_NEXT(row, cir);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                for (uint32_t cb = cb0 + uint32_t(R) * cw.step; cb < cw.total; cb += cw.step) {
+                    cand_chunk(load_row_chunk<T, ALIGNED>(W + int64_t(row) * jb.ldw, cir * 8, in_f), cir * 8);
+                    VLMC_WALK_NEXT(row, cir);
+                }
+                __syncthreads();
+                {
+                    // one reservation per workgroup in the job's list (a per-element atomic on one address serialises
+                    // at the memory side: ~30 ns each, 600 of them per linear), then device-scope stores
+                    const uint32_t mine = red[35];
+                    if (tid == 0) red[36] = mine ? atomicAdd(&ws[kCtrl + C_NCAND], mine) : 0u;
+                    __syncthreads();
+                    const uint32_t base = red[36];
+                    for (uint32_t i = tid; i < mine && i < uint32_t(kFusedCand); i += 1024u)
+                        if (base + i < uint32_t(kFusedCand))
+                            __hip_atomic_store(&ws[kCand + base + i], cand[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                VLMC_FSTAMP(4);
+                if (tid == 0) red[34] = grid_arrive_wait(ws, C_BAR_B, jb.nwg) ? 1u : 0u;     // ---- barrier B
+                __syncthreads();
+                fail = red[34] == 0;
+                VLMC_FSTAMP(5);
+                // ---- P3: exact rank `rankb` among the candidates (keys relative to lob, < 2^bshift) ----------
+                const uint32_t ncand = fail ? 0u : ld_dev(&ws[kCtrl + C_NCAND]);
+                if (ncand > uint32_t(kFusedCand)) fail = true;     // heavy ties overflowed the list
+                if (!fail) {
+                    for (uint32_t i = tid; i < ncand; i += 1024u) cand[i] = ld_dev(&ws[kCand + i]);
+                    uint32_t prefix = 0, pmask = 0, r = rankb;
+                    for (int sh = int((bshift - 1u) & ~7u); sh >= 0; sh -= 8) {
+                        if (tid < 256) lh[tid] = 0;
+                        __syncthreads();                          // (also: cand[] complete)
+                        for (uint32_t i = tid; i < ncand; i += 1024u) {
+                            const uint32_t key = cand[i];
+                            if ((key & pmask) == prefix) atomicAdd(&lh[(key >> sh) & 255u], 1u);
+                        }
+                        __syncthreads();
+                        uint32_t hh[4] = {0, 0, 0, 0};
+                        if (tid < 64) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) hh[i] = lh[tid * 4 + i];
+                        }
+                        uint32_t bn, bf;
+                        block_find_rank(hh, r, red, bn, bf);      // r < matching keys by construction
+                        prefix |= bn << sh;
+                        pmask |= 0xFFu << sh;
+                        r -= bf;
+                    }
+                    thr = lob + prefix;
+                }
+            }
+        }
+    }
+    VLMC_FSTAMP(6);
+    // ---- P4: apply --------------------------------------------------------------------------------------
+    auto apply_chunk = [&](Chunk8<T> &c, uint32_t rowu, uint32_t col0) {
+        uint32_t keepbits = 0xFFu;
+        if (!fail) {
+            float sq[8];
+            load_sq(col0, sq);
+            keepbits = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bool pruned = false;
+                if (ALIGNED || col0 + j < in_f)
+                    pruned = stream_key(ieee_mul(fabsf(to_f32<T>(c.v[j])), sq[j])) < thr;
+                keepbits |= (pruned ? 0u : 1u) << j;
+                if (pruned) c.v[j] = typename T::raw(0);
+            }
+        }
+        store_mask_chunk<ALIGNED, true>(jb.mask + int64_t(rowu) * in_f, col0, in_f, keepbits);
+        if (b.apply_zero && keepbits != 0xFFu) store_row_chunk<T, ALIGNED, true>(W + int64_t(rowu) * jb.ldw, col0, in_f, c);
+    };
+    {
+        uint32_t row = row0, cir = cir0;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            if (cb0 + uint32_t(u) * cw.step < cw.total) apply_chunk(raw[u], row, cir * 8);
+            VLMC_WALK_NEXT(row, cir);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (uint32_t cb = cb0 + uint32_t(R) * cw.step; cb < cw.total; cb += cw.step) {
+            Chunk8<T> c = load_row_chunk<T, ALIGNED, true>(W + int64_t(row) * jb.ldw, cir * 8, in_f);
+            apply_chunk(c, row, cir * 8);
+            VLMC_WALK_NEXT(row, cir);
+        }
+    }
+#undef VLMC_WALK_NEXT
+    VLMC_FSTAMP(7);
+    if (tid == 0) {
+        // the resolve launch that follows: nothing to do, or the exact streaming select over the untouched W
+        if (fail) __hip_atomic_store(&ws[kCtrl + C_FAIL], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (wg == 0) __hip_atomic_store(&ws[kCtrl + C_FUSED_OK], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (jb.parts) {
+        dsum = wave_sum_f64(dsum);
+        if ((tid & 63) == 0) dsm[tid >> 6] = dsum;
+        __syncthreads();
+        if (tid == 0) {
+            double a = 0.0;
+            for (int w = 0; w < 16; ++w) a += dsm[w];
+            jb.parts[wg] = a;
+        }
+        if (wg == 0) {
+            for (uint32_t i = jb.nwg + uint32_t(tid); i < uint32_t(kMatrixParts); i += 1024u) jb.parts[i] = 0.0;
         }
     }
 }
@@ -1050,6 +1355,42 @@ static int launch_matrix(const vlmc_select_job *jobs, const int *idx, int n, int
         aligned = aligned && job_aligned(jobs[idx[i]]);
     }
     hipLaunchKernelGGL((matrix_sample_kernel<T>), dim3(unsigned(n)), dim3(1024), 0, st, b);
+    int64_t max_in = 0;
+    for (int i = 0; i < n; ++i) max_in = jobs[idx[i]].in_features > max_in ? jobs[idx[i]].in_features : max_in;
+    if (env_int("VLMC_MATRIX_FUSED", 1) && max_in <= kFusedMaxIn) {
+        // one workgroup per CU at most: co-resident by construction (see matrix_fused_kernel)
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus < n) {
+            set_error("vlmc_wanda_select: cannot query the device's CU count");
+            return VLMC_EHIP;
+        }
+        const int fbudget = env_int("VLMC_MATRIX_FUSED_WGS", cus) < cus ? env_int("VLMC_MATRIX_FUSED_WGS", cus) : cus;
+        uint32_t total = 0;
+        int big = 0;
+        for (int i = 0; i < n; ++i) {
+            const int64_t chunks = jobs[idx[i]].out_features * ((jobs[idx[i]].in_features + 7) / 8);
+            int64_t share = chunks * fbudget / all_chunks;
+            const uint32_t cap = job_wgs(jobs[idx[i]], 1024, kMatrixParts);
+            b.job[i].nwg = uint32_t(share < 1 ? 1 : (share > cap ? cap : share));
+            total += b.job[i].nwg;
+            if (b.job[i].nwg > b.job[big].nwg) big = i;
+        }
+        while (total > uint32_t(fbudget > n ? fbudget : n)) {               // the minimum of one per job overshot the budget
+            big = 0;
+            for (int i = 1; i < n; ++i) if (b.job[i].nwg > b.job[big].nwg) big = i;
+            if (b.job[big].nwg <= 1) break;
+            --b.job[big].nwg; --total;
+        }
+        wgs = 0;
+        for (int i = 0; i < n; ++i) { wgs += b.job[i].nwg; b.job[i].unit_end = wgs; }
+        // chunks a lane keeps in registers (128 VGPRs per lane at 1024 lanes per CU): 14 x 16 B covers a ViT-g block
+        constexpr int R = sizeof(typename T::raw) == 2 ? 14 : 8;
+        if (aligned) hipLaunchKernelGGL((matrix_fused_kernel<T, true, R>), dim3(wgs), dim3(1024), 0, st, b);
+        else hipLaunchKernelGGL((matrix_fused_kernel<T, false, 8>), dim3(wgs), dim3(1024), 0, st, b);
+        hipLaunchKernelGGL((matrix_resolve_kernel<T>), dim3(unsigned(n)), dim3(1024), 0, st, b);
+        return VLMC_OK;
+    }
     if (aligned) {
         hipLaunchKernelGGL((matrix_count_kernel<T, true>), dim3(wgs), dim3(1024), 0, st, b);
         hipLaunchKernelGGL((matrix_apply_kernel<T, true>), dim3(wgs), dim3(1024), 0, st, b);
