@@ -115,7 +115,13 @@ def build_plans(blocks, acts, weights, n_local, world, dev, state):
                 li += 1
         sel = ops.plan_select_batch(ws, sqs, b.mode, ks=ks, apply_zero=True, masks=state["masks"][bi],
                                     partials=state["partials"][bi])
-        n_launch = len({(w.shape[1], k) for w, k in zip(ws, ks)}) if b.mode == "row" else 0
+        n_launch = 0
+        if b.mode == "row":
+            # csrc/wanda_select.hip: 16-bit rows of <= 2048 and of 2049..8192 columns in one call share ONE mixed launch
+            widths = {w.shape[1] for w in ws}
+            mixed = (os.environ.get("VLMC_SELECT_MIXED", "1") != "0" and len(ws) <= 12 and ws[0].element_size() == 2
+                     and max(widths) <= 8192 and min(widths) <= 2048 < max(widths) and all(i % 8 == 0 for i in widths))
+            n_launch = 1 if mixed else len({(w.shape[1], k) for w, k in zip(ws, ks)})
         sbytes = sum(wl.stat_bytes(inp, n_local, acts[bi][ii].element_size()) for ii, inp in enumerate(b.inputs))
         steps.append((stat, upd, sel, b.mode == "row", nbytes, n_launch, sbytes))
     return steps
@@ -311,8 +317,8 @@ def main():
 
     roofline = roof("stat", "vlmc::act_sqnorm_kernel (per-sample squared column norms of every distinct linear input "
                             "of a block, one launch per block)", "act_sqnorm_kernel_bytes_per_launch")
-    roofline["other"] = [roof("rows", "vlmc::select_rows_kernel (score+select+apply, per-row rule; one launch per distinct "
-                                      "in_features of a T5 block)", "select_rows_kernel_bytes_per_launch")]
+    roofline["other"] = [roof("rows", "vlmc::select_rows_mixed_kernel (score+select+apply, per-row rule; all linears of a T5 "
+                                      "block in one launch)", "select_rows_mixed_kernel_bytes_per_launch")]
 
     e2e, n_sets = None, len(sets)
     if args.e2e == "1" or (args.e2e == "auto" and world == 1):

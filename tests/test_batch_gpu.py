@@ -117,6 +117,34 @@ def test_select_batch_equals_single_calls(mode, dtype):
         assert np.array_equal(masks[j].cpu().numpy(), want["mask"]), (mode, j)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shapes", [
+    [(64, 2048), (40, 5120), (33, 2048), (6, 2048)],                       # T5-XL widths: 1 wave / 4 waves x 3 chunks
+    [(16, 4096), (7, 8192), (5, 1024), (9, 2048), (3, 6144), (21, 520)],    # 2 / 4 / 3 chunks per lane, short narrow rows
+])
+def test_select_batch_mixed_row_widths(dtype, shapes):
+    """Narrow (<= 2048 columns) and wide rows of one call share ONE launch (select_rows_mixed_kernel):
+    results must equal the single calls (the tuned per-width kernels) and the oracle, ties and k = 0 / in included."""
+    ops = _ops()
+    cases = [_w(o, i, dtype, 300 + j, zero_frac=0.6 if j == 1 else (0.2 if j == 2 else 0.0)) for j, (o, i) in enumerate(shapes)]
+    Ws = [c[0].clone().to(DEV) for c in cases]
+    sqs = [ops.sqrt_scaler(torch.from_numpy(c[1]).to(DEV)) for c in cases]
+    for ratios in ([0.5] * len(shapes), [0.3, 0.7, 0.0, 1.0, 0.5, 0.9][:len(shapes)]):
+        for W, c in zip(Ws, cases):
+            W.copy_(c[0])
+        ks = [int(i * r) for (_, i), r in zip(shapes, ratios)]
+        masks, parts = ops.wanda_select_batch(Ws, sqs, "row", ks=ks, apply_zero=True)
+        for j, (W, s) in enumerate(cases):
+            m1, W1, p1 = _single(W, s, "row", k=ks[j])
+            assert torch.equal(masks[j], m1), j
+            assert torch.equal(Ws[j], W1), j
+            # fp32 lane sums grouped by another number of waves per row: the importance score's 1e-5 contract
+            assert float(parts[j].sum()) == pytest.approx(float(p1.sum()), rel=1e-6)
+            assert int((~masks[j]).sum()) == ks[j] * shapes[j][0]
+            score = OW.wanda_score(W, s)
+            assert np.array_equal(~masks[j].cpu().numpy(), OW.select_rows(score, ks[j])), j
+
+
 def _check_matrix(W, s, k):
     mask, Wd, parts = _single(W, s, "matrix", k=k)
     score = OW.wanda_score(W, s)

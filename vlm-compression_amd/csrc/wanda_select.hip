@@ -224,20 +224,18 @@ template <int NW> __device__ __forceinline__ void row_sync() {
     }
 }
 
+// One row by the NW waves whose lanes are numbered `tid` = 0 .. 64*NW-1 and who own `sm`.
 template <typename T, int CH, int NW, bool ALIGNED>
-__global__ __launch_bounds__(64 * NW, (NW * CH >= 4 && CH >= 3) ? 5 : 8)
-void select_rows_kernel(const SelBatch b) {
+__device__ __forceinline__ void select_row_body(const SelBatch &b, const SelJob &jb, const uint32_t row32, RowSmem<NW> &sm,
+                                                const int tid) {
     constexpr int NT = 64 * NW;
     constexpr int E = CH * 8;
-    __shared__ RowSmem<NW> sm;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t row32;
-    const SelJob &jb = b.job[find_job(b, blockIdx.x, row32)];
+    const int lane = tid & 63, wave = tid >> 6;
     const int64_t in_f = jb.in_f, row = row32;
     const float *__restrict__ sqrt_scaler = jb.sq;
     uint8_t *__restrict__ mask = jb.mask;
     double *__restrict__ row_sums = jb.parts;
-    const uint32_t k = jb.k, sample_margin = b.p0, frac_q16 = b.p1;
+    const uint32_t k = jb.k, sample_margin = b.p0, frac_q16 = jb.nwg /* k/in as Q16, set by the host */;
     const int apply_zero = b.apply_zero;
     const int64_t nchunks = (in_f + 7) / 8;
     typename T::raw *wrow = static_cast<typename T::raw *>(jb.W) + row * int64_t(jb.ldw);
@@ -483,6 +481,36 @@ void select_rows_kernel(const SelBatch b) {
         atomicAdd(reinterpret_cast<unsigned long long *>(row_sums) + 8, 1ull);
     }
 #endif
+}
+
+template <typename T, int CH, int NW, bool ALIGNED>
+__global__ __launch_bounds__(64 * NW, (NW * CH >= 4 && CH >= 3) ? 5 : 8)
+void select_rows_kernel(const SelBatch b) {
+    __shared__ RowSmem<NW> sm;
+    uint32_t row32;
+    const SelJob &jb = b.job[find_job(b, blockIdx.x, row32)];
+    select_row_body<T, CH, NW, ALIGNED>(b, jb, row32, sm, int(threadIdx.x));
+}
+
+// Rows of two widths in ONE grid of 4-wave workgroups (a T5 block: the 2048-wide rows of q/k/v/o/wi and the
+// 5120-wide rows of wo): a workgroup takes four narrow rows, one per wave (no workgroup barriers), or one wide
+// row with all four waves.  The wide jobs come first in the table, so their longer workgroups start first and
+// the narrow ones fill the tail -- instead of a second, poorly filled launch (2048 workgroups, 1.6 rounds).
+template <typename T, int CHW>
+__global__ __launch_bounds__(256, 5) void select_rows_mixed_kernel(const SelBatch b) {
+    __shared__ union MixedSmem {
+        RowSmem<1> narrow[4];
+        RowSmem<4> wide;
+    } sm;
+    uint32_t unit;
+    const SelJob &jb = b.job[find_job(b, blockIdx.x, unit)];
+    const int tid = threadIdx.x;
+    if (jb.in_f > 2048u) {
+        select_row_body<T, CHW, 4, true>(b, jb, unit, sm.wide, tid);
+    } else {
+        const uint32_t row = unit * 4u + uint32_t(tid >> 6);
+        if (row < jb.out_f) select_row_body<T, 4, 1, true>(b, jb, row, sm.narrow[tid >> 6], tid & 63);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1284,12 +1312,13 @@ static int launch_rows(const vlmc_select_job *jobs, const int *idx, int n, int a
     SelBatch b;
     b.n = n; b.apply_zero = apply_zero;
     b.p0 = uint32_t(env_int("VLMC_SELECT_SAMPLE_MARGIN", 9));          // ~ +-3 sigma of a 32-sample rank
-    b.p1 = uint32_t((uint64_t(j0.k) << 16) / uint64_t(in_f));
+    b.p1 = 0;
     int64_t rows = 0;
     for (int i = 0; i < n; ++i) {
         fill_job(b.job[i], jobs[idx[i]]);
         rows += jobs[idx[i]].out_features;
         b.job[i].unit_end = uint32_t(rows);
+        b.job[i].nwg = uint32_t((uint64_t(jobs[idx[i]].k) << 16) / uint64_t(in_f));
     }
     const bool aligned = job_aligned(j0);
 #define VLMC_ROWS(CH, NW, AL) \
@@ -1322,6 +1351,49 @@ static int launch_rows(const vlmc_select_job *jobs, const int *idx, int n, int a
     }
 #undef VLMC_ROWS_NW
 #undef VLMC_ROWS
+    return VLMC_OK;
+}
+
+// All SEL_ROW jobs of a call in one mixed launch: possible when every job is 16-byte aligned, every row fits
+// 4 waves x 4 chunks (in <= 8192) and both widths occur (one width alone: launch_rows is the tuned path).
+static bool mixed_rows_eligible(const vlmc_select_job *jobs, int n_jobs) {
+    if (n_jobs < 2 || n_jobs > kMaxSelJobs || !env_int("VLMC_SELECT_MIXED", 1)) return false;
+    bool narrow = false, wide = false;
+    for (int i = 0; i < n_jobs; ++i) {
+        if (!job_aligned(jobs[i]) || jobs[i].in_features > 8192) return false;
+        (jobs[i].in_features > 2048 ? wide : narrow) = true;
+    }
+    return narrow && wide;
+}
+
+template <typename T>
+static int launch_rows_mixed(const vlmc_select_job *jobs, int n_jobs, int apply_zero, hipStream_t st) {
+    SelBatch b;
+    b.n = n_jobs; b.apply_zero = apply_zero;
+    b.p0 = uint32_t(env_int("VLMC_SELECT_SAMPLE_MARGIN", 9));
+    b.p1 = 0;
+    uint32_t units = 0;
+    int64_t max_chunks = 0;
+    int n = 0;
+    for (int pass = 0; pass < 2; ++pass) {                      // wide jobs first
+        for (int i = 0; i < n_jobs; ++i) {
+            const vlmc_select_job &j = jobs[i];
+            const bool is_wide = j.in_features > 2048;
+            if (is_wide != (pass == 0)) continue;
+            fill_job(b.job[n], j);
+            units += uint32_t(is_wide ? j.out_features : (j.out_features + 3) / 4);
+            b.job[n].unit_end = units;
+            b.job[n].nwg = uint32_t((uint64_t(j.k) << 16) / uint64_t(j.in_features));
+            if (is_wide && (j.in_features + 7) / 8 > max_chunks) max_chunks = (j.in_features + 7) / 8;
+            ++n;
+        }
+    }
+    const int chw = int((max_chunks + 255) / 256);
+    switch (chw) {
+        case 2: hipLaunchKernelGGL((select_rows_mixed_kernel<T, 2>), dim3(units), dim3(256), 0, st, b); break;
+        case 3: hipLaunchKernelGGL((select_rows_mixed_kernel<T, 3>), dim3(units), dim3(256), 0, st, b); break;
+        default: hipLaunchKernelGGL((select_rows_mixed_kernel<T, 4>), dim3(units), dim3(256), 0, st, b); break;
+    }
     return VLMC_OK;
 }
 
@@ -1438,6 +1510,14 @@ static int select_typed(const vlmc_select_job *jobs, int n_jobs, int mode, int p
     // launch groups: consecutive runs of <= kMaxSelJobs jobs; SEL_ROW additionally needs equal (in, k, alignment).
     // (Running the groups of one call side by side on a second stream was measured: the event fork/join costs
     // more than the overlap of T5's small `wo` group with the large one gains -- 46 vs 35 us per block.)
+    if constexpr (sizeof(typename T::raw) == 2) {              // (fp32 rows need twice the registers: separate launches)
+        if (mode == VLMC_SEL_ROW && mixed_rows_eligible(jobs, n_jobs)) {
+            const int rc = launch_rows_mixed<T>(jobs, n_jobs, apply_zero, st);
+            if (rc != VLMC_OK) return rc;
+            VLMC_HIP_CHECK_LAUNCH("vlmc_wanda_select");
+            return VLMC_OK;
+        }
+    }
     int idx[kMaxSelJobs];
     bool done[256] = {false};
     for (int s0 = 0; s0 < n_jobs; ++s0) {
