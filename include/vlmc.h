@@ -108,7 +108,10 @@ int vlmc_wanda_scaler_update_batch(const vlmc_update_job *jobs /* host array */,
  *                         device reduction per transformer block instead of one launch per
  *                         linear.  `vlmc_wanda_select_partials()` gives the count; may be NULL.
  * `k` is computed by the caller exactly like the reference (int(in*ratio) or
- * int(out*in*ratio)).  Only SEL_MATRIX needs a workspace (else size 0, NULL is fine).
+ * int(out*in*ratio)).  Only SEL_MATRIX needs a workspace (else size 0, NULL is fine).  A SEL_MATRIX
+ * workspace must be ZERO-FILLED when it is first handed to the library (hipMemset once after allocating
+ * it); every call returns it zero-filled again, so it can be reused as is.  (The workgroups of one launch
+ * agree on the threshold through counters in it; clearing them inside the call would cost a launch.)
  *
  * vlmc_wanda_select_batch does the same for several linears -- the `for name in subset` loop of
  * wanda_pruner.py:316-341 -- with as few launches as the shapes allow (SEL_ROW: one per distinct

@@ -596,6 +596,70 @@ __device__ __forceinline__ uint32_t coarse_bin(uint32_t key) {
     return b < uint32_t(kMatBins) ? b : uint32_t(kMatBins - 1);   // NaN keys (0xFFFFFFFF) -> last bin
 }
 
+// The sample of a job: kMatSample elements drawn uniformly with replacement, (row, col) = two multiplicative hashes
+// of the sample index scaled by mul-high (no integer division).  `issue` starts the loads, `finish` turns them into
+// the bracket [lo, lo + 2048 * 2^shift) around flat rank k (6-sigma margin, resolved to whole coarse bins).
+// Every workgroup that runs this on the same W gets the same bracket.
+constexpr int kSamplesPerThread = kMatSample / 1024;
+template <typename T> struct SampleRegs {
+    uint32_t col[kSamplesPerThread];
+    typename T::raw wv[kSamplesPerThread];
+};
+template <typename T>
+__device__ __forceinline__ void sample_issue(const SelJob &jb, int tid, SampleRegs<T> &r) {
+    const uint32_t numel = jb.out_f * jb.in_f;
+    const uint32_t S = numel < uint32_t(kMatSample) ? numel : uint32_t(kMatSample);
+    const typename T::raw *W = static_cast<const typename T::raw *>(jb.W);
+#pragma unroll
+    for (int j = 0; j < kSamplesPerThread; ++j) {
+        const uint32_t i = uint32_t(tid) + 1024u * j;
+        uint32_t h = (i + 1u) * 2654435761u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const uint32_t row = __umulhi(h, jb.out_f);
+        h *= 3266489917u; h ^= h >> 16;
+        r.col[j] = __umulhi(h, jb.in_f);
+        const bool on = i < S;
+        r.col[j] = on ? r.col[j] : 0u;
+        r.wv[j] = W[on ? int64_t(row) * jb.ldw + r.col[j] : 0];
+    }
+}
+// hist: kMatBins LDS counters, zeroed and synchronised by the caller; sq: sqrt(scaler_row) (global or LDS)
+template <typename T>
+__device__ __forceinline__ void sample_finish(const SelJob &jb, int tid, const SampleRegs<T> &r, const float *sq, uint32_t *hist,
+                                              uint32_t *red, uint32_t &lo, uint32_t &shift) {
+    const uint32_t numel = jb.out_f * jb.in_f;
+    const uint32_t S = numel < uint32_t(kMatSample) ? numel : uint32_t(kMatSample);
+    float sv[kSamplesPerThread];
+#pragma unroll
+    for (int j = 0; j < kSamplesPerThread; ++j) sv[j] = sq[r.col[j]];
+#pragma unroll
+    for (int j = 0; j < kSamplesPerThread; ++j)
+        if (uint32_t(tid) + 1024u * j < S)
+            atomicAdd(&hist[coarse_bin(score_key(ieee_mul(fabsf(to_f32<T>(r.wv[j])), sv[j])))], 1u);
+    __syncthreads();
+    const uint32_t rs = uint32_t((uint64_t(jb.k) * S) / numel);
+    const float pr = float(jb.k) / float(numel);
+    const uint32_t margin = uint32_t(6.f * sqrtf(float(S) * pr * (1.f - pr))) + 8u;
+    uint32_t h[4] = {0, 0, 0, 0};
+    if (tid < kMatBins / 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = hist[tid * 4 + i];
+    }
+    uint32_t hi = 0xFFFFFFFFu, bin, before;
+    lo = 0;
+    if (rs > margin) {
+        block_find_rank(h, rs - margin, red, bin, before);
+        lo = bin << kCoarseShift;
+    }
+    if (rs + margin < S) {
+        block_find_rank(h, rs + margin, red, bin, before);
+        if (bin < uint32_t(kMatBins - 1)) hi = ((bin + 1u) << kCoarseShift) - 1u;
+    }
+    shift = 0;
+    while (((hi - lo) >> shift) >= uint32_t(kMatBins)) ++shift;
+}
+
+// Four-launch form only: one workgroup per job clears the job's histogram and control words and publishes the bracket.
 template <typename T>
 __global__ __launch_bounds__(1024) void matrix_sample_kernel(const SelBatch b) {
     __shared__ uint32_t hist[kMatBins];
@@ -605,55 +669,11 @@ __global__ __launch_bounds__(1024) void matrix_sample_kernel(const SelBatch b) {
     uint32_t *ws = jb.ws;
     for (int i = tid; i < kCand; i += 1024) ws[i] = 0;           // histogram + control words
     for (int i = tid; i < kMatBins; i += 1024) hist[i] = 0;
+    SampleRegs<T> sr;
+    sample_issue<T>(jb, tid, sr);
     __syncthreads();                                             // ctrl words are rewritten below
-    const uint32_t numel = jb.out_f * jb.in_f;
-    const uint32_t S = numel < uint32_t(kMatSample) ? numel : uint32_t(kMatSample);
-    // uniform sampling with replacement: (row, col) = two multiplicative hashes scaled by mul-high (no integer
-    // division: this single workgroup is instruction-bound); all loads of a lane are issued before the first use
-    const typename T::raw *W = static_cast<const typename T::raw *>(jb.W);
-    constexpr int SPT = kMatSample / 1024;                       // samples per thread
-    uint32_t col[SPT];
-    typename T::raw wv[SPT];
-    float sv[SPT];
-#pragma unroll
-    for (int j = 0; j < SPT; ++j) {
-        const uint32_t i = uint32_t(tid) + 1024u * j;
-        uint32_t h = (i + 1u) * 2654435761u;
-        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-        const uint32_t row = __umulhi(h, jb.out_f);
-        h *= 3266489917u; h ^= h >> 16;
-        col[j] = __umulhi(h, jb.in_f);
-        const bool on = i < S;
-        col[j] = on ? col[j] : 0u;
-        wv[j] = W[on ? int64_t(row) * jb.ldw + col[j] : 0];
-    }
-#pragma unroll
-    for (int j = 0; j < SPT; ++j) sv[j] = jb.sq[col[j]];
-#pragma unroll
-    for (int j = 0; j < SPT; ++j)
-        if (uint32_t(tid) + 1024u * j < S)
-            atomicAdd(&hist[coarse_bin(score_key(ieee_mul(fabsf(to_f32<T>(wv[j])), sv[j])))], 1u);
-    __syncthreads();
-    // sample ranks that bracket flat rank k with a 6-sigma margin, resolved to whole coarse bins
-    const uint32_t rs = uint32_t((uint64_t(jb.k) * S) / numel);
-    const float pr = float(jb.k) / float(numel);
-    const uint32_t margin = uint32_t(6.f * sqrtf(float(S) * pr * (1.f - pr))) + 8u;
-    uint32_t h[4] = {0, 0, 0, 0};
-    if (tid < kMatBins / 4) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) h[i] = hist[tid * 4 + i];
-    }
-    uint32_t lo = 0, hi = 0xFFFFFFFFu, bin, before;
-    if (rs > margin) {
-        block_find_rank(h, rs - margin, red, bin, before);
-        lo = bin << kCoarseShift;
-    }
-    if (rs + margin < S) {
-        block_find_rank(h, rs + margin, red, bin, before);
-        if (bin < uint32_t(kMatBins - 1)) hi = ((bin + 1u) << kCoarseShift) - 1u;
-    }
-    uint32_t shift = 0;
-    while (((hi - lo) >> shift) >= uint32_t(kMatBins)) ++shift;
+    uint32_t lo, shift;
+    sample_finish<T>(jb, tid, sr, jb.sq, hist, red, lo, shift);
     if (tid == 0) {
         ws[kCtrl + C_LO] = lo;
         ws[kCtrl + C_SHIFT] = shift;
@@ -854,10 +874,7 @@ __global__ __launch_bounds__(1024) void matrix_apply_kernel(const SelBatch b) {
 //   fallback  the bracket missed rank k (everything is undecided) or the bin overflowed the list: the same
 //             select, but streaming the matrix (4 x 8-bit radix over the keys inside [lob, lob + width))
 template <typename T>
-__global__ __launch_bounds__(1024) void matrix_resolve_kernel(const SelBatch b) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t red[20];
-    const SelJob &jb = b.job[blockIdx.x];
+__device__ void matrix_resolve_job(const SelBatch &b, const SelJob &jb, uint32_t *hist, uint32_t *red) {
     uint32_t *ws = jb.ws;
     const int tid = threadIdx.x;
     if (ws[kCtrl + C_NONE]) return;
@@ -907,6 +924,23 @@ __global__ __launch_bounds__(1024) void matrix_resolve_kernel(const SelBatch b) 
     }
 }
 
+// One workgroup per job, last launch of a SEL_MATRIX call: decides what the earlier launches left undecided, then
+// leaves the job's histogram and control words ZERO -- the state the fused kernel expects to find (include/vlmc.h:
+// a SEL_MATRIX workspace is zero-filled when first handed over and is returned zero-filled by every call).
+template <typename T>
+__global__ __launch_bounds__(1024) void matrix_resolve_kernel(const SelBatch b) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t red[20];
+    const SelJob &jb = b.job[blockIdx.x];
+    matrix_resolve_job<T>(b, jb, hist, red);
+    __syncthreads();
+#ifdef VLMC_FUSED_STAMPS
+    for (int i = threadIdx.x; i < kCtrl + 16; i += 1024) jb.ws[i] = 0;       // (keep the phase clocks)
+#else
+    for (int i = threadIdx.x; i < kCand; i += 1024) jb.ws[i] = 0;
+#endif
+}
+
 // ------------------------------------------------------------------------------------------
 // SEL_MATRIX, fused form (default): count + candidates + apply in ONE launch of co-resident workgroups.
 //
@@ -914,6 +948,9 @@ __global__ __launch_bounds__(1024) void matrix_resolve_kernel(const SelBatch b) 
 // (256 CUs x 512 KB): every lane loads its R 16-byte chunks ONCE, keeps them in VGPRs, and the threshold
 // is agreed on through two grid barriers per linear, so W is read once and mask / zeroed W written once
 // -- exactly the 5 B / weight of SURVEY 8(d) instead of 7 B, and one launch instead of three.
+//   P0  every workgroup draws the job's 2048-element sample itself (same hashes => same bracket [lo, lo + 2048 * 2^s)
+//       everywhere, nothing to exchange); the sample's loads are issued before the row chunks, its histogram and
+//       rank search run while the chunks stream in
 //   P1  load R chunks per lane (chunks past R x grid are streamed and re-read in the later phases);
 //       count(key < lo), 2048-bin LDS histogram of the sampled bracket, score partial sums; flush the
 //       histogram with device-scope atomics                                          -- barrier A
@@ -928,6 +965,7 @@ __global__ __launch_bounds__(1024) void matrix_resolve_kernel(const SelBatch b) 
 // bounded spin runs out, the waiters raise the fail bit, everybody leaves W untouched and writes an all-keep
 // mask, and the resolve launch that follows does the exact streaming select (its fallback mode).  Every
 // wave therefore reaches the end of the kernel whatever the residency.
+// The job's global histogram and control words must be ZERO on entry; the resolve launch zeroes them again.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kBarFail = 0x80000000u;
 constexpr int kFusedCand = 4096;                 // candidate keys a workgroup can hold (more => exact fallback)
@@ -971,11 +1009,13 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
     const SelJob &jb = b.job[find_job(b, blockIdx.x, wg)];
     const int tid = threadIdx.x;
     uint32_t *ws = jb.ws;
-    const uint4 c0 = reinterpret_cast<const uint4 *>(ws + kCtrl)[0], c1 = reinterpret_cast<const uint4 *>(ws + kCtrl)[1];
-    bool fail = c1.w != 0;                                       // C_FAIL: forced by the sample launch (test hook)
-    const uint32_t lo = c0.x /* C_LO */, bshift = c0.y /* C_SHIFT */;
+    bool fail = b.p0 != 0;                                       // test hook: force the fallback
     const uint32_t in_f = jb.in_f;
     typename T::raw *W = static_cast<typename T::raw *>(jb.W);
+    // ---- P0: the sample's loads go out first, its bracket is computed while the row chunks stream in ----------
+    SampleRegs<T> sr;
+    sample_issue<T>(jb, tid, sr);
+    for (uint32_t i = tid; i < in_f; i += 1024u) sqs[i] = jb.sq[i];
     const ChunkWalk cw(jb);
     const uint32_t cb0 = wg * 1024u + uint32_t(tid);
     const uint32_t row0 = cb0 / cw.cpr, cir0 = cb0 - row0 * cw.cpr;
@@ -995,7 +1035,10 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
         }
     }
     for (int i = tid; i < kMatBins; i += 1024) lh[i] = 0;
-    for (uint32_t i = tid; i < in_f; i += 1024u) sqs[i] = jb.sq[i];
+    __syncthreads();
+    uint32_t lo, bshift;
+    sample_finish<T>(jb, tid, sr, sqs, lh, red, lo, bshift);     // (ends with a workgroup barrier)
+    for (int i = tid; i < kMatBins; i += 1024) lh[i] = 0;
     __syncthreads();
     auto load_sq = [&](uint32_t col0, float *o) {
         if constexpr (ALIGNED) {
@@ -1426,7 +1469,6 @@ static int launch_matrix(const vlmc_select_job *jobs, const int *idx, int n, int
         b.job[i].unit_end = wgs;
         aligned = aligned && job_aligned(jobs[idx[i]]);
     }
-    hipLaunchKernelGGL((matrix_sample_kernel<T>), dim3(unsigned(n)), dim3(1024), 0, st, b);
     int64_t max_in = 0;
     for (int i = 0; i < n; ++i) max_in = jobs[idx[i]].in_features > max_in ? jobs[idx[i]].in_features : max_in;
     if (env_int("VLMC_MATRIX_FUSED", 1) && max_in <= kFusedMaxIn) {
@@ -1463,6 +1505,7 @@ static int launch_matrix(const vlmc_select_job *jobs, const int *idx, int n, int
         hipLaunchKernelGGL((matrix_resolve_kernel<T>), dim3(unsigned(n)), dim3(1024), 0, st, b);
         return VLMC_OK;
     }
+    hipLaunchKernelGGL((matrix_sample_kernel<T>), dim3(unsigned(n)), dim3(1024), 0, st, b);
     if (aligned) {
         hipLaunchKernelGGL((matrix_count_kernel<T, true>), dim3(wgs), dim3(1024), 0, st, b);
         hipLaunchKernelGGL((matrix_apply_kernel<T, true>), dim3(wgs), dim3(1024), 0, st, b);

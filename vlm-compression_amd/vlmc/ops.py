@@ -37,9 +37,10 @@ class Workspace:
     """Grow-only device scratch buffers for one purpose, one per (device, stream): calls on different streams
     or devices never share scratch memory, calls on one stream are ordered by the stream itself."""
 
-    def __init__(self):
+    def __init__(self, zeroed: bool = False):
         self._bufs = {}
         self._lock = threading.Lock()
+        self._alloc = torch.zeros if zeroed else torch.empty     # SEL_MATRIX workspaces: zero-filled at first use (vlmc.h)
 
     def get(self, nbytes: int, device) -> torch.Tensor:
         device = torch.device(device)
@@ -47,11 +48,11 @@ class Workspace:
         with self._lock:
             buf = self._bufs.get(key)
             if buf is None or buf.numel() < nbytes:
-                buf = self._bufs[key] = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+                buf = self._bufs[key] = self._alloc(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
             return buf
 
 
-_select_ws = Workspace()
+_select_ws = Workspace(zeroed=True)
 _MODES = {"row": _lib.SEL_ROW, "matrix": _lib.SEL_MATRIX, "nm": _lib.SEL_NM}
 
 
@@ -195,7 +196,7 @@ def wanda_scaler_update_batch(scalers, nsamples_before: int, normsqs, batch: int
     return nsamples_before + calls * batch
 
 
-_batch_ws = Workspace()
+_batch_ws = Workspace(zeroed=True)
 
 
 def _select_jobs(weights, sqrt_rows, code, ks, masks, partials, ws_holder):
@@ -345,7 +346,7 @@ def plan_select_batch(weights, sqrt_rows, mode: str, *, ks=None, n=0, m=0, apply
     """Pre-bound batched select.  The plan owns its SEL_MATRIX workspace (plans may be replayed in any order)."""
     code = _MODES[mode]
     ks = [0] * len(weights) if ks is None else ks
-    holder = Workspace()
+    holder = Workspace(zeroed=True)
     jobs = _select_jobs(weights, sqrt_rows, code, ks, masks, partials, holder)
     run = _bind(_lib.load().vlmc_wanda_select_batch, (jobs, len(weights), _dtype_code(weights[0]), code, int(n), int(m),
                                                      int(bool(apply_zero)), _stream()))
