@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--e2e", default="auto", choices=["auto", "0", "1"],
                     help="also time one whole drop-in blipt5_wanda_pruner.prune() on the synthetic InstructBLIP-FlanT5-XL "
                          "(auto: only at N=1)")
+    ap.add_argument("--event-stride", type=int, default=4,
+                    help="HIP events on every N-th block of a step, rotating with the step (1 = every launch; a timed "
+                         "launch idles the GPU for ~10 us)")
     ap.add_argument("--weight-sets", type=int, default=0, help="dense weight copies kept in HBM (0 = steps+warmup, capped by memory)")
     return ap.parse_args()
 
@@ -152,16 +155,55 @@ def alloc_state(blocks, n_local, world, dev):
     return st
 
 
-def run_step(plans, state, world, events=None):
-    """events = {"stat": [...], "rows": [...]} collects (start, stop, algorithmic bytes, launches) on the
-    launch stream around the statistics launch of every block and the per-row select launches of the T5 blocks."""
-    ev = torch.cuda.Event
+class HipEvents:
+    """HIP events of the runtime this process has loaded (ctypes on libamdhip64), handed to the kernel launch itself
+    (vlmc_set_launch_events -> hipExtLaunchKernel): start / stop are the kernel's own begin / end on its stream.
+    An hipEventRecord between two kernels (torch.cuda.Event.record) costs ~5 us of idle GPU per record on MI355X --
+    270 records per step were 11 % of the step; this form costs nothing."""
+
+    def __init__(self):
+        import ctypes
+        path = "libamdhip64.so"
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
+        self.ct, self.hip = ctypes, ctypes.CDLL(path)
+        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+
+    def new(self):
+        e = self.ct.c_void_p()
+        rc = self.hip.hipEventCreate(self.ct.byref(e))
+        if rc != 0 or not e.value:
+            raise RuntimeError(f"hipEventCreate failed ({rc})")
+        return e
+
+    def elapsed_ms(self, a, b):
+        ms = self.ct.c_float()
+        rc = self.hip.hipEventElapsedTime(self.ct.byref(ms), a, b)
+        if rc != 0:
+            raise RuntimeError(f"hipEventElapsedTime failed ({rc})")
+        return float(ms.value)
+
+    def free(self, *evs):
+        for e in evs:
+            self.hip.hipEventDestroy(e)
+
+
+def run_step(plans, state, world, events=None, hipev=None, set_events=None, phase=0, stride=1):
+    """events = {"stat": [...], "rows": [...]} collects (start, stop, algorithmic bytes, launches): HIP events carried by
+    the statistics launch and by the per-row select launch of a block, on the launch stream.  A launch that carries
+    events is preceded and followed by ~5 us of idle GPU (its completion signal is waited for), so only every
+    `stride`-th block of a step is timed, rotating with the step index: every launch is covered once per `stride` steps."""
     for bi, (stat, upd, sel, is_row, nbytes, n_launch, sbytes) in enumerate(plans):
-        if events is not None:
-            a, b = ev(enable_timing=True), ev(enable_timing=True)
-            a.record()
+        timed = events is not None and (bi + phase) % stride == 0
+        if timed:
+            a, b = hipev.new(), hipev.new()
+            set_events(a, b)
             stat()
-            b.record()
             events["stat"].append((a, b, sbytes, 1))
         else:
             stat()
@@ -169,11 +211,10 @@ def run_step(plans, state, world, events=None):
             flat_local, flat_all = state["flat"][bi]
             dist.all_gather_into_tensor(flat_all, flat_local)
         upd()
-        if events is not None and is_row:
-            a, b = ev(enable_timing=True), ev(enable_timing=True)
-            a.record()
+        if timed and is_row and n_launch == 1:
+            a, b = hipev.new(), hipev.new()
+            set_events(a, b)
             sel()
-            b.record()
             events["rows"].append((a, b, nbytes, n_launch))
         else:
             sel()
@@ -284,9 +325,12 @@ def main():
         run_step(plans[i % len(plans)], state, world)
     sync()
     events = {"stat": [], "rows": []}
+    hipev = HipEvents()
+    set_events = _lib.load().vlmc_set_launch_events
     t0 = time.perf_counter()
     for i in range(args.steps):
-        run_step(plans[(args.warmup + i) % len(plans)], state, world, events)
+        run_step(plans[(args.warmup + i) % len(plans)], state, world, events, hipev, set_events, phase=i,
+                 stride=max(1, args.event_stride))
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -306,13 +350,15 @@ def main():
 
     def roof(kind, kernel, tkey):
         evs = events[kind]
-        tot_ms = sum(a.elapsed_time(b) for a, b, _, _ in evs)
+        tot_ms = sum(hipev.elapsed_ms(a, b) for a, b, _, _ in evs)
         tot_bytes = sum(nb for _, _, nb, _ in evs)
         n_launches = sum(nl for _, _, _, nl in evs)
         ach = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
         return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(tkey), "launches": n_launches,
                 "avg_launch_us": round(tot_ms * 1e3 / max(1, n_launches), 2),
+                "timed": f"HIP events carried by the launch (hipExtLaunchKernel) on every {max(1, args.event_stride)}-th block "
+                         f"of a step, rotating with the step index",
                 "bytes_per_launch": round(tot_bytes / max(1, n_launches))}
 
     roofline = roof("stat", "vlmc::act_sqnorm_kernel (per-sample squared column norms of every distinct linear input "

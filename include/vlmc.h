@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLMC_ABI_VERSION 1
+#define VLMC_ABI_VERSION 2
 
 #define VLMC_OK 0
 #define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
@@ -50,6 +50,14 @@ extern "C" {
 
 int vlmc_abi_version(void);
 const char *vlmc_last_error(void);
+
+/* Timing hook for benchmarks (no reference counterpart): the next statistics or select kernel launched from the
+ * calling thread -- vlmc_act_sqnorm[_batch], vlmc_wanda_select[_batch] (first launch of the call) -- records its own
+ * begin / end timestamps into the caller's HIP events (hipEvent_t, created by the caller with timing enabled) through
+ * hipExtLaunchKernel: hipEventElapsedTime(start, stop) is then the kernel's duration, and no marker packet sits
+ * between kernels (hipEventRecord between two kernels idles an MI355X for ~5 us).  Either event may be NULL; the pair
+ * is consumed by that one launch. */
+void vlmc_set_launch_events(void *start_event, void *stop_event);
 
 /* ---- K1: activation statistics ------------------------------------------------
  * Replaces the body of WrappedGPT.add_batch, wanda_pruner.py:68-81

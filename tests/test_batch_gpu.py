@@ -191,6 +191,43 @@ def test_matrix_select_extreme_ranks_and_nan():
     _check_matrix(W, s2, W.numel() // 3)
 
 
+def test_matrix_select_two_streams_compete_for_the_cus():
+    """The fused matrix-wide kernel wants one workgroup per CU resident at the same time.  Two streams launching
+    it concurrently can each get only part of the chip: the bounded barrier wait must then run out and hand the
+    job to the exact streaming fallback (slow, never a hang, never a wrong mask)."""
+    ops = _ops()
+    shapes = [(1408, 1408), (1408, 6144), (4224, 1408)]
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    runs = []
+    for si, st in enumerate(streams):
+        cases = [_w(o, i, torch.float16, 400 + 10 * si + j) for j, (o, i) in enumerate(shapes)]
+        with torch.cuda.stream(st):
+            Ws = [c[0].clone().to(DEV) for c in cases]
+            sqs = [ops.sqrt_scaler(torch.from_numpy(c[1]).to(DEV)) for c in cases]
+            masks = [torch.empty(w.shape, dtype=torch.bool, device=DEV) for w in Ws]
+            parts = [torch.empty(ops.select_partials("matrix", *w.shape), dtype=torch.float64, device=DEV) for w in Ws]
+            ks = [int(w.numel() * 0.5) for w in Ws]
+            plan = ops.plan_select_batch(Ws, sqs, "matrix", ks=ks, apply_zero=True, masks=masks, partials=parts)
+        runs.append((cases, Ws, masks, ks, plan))
+    torch.cuda.synchronize()
+    for rep in range(3):                                        # (re-pruning pruned weights: heavy ties as well)
+        for (cases, Ws, masks, ks, plan), st in zip(runs, streams):
+            with torch.cuda.stream(st):
+                if rep < 2:
+                    for W, c in zip(Ws, cases):
+                        W.copy_(c[0], non_blocking=True)
+                plan()
+        torch.cuda.synchronize()
+        if rep < 2:
+            for cases, Ws, masks, ks, plan in runs:
+                for (W, s), Wd, mk, k in zip(cases, Ws, masks, ks):
+                    pruned = OW.select_matrix(OW.wanda_score(W, s), k)
+                    assert np.array_equal(mk.cpu().numpy(), ~pruned)
+                    want = W.clone()
+                    want[torch.from_numpy(pruned)] = 0
+                    assert torch.equal(Wd.cpu(), want)
+
+
 def test_select_batch_rejects_shared_workspace_and_bad_args():
     from vlmc import _lib
     ops = _ops()

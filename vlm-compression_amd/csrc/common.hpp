@@ -3,6 +3,7 @@
 // makes mask indices bit-identical to the reference's PyTorch path.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <atomic>
 #include <cstdarg>
@@ -131,6 +132,18 @@ struct PerDeviceOnce {
         if (dev < 64) done.fetch_or(uint64_t(1) << dev, std::memory_order_release);
     }
 };
+
+// Timing hook (vlmc_set_launch_events): the NEXT timed kernel launched from this thread carries the caller's HIP
+// events in its own dispatch (hipExtLaunchKernel): start / stop are the kernel's begin / end timestamps, and no marker
+// packet is put between kernels (an hipEventRecord between two kernels idles the GPU for ~5 us on MI355X).
+struct LaunchEvents { hipEvent_t start, stop; };
+LaunchEvents take_launch_events();                 // returns the pending pair (nullptr, nullptr if none) and clears it
+#define VLMC_LAUNCH_TIMED(kernel, grid, block, stream, ...)                                                  \
+    do {                                                                                                     \
+        const ::vlmc::LaunchEvents ev_ = ::vlmc::take_launch_events();                                       \
+        if (ev_.start || ev_.stop) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ev_.start, ev_.stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                \
+    } while (0)
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -214,7 +214,7 @@ static int launch_sqnorm(const vlmc_stat_job *jobs, int n_jobs, int64_t n_calls,
             set_error("vlmc_act_sqnorm: grid too large");
             return VLMC_EINVAL;
         }
-        hipLaunchKernelGGL((act_sqnorm_kernel<T>), dim3(unsigned(wgs)), dim3(64), 0, st, b);
+        VLMC_LAUNCH_TIMED((act_sqnorm_kernel<T>), dim3(unsigned(wgs)), dim3(64), st, b);
     }
     VLMC_HIP_CHECK_LAUNCH("vlmc_act_sqnorm");
     return VLMC_OK;

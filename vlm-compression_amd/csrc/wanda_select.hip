@@ -873,13 +873,15 @@ __global__ __launch_bounds__(1024) void matrix_apply_kernel(const SelBatch b) {
 //   normal    the <= 8192 candidates of the final bin: exact rank select in LDS, prune those below the threshold
 //   fallback  the bracket missed rank k (everything is undecided) or the bin overflowed the list: the same
 //             select, but streaming the matrix (4 x 8-bit radix over the keys inside [lob, lob + width))
-template <typename T>
+// WRITE_ALL (the fused kernel's own fallback): nothing has been written yet -- select over the whole matrix and
+// write EVERY mask byte, without looking at the control words.
+template <typename T, bool WRITE_ALL>
 __device__ void matrix_resolve_job(const SelBatch &b, const SelJob &jb, uint32_t *hist, uint32_t *red) {
     uint32_t *ws = jb.ws;
     const int tid = threadIdx.x;
-    if (ws[kCtrl + C_NONE]) return;
-    const uint32_t fail = ws[kCtrl + C_FAIL], ncand = ws[kCtrl + C_NCAND], shift = ws[kCtrl + C_SHIFT];
-    if (!fail && ws[kCtrl + C_FUSED_OK]) return;                // the fused kernel decided everything itself
+    if (!WRITE_ALL && ws[kCtrl + C_NONE]) return;
+    const uint32_t fail = WRITE_ALL ? 1u : ws[kCtrl + C_FAIL];
+    const uint32_t ncand = WRITE_ALL ? 0u : ws[kCtrl + C_NCAND], shift = WRITE_ALL ? 0u : ws[kCtrl + C_SHIFT];
     const bool from_list = !fail && ncand <= uint32_t(kCandCap);
     if (!fail && (shift == 0 || ncand == 0)) return;            // nothing was left undecided
     const uint32_t lob = fail ? 0u : ws[kCtrl + C_LOB];
@@ -912,19 +914,23 @@ __device__ void matrix_resolve_job(const SelBatch &b, const SelJob &jb, uint32_t
         r -= before;
     }
     const uint32_t thr = prefix;
-    if (thr == 0xFFFFFFFFu) return;                              // NaN threshold (fallback path): prunes nothing
+    const bool none = thr == 0xFFFFFFFFu;                        // NaN threshold (fallback path): prunes nothing
+    if (none && !WRITE_ALL) return;
     for (uint32_t i = tid; i < n_items; i += 1024u) {
         const uint32_t key = key_of(i);
-        if (undecided(key) && key < thr) {
+        const bool pruned = !none && undecided(key) && key < thr;
+        if (pruned || WRITE_ALL) {
             const uint32_t e = from_list ? ws[kCand + 2 * i] : i;
-            const uint32_t row = e / jb.in_f, col = e - row * jb.in_f;
-            jb.mask[e] = 0;
-            if (b.apply_zero) W[int64_t(row) * jb.ldw + col] = typename T::raw(0);
+            jb.mask[e] = pruned ? 0 : 1;
+            if (pruned && b.apply_zero) {
+                const uint32_t row = e / jb.in_f, col = e - row * jb.in_f;
+                W[int64_t(row) * jb.ldw + col] = typename T::raw(0);
+            }
         }
     }
 }
 
-// One workgroup per job, last launch of a SEL_MATRIX call: decides what the earlier launches left undecided, then
+// One workgroup per job, last launch of the four-launch form: decides what the earlier launches left undecided, then
 // leaves the job's histogram and control words ZERO -- the state the fused kernel expects to find (include/vlmc.h:
 // a SEL_MATRIX workspace is zero-filled when first handed over and is returned zero-filled by every call).
 template <typename T>
@@ -932,7 +938,7 @@ __global__ __launch_bounds__(1024) void matrix_resolve_kernel(const SelBatch b) 
     __shared__ uint32_t hist[256];
     __shared__ uint32_t red[20];
     const SelJob &jb = b.job[blockIdx.x];
-    matrix_resolve_job<T>(b, jb, hist, red);
+    matrix_resolve_job<T, false>(b, jb, hist, red);
     __syncthreads();
 #ifdef VLMC_FUSED_STAMPS
     for (int i = threadIdx.x; i < kCtrl + 16; i += 1024) jb.ws[i] = 0;       // (keep the phase clocks)
@@ -962,29 +968,39 @@ __global__ __launch_bounds__(1024) void matrix_resolve_kernel(const SelBatch b) 
 // Barriers: one arrival counter per barrier in the control block, device-scope atomics only (no L2
 // write-back fences, see matrix_count_kernel).  The grid never exceeds one workgroup per CU, so all
 // workgroups are resident on an otherwise idle GPU; if they are not (CUs held by another stream), the
-// bounded spin runs out, the waiters raise the fail bit, everybody leaves W untouched and writes an all-keep
-// mask, and the resolve launch that follows does the exact streaming select (its fallback mode).  Every
-// wave therefore reaches the end of the kernel whatever the residency.
-// The job's global histogram and control words must be ZERO on entry; the resolve launch zeroes them again.
+// bounded spin runs out and a waiter raises the barrier's fail bit: then NO workgroup of the job passes that
+// barrier, nobody touches W or the mask, and the job's last workgroup to finish (done counter) does the exact
+// streaming select over the whole matrix (matrix_resolve_job<WRITE_ALL>) -- as it does when the sampled bracket
+// missed rank k, the bin reaches the NaN keys or heavy ties overflow the candidate list.  Every wave therefore
+// reaches the end of the kernel whatever the residency.
+// The job's global histogram and control words must be ZERO on entry; the last workgroup zeroes them again.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kBarFail = 0x80000000u;
 constexpr int kFusedCand = 4096;                 // candidate keys a workgroup can hold (more => exact fallback)
+constexpr int kSlot = 64;                        // candidate keys one workgroup may publish (expected: < 10)
+constexpr int kMaxFusedWgs = 2 * kCandCap / kSlot;            // slots in the workspace's candidate area (256)
+constexpr uint32_t kSlotEmpty = 0xFFFFFFFFu, kSlotOverflow = 0xFFFFFFFEu;   // (keys are relative to the bin: < 2^22)
 constexpr int kFusedMaxIn = 8192;                // in_features the LDS copy of sqrt(scaler_row) can hold
 constexpr uint32_t kSpinMax = 1u << 16;          // x (device-scope load + s_sleep) ~ 50-100 ms
 
-// tid 0 of a workgroup: arrive at the barrier word and wait for `n` arrivals.  false = fail bit seen or timed out.
+// tid 0 of a workgroup: arrive at the barrier word and wait for `n` arrivals.  false = the barrier failed.
+// The fail bit can only be set (compare-and-swap) while the count is still short, and whoever arrives or polls
+// afterwards sees it before the count: either every workgroup of the job passes the barrier or none does.
 __device__ __forceinline__ bool grid_arrive_wait(uint32_t *ws, int which, uint32_t n) {
     uint32_t *ctr = ws + kCtrl + which;
     uint32_t v = atomicAdd(ctr, 1u) + 1u;
-    for (uint32_t it = 0; it < kSpinMax; ++it) {
+    for (uint32_t it = 0;; ++it) {
         if (v & kBarFail) return false;
         if (v >= n) return true;
+        if (it >= kSpinMax) {                                    // give up: declare the failure unless it completed meanwhile
+            const uint32_t seen = atomicCAS(ctr, v, v | kBarFail);
+            if (seen == v) return false;
+            v = seen;
+            continue;
+        }
         __builtin_amdgcn_s_sleep(8);
         v = ld_dev(ctr);
     }
-    atomicOr(ws + kCtrl + C_BAR_A, kBarFail);    // release everybody who is, or will be, waiting
-    atomicOr(ws + kCtrl + C_BAR_B, kBarFail);
-    return false;
 }
 
 #ifdef VLMC_FUSED_STAMPS
@@ -1150,16 +1166,13 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
                     VLMC_WALK_NEXT(row, cir);
                 }
                 __syncthreads();
-                {
-                    // one reservation per workgroup in the job's list (a per-element atomic on one address serialises
-                    // at the memory side: ~30 ns each, 600 of them per linear), then device-scope stores
+                // every workgroup publishes its (few) candidates in its OWN slot of the list, padded with a sentinel:
+                // no reservation round trip, and the readers need no count before they can issue their loads.
+                // (A per-element atomic on one shared counter serialises at the memory side: ~30 ns x 600 per linear.)
+                if (tid < kSlot) {
                     const uint32_t mine = red[35];
-                    if (tid == 0) red[36] = mine ? atomicAdd(&ws[kCtrl + C_NCAND], mine) : 0u;
-                    __syncthreads();
-                    const uint32_t base = red[36];
-                    for (uint32_t i = tid; i < mine && i < uint32_t(kFusedCand); i += 1024u)
-                        if (base + i < uint32_t(kFusedCand))
-                            __hip_atomic_store(&ws[kCand + base + i], cand[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t v = mine > uint32_t(kSlot) ? kSlotOverflow : (uint32_t(tid) < mine ? cand[tid] : kSlotEmpty);
+                    __hip_atomic_store(&ws[kCand + wg * kSlot + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
@@ -1169,10 +1182,23 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
                 fail = red[34] == 0;
                 VLMC_FSTAMP(5);
                 // ---- P3: exact rank `rankb` among the candidates (keys relative to lob, < 2^bshift) ----------
-                const uint32_t ncand = fail ? 0u : ld_dev(&ws[kCtrl + C_NCAND]);
-                if (ncand > uint32_t(kFusedCand)) fail = true;     // heavy ties overflowed the list
+                uint32_t ncand = 0;
                 if (!fail) {
-                    for (uint32_t i = tid; i < ncand; i += 1024u) cand[i] = ld_dev(&ws[kCand + i]);
+                    if (tid == 0) { red[35] = 0; red[38] = 0; }
+                    __syncthreads();
+                    for (uint32_t i = tid; i < jb.nwg * uint32_t(kSlot); i += 1024u) {     // all slots, one round trip
+                        const uint32_t v = ld_dev(&ws[kCand + i]);
+                        if (v == kSlotOverflow) red[38] = 1;
+                        else if (v != kSlotEmpty) {
+                            const uint32_t pos = atomicAdd(&red[35], 1u);
+                            if (pos < uint32_t(kFusedCand)) cand[pos] = v;
+                        }
+                    }
+                    __syncthreads();
+                    ncand = red[35];
+                    if (red[38] || ncand > uint32_t(kFusedCand)) fail = true;   // heavy ties: more than a slot / the list holds
+                }
+                if (!fail) {
                     uint32_t prefix = 0, pmask = 0, r = rankb;
                     for (int sh = int((bshift - 1u) & ~7u); sh >= 0; sh -= 8) {
                         if (tid < 256) lh[tid] = 0;
@@ -1200,25 +1226,24 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
     }
     VLMC_FSTAMP(6);
     // ---- P4: apply --------------------------------------------------------------------------------------
+    // my last look at the workspace is behind me: the done count (its round trip hides behind the stores)
+    if (tid == 0) red[37] = atomicAdd(&ws[kCtrl + C_DONE], 1u);
     auto apply_chunk = [&](Chunk8<T> &c, uint32_t rowu, uint32_t col0) {
-        uint32_t keepbits = 0xFFu;
-        if (!fail) {
-            float sq[8];
-            load_sq(col0, sq);
-            keepbits = 0;
+        uint32_t keepbits = 0;
+        float sq[8];
+        load_sq(col0, sq);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                bool pruned = false;
-                if (ALIGNED || col0 + j < in_f)
-                    pruned = stream_key(ieee_mul(fabsf(to_f32<T>(c.v[j])), sq[j])) < thr;
-                keepbits |= (pruned ? 0u : 1u) << j;
-                if (pruned) c.v[j] = typename T::raw(0);
-            }
+        for (int j = 0; j < 8; ++j) {
+            bool pruned = false;
+            if (ALIGNED || col0 + j < in_f)
+                pruned = stream_key(ieee_mul(fabsf(to_f32<T>(c.v[j])), sq[j])) < thr;
+            keepbits |= (pruned ? 0u : 1u) << j;
+            if (pruned) c.v[j] = typename T::raw(0);
         }
         store_mask_chunk<ALIGNED, true>(jb.mask + int64_t(rowu) * in_f, col0, in_f, keepbits);
         if (b.apply_zero && keepbits != 0xFFu) store_row_chunk<T, ALIGNED, true>(W + int64_t(rowu) * jb.ldw, col0, in_f, c);
     };
-    {
+    if (!fail) {                                                 // (a failed job is written by its last workgroup, below)
         uint32_t row = row0, cir = cir0;
 #pragma unroll
         for (int u = 0; u < R; ++u) {
@@ -1234,11 +1259,6 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
     }
 #undef VLMC_WALK_NEXT
     VLMC_FSTAMP(7);
-    if (tid == 0) {
-        // the resolve launch that follows: nothing to do, or the exact streaming select over the untouched W
-        if (fail) __hip_atomic_store(&ws[kCtrl + C_FAIL], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else if (wg == 0) __hip_atomic_store(&ws[kCtrl + C_FUSED_OK], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     if (jb.parts) {
         dsum = wave_sum_f64(dsum);
         if ((tid & 63) == 0) dsm[tid >> 6] = dsum;
@@ -1252,6 +1272,18 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
             for (uint32_t i = jb.nwg + uint32_t(tid); i < uint32_t(kMatrixParts); i += 1024u) jb.parts[i] = 0.0;
         }
     }
+    // ---- the job's last workgroup: exact fallback of a failed job (every workgroup of the job knows `fail`, and none
+    // ---- of them has written W or the mask), then the histogram and control words go back to zero -------------------
+    __syncthreads();
+    if (red[37] != jb.nwg - 1) return;
+    if (fail) matrix_resolve_job<T, true>(b, jb, lh, red);
+    __syncthreads();
+#ifdef VLMC_FUSED_STAMPS
+    for (int i = tid; i < kCtrl + 16; i += 1024)                 // (keep the phase clocks)
+#else
+    for (int i = tid; i < kCand; i += 1024)
+#endif
+        __hip_atomic_store(&ws[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1365,7 +1397,7 @@ static int launch_rows(const vlmc_select_job *jobs, const int *idx, int n, int a
     }
     const bool aligned = job_aligned(j0);
 #define VLMC_ROWS(CH, NW, AL) \
-    hipLaunchKernelGGL((select_rows_kernel<T, CH, NW, AL>), dim3(unsigned(rows)), dim3(64 * NW), 0, st, b)
+    VLMC_LAUNCH_TIMED((select_rows_kernel<T, CH, NW, AL>), dim3(unsigned(rows)), dim3(64 * NW), st, b)
     if (!aligned) {
         if (nchunks <= 256) VLMC_ROWS(4, 1, false);
         else VLMC_ROWS(4, 8, false);
@@ -1433,9 +1465,9 @@ static int launch_rows_mixed(const vlmc_select_job *jobs, int n_jobs, int apply_
     }
     const int chw = int((max_chunks + 255) / 256);
     switch (chw) {
-        case 2: hipLaunchKernelGGL((select_rows_mixed_kernel<T, 2>), dim3(units), dim3(256), 0, st, b); break;
-        case 3: hipLaunchKernelGGL((select_rows_mixed_kernel<T, 3>), dim3(units), dim3(256), 0, st, b); break;
-        default: hipLaunchKernelGGL((select_rows_mixed_kernel<T, 4>), dim3(units), dim3(256), 0, st, b); break;
+        case 2: VLMC_LAUNCH_TIMED((select_rows_mixed_kernel<T, 2>), dim3(units), dim3(256), st, b); break;
+        case 3: VLMC_LAUNCH_TIMED((select_rows_mixed_kernel<T, 3>), dim3(units), dim3(256), st, b); break;
+        default: VLMC_LAUNCH_TIMED((select_rows_mixed_kernel<T, 4>), dim3(units), dim3(256), st, b); break;
     }
     return VLMC_OK;
 }
@@ -1479,7 +1511,9 @@ static int launch_matrix(const vlmc_select_job *jobs, const int *idx, int n, int
             set_error("vlmc_wanda_select: cannot query the device's CU count");
             return VLMC_EHIP;
         }
-        const int fbudget = env_int("VLMC_MATRIX_FUSED_WGS", cus) < cus ? env_int("VLMC_MATRIX_FUSED_WGS", cus) : cus;
+        int fbudget = env_int("VLMC_MATRIX_FUSED_WGS", cus) < cus ? env_int("VLMC_MATRIX_FUSED_WGS", cus) : cus;
+        if (fbudget > kMaxFusedWgs) fbudget = kMaxFusedWgs;
+        if (fbudget < n) fbudget = n;
         uint32_t total = 0;
         int big = 0;
         for (int i = 0; i < n; ++i) {
@@ -1500,9 +1534,8 @@ static int launch_matrix(const vlmc_select_job *jobs, const int *idx, int n, int
         for (int i = 0; i < n; ++i) { wgs += b.job[i].nwg; b.job[i].unit_end = wgs; }
         // chunks a lane keeps in registers (128 VGPRs per lane at 1024 lanes per CU): 14 x 16 B covers a ViT-g block
         constexpr int R = sizeof(typename T::raw) == 2 ? 14 : 8;
-        if (aligned) hipLaunchKernelGGL((matrix_fused_kernel<T, true, R>), dim3(wgs), dim3(1024), 0, st, b);
-        else hipLaunchKernelGGL((matrix_fused_kernel<T, false, 8>), dim3(wgs), dim3(1024), 0, st, b);
-        hipLaunchKernelGGL((matrix_resolve_kernel<T>), dim3(unsigned(n)), dim3(1024), 0, st, b);
+        if (aligned) VLMC_LAUNCH_TIMED((matrix_fused_kernel<T, true, R>), dim3(wgs), dim3(1024), st, b);
+        else VLMC_LAUNCH_TIMED((matrix_fused_kernel<T, false, 8>), dim3(wgs), dim3(1024), st, b);
         return VLMC_OK;
     }
     hipLaunchKernelGGL((matrix_sample_kernel<T>), dim3(unsigned(n)), dim3(1024), 0, st, b);

@@ -43,6 +43,7 @@ class ScoreJob(_c.Structure):         # vlmc_score_job
 SIGNATURES = {
     "vlmc_abi_version": (_i, []),
     "vlmc_last_error": (_c.c_char_p, []),
+    "vlmc_set_launch_events": (None, [_p, _p]),
     "vlmc_act_sqnorm": (_i, [_p, _i, _i64, _i64, _i64, _i64, _i64, _p, _p]),
     "vlmc_wanda_scaler_update": (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _p]),
     "vlmc_act_sqnorm_batch": (_i, [_p, _i, _i, _i64, _p]),
