@@ -11,8 +11,11 @@ One "step" = one pass of the hot path over the whole model: per transformer bloc
 activation statistics of every distinct linear input over the 128 samples
 (vlmc_act_sqnorm), the running-mean recurrence + sqrt (vlmc_wanda_scaler_update),
 and the fused score + select + apply of every linear (vlmc_wanda_select) -- i.e.
-SURVEY.md §8 rows a3-a8 without the block forward (row (f)1, not built yet).  Each
-timed step prunes a fresh copy of the dense weights.
+SURVEY.md §8 rows a3-a8 without the block forward (row (f)1: the `end_to_end` object times a
+whole drop-in prune, replay engine included, beside the bench line).  Each timed step prunes a
+fresh copy of the dense weights.  `roofline` comes from HIP events carried by the kernel launches
+themselves (vlmc_set_launch_events -> hipExtLaunchKernel) on the launch stream, inside the timed
+region, on every `--event-stride`-th block of a step (DESIGN.md section 6 says why).
 
 N GPUs (`torchrun`, one rank per GPU): the 128 calibration samples are sharded in
 contiguous ranges, one RCCL all-gather of per-sample squared norms per block, select
