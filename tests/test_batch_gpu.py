@@ -191,6 +191,39 @@ def test_matrix_select_extreme_ranks_and_nan():
     _check_matrix(W, s2, W.numel() // 3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_matrix_select_fused_streams_what_the_registers_do_not_hold(monkeypatch, dtype):
+    """With a grid of 8 workgroups a lane's register chunks cover only part of a 1408 x 1408 matrix: the rest is
+    streamed in the count pass and re-read in the candidate and apply passes -- same exact result."""
+    monkeypatch.setenv("VLMC_MATRIX_FUSED_WGS", "8")
+    for seed, shape in ((21, (1408, 1408)), (22, (700, 1001))):          # aligned and unaligned rows
+        W, s = _w(shape[0], shape[1], dtype, seed)
+        for ratio in (0.5, 0.1):
+            _check_matrix(W, s, int(W.numel() * ratio))
+
+
+def test_matrix_select_fused_equals_four_launch_form(monkeypatch):
+    """VLMC_MATRIX_FUSED=0 (sample / count / apply / resolve launches) is the cross-check of the fused kernel; rows wider
+    than the fused kernel's LDS table (in > 8192) always take it.  Both leave the workspace zero-filled for the other."""
+    ops = _ops()
+    shapes = [(1408, 1408), (64, 8200), (300, 6144)]
+    cases = [_w(o, i, torch.float16, 500 + j) for j, (o, i) in enumerate(shapes)]
+    sqs = [ops.sqrt_scaler(torch.from_numpy(c[1]).to(DEV)) for c in cases]
+    ks = [int(o * i * 0.4) for o, i in shapes]
+    got = {}
+    for fused in ("1", "0", "1"):
+        monkeypatch.setenv("VLMC_MATRIX_FUSED", fused)
+        Ws = [c[0].clone().to(DEV) for c in cases]
+        masks, parts = ops.wanda_select_batch(Ws, sqs, "matrix", ks=ks, apply_zero=True)
+        cur = ([m.clone() for m in masks], [w.clone() for w in Ws])
+        if got:
+            assert all(torch.equal(a, b) for a, b in zip(got["m"], cur[0]))
+            assert all(torch.equal(a, b) for a, b in zip(got["w"], cur[1]))
+        got = {"m": cur[0], "w": cur[1]}
+    for (W, s), mk, k in zip(cases, got["m"], ks):
+        assert np.array_equal(mk.cpu().numpy(), ~OW.select_matrix(OW.wanda_score(W, s), k))
+
+
 def test_matrix_select_two_streams_compete_for_the_cus():
     """The fused matrix-wide kernel wants one workgroup per CU resident at the same time.  Two streams launching
     it concurrently can each get only part of the chip: the bounded barrier wait must then run out and hand the
