@@ -204,6 +204,75 @@ def test_graph_captured_replay_is_bit_identical_to_the_eager_loop(method, monkey
             assert torch.equal(a[k], b[k]), k
 
 
+def test_tower_memo_hands_over_recorded_outputs_only_when_inputs_and_weights_are_unchanged():
+    """calibration.TowerMemo: phase 1 records (first block's inputs, last block's output) per forward; phase 2 returns
+    the record when the inputs are bit-equal, runs the blocks otherwise; changed weights start a new record."""
+    from lavis.compression.pruners import calibration as cal
+
+    class Tower(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks = torch.nn.ModuleList([torch.nn.Sequential(torch.nn.Linear(32, 32), torch.nn.GELU()) for _ in range(3)])
+
+        def forward(self, x, scale=1.0):
+            for blk in self.blocks:
+                x = blk(x)
+            return x * scale
+
+    torch.manual_seed(0)
+    model = Tower().to("cuda:0").eval()
+    xs = [torch.randn(2, 5, 32, device="cuda:0") for _ in range(5)]
+    with torch.no_grad():
+        want = [model(x) for x in xs]
+        cache = {}
+
+        def phase(inputs):
+            undo = cal._wrap_towers(model, ["blocks"], cache)
+            try:
+                return [model(x) for x in inputs]
+            finally:
+                for blocks, i, orig in undo:
+                    blocks[i].__dict__["_memo"] = None
+                    blocks[i] = orig
+
+        s0 = dict(cal.graph_stats)
+        got = phase(xs)                                                    # records
+        assert all(torch.equal(a, b) for a, b in zip(got, want))
+        assert cal.graph_stats["memo_recorded"] == s0["memo_recorded"] + 5 and cal.graph_stats["memo_hits"] == s0["memo_hits"]
+        other = torch.randn(2, 5, 32, device="cuda:0")
+        got = phase(xs[:3] + [other, xs[4]])                               # replays 4, runs the changed forward
+        assert all(torch.equal(a, b) for a, b in zip(got, want[:3] + [model(other), want[4]]))
+        assert cal.graph_stats["memo_hits"] == s0["memo_hits"] + 4 and cal.graph_stats["memo_misses"] == s0["memo_misses"] + 1
+        model.blocks[1][0].weight.mul_(1.5)                                # same addresses, other values
+        want2 = [model(x) for x in xs]
+        got = phase(xs)                                                    # fingerprint differs: a new record, no hits
+        assert all(torch.equal(a, b) for a, b in zip(got, want2))
+        assert cal.graph_stats["memo_hits"] == s0["memo_hits"] + 4
+        got = phase(xs)
+        assert all(torch.equal(a, b) for a, b in zip(got, want2)) and cal.graph_stats["memo_hits"] == s0["memo_hits"] + 9
+
+
+def test_tower_memo_in_a_whole_prune_is_bit_identical(monkeypatch):
+    """Decoder capture of the toy InstructBLIP with the ViT's outputs taken from the encoder capture's record."""
+    from lavis.compression.pruners import calibration as cal
+
+    def state(model):
+        sd = dict(model.state_dict())
+        for n, mod in model.named_modules():
+            if hasattr(mod, "mask") and torch.is_tensor(mod.mask):
+                sd[n + ".mask*"] = mod.mask
+        return sd
+
+    monkeypatch.setenv("VLMC_TOWER_MEMO", "0")
+    s0 = dict(cal.graph_stats)
+    off = state(H.run_pruner("fp32_r50", "cuda:0")[0])
+    assert cal.graph_stats["memo_hits"] == s0["memo_hits"] and cal.graph_stats["memo_recorded"] == s0["memo_recorded"]
+    monkeypatch.setenv("VLMC_TOWER_MEMO", "1")
+    on = state(H.run_pruner("fp32_r50", "cuda:0")[0])
+    assert cal.graph_stats["memo_hits"] > s0["memo_hits"] and cal.graph_stats["memo_misses"] == s0["memo_misses"]
+    assert off.keys() == on.keys() and all(torch.equal(off[k], on[k]) for k in off)
+
+
 def test_graphed_module_proxy_replays_identically_and_falls_back():
     """calibration.GraphedModule (stand-in for already pruned blocks during capture): eager first call, captured second,
     replayed afterwards, one graph per argument signature; gradients / odd arguments go straight to the module."""

@@ -85,7 +85,118 @@ def graph_replay_enabled():
 
 
 GRAPH_MIN_SAMPLES = 4         # a capture costs about three eager forwards
-graph_stats = {"captured": 0, "replayed": 0, "fallbacks": 0}
+graph_stats = {"captured": 0, "replayed": 0, "fallbacks": 0, "memo_recorded": 0, "memo_hits": 0, "memo_misses": 0}
+MEMO_MAX_BYTES = 4 << 30
+
+
+def tower_memo_enabled():
+    """Outputs of a finished tower are remembered from one capture phase to the next (`VLMC_TOWER_MEMO=0`: off)."""
+    return os.environ.get("VLMC_TOWER_MEMO", "1") != "0"
+
+
+class TowerMemo:
+    """What a FINISHED tower produced for each calibration forward of one capture phase, for the next phase.
+
+    A three-tower model (ViT -> T5 encoder -> T5 decoder) runs its own forward over the calibration set once per
+    tower; the decoder's capture re-runs the ViT on the same images with the same, already pruned weights as the
+    encoder's capture did -- 128 x 39 batch-1 block forwards, a tenth of a whole FlanT5-XL prune.  While the
+    encoder's inputs are captured the memo records, per forward, the inputs of the tower's first block and the
+    output of its last block; in the next phase the first block compares its inputs BIT FOR BIT with the record of
+    the same forward and, if they agree, the blocks hand their input through and the last one returns the recorded
+    output -- the tensor the blocks would compute again.  Guards: the tower's parameters and buffers must be where
+    they were and sum (float64, per tensor) to what they summed when the record was made; every recorded forward
+    called the blocks exactly once each, in order, with a single tensor as output; anything else leaves the blocks
+    to run."""
+
+    def __init__(self, fingerprint, n_blocks):
+        self.fp, self.n = fingerprint, n_blocks
+        self.entries, self.mode, self.ok = [], "record", True
+        self.cursor, self.hit, self.pending, self.expect, self.bytes = 0, None, None, 0, 0
+
+    @staticmethod
+    def fingerprint(blocks):
+        ts = [t for b in blocks for t in list(b.parameters()) + list(b.buffers())]
+        sums = torch.stack([torch.sum(t.detach(), dtype=torch.float64) for t in ts]) if ts else torch.zeros(0)
+        return tuple(t.data_ptr() for t in ts), sums
+
+    def matches(self, fp):
+        return self.ok and bool(self.entries) and self.fp[0] == fp[0] and self.fp[1].shape == fp[1].shape \
+            and bool(torch.equal(self.fp[1], fp[1]))
+
+    def begin(self, mode):
+        self.mode, self.cursor, self.hit, self.pending, self.expect = mode, 0, None, None, 0
+        if mode == "record":
+            self.entries, self.bytes = [], 0
+
+    @staticmethod
+    def _snapshot(args, kwargs):
+        snap = lambda v: v.detach().clone() if isinstance(v, torch.Tensor) else v
+        return [snap(a) for a in args], {k: snap(v) for k, v in kwargs.items()}
+
+    @staticmethod
+    def _same(rec, args, kwargs):
+        rargs, rkw = rec
+        if len(rargs) != len(args) or sorted(rkw) != sorted(kwargs):
+            return False
+        for r, v in list(zip(rargs, args)) + [(rkw[k], kwargs[k]) for k in rkw]:
+            if isinstance(r, torch.Tensor) != isinstance(v, torch.Tensor):
+                return False
+            if isinstance(r, torch.Tensor):
+                if r.shape != v.shape or r.dtype != v.dtype or r.device != v.device or not torch.equal(r, v):
+                    return False
+            elif r is not v and r != v:
+                return False
+        return True
+
+    def _drop(self):
+        self.ok, self.entries, self.hit, self.pending = False, [], None, None
+
+    def enter(self, index, args, kwargs):
+        """-> (handled, value).  Called by block `index` of the tower before it would run."""
+        if not self.ok:
+            return False, None
+        if index == 0:
+            self.expect, self.hit, self.pending = 0, None, None
+        if index != self.expect:                                   # blocks skipped or repeated inside one forward
+            if self.hit is not None:
+                raise RuntimeError("tower memo: the model called the tower's blocks in another order than when the memo "
+                                   "was recorded (set VLMC_TOWER_MEMO=0)")
+            self._drop()
+            return False, None
+        self.expect = index + 1
+        if self.mode == "record":
+            if index == 0:
+                self.pending = self._snapshot(args, kwargs) if args and isinstance(args[0], torch.Tensor) else None
+                if self.pending is None:
+                    self._drop()
+            return False, None
+        if index == 0:
+            j, self.cursor = self.cursor, self.cursor + 1
+            if j < len(self.entries) and self._same(self.entries[j][0], args, kwargs):
+                self.hit = self.entries[j][1]
+                graph_stats["memo_hits"] += 1
+            else:
+                graph_stats["memo_misses"] += 1
+        if self.hit is None:
+            return False, None
+        if index == self.n - 1:
+            out, self.hit = self.hit.clone(), None
+            return True, out
+        return True, args[0]
+
+    def leave(self, index, result):
+        if self.ok and self.mode == "record" and index == self.n - 1:
+            if isinstance(result, torch.Tensor) and self.pending is not None and self.expect == self.n:
+                self.entries.append((self.pending, result.detach().clone()))
+                self.bytes += result.numel() * result.element_size() + sum(
+                    v.numel() * v.element_size() for v in list(self.pending[0]) + list(self.pending[1].values())
+                    if isinstance(v, torch.Tensor))
+                self.pending = None
+                graph_stats["memo_recorded"] += 1
+                if self.bytes > MEMO_MAX_BYTES:
+                    self._drop()
+            else:
+                self._drop()
 
 
 class GraphedModule(nn.Module):
@@ -113,6 +224,17 @@ class GraphedModule(nn.Module):
         return NotImplemented
 
     def forward(self, *args, **kwargs):
+        memo = self.__dict__.get("_memo")                       # (TowerMemo, index of this block in its tower) or None
+        if memo is None or torch.is_grad_enabled():
+            return self._forward(*args, **kwargs)
+        handled, value = memo[0].enter(memo[1], args, kwargs)
+        if handled:
+            return value
+        out = self._forward(*args, **kwargs)
+        memo[0].leave(memo[1], out)
+        return out
+
+    def _forward(self, *args, **kwargs):
         mod = self.__dict__["_wrapped"]
         if self._off or torch.is_grad_enabled():
             return mod(*args, **kwargs)
@@ -167,6 +289,7 @@ def _wrap_towers(model, towers, proxy_cache=None):
             blocks = get_module_recursive(model, path)
         except AttributeError:
             continue
+        proxies, originals = [], []
         for i in range(len(blocks)):
             if not isinstance(blocks[i], GraphedModule) and next(blocks[i].parameters(), torch.empty(0)).is_cuda:
                 mod = blocks[i]
@@ -177,6 +300,20 @@ def _wrap_towers(model, towers, proxy_cache=None):
                         proxy_cache[id(mod)] = proxy
                 undo.append((blocks, i, mod))
                 blocks[i] = proxy
+                proxy.__dict__["_memo"] = None
+                proxies.append(proxy)
+                originals.append(mod)
+        # the tower's outputs of this phase are remembered for the next one (TowerMemo)
+        if proxy_cache is not None and tower_memo_enabled() and len(proxies) == len(blocks) >= 2:
+            fp = TowerMemo.fingerprint(originals)
+            memo = proxy_cache.get(("memo", path))
+            if memo is not None and memo.matches(fp):
+                memo.begin("replay")
+            else:
+                memo = proxy_cache[("memo", path)] = TowerMemo(fp, len(proxies))
+                memo.begin("record")
+            for i, proxy in enumerate(proxies):
+                proxy.__dict__["_memo"] = (memo, i)
     return undo
 
 
@@ -244,6 +381,7 @@ def capture_block_inputs(model, dataloader, n_samples, module_to_process, forwar
     finally:
         layers[0] = layers[0].module
         for blocks, i, orig in undo:
+            blocks[i].__dict__["_memo"] = None
             blocks[i] = orig
     return inps, [None] * len(inps), caches
 
