@@ -123,7 +123,8 @@ int vlmc_wanda_scaler_update_batch(const vlmc_update_job *jobs /* host array */,
  *
  * vlmc_wanda_select_batch does the same for several linears -- the `for name in subset` loop of
  * wanda_pruner.py:316-341 -- with as few launches as the shapes allow (SEL_ROW: one per distinct
- * (in_features, k); SEL_MATRIX / SEL_NM: one launch sequence per 12 linears).  All jobs share
+ * (in_features, k), or ONE for up to 12 linears of 16-bit rows of <= 2048 and of 2049..8192 columns;
+ * SEL_MATRIX: one kernel per 12 linears; SEL_NM: one launch per 12 linears).  All jobs share
  * dtype, mode, n:m and apply_zero; SEL_MATRIX jobs need DISTINCT workspaces.                   */
 typedef struct vlmc_select_job {
     void *W;
