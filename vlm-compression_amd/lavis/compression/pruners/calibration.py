@@ -104,9 +104,9 @@ class TowerMemo:
     output of its last block; in the next phase the first block compares its inputs BIT FOR BIT with the record of
     the same forward and, if they agree, the blocks hand their input through and the last one returns the recorded
     output -- the tensor the blocks would compute again.  Guards: the tower's parameters and buffers must be where
-    they were and sum (float64, per tensor) to what they summed when the record was made; every recorded forward
-    called the blocks exactly once each, in order, with a single tensor as output; anything else leaves the blocks
-    to run."""
+    they were and sum (float64, per tensor) to what they summed when the record was made; the blocks are in eval
+    mode; every recorded forward called the blocks exactly once each, in order, with a single tensor as output;
+    anything else leaves the blocks to run."""
 
     def __init__(self, fingerprint, n_blocks):
         self.fp, self.n = fingerprint, n_blocks
@@ -129,14 +129,20 @@ class TowerMemo:
             self.entries, self.bytes = [], 0
 
     @staticmethod
+    def context():
+        """What besides its inputs and weights decides a block's output: the autocast state."""
+        on = torch.is_autocast_enabled()
+        return on, (torch.get_autocast_gpu_dtype() if on else None)
+
+    @staticmethod
     def _snapshot(args, kwargs):
         snap = lambda v: v.detach().clone() if isinstance(v, torch.Tensor) else v
-        return [snap(a) for a in args], {k: snap(v) for k, v in kwargs.items()}
+        return [snap(a) for a in args], {k: snap(v) for k, v in kwargs.items()}, TowerMemo.context()
 
     @staticmethod
     def _same(rec, args, kwargs):
-        rargs, rkw = rec
-        if len(rargs) != len(args) or sorted(rkw) != sorted(kwargs):
+        rargs, rkw, ctx = rec
+        if ctx != TowerMemo.context() or len(rargs) != len(args) or sorted(rkw) != sorted(kwargs):
             return False
         for r, v in list(zip(rargs, args)) + [(rkw[k], kwargs[k]) for k in rkw]:
             if isinstance(r, torch.Tensor) != isinstance(v, torch.Tensor):
@@ -197,6 +203,27 @@ class TowerMemo:
                     self._drop()
             else:
                 self._drop()
+
+
+def seed_tower_memo(proxy_cache, module_to_process, layers, final_outs, autocast):
+    """After the walk over a tower whose blocks all receive the SAME kwargs in the model's own forward (the ViT): the
+    second pass of the last block has just produced, per calibration sample, what the pruned tower makes of the inputs
+    the catcher saw -- the next capture phase need not run the tower at all.  `proxy_cache[("calls", tower)]` holds the
+    catcher's record of how the model called block 0 (capture_block_inputs)."""
+    calls = proxy_cache.pop(("calls", module_to_process), None) if proxy_cache is not None else None
+    if not (calls and tower_memo_enabled() and graph_replay_enabled() and replay_group_size() == 1 and len(layers) >= 2):
+        return False
+    n = min(len(calls), len(final_outs))
+    if n == 0 or not all(isinstance(o, torch.Tensor) and o.is_cuda for o in final_outs[:n]) or \
+            any(m.training for mod in layers for m in mod.modules()):
+        return False
+    with autocast():
+        ctx = TowerMemo.context()                    # the walk's forwards ran under this autocast state
+    memo = TowerMemo(TowerMemo.fingerprint(list(layers)), len(layers))
+    memo.entries = [((c[0], c[1], ctx), final_outs[j].detach()) for j, c in enumerate(calls[:n])]
+    proxy_cache[("memo", module_to_process)] = memo
+    graph_stats["memo_recorded"] += n
+    return True
 
 
 class GraphedModule(nn.Module):
@@ -304,7 +331,9 @@ def _wrap_towers(model, towers, proxy_cache=None):
                 proxies.append(proxy)
                 originals.append(mod)
         # the tower's outputs of this phase are remembered for the next one (TowerMemo)
-        if proxy_cache is not None and tower_memo_enabled() and len(proxies) == len(blocks) >= 2:
+        # (a block in training mode may draw dropout / drop-path masks: its output is not a function of its inputs)
+        if proxy_cache is not None and tower_memo_enabled() and len(proxies) == len(blocks) >= 2 \
+                and not any(m.training for mod in originals for m in mod.modules()):
             fp = TowerMemo.fingerprint(originals)
             memo = proxy_cache.get(("memo", path))
             if memo is not None and memo.matches(fp):
@@ -332,6 +361,9 @@ def capture_block_inputs(model, dataloader, n_samples, module_to_process, forwar
     keys = None if vit else _keys_for(model_prefix)
     inps, caches = [], []
     rank, world = calibration_shard()
+    # how the model calls block 0, for seed_tower_memo (towers whose blocks all get the same kwargs: the ViT)
+    calls = [] if (vit and proxy_cache is not None and tower_memo_enabled() and graph_replay_enabled()
+                   and torch.cuda.is_available()) else None
 
     class Catcher(nn.Module):
         def __init__(self, module):
@@ -339,6 +371,8 @@ def capture_block_inputs(model, dataloader, n_samples, module_to_process, forwar
             self.module = module
 
         def forward(self, inp, *args, **kwargs):
+            if calls is not None:
+                calls.append(TowerMemo._snapshot((inp,) + tuple(args), kwargs))
             if vit:
                 rel_pos_bias = args[0] if args else kwargs.get("rel_pos_bias")
                 dense = args[1] if len(args) > 1 else kwargs.get("dense", True)
@@ -383,6 +417,8 @@ def capture_block_inputs(model, dataloader, n_samples, module_to_process, forwar
         for blocks, i, orig in undo:
             blocks[i].__dict__["_memo"] = None
             blocks[i] = orig
+    if calls is not None:
+        proxy_cache[("calls", module_to_process)] = calls
     return inps, [None] * len(inps), caches
 
 
@@ -480,7 +516,8 @@ class BlockGraph:
         return self.y.clone()
 
 
-def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocast, prune_block, tuple_output):
+def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocast, prune_block, tuple_output,
+                memo_cache=None):
     """The block loop of `_prune`: for every block, `prune_block(i, layer, subset, run)`
     is called with `run()` = one pass of the block over all samples (filling `outs`);
     afterwards the block runs again with whatever weights `prune_block` left, and
@@ -567,4 +604,6 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
         prune_block(i, layer, subset, run_pass, state)
         run_pass()
         state["inps"], state["outs"] = state["outs"], state["inps"]
+    if memo_cache is not None and not tuple_output:
+        seed_tower_memo(memo_cache, module_to_process, layers, state["inps"][:n_samples], autocast)
     return model

@@ -277,7 +277,8 @@ class VITLayerDSnoTPruner(LayerWiseBasePruner, _DsnotBlockMixin):
                               model_prefix=model_prefix, sparsity_ratio=sparsity_ratio, lora_model=lora_model)
 
         cal.walk_blocks(model, inps, outs, caches, module_to_process, n_samples,
-                        lambda: model.maybe_autocast(dtype=torch.bfloat16), prune_block, tuple_output=False)
+                        lambda: model.maybe_autocast(dtype=torch.bfloat16), prune_block, tuple_output=False,
+                        memo_cache=self.__dict__.get("_proxy_cache"))
         torch.cuda.empty_cache()
         gc.collect()
         return model

@@ -202,7 +202,7 @@ class VITLayerSparseGPTPruner(LayerWiseBasePruner, _SparseGPTBlockMixin):
             self._sparsegpt_block(i, subset, run_pass, n_inps, module_to_process, sparsity_ratio)
 
         cal.walk_blocks(model, inps, outs, caches, module_to_process, n_samples, lambda: model.maybe_autocast(),
-                        prune_block, tuple_output=False)
+                        prune_block, tuple_output=False, memo_cache=self.__dict__.get("_proxy_cache"))
         torch.cuda.empty_cache()
         return model
 

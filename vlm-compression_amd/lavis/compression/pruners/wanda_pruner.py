@@ -279,7 +279,7 @@ class VITLayerWandaPruner(LayerWiseBasePruner, _WandaBlockMixin):
                               sparsity_ratio=sparsity_ratio, lora_model=lora_model)
 
         cal.walk_blocks(model, inps, outs, caches, module_to_process, n_samples, lambda: model.maybe_autocast(),
-                        prune_block, tuple_output=False)
+                        prune_block, tuple_output=False, memo_cache=self.__dict__.get("_proxy_cache"))
         torch.cuda.empty_cache()
         gc.collect()
         return model
