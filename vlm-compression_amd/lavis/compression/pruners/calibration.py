@@ -209,9 +209,10 @@ def seed_tower_memo(proxy_cache, module_to_process, layers, final_outs, autocast
     """After the walk over a tower whose blocks all receive the SAME kwargs in the model's own forward (the ViT): the
     second pass of the last block has just produced, per calibration sample, what the pruned tower makes of the inputs
     the catcher saw -- the next capture phase need not run the tower at all.  `proxy_cache[("calls", tower)]` holds the
-    catcher's record of how the model called block 0 (capture_block_inputs)."""
+    catcher's record of how the model called block 0 (capture_block_inputs).  (Under VLMC_BATCH_REPLAY the outputs come
+    from the stacked forwards, like everything else downstream of a batched pass.)"""
     calls = proxy_cache.pop(("calls", module_to_process), None) if proxy_cache is not None else None
-    if not (calls and tower_memo_enabled() and graph_replay_enabled() and replay_group_size() == 1 and len(layers) >= 2):
+    if not (calls and tower_memo_enabled() and graph_replay_enabled() and len(layers) >= 2):
         return False
     n = min(len(calls), len(final_outs))
     if n == 0 or not all(isinstance(o, torch.Tensor) and o.is_cuda for o in final_outs[:n]) or \
