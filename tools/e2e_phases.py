@@ -25,12 +25,12 @@ cal.capture_block_inputs = timed("capture (model forward up to the tower)", cal.
 orig_walk = cal.walk_blocks
 
 
-def walk(model, inps, outs, caches, mtp, n, autocast, prune_block, tuple_output):
+def walk(model, inps, outs, caches, mtp, n, autocast, prune_block, tuple_output, **kw):
     def pb(i, layer, subset, run_pass, state):
         def rp(before_sample=None):
             return timed("replay pass with hooks" if before_sample is not None else "replay pass plain", run_pass)(before_sample)
         return timed("prune_block total (incl. hooked pass)", prune_block)(i, layer, subset, rp, state)
-    return orig_walk(model, inps, outs, caches, mtp, n, autocast, pb, tuple_output)
+    return orig_walk(model, inps, outs, caches, mtp, n, autocast, pb, tuple_output, **kw)
 
 
 cal.walk_blocks = timed("walk_blocks total", walk)
