@@ -22,6 +22,11 @@ for seed in range(100, 160):
                 Gt.test_score_select_matches_oracle(seed, mode, layout)
             except AssertionError as e:
                 fails += 1; print("FAIL score", seed, mode, layout, str(e)[:200])
+for seed in range(100, 180):
+    try:
+        F.test_mixed_width_row_select_random_job_mixes(seed)
+    except AssertionError as e:
+        fails += 1; print("FAIL mixed rows", seed, str(e)[:200])
 print("done, failures:", fails)
 
 # DSnoT: the list-head kernel against the per-cycle kernel (bit-identical events) and, for small rows, the CPU oracle
