@@ -533,7 +533,8 @@ __global__ __launch_bounds__(256, 5) void select_rows_mixed_kernel(const SelBatc
 //            re-pruning weights that are already half zero): it then selects by streaming the matrix itself.
 // Every decision rests on exact counts; sampling only affects speed.  No device-wide fences: everything
 // exchanged between workgroups inside a launch goes through device-scope atomics.
-// Workspace per job (u32 words): hist[2048] | ctrl[32] | candidates[2 x 8192].
+// Workspace per job (u32 words): hist[2048] | ctrl[32] | candidates[2 x 8192]  (fused form: the candidate area holds
+// the workgroups' key slots [8192] and the histograms of the two refinement levels [2 x 2048]).
 // ------------------------------------------------------------------------------------------
 constexpr int kMatBins = 2048;
 constexpr int kMatSample = 2048;   // one CU issues every sample load: the sample size is what its kernel costs
@@ -541,7 +542,7 @@ constexpr int kCandCap = 8192;
 constexpr int kCtrl = kMatBins;
 constexpr int kCand = kMatBins + 32;
 constexpr int kWsWords = kCand + 2 * kCandCap;
-enum { C_LO = 0, C_SHIFT, C_BELOW, C_NANC, C_LOB, C_RANKB, C_NONE, C_FAIL, C_DONE, C_NCAND, C_BAR_A, C_BAR_B, C_FUSED_OK };
+enum { C_LO = 0, C_SHIFT, C_BELOW, C_NANC, C_LOB, C_RANKB, C_NONE, C_FAIL, C_DONE, C_NCAND, C_BAR_A, C_BAR_B, C_BAR_A1, C_BAR_A2 };
 
 __device__ __forceinline__ uint32_t ld_dev(const uint32_t *p) {       // device-scope load (bypasses the CU's L1)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -569,6 +570,7 @@ __device__ bool block_find_rank(const uint32_t (&h)[4], uint32_t need, uint32_t 
         }
         red[16] = uint32_t(tid * 4 + i);
         red[17] = cum;
+        red[18] = h[i];                                          // population of that bin (read by callers that need it)
     }
     __syncthreads();
     bin = red[16];
@@ -945,6 +947,8 @@ __global__ __launch_bounds__(1024) void matrix_resolve_kernel(const SelBatch b) 
 #else
     for (int i = threadIdx.x; i < kCand; i += 1024) jb.ws[i] = 0;
 #endif
+    // (the candidate pairs of this form overlap the fused kernel's refinement histograms, which it expects zeroed)
+    for (int i = threadIdx.x; i < 2 * kMatBins; i += 1024) jb.ws[kCand + 8192 + i] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -977,8 +981,10 @@ __global__ __launch_bounds__(1024) void matrix_resolve_kernel(const SelBatch b) 
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kBarFail = 0x80000000u;
 constexpr int kFusedCand = 4096;                 // candidate keys a workgroup can hold (more => exact fallback)
-constexpr int kSlot = 64;                        // candidate keys one workgroup may publish (expected: < 10)
-constexpr int kMaxFusedWgs = 2 * kCandCap / kSlot;            // slots in the workspace's candidate area (256)
+constexpr int kSlotArea = 8192;                  // words of the workspace's candidate area used for the slots
+constexpr int kSlotMax = 64;                     // candidate keys one workgroup may publish: min(64, kSlotArea / workgroups)
+constexpr int kMaxFusedWgs = 256;                // => at least 32 keys per slot
+constexpr int kHist1 = kCand + kSlotArea;        // global histograms of the refinement levels 1 and 2 (2 x 2048 words)
 constexpr uint32_t kSlotEmpty = 0xFFFFFFFFu, kSlotOverflow = 0xFFFFFFFEu;   // (keys are relative to the bin: < 2^22)
 constexpr int kFusedMaxIn = 8192;                // in_features the LDS copy of sqrt(scaler_row) can hold
 constexpr uint32_t kSpinMax = 1u << 16;          // x (device-scope load + s_sleep) ~ 50-100 ms
@@ -1134,7 +1140,64 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
         // the sampled bracket missed rank k, or the bin reaches the NaN keys: exact fallback (resolve launch)
         fail = bel > jb.k || !found || bin_end > 0x7F800001ull;
         if (!fail) {
-            const uint32_t lob = lo + (bin << bshift), rankb = jb.k - bel - before;
+            uint32_t lob = lo + (bin << bshift), rankb = jb.k - bel - before, pop = red[18];
+            const uint32_t slot = min(uint32_t(kSlotMax), uint32_t(kSlotArea) / jb.nwg);
+            // ---- refinement: a bin too crowded for the candidate slots (ties: re-pruning weights that are already half
+            // ---- zero, dead input channels) is histogrammed again, 11 more key bits per level, from the registers; after
+            // ---- at most two levels a bin is ONE key value and needs no candidates at all (ties with the threshold stay)
+            for (int level = 1; level <= 2 && !fail && bshift != 0 && (pop > (slot / 4u) * jb.nwg || pop > 2048u); ++level) {
+                const uint32_t nshift = bshift > 11u ? bshift - 11u : 0u, base = lob, width = 1u << bshift;
+                uint32_t *gh = ws + kHist1 + (level - 1) * kMatBins;
+                for (int i = tid; i < kMatBins; i += 1024) lh[i] = 0;
+                __syncthreads();
+                auto bin_chunk = [&](const Chunk8<T> &c, uint32_t col0) {
+                    float sq[8];
+                    load_sq(col0, sq);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (ALIGNED || col0 + j < in_f) {
+                            const uint32_t key = stream_key(ieee_mul(fabsf(to_f32<T>(c.v[j])), sq[j]));
+                            if (key >= base && key - base < width) atomicAdd(&lh[(key - base) >> nshift], 1u);
+                        }
+                    }
+                };
+                uint32_t row = row0, cir = cir0;
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    if (cb0 + uint32_t(u) * cw.step < cw.total) bin_chunk(raw[u], cir * 8);
+                    VLMC_WALK_NEXT(row, cir);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                for (uint32_t cb = cb0 + uint32_t(R) * cw.step; cb < cw.total; cb += cw.step) {
+                    bin_chunk(load_row_chunk<T, ALIGNED>(W + int64_t(row) * jb.ldw, cir * 8, in_f), cir * 8);
+                    VLMC_WALK_NEXT(row, cir);
+                }
+                __syncthreads();
+                for (int i = tid; i < kMatBins / 2; i += 1024) {
+                    const unsigned long long v = (unsigned long long)(lh[2 * i]) | ((unsigned long long)(lh[2 * i + 1]) << 32);
+                    if (v) atomicAdd(reinterpret_cast<unsigned long long *>(gh) + i, v);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) red[34] = grid_arrive_wait(ws, level == 1 ? C_BAR_A1 : C_BAR_A2, jb.nwg) ? 1u : 0u;
+                __syncthreads();
+                fail = red[34] == 0;
+                if (!fail) {
+                    uint32_t hh[4] = {0, 0, 0, 0};
+                    if (tid < kMatBins / 4) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) hh[i] = ld_dev(&gh[tid * 4 + i]);
+                    }
+                    uint32_t bn, bf;
+                    if (!block_find_rank(hh, rankb, red, bn, bf)) fail = true;       // (cannot happen: rankb < pop)
+                    lob = base + (bn << nshift);
+                    rankb -= bf;
+                    pop = red[18];
+                    bshift = nshift;
+                    __syncthreads();
+                }
+            }
+            if (fail) bshift = 0;
             thr = lob;                                           // one-key bin: ties with the threshold are kept
             if (bshift) {
                 const uint32_t width = 1u << bshift;
@@ -1169,10 +1232,10 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
                 // every workgroup publishes its (few) candidates in its OWN slot of the list, padded with a sentinel:
                 // no reservation round trip, and the readers need no count before they can issue their loads.
                 // (A per-element atomic on one shared counter serialises at the memory side: ~30 ns x 600 per linear.)
-                if (tid < kSlot) {
+                if (uint32_t(tid) < slot) {
                     const uint32_t mine = red[35];
-                    const uint32_t v = mine > uint32_t(kSlot) ? kSlotOverflow : (uint32_t(tid) < mine ? cand[tid] : kSlotEmpty);
-                    __hip_atomic_store(&ws[kCand + wg * kSlot + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t v = mine > slot ? kSlotOverflow : (uint32_t(tid) < mine ? cand[tid] : kSlotEmpty);
+                    __hip_atomic_store(&ws[kCand + wg * slot + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
@@ -1186,7 +1249,7 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
                 if (!fail) {
                     if (tid == 0) { red[35] = 0; red[38] = 0; }
                     __syncthreads();
-                    for (uint32_t i = tid; i < jb.nwg * uint32_t(kSlot); i += 1024u) {     // all slots, one round trip
+                    for (uint32_t i = tid; i < jb.nwg * slot; i += 1024u) {                // all slots, one round trip
                         const uint32_t v = ld_dev(&ws[kCand + i]);
                         if (v == kSlotOverflow) red[38] = 1;
                         else if (v != kSlotEmpty) {
@@ -1284,6 +1347,8 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
     for (int i = tid; i < kCand; i += 1024)
 #endif
         __hip_atomic_store(&ws[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = tid; i < 2 * kMatBins; i += 1024)               // the refinement levels' histograms
+        __hip_atomic_store(&ws[kHist1 + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------
