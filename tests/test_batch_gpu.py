@@ -224,6 +224,14 @@ def test_matrix_select_fused_equals_four_launch_form(monkeypatch):
         assert np.array_equal(mk.cpu().numpy(), ~OW.select_matrix(OW.wanda_score(W, s), k))
 
 
+@pytest.mark.parametrize("zero_frac,ratio", [(0.5, 0.25), (0.5, 0.4999), (0.97, 0.5)])
+def test_matrix_select_tie_floods_at_model_size(zero_frac, ratio):
+    """The threshold falls inside a run of millions of equal scores (weights pruned before, dead channels): the fused
+    kernel refines the crowded bin from its registers down to one key value (no candidates, no streaming fallback)."""
+    W, s = _w(6144, 1408, torch.float16, 31, zero_frac=zero_frac)
+    _check_matrix(W, s, int(W.numel() * ratio))
+
+
 def test_matrix_select_two_streams_compete_for_the_cus():
     """The fused matrix-wide kernel wants one workgroup per CU resident at the same time.  Two streams launching
     it concurrently can each get only part of the chip: the bounded barrier wait must then run out and hand the
