@@ -987,7 +987,7 @@ constexpr int kMaxFusedWgs = 256;                // => at least 32 keys per slot
 constexpr int kHist1 = kCand + kSlotArea;        // global histograms of the refinement levels 1 and 2 (2 x 2048 words)
 constexpr uint32_t kSlotEmpty = 0xFFFFFFFFu, kSlotOverflow = 0xFFFFFFFEu;   // (keys are relative to the bin: < 2^22)
 constexpr int kFusedMaxIn = 8192;                // in_features the LDS copy of sqrt(scaler_row) can hold
-constexpr uint32_t kSpinMax = 1u << 16;          // x (device-scope load + s_sleep) ~ 50-100 ms
+constexpr uint32_t kSpinMax = 1u << 12;          // x (device-scope load + s_sleep, ~2.2 us) ~ 9 ms; a barrier normally takes < 20 us
 
 // tid 0 of a workgroup: arrive at the barrier word and wait for `n` arrivals.  false = the barrier failed.
 // The fail bit can only be set (compare-and-swap) while the count is still short, and whoever arrives or polls
