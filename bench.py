@@ -299,6 +299,9 @@ def main():
     one_device = os.environ.get("VLMC_BENCH_ONE_DEVICE", "0") == "1"
     if one_device:
         local_rank = 0
+        # several processes on one device contend for the CUs the fused matrix-wide select keeps to itself (its barriers
+        # would time out and the exact fallback run): the rehearsal uses the four-launch form
+        os.environ.setdefault("VLMC_MATRIX_FUSED", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
