@@ -227,3 +227,35 @@ def test_bad_arguments_raise():
         ops.wanda_select(W, s, "nm", n=2, m=3)
     with pytest.raises(_lib.VlmcError):
         ops.wanda_select(W, s, "matrix", k=64)
+
+
+def test_launch_events_are_carried_by_the_next_timed_kernel():
+    """vlmc_set_launch_events (the benchmark's timing hook): the next statistics launch records its own begin / end
+    into the caller's HIP events (hipExtLaunchKernel); the pair is consumed by that one launch; results are unchanged."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from vlmc import _lib, ops
+    lib = _lib.load()
+    hipev = bench.HipEvents()
+    x = (torch.randn(64, 257, 1408, device="cuda:0") + 0.1).half()              # 46 MB: a launch of ~10 us
+    want = ops.act_sqnorm(x)
+    torch.cuda.synchronize()
+    a, b = hipev.new(), hipev.new()
+    lib.vlmc_set_launch_events(a, b)
+    got = ops.act_sqnorm(x)
+    again = ops.act_sqnorm(x)                                                    # (no events pending any more)
+    torch.cuda.synchronize()
+    ms = hipev.elapsed_ms(a, b)
+    assert 0.002 < ms < 5.0, ms
+    assert torch.equal(got, want) and torch.equal(again, want)
+    # a select launch takes them as well
+    W = (torch.randn(256, 2048, device="cuda:0") * 0.02).bfloat16()
+    sq = ops.sqrt_scaler(torch.rand(2048, device="cuda:0") + 0.1)
+    c, d = hipev.new(), hipev.new()
+    lib.vlmc_set_launch_events(c, d)
+    ops.wanda_select(W, sq, "row", k=1024)
+    torch.cuda.synchronize()
+    assert 0.001 < hipev.elapsed_ms(c, d) < 5.0
+    hipev.free(a, b, c, d)
