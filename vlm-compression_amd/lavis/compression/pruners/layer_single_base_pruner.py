@@ -47,6 +47,10 @@ class LayerWiseBasePruner(BasePruner):
         for n, p in model.named_parameters():
             p.data = p.data.type(dtype_record[n])
         model.to(device)
+        # what the replay engine kept for THIS prune (graph proxies of finished towers, their recorded outputs, the list of
+        # finished towers): released with it, so a later prune() -- or a training stage -- starts from the model alone
+        self.__dict__.pop("_proxy_cache", None)
+        self.__dict__.pop("_done_towers", None)
 
 
 class UniformSparsity:
