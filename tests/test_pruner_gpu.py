@@ -204,10 +204,12 @@ def test_graph_captured_replay_is_bit_identical_to_the_eager_loop(method, monkey
             assert torch.equal(a[k], b[k]), k
 
 
-def test_tower_memo_hands_over_recorded_outputs_only_when_inputs_and_weights_are_unchanged():
+def test_tower_memo_hands_over_recorded_outputs_only_when_inputs_and_weights_are_unchanged(monkeypatch):
     """calibration.TowerMemo: phase 1 records (first block's inputs, last block's output) per forward; phase 2 returns
     the record when the inputs are bit-equal, runs the blocks otherwise; changed weights start a new record."""
     from lavis.compression.pruners import calibration as cal
+    monkeypatch.setenv("VLMC_TOWER_MEMO", "1")
+    monkeypatch.setenv("VLMC_GRAPH_REPLAY", "1")
 
     class Tower(torch.nn.Module):
         def __init__(self):
@@ -263,6 +265,7 @@ def test_tower_memo_in_a_whole_prune_is_bit_identical(monkeypatch):
                 sd[n + ".mask*"] = mod.mask
         return sd
 
+    monkeypatch.setenv("VLMC_GRAPH_REPLAY", "1")
     monkeypatch.setenv("VLMC_TOWER_MEMO", "0")
     s0 = dict(cal.graph_stats)
     off = state(H.run_pruner("fp32_r50", "cuda:0")[0])
