@@ -9,10 +9,13 @@
 //             (lanes own 16-byte column chunks, so loads/stores are coalesced).  The k-th smallest
 //             key is found by radix-64 refinement of a bracket with 64 LDS counters (6 key bits
 //             per sweep), seeded by a 32-key sample of the row; ties are broken by column index
-//             exactly like the reference's stable sort.  See the kernel's header comment.
-//  SEL_MATRIX sample -> bracket, one counting pass (2048 LDS bins inside the bracket), one apply pass that
-//             leaves the few hundred elements of the threshold's bin to a one-workgroup resolve kernel
-//             (which is also the exact fallback).  See the section comment below.
+//             exactly like the reference's stable sort.  See the kernel's header comment.  Rows of two widths
+//             (a T5 block: 2048 and 5120 columns) share one launch of 4-wave workgroups (select_rows_mixed_kernel).
+//  SEL_MATRIX one kernel of co-resident workgroups that keep W in registers (matrix_fused_kernel): sample ->
+//             bracket, 2048-bin histogram of the bracket, grid barrier, bin of rank k (refined from the registers if
+//             crowded), candidate keys exchanged through per-workgroup slots, grid barrier, exact threshold, apply.
+//             The four-launch form (sample / count / apply / resolve) remains for in_features > 8192 and as the
+//             cross-check.  See the section comments below.
 //  SEL_NM     elementwise: each lane ranks the columns of its m-groups in registers.
 // Every kernel takes a table of up to 12 linears ("jobs") by value, so all linears of a transformer
 // block that share a launch shape go to the GPU in ONE launch.
@@ -975,7 +978,7 @@ __global__ __launch_bounds__(1024) void matrix_resolve_kernel(const SelBatch b) 
 // bounded spin runs out and a waiter raises the barrier's fail bit: then NO workgroup of the job passes that
 // barrier, nobody touches W or the mask, and the job's last workgroup to finish (done counter) does the exact
 // streaming select over the whole matrix (matrix_resolve_job<WRITE_ALL>) -- as it does when the sampled bracket
-// missed rank k, the bin reaches the NaN keys or heavy ties overflow the candidate list.  Every wave therefore
+// missed rank k, the bin reaches the NaN keys or a skewed bin overflows one workgroup's slot.  Every wave therefore
 // reaches the end of the kernel whatever the residency.
 // The job's global histogram and control words must be ZERO on entry; the last workgroup zeroes them again.
 // ------------------------------------------------------------------------------------------
@@ -1137,7 +1140,7 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
         uint32_t bin, before;
         const bool found = block_find_rank(h, jb.k - bel, red, bin, before);
         const uint64_t bin_end = uint64_t(lo) + (uint64_t(bin + 1u) << bshift);
-        // the sampled bracket missed rank k, or the bin reaches the NaN keys: exact fallback (resolve launch)
+        // the sampled bracket missed rank k, or the bin reaches the NaN keys: exact fallback (the job's last workgroup)
         fail = bel > jb.k || !found || bin_end > 0x7F800001ull;
         if (!fail) {
             uint32_t lob = lo + (bin << bshift), rankb = jb.k - bel - before, pop = red[18];
