@@ -115,12 +115,17 @@ class TowerMemo:
 
     @staticmethod
     def fingerprint(blocks):
+        """(addresses, per-tensor float64 sums) of the tower's parameters and buffers, or None if they cannot be taken
+        (tensors on several devices, exotic dtypes): then there is no memo."""
         ts = [t for b in blocks for t in list(b.parameters()) + list(b.buffers())]
-        sums = torch.stack([torch.sum(t.detach(), dtype=torch.float64) for t in ts]) if ts else torch.zeros(0)
+        try:
+            sums = torch.stack([torch.sum(t.detach(), dtype=torch.float64) for t in ts]) if ts else torch.zeros(0)
+        except Exception:
+            return None
         return tuple(t.data_ptr() for t in ts), sums
 
     def matches(self, fp):
-        return self.ok and bool(self.entries) and self.fp[0] == fp[0] and self.fp[1].shape == fp[1].shape \
+        return fp is not None and self.ok and bool(self.entries) and self.fp[0] == fp[0] and self.fp[1].shape == fp[1].shape \
             and bool(torch.equal(self.fp[1], fp[1]))
 
     def begin(self, mode):
@@ -220,7 +225,10 @@ def seed_tower_memo(proxy_cache, module_to_process, layers, final_outs, autocast
         return False
     with autocast():
         ctx = TowerMemo.context()                    # the walk's forwards ran under this autocast state
-    memo = TowerMemo(TowerMemo.fingerprint(list(layers)), len(layers))
+    fp = TowerMemo.fingerprint(list(layers))
+    if fp is None:
+        return False
+    memo = TowerMemo(fp, len(layers))
     memo.entries = [((c[0], c[1], ctx), final_outs[j].detach()) for j, c in enumerate(calls[:n])]
     proxy_cache[("memo", module_to_process)] = memo
     graph_stats["memo_recorded"] += n
@@ -339,11 +347,13 @@ def _wrap_towers(model, towers, proxy_cache=None):
             memo = proxy_cache.get(("memo", path))
             if memo is not None and memo.matches(fp):
                 memo.begin("replay")
-            else:
+            elif fp is not None:
                 memo = proxy_cache[("memo", path)] = TowerMemo(fp, len(proxies))
                 memo.begin("record")
+            else:
+                memo = None
             for i, proxy in enumerate(proxies):
-                proxy.__dict__["_memo"] = (memo, i)
+                proxy.__dict__["_memo"] = (memo, i) if memo is not None else None
     return undo
 
 
