@@ -1518,11 +1518,12 @@ static int launch_rows_mixed(const vlmc_select_job *jobs, int n_jobs, int apply_
     uint32_t units = 0;
     int64_t max_chunks = 0;
     int n = 0;
+    const bool wide_first = env_int("VLMC_MIXED_WIDE_FIRST", 1) != 0;   // (0: narrow first -- measured 62.5 vs 58.9 us per T5 block)
     for (int pass = 0; pass < 2; ++pass) {                      // wide jobs first
         for (int i = 0; i < n_jobs; ++i) {
             const vlmc_select_job &j = jobs[i];
             const bool is_wide = j.in_features > 2048;
-            if (is_wide != (pass == 0)) continue;
+            if (is_wide != (pass == (wide_first ? 0 : 1))) continue;
             fill_job(b.job[n], j);
             units += uint32_t(is_wide ? j.out_features : (j.out_features + 3) / 4);
             b.job[n].unit_end = units;
