@@ -1,31 +1,35 @@
 #!/usr/bin/env python
-"""bench.py -- Wanda 50 % unstructured prune of InstructBLIP-FlanT5-XL on MI355X.
+"""bench.py -- end-to-end Wanda 50 % unstructured prune of InstructBLIP-FlanT5-XL on MI355X.
 
-Metric (BASELINE.json): layers/sec (layer = one pruned nn.Linear) and total prune
-wall-clock for configs[1]: all 588 prunable linears (39 ViT-g blocks fp16 with the
-matrix-wide rule, 24+24 T5 blocks bf16 with the per-row rule), 128 calibration
-samples, synthetic weights N(0, 0.02) and synthetic activations N(0.1, 1) of the
-model's shapes (257 / 64 / 16 tokens), all resident in HBM before the timed region.
+Metric (BASELINE.json / SURVEY.md §8(d)): layers/sec and total prune wall-clock, where wall-clock is entry -> exit of
+`load_pruner("blipt5_wanda_pruner", ...).prune()` (what the reference's `@print_time prune` reports,
+wanda_pruner.py:947) on configs[1]: all 588 prunable linears (39 ViT-g blocks fp16 with the matrix-wide rule, 24 + 24
+Flan-T5-XL blocks bf16 with the per-row rule), 128 batch-1 calibration samples, random-init weights of the true
+architecture and synthetic calibration data (`vlmc/synthetic.py`), everything resident in HBM before the timed region.
 
-One "step" = one pass of the hot path over the whole model: per transformer block,
-activation statistics of every distinct linear input over the 128 samples
-(vlmc_act_sqnorm), the running-mean recurrence + sqrt (vlmc_wanda_scaler_update),
-and the fused score + select + apply of every linear (vlmc_wanda_select) -- i.e.
-SURVEY.md §8 rows a3-a8 without the block forward (row (f)1: the `end_to_end` object times a
-whole drop-in prune, replay engine included, beside the bench line).  Each timed step prunes a
-fresh copy of the dense weights.  `roofline` comes from HIP events carried by the kernel launches
-themselves (vlmc_set_launch_events -> hipExtLaunchKernel) on the launch stream, inside the timed
-region, on every `--event-stride`-th block of a step (DESIGN.md section 6 says why).
+One "step" = ONE whole prune through the drop-in pruner API: capture of each tower's inputs by the model's own
+forward, block replay over the calibration samples, activation statistics, score / select / apply of every linear.
+Before each step the dense weights are copied back (7.4 GB device-to-device, ~3 ms, inside the timed region).
+`value` = 588 x steps / seconds.  `config.subtotals_s` (capture / replay / stat / select) come from ONE extra, untimed
+prune with synchronising phase timers.  `roofline` is measured inside the timed steps with HIP events carried by the
+kernel launches themselves (vlmc_set_launch_events -> hipExtLaunchKernel) on a rotating subset of the launches.
+`kernel_pass` is last round's headline kept as a sub-object: statistics + select kernels alone on resident
+activations (no block forward).
 
-N GPUs (`torchrun`, one rank per GPU): the 128 calibration samples are sharded in
-contiguous ranges, one RCCL all-gather of per-sample squared norms per block, select
-replicated on every rank -> total work fixed => "scaling": "strong".
+N GPUs: `python bench.py --gpus N` starts N ranks by itself (torch.distributed.run as a child process, before this
+process touches a GPU); under a launcher (WORLD_SIZE set) it is one of the ranks.  The 128 calibration samples are
+sharded over the ranks (capture, replay and statistics scale 1/N), one RCCL all-gather of per-sample statistics per
+block, select replicated: total work fixed => "scaling": "strong".
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 """
 import argparse
+import contextlib
+import io
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -37,8 +41,10 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA
 N_CALIB = 128
 RATIO = 0.5
+PRUNER = "blipt5_wanda_pruner"
 
 
 def parse():
@@ -46,123 +52,54 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline leg (0 = skip)")
-    ap.add_argument("--e2e", default="auto", choices=["auto", "0", "1"],
-                    help="also time one whole drop-in blipt5_wanda_pruner.prune() on the synthetic InstructBLIP-FlanT5-XL "
-                         "(auto: only at N=1)")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU-baseline leg (0 = skip)")
+    ap.add_argument("--kernel-pass", default="auto", choices=["auto", "0", "1"],
+                    help="also time the statistics + select kernels alone on resident activations (auto: only at N=1)")
+    ap.add_argument("--kernel-steps", type=int, default=10)
     ap.add_argument("--event-stride", type=int, default=4,
-                    help="HIP events on every N-th block of a step, rotating with the step (1 = every launch; a timed "
-                         "launch idles the GPU for ~10 us)")
-    ap.add_argument("--weight-sets", type=int, default=0, help="dense weight copies kept in HBM (0 = steps+warmup, capped by memory)")
+                    help="HIP events on every N-th launch of a timed kernel (1 = every launch; a timed launch idles the "
+                         "GPU for ~10 us)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds before self-launched ranks are killed")
     return ap.parse_args()
 
 
-def build_workload(dev, rank, world, n_sets_wanted):
-    from vlmc import workload as wl
-    blocks = wl.flan_t5_xl()
-    n_local = N_CALIB // world
-    # ---- activations: rank r holds samples [r*n_local, (r+1)*n_local) of every distinct input
-    acts = []
-    for bi, b in enumerate(blocks):
-        per_in = []
-        for ii, inp in enumerate(b.inputs):
-            g = torch.Generator(device=dev)
-            g.manual_seed(1_000_003 * bi + 1009 * ii + rank)
-            x = torch.empty((n_local, inp.tokens, inp.in_features), dtype=b.dtype, device=dev)
-            x.normal_(0.1, 1.0, generator=g)
-            per_in.append(x)
-        acts.append(per_in)
-    # ---- weights: as many dense copies as fit (each timed step prunes a fresh one)
-    bytes_per_set = sum(l.out_features * l.in_features * 2 for b in blocks for l in b.linears)
-    free, _ = torch.cuda.mem_get_info(dev)
-    mask_bytes = bytes_per_set // 2
-    fit = int((free - mask_bytes - (8 << 30)) // bytes_per_set)
-    n_sets = max(1, min(n_sets_wanted, fit))
-    sets = []
-    for s in range(n_sets):
-        ws, gi = [], 0
-        for b in blocks:
-            wb = []
-            for lin in b.linears:
-                if s == 0:
-                    g = torch.Generator(device=dev)
-                    g.manual_seed(gi)
-                    w = torch.empty((lin.out_features, lin.in_features), dtype=b.dtype, device=dev)
-                    w.normal_(0.0, 0.02, generator=g)
-                else:
-                    w = sets[0][len(ws)][len(wb)].clone()
-                wb.append(w)
-                gi += 1
-            ws.append(wb)
-        sets.append(ws)
-    return blocks, acts, sets, n_local
+# ----------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks as a child process, before anything here touches a GPU
+# ----------------------------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    import signal
+    import socket
+    n_dev = torch.cuda.device_count()               # counting devices does not initialise the GPU
+    one_device = os.environ.get("VLMC_BENCH_ONE_DEVICE", "0") == "1"
+    if n_dev < args.gpus and not one_device:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible "
+                         f"(VLMC_BENCH_ONE_DEVICE=1 rehearses the N > 1 path with all ranks on cuda:0 over gloo)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        rc = child.wait(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(child.pid, signal.SIGKILL)          # exactly the process group started above
+        child.wait()
+        raise SystemExit(f"bench.py: the {args.gpus} ranks did not finish within {args.launch_timeout:.0f} s "
+                         f"(collective hang?) -- killed")
+    raise SystemExit(rc)
 
 
-def build_plans(blocks, acts, weights, n_local, world, dev, state):
-    """Pre-bind every launch of one step for one weight set: per block ONE batched statistics launch
-    (all distinct linear inputs), ONE batched running-mean launch, and one batched select call (the
-    library issues one launch per distinct (in_features, k) for the per-row rule, one launch sequence
-    for the matrix-wide rule)."""
-    from vlmc import ops, workload as wl
-    steps = []
-    for bi, b in enumerate(blocks):
-        ins = state["blocks"][bi]
-        stat = ops.plan_act_sqnorm_batch(acts[bi], [s["normsq_local"] for s in ins])
-        upd = ops.plan_scaler_update_batch([s["scaler"] for s in ins], 0, [s["normsq_all"] for s in ins], 1,
-                                           [s["sqrt"] for s in ins])
-        ws, sqs, ks, nbytes, li = [], [], [], 0, 0
-        for ii, inp in enumerate(b.inputs):
-            for lin in inp.linears:
-                w = weights[bi][li]
-                ws.append(w)
-                sqs.append(ins[ii]["sqrt"])
-                ks.append(int(lin.in_features * RATIO) if b.mode == "row" else int(lin.out_features * lin.in_features * RATIO))
-                nbytes += wl.select_bytes(lin, w.element_size(), True)
-                li += 1
-        sel = ops.plan_select_batch(ws, sqs, b.mode, ks=ks, apply_zero=True, masks=state["masks"][bi],
-                                    partials=state["partials"][bi])
-        n_launch = 0
-        if b.mode == "row":
-            # csrc/wanda_select.hip: 16-bit rows of <= 2048 and of 2049..8192 columns in one call share ONE mixed launch
-            widths = {w.shape[1] for w in ws}
-            mixed = (os.environ.get("VLMC_SELECT_MIXED", "1") != "0" and len(ws) <= 12 and ws[0].element_size() == 2
-                     and max(widths) <= 8192 and min(widths) <= 2048 < max(widths) and all(i % 8 == 0 for i in widths))
-            n_launch = 1 if mixed else len({(w.shape[1], k) for w, k in zip(ws, ks)})
-        sbytes = sum(wl.stat_bytes(inp, n_local, acts[bi][ii].element_size()) for ii, inp in enumerate(b.inputs))
-        steps.append((stat, upd, sel, b.mode == "row", nbytes, n_launch, sbytes))
-    return steps
-
-
-def alloc_state(blocks, n_local, world, dev):
-    from vlmc import ops
-    st = {"blocks": [], "masks": [], "partials": [], "flat": []}
-    for b in blocks:
-        ins = []
-        tot = sum(i.in_features for i in b.inputs)
-        # one flat [samples, sum(in)] buffer per block: the statistics kernel writes column slices of it, the
-        # multi-GPU exchange is a single all-gather of it, the running-mean kernel reads column slices of it
-        flat_local = torch.empty((n_local, tot), dtype=torch.float32, device=dev)
-        flat_all = torch.empty((N_CALIB, tot), dtype=torch.float32, device=dev) if world > 1 else flat_local
-        off = 0
-        for inp in b.inputs:
-            ins.append({"scaler": torch.zeros(inp.in_features, dtype=torch.float32, device=dev),
-                        "sqrt": torch.empty(inp.in_features, dtype=torch.float32, device=dev),
-                        "normsq_local": flat_local[:, off:off + inp.in_features],
-                        "normsq_all": flat_all[:, off:off + inp.in_features]})
-            off += inp.in_features
-        st["blocks"].append(ins)
-        st["flat"].append((flat_local, flat_all))
-        st["masks"].append([torch.empty((l.out_features, l.in_features), dtype=torch.bool, device=dev) for l in b.linears])
-        st["partials"].append([torch.empty(ops.select_partials(b.mode, l.out_features, l.in_features), dtype=torch.float64,
-                                           device=dev) for l in b.linears])
-    return st
-
-
+# ----------------------------------------------------------------------------------------------------------------
+# HIP events carried by a kernel's own dispatch
+# ----------------------------------------------------------------------------------------------------------------
 class HipEvents:
     """HIP events of the runtime this process has loaded (ctypes on libamdhip64), handed to the kernel launch itself
     (vlmc_set_launch_events -> hipExtLaunchKernel): start / stop are the kernel's own begin / end on its stream.
-    An hipEventRecord between two kernels (torch.cuda.Event.record) costs ~5 us of idle GPU per record on MI355X --
-    270 records per step were 11 % of the step; this form costs nothing."""
+    An hipEventRecord between two kernels (torch.cuda.Event.record) costs ~5 us of idle GPU per record on MI355X."""
 
     def __init__(self):
         import ctypes
@@ -191,135 +128,325 @@ class HipEvents:
             raise RuntimeError(f"hipEventElapsedTime failed ({rc})")
         return float(ms.value)
 
-    def free(self, *evs):
-        for e in evs:
-            self.hip.hipEventDestroy(e)
+
+class LaunchProbe:
+    """Times launches of product kernels INSIDE the timed prunes: wraps entry points of `vlmc.ops` so that every
+    `stride`-th call that issues exactly ONE kernel launch carries a start / stop event pair.  The wrapper changes
+    nothing else about the call; the events are read after the timed region."""
+
+    def __init__(self, stride):
+        from vlmc import _lib
+        self.hipev = HipEvents()
+        self.arm = _lib.load().vlmc_set_launch_events
+        self.stride = max(1, stride)
+        self.records = {}          # kind -> [(start, stop, algorithmic units, launches)]
+        self.calls = {}
+        self.active = False
+        self._undo = []
+
+    def wrap(self, module, name, kind, units_of, single_launch=lambda *a, **k: True):
+        real = getattr(module, name)
+        probe = self
+
+        def wrapped(*a, **k):
+            if not probe.active or not single_launch(*a, **k):
+                return real(*a, **k)
+            n = probe.calls[kind] = probe.calls.get(kind, 0) + 1
+            if n % probe.stride:
+                return real(*a, **k)
+            e0, e1 = probe.hipev.new(), probe.hipev.new()
+            probe.arm(e0, e1)
+            out = real(*a, **k)
+            probe.records.setdefault(kind, []).append((e0, e1, units_of(*a, **k), 1))
+            return out
+        setattr(module, name, wrapped)
+        self._undo.append((module, name, real))
+
+    def restore(self):
+        for module, name, real in self._undo:
+            setattr(module, name, real)
+        self._undo = []
+
+    def summary(self, kind):
+        evs = self.records.get(kind, [])
+        ms = sum(self.hipev.elapsed_ms(a, b) for a, b, _, _ in evs)
+        return ms, sum(u for _, _, u, _ in evs), sum(n for _, _, _, n in evs)
 
 
-def run_step(plans, state, world, events=None, hipev=None, set_events=None, phase=0, stride=1):
-    """events = {"stat": [...], "rows": [...]} collects (start, stop, algorithmic bytes, launches): HIP events carried by
-    the statistics launch and by the per-row select launch of a block, on the launch stream.  A launch that carries
-    events is preceded and followed by ~5 us of idle GPU (its completion signal is waited for), so only every
-    `stride`-th block of a step is timed, rotating with the step index: every launch is covered once per `stride` steps."""
-    for bi, (stat, upd, sel, is_row, nbytes, n_launch, sbytes) in enumerate(plans):
-        timed = events is not None and (bi + phase) % stride == 0
-        if timed:
-            a, b = hipev.new(), hipev.new()
-            set_events(a, b)
-            stat()
-            events["stat"].append((a, b, sbytes, 1))
-        else:
-            stat()
-        if world > 1:          # ONE all-gather per block: [n_local, sum(in)] -> [128, sum(in)] in sample order
-            flat_local, flat_all = state["flat"][bi]
-            dist.all_gather_into_tensor(flat_all, flat_local)
-        upd()
-        if timed and is_row and n_launch == 1:
-            a, b = hipev.new(), hipev.new()
-            set_events(a, b)
-            sel()
-            events["rows"].append((a, b, nbytes, n_launch))
-        else:
-            sel()
+def install_probes(probe):
+    """The statistics kernel (one launch per group of calibration samples and block) and the per-row select (one
+    mixed launch per T5 block) are single launches behind one `vlmc.ops` call each."""
+    from vlmc import ops
+
+    def sq_bytes(xs, outs=None):
+        return sum(x.numel() * x.element_size() + x.shape[0] * x.shape[-1] * 4 for x in xs)
+
+    def sel_bytes(ws, sqs, mode, ks=None, n=0, m=0, apply_zero=True, **kw):
+        return sum(w.numel() * (w.element_size() + 1 + (w.element_size() if apply_zero else 0)) + 4 * w.shape[1] for w in ws)
+
+    def sel_single(ws, sqs, mode, ks=None, **kw):
+        if mode != "row" or ws[0].element_size() != 2 or len(ws) > 12:
+            return False
+        widths = {w.shape[1] for w in ws}
+        return (len(widths) == 1 and len(set(ks)) == 1) or \
+            (os.environ.get("VLMC_SELECT_MIXED", "1") != "0" and max(widths) <= 8192 and min(widths) <= 2048 < max(widths)
+             and all(i % 8 == 0 for i in widths))
+
+    probe.wrap(ops, "act_sqnorm_batch", "stat", sq_bytes)
+    probe.wrap(ops, "wanda_select_batch", "rows", sel_bytes, sel_single)
 
 
-def cpu_baseline(blocks, budget_s):
-    """Time the oracle (the reference's PyTorch-CPU op sequence, oracle/wanda_torch.py) on a
-    bounded sample of the same workload: whole blocks taken round-robin from the three towers
-    until the time budget is used.  Checker code timed as a baseline, never shipped."""
-    from oracle import wanda_torch as OT
-    order = [0, 39, 63]                      # first ViT block, first encoder block, first decoder block
-    order += [1, 40, 64, 2, 41, 65]
-    t0 = time.perf_counter()
-    done, names = 0, []
-    for bi in order:
-        b = blocks[bi]
-        g = torch.Generator().manual_seed(bi)
+# ----------------------------------------------------------------------------------------------------------------
+# the headline: whole prunes through the drop-in API
+# ----------------------------------------------------------------------------------------------------------------
+class PruneJob:
+    def __init__(self, dev):
+        from vlmc import synthetic
+        self.dev = dev
+        self.model = synthetic.InstructBlipT5().to(dev).eval()
+        synthetic.randomize_(self.model, 0)
+        self.params = [p for p in self.model.parameters()]
+        self.dense = [p.detach().clone() for p in self.params]
+        self.batches = synthetic.calibration_batches(N_CALIB, dev, vocab=self.model.t5_model.shared.num_embeddings)
+        self.n_linears = synthetic.prunable_linears(self.model)
+        keep = 1 - RATIO
+        self.cfg = dict(t5_prune_spec=f"24-{keep!r}-1.0-1.0", vit_prune_spec=f"39-{keep!r}-1.0-1.0", t5_pruning_method="wanda",
+                        vit_pruning_method="wanda", num_samples=N_CALIB, max_sparsity_per_layer=1.01)
+
+    def step(self):
+        from lavis.compression import load_pruner
+        with torch.no_grad():
+            torch._foreach_copy_(self.params, self.dense)           # dense weights back (7.4 GB d2d)
+        pruner = load_pruner(PRUNER, self.model, self.batches, cfg=dict(self.cfg))
+        with contextlib.redirect_stdout(io.StringIO()):
+            pruner.prune()
+
+    def pruned_fraction(self):
+        zeros = total = 0
+        for name, mod in self.model.named_modules():
+            if isinstance(mod, torch.nn.Linear) and (".blocks." in name or ".block." in name):
+                zeros += int((mod.weight == 0).sum())
+                total += mod.weight.numel()
+        return zeros / max(1, total)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# kernel pass (last round's headline, kept as a sub-object): statistics + select on resident activations
+# ----------------------------------------------------------------------------------------------------------------
+def kernel_pass(dev, steps, warmup, stride):
+    from vlmc import _lib, ops, workload as wl
+    blocks = wl.flan_t5_xl()
+    acts, weights0 = [], []
+    gi = 0
+    for bi, b in enumerate(blocks):
+        per_in = []
+        for ii, inp in enumerate(b.inputs):
+            g = torch.Generator(device=dev).manual_seed(1_000_003 * bi + 1009 * ii)
+            x = torch.empty((N_CALIB, inp.tokens, inp.in_features), dtype=b.dtype, device=dev)
+            x.normal_(0.1, 1.0, generator=g)
+            per_in.append(x)
+        acts.append(per_in)
+        wb = []
+        for lin in b.linears:
+            g = torch.Generator(device=dev).manual_seed(gi)
+            w = torch.empty((lin.out_features, lin.in_features), dtype=b.dtype, device=dev)
+            w.normal_(0.0, 0.02, generator=g)
+            wb.append(w)
+            gi += 1
+        weights0.append(wb)
+    n_sets = steps + warmup
+    sets = [weights0] + [[[w.clone() for w in wb] for wb in weights0] for _ in range(n_sets - 1)]
+    plans_per_set = []
+    state = []
+    for b in blocks:
+        tot = sum(i.in_features for i in b.inputs)
+        flat = torch.empty((N_CALIB, tot), dtype=torch.float32, device=dev)
+        ins, off = [], 0
         for inp in b.inputs:
-            st = OT.WandaStat(inp.in_features)
-            for j in range(N_CALIB):
-                x = (torch.randn((1, inp.tokens, inp.in_features), generator=g) + 0.1).to(b.dtype)
-                st.add_batch(x)
-            for lin in inp.linears:
-                w = (torch.randn((lin.out_features, lin.in_features), generator=g) * 0.02).to(b.dtype)
-                OT.prune_linear(w, st.scaler_row, b.mode, ratio=RATIO, apply_zero=True)
-                done += 1
-        names.append(b.name)
-        if time.perf_counter() - t0 > budget_s:
-            break
+            ins.append({"scaler": torch.zeros(inp.in_features, dtype=torch.float32, device=dev),
+                        "sqrt": torch.empty(inp.in_features, dtype=torch.float32, device=dev),
+                        "normsq": flat[:, off:off + inp.in_features]})
+            off += inp.in_features
+        state.append({"ins": ins,
+                      "masks": [torch.empty((l.out_features, l.in_features), dtype=torch.bool, device=dev) for l in b.linears],
+                      "partials": [torch.empty(ops.select_partials(b.mode, l.out_features, l.in_features), dtype=torch.float64,
+                                               device=dev) for l in b.linears]})
+    for ws_all in sets:
+        plans = []
+        for bi, b in enumerate(blocks):
+            ins = state[bi]["ins"]
+            stat = ops.plan_act_sqnorm_batch(acts[bi], [s["normsq"] for s in ins])
+            upd = ops.plan_scaler_update_batch([s["scaler"] for s in ins], 0, [s["normsq"] for s in ins], 1, [s["sqrt"] for s in ins])
+            ws, sqs, ks, nbytes, li = [], [], [], 0, 0
+            for ii, inp in enumerate(b.inputs):
+                for lin in inp.linears:
+                    w = ws_all[bi][li]
+                    ws.append(w)
+                    sqs.append(ins[ii]["sqrt"])
+                    ks.append(int(lin.in_features * RATIO) if b.mode == "row" else int(lin.out_features * lin.in_features * RATIO))
+                    nbytes += wl.select_bytes(lin, w.element_size(), True)
+                    li += 1
+            sel = ops.plan_select_batch(ws, sqs, b.mode, ks=ks, apply_zero=True, masks=state[bi]["masks"],
+                                        partials=state[bi]["partials"])
+            sbytes = sum(wl.stat_bytes(inp, N_CALIB, acts[bi][ii].element_size()) for ii, inp in enumerate(b.inputs))
+            plans.append((stat, upd, sel, b.mode, nbytes, sbytes))
+        plans_per_set.append(plans)
+
+    hipev = HipEvents()
+    arm = _lib.load().vlmc_set_launch_events
+    events = {"stat": [], "rows": [], "matrix": []}
+
+    def run(plans, phase=None):
+        for bi, (stat, upd, sel, mode, nbytes, sbytes) in enumerate(plans):
+            timed = phase is not None and (bi + phase) % stride == 0
+            if timed:
+                a, b_ = hipev.new(), hipev.new()
+                arm(a, b_)
+                stat()
+                events["stat"].append((a, b_, sbytes))
+            else:
+                stat()
+            upd()
+            if timed:
+                a, b_ = hipev.new(), hipev.new()
+                arm(a, b_)
+                sel()
+                events["rows" if mode == "row" else "matrix"].append((a, b_, nbytes))
+            else:
+                sel()
+
+    for i in range(warmup):
+        run(plans_per_set[i])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        run(plans_per_set[warmup + i], phase=i)
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "layers/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{done} linears of {len(names)} blocks ({', '.join(names)}), {N_CALIB} calib samples each, "
-                      f"synthetic data generation included, {dt:.1f} s"}
+    n_lin = sum(len(b.linears) for b in blocks)
 
+    def roof(kind, kernel, tkey, traffic):
+        evs = events[kind]
+        ms = sum(hipev.elapsed_ms(a, b_) for a, b_, _ in evs)
+        nb = sum(x for _, _, x in evs)
+        ach = nb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(tkey), "launches": len(evs),
+                "avg_launch_us": round(ms * 1e3 / max(1, len(evs)), 2), "bytes_per_launch": round(nb / max(1, len(evs)))}
 
-def end_to_end(dev, world):
-    """Whole-prune wall-clock through the drop-in pruner API (capture of the towers' inputs by the model's own forward,
-    block replay, statistics, score/select/apply of all 588 linears) on a random-init model of the true shapes.
-    Reported beside the timed hot path, never part of `value`."""
-    from vlmc import synthetic
-    out = {"model": "synthetic InstructBLIP-FlanT5-XL shapes (39 ViT-g fp16 + 24/24 Flan-T5-XL bf16 blocks, Q-Former replaced "
-                    "by its 32 query tokens), random init", "pruner": "blipt5_wanda_pruner", "calib_samples": N_CALIB,
-           "calib_sharded_over": world}
-    model = None
-    for key, env in (("seconds", {}), ("seconds_batched32", {"VLMC_BATCH_REPLAY": "32"})):
-        saved = {k: os.environ.get(k) for k in ("VLMC_BATCH_REPLAY", "VLMC_GRAPH_REPLAY")}
-        os.environ.update(env)
-        try:
-            dt, model, info = synthetic.time_prune(dev, "blipt5_wanda_pruner", n_samples=N_CALIB, ratio=RATIO, model=model)
-        finally:
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        out[key] = round(dt, 3)
-        out["layers_per_s" + key[len("seconds"):]] = round(info["linears"] / dt, 1)
-        out["pruned_fraction"] = round(info["pruned_fraction"], 6)
-    out["replay"] = {"seconds": "per-sample block forwards from HIP graphs (bit-identical to the reference's loop)",
-                     "seconds_batched32": "VLMC_BATCH_REPLAY=32 (32 samples per block forward; masks agree up to near-ties)"}
+    traffic = load_traffic()
+    out = {"what": "statistics + running mean + fused score/select/apply of all 588 linears on activations resident in HBM "
+                   "(128 samples x 257/64/16 tokens), no block forward -- SURVEY.md §8 rows a3-a8 alone",
+           "steps": steps, "ms_per_pass": round(dt / steps * 1e3, 3), "layers_per_s": round(n_lin * steps / dt, 1),
+           "kernels": [roof("stat", "vlmc::act_sqnorm_kernel", "act_sqnorm_kernel_bytes_per_launch", traffic),
+                       roof("rows", "vlmc::select_rows_mixed_kernel", "select_rows_mixed_kernel_bytes_per_launch", traffic),
+                       roof("matrix", "vlmc::matrix_fused_kernel", "matrix_fused_kernel_bytes_per_launch", traffic)]}
+    del acts, sets, plans_per_set, state
+    torch.cuda.empty_cache()
     return out
 
 
+def load_traffic():
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(tpath)) if os.path.exists(tpath) else {}
+    except Exception:
+        return {}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline (SURVEY.md §8(d)): the oracle's PyTorch-CPU op sequence on the GPU box's host cores
+# ----------------------------------------------------------------------------------------------------------------
+def cpu_baseline(budget_s):
+    """`oracle/wanda_torch.py` (the reference's own op sequence: running-mean (||x||_2)^2 statistics -> |W| * sqrt(s) ->
+    stable per-row sort / matrix-wide threshold -> scatter + zero), pinned to the reference's goldens by
+    tests/test_oracle_golden.py.  Data are generated OUTSIDE the timers; per linear 1 warm-up + median of >= 5 runs,
+    with all host threads and with one.  Checker code timed as a baseline, never shipped."""
+    from oracle import wanda_torch as OT
+    cases = [  # configs[0] (one FlanT5-XL encoder FFN linear, 8 CPU calibration samples of 64 tokens) + the ViT rule
+        ("t5.wi_0 5120x2048 bf16 per-row", 5120, 2048, torch.bfloat16, "row", 8, 64),
+        ("t5.wo 2048x5120 bf16 per-row", 2048, 5120, torch.bfloat16, "row", 8, 64),
+        ("vit.fc1 6144x1408 fp16 matrix-wide", 6144, 1408, torch.float16, "matrix", 8, 257),
+    ]
+    data = []
+    for ci, (name, out_f, in_f, dt, mode, n, T) in enumerate(cases):
+        g = torch.Generator().manual_seed(ci)
+        w = (torch.randn((out_f, in_f), generator=g) * 0.02).to(dt)
+        xs = [(torch.randn((1, T, in_f), generator=torch.Generator().manual_seed(1 + j)) + 0.1).to(dt) for j in range(n)]
+        data.append((name, w, xs, mode))
+    all_threads = torch.get_num_threads()
+    t_start = time.perf_counter()
+
+    def one(w, xs, mode):
+        st = OT.WandaStat(w.shape[1])
+        for x in xs:
+            st.add_batch(x)
+        OT.prune_linear(w.clone(), st.scaler_row, mode, ratio=RATIO, apply_zero=True)
+
+    res = {}
+    for threads in (all_threads, 1):
+        torch.set_num_threads(threads)
+        per = []
+        for name, w, xs, mode in data:
+            one(w, xs, mode)                                                    # warm-up
+            ts = []
+            while len(ts) < 5 or (len(ts) < 9 and time.perf_counter() - t_start < budget_s * 0.5):
+                t0 = time.perf_counter()
+                one(w, xs, mode)
+                ts.append(time.perf_counter() - t0)
+                if time.perf_counter() - t_start > budget_s * 2:
+                    break
+            med = statistics.median(ts)
+            b_sel = w.numel() * (w.element_size() + 1 + w.element_size()) + 4 * w.shape[1]
+            per.append({"linear": name, "ms": round(med * 1e3, 2), "runs": len(ts), "GBps": round(b_sel / med / 1e9, 4)})
+        res[threads] = per
+    torch.set_num_threads(all_threads)
+    tot = sum(p["ms"] for p in res[all_threads]) * 1e-3
+    tot1 = sum(p["ms"] for p in res[1]) * 1e-3
+    return {"value": round(len(cases) / tot, 3), "unit": "layers/s", "cores": all_threads, "kind": "port",
+            "sample": f"configs[0]: Wanda 50 % of t5.wi_0 5120x2048 and t5.wo 2048x5120 (bf16, per-row rule, 8 calibration samples "
+                      f"x 64 tokens) + vit.fc1 6144x1408 (fp16, matrix-wide rule, 8 x 257 tokens): statistics + score + "
+                      f"select + apply per linear, data generated outside the timers, 1 warm-up + median of >= 5 runs; "
+                      f"{time.perf_counter() - t_start:.1f} s of CPU work",
+            "ms_per_linear": res[all_threads], "one_thread": {"value": round(len(cases) / tot1, 3), "unit": "layers/s",
+                                                              "cores": 1, "ms_per_linear": res[1]},
+            "bytes_model": "B_sel = out*in*(2 [read W] + 1 [bool mask] + 2 [zeroed W]) + 4*in (SURVEY.md §8d)"}
+
+
+# ----------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)                          # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback of the product path)")
-    # VLMC_BENCH_ONE_DEVICE=1 (testing the N > 1 code path on a 1-GPU box): every rank uses cuda:0 and the
-    # collective runs over gloo -- never set by the driver
+    # VLMC_BENCH_ONE_DEVICE=1 (rehearsing the N > 1 code path on a 1-GPU box): every rank uses cuda:0 and the
+    # collectives run over gloo -- never set by the driver
     one_device = os.environ.get("VLMC_BENCH_ONE_DEVICE", "0") == "1"
     if one_device:
         local_rank = 0
-        # several processes on one device contend for the CUs the fused matrix-wide select keeps to itself (its barriers
-        # would time out and the exact fallback run): the rehearsal uses the four-launch form
+        # ranks sharing a device contend for the CUs the fused matrix-wide select keeps to itself: four-launch form
         os.environ.setdefault("VLMC_MATRIX_FUSED", "0")
+    elif world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"WORLD_SIZE={world} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if one_device:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        import datetime
+        backend = "gloo" if one_device else "nccl"
+        kw = {} if one_device else {"device_id": dev}
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=600), **kw)
     assert N_CALIB % world == 0
 
     from vlmc import _lib
     _lib.load()                                   # fail loudly if the HIP library is missing
-
-    want_sets = args.weight_sets or (args.steps + args.warmup)
-    blocks, acts, sets, n_local = build_workload(dev, rank, world, want_sets)
-    state = alloc_state(blocks, n_local, world, dev)
-    plans = [build_plans(blocks, acts, w, n_local, world, dev, state) for w in sets]
-    n_lin = sum(len(b.linears) for b in blocks)
 
     def sync():
         torch.cuda.synchronize()
@@ -327,81 +454,93 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        run_step(plans[i % len(plans)], state, world)
+    job = PruneJob(dev)
+    probe = LaunchProbe(args.event_stride)
+    install_probes(probe)
+    for _ in range(args.warmup):
+        job.step()
     sync()
-    events = {"stat": [], "rows": []}
-    hipev = HipEvents()
-    set_events = _lib.load().vlmc_set_launch_events
+    probe.active = True
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        run_step(plans[(args.warmup + i) % len(plans)], state, world, events, hipev, set_events, phase=i,
-                 stride=max(1, args.event_stride))
+    for _ in range(args.steps):
+        job.step()
     sync()
     elapsed = time.perf_counter() - t0
+    probe.active = False
+    probe.restore()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    pruned_fraction = job.pruned_fraction()
 
-    # ---- roofline of the dominant kernel (largest share of the step's GPU time): the activation
-    # ---- statistics kernel; the per-row score+select kernel is reported beside it ----------------
-    traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath))
-        except Exception:
-            traffic = {}
+    # ---- sub-totals: one extra, untimed prune with synchronising phase timers ------------------------------------
+    from vlmc import phases
+    os.environ["VLMC_PHASE_TIMERS"] = "1"
+    phases.reset()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    job.step()
+    torch.cuda.synchronize()
+    phased_total = time.perf_counter() - t1
+    os.environ["VLMC_PHASE_TIMERS"] = "0"
+    sub = {k: round(v, 4) for k, v in phases.times.items()}
+    sub["other_host"] = round(phased_total - sum(phases.times.values()), 4)
+    sub["total_with_phase_syncs"] = round(phased_total, 4)
+
+    # ---- roofline of the dominant product kernel of the step --------------------------------------------------------
+    traffic = load_traffic()
 
     def roof(kind, kernel, tkey):
-        evs = events[kind]
-        tot_ms = sum(hipev.elapsed_ms(a, b) for a, b, _, _ in evs)
-        tot_bytes = sum(nb for _, _, nb, _ in evs)
-        n_launches = sum(nl for _, _, _, nl in evs)
-        ach = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+        ms, nbytes, n = probe.summary(kind)
+        ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(tkey), "launches": n_launches,
-                "avg_launch_us": round(tot_ms * 1e3 / max(1, n_launches), 2),
-                "timed": f"HIP events carried by the launch (hipExtLaunchKernel) on every {max(1, args.event_stride)}-th block "
-                         f"of a step, rotating with the step index",
-                "bytes_per_launch": round(tot_bytes / max(1, n_launches))}
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(tkey), "launches": n,
+                "avg_launch_us": round(ms * 1e3 / max(1, n), 2), "bytes_per_launch": round(nbytes / max(1, n)),
+                "timed": f"HIP events carried by the launch (hipExtLaunchKernel) on every {probe.stride}-th launch of this "
+                         f"kernel inside the timed prunes"}
 
-    roofline = roof("stat", "vlmc::act_sqnorm_kernel (per-sample squared column norms of every distinct linear input "
-                            "of a block, one launch per block)", "act_sqnorm_kernel_bytes_per_launch")
+    roofline = roof("stat", "vlmc::act_sqnorm_kernel (per-sample squared column norms of every distinct linear input of a "
+                            "block; one launch per group of calibration samples)", "act_sqnorm_kernel_bytes_per_launch")
     roofline["other"] = [roof("rows", "vlmc::select_rows_mixed_kernel (score+select+apply, per-row rule; all linears of a T5 "
                                       "block in one launch)", "select_rows_mixed_kernel_bytes_per_launch")]
 
-    e2e, n_sets = None, len(sets)
-    if args.e2e == "1" or (args.e2e == "auto" and world == 1):
-        n_sets = len(sets)
-        del plans, sets, acts, state
+    kp = None
+    if args.kernel_pass == "1" or (args.kernel_pass == "auto" and world == 1):
+        del job
         torch.cuda.empty_cache()
         try:
-            e2e = end_to_end(dev, world)
+            kp = kernel_pass(dev, args.kernel_steps, 2, max(1, args.event_stride))
+            for k in kp["kernels"]:
+                if "matrix_fused" in k["kernel"]:
+                    roofline["other"].append(dict(k, timed="kernel_pass sub-run (the fused matrix-wide select's call issues no "
+                                                           "other launch there)"))
         except Exception as e:                    # never lose the bench line to the side measurement
-            e2e = {"error": f"{type(e).__name__}: {e}"}
+            kp = {"error": f"{type(e).__name__}: {e}"}
 
     out = None
     if rank == 0:
+        sec = elapsed / args.steps
+        n_lin = 588
         out = {
-            "metric": "layers/sec, Wanda@50% unstructured, InstructBLIP-FlanT5-XL (588 linears, 128 calib samples)",
+            "metric": "layers/sec + total prune wall-clock, InstructBLIP-FlanT5-XL Wanda@50% (588 linears, 128 calib samples)",
             "value": round(n_lin * args.steps / elapsed, 1), "unit": "layers/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: Wanda 50% unstructured, full InstructBLIP-FlanT5-XL shapes "
-                                   "(39 ViT-g blocks fp16 matrix-wide rule + 24/24 T5 blocks bf16 per-row rule), "
-                                   "128 calib samples, tokens 257/64/16; statistics + score/select/apply of every linear",
-                       "linears": n_lin, "blocks": len(blocks), "calib_samples": N_CALIB, "ratio": RATIO,
-                       "weight_sets": n_sets, "total_prune_wall_clock_s": round(elapsed / args.steps, 5),
-                       "parallelism": f"calib-dp{world}"},
+            "warmup": args.warmup, "ms_per_step": round(sec * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f16/bf16", "data": "synthetic",
+            "config": {"workload": "configs[1]: one whole load_pruner('blipt5_wanda_pruner').prune() -- Wanda 50% unstructured, "
+                                   "InstructBLIP-FlanT5-XL architecture and shapes (39 ViT-g blocks fp16 matrix-wide rule + 24/24 "
+                                   "Flan-T5-XL blocks bf16 per-row rule; Q-Former, never pruned, replaced by its 32 query tokens), "
+                                   "random init, 128 batch-1 calibration samples (257 image tokens, 32+32 text, 16 output tokens)",
+                       "linears": n_lin, "blocks": 87, "calib_samples": N_CALIB, "ratio": RATIO,
+                       "total_prune_wall_clock_s": round(sec, 4), "blocks_per_s": round(87 / sec, 1),
+                       "pruned_fraction": round(pruned_fraction, 6), "subtotals_s": sub,
+                       "replay": f"grouped: up to {os.environ.get('VLMC_BATCH_REPLAY', '128')} equal-shape samples per block forward",
+                       "parallelism": f"calib-dp{world}", "backend": backend,
+                       "world_size": dist.get_world_size() if world > 1 else 1},
             "roofline": roofline,
-            "end_to_end": e2e,
+            "kernel_pass": kp,
         }
-        if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(blocks, args.cpu_seconds)
-        else:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds) if world == 1 and args.cpu_seconds > 0 else None
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -541,6 +541,8 @@ def gen_ecoflap():
         "wanda_layer_obd_avg": dict(cls="wanda", gran="layer", score="obd_avg", kw={}),
         "wanda_model_gradient_sum": dict(cls="wanda", gran="model", score="gradient_sum", kw={}),
         "wanda_block_olmezo": dict(cls="wanda", gran="block", score="olmezo-gradient_sum", kw=dict(num_noise=2)),
+        "wanda_block_olmezo_aobd": dict(cls="wanda", gran="block", score="olmezo-aobd_sum", kw=dict(num_noise=2)),
+        "wanda_layer_lmezo_obd": dict(cls="wanda", gran="layer", score="lmezo-obd_sum", kw={}),
         "dsnot_block_per_model": dict(cls="dsnot", gran="block", score="aobd_sum", kw=dict(prune_per_model=True, max_cycle_time=4)),
     }
     out = {}

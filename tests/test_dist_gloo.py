@@ -105,6 +105,33 @@ def test_sample_sharded_pruner_world2_matches_reference_golden(tmp_path):
             assert torch.equal(m, G[f"fp32_r50/mask/{mn}"]), (r, mn)
 
 
+def _worker_replicas(rank, world, port, out_dir):
+    os.environ["VLMC_SHARD_CALIB"] = "0"
+    _setup(rank, world, port)
+    import pruner_helpers as H
+    for tag, run in (("wanda", H.run_pruner), ("dsnot", H.run_dsnot_pruner)):
+        pruned, _ = run("fp32_r50", "cpu")
+        torch.save({n: m.mask.clone() for n, m in pruned.named_modules() if hasattr(m, "mask")},
+                   os.path.join(out_dir, f"replica_{tag}_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_replica_mode_world2_exchanges_nothing_and_matches_reference_golden(tmp_path):
+    """`VLMC_SHARD_CALIB=0` under an initialised group (the reference's replica behaviour, and what the sharding error
+    message tells users to set): every rank replays ALL samples, so the statistics exchange must be skipped -- gathering
+    would count every sample world times (`assert st.nsamples == n_inps * batch0`, wanda_pruner.py:317)."""
+    import pruner_helpers as H
+    mp.spawn(_worker_replicas, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for tag, which in (("wanda", "wanda_e2e"), ("dsnot", "dsnot_e2e")):
+        G = H.golden(which)
+        for r in range(2):
+            masks = torch.load(tmp_path / f"replica_{tag}_{r}.pt")
+            assert len(masks) == 2 * 4 + 2 * 7 + 2 * 11
+            for mn, m in masks.items():
+                assert torch.equal(m, G[f"fp32_r50/mask/{mn}"]), (tag, r, mn)
+
+
 def _worker_dsnot_pruner(rank, world, port, out_dir):
     _setup(rank, world, port)
     import pruner_helpers as H

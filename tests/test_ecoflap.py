@@ -17,6 +17,8 @@ VARIANTS = {
     "wanda_layer_obd_avg": dict(cls="wanda", gran="layer", score="obd_avg", kw={}),
     "wanda_model_gradient_sum": dict(cls="wanda", gran="model", score="gradient_sum", kw={}),
     "wanda_block_olmezo": dict(cls="wanda", gran="block", score="olmezo-gradient_sum", kw=dict(num_noise=2)),
+    "wanda_block_olmezo_aobd": dict(cls="wanda", gran="block", score="olmezo-aobd_sum", kw=dict(num_noise=2)),
+    "wanda_layer_lmezo_obd": dict(cls="wanda", gran="layer", score="lmezo-obd_sum", kw={}),
     "dsnot_block_per_model": dict(cls="dsnot", gran="block", score="aobd_sum", kw=dict(prune_per_model=True, max_cycle_time=4)),
 }
 
@@ -87,3 +89,23 @@ def test_allocation_on_gpu_tracks_reference_run(name):
             tot += ref.numel()
             diff += int((mod.mask.cpu() != ref).sum())
     assert tot > 0 and diff / tot < 0.02, diff / tot
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["wanda_block_olmezo", "wanda_block_olmezo_aobd", "wanda_layer_lmezo_obd"])
+def test_zeroth_order_scores_run_on_gpu(name):
+    """The per-layer zeroth-order variants keep ONE host scalar per layer and combine it with the weights
+    (layer_single_base_pruner.py:566-571, :645-650, :722-727); the weights live on the GPU here.  The perturbations come
+    from the device's random stream, so the allocation is checked for what any seed must give, not against the CPU run."""
+    pruned, sd = _run(name, "cuda:0")
+    keys = [str(k) for k in G[f"{name}/keys"]]
+    assert sorted(sd.keys()) == keys
+    got = torch.tensor([float(sd[k]) for k in keys], dtype=torch.float64)
+    assert bool(torch.isfinite(got).all()) and 0.0 <= float(got.min()) and float(got.max()) <= 0.8 + 1e-6
+    assert float(got.max() - got.min()) > 1e-3                                           # non-uniform
+    n = 0
+    for mn, mod in pruned.named_modules():
+        if f"{name}/mask/{mn}" in G:
+            assert mod.mask.is_cuda and mod.mask.shape == mod.weight.shape
+            n += 1
+    assert n == 2 * 4 + 2 * 7 + 2 * 11

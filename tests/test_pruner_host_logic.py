@@ -73,6 +73,10 @@ def _run_sparsegpt_pruner(name, device="cpu"):
 @pytest.mark.parametrize("name", ["fp32_u50", "fp32_2_4"])
 def test_blipt5_sparsegpt_pruner_matches_reference_run(name, monkeypatch):
     oracle_ops.install_sparsegpt(monkeypatch)
+    # bit-exact against the reference's run needs its per-sample Hessian recurrence (one rounding pattern per update);
+    # the default grouped replay feeds all samples in one update and is held to SparseGPT's tolerance below
+    # (test_batched_replay_keeps_per_sample_statistics[sparsegpt])
+    monkeypatch.setenv("VLMC_BATCH_REPLAY", "1")
     nthreads = torch.get_num_threads()
     torch.set_num_threads(1)                      # the goldens' BLAS configuration (see test_oracle_golden.py)
     try:
@@ -186,3 +190,48 @@ def test_batched_replay_keeps_per_sample_statistics(method, monkeypatch):
     # 6 samples in groups of 4 + 2 -> two stacked calls per block pass, two passes per block, six blocks
     assert calls["stacked"] == 2 * 2 * 6
     print(method, st)
+
+
+@pytest.mark.parametrize("method", ["wanda", "dsnot"])
+def test_grouped_replay_of_ragged_calibration_text_keeps_the_sample_order(method, monkeypatch):
+    """Real calibration text is ragged: samples of equal shape are grouped even when they are not neighbours
+    (calibration.plan_groups), and the statistics still run the reference's recurrence in SAMPLE order -- the masks of
+    the grouped replay equal those of the per-sample loop (this CPU's matmul gives the same rows for any batch)."""
+    import toy_models
+    from lavis.compression import load_pruner
+    from lavis.compression.pruners import calibration as cal
+    (oracle_ops.install if method == "wanda" else oracle_ops.install_dsnot)(monkeypatch)
+    lens = [5, 7, 5, 5, 7, 3, 5, 7]                                  # text lengths: three shapes, interleaved
+
+    def run(group):
+        monkeypatch.setenv("VLMC_BATCH_REPLAY", str(group))
+        model = toy_models.init_toy(toy_models.ToyBlipT5(), seed=7).eval()
+        batches = []
+        for j, n in enumerate(lens):
+            b = toy_models.make_batches(1, txt_len=n, out_len=2 + n % 3, seed=100 + j)[0]
+            batches.append(b)
+        spec = "2-0.5-1.0-1.0"
+        cfg = dict(t5_prune_spec=spec, vit_prune_spec=spec, t5_pruning_method=method, vit_pruning_method=method,
+                   num_samples=len(lens), max_sparsity_per_layer=1.01)
+        if method == "dsnot":
+            cfg["max_cycle_time"] = 8
+        pruned, _ = load_pruner(f"blipt5_{method}_pruner", model, batches, cfg=cfg).prune()
+        return {n: m.mask.clone() for n, m in pruned.named_modules() if hasattr(m, "mask")}
+
+    plans = []
+    real = cal.plan_groups
+
+    def spy(cur_in, caches, n, g):
+        out = real(cur_in, caches, n, g)
+        plans.append(out)
+        return out
+    monkeypatch.setattr(cal, "plan_groups", spy)
+    per_sample = run(1)
+    assert not plans                                                  # the per-sample loop plans nothing
+    grouped = run(128)
+    assert [5, 7, 3] and any(len(c) > 1 and c != list(range(c[0], c[0] + len(c))) for p in plans for c in p), \
+        "no group of non-neighbouring samples was formed"
+    assert all(sorted(j for c in p for j in c) == list(range(len(lens))) for p in plans)
+    assert per_sample.keys() == grouped.keys() and len(grouped) == 2 * 4 + 2 * 7 + 2 * 11
+    for k in per_sample:
+        assert torch.equal(per_sample[k], grouped[k]), k

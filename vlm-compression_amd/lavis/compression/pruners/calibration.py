@@ -27,6 +27,8 @@ import os
 import torch
 import torch.nn as nn
 
+from vlmc import phases
+
 T5_KEYS = ["attention_mask", "position_bias", "encoder_attention_mask", "encoder_decoder_position_bias",
            "layer_head_mask", "cross_attn_layer_head_mask", "encoder_hidden_states"]      # wanda_pruner.py:225-228
 OPT_KEYS = ["attention_mask", "layer_head_mask"]                                         # :230-232
@@ -59,14 +61,7 @@ class _Stop(ValueError):
     """Raised by the catcher to abort the model forward (the reference raises ValueError)."""
 
 
-def calibration_shard():
-    """(rank, world) for sample sharding, or (0, 1) when running as replicas."""
-    import torch.distributed as dist
-    if os.environ.get("VLMC_SHARD_CALIB", "1") == "0":
-        return 0, 1
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return dist.get_rank(), dist.get_world_size()
-    return 0, 1
+from vlmc.shard import calibration_shard  # noqa: E402,F401  (one answer for capture, replay and the exchanges)
 
 
 def _keys_for(model_prefix):
@@ -275,8 +270,10 @@ class GraphedModule(nn.Module):
         if self._off or torch.is_grad_enabled():
             return mod(*args, **kwargs)
         names = sorted(kwargs)
-        key = tuple(self._sig(a) for a in args) + tuple((k, self._sig(kwargs[k])) for k in names)
-        if any(x is NotImplemented or (isinstance(x, tuple) and len(x) == 2 and x[1] is NotImplemented) for x in key) or \
+        # besides its arguments, the autocast state and the train / eval flags decide which kernels a block runs
+        key = (TowerMemo.context(), tuple(m.training for m in mod.modules())) + \
+            tuple(self._sig(a) for a in args) + tuple((k, self._sig(kwargs[k])) for k in names)
+        if any(x is NotImplemented or (isinstance(x, tuple) and len(x) == 2 and x[1] is NotImplemented) for x in key[2:]) or \
                 not any(isinstance(a, torch.Tensor) for a in list(args) + list(kwargs.values())):
             return mod(*args, **kwargs)
         ent = self._graphs.get(key)
@@ -368,6 +365,14 @@ def capture_block_inputs(model, dataloader, n_samples, module_to_process, forwar
     count_batches=True reproduces the SparseGPT pruners' stop rule (`i >= n_samples` on the
     batch index, sparsegpt_pruner.py:391-393) instead of Wanda's sample count.
     """
+    with phases.phase("capture"):
+        return _capture_block_inputs(model, dataloader, n_samples, module_to_process, forward_to_cache, lora_model, vit=vit,
+                                     model_prefix=model_prefix, count_batches=count_batches, done_towers=done_towers,
+                                     proxy_cache=proxy_cache)
+
+
+def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forward_to_cache, lora_model, *, vit,
+                          model_prefix, count_batches, done_towers, proxy_cache):
     layers = get_module_recursive(model, module_to_process)
     keys = None if vit else _keys_for(model_prefix)
     inps, caches = [], []
@@ -433,17 +438,45 @@ def capture_block_inputs(model, dataloader, n_samples, module_to_process, forwar
     return inps, [None] * len(inps), caches
 
 
+REPLAY_GROUP_DEFAULT = 128
+REPLAY_TOKEN_BUDGET = 1 << 16
+
+
 def replay_group_size():
-    """`VLMC_BATCH_REPLAY=G` (default 1 = the reference's per-sample loop): replay up to G calibration samples
-    of equal shape through a block in ONE forward call."""
+    """`VLMC_BATCH_REPLAY=G`: replay up to G calibration samples of equal shape through a block in ONE forward call
+    (default 128, i.e. the whole calibration set of the reference's scripts; `VLMC_BATCH_REPLAY=1` is the reference's
+    per-sample loop, replayed from HIP graphs)."""
     try:
-        return max(1, int(os.environ.get("VLMC_BATCH_REPLAY", "1")))
+        return max(1, int(os.environ.get("VLMC_BATCH_REPLAY", str(REPLAY_GROUP_DEFAULT))))
     except ValueError:
-        return 1
+        return REPLAY_GROUP_DEFAULT
 
 
-# While a stacked forward runs: (number of stacked calibration samples, their common batch size).  The statistics
-# hooks read it to keep the reference's per-sample bookkeeping (one `add_batch` per sample, :304-314).
+def plan_groups(cur_in, caches, n_samples, group_max):
+    """Which calibration samples go through the block together: samples whose input and cached kwargs have identical
+    shapes and dtypes (they need not be neighbours: real calibration text is ragged), at most `group_max` per call and at
+    most `VLMC_REPLAY_TOKENS` (default 65536) rows of activations per call.  Returns lists of sample indices, ordered by
+    their first member; the statistics keep the reference's per-sample order whatever the grouping."""
+    try:
+        budget = max(1, int(os.environ.get("VLMC_REPLAY_TOKENS", str(REPLAY_TOKEN_BUDGET))))
+    except ValueError:
+        budget = REPLAY_TOKEN_BUDGET
+    buckets = {}
+    for j in range(n_samples):
+        buckets.setdefault(_stack_key(cur_in[j], caches[j]), []).append(j)
+    chunks = []
+    for idx in buckets.values():
+        x = cur_in[idx[0]]
+        rows = max(1, x.numel() // max(1, x.shape[-1]))
+        g = max(1, min(group_max, budget // rows))
+        chunks += [idx[t:t + g] for t in range(0, len(idx), g)]
+    chunks.sort(key=lambda c: c[0])
+    return chunks
+
+
+# While a stacked forward runs: (number of stacked calibration samples, their common batch size, their indices in the
+# calibration set).  The statistics hooks read it to keep the reference's per-sample bookkeeping (one `add_batch` per
+# sample, :304-314) in the reference's sample order.
 _STACKED = None
 
 
@@ -506,9 +539,20 @@ class BlockGraph:
             torch.cuda.current_stream(x.device).wait_stream(side)
             self.records.clear()
             self.graph = torch.cuda.CUDAGraph()
+            versions = []
+
+            def recorder(mod, inp, out):                             # noqa: F811  (the capture's recorder also notes versions)
+                self.records.append((mod, inp[0], out))
+                versions.append((inp[0], inp[0]._version))
+            for m in modules:
+                m._forward_hooks = OrderedDict({0: recorder})
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad(), autocast():
                 y = layer(self.x, **self.cache)
                 self.y = y[0] if tuple_output else y
+            # the real hooks run AFTER the whole replay, on these static tensors: a block that writes into a linear's
+            # input in place after the linear has run would show them other activations than the eager loop does
+            if any(t._version != v for t, v in versions):
+                raise RuntimeError("the block modifies a hooked linear's input in place after the linear ran")
         finally:
             for m, h in zip(modules, saved):
                 m._forward_hooks = h
@@ -534,12 +578,14 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
     afterwards the block runs again with whatever weights `prune_block` left, and
     inputs/outputs swap (wanda_pruner.py:287-347).
 
-    Batched replay (`VLMC_BATCH_REPLAY=G`): runs of up to G consecutive samples whose inputs and
-    cached kwargs have identical shapes are concatenated along the batch dimension and go through the block in
-    one call -- batch-1 forwards of a 2048-wide block leave the matrix cores idle, and the 2 x 128 x 87 of them
-    are > 99 % of a FlanT5-XL prune once the statistics and select kernels take 14 ms.  Per-sample statistics are
-    kept (the hooks see `stacked_samples()`), so the only difference to the per-sample loop is the GEMM library's
-    accumulation order for a different M: activations agree to the last bits, masks up to near-ties.  Opt-in."""
+    Batched replay (default, `VLMC_BATCH_REPLAY=G` sets the group size): up to G samples whose inputs
+    and cached kwargs have identical shapes (`plan_groups`) are concatenated along the batch dimension and go through
+    the block in one call -- batch-1 forwards of a 2048-wide block leave the matrix cores idle, and the 2 x 128 x 87 of
+    them are > 75 % of a FlanT5-XL prune once the statistics and select kernels take 14 ms.  Per-sample statistics are
+    kept in the reference's sample order (the hooks see `stacked_samples()`).  `VLMC_BATCH_REPLAY=1` is the reference's
+    per-sample loop (:308-311, :343-346), replayed from HIP graphs.  Either way the activations are the GPU's, not
+    the reference host's: both modes track the reference's masks to the same near-tie agreement
+    (tests/test_pruner_gpu.py::test_replay_modes_agree_with_the_reference_side_by_side)."""
     global _STACKED
     layers = get_module_recursive(model, module_to_process)
     n_samples = min(n_samples, len(inps))
@@ -547,6 +593,10 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
     group_max = replay_group_size()
 
     def run_pass(before_sample=None):
+        with phases.phase("replay"):
+            _run_pass(before_sample)
+
+    def _run_pass(before_sample):
         global _STACKED
         cur_in, cur_out = state["inps"], state["outs"]
         keys = None
@@ -561,51 +611,50 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
             counts = {}
             for k in keys:
                 counts[k] = counts.get(k, 0) + 1
-        j = 0
-        while j < n_samples:
-            if keys is not None and counts[keys[j]] >= GRAPH_MIN_SAMPLES and graphs.get(keys[j]) is not False:
+        if keys is not None:                                      # per-sample loop, replayed from HIP graphs
+            j = 0
+            while j < n_samples:
                 if before_sample is not None:
                     before_sample(j)
-                bg = graphs.get(keys[j])
-                if bg is None:
-                    try:
-                        bg = graphs[keys[j]] = BlockGraph(layer, cur_in[j], caches[j], subset, autocast, tuple_output)
-                    except Exception as e:          # block not capturable (host sync, data-dependent shapes): eager loop
-                        graphs[keys[j]] = False
-                        layer._vlmc_no_graph = True             # do not try again in the second pass
-                        graph_stats["fallbacks"] += 1
-                        print(f"graph replay disabled for this block ({type(e).__name__}: {e})")
-                        bg = None
+                bg = None
+                if counts[keys[j]] >= GRAPH_MIN_SAMPLES and graphs.get(keys[j]) is not False:
+                    bg = graphs.get(keys[j])
+                    if bg is None:
+                        try:
+                            bg = graphs[keys[j]] = BlockGraph(layer, cur_in[j], caches[j], subset, autocast, tuple_output)
+                        except Exception as e:      # block not capturable (host sync, data-dependent shapes): eager loop
+                            graphs[keys[j]] = False
+                            layer._vlmc_no_graph = True         # do not try again in the second pass
+                            graph_stats["fallbacks"] += 1
+                            print(f"graph replay disabled for this block ({type(e).__name__}: {e})")
+                            bg = None
                 if bg is not None:
                     cur_out[j] = bg.run(cur_in[j], caches[j])
-                    j += 1
-                    continue
-                before_sample_done = True
-            else:
-                before_sample_done = False
-            g = 1
-            if group_max > 1:
-                key = _stack_key(cur_in[j], caches[j])
-                while j + g < n_samples and g < group_max and _stack_key(cur_in[j + g], caches[j + g]) == key:
-                    g += 1
-            if before_sample is not None and not before_sample_done:
-                before_sample(j)
-            with torch.no_grad():
-                with autocast():
-                    if g == 1:
+                else:
+                    with torch.no_grad(), autocast():
                         y = layer(cur_in[j], **caches[j])
-                        cur_out[j] = y[0] if tuple_output else y
-                    else:
-                        b0 = cur_in[j].shape[0]
-                        _STACKED = (g, b0)
-                        try:
-                            y = layer(torch.cat(cur_in[j:j + g], dim=0), **_stack_caches(caches[j:j + g]))
-                        finally:
-                            _STACKED = None
-                        y = y[0] if tuple_output else y
-                        for t in range(g):
-                            cur_out[j + t] = y[t * b0:(t + 1) * b0]
-            j += g
+                    cur_out[j] = y[0] if tuple_output else y
+                j += 1
+            return
+        chunks = plan_groups(cur_in, caches, n_samples, group_max) if group_max > 1 else [[j] for j in range(n_samples)]
+        for chunk in chunks:
+            if before_sample is not None:
+                before_sample(chunk[0])
+            with torch.no_grad(), autocast():
+                if len(chunk) == 1:
+                    j = chunk[0]
+                    y = layer(cur_in[j], **caches[j])
+                    cur_out[j] = y[0] if tuple_output else y
+                else:
+                    b0 = cur_in[chunk[0]].shape[0]
+                    _STACKED = (len(chunk), b0, tuple(chunk))
+                    try:
+                        y = layer(torch.cat([cur_in[j] for j in chunk], dim=0), **_stack_caches([caches[j] for j in chunk]))
+                    finally:
+                        _STACKED = None
+                    y = y[0] if tuple_output else y
+                    for t, j in enumerate(chunk):
+                        cur_out[j] = y[t * b0:(t + 1) * b0]
 
     graphs = {}
     for i in range(len(layers)):

@@ -50,8 +50,9 @@ class DsnotStatCollector:
         from vlmc import dsnot
         self._dsnot = dsnot
         self.subset = subset
-        self.calls = {n: [] for n in subset}              # per linear: one single-call record per hook call
+        self.calls = {n: [] for n in subset}              # per linear: (sample index, single-call record) per hook call
         self._cache = {}
+        self._cur = -1
         self.handles = [m.register_forward_hook(self._make_hook(n)) for n, m in subset.items()]
 
     def _make_hook(self, name):
@@ -63,19 +64,20 @@ class DsnotStatCollector:
             hit = self._cache.get(key)
             if hit is None:
                 stacked = cal.stacked_samples()              # batched replay: one record per stacked calibration sample
-                calls, b0 = stacked if stacked and stacked[0] * stacked[1] == x.shape[0] else (1, x.shape[0])
+                calls, b0, idx = stacked if stacked and stacked[0] * stacked[1] == x.shape[0] else (1, x.shape[0], (self._cur,))
                 recs = []
                 for c in range(calls):
                     st = self._dsnot.DsnotInputStat(x.shape[-1], x.device)
                     st.add_call(x[c * b0:(c + 1) * b0])      # one launch: sum of squares, sum, variance over tokens
-                    recs.append(st)
+                    recs.append((idx[c], st))
                 hit = (x, recs)                              # `x` stays referenced until the next sample (see wanda collector)
                 self._cache[key] = hit
             self.calls[name].extend(hit[1])
         return hook
 
-    def next_sample(self, _j=None):
+    def next_sample(self, j=None):
         self._cache.clear()
+        self._cur = self._cur + 1 if j is None else j
 
     def close(self):
         for h in self.handles:
@@ -87,6 +89,7 @@ class DsnotStatCollector:
         """{name: DsnotInputStat}; linears whose hooks saw identical tensors share the object."""
         shared, out, order = {}, {}, []
         for name, calls in self.calls.items():
+            calls = [c for _, c in sorted(calls, key=lambda r: r[0])]      # the reference's sample order (grouped replay)
             sig = tuple(id(c) for c in calls)
             st = shared.get(sig)
             if st is None:

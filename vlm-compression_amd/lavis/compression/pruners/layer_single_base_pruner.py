@@ -253,10 +253,13 @@ class LayerSparsity:
         """Final formula shared by the zeroth-order variants (:566-571, :645-650, :722-727)."""
         if self.score_compute == prefix + "-gradient":
             return {k: grads[k].abs() for k in names}
+        # the per-layer variants keep ONE host scalar per layer (shape [1], :642,:719); the reference brings the weights
+        # to the host to combine (`v.cpu().data.float()`), here the scalar goes to the weights' device instead
+        g = {k: (grads[k].to(v.device) if torch.is_tensor(grads[k]) else grads[k]) for k, v in zip(names, params)}
         if self.score_compute == prefix + "-aobd":
-            return {k: v.data.float().abs() * grads[k].abs() for k, v in zip(names, params)}
+            return {k: v.data.float().abs() * g[k].abs() for k, v in zip(names, params)}
         if self.score_compute == prefix + "-obd":
-            return {k: v.data.float() ** 2 * grads[k] ** 2 for k, v in zip(names, params)}
+            return {k: v.data.float() ** 2 * g[k] ** 2 for k, v in zip(names, params)}
         raise UnboundLocalError(f"score method {self.score_compute!r} defines no importance measure")   # as the reference fails
 
     @print_time

@@ -264,4 +264,6 @@ class BLIPT5LayerSparseGPTPruner(LayerWiseBasePruner, _SparseGPTBlockMixin):
                                                            module_to_process=f"{self.t5_model_prefix}.model.decoder.layers",
                                                            n_samples=self.num_samples, sparsity_ratio=sd)
         self.model_reset(self.model, dtype_record, requires_grad_record, device)
+        from vlmc import sparsegpt as _sg
+        _sg.release_caches()          # factorization graphs + n x n work buffers are not kept past the prune
         return self.model, global_sparsity_dict

@@ -31,6 +31,7 @@ from lavis.common.registry import registry
 from lavis.compression.pruners import calibration as cal
 from lavis.compression.pruners.layer_single_base_pruner import LayerSparsity, LayerWiseBasePruner
 from lavis.compression.pruners.utils import print_time
+from vlmc import phases
 
 _VERBOSE = os.environ.get("VLMC_VERBOSE", "0") != "0"
 
@@ -48,8 +49,8 @@ class WandaStatCollector:
         from vlmc import ops
         self._ops = ops
         self.subset = subset
-        self.rows = {n: [] for n in subset}          # per linear: holders [row tensor | None], one per hook call
-        self.batches = {n: [] for n in subset}
+        self.rows = {n: [] for n in subset}          # per linear: (sample index, holder [row tensor | None], batch), one per
+        self._cur = -1                               # hook call; index of the sample an unstacked forward belongs to
         self._cache = {}                              # input signature -> (x kept alive, holder)
         self._pending = []                            # (x [1, tokens, in], holder) not yet reduced
         self.handles = [m.register_forward_hook(self._make_hook(n)) for n, m in subset.items()]
@@ -61,19 +62,24 @@ class WandaStatCollector:
                 x = x.unsqueeze(0)
             key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, x._version)
             hit = self._cache.get(key)
-            stacked = cal.stacked_samples()                    # (samples, batch per sample) of a batched replay call
-            calls, b0 = stacked if stacked and stacked[0] * stacked[1] == x.shape[0] else (1, x.shape[0])
+            stacked = cal.stacked_samples()          # (samples, batch per sample, sample indices) of a batched replay call
+            calls, b0, idx = stacked if stacked and stacked[0] * stacked[1] == x.shape[0] else (1, x.shape[0], (self._cur,))
             if hit is None:
                 # `x` stays referenced until it has been reduced, so its memory cannot be recycled for a
                 # different activation with the same address/shape in the meantime
                 hit = (x, [[None] for _ in range(calls)])
                 self._cache[key] = hit
                 self._pending.append((x.reshape(calls, -1, x.shape[-1]), hit[1]))
-            self.rows[name].extend(hit[1])                     # one record per calibration sample, as in the reference
-            self.batches[name].extend([b0] * calls)
+            # one record per calibration sample, as in the reference; grouped replay visits samples out of order
+            self.rows[name].extend((j, h, b0) for j, h in zip(idx, hit[1]))
         return hook
 
     def _flush(self):
+        if self._pending:
+            with phases.phase("stat"):
+                self._flush_pending()
+
+    def _flush_pending(self):
         by_dtype = {}
         for x, holder in self._pending:
             by_dtype.setdefault(x.dtype, []).append((x, holder))
@@ -88,9 +94,10 @@ class WandaStatCollector:
                         holder[0] = rows[c:c + 1]
         self._pending = []
 
-    def next_sample(self, _j=None):
+    def next_sample(self, j=None):
         self._flush()
         self._cache.clear()
+        self._cur = self._cur + 1 if j is None else j
 
     def close(self):
         for h in self.handles:
@@ -103,14 +110,15 @@ class WandaStatCollector:
         """{name: InputStat}; linears whose hooks saw identical tensors share the object."""
         from vlmc import wanda
         shared, out, order = {}, {}, []
-        for name, holders in self.rows.items():
-            sig = tuple(id(h) for h in holders)
+        for name, recs in self.rows.items():
+            recs = sorted(recs, key=lambda r: r[0])            # the reference's sample order (stable: calls within a sample)
+            sig = tuple(id(h) for _, h, _ in recs)
             st = shared.get(sig)
             if st is None:
                 in_f = self.subset[name].weight.shape[1]
                 st = wanda.InputStat(in_f, self.subset[name].weight.device)
-                st.rows = [h[0] for h in holders]
-                st.batches = list(self.batches[name])
+                st.rows = [h[0] for _, h, _ in recs]
+                st.batches = [b for _, _, b in recs]
                 shared[sig] = st
                 order.append(st)
             out[name] = st
@@ -137,7 +145,16 @@ class _WandaBlockMixin:
             run_pass(col.next_sample)
         finally:
             col.close()
-        stats = col.finalize()
+        with phases.phase("stat"):
+            stats = col.finalize()
+        with phases.phase("select"):
+            self._wanda_select_block(i, subset, stats, n_inps, batch0, unstructured_mode=unstructured_mode,
+                                     module_to_process=module_to_process, model_prefix=model_prefix,
+                                     sparsity_ratio=sparsity_ratio, lora_model=lora_model)
+
+    def _wanda_select_block(self, i, subset, stats, n_inps, batch0, *, unstructured_mode, module_to_process, model_prefix,
+                            sparsity_ratio, lora_model):
+        from vlmc import ops, wanda
 
         names = list(subset)
         mode = unstructured_mode if self.prune_n == 0 else "nm"
@@ -357,6 +374,7 @@ class BLIPT5LayerWandaPruner(LayerWiseBasePruner):
     # the tower implementations are borrowed as unbound methods, like the reference does with
     # functools.partial (:983-988, :1011-1015)
     _wanda_block = _WandaBlockMixin._wanda_block
+    _wanda_select_block = _WandaBlockMixin._wanda_select_block
 
     def get_sparsity(self, original_sparsity, sparsity_ratio_granularity=None):
         return uniform_or_layer_sparsity(self, original_sparsity, sparsity_ratio_granularity)

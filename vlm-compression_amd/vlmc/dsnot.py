@@ -79,7 +79,8 @@ class DsnotInputStat:
 def gather_stats(stats):
     """Multi-GPU: all-gather the per-call moments (rank-major = sample order), then finalise."""
     import torch.distributed as dist
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    from .shard import calibration_shard
+    world = calibration_shard()[1]          # 1 for replicas (VLMC_SHARD_CALIB=0): they already hold every sample
     if world == 1:
         for st in stats:
             st.finalize()

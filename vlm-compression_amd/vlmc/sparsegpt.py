@@ -178,6 +178,14 @@ def blocked_cholesky(H: torch.Tensor, upper=False):
     return (L.t().contiguous() if upper else L), info
 
 
+def release_caches():
+    """Drop the captured factorization graphs and their n x n work buffers (4 + 2 fp32 matrices per distinct n: ~2 GB
+    after a Vicuna-7B prune).  The SparseGPT pruners call it when `prune()` ends, so a RESSA training or evaluation stage in
+    the same process starts without them; the next prune captures again."""
+    _chol_graphs.clear()
+    _inv_graphs.clear()
+
+
 _SELECT_THRESHOLD = __import__("os").environ.get("VLMC_SGPT_SORT_THRESHOLD", "0") != "1"
 factor_stats = {"direct": 0, "chain": 0}     # how often each route produced the inverse factor
 _DIRECT_FACTOR = __import__("os").environ.get("VLMC_SGPT_DIRECT_FACTOR", "1") == "1"

@@ -99,9 +99,9 @@ def gather_stats(stats, group=None):
     norms of every distinct input in ONE collective, then finalise each statistic over
     the full, ordered sample set.  With no process group this is just the finalisation."""
     import torch.distributed as dist
-    world = 1
-    if group is not None or (dist.is_available() and dist.is_initialized()):
-        world = dist.get_world_size(group)
+    from .shard import calibration_shard
+    # replicas (VLMC_SHARD_CALIB=0) have every sample already: no exchange, or the rows would be counted world times
+    world = dist.get_world_size(group) if group is not None else calibration_shard()[1]
     if world == 1:
         return finalize_stats(stats, [st.local_normsq() for st in stats], [st.batches for st in stats])
     local = [st.local_normsq() for st in stats]
