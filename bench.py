@@ -128,6 +128,10 @@ class HipEvents:
             raise RuntimeError(f"hipEventElapsedTime failed ({rc})")
         return float(ms.value)
 
+    def free(self, *evs):
+        for e in evs:
+            self.hip.hipEventDestroy(e)
+
 
 class LaunchProbe:
     """Times launches of product kernels INSIDE the timed prunes: wraps entry points of `vlmc.ops` so that every

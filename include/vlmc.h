@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLMC_ABI_VERSION 2
+#define VLMC_ABI_VERSION 3
 
 #define VLMC_OK 0
 #define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
@@ -52,7 +52,8 @@ int vlmc_abi_version(void);
 const char *vlmc_last_error(void);
 
 /* Timing hook for benchmarks (no reference counterpart): the next statistics or select kernel launched from the
- * calling thread -- vlmc_act_sqnorm[_batch], vlmc_wanda_select[_batch] (first launch of the call) -- records its own
+ * calling thread -- vlmc_act_sqnorm[_batch], vlmc_wanda_select[_batch] (first launch of the call), vlmc_linear_fwd,
+ * vlmc_hessian_accum (its matrix-core kernel) -- records its own
  * begin / end timestamps into the caller's HIP events (hipEvent_t, created by the caller with timing enabled) through
  * hipExtLaunchKernel: hipEventElapsedTime(start, stop) is then the kernel's duration, and no marker packet sits
  * between kernels (hipEventRecord between two kernels idles an MI355X for ~5 us).  Either event may be NULL; the pair
@@ -176,6 +177,33 @@ size_t vlmc_lora_grad_workspace(int64_t out_features, int64_t in_features, int r
 int vlmc_lora_grad(const void *G, int dtype, int64_t out_features, int64_t in_features, int64_t ldg, const float *A,
                    const float *B, int r, float scaling, const uint8_t *mask, int sparse, int autocast, float *dA,
                    float *dB, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- dense calibration forward of one linear (MFMA) ---------------------------------------------
+ * Replaces `F.linear(x, weight, bias)` inside the block forwards of the calibration replay,
+ * `layer(inps[j], **caches[j])` at wanda_pruner.py:308-311 / :343-346 (sparsegpt_pruner.py:428-431, :452-454;
+ * dsnot_pruner.py:349-356, :763-766), for 16-bit weights and activations of the same dtype:
+ *     Y[m, n] = wd(sum_k X[m, k] * W[n, k] + bias[n])        fp32 accumulation, ONE rounding to the dtype
+ * X [M, K] (row stride ldx), W [N, K] (`nn.Linear.weight`, row stride ldw), bias [N] in the same dtype or NULL,
+ * Y [M, N] (row stride ldy).  K, ldx, ldw multiples of 8 elements; X, W 16-byte aligned.
+ * Batch-invariant: every output element is ONE accumulator fed the K-steps in ascending order by one
+ * matrix-core instruction shape (v_mfma_f32_16x16x32), whatever M is -- replaying 1 or 128 calibration
+ * samples per call, or any share of them on another GPU, yields identical rows.                     */
+int vlmc_linear_fwd(const void *X, const void *W, const void *bias, int dtype, int64_t M, int64_t N, int64_t K, int64_t ldx,
+                    int64_t ldw, void *Y, int64_t ldy, void *stream);
+
+/* ---- K8: SparseGPT Hessian accumulation (MFMA SYRK) -------------------------------------------------
+ * Replaces the arithmetic of SparseGPT.add_batch, sparsegpt_pruner.py:76-79
+ *     H *= n / (n + b);  n += b;  inp = sqrt(2 / n) * inp.float();  H += inp @ inp.t()
+ * as  H = alpha * H + beta * X^T X  with alpha = n/(n+b), beta = 2/(n+b) chosen by the caller, X [rows, in_features]
+ * (row stride ldx) = the tokens of one or more hook calls.  Only the tiles on and below the diagonal of H are
+ * computed and updated (H is symmetric): call vlmc_symmetrize_lower once before H is read as a full matrix.
+ * fp16 / bf16 X: the products are exact in fp32 (11- / 8-bit significands), fp32 accumulation on the matrix cores;
+ * fp32 X is split into three bf16 planes (x = hi + mid + lo exactly) and all nine plane products are accumulated.
+ * alpha == 0 does not read H.  Workspace: vlmc_hessian_workspace() bytes (the transposed operand), 16-byte aligned. */
+size_t vlmc_hessian_workspace(int dtype, int64_t rows, int64_t in_features);
+int vlmc_hessian_accum(const void *X, int dtype, int64_t rows, int64_t in_features, int64_t ldx, float *H, int64_t ldh,
+                       float alpha, float beta, void *workspace, size_t workspace_bytes, void *stream);
+int vlmc_symmetrize_lower(float *H, int64_t n, int64_t ldh, void *stream);
 
 /* ---- K9: diagonal block of the blocked Cholesky factorization ------------------------------
  * Replaces the unblocked panel step inside `torch.linalg.cholesky(H)` (sparsegpt_pruner.py:116,148):

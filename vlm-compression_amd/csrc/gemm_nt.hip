@@ -1,0 +1,401 @@
+// MFMA GEMM engine for the calibration forward and the SparseGPT Hessian (gfx950).
+//
+//   C[p][q] = sum_k P[p][k] * Q[q][k]        P: [NP, K], Q: [NQ, K], both K-contiguous ("NT"), 16-bit (fp16 / bf16)
+//
+// on v_mfma_f32_16x16x32_{f16,bf16}, fp32 accumulate.  Two products are built on it:
+//
+//  * vlmc_linear_fwd   Y[m][n] = wd(sum_k X[m][k] W[n][k] + bias[n])      P = W (nn.Linear.weight), Q = X
+//    -- the dense calibration forward of a transformer block's linears (the reference runs `layer(inps[j], **caches[j])`
+//    per calibration sample, wanda_pruner.py:308-311,343-346).  BATCH-INVARIANT BY CONSTRUCTION: an output element is
+//    one accumulator that takes the K-steps of 32 in ascending order through one MFMA shape -- no split-K, no choice
+//    of algorithm by problem size -- so a row of Y depends on its row of X and on W only, whatever other rows share the
+//    launch.  Replaying 1, 32 or 128 calibration samples per forward, or sharding them over GPUs, gives the same bits.
+//  * vlmc_hessian_accum   H = alpha * H + beta * X^T X  (lower-triangle tiles)   P = Q = X^T
+//    -- SparseGPT.add_batch (sparsegpt_pruner.py:68-79).  Products of two bf16 (8-bit significands) or two fp16
+//    (11-bit) values are exact in fp32, so a 16-bit MFMA with fp32 accumulation loses nothing against the reference's
+//    `inp.float()` GEMM but its summation order.  fp32 activations are split into three bf16 planes
+//    (x = hi + mid + lo exactly) by the transposing pre-pass and all nine plane products are accumulated.
+//
+// Tile: 128 (p) x 128 (q) x 64 (k) per 256-thread workgroup; wave w owns a 64 x 64 quadrant = 4 x 4 MFMA tiles.
+// Operands travel global -> registers -> LDS (double buffered; the loads of K-tile t+1 are in flight while tile t is
+// multiplied), rows of 64 elements = 128 B in LDS with the 16-B chunk index XOR-ed with (row & 7): the fragment reads
+// (ds_read_b128, 16 rows x 4 chunks per wave-instruction) are bank-conflict free.  Lanes hold 4 consecutive p for one
+// q in an accumulator tile, so both epilogues store along p: 8 B of Y[m][n..n+3], 16 B of H[q][p..p+3].
+#include "common.hpp"
+
+namespace vlmc {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <typename T> __device__ __forceinline__ f32x4_t mfma16(const u32x4_t &a, const u32x4_t &b, const f32x4_t &c);
+template <> __device__ __forceinline__ f32x4_t mfma16<bf16_t>(const u32x4_t &a, const u32x4_t &b, const f32x4_t &c) {
+    bf16x8_t x, y;
+    __builtin_memcpy(&x, &a, 16);
+    __builtin_memcpy(&y, &b, 16);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_t mfma16<f16_t>(const u32x4_t &a, const u32x4_t &b, const f32x4_t &c) {
+    f16x8_t x, y;
+    __builtin_memcpy(&x, &a, 16);
+    __builtin_memcpy(&y, &b, 16);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0);
+}
+
+template <typename T> __device__ __forceinline__ uint16_t from_f32(float v);
+template <> __device__ __forceinline__ uint16_t from_f32<bf16_t>(float v) {
+    const __bf16 h = static_cast<__bf16>(v);          // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+    uint16_t r;
+    __builtin_memcpy(&r, &h, 2);
+    return r;
+}
+template <> __device__ __forceinline__ uint16_t from_f32<f16_t>(float v) {
+    const _Float16 h = static_cast<_Float16>(v);
+    uint16_t r;
+    __builtin_memcpy(&r, &h, 2);
+    return r;
+}
+
+constexpr int BP = 128, BQ = 128, BK = 64;            // elements
+constexpr int ROW_BYTES = BK * 2;                     // 128 B per tile row in LDS
+constexpr int TILE_BYTES = BP * ROW_BYTES;            // 16 KiB per operand tile
+constexpr int NTHREADS = 256;
+constexpr int CHUNKS = BP * (BK / 8) / NTHREADS;      // 16-B chunks per thread and operand tile: 4
+static_assert(BP == BQ, "one staging routine serves both operands");
+
+enum { EPI_LINEAR = 0, EPI_SYRK = 1 };
+
+struct GemmArgs {
+    const uint16_t *P, *Q;        // [NP, K], [NQ, K]
+    int64_t ldp, ldq;             // row strides, elements (multiples of 8)
+    int NP, NQ, K;
+    int np_blocks, nq_blocks;
+    // EPI_LINEAR
+    uint16_t *Y;                  // [NQ, NP]
+    int64_t ldy;
+    const void *bias;             // [NP] in the operand dtype, or NULL
+    // EPI_SYRK
+    float *H;                     // [N, N], lower-triangle tiles are updated
+    int64_t ldh;
+    float alpha, beta;
+};
+
+// byte offset of 16-B chunk `ch` (0..7) of tile row `row` in an LDS operand tile
+__device__ __forceinline__ int lds_off(int row, int ch) { return row * ROW_BYTES + ((ch ^ (row & 7)) << 4); }
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TILE_BYTES];      // [buf][P | Q]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- which tile ---------------------------------------------------------------------------------------------
+    int bp, bq;
+    {
+        // contiguous runs of block ids per XCD (blocks b and b + 8 share an XCD's L2), then groups of 8 p-blocks with
+        // q running inside a group: the ~64 tiles an XCD works on at a time share few operand panels
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
+        int id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+        if constexpr (EPI == EPI_SYRK) {
+            // lower triangle, row-block bq >= column-block bp: id -> (bq, bp) by rows of the triangle
+            int r = int((__builtin_sqrtf(8.0f * float(id) + 1.0f) - 1.0f) * 0.5f);
+            while ((r + 1) * (r + 2) / 2 <= id) ++r;
+            while (r * (r + 1) / 2 > id) --r;
+            bq = r;
+            bp = id - r * (r + 1) / 2;
+        } else {
+            const int G = 8;
+            const int per_group = G * a.nq_blocks;
+            const int g = id / per_group, in_g = id - g * per_group;
+            const int gp = min(G, a.np_blocks - g * G);
+            bq = in_g / gp;
+            bp = g * G + (in_g - bq * gp);
+        }
+    }
+    const int p0 = bp * BP, q0 = bq * BQ;
+
+    // ---- staging: thread t moves chunks t, t + 256, ... of each operand tile (8 consecutive threads = one 128-B row)
+    u32x4_t stage_p[CHUNKS], stage_q[CHUNKS];
+    int st_row[CHUNKS], st_ch[CHUNKS];
+#pragma unroll
+    for (int i = 0; i < CHUNKS; ++i) {
+        const int c = tid + i * NTHREADS;
+        st_row[i] = c >> 3;
+        st_ch[i] = c & 7;
+    }
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) {
+            const int k = k0 + st_ch[i] * 8;
+            const int rp = p0 + st_row[i], rq = q0 + st_row[i];
+            const u32x4_t zero = {0u, 0u, 0u, 0u};
+            stage_p[i] = (rp < a.NP && k < a.K) ? *reinterpret_cast<const u32x4_t *>(a.P + int64_t(rp) * a.ldp + k) : zero;
+            stage_q[i] = (rq < a.NQ && k < a.K) ? *reinterpret_cast<const u32x4_t *>(a.Q + int64_t(rq) * a.ldq + k) : zero;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        unsigned char *base = lds + buf * 2 * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) {
+            const int off = lds_off(st_row[i], st_ch[i]);
+            *reinterpret_cast<u32x4_t *>(base + off) = stage_p[i];
+            *reinterpret_cast<u32x4_t *>(base + TILE_BYTES + off) = stage_q[i];
+        }
+    };
+
+    // ---- accumulators: wave (wp, wq) owns rows wp*64.. of P and wq*64.. of Q ------------------------------------
+    const int wp = wave >> 1, wq = wave & 1;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fch = lane >> 4;          // fragment: row (lane & 15), k = 8 * (lane >> 4) + j
+
+    const int nk = (a.K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tiles((kt + 1) * BK);       // in flight during the MFMAs below
+        const unsigned char *tp = lds + cur * 2 * TILE_BYTES + wp * 64 * ROW_BYTES;
+        const unsigned char *tq = lds + cur * 2 * TILE_BYTES + TILE_BYTES + wq * 64 * ROW_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4_t fp[4], fq[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 16 + frow;            // (wave offsets are multiples of 8: row & 7 is unchanged)
+                fp[i] = *reinterpret_cast<const u32x4_t *>(tp + lds_off(row, fch + 4 * kk));
+                fq[i] = *reinterpret_cast<const u32x4_t *>(tq + lds_off(row, fch + 4 * kk));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(fp[i], fq[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds p = pbase + 16 i + 4 (lane >> 4) + r (r = 0..3), q = qbase + 16 j + (lane & 15) -----
+    const int pl = p0 + wp * 64 + (lane >> 4) * 4, ql = q0 + wq * 64 + (lane & 15);
+    if constexpr (EPI == EPI_LINEAR) {
+        const uint16_t *bias = static_cast<const uint16_t *>(a.bias);
+        const bool vec_ok = (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 7u) == 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = pl + i * 16;
+            float b[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (p + r < a.NP) b[r] = to_f32<T>(bias[p + r]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = ql + j * 16;
+                if (q >= a.NQ || p >= a.NP) continue;
+                uint16_t o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(bias != nullptr ? acc[i][j][r] + b[r] : acc[i][j][r]);
+                uint16_t *dst = a.Y + int64_t(q) * a.ldy + p;
+                if (vec_ok && p + 3 < a.NP) {
+                    u32x2_t v = {uint32_t(o[0]) | uint32_t(o[1]) << 16, uint32_t(o[2]) | uint32_t(o[3]) << 16};
+                    *reinterpret_cast<u32x2_t *>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (p + r < a.NP) dst[r] = o[r];
+                }
+            }
+        }
+    } else {
+        const bool vec_ok = (a.ldh & 3) == 0 && (reinterpret_cast<uintptr_t>(a.H) & 15u) == 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = pl + i * 16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = ql + j * 16;
+                if (q >= a.NQ || p >= a.NP) continue;
+                float *dst = a.H + int64_t(q) * a.ldh + p;              // element (row q, column p): the lower triangle
+                if (vec_ok && p + 3 < a.NP) {
+                    f32x4_t h = {0.f, 0.f, 0.f, 0.f};
+                    if (a.alpha != 0.f) h = *reinterpret_cast<const f32x4_t *>(dst);
+                    f32x4_t o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = a.alpha != 0.f ? a.alpha * h[r] + a.beta * acc[i][j][r] : a.beta * acc[i][j][r];
+                    *reinterpret_cast<f32x4_t *>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (p + r < a.NP) dst[r] = a.alpha != 0.f ? a.alpha * dst[r] + a.beta * acc[i][j][r] : a.beta * acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
+// ---- transposing pre-pass of the Hessian: X [T, C] (any of the three dtypes) -> X^T planes [C, ldt] 16-bit -------------
+// fp32 input: three bf16 planes hi | mid | lo laid out along k so that the NT product of
+//   P' = [hi hi hi mid mid mid lo lo lo]  and  Q' = [hi mid lo hi mid lo hi mid lo]
+// is the sum of all nine plane products; rows are padded with zeros up to ldt (a multiple of 64).
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_planes_kernel(const typename T::raw *x, int64_t ldx, int T_rows, int C,
+                                                               uint16_t *pt, uint16_t *qt, int64_t ldt, int Tpad) {
+    __shared__ float tile[64][65];
+    const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int t = t0 + r, c = c0 + tx;
+        tile[r][tx] = (t < T_rows && c < C) ? to_f32<T>(x[int64_t(t) * ldx + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r, t = t0 + tx;
+        if (c >= C || t >= Tpad) continue;
+        const float v = tile[tx][r];
+        if constexpr (sizeof(typename T::raw) == 2) {
+            uint16_t raw;
+            if constexpr (__is_same(T, bf16_t)) raw = uint16_t(__float_as_uint(v) >> 16); else raw = from_f32<f16_t>(v);
+            pt[int64_t(c) * ldt + t] = raw;
+        } else {
+            const uint16_t hi = from_f32<bf16_t>(v);
+            const float r1 = v - to_f32<bf16_t>(hi);
+            const uint16_t mid = from_f32<bf16_t>(r1);
+            const float r2 = r1 - to_f32<bf16_t>(mid);
+            const uint16_t lo = from_f32<bf16_t>(r2);
+            const uint16_t pl[3] = {hi, mid, lo};
+            uint16_t *prow = pt + int64_t(c) * ldt, *qrow = qt + int64_t(c) * ldt;
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    prow[int64_t(u * 3 + w) * Tpad + t] = pl[u];
+                    qrow[int64_t(u * 3 + w) * Tpad + t] = pl[w];
+                }
+        }
+    }
+}
+
+// lower triangle -> upper triangle (once per Hessian, before it is factorized)
+__global__ __launch_bounds__(256) void symmetrize_kernel(float *H, int64_t ldh, int n) {
+    __shared__ float tile[64][65];
+    const int bi = blockIdx.y, bj = blockIdx.x;            // tile (row block bi, column block bj), bj < bi is copied
+    if (bj > bi) return;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int i = bi * 64 + r, j = bj * 64 + tx;
+        tile[r][tx] = (i < n && j < n) ? H[int64_t(i) * ldh + j] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int i = bj * 64 + r, j = bi * 64 + tx;       // transposed position
+        if (i < n && j < n && j > i) H[int64_t(i) * ldh + j] = tile[tx][r];
+    }
+}
+
+static int dtype_ok16(int dtype) { return dtype == VLMC_F16 || dtype == VLMC_BF16; }
+
+}  // namespace vlmc
+
+using namespace vlmc;
+
+extern "C" int vlmc_linear_fwd(const void *X, const void *W, const void *bias, int dtype, int64_t M, int64_t N, int64_t K,
+                               int64_t ldx, int64_t ldw, void *Y, int64_t ldy, void *stream) {
+    VLMC_REQUIRE(dtype_ok16(dtype), "vlmc_linear_fwd: dtype must be VLMC_F16 or VLMC_BF16");
+    VLMC_REQUIRE(X && W && Y, "vlmc_linear_fwd: null pointer");
+    VLMC_REQUIRE(M >= 0 && N > 0 && K > 0 && M < (int64_t(1) << 31) && N < (int64_t(1) << 31) && K < (int64_t(1) << 31),
+                 "vlmc_linear_fwd: bad shape");
+    VLMC_REQUIRE(K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldx >= K && ldw >= K && ldy >= N,
+                 "vlmc_linear_fwd: K and the row strides of X and W must be multiples of 8 elements");
+    VLMC_REQUIRE(aligned16(X) && aligned16(W), "vlmc_linear_fwd: X and W must be 16-byte aligned");
+    if (M == 0) return VLMC_OK;
+    GemmArgs a{};
+    a.P = static_cast<const uint16_t *>(W);
+    a.Q = static_cast<const uint16_t *>(X);
+    a.ldp = ldw;
+    a.ldq = ldx;
+    a.NP = int(N);
+    a.NQ = int(M);
+    a.K = int(K);
+    a.np_blocks = int((N + BP - 1) / BP);
+    a.nq_blocks = int((M + BQ - 1) / BQ);
+    a.Y = static_cast<uint16_t *>(Y);
+    a.ldy = ldy;
+    a.bias = bias;
+    const int64_t nblocks = int64_t(a.np_blocks) * a.nq_blocks;
+    VLMC_REQUIRE(nblocks < (int64_t(1) << 31), "vlmc_linear_fwd: too many tiles");
+    const dim3 grid{unsigned(nblocks)}, block{NTHREADS};
+    if (dtype == VLMC_BF16) VLMC_LAUNCH_TIMED((gemm_nt_kernel<bf16_t, EPI_LINEAR>), grid, block, as_stream(stream), a);
+    else VLMC_LAUNCH_TIMED((gemm_nt_kernel<f16_t, EPI_LINEAR>), grid, block, as_stream(stream), a);
+    VLMC_HIP_CHECK_LAUNCH("vlmc_linear_fwd");
+    return VLMC_OK;
+}
+
+extern "C" size_t vlmc_hessian_workspace(int dtype, int64_t rows, int64_t in_features) {
+    if (rows <= 0 || in_features <= 0) return 0;
+    const int64_t tpad = (rows + 63) / 64 * 64;
+    const int64_t planes = dtype == VLMC_F32 ? 9 : 1;
+    const int64_t one = in_features * tpad * planes * 2;
+    return size_t(dtype == VLMC_F32 ? 2 * one : one);
+}
+
+extern "C" int vlmc_hessian_accum(const void *X, int dtype, int64_t rows, int64_t in_features, int64_t ldx, float *H,
+                                  int64_t ldh, float alpha, float beta, void *workspace, size_t workspace_bytes,
+                                  void *stream) {
+    VLMC_REQUIRE(dtype == VLMC_F32 || dtype_ok16(dtype), "vlmc_hessian_accum: bad dtype");
+    VLMC_REQUIRE(X && H, "vlmc_hessian_accum: null pointer");
+    VLMC_REQUIRE(rows > 0 && in_features > 0 && ldx >= in_features && ldh >= in_features, "vlmc_hessian_accum: bad shape");
+    VLMC_REQUIRE(rows < (int64_t(1) << 24) && in_features < (int64_t(1) << 20), "vlmc_hessian_accum: shape too large");
+    const size_t need = vlmc_hessian_workspace(dtype, rows, in_features);
+    if (workspace_bytes < need || !workspace) {
+        set_error("vlmc_hessian_accum: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+        return VLMC_EWORKSPACE;
+    }
+    VLMC_REQUIRE(aligned16(workspace), "vlmc_hessian_accum: workspace must be 16-byte aligned");
+    const int tpad = int((rows + 63) / 64 * 64);
+    const int planes = dtype == VLMC_F32 ? 9 : 1;
+    const int64_t ldt = int64_t(tpad) * planes;
+    uint16_t *pt = static_cast<uint16_t *>(workspace);
+    uint16_t *qt = dtype == VLMC_F32 ? pt + in_features * ldt : pt;
+    const dim3 tgrid{unsigned(tpad / 64), unsigned((in_features + 63) / 64)}, tblock{256};
+    hipStream_t s = as_stream(stream);
+    if (dtype == VLMC_F32)
+        hipLaunchKernelGGL(transpose_planes_kernel<f32_t>, tgrid, tblock, 0, s, static_cast<const float *>(X), ldx, int(rows),
+                           int(in_features), pt, qt, ldt, tpad);
+    else if (dtype == VLMC_BF16)
+        hipLaunchKernelGGL(transpose_planes_kernel<bf16_t>, tgrid, tblock, 0, s, static_cast<const uint16_t *>(X), ldx, int(rows),
+                           int(in_features), pt, qt, ldt, tpad);
+    else
+        hipLaunchKernelGGL(transpose_planes_kernel<f16_t>, tgrid, tblock, 0, s, static_cast<const uint16_t *>(X), ldx, int(rows),
+                           int(in_features), pt, qt, ldt, tpad);
+    VLMC_HIP_CHECK_LAUNCH("vlmc_hessian_accum (transpose)");
+    GemmArgs a{};
+    a.P = pt;
+    a.Q = qt;
+    a.ldp = a.ldq = ldt;
+    a.NP = a.NQ = int(in_features);
+    a.K = int(ldt);
+    a.np_blocks = a.nq_blocks = int((in_features + BP - 1) / BP);
+    a.H = H;
+    a.ldh = ldh;
+    a.alpha = alpha;
+    a.beta = beta;
+    const int64_t nblocks = int64_t(a.np_blocks) * (a.np_blocks + 1) / 2;
+    const dim3 grid{unsigned(nblocks)}, block{NTHREADS};
+    if (dtype == VLMC_F16) VLMC_LAUNCH_TIMED((gemm_nt_kernel<f16_t, EPI_SYRK>), grid, block, s, a);
+    else VLMC_LAUNCH_TIMED((gemm_nt_kernel<bf16_t, EPI_SYRK>), grid, block, s, a);
+    VLMC_HIP_CHECK_LAUNCH("vlmc_hessian_accum");
+    return VLMC_OK;
+}
+
+extern "C" int vlmc_symmetrize_lower(float *H, int64_t n, int64_t ldh, void *stream) {
+    VLMC_REQUIRE(H && n > 0 && ldh >= n && n < (int64_t(1) << 20), "vlmc_symmetrize_lower: bad arguments");
+    const unsigned nb = unsigned((n + 63) / 64);
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(nb, nb), dim3(256), 0, as_stream(stream), H, ldh, int(n));
+    VLMC_HIP_CHECK_LAUNCH("vlmc_symmetrize_lower");
+    return VLMC_OK;
+}
