@@ -22,6 +22,7 @@ every world size.  `VLMC_SHARD_CALIB=0` restores the reference's replica behavio
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import torch
@@ -62,6 +63,18 @@ class _Stop(ValueError):
 
 
 from vlmc.shard import calibration_shard  # noqa: E402,F401  (one answer for capture, replay and the exchanges)
+
+
+def release_tower_memory():
+    """End of a tower's `_prune` (the reference calls `torch.cuda.empty_cache(); gc.collect()` there, wanda_pruner.py:349-351).
+    The calibration activations are ordinary tensors whose memory returns to the caching allocator when they go out of
+    scope; handing it back to the driver and sweeping the Python heap cost ~0.1 s per prune of FlanT5-XL for nothing the next
+    tower needs, so both are opt-in: `VLMC_RELEASE_MEMORY=1`."""
+    if os.environ.get("VLMC_RELEASE_MEMORY", "0") == "1":
+        import gc
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+        gc.collect()
 
 
 def _keys_for(model_prefix):
@@ -230,6 +243,23 @@ def seed_tower_memo(proxy_cache, module_to_process, layers, final_outs, autocast
     return True
 
 
+# Capture phases run the calibration forwards round-robin on a few side streams (capture_streams()); the slot a forward
+# runs in picks the graph instance -- and with it the static buffers -- its proxies replay (None: the caller's stream).
+_CAPTURE_SLOT = None
+
+
+def capture_streams():
+    """`VLMC_CAPTURE_STREAMS=S` (default 4; 1 = the caller's stream only): while the model's own forward runs the
+    calibration batches up to the next tower, batch j goes to side stream j mod S.  A batch-1 forward through an already
+    pruned tower is a chain of short kernels that leaves the GPU mostly idle (the ~30 kernels of a Flan-T5-XL block take
+    160 us where streaming its 96 MB of weights takes 19); independent samples on S streams fill it.  Same kernels, same
+    arguments, same results."""
+    try:
+        return max(1, int(os.environ.get("VLMC_CAPTURE_STREAMS", "4")))
+    except ValueError:
+        return 1
+
+
 class GraphedModule(nn.Module):
     """Stands in for a block of an ALREADY PRUNED tower while the model's own forward runs the calibration batches up
     to the next tower (`capture_block_inputs`): the first call with a given argument signature runs eagerly, the second
@@ -271,9 +301,9 @@ class GraphedModule(nn.Module):
             return mod(*args, **kwargs)
         names = sorted(kwargs)
         # besides its arguments, the autocast state and the train / eval flags decide which kernels a block runs
-        key = (TowerMemo.context(), tuple(m.training for m in mod.modules())) + \
+        key = (TowerMemo.context(), mod.training, _CAPTURE_SLOT) + \
             tuple(self._sig(a) for a in args) + tuple((k, self._sig(kwargs[k])) for k in names)
-        if any(x is NotImplemented or (isinstance(x, tuple) and len(x) == 2 and x[1] is NotImplemented) for x in key[2:]) or \
+        if any(x is NotImplemented or (isinstance(x, tuple) and len(x) == 2 and x[1] is NotImplemented) for x in key[3:]) or \
                 not any(isinstance(a, torch.Tensor) for a in list(args) + list(kwargs.values())):
             return mod(*args, **kwargs)
         ent = self._graphs.get(key)
@@ -401,8 +431,23 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
             if lora_model:
                 cache["dense"] = dense
             caches.append(cache)
+            if main_stream is not None:               # produced on a side stream, consumed on the caller's: tell the allocator
+                for t in [inp] + list(cache.values()):
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(main_stream)
             raise _Stop
 
+    # side streams for the forwards (kept by the pruner from phase to phase): only worth it when finished towers are run
+    # through, and only on a GPU model
+    global _CAPTURE_SLOT
+    sides, main_stream = [], None
+    p0 = next(model.parameters(), None)
+    if capture_streams() > 1 and done_towers and p0 is not None and p0.is_cuda and graph_replay_enabled():
+        main_stream = torch.cuda.current_stream(p0.device)
+        holder = proxy_cache if proxy_cache is not None else {}
+        sides = holder.get(("streams", p0.device.index))
+        if sides is None or len(sides) != capture_streams():
+            sides = holder[("streams", p0.device.index)] = [torch.cuda.Stream(device=p0.device) for _ in range(capture_streams())]
     layers[0] = Catcher(layers[0])
     # blocks of towers that were pruned before this one (`done_towers`: their module paths) replay from HIP graphs
     undo = _wrap_towers(model, [t for t in (done_towers or []) if t != module_to_process], proxy_cache)
@@ -423,12 +468,23 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
             raise RuntimeError(f"calibration sharding needs the {len(batches)} calibration batches to divide evenly "
                                f"over {world} ranks (set VLMC_SHARD_CALIB=0 to run as replicas)")
         per = len(batches) // world
-        for batch in batches[rank * per:(rank + 1) * per] if world > 1 else batches:
+        mine = batches[rank * per:(rank + 1) * per] if world > 1 else batches
+        if sides:
+            for st in sides:
+                st.wait_stream(main_stream)
+        for j, batch in enumerate(mine):
+            if sides:
+                _CAPTURE_SLOT = j % len(sides)
             try:
-                forward_to_cache(model, batch, lora_model)
+                with (torch.cuda.stream(sides[_CAPTURE_SLOT]) if sides else contextlib.nullcontext()):
+                    forward_to_cache(model, batch, lora_model)
             except ValueError:                         # _Stop, or the reference's bare ValueError
                 pass
     finally:
+        _CAPTURE_SLOT = None
+        if sides:
+            for st in sides:
+                main_stream.wait_stream(st)
         layers[0] = layers[0].module
         for blocks, i, orig in undo:
             blocks[i].__dict__["_memo"] = None
@@ -636,7 +692,12 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                     cur_out[j] = y[0] if tuple_output else y
                 j += 1
             return
-        chunks = plan_groups(cur_in, caches, n_samples, group_max) if group_max > 1 else [[j] for j in range(n_samples)]
+        # blocks of a tower map [.., T, d] to [.., T, d]: the plan of the first pass holds while the shapes do
+        shapes = [tuple(cur_in[j].shape) for j in range(n_samples)]
+        if plan.get("shapes") != shapes:
+            plan["shapes"] = shapes
+            plan["chunks"] = plan_groups(cur_in, caches, n_samples, group_max) if group_max > 1 else [[j] for j in range(n_samples)]
+        chunks = plan["chunks"]
         for chunk in chunks:
             if before_sample is not None:
                 before_sample(chunk[0])
@@ -656,7 +717,7 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                     for t, j in enumerate(chunk):
                         cur_out[j] = y[t * b0:(t + 1) * b0]
 
-    graphs = {}
+    graphs, plan = {}, {}
     for i in range(len(layers)):
         layer = layers[i]
         subset = find_layers(layer)

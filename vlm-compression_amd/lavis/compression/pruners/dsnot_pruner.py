@@ -29,7 +29,6 @@ There is no CPU fallback: without the HIP library or a GPU model the pruner rais
 """
 from __future__ import annotations
 
-import gc
 import os
 
 import torch
@@ -219,8 +218,7 @@ class T5LayerDSnoTPruner(LayerWiseBasePruner, _DsnotBlockMixin):
         cal.walk_blocks(model, inps, outs, caches, module_to_process, n_samples,
                         lambda: model.maybe_autocast(dtype=torch.bfloat16), prune_block, tuple_output=True)
         cfg.use_cache = use_cache
-        torch.cuda.empty_cache()
-        gc.collect()
+        cal.release_tower_memory()
         return model
 
     @print_time
@@ -282,8 +280,7 @@ class VITLayerDSnoTPruner(LayerWiseBasePruner, _DsnotBlockMixin):
         cal.walk_blocks(model, inps, outs, caches, module_to_process, n_samples,
                         lambda: model.maybe_autocast(dtype=torch.bfloat16), prune_block, tuple_output=False,
                         memo_cache=self.__dict__.get("_proxy_cache"))
-        torch.cuda.empty_cache()
-        gc.collect()
+        cal.release_tower_memory()
         return model
 
     @print_time

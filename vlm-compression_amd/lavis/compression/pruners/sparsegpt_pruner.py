@@ -176,7 +176,7 @@ class T5LayerSparseGPTPruner(LayerWiseBasePruner, _SparseGPTBlockMixin):
         cal.walk_blocks(model, inps, outs, caches, module_to_process, n_samples,
                         lambda: model.maybe_autocast(dtype=torch.bfloat16), prune_block, tuple_output=True)
         cfg.use_cache = use_cache
-        torch.cuda.empty_cache()
+        cal.release_tower_memory()
         return model
 
 
@@ -203,7 +203,7 @@ class VITLayerSparseGPTPruner(LayerWiseBasePruner, _SparseGPTBlockMixin):
 
         cal.walk_blocks(model, inps, outs, caches, module_to_process, n_samples, lambda: model.maybe_autocast(),
                         prune_block, tuple_output=False, memo_cache=self.__dict__.get("_proxy_cache"))
-        torch.cuda.empty_cache()
+        cal.release_tower_memory()
         return model
 
 

@@ -58,6 +58,10 @@ SIGNATURES = {
     "vlmc_dsnot_stats_update": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p]),
     "vlmc_dsnot_refine": (_i, [_p, _i, _i64, _i64, _i64, _p, _p, _p, _p, _i, _i, _i, _i, _c.c_float, _c.c_float, _i, _p, _p, _p]),
     "vlmc_dsnot_apply": (_i, [_p, _i, _i64, _i64, _i64, _p, _p, _p, _i, _i, _i, _p]),
+    "vlmc_linear_fwd": (_i, [_p, _p, _p, _i, _i64, _i64, _i64, _i64, _i64, _p, _i64, _p]),
+    "vlmc_hessian_workspace": (_sz, [_i, _i64, _i64]),
+    "vlmc_hessian_accum": (_i, [_p, _i, _i64, _i64, _i64, _p, _i64, _c.c_float, _c.c_float, _p, _sz, _p]),
+    "vlmc_symmetrize_lower": (_i, [_p, _i64, _i64, _p]),
     "vlmc_chol_block": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, _p, _i, _p]),
     "vlmc_sparsegpt_sweep": (_i, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i, _i, _p, _i64, _p, _i64, _p]),
     "vlmc_score_select_workspace": (_sz, [_i, _i]),

@@ -56,6 +56,59 @@ _select_ws = Workspace(zeroed=True)
 _MODES = {"row": _lib.SEL_ROW, "matrix": _lib.SEL_MATRIX, "nm": _lib.SEL_NM}
 
 
+_hessian_ws = Workspace()
+
+
+def linear_fwd_supported(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> bool:
+    """Whether `linear_fwd` takes this call: 16-bit activations and weights of one dtype on the GPU, K a multiple of 8."""
+    return (x.is_cuda and weight.is_cuda and x.dtype == weight.dtype and x.dtype in (torch.float16, torch.bfloat16)
+            and weight.dim() == 2 and x.shape[-1] == weight.shape[1] and weight.shape[1] % 8 == 0 and weight.stride(1) == 1
+            and weight.stride(0) % 8 == 0 and weight.data_ptr() % 16 == 0
+            and (bias is None or (bias.is_cuda and bias.dtype == weight.dtype and bias.is_contiguous())))
+
+
+def linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """y = x @ weight.T + bias on the batch-invariant MFMA kernel (`F.linear` inside the calibration replay's block
+    forwards, wanda_pruner.py:308-311,343-346): a row of y depends on its row of x only, whatever else is in the call."""
+    _need_gpu(x, weight, bias)
+    if not linear_fwd_supported(x, weight, bias):
+        raise TypeError("vlmc.linear_fwd: fp16/bf16 tensors of one dtype with in_features % 8 == 0 expected")
+    N, K = weight.shape
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1 or x2.stride(0) % 8 != 0 or x2.data_ptr() % 16 != 0:
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().vlmc_linear_fwd(x2.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                           _dtype_code(x), M, N, K, x2.stride(0), weight.stride(0), y.data_ptr(), N, _stream()))
+    return y.reshape(*x.shape[:-1], N)
+
+
+def hessian_accum(H: torch.Tensor, x: torch.Tensor, alpha: float, beta: float) -> torch.Tensor:
+    """H = alpha * H + beta * x^T x on the tiles on and below the diagonal (SparseGPT.add_batch, sparsegpt_pruner.py:76-79,
+    with alpha = n/(n+b) and beta = 2/(n+b)); x [rows, in] fp16 / bf16 / fp32.  `symmetrize_lower(H)` completes H."""
+    _need_gpu(H, x)
+    assert H.dtype == torch.float32 and H.dim() == 2 and H.shape[0] == H.shape[1] == x.shape[-1] and H.stride(1) == 1
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    lib = _lib.load()
+    code = _dtype_code(x2)
+    need = lib.vlmc_hessian_workspace(code, x2.shape[0], x2.shape[1])
+    ws = _hessian_ws.get(need, x.device)
+    _lib.check(lib.vlmc_hessian_accum(x2.data_ptr(), code, x2.shape[0], x2.shape[1], x2.stride(0), H.data_ptr(), H.stride(0),
+                                      float(alpha), float(beta), ws.data_ptr(), ws.numel(), _stream()))
+    return H
+
+
+def symmetrize_lower(H: torch.Tensor) -> torch.Tensor:
+    """Copy the lower triangle of H onto the upper one (once, before a Hessian from `hessian_accum` is read in full)."""
+    _need_gpu(H)
+    assert H.dtype == torch.float32 and H.dim() == 2 and H.shape[0] == H.shape[1] and H.stride(1) == 1
+    _lib.check(_lib.load().vlmc_symmetrize_lower(H.data_ptr(), H.shape[0], H.stride(0), _stream()))
+    return H
+
+
 def act_sqnorm(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     """normsq[c, ch] = (||x[c, :, ch]||_2)**2 for hook inputs x [calls, tokens, in]
     (or [tokens, in] = one call).  wanda_pruner.py:73-81 without the running mean."""

@@ -28,6 +28,7 @@ from .ops import _need_gpu, _stream
 
 
 _DEFER = __import__("os").environ.get("VLMC_SGPT_DEFER", "1") != "0"
+_SYRK = __import__("os").environ.get("VLMC_SGPT_SYRK", "1") != "0"
 _DEFER_BYTES = 256 << 20        # staged activations (as fp32) folded into H once they exceed this
 
 
@@ -49,25 +50,40 @@ class SparseGPT:
         self.nsamples = 0
         self._folded = 0                     # samples already inside _H
         self._staged, self._staged_elems = [], 0
+        self._lower_only = False
         self.factor_cache = {}
 
     @property
     def H(self):
         self._fold()
+        if self._lower_only:                  # the SYRK kernel maintains the tiles on and below the diagonal
+            ops.symmetrize_lower(self._H)
+            self._lower_only = False
         return self._H
 
     @H.setter
     def H(self, value):
         self._staged, self._staged_elems = [], 0
+        self._lower_only = False
         self._H = value
+
+    def _accumulate(self, X, alpha, beta):
+        """H <- alpha H + beta X^T X (:76-79).  `vlmc_hessian_accum` (hand-written MFMA SYRK: 16-bit products are exact in
+        fp32, fp32 activations go as three bf16 planes; lower-triangle tiles only); `VLMC_SGPT_SYRK=0`: the library GEMM."""
+        if _SYRK:
+            ops.hessian_accum(self._H, X, alpha, beta)
+            self._lower_only = True
+        else:
+            Xf = X.float()
+            self._H.addmm_(Xf.t(), Xf, beta=alpha, alpha=beta)
 
     @torch.no_grad()
     def _fold(self):
         if not self._staged:
             return
         n = self.nsamples
-        X = torch.cat(self._staged, dim=0).float() if len(self._staged) > 1 else self._staged[0].float()
-        self._H.addmm_(X.t(), X, beta=self._folded / n, alpha=2.0 / n)       # :76-79 with b = the staged samples
+        X = torch.cat(self._staged, dim=0) if len(self._staged) > 1 else self._staged[0]
+        self._accumulate(X, self._folded / n, 2.0 / n)                       # :76-79 with b = the staged samples
         self._folded = n
         self._staged, self._staged_elems = [], 0
 
@@ -89,8 +105,11 @@ class SparseGPT:
         beta = self.nsamples / (self.nsamples + b)
         self.nsamples += b
         self._folded = self.nsamples
-        xs = math.sqrt(2 / self.nsamples) * x.float()                 # :78 (scaled in fp32 before the product)
-        self._H.addmm_(xs.t(), xs, beta=beta, alpha=1.0)              # H *= beta; H += xs^T xs  (:76-79)
+        if _SYRK:
+            self._accumulate(x, beta, 2.0 / self.nsamples)            # the scale 2/n rides in the epilogue
+        else:
+            xs = math.sqrt(2 / self.nsamples) * x.float()             # :78 (scaled in fp32 before the product)
+            self._H.addmm_(xs.t(), xs, beta=beta, alpha=1.0)          # H *= beta; H += xs^T xs  (:76-79)
 
     def free(self):
         self.H = None
