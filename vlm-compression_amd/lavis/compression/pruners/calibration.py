@@ -28,7 +28,7 @@ import os
 import torch
 import torch.nn as nn
 
-from vlmc import phases
+from vlmc import forward, phases
 
 T5_KEYS = ["attention_mask", "position_bias", "encoder_attention_mask", "encoder_decoder_position_bias",
            "layer_head_mask", "cross_attn_layer_head_mask", "encoder_hidden_states"]      # wanda_pruner.py:225-228
@@ -722,8 +722,11 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
         layer = layers[i]
         subset = find_layers(layer)
         graphs.clear()             # per block; the second pass reuses the first one's graphs when storage is unchanged
-        prune_block(i, layer, subset, run_pass, state)
-        run_pass()
+        # the block's linears run on the batch-invariant MFMA kernel in both passes (vlmc/forward.py): how the samples are
+        # grouped -- or sharded over GPUs -- does not reach the statistics
+        with forward.invariant_linears(subset.values()):
+            prune_block(i, layer, subset, run_pass, state)
+            run_pass()
         state["inps"], state["outs"] = state["outs"], state["inps"]
     if memo_cache is not None and not tuple_output:
         seed_tower_memo(memo_cache, module_to_process, layers, state["inps"][:n_samples], autocast)

@@ -144,7 +144,11 @@ class Linear(nn.Linear, LoraLayer):
     def forward(self, x: torch.Tensor, dense=False):
         previous_dtype = self.weight.dtype
         if dense or self.disable_adapters or not (self.r > 0 and not self.merged):
-            result = F.linear(x, transpose(self.weight, self.fan_in_fan_out), bias=self.bias)
+            if self.fan_in_fan_out:
+                result = F.linear(x, transpose(self.weight, self.fan_in_fan_out), bias=self.bias)
+            else:
+                from vlmc import forward as _fw        # the calibration replay's batch-invariant kernel when it is active
+                result = _fw.linear(x, self.weight, self.bias)
         else:
             if self.fan_in_fan_out:
                 raise NotImplementedError("SparseLoRA kernels expect [out, in] weights (fan_in_fan_out=False)")

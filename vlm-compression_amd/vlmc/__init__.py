@@ -5,6 +5,6 @@
 stream, caller-owned workspace).  There is NO CPU fallback: every op raises if the
 library is missing or the tensors are not on a GPU.
 """
-from . import _lib, dsnot, ops, sparse_lora, sparsegpt, wanda, workload  # noqa: F401
+from . import _lib, dsnot, forward, ops, phases, shard, sparse_lora, sparsegpt, wanda, workload  # noqa: F401
 
-__all__ = ["_lib", "dsnot", "ops", "sparse_lora", "sparsegpt", "wanda", "workload"]
+__all__ = ["_lib", "dsnot", "forward", "ops", "phases", "shard", "sparse_lora", "sparsegpt", "wanda", "workload"]
