@@ -176,3 +176,32 @@ def test_sparsegpt_class_uses_the_syrk_kernel_and_matches_the_library_route(monk
     assert float((Ha - b.H).norm() / b.H.norm()) < 1e-6
     ref = _hessian_ref(xs)
     assert float((Ha.double() - ref).norm() / ref.norm()) < 1e-6
+
+
+def test_hessian_of_the_reference_golden_inputs_through_the_syrk_kernel():
+    """tests/golden/sparsegpt.npz holds the reference's own H after `SparseGPT.add_batch` over its calls
+    (sparsegpt_pruner.py:68-79).  The fp32 cases store inputs that are exactly representable in fp16, so the fp16 MFMA
+    path sees the very numbers the reference saw: H within rel 1e-5 of the reference's."""
+    import golden_io
+    from vlmc import ops
+    G = golden_io.load("sparsegpt")
+    n_checked = 0
+    for name in sorted({k.split("/")[0] for k in G}):
+        if f"{name}/H" not in G:
+            continue
+        xs, Href = G[f"{name}/xs"], G[f"{name}/H"]
+        x16 = xs.to(torch.float16)
+        if not torch.equal(x16.float(), xs.float()):
+            x16 = xs.to(torch.bfloat16)
+            if not torch.equal(x16.float(), xs.float()):
+                continue
+        H = torch.zeros(Href.shape, device=DEV)
+        n = 0
+        for x in x16:
+            ops.hessian_accum(H, x[None].to(DEV), n / (n + 1), 2.0 / (n + 1))
+            n += 1
+        ops.symmetrize_lower(H)
+        rel = float((H.cpu() - Href).norm() / Href.norm())
+        assert rel < 1e-5, (name, rel)
+        n_checked += 1
+    assert n_checked >= 2

@@ -395,7 +395,7 @@ def capture_block_inputs(model, dataloader, n_samples, module_to_process, forwar
     count_batches=True reproduces the SparseGPT pruners' stop rule (`i >= n_samples` on the
     batch index, sparsegpt_pruner.py:391-393) instead of Wanda's sample count.
     """
-    with phases.phase("capture"):
+    with phases.phase("capture " + module_to_process):
         return _capture_block_inputs(model, dataloader, n_samples, module_to_process, forward_to_cache, lora_model, vit=vit,
                                      model_prefix=model_prefix, count_batches=count_batches, done_towers=done_towers,
                                      proxy_cache=proxy_cache)

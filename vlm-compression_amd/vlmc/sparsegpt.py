@@ -29,6 +29,9 @@ from .ops import _need_gpu, _stream
 
 _DEFER = __import__("os").environ.get("VLMC_SGPT_DEFER", "1") != "0"
 _SYRK = __import__("os").environ.get("VLMC_SGPT_SYRK", "1") != "0"
+# fp32 activations (toy / full-precision models) go as nine bf16 plane products: exact products, but 9x the matrix-core work
+# and a scattering transpose -- measured 48 TFLOP/s-equivalent against 129 for the library's fp32 GEMM, so off by default
+_SYRK_F32 = __import__("os").environ.get("VLMC_SGPT_SYRK_F32", "0") == "1"
 _DEFER_BYTES = 256 << 20        # staged activations (as fp32) folded into H once they exceed this
 
 
@@ -69,8 +72,8 @@ class SparseGPT:
 
     def _accumulate(self, X, alpha, beta):
         """H <- alpha H + beta X^T X (:76-79).  `vlmc_hessian_accum` (hand-written MFMA SYRK: 16-bit products are exact in
-        fp32, fp32 activations go as three bf16 planes; lower-triangle tiles only); `VLMC_SGPT_SYRK=0`: the library GEMM."""
-        if _SYRK:
+        fp32; lower-triangle tiles only) for 16-bit activations; fp32 activations and `VLMC_SGPT_SYRK=0`: the library GEMM."""
+        if _SYRK and (X.dtype != torch.float32 or _SYRK_F32):
             ops.hessian_accum(self._H, X, alpha, beta)
             self._lower_only = True
         else:
@@ -105,7 +108,7 @@ class SparseGPT:
         beta = self.nsamples / (self.nsamples + b)
         self.nsamples += b
         self._folded = self.nsamples
-        if _SYRK:
+        if _SYRK and (x.dtype != torch.float32 or _SYRK_F32):
             self._accumulate(x, beta, 2.0 / self.nsamples)            # the scale 2/n rides in the epilogue
         else:
             xs = math.sqrt(2 / self.nsamples) * x.float()             # :78 (scaled in fp32 before the product)
