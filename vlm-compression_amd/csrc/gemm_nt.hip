@@ -16,12 +16,18 @@
 //    `inp.float()` GEMM but its summation order.  fp32 activations are split into three bf16 planes
 //    (x = hi + mid + lo exactly) by the transposing pre-pass and all nine plane products are accumulated.
 //
-// Tile: 128 (p) x 128 (q) x 64 (k) per 256-thread workgroup; wave w owns a 64 x 64 quadrant = 4 x 4 MFMA tiles.
+// Two tile shapes, picked by the number of tiles (a launch wants >= 2 workgroups per CU of work): 256 (p) x 256 (q) x 64 (k)
+// per 512-thread workgroup (wave = 128 x 64: 8 x 4 MFMA tiles, 1/131 B of operand per flop -- a CU takes in ~70 GB/s from
+// L2, which caps 128 x 128 tiles near 0.8 PFLOP/s) and 128 x 128 x 64 per 256 threads (wave = 64 x 64) for the small
+// problems.  An output element is accumulated identically in both (same MFMA shape, same K order): the choice cannot be
+// seen in the result.
 // Operands travel global -> registers -> LDS (double buffered; the loads of K-tile t+1 are in flight while tile t is
 // multiplied), rows of 64 elements = 128 B in LDS with the 16-B chunk index XOR-ed with (row & 7): the fragment reads
 // (ds_read_b128, 16 rows x 4 chunks per wave-instruction) are bank-conflict free.  Lanes hold 4 consecutive p for one
 // q in an accumulator tile, so both epilogues store along p: 8 B of Y[m][n..n+3], 16 B of H[q][p..p+3].
 #include "common.hpp"
+
+#include <cstdlib>
 
 namespace vlmc {
 
@@ -57,12 +63,20 @@ template <> __device__ __forceinline__ uint16_t from_f32<f16_t>(float v) {
     return r;
 }
 
-constexpr int BP = 128, BQ = 128, BK = 64;            // elements
+constexpr int BK = 64;                                // elements
 constexpr int ROW_BYTES = BK * 2;                     // 128 B per tile row in LDS
-constexpr int TILE_BYTES = BP * ROW_BYTES;            // 16 KiB per operand tile
-constexpr int NTHREADS = 256;
-constexpr int CHUNKS = BP * (BK / 8) / NTHREADS;      // 16-B chunks per thread and operand tile: 4
-static_assert(BP == BQ, "one staging routine serves both operands");
+
+// TP x TQ MFMA tiles (16 x 16) per wave, WP x WQ waves per workgroup
+template <int TP_, int TQ_, int WP_, int WQ_> struct Shape {
+    static constexpr int TP = TP_, TQ = TQ_, WP = WP_, WQ = WQ_;
+    static constexpr int BP = TP * 16 * WP, BQ = TQ * 16 * WQ;
+    static constexpr int NT = 64 * WP * WQ;
+    static constexpr int P_BYTES = BP * ROW_BYTES, Q_BYTES = BQ * ROW_BYTES;
+    static constexpr int CP = BP * (BK / 8) / NT, CQ = BQ * (BK / 8) / NT;       // 16-B chunks per thread and K-tile
+    static_assert(BP * (BK / 8) % NT == 0 && BQ * (BK / 8) % NT == 0, "whole chunks per thread");
+};
+using ShapeBig = Shape<8, 4, 2, 4>;                   // 256 x 256, 512 threads, 128 KiB of LDS
+using ShapeSmall = Shape<4, 4, 2, 2>;                 // 128 x 128, 256 threads, 64 KiB
 
 enum { EPI_LINEAR = 0, EPI_SYRK = 1 };
 
@@ -84,15 +98,16 @@ struct GemmArgs {
 // byte offset of 16-B chunk `ch` (0..7) of tile row `row` in an LDS operand tile
 __device__ __forceinline__ int lds_off(int row, int ch) { return row * ROW_BYTES + ((ch ^ (row & 7)) << 4); }
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TILE_BYTES];      // [buf][P | Q]
+template <typename T, int EPI, typename S>
+__global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(const GemmArgs a) {
+    constexpr int BP = S::BP, BQ = S::BQ, NT = S::NT, TP = S::TP, TQ = S::TQ;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (S::P_BYTES + S::Q_BYTES)];      // [buf][P | Q]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ---- which tile ---------------------------------------------------------------------------------------------
     int bp, bq;
     {
         // contiguous runs of block ids per XCD (blocks b and b + 8 share an XCD's L2), then groups of 8 p-blocks with
-        // q running inside a group: the ~64 tiles an XCD works on at a time share few operand panels
+        // q running inside a group: the tiles an XCD works on at a time share few operand panels
         const int nwg = gridDim.x, orig = blockIdx.x;
         const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
         int id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
@@ -114,42 +129,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const GemmArgs a) 
     }
     const int p0 = bp * BP, q0 = bq * BQ;
 
-    // ---- staging: thread t moves chunks t, t + 256, ... of each operand tile (8 consecutive threads = one 128-B row)
-    u32x4_t stage_p[CHUNKS], stage_q[CHUNKS];
-    int st_row[CHUNKS], st_ch[CHUNKS];
-#pragma unroll
-    for (int i = 0; i < CHUNKS; ++i) {
-        const int c = tid + i * NTHREADS;
-        st_row[i] = c >> 3;
-        st_ch[i] = c & 7;
-    }
+    // ---- staging: thread t moves chunks t, t + NT, ... of each operand tile (8 consecutive threads = one 128-B row)
+    u32x4_t stage_p[S::CP], stage_q[S::CQ];
     auto load_tiles = [&](int k0) {
+        const u32x4_t zero = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int i = 0; i < CHUNKS; ++i) {
-            const int k = k0 + st_ch[i] * 8;
-            const int rp = p0 + st_row[i], rq = q0 + st_row[i];
-            const u32x4_t zero = {0u, 0u, 0u, 0u};
-            stage_p[i] = (rp < a.NP && k < a.K) ? *reinterpret_cast<const u32x4_t *>(a.P + int64_t(rp) * a.ldp + k) : zero;
-            stage_q[i] = (rq < a.NQ && k < a.K) ? *reinterpret_cast<const u32x4_t *>(a.Q + int64_t(rq) * a.ldq + k) : zero;
+        for (int i = 0; i < S::CP; ++i) {
+            const int c = tid + i * NT, row = p0 + (c >> 3), k = k0 + (c & 7) * 8;
+            stage_p[i] = (row < a.NP && k < a.K) ? *reinterpret_cast<const u32x4_t *>(a.P + int64_t(row) * a.ldp + k) : zero;
+        }
+#pragma unroll
+        for (int i = 0; i < S::CQ; ++i) {
+            const int c = tid + i * NT, row = q0 + (c >> 3), k = k0 + (c & 7) * 8;
+            stage_q[i] = (row < a.NQ && k < a.K) ? *reinterpret_cast<const u32x4_t *>(a.Q + int64_t(row) * a.ldq + k) : zero;
         }
     };
     auto store_tiles = [&](int buf) {
-        unsigned char *base = lds + buf * 2 * TILE_BYTES;
+        unsigned char *base = lds + buf * (S::P_BYTES + S::Q_BYTES);
 #pragma unroll
-        for (int i = 0; i < CHUNKS; ++i) {
-            const int off = lds_off(st_row[i], st_ch[i]);
-            *reinterpret_cast<u32x4_t *>(base + off) = stage_p[i];
-            *reinterpret_cast<u32x4_t *>(base + TILE_BYTES + off) = stage_q[i];
+        for (int i = 0; i < S::CP; ++i) {
+            const int c = tid + i * NT;
+            *reinterpret_cast<u32x4_t *>(base + lds_off(c >> 3, c & 7)) = stage_p[i];
+        }
+#pragma unroll
+        for (int i = 0; i < S::CQ; ++i) {
+            const int c = tid + i * NT;
+            *reinterpret_cast<u32x4_t *>(base + S::P_BYTES + lds_off(c >> 3, c & 7)) = stage_q[i];
         }
     };
 
-    // ---- accumulators: wave (wp, wq) owns rows wp*64.. of P and wq*64.. of Q ------------------------------------
-    const int wp = wave >> 1, wq = wave & 1;
-    f32x4_t acc[4][4];
+    // ---- accumulators: wave (wp, wq) owns rows wp * TP * 16.. of the P tile and wq * TQ * 16.. of the Q tile --------
+    const int wp = wave / S::WQ, wq = wave % S::WQ;
+    f32x4_t acc[TP][TQ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TP; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TQ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15, fch = lane >> 4;          // fragment: row (lane & 15), k = 8 * (lane >> 4) + j
 
     const int nk = (a.K + BK - 1) / BK;
@@ -159,33 +174,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const GemmArgs a) 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) load_tiles((kt + 1) * BK);       // in flight during the MFMAs below
-        const unsigned char *tp = lds + cur * 2 * TILE_BYTES + wp * 64 * ROW_BYTES;
-        const unsigned char *tq = lds + cur * 2 * TILE_BYTES + TILE_BYTES + wq * 64 * ROW_BYTES;
+        const unsigned char *tp = lds + cur * (S::P_BYTES + S::Q_BYTES) + wp * (TP * 16) * ROW_BYTES;
+        const unsigned char *tq = lds + cur * (S::P_BYTES + S::Q_BYTES) + S::P_BYTES + wq * (TQ * 16) * ROW_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            u32x4_t fp[4], fq[4];
+            u32x4_t fp[TP], fq[TQ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = i * 16 + frow;            // (wave offsets are multiples of 8: row & 7 is unchanged)
-                fp[i] = *reinterpret_cast<const u32x4_t *>(tp + lds_off(row, fch + 4 * kk));
-                fq[i] = *reinterpret_cast<const u32x4_t *>(tq + lds_off(row, fch + 4 * kk));
-            }
+            for (int j = 0; j < TQ; ++j)                  // (wave offsets are multiples of 8: row & 7 is unchanged)
+                fq[j] = *reinterpret_cast<const u32x4_t *>(tq + lds_off(j * 16 + frow, fch + 4 * kk));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TP; ++i)
+                fp[i] = *reinterpret_cast<const u32x4_t *>(tp + lds_off(i * 16 + frow, fch + 4 * kk));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(fp[i], fq[j], acc[i][j]);
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int j = 0; j < TQ; ++j) acc[i][j] = mfma16<T>(fp[i], fq[j], acc[i][j]);
         }
         if (kt + 1 < nk) store_tiles(cur ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue: lane holds p = pbase + 16 i + 4 (lane >> 4) + r (r = 0..3), q = qbase + 16 j + (lane & 15) -----
-    const int pl = p0 + wp * 64 + (lane >> 4) * 4, ql = q0 + wq * 64 + (lane & 15);
+    const int pl = p0 + wp * (TP * 16) + (lane >> 4) * 4, ql = q0 + wq * (TQ * 16) + (lane & 15);
     if constexpr (EPI == EPI_LINEAR) {
         const uint16_t *bias = static_cast<const uint16_t *>(a.bias);
         const bool vec_ok = (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 7u) == 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TP; ++i) {
             const int p = pl + i * 16;
             float b[4] = {0.f, 0.f, 0.f, 0.f};
             if (bias != nullptr) {
@@ -194,7 +209,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const GemmArgs a) 
                     if (p + r < a.NP) b[r] = to_f32<T>(bias[p + r]);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < TQ; ++j) {
                 const int q = ql + j * 16;
                 if (q >= a.NQ || p >= a.NP) continue;
                 uint16_t o[4];
@@ -214,10 +229,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const GemmArgs a) 
     } else {
         const bool vec_ok = (a.ldh & 3) == 0 && (reinterpret_cast<uintptr_t>(a.H) & 15u) == 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TP; ++i) {
             const int p = pl + i * 16;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < TQ; ++j) {
                 const int q = ql + j * 16;
                 if (q >= a.NQ || p >= a.NP) continue;
                 float *dst = a.H + int64_t(q) * a.ldh + p;              // element (row q, column p): the lower triangle
@@ -236,6 +251,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const GemmArgs a) 
             }
         }
     }
+}
+
+// launch with the tile shape the problem size asks for
+template <typename T, int EPI, typename S> static void launch_shape(GemmArgs a, int64_t np_rows, int64_t nq_rows, hipStream_t s) {
+    a.np_blocks = int((np_rows + S::BP - 1) / S::BP);
+    a.nq_blocks = int((nq_rows + S::BQ - 1) / S::BQ);
+    const int64_t nblocks = EPI == EPI_SYRK ? int64_t(a.np_blocks) * (a.np_blocks + 1) / 2 : int64_t(a.np_blocks) * a.nq_blocks;
+    VLMC_LAUNCH_TIMED((gemm_nt_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
+}
+template <typename T, int EPI> static void launch_gemm(const GemmArgs &a, hipStream_t s) {
+    // big tiles once they still give every CU two workgroups' worth of tiles (512 on this 256-CU part)
+    const int64_t bp = (a.NP + ShapeBig::BP - 1) / ShapeBig::BP, bq = (a.NQ + ShapeBig::BQ - 1) / ShapeBig::BQ;
+    const int64_t big_tiles = EPI == EPI_SYRK ? bp * (bp + 1) / 2 : bp * bq;
+    static const int min_big = [] {
+        const char *e = getenv("VLMC_GEMM_BIG_TILES");            // tuning knob: tiles needed to pick 256 x 256 (0 = never)
+        return e ? atoi(e) : 384;
+    }();
+    if (min_big > 0 && big_tiles >= min_big) launch_shape<T, EPI, ShapeBig>(a, a.NP, a.NQ, s);
+    else launch_shape<T, EPI, ShapeSmall>(a, a.NP, a.NQ, s);
 }
 
 // ---- transposing pre-pass of the Hessian: X [T, C] (any of the three dtypes) -> X^T planes [C, ldt] 16-bit -------------
@@ -321,16 +355,11 @@ extern "C" int vlmc_linear_fwd(const void *X, const void *W, const void *bias, i
     a.NP = int(N);
     a.NQ = int(M);
     a.K = int(K);
-    a.np_blocks = int((N + BP - 1) / BP);
-    a.nq_blocks = int((M + BQ - 1) / BQ);
     a.Y = static_cast<uint16_t *>(Y);
     a.ldy = ldy;
     a.bias = bias;
-    const int64_t nblocks = int64_t(a.np_blocks) * a.nq_blocks;
-    VLMC_REQUIRE(nblocks < (int64_t(1) << 31), "vlmc_linear_fwd: too many tiles");
-    const dim3 grid{unsigned(nblocks)}, block{NTHREADS};
-    if (dtype == VLMC_BF16) VLMC_LAUNCH_TIMED((gemm_nt_kernel<bf16_t, EPI_LINEAR>), grid, block, as_stream(stream), a);
-    else VLMC_LAUNCH_TIMED((gemm_nt_kernel<f16_t, EPI_LINEAR>), grid, block, as_stream(stream), a);
+    if (dtype == VLMC_BF16) launch_gemm<bf16_t, EPI_LINEAR>(a, as_stream(stream));
+    else launch_gemm<f16_t, EPI_LINEAR>(a, as_stream(stream));
     VLMC_HIP_CHECK_LAUNCH("vlmc_linear_fwd");
     return VLMC_OK;
 }
@@ -379,15 +408,12 @@ extern "C" int vlmc_hessian_accum(const void *X, int dtype, int64_t rows, int64_
     a.ldp = a.ldq = ldt;
     a.NP = a.NQ = int(in_features);
     a.K = int(ldt);
-    a.np_blocks = a.nq_blocks = int((in_features + BP - 1) / BP);
     a.H = H;
     a.ldh = ldh;
     a.alpha = alpha;
     a.beta = beta;
-    const int64_t nblocks = int64_t(a.np_blocks) * (a.np_blocks + 1) / 2;
-    const dim3 grid{unsigned(nblocks)}, block{NTHREADS};
-    if (dtype == VLMC_F16) VLMC_LAUNCH_TIMED((gemm_nt_kernel<f16_t, EPI_SYRK>), grid, block, s, a);
-    else VLMC_LAUNCH_TIMED((gemm_nt_kernel<bf16_t, EPI_SYRK>), grid, block, s, a);
+    if (dtype == VLMC_F16) launch_gemm<f16_t, EPI_SYRK>(a, s);
+    else launch_gemm<bf16_t, EPI_SYRK>(a, s);
     VLMC_HIP_CHECK_LAUNCH("vlmc_hessian_accum");
     return VLMC_OK;
 }
