@@ -146,3 +146,30 @@ def run_ressa(device="cpu", iters=5):
     stats = task._train_inner_loop(epoch=0, iters_per_epoch=iters, model=model, data_loader=iter(batches), optimizer=opt,
                                    lr_scheduler=Sched(), scaler=None, log_freq=1, cuda_enabled=False, accum_grad_iters=2)
     return model, task, stats
+
+
+# ---- 16-bit toy (fp16 ViT + bf16 T5): the dtypes of the real model, on which the batch-invariant MFMA forward engages --------
+def run_16bit_toy(method, device, n_samples=8, ragged=False):
+    """Whole `blipt5_<method>_pruner.prune()` on the toy InstructBLIP in the real model's dtypes; returns every state
+    tensor, mask and importance score.  Ragged: three text lengths, interleaved."""
+    from lavis.compression import load_pruner
+    model = toy_models.init_toy(toy_models.ToyBlipT5(vit_dtype=torch.float16, t5_dtype=torch.bfloat16), seed=7).eval().to(device)
+    lens = [5, 7, 5, 5, 7, 3, 5, 7]
+    batches = []
+    for j in range(n_samples):
+        ln = lens[j % len(lens)]
+        b = toy_models.make_batches(1, txt_len=ln if ragged else 5, out_len=(2 + ln % 3) if ragged else 4, seed=100 + j)[0]
+        batches.append({k: t.to(device) for k, t in b.items()})
+    spec = "2-0.5-1.0-1.0"
+    cfg = dict(t5_prune_spec=spec, vit_prune_spec=spec, t5_pruning_method=method, vit_pruning_method=method,
+               num_samples=n_samples, max_sparsity_per_layer=1.01)
+    if method == "dsnot":
+        cfg["max_cycle_time"] = 8
+    pruned, _ = load_pruner(f"blipt5_{method}_pruner", model, batches, cfg=cfg).prune()
+    sd = {k: v.clone() for k, v in pruned.state_dict().items()}
+    for n, m in pruned.named_modules():
+        if hasattr(m, "mask") and torch.is_tensor(m.mask):
+            sd[n + ".mask*"] = m.mask.clone()
+        if hasattr(m, "weight") and hasattr(m.weight, "importance_score"):
+            sd[n + ".importance*"] = torch.tensor(m.weight.importance_score, dtype=torch.float64)
+    return sd

@@ -378,3 +378,82 @@ def test_blocks_that_cannot_be_captured_fall_back_to_the_eager_loop(monkeypatch)
     assert cal.graph_stats["captured"] > before["captured"]                   # ... the ViT blocks were not
     for (ka, va), (kb, vb) in zip(eager.state_dict().items(), graphed.state_dict().items()):
         assert ka == kb and torch.equal(va, vb), ka
+
+
+def _capture_decoder_inputs(model, batches, **env):
+    """Inputs of the T5 decoder's first block as captured while the (finished) ViT and encoder towers are run through."""
+    from lavis.compression.pruners import calibration as cal
+    cache = {}
+    with torch.no_grad():
+        inps, _, caches = cal.capture_block_inputs(model, batches, len(batches), "t5_model.decoder.block",
+                                                   lambda m, b, _l=False: m(b), False, vit=False, model_prefix="t5_model",
+                                                   done_towers=["visual_encoder.blocks", "t5_model.encoder.block"], proxy_cache=cache)
+    torch.cuda.synchronize()
+    return inps, caches, cache
+
+
+@pytest.mark.parametrize("streams", ["1", "3"])
+def test_tower_graph_gives_the_eager_forward_bit_for_bit(streams, monkeypatch):
+    """calibration.TowerGraph: the finished towers run as ONE graph per calibration forward (traced twice, then captured per
+    stream slot); the captured decoder inputs equal those of the plain eager forward, on one stream and on three."""
+    import toy_models
+    from lavis.compression.pruners import calibration as cal
+    model = toy_models.init_toy(toy_models.ToyBlipT5(), seed=7).eval().to("cuda:0")
+    batches = [{k: t.to("cuda:0") for k, t in b.items()} for b in toy_models.make_batches(12, seed=11)]
+    monkeypatch.setenv("VLMC_GRAPH_REPLAY", "0")
+    want, want_c, _ = _capture_decoder_inputs(model, batches)
+    monkeypatch.setenv("VLMC_GRAPH_REPLAY", "1")
+    monkeypatch.setenv("VLMC_TOWER_MEMO", "0")
+    monkeypatch.setenv("VLMC_CAPTURE_STREAMS", streams)
+    before = dict(cal.graph_stats)
+    got, got_c, cache = _capture_decoder_inputs(model, batches)
+    assert cal.graph_stats.get("tower_graphs", 0) - before.get("tower_graphs", 0) == 2 * int(streams)     # two towers x slots
+    assert cal.graph_stats["fallbacks"] == before["fallbacks"]
+    assert len(got) == len(want) == 12
+    for a, b, ca, cb in zip(got, want, got_c, want_c):
+        assert torch.equal(a, b)
+        assert torch.equal(ca["encoder_hidden_states"], cb["encoder_hidden_states"])
+    # per-block graphs instead (`VLMC_TOWER_GRAPH=0`): the same again
+    monkeypatch.setenv("VLMC_TOWER_GRAPH", "0")
+    got2, _, _ = _capture_decoder_inputs(model, batches)
+    assert all(torch.equal(a, b) for a, b in zip(got2, want))
+
+
+def test_tower_graph_falls_back_when_the_model_passes_on_something_else(monkeypatch):
+    from lavis.compression.pruners import calibration as cal
+    monkeypatch.setenv("VLMC_GRAPH_REPLAY", "1")
+
+    class Tower(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks = torch.nn.ModuleList([torch.nn.Sequential(torch.nn.Linear(32, 32), torch.nn.GELU()) for _ in range(3)])
+            self.tweak, self.tweak2 = -1, -1
+
+        def forward(self, x, j):
+            for i, blk in enumerate(self.blocks):
+                if i == 1 and j == self.tweak:
+                    x = x * 2.0                              # a new tensor, not what block 0 returned
+                if i == 2 and j == self.tweak2:
+                    x.mul_(0.5)                              # what block 1 returned, edited in place
+                x = blk(x)
+            return x
+
+    torch.manual_seed(0)
+    model = Tower().to("cuda:0").eval()
+    xs = [torch.randn(2, 5, 32, device="cuda:0") for _ in range(8)]
+    with torch.no_grad():
+        for tweak, tweak2 in ((5, -1), (-1, 6)):
+            model.tweak, model.tweak2 = tweak, tweak2
+            want = [model(x, j) for j, x in enumerate(xs)]
+            undo = cal._wrap_towers(model, ["blocks"], {})
+            before = dict(cal.graph_stats)
+            try:
+                got = [model(x, j) for j, x in enumerate(xs)]
+            finally:
+                for blocks, i, orig in undo:
+                    blocks[i].__dict__["_memo"] = blocks[i].__dict__["_tower"] = None
+                    blocks[i] = orig
+            assert cal.graph_stats.get("tower_graphs", 0) == before.get("tower_graphs", 0) + 1
+            assert cal.graph_stats["fallbacks"] == before["fallbacks"] + 1      # one sample left the traced path
+            for a, b in zip(got, want):
+                assert torch.equal(a, b)

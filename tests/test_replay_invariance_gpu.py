@@ -54,29 +54,10 @@ def test_block_forward_is_batch_invariant_at_model_width(which):
     assert not any("forward" in m.__dict__ for m in subset.values())                 # patches are gone
 
 
-def _run_16bit_toy(method, group, monkeypatch, n_samples=8, ragged=False):
-    import toy_models
-    from lavis.compression import load_pruner
+def _run_16bit_toy(method, group, monkeypatch, ragged=False):
+    import pruner_helpers as H
     monkeypatch.setenv("VLMC_BATCH_REPLAY", str(group))
-    model = toy_models.init_toy(toy_models.ToyBlipT5(vit_dtype=torch.float16, t5_dtype=torch.bfloat16), seed=7).eval().to(DEV)
-    lens = [5, 7, 5, 5, 7, 3, 5, 7]
-    batches = []
-    for j in range(n_samples):
-        b = toy_models.make_batches(1, txt_len=lens[j] if ragged else 5, out_len=(2 + lens[j] % 3) if ragged else 4, seed=100 + j)[0]
-        batches.append({k: t.to(DEV) for k, t in b.items()})
-    spec = "2-0.5-1.0-1.0"
-    cfg = dict(t5_prune_spec=spec, vit_prune_spec=spec, t5_pruning_method=method, vit_pruning_method=method,
-               num_samples=n_samples, max_sparsity_per_layer=1.01)
-    if method == "dsnot":
-        cfg["max_cycle_time"] = 8
-    pruned, _ = load_pruner(f"blipt5_{method}_pruner", model, batches, cfg=cfg).prune()
-    sd = {k: v.clone() for k, v in pruned.state_dict().items()}
-    for n, m in pruned.named_modules():
-        if hasattr(m, "mask") and torch.is_tensor(m.mask):
-            sd[n + ".mask*"] = m.mask.clone()
-        if hasattr(m, "weight") and hasattr(m.weight, "importance_score"):
-            sd[n + ".importance*"] = torch.tensor(m.weight.importance_score, dtype=torch.float64)
-    return sd
+    return H.run_16bit_toy(method, DEV, ragged=ragged)
 
 
 @pytest.mark.parametrize("ragged", [False, True])

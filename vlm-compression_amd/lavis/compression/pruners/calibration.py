@@ -243,6 +243,34 @@ def seed_tower_memo(proxy_cache, module_to_process, layers, final_outs, autocast
     return True
 
 
+_capture_side = {}
+
+
+def capture_graph(fn, device):
+    """(graph, fn()) with fn's kernels captured in a HIP graph.  `torch.cuda.graph` synchronises the device, collects garbage
+    and empties the allocator cache on entry (~1 ms) -- per block, tower, slot and prune that was 0.1 s of a FlanT5-XL prune;
+    the capture itself needs none of it."""
+    graph = torch.cuda.CUDAGraph()
+    cur = torch.cuda.current_stream(device)
+    side = _capture_side.get(device)
+    if side is None:
+        side = _capture_side[device] = torch.cuda.Stream(device=device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        graph.capture_begin(capture_error_mode="thread_local")
+        try:
+            out = fn()
+        except BaseException:
+            try:
+                graph.capture_end()
+            except Exception:
+                pass
+            raise
+        graph.capture_end()
+    cur.wait_stream(side)
+    return graph, out
+
+
 # Capture phases run the calibration forwards round-robin on a few side streams (capture_streams()); the slot a forward
 # runs in picks the graph instance -- and with it the static buffers -- its proxies replay (None: the caller's stream).
 _CAPTURE_SLOT = None
@@ -258,6 +286,213 @@ def capture_streams():
         return max(1, int(os.environ.get("VLMC_CAPTURE_STREAMS", "4")))
     except ValueError:
         return 1
+
+
+def tower_graph_enabled():
+    """One HIP graph per finished TOWER and calibration forward (`VLMC_TOWER_GRAPH=0`: one per block)."""
+    return os.environ.get("VLMC_TOWER_GRAPH", "1") != "0"
+
+
+class TowerGraph:
+    """All blocks of a FINISHED tower as ONE HIP graph per calibration forward.
+
+    While the next tower's inputs are captured, the model's own forward walks an already pruned tower block by block; with a
+    proxy and a graph per block that is 24 graph launches, 48 buffer copies and ~100 us of Python per block and sample --
+    the host, not the GPU, bounded the capture of the T5 decoder's inputs (128 x 24 encoder block forwards).  The first
+    forwards through the tower are traced: which argument of block i is which output of an earlier block, which is an
+    outside tensor (by object identity), what is a plain value.  If every outside tensor is already an argument of block
+    0, the whole chain can run when block 0 is entered: it is captured once per (stream slot, argument signature) and
+    replayed from then on; the proxies of blocks 1.. hand out the outputs the graph has already produced, after checking
+    that the model passed on exactly the tensors it was given (same objects, unmodified).  Any deviation -- another
+    argument, an in-place edit, blocks called out of order -- falls back to the per-block path from that block on and
+    switches the tower graph off.  Same kernels on the same values as the per-block graphs: bit-identical."""
+
+    NEED = 2                                  # identical traces before a graph is built
+
+    def __init__(self, modules):
+        self.mods, self.n = list(modules), len(modules)
+        self.plans, self.traces, self.wirings = {}, {}, {}
+        self.off = False
+        self.live = None                      # replay in progress: {"plan", "given": id -> (tensor, version)}
+        self.trace = None                     # recording in progress
+
+    # -- helpers ---------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _flat(out):
+        return list(out) if isinstance(out, (tuple, list)) else [out]
+
+    def _key0(self, args, kwargs):
+        """What decides the tower's kernels and the wiring, from block 0's arguments (the stream slot is not part of it)."""
+        sig = [TowerMemo.context(), self.mods[0].training]
+        first = {}
+        for pos, v in enumerate(list(args) + [kwargs[k] for k in sorted(kwargs)]):
+            s_ = GraphedModule._sig(v)
+            if s_ is NotImplemented:
+                return None
+            sig.append(s_)
+            if isinstance(v, torch.Tensor):
+                sig.append(first.setdefault(id(v), pos))                 # which arguments are one and the same tensor
+        return tuple(sig) + tuple(sorted(kwargs))
+
+    def _wire(self, v, known):
+        if isinstance(v, torch.Tensor):
+            src = known.get(id(v))
+            if src is None or src[0] is not v:
+                return None
+            return src[1]                                     # ("ext", k) or ("out", block, position)
+        if v is None or isinstance(v, (bool, int, float, str)):
+            return ("val", v)
+        return None
+
+    # -- called by the proxies -----------------------------------------------------------------------------------------
+    def enter(self, index, args, kwargs):
+        """-> (handled, value)"""
+        if self.off or torch.is_grad_enabled():
+            self.live = self.trace = None
+            return False, None
+        if index == 0:
+            self.live = self.trace = None
+            key = self._key0(args, kwargs)
+            wiring = self.wirings.get(key) if key is not None else False
+            if wiring is False or key is None:
+                return False, None
+            if wiring is None:                                            # not known yet: trace this forward
+                known = {}
+                ext = []
+                for v in list(args) + [kwargs[k] for k in sorted(kwargs)]:
+                    if isinstance(v, torch.Tensor) and id(v) not in known:
+                        known[id(v)] = (v, ("ext", len(ext)))
+                        ext.append(v)
+                self.trace = {"key": key, "known": known, "calls": [], "next": 0}
+                return False, None
+            plan = self.plans.get((_CAPTURE_SLOT, key))
+            if plan is None:                                              # one graph (and its buffers) per stream slot
+                plan = self.plans[(_CAPTURE_SLOT, key)] = self._build(wiring, args, kwargs)
+            if plan is False:
+                return False, None
+            return self._replay(plan, args, kwargs)
+        if self.live is not None:
+            return self._serve(index, args, kwargs)
+        return False, None
+
+    def leave(self, index, args, kwargs, out):
+        tr = self.trace
+        if tr is None:
+            return
+        if index != tr["next"]:
+            self.trace = None
+            return
+        tr["next"] = index + 1
+        wires = [self._wire(v, tr["known"]) for v in args]
+        kwires = {k: self._wire(v, tr["known"]) for k, v in kwargs.items()}
+        flat = self._flat(out)
+        if any(w is None for w in wires) or any(w is None for w in kwires.values()) or \
+                not all(o is None or isinstance(o, torch.Tensor) for o in flat):
+            self.wirings[tr["key"]] = False                               # an argument from outside appears after block 0
+            self.trace = None
+            return
+        for pos, o in enumerate(flat):
+            if isinstance(o, torch.Tensor):
+                tr["known"][id(o)] = (o, ("out", index, pos))
+        tr["calls"].append((tuple(wires), tuple(sorted(kwires.items())), isinstance(out, tuple), isinstance(out, list),
+                            tuple(o is None for o in flat)))
+        if index == self.n - 1:
+            self._finish_trace(tr)
+            self.trace = None
+
+    # -- building and running the graph ----------------------------------------------------------------------------------
+    def tracing(self):
+        return self.trace is not None
+
+    def _finish_trace(self, tr):
+        key, calls = tr["key"], tuple(tr["calls"])
+        seen = self.traces.setdefault(key, [])
+        if seen and seen[-1] != calls:
+            self.wirings[key] = False
+            return
+        seen.append(calls)
+        if len(seen) >= self.NEED:
+            self.wirings[key] = calls
+
+    def _build(self, calls, args, kwargs):
+        try:
+            ext, seen = [], set()
+            for v in list(args) + [kwargs[k] for k in sorted(kwargs)]:
+                if isinstance(v, torch.Tensor) and id(v) not in seen:
+                    seen.add(id(v))
+                    ext.append(v.clone())
+            outs = []
+
+            def resolve(w):
+                if w[0] == "ext":
+                    return ext[w[1]]
+                if w[0] == "out":
+                    return self._flat(outs[w[1]])[w[2]]
+                return w[1]
+
+            def body():
+                for i, (wires, kwires, _t, _l, _n) in enumerate(calls):
+                    outs.append(self.mods[i](*[resolve(w) for w in wires], **{k: resolve(w) for k, w in kwires}))
+                return outs
+            graph, _ = capture_graph(body, ext[0].device)
+            graph_stats["captured"] += 1
+            graph_stats["tower_graphs"] = graph_stats.get("tower_graphs", 0) + 1
+            return {"graph": graph, "ext": ext, "outs": outs, "calls": calls}
+        except Exception as e:
+            graph_stats["fallbacks"] += 1
+            print(f"tower graph not built ({type(e).__name__}: {e})")
+            return False
+
+    def _hand_out(self, index):
+        plan, live = self.live["plan"], self.live
+        out = plan["outs"][index]
+        flat = [o.clone() if isinstance(o, torch.Tensor) else o for o in self._flat(out)]
+        for pos, o in enumerate(flat):
+            if isinstance(o, torch.Tensor):
+                live["given"][("out", index, pos)] = (o, o._version)
+        if isinstance(out, tuple):
+            return tuple(flat)
+        if isinstance(out, list):
+            return flat
+        return flat[0]
+
+    def _replay(self, plan, args, kwargs):
+        given = {}
+        k = 0
+        seen = set()
+        for v in list(args) + [kwargs[kk] for kk in sorted(kwargs)]:
+            if isinstance(v, torch.Tensor) and id(v) not in seen:
+                seen.add(id(v))
+                plan["ext"][k].copy_(v)
+                given[("ext", k)] = (v, v._version)
+                k += 1
+        plan["graph"].replay()
+        graph_stats["replayed"] += 1
+        self.live = {"plan": plan, "given": given}
+        return True, self._hand_out(0)
+
+    def _serve(self, index, args, kwargs):
+        live = self.live
+        wires, kwires = live["plan"]["calls"][index][0], dict(live["plan"]["calls"][index][1])
+        ok = len(args) == len(wires) and sorted(kwargs) == sorted(kwires)
+        if ok:
+            for v, w in list(zip(args, wires)) + [(kwargs[k], kwires[k]) for k in kwires]:
+                if w[0] == "val":
+                    ok = not isinstance(v, torch.Tensor) and (v is w[1] or v == w[1])
+                else:
+                    g = live["given"].get(w)
+                    ok = g is not None and g[0] is v and v._version == g[1]
+                if not ok:
+                    break
+        if not ok:                      # the model did something else with the tower this time: per-block path from here
+            self.live = None
+            self.off = True
+            graph_stats["fallbacks"] += 1
+            return False, None
+        out = self._hand_out(index)
+        if index == self.n - 1:
+            self.live = None
+        return True, out
 
 
 class GraphedModule(nn.Module):
@@ -287,12 +522,24 @@ class GraphedModule(nn.Module):
     def forward(self, *args, **kwargs):
         memo = self.__dict__.get("_memo")                       # (TowerMemo, index of this block in its tower) or None
         if memo is None or torch.is_grad_enabled():
-            return self._forward(*args, **kwargs)
+            return self._tower_forward(*args, **kwargs)
         handled, value = memo[0].enter(memo[1], args, kwargs)
         if handled:
             return value
-        out = self._forward(*args, **kwargs)
+        out = self._tower_forward(*args, **kwargs)
         memo[0].leave(memo[1], out)
+        return out
+
+    def _tower_forward(self, *args, **kwargs):
+        tg = self.__dict__.get("_tower")                        # (TowerGraph, index) or None
+        if tg is None:
+            return self._forward(*args, **kwargs)
+        handled, value = tg[0].enter(tg[1], args, kwargs)
+        if handled:
+            return value
+        # (while the tower is traced for its own graph the blocks run eagerly: a graph per block would be captured for nothing)
+        out = self.__dict__["_wrapped"](*args, **kwargs) if tg[0].tracing() else self._forward(*args, **kwargs)
+        tg[0].leave(tg[1], args, kwargs, out)
         return out
 
     def _forward(self, *args, **kwargs):
@@ -314,9 +561,8 @@ class GraphedModule(nn.Module):
             try:
                 sargs = [a.clone() if isinstance(a, torch.Tensor) else a for a in args]
                 skw = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in kwargs.items()}
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    out = mod(*sargs, **skw)
+                dev_ = next(a for a in list(sargs) + list(skw.values()) if isinstance(a, torch.Tensor)).device
+                graph, out = capture_graph(lambda: mod(*sargs, **skw), dev_)
                 flat = out if isinstance(out, (tuple, list)) else (out,)
                 if not all(o is None or isinstance(o, torch.Tensor) for o in flat):
                     raise TypeError("block output is not a tensor or a flat tuple of tensors")
@@ -366,6 +612,20 @@ def _wrap_towers(model, towers, proxy_cache=None):
                 proxy.__dict__["_memo"] = None
                 proxies.append(proxy)
                 originals.append(mod)
+        # the whole tower as one graph per calibration forward (TowerGraph), kept with the proxies from phase to phase
+        if tower_graph_enabled() and len(proxies) == len(blocks) >= 2 and not any(m.training for mod in originals for m in mod.modules()):
+            tg = proxy_cache.get(("tower_graph", path)) if proxy_cache is not None else None
+            if tg is None or len(tg.mods) != len(originals) or any(a is not b for a, b in zip(tg.mods, originals)) or \
+                    tg.storage != tuple(storage_signature(m) for m in originals):
+                tg = TowerGraph(originals)
+                tg.storage = tuple(storage_signature(m) for m in originals)
+                if proxy_cache is not None:
+                    proxy_cache[("tower_graph", path)] = tg
+            for i, proxy in enumerate(proxies):
+                proxy.__dict__["_tower"] = (tg, i)
+        else:
+            for proxy in proxies:
+                proxy.__dict__["_tower"] = None
         # the tower's outputs of this phase are remembered for the next one (TowerMemo)
         # (a block in training mode may draw dropout / drop-path masks: its output is not a function of its inputs)
         if proxy_cache is not None and tower_memo_enabled() and len(proxies) == len(blocks) >= 2 \
@@ -488,6 +748,7 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
         layers[0] = layers[0].module
         for blocks, i, orig in undo:
             blocks[i].__dict__["_memo"] = None
+            blocks[i].__dict__["_tower"] = None
             blocks[i] = orig
     if calls is not None:
         proxy_cache[("calls", module_to_process)] = calls
@@ -594,7 +855,6 @@ class BlockGraph:
                 layer(self.x, **self.cache)                   # warm-up: lazy initialisation must not land in the capture
             torch.cuda.current_stream(x.device).wait_stream(side)
             self.records.clear()
-            self.graph = torch.cuda.CUDAGraph()
             versions = []
 
             def recorder(mod, inp, out):                             # noqa: F811  (the capture's recorder also notes versions)
@@ -602,9 +862,11 @@ class BlockGraph:
                 versions.append((inp[0], inp[0]._version))
             for m in modules:
                 m._forward_hooks = OrderedDict({0: recorder})
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad(), autocast():
-                y = layer(self.x, **self.cache)
-                self.y = y[0] if tuple_output else y
+            def body():
+                with torch.no_grad(), autocast():
+                    return layer(self.x, **self.cache)
+            self.graph, y = capture_graph(body, x.device)
+            self.y = y[0] if tuple_output else y
             # the real hooks run AFTER the whole replay, on these static tensors: a block that writes into a linear's
             # input in place after the linear has run would show them other activations than the eager loop does
             if any(t._version != v for t, v in versions):

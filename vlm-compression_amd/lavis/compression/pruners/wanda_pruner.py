@@ -90,7 +90,7 @@ class WandaStatCollector:
                 outs = self._ops.act_sqnorm_batch([x for x, _ in same])
                 for (_, holders), rows in zip(same, outs):
                     for c, holder in enumerate(holders):
-                        holder[0] = rows[c:c + 1]
+                        holder[0] = (rows, c)                  # row c of `rows`, sliced only where it is needed
         self._pending = []
 
     def next_sample(self, j=None):
@@ -116,13 +116,27 @@ class WandaStatCollector:
             if st is None:
                 in_f = self.subset[name].weight.shape[1]
                 st = wanda.InputStat(in_f, self.subset[name].weight.device)
-                st.rows = [h[0] for _, h, _ in recs]
+                st.rows = _row_runs([h[0] for _, h, _ in recs])
                 st.batches = [b for _, _, b in recs]
                 shared[sig] = st
                 order.append(st)
             out[name] = st
         wanda.gather_stats(order)
         return out
+
+
+def _row_runs(refs):
+    """[(rows tensor, row index)] in sample order -> the fewest [k, in] tensors with the same rows in the same order: runs
+    of consecutive rows of one launch's output stay ONE slice (all 128 samples of a grouped replay: the tensor itself)."""
+    out, i = [], 0
+    while i < len(refs):
+        base, c0 = refs[i]
+        j = i + 1
+        while j < len(refs) and refs[j][0] is base and refs[j][1] == c0 + (j - i):
+            j += 1
+        out.append(base[c0:c0 + (j - i)])
+        i = j
+    return out
 
 
 def _importance_backlog(backlog, subset, names, partial_rows, numels):
