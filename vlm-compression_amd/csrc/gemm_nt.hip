@@ -129,35 +129,32 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(const GemmArgs a) {
     }
     const int p0 = bp * BP, q0 = bq * BQ;
 
-    // ---- staging: thread t moves chunks t, t + NT, ... of each operand tile (8 consecutive threads = one 128-B row).
-    // Two register sets: the loads of K-tile t + 2 are issued before tile t is multiplied and land in LDS at the end of
-    // step t + 1 -- two steps of MFMAs (~4k cycles) cover a load's way through L2 / Infinity Cache with every CU asking.
-    struct Stage { u32x4_t p[S::CP], q[S::CQ]; };
-    Stage s0, s1;
-    auto load_tiles = [&](Stage &st, int k0) {
+    // ---- staging: thread t moves chunks t, t + NT, ... of each operand tile (8 consecutive threads = one 128-B row)
+    u32x4_t stage_p[S::CP], stage_q[S::CQ];
+    auto load_tiles = [&](int k0) {
         const u32x4_t zero = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < S::CP; ++i) {
             const int c = tid + i * NT, row = p0 + (c >> 3), k = k0 + (c & 7) * 8;
-            st.p[i] = (row < a.NP && k < a.K) ? *reinterpret_cast<const u32x4_t *>(a.P + int64_t(row) * a.ldp + k) : zero;
+            stage_p[i] = (row < a.NP && k < a.K) ? *reinterpret_cast<const u32x4_t *>(a.P + int64_t(row) * a.ldp + k) : zero;
         }
 #pragma unroll
         for (int i = 0; i < S::CQ; ++i) {
             const int c = tid + i * NT, row = q0 + (c >> 3), k = k0 + (c & 7) * 8;
-            st.q[i] = (row < a.NQ && k < a.K) ? *reinterpret_cast<const u32x4_t *>(a.Q + int64_t(row) * a.ldq + k) : zero;
+            stage_q[i] = (row < a.NQ && k < a.K) ? *reinterpret_cast<const u32x4_t *>(a.Q + int64_t(row) * a.ldq + k) : zero;
         }
     };
-    auto store_tiles = [&](const Stage &st, int buf) {
+    auto store_tiles = [&](int buf) {
         unsigned char *base = lds + buf * (S::P_BYTES + S::Q_BYTES);
 #pragma unroll
         for (int i = 0; i < S::CP; ++i) {
             const int c = tid + i * NT;
-            *reinterpret_cast<u32x4_t *>(base + lds_off(c >> 3, c & 7)) = st.p[i];
+            *reinterpret_cast<u32x4_t *>(base + lds_off(c >> 3, c & 7)) = stage_p[i];
         }
 #pragma unroll
         for (int i = 0; i < S::CQ; ++i) {
             const int c = tid + i * NT;
-            *reinterpret_cast<u32x4_t *>(base + S::P_BYTES + lds_off(c >> 3, c & 7)) = st.q[i];
+            *reinterpret_cast<u32x4_t *>(base + S::P_BYTES + lds_off(c >> 3, c & 7)) = stage_q[i];
         }
     };
 
@@ -170,9 +167,15 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(const GemmArgs a) {
         for (int j = 0; j < TQ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15, fch = lane >> 4;          // fragment: row (lane & 15), k = 8 * (lane >> 4) + j
 
-    auto multiply = [&](int buf) {
-        const unsigned char *tp = lds + buf * (S::P_BYTES + S::Q_BYTES) + wp * (TP * 16) * ROW_BYTES;
-        const unsigned char *tq = lds + buf * (S::P_BYTES + S::Q_BYTES) + S::P_BYTES + wq * (TQ * 16) * ROW_BYTES;
+    const int nk = (a.K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tiles((kt + 1) * BK);       // in flight during the MFMAs below
+        const unsigned char *tp = lds + cur * (S::P_BYTES + S::Q_BYTES) + wp * (TP * 16) * ROW_BYTES;
+        const unsigned char *tq = lds + cur * (S::P_BYTES + S::Q_BYTES) + S::P_BYTES + wq * (TQ * 16) * ROW_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             u32x4_t fp[TP], fq[TQ];
@@ -187,24 +190,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(const GemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < TQ; ++j) acc[i][j] = mfma16<T>(fp[i], fq[j], acc[i][j]);
         }
-    };
-
-    const int nk = (a.K + BK - 1) / BK;
-    load_tiles(s0, 0);
-    if (nk > 1) load_tiles(s1, BK);
-    store_tiles(s0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-        // even step: tile kt is in LDS buffer 0, tile kt + 1 in register set 1
-        if (kt + 2 < nk) load_tiles(s0, (kt + 2) * BK);
-        multiply(0);
-        if (kt + 1 < nk) store_tiles(s1, 1);
-        __syncthreads();
-        if (kt + 1 >= nk) break;
-        // odd step: tile kt + 1 is in LDS buffer 1, tile kt + 2 in register set 0
-        if (kt + 3 < nk) load_tiles(s1, (kt + 3) * BK);
-        multiply(1);
-        if (kt + 2 < nk) store_tiles(s0, 0);
+        if (kt + 1 < nk) store_tiles(cur ^ 1);
         __syncthreads();
     }
 
