@@ -457,3 +457,32 @@ def test_tower_graph_falls_back_when_the_model_passes_on_something_else(monkeypa
             assert cal.graph_stats["fallbacks"] == before["fallbacks"] + 1      # one sample left the traced path
             for a, b in zip(got, want):
                 assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_tower_batching_gives_the_per_sample_forward_bit_for_bit(ragged, monkeypatch):
+    """Finished 16-bit towers (their linears on the batch-invariant kernel) run ONCE for all postponed calibration forwards
+    of a shape (`TowerGraph.run_deferred`); the forwards are repeated and served slices.  The captured decoder inputs equal
+    those of the sample-by-sample route bit for bit, in sample order, also with ragged text (three shapes, interleaved)."""
+    import toy_models
+    from lavis.compression.pruners import calibration as cal
+    model = toy_models.init_toy(toy_models.ToyBlipT5(vit_dtype=torch.float16, t5_dtype=torch.bfloat16), seed=7).eval().to("cuda:0")
+    lens = [5, 7, 5, 5, 7, 3, 5, 7, 5, 5, 7, 5]
+    batches = []
+    for j, n in enumerate(lens):
+        b = toy_models.make_batches(1, txt_len=n if ragged else 5, out_len=(2 + n % 3) if ragged else 4, seed=100 + j)[0]
+        batches.append({k: t.to("cuda:0") for k, t in b.items()})
+    monkeypatch.setenv("VLMC_TOWER_MEMO", "0")
+    monkeypatch.setenv("VLMC_TOWER_BATCH", "0")
+    monkeypatch.setenv("VLMC_TOWER_GRAPH", "0")
+    want, want_c, _ = _capture_decoder_inputs(model, batches)
+    monkeypatch.setenv("VLMC_TOWER_BATCH", "1")
+    monkeypatch.setenv("VLMC_TOWER_GRAPH", "1")
+    before = dict(cal.graph_stats)
+    got, got_c, _ = _capture_decoder_inputs(model, batches)
+    assert cal.graph_stats.get("tower_batches", 0) > before.get("tower_batches", 0)
+    assert cal.graph_stats["fallbacks"] == before["fallbacks"]
+    assert len(got) == len(want) == len(lens)
+    for j, (a, b, ca, cb) in enumerate(zip(got, want, got_c, want_c)):
+        assert a.shape == b.shape and torch.equal(a, b), j
+        assert torch.equal(ca["encoder_hidden_states"], cb["encoder_hidden_states"]), j

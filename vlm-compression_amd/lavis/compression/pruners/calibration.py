@@ -118,8 +118,9 @@ class TowerMemo:
 
     def __init__(self, fingerprint, n_blocks):
         self.fp, self.n = fingerprint, n_blocks
-        self.entries, self.mode, self.ok = [], "record", True
+        self.entries, self.mode, self.ok = {}, "record", True        # entries: index of the calibration forward -> record
         self.cursor, self.hit, self.pending, self.expect, self.bytes = 0, None, None, 0, 0
+        self.current = 0
 
     @staticmethod
     def fingerprint(blocks):
@@ -139,7 +140,7 @@ class TowerMemo:
     def begin(self, mode):
         self.mode, self.cursor, self.hit, self.pending, self.expect = mode, 0, None, None, 0
         if mode == "record":
-            self.entries, self.bytes = [], 0
+            self.entries, self.bytes = {}, 0
 
     @staticmethod
     def context():
@@ -168,7 +169,7 @@ class TowerMemo:
         return True
 
     def _drop(self):
-        self.ok, self.entries, self.hit, self.pending = False, [], None, None
+        self.ok, self.entries, self.hit, self.pending = False, {}, None, None
 
     def enter(self, index, args, kwargs):
         """-> (handled, value).  Called by block `index` of the tower before it would run."""
@@ -176,6 +177,11 @@ class TowerMemo:
             return False, None
         if index == 0:
             self.expect, self.hit, self.pending = 0, None, None
+            # which calibration forward this is: the capture loop says so (it may run a forward twice); else they are counted
+            if _CAPTURE_SAMPLE is not None:
+                self.current = _CAPTURE_SAMPLE
+            else:
+                self.current, self.cursor = self.cursor, self.cursor + 1
         if index != self.expect:                                   # blocks skipped or repeated inside one forward
             if self.hit is not None:
                 raise RuntimeError("tower memo: the model called the tower's blocks in another order than when the memo "
@@ -190,9 +196,9 @@ class TowerMemo:
                     self._drop()
             return False, None
         if index == 0:
-            j, self.cursor = self.cursor, self.cursor + 1
-            if j < len(self.entries) and self._same(self.entries[j][0], args, kwargs):
-                self.hit = self.entries[j][1]
+            ent = self.entries.get(self.current)
+            if ent is not None and self._same(ent[0], args, kwargs):
+                self.hit = ent[1]
                 graph_stats["memo_hits"] += 1
             else:
                 graph_stats["memo_misses"] += 1
@@ -206,7 +212,7 @@ class TowerMemo:
     def leave(self, index, result):
         if self.ok and self.mode == "record" and index == self.n - 1:
             if isinstance(result, torch.Tensor) and self.pending is not None and self.expect == self.n:
-                self.entries.append((self.pending, result.detach().clone()))
+                self.entries[self.current] = (self.pending, result.detach().clone())
                 self.bytes += result.numel() * result.element_size() + sum(
                     v.numel() * v.element_size() for v in list(self.pending[0]) + list(self.pending[1].values())
                     if isinstance(v, torch.Tensor))
@@ -237,7 +243,7 @@ def seed_tower_memo(proxy_cache, module_to_process, layers, final_outs, autocast
     if fp is None:
         return False
     memo = TowerMemo(fp, len(layers))
-    memo.entries = [((c[0], c[1], ctx), final_outs[j].detach()) for j, c in enumerate(calls[:n])]
+    memo.entries = {j: ((c[0], c[1], ctx), final_outs[j].detach()) for j, c in enumerate(calls[:n])}
     proxy_cache[("memo", module_to_process)] = memo
     graph_stats["memo_recorded"] += n
     return True
@@ -288,6 +294,21 @@ def capture_streams():
         return 1
 
 
+# Index (within this rank's share) of the calibration forward that capture_block_inputs is running; None outside of it.
+_CAPTURE_SAMPLE = None
+
+
+class _Defer(ValueError):
+    """Raised by a finished tower's first block to abort a calibration forward whose tower pass is postponed: the tower
+    will run for many samples at once (TowerGraph.run_deferred) and the forward be repeated (a ValueError, like the
+    catcher's stop, so that `forward_to_cache` wrappers that swallow it keep working)."""
+
+
+def tower_batch_enabled():
+    """Finished towers run for all calibration samples of one shape in ONE pass (`VLMC_TOWER_BATCH=0`: per sample)."""
+    return os.environ.get("VLMC_TOWER_BATCH", "1") != "0"
+
+
 def tower_graph_enabled():
     """One HIP graph per finished TOWER and calibration forward (`VLMC_TOWER_GRAPH=0`: one per block)."""
     return os.environ.get("VLMC_TOWER_GRAPH", "1") != "0"
@@ -305,13 +326,23 @@ class TowerGraph:
     replayed from then on; the proxies of blocks 1.. hand out the outputs the graph has already produced, after checking
     that the model passed on exactly the tensors it was given (same objects, unmodified).  Any deviation -- another
     argument, an in-place edit, blocks called out of order -- falls back to the per-block path from that block on and
-    switches the tower graph off.  Same kernels on the same values as the per-block graphs: bit-identical."""
+    switches the tower graph off.  Same kernels on the same values as the per-block graphs: bit-identical.
+
+    Tower batching (the default when the tower qualifies): a batch-1 pass through a 24-block tower is ~700 kernels of a
+    few microseconds, 128 times over.  With the wiring known, the forward of sample j is ABORTED at block 0 (`_Defer`), its
+    arguments are kept, and once every sample of the sweep has arrived the tower runs ONCE per group of equal-shape
+    samples, stacked along the batch dimension (`run_deferred`); the capture loop then repeats those forwards, and this
+    time the proxies hand out the per-sample slices.  A tower qualifies when every linear in it runs on the
+    batch-invariant kernel (16-bit weights, vlmc/forward.py) and every outside tensor has the hidden states' batch
+    dimension: the stacked pass then gives every sample the bits its own pass would."""
 
     NEED = 2                                  # identical traces before a graph is built
 
     def __init__(self, modules):
         self.mods, self.n = list(modules), len(modules)
         self.plans, self.traces, self.wirings = {}, {}, {}
+        self.deferred, self.ready = [], {}    # forwards postponed at block 0; their per-block outputs once the tower ran
+        self.linears = [m for mod in self.mods for m in find_layers(mod).values()]
         self.off = False
         self.live = None                      # replay in progress: {"plan", "given": id -> (tensor, version)}
         self.trace = None                     # recording in progress
@@ -365,6 +396,22 @@ class TowerGraph:
                         ext.append(v)
                 self.trace = {"key": key, "known": known, "calls": [], "next": 0}
                 return False, None
+            if _CAPTURE_SAMPLE is not None and tower_batch_enabled():
+                r = self.ready.pop(_CAPTURE_SAMPLE, None)
+                if r is not None:
+                    if self._same_inputs(r, args, kwargs):
+                        given, k, seen = {}, 0, set()
+                        for v in list(args) + [kwargs[kk] for kk in sorted(kwargs)]:
+                            if isinstance(v, torch.Tensor) and id(v) not in seen:
+                                seen.add(id(v))
+                                given[("ext", k)] = (v, v._version)
+                                k += 1
+                        self.live = {"outs": r["outs"], "calls": wiring, "given": given, "clone": False}
+                        return True, self._hand_out(0)
+                elif self._batchable(args, kwargs):
+                    self.deferred.append({"j": _CAPTURE_SAMPLE, "key": key, "args": args, "kwargs": kwargs,
+                                          "ctx": TowerMemo.context()})
+                    raise _Defer
             plan = self.plans.get((_CAPTURE_SLOT, key))
             if plan is None:                                              # one graph (and its buffers) per stream slot
                 plan = self.plans[(_CAPTURE_SLOT, key)] = self._build(wiring, args, kwargs)
@@ -444,9 +491,9 @@ class TowerGraph:
             return False
 
     def _hand_out(self, index):
-        plan, live = self.live["plan"], self.live
-        out = plan["outs"][index]
-        flat = [o.clone() if isinstance(o, torch.Tensor) else o for o in self._flat(out)]
+        live = self.live
+        out = live["outs"][index]
+        flat = [(o.clone() if live["clone"] else o) if isinstance(o, torch.Tensor) else o for o in self._flat(out)]
         for pos, o in enumerate(flat):
             if isinstance(o, torch.Tensor):
                 live["given"][("out", index, pos)] = (o, o._version)
@@ -468,12 +515,13 @@ class TowerGraph:
                 k += 1
         plan["graph"].replay()
         graph_stats["replayed"] += 1
-        self.live = {"plan": plan, "given": given}
+        # (the graph's output buffers are overwritten by the slot's next replay: hand out copies)
+        self.live = {"outs": plan["outs"], "calls": plan["calls"], "given": given, "clone": True}
         return True, self._hand_out(0)
 
     def _serve(self, index, args, kwargs):
         live = self.live
-        wires, kwires = live["plan"]["calls"][index][0], dict(live["plan"]["calls"][index][1])
+        wires, kwires = live["calls"][index][0], dict(live["calls"][index][1])
         ok = len(args) == len(wires) and sorted(kwargs) == sorted(kwires)
         if ok:
             for v, w in list(zip(args, wires)) + [(kwargs[k], kwires[k]) for k in kwires]:
@@ -493,6 +541,77 @@ class TowerGraph:
         if index == self.n - 1:
             self.live = None
         return True, out
+
+    # -- tower batching ----------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _ext(args, kwargs):
+        out, seen = [], set()
+        for v in list(args) + [kwargs[k] for k in sorted(kwargs)]:
+            if isinstance(v, torch.Tensor) and id(v) not in seen:
+                seen.add(id(v))
+                out.append(v)
+        return out
+
+    def _batchable(self, args, kwargs):
+        """Every linear of the tower on the batch-invariant kernel, every outside tensor stackable along the batch."""
+        from vlmc import forward as fw
+        if not (args and isinstance(args[0], torch.Tensor) and args[0].dim() >= 2 and fw.enabled() and self.linears):
+            return False
+        ctx = TowerMemo.context()
+        for m in self.linears:
+            w = getattr(m, "weight", None)
+            if type(m) is not nn.Linear or w is None or w.dtype not in (torch.float16, torch.bfloat16) or w.shape[1] % 8 or \
+                    (ctx[0] and ctx[1] != w.dtype):
+                return False
+        b0 = args[0].shape[0]
+        return all(e.dim() >= 1 and e.shape[0] == b0 for e in self._ext(args, kwargs))
+
+    @staticmethod
+    def _same_inputs(r, args, kwargs):
+        a, b = TowerGraph._ext(r["args"], r["kwargs"]), TowerGraph._ext(args, kwargs)
+        return len(a) == len(b) and all(x.shape == y.shape and x.dtype == y.dtype and bool(torch.equal(x, y)) for x, y in zip(a, b))
+
+    @torch.no_grad()
+    def run_deferred(self):
+        """The tower for every postponed forward, stacked per group of equal signature; returns their indices."""
+        from vlmc import forward as fw
+        todo, self.deferred = self.deferred, []
+        groups = {}
+        for rec in todo:
+            groups.setdefault(rec["key"], []).append(rec)
+        for key, recs in groups.items():
+            calls = self.wirings[key]
+            x0 = recs[0]["args"][0]
+            rows = max(1, x0.numel() // max(1, x0.shape[-1]))
+            per = max(1, min(replay_group_size(), REPLAY_TOKEN_BUDGET // rows))
+            b0 = x0.shape[0]
+            ctx = recs[0]["ctx"]
+            for c0 in range(0, len(recs), per):
+                chunk = recs[c0:c0 + per]
+                exts = [self._ext(r["args"], r["kwargs"]) for r in chunk]
+                ext = [torch.cat([e[k] for e in exts], dim=0) for k in range(len(exts[0]))]
+                outs = []
+
+                def resolve(w):
+                    if w[0] == "ext":
+                        return ext[w[1]]
+                    if w[0] == "out":
+                        return self._flat(outs[w[1]])[w[2]]
+                    return w[1]
+                with torch.autocast(device_type="cuda", dtype=ctx[1], enabled=ctx[0]) if ctx[0] else contextlib.nullcontext(), \
+                        fw.invariant_linears(self.linears):
+                    for i, (wires, kwires, _t, _l, _n) in enumerate(calls):
+                        outs.append(self.mods[i](*[resolve(w) for w in wires], **{k: resolve(w) for k, w in kwires}))
+                g = len(chunk)
+                for t, rec in enumerate(chunk):
+                    mine = []
+                    for out in outs:
+                        flat = [(o[t * b0:(t + 1) * b0] if o.dim() >= 1 and o.shape[0] == g * b0 else o) if isinstance(o, torch.Tensor)
+                                else o for o in self._flat(out)]
+                        mine.append(tuple(flat) if isinstance(out, tuple) else flat if isinstance(out, list) else flat[0])
+                    self.ready[rec["j"]] = {"outs": mine, "args": rec["args"], "kwargs": rec["kwargs"]}
+                graph_stats["tower_batches"] = graph_stats.get("tower_batches", 0) + 1
+        return [rec["j"] for rec in todo]
 
 
 class GraphedModule(nn.Module):
@@ -665,7 +784,7 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
                           model_prefix, count_batches, done_towers, proxy_cache):
     layers = get_module_recursive(model, module_to_process)
     keys = None if vit else _keys_for(model_prefix)
-    inps, caches = [], []
+    arrived = []                                   # (index of the calibration forward, block-0 input, cached kwargs)
     rank, world = calibration_shard()
     # how the model calls block 0, for seed_tower_memo (towers whose blocks all get the same kwargs: the ViT)
     calls = [] if (vit and proxy_cache is not None and tower_memo_enabled() and graph_replay_enabled()
@@ -678,7 +797,8 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
 
         def forward(self, inp, *args, **kwargs):
             if calls is not None:
-                calls.append(TowerMemo._snapshot((inp,) + tuple(args), kwargs))
+                calls.append((_CAPTURE_SAMPLE if _CAPTURE_SAMPLE is not None else len(calls),
+                              TowerMemo._snapshot((inp,) + tuple(args), kwargs)))
             if vit:
                 rel_pos_bias = args[0] if args else kwargs.get("rel_pos_bias")
                 dense = args[1] if len(args) > 1 else kwargs.get("dense", True)
@@ -686,11 +806,10 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
             else:
                 dense = kwargs.pop("dense", True)
                 cache = {k: kwargs[k] for k in keys}
-            inps.append(inp)
-            inps[-1].requires_grad = False
+            inp.requires_grad = False
             if lora_model:
                 cache["dense"] = dense
-            caches.append(cache)
+            arrived.append((_CAPTURE_SAMPLE if _CAPTURE_SAMPLE is not None else len(arrived), inp, cache))
             if main_stream is not None:               # produced on a side stream, consumed on the caller's: tell the allocator
                 for t in [inp] + list(cache.values()):
                     if isinstance(t, torch.Tensor) and t.is_cuda:
@@ -699,7 +818,7 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
 
     # side streams for the forwards (kept by the pruner from phase to phase): only worth it when finished towers are run
     # through, and only on a GPU model
-    global _CAPTURE_SLOT
+    global _CAPTURE_SLOT, _CAPTURE_SAMPLE
     sides, main_stream = [], None
     p0 = next(model.parameters(), None)
     if capture_streams() > 1 and done_towers and p0 is not None and p0.is_cuda and graph_replay_enabled():
@@ -729,27 +848,63 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
                                f"over {world} ranks (set VLMC_SHARD_CALIB=0 to run as replicas)")
         per = len(batches) // world
         mine = batches[rank * per:(rank + 1) * per] if world > 1 else batches
-        if sides:
-            for st in sides:
-                st.wait_stream(main_stream)
-        for j, batch in enumerate(mine):
-            if sides:
-                _CAPTURE_SLOT = j % len(sides)
-            try:
-                with (torch.cuda.stream(sides[_CAPTURE_SLOT]) if sides else contextlib.nullcontext()):
-                    forward_to_cache(model, batch, lora_model)
-            except ValueError:                         # _Stop, or the reference's bare ValueError
-                pass
+        towers = []
+        for blocks_, i_, _orig in undo:
+            tg_ = blocks_[i_].__dict__.get("_tower")
+            if tg_ is not None and not any(tg_[0] is t for t in towers):
+                towers.append(tg_[0])
+        # the finished towers' linears run on the batch-invariant kernel whichever way a sample gets through them (alone,
+        # from a graph, or stacked with others): the captured inputs do not depend on the route
+        with forward.invariant_linears([m for t in towers for m in t.linears]):
+            pending, sweeps = list(range(len(mine))), 0
+            while pending:
+                sweeps += 1
+                if sides:
+                    for st in sides:
+                        st.wait_stream(main_stream)
+                for n_, j in enumerate(pending):
+                    _CAPTURE_SAMPLE = j
+                    if sides:
+                        _CAPTURE_SLOT = n_ % len(sides)
+                    try:
+                        with (torch.cuda.stream(sides[_CAPTURE_SLOT]) if sides else contextlib.nullcontext()):
+                            forward_to_cache(model, mine[j], lora_model)
+                    except ValueError:                 # _Stop / _Defer, or the reference's bare ValueError
+                        pass
+                _CAPTURE_SAMPLE = _CAPTURE_SLOT = None
+                if sides:
+                    for st in sides:
+                        main_stream.wait_stream(st)
+                pending = []
+                for t in towers:
+                    if t.deferred:
+                        if main_stream is not None:            # arguments made on the side streams, used on the caller's
+                            for rec in t.deferred:
+                                for e in TowerGraph._ext(rec["args"], rec["kwargs"]):
+                                    e.record_stream(main_stream)
+                        pending += t.run_deferred()
+                pending = sorted(set(pending))
+                if sweeps > 2 * len(towers) + 2 and pending:   # cannot happen with towers in sequence; never loop forever
+                    raise RuntimeError("calibration capture: postponed forwards do not get through the finished towers "
+                                       "(set VLMC_TOWER_BATCH=0)")
     finally:
-        _CAPTURE_SLOT = None
+        _CAPTURE_SLOT = _CAPTURE_SAMPLE = None
         if sides:
             for st in sides:
                 main_stream.wait_stream(st)
         layers[0] = layers[0].module
         for blocks, i, orig in undo:
+            tg = blocks[i].__dict__.get("_tower")
+            if tg is not None:
+                tg[0].deferred, tg[0].ready, tg[0].live, tg[0].trace = [], {}, None, None
             blocks[i].__dict__["_memo"] = None
             blocks[i].__dict__["_tower"] = None
             blocks[i] = orig
+    arrived.sort(key=lambda a: a[0])                   # postponed forwards arrive late; the reference's order is by sample
+    inps, caches = [a[1] for a in arrived], [a[2] for a in arrived]
+    if calls is not None:
+        calls.sort(key=lambda c: c[0])
+        calls = [c[1] for c in calls]
     if calls is not None:
         proxy_cache[("calls", module_to_process)] = calls
     return inps, [None] * len(inps), caches
