@@ -15,6 +15,15 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _restore_toy_attention():
+    import toy_models
+    yield
+    toy_models.ToyAttention.use_sdpa = False
+
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
@@ -58,7 +67,8 @@ sys.path[:0] = [{root!r}, os.path.join({root!r}, "vlm-compression_amd"), os.path
 rank = int(os.environ["RANK"])
 torch.cuda.set_device(rank)
 dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
-import pruner_helpers as H
+import pruner_helpers as H, toy_models
+toy_models.ToyAttention.use_sdpa = True
 out = {{tag: {{k: v.cpu() for k, v in H.run_16bit_toy(tag, f"cuda:{{rank}}", ragged=(tag == "dsnot")).items()}} for tag in ("wanda", "dsnot")}}
 torch.save(out, os.path.join({out!r}, f"rank{{rank}}.pt"))
 dist.barrier()
@@ -82,6 +92,8 @@ def test_sample_sharded_pruners_over_rccl_equal_single_process(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     # the toy in the real model's dtypes: its linears run on the batch-invariant kernel, so sharding the samples (other
     # groups per rank) cannot change a bit
+    import toy_models
+    toy_models.ToyAttention.use_sdpa = True        # (restored by the fixture below)
     for tag in ("wanda", "dsnot"):
         single = {k: v.cpu() for k, v in H.run_16bit_toy(tag, "cuda:0", ragged=(tag == "dsnot")).items()}
         for rank in range(2):
@@ -111,6 +123,8 @@ def test_sample_sharding_with_the_kernels_is_bit_identical_to_single_process(tmp
     r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
               "--master-port", str(port), str(script)], timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
+    import toy_models
+    toy_models.ToyAttention.use_sdpa = True        # (restored by the fixture below)
     for tag in ("wanda", "dsnot"):
         single = {k: v.cpu() for k, v in H.run_16bit_toy(tag, "cuda:0", ragged=(tag == "dsnot")).items()}
         for rank in range(2):

@@ -466,6 +466,7 @@ def test_tower_batching_gives_the_per_sample_forward_bit_for_bit(ragged, monkeyp
     those of the sample-by-sample route bit for bit, in sample order, also with ragged text (three shapes, interleaved)."""
     import toy_models
     from lavis.compression.pruners import calibration as cal
+    monkeypatch.setattr(toy_models.ToyAttention, "use_sdpa", True)        # attention per sample and head by construction
     model = toy_models.init_toy(toy_models.ToyBlipT5(vit_dtype=torch.float16, t5_dtype=torch.bfloat16), seed=7).eval().to("cuda:0")
     lens = [5, 7, 5, 5, 7, 3, 5, 7, 5, 5, 7, 5]
     batches = []
