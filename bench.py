@@ -196,8 +196,12 @@ def install_probes(probe):
             (os.environ.get("VLMC_SELECT_MIXED", "1") != "0" and max(widths) <= 8192 and min(widths) <= 2048 < max(widths)
              and all(i % 8 == 0 for i in widths))
 
+    def gemm_flops(x, weight, bias=None):
+        return 2.0 * (x.numel() // x.shape[-1]) * weight.shape[0] * weight.shape[1]
+
     probe.wrap(ops, "act_sqnorm_batch", "stat", sq_bytes)
     probe.wrap(ops, "wanda_select_batch", "rows", sel_bytes, sel_single)
+    probe.wrap(ops, "linear_fwd", "gemm", gemm_flops)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -498,19 +502,32 @@ def main():
     # ---- roofline of the dominant product kernel of the step --------------------------------------------------------
     traffic = load_traffic()
 
-    def roof(kind, kernel, tkey):
-        ms, nbytes, n = probe.summary(kind)
-        ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(tkey), "launches": n,
-                "avg_launch_us": round(ms * 1e3 / max(1, n), 2), "bytes_per_launch": round(nbytes / max(1, n)),
-                "timed": f"HIP events carried by the launch (hipExtLaunchKernel) on every {probe.stride}-th launch of this "
-                         f"kernel inside the timed prunes"}
+    def roof(kind, kernel, tkey, bound="hbm"):
+        ms, units, n = probe.summary(kind)
+        calls = probe.calls.get(kind, 0)
+        timed = (f"HIP events carried by the launch (hipExtLaunchKernel) on every {probe.stride}-th launch of this kernel inside "
+                 f"the timed prunes")
+        avg_us = ms * 1e3 / max(1, n)
+        common = {"kernel": kernel, "launches": n, "avg_launch_us": round(avg_us, 2), "launches_per_step": round(calls / args.steps, 1),
+                  "gpu_ms_per_step": round(avg_us * calls / args.steps * 1e-3, 2), "traffic": traffic.get(tkey), "timed": timed}
+        if bound == "mfma":
+            ach = units / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            return dict(common, bound="mfma", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / MFMA_PEAK_TFLOPS, 4), flops_per_launch=round(units / max(1, n)))
+        ach = units / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return dict(common, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                    bytes_per_launch=round(units / max(1, n)))
 
-    roofline = roof("stat", "vlmc::act_sqnorm_kernel (per-sample squared column norms of every distinct linear input of a "
-                            "block; one launch per group of calibration samples)", "act_sqnorm_kernel_bytes_per_launch")
-    roofline["other"] = [roof("rows", "vlmc::select_rows_mixed_kernel (score+select+apply, per-row rule; all linears of a T5 "
-                                      "block in one launch)", "select_rows_mixed_kernel_bytes_per_launch")]
+    rows = [roof("gemm", "vlmc::gemm_nt_kernel (vlmc_linear_fwd: the dense calibration forward of the blocks' linears on "
+                         "v_mfma_f32_16x16x32, batch-invariant; algorithmic flops = 2 M N K)", "gemm_nt_kernel_bytes_per_launch", "mfma"),
+            roof("stat", "vlmc::act_sqnorm_kernel (per-sample squared column norms of every distinct linear input of a block; one "
+                         "launch per group of calibration samples)", "act_sqnorm_kernel_bytes_per_launch"),
+            roof("rows", "vlmc::select_rows_mixed_kernel (score+select+apply, per-row rule; all linears of a T5 block in one "
+                         "launch)", "select_rows_mixed_kernel_bytes_per_launch")]
+    # the dominant kernel = the product kernel with the most GPU time per step (measured, not assumed)
+    rows.sort(key=lambda r: -r["gpu_ms_per_step"])
+    roofline = rows[0]
+    roofline["other"] = rows[1:]
 
     kp = None
     if args.kernel_pass == "1" or (args.kernel_pass == "auto" and world == 1):
