@@ -205,3 +205,39 @@ def test_hessian_of_the_reference_golden_inputs_through_the_syrk_kernel():
         assert rel < 1e-5, (name, rel)
         n_checked += 1
     assert n_checked >= 2
+
+
+def test_ring_and_register_staged_kernels_give_the_same_bits(tmp_path):
+    """Two kernels compute the product (operands streamed into an LDS ring by global_load_lds, K % 32 == 0; or staged through
+    registers, any K % 8 == 0) with two tile shapes each: an output element sees the same MFMAs in the same order in all of
+    them.  `VLMC_GEMM_RING` / `VLMC_GEMM_BIG_TILES` are read once per process, hence the child processes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys, torch
+sys.path.insert(0, {os.path.join(root, 'vlm-compression_amd')!r})
+from vlmc import ops
+g = torch.Generator(device='cuda:0').manual_seed(11)
+outs = []
+for dt, M, N, K in [(torch.bfloat16, 700, 1024, 2048), (torch.float16, 3000, 1408, 1408), (torch.bfloat16, 64, 5120, 2048)]:
+    x = (torch.randn(M, K, generator=g, device='cuda:0') * 0.5 + 0.1).to(dt)
+    w = (torch.randn(N, K, generator=g, device='cuda:0') * 0.05).to(dt)
+    b = (torch.randn(N, generator=g, device='cuda:0') * 0.1).to(dt)
+    outs.append(ops.linear_fwd(x, w, b).cpu())
+    H = torch.zeros(K, K, device='cuda:0')
+    ops.hessian_accum(H, x, 0.0, 0.01)
+    outs.append(ops.symmetrize_lower(H).cpu())
+torch.save(outs, sys.argv[1])
+"""
+    results = []
+    for ring, big in (("1", "384"), ("0", "384"), ("1", "1"), ("0", "0"), ("1", "0")):
+        out = tmp_path / f"r{ring}_b{big}.pt"
+        env = dict(os.environ, VLMC_GEMM_RING=ring, VLMC_GEMM_BIG_TILES=big)
+        r = subprocess.run([sys.executable, "-c", code, str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        results.append(torch.load(out))
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            assert torch.equal(a, b)

@@ -98,6 +98,69 @@ struct GemmArgs {
 // byte offset of 16-B chunk `ch` (0..7) of tile row `row` in an LDS operand tile
 __device__ __forceinline__ int lds_off(int row, int ch) { return row * ROW_BYTES + ((ch ^ (row & 7)) << 4); }
 
+// ---- epilogue: lane holds p = pbase + 16 i + 4 (lane >> 4) + r (r = 0..3), q = qbase + 16 j + (lane & 15) ---------------
+template <typename T, int EPI, typename S>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4_t (&acc)[S::TP][S::TQ], int p0, int q0, int wp, int wq,
+                                              int lane) {
+    constexpr int TP = S::TP, TQ = S::TQ;
+    const int pl = p0 + wp * (TP * 16) + (lane >> 4) * 4, ql = q0 + wq * (TQ * 16) + (lane & 15);
+    if constexpr (EPI == EPI_LINEAR) {
+        const uint16_t *bias = static_cast<const uint16_t *>(a.bias);
+        const bool vec_ok = (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 7u) == 0;
+#pragma unroll
+        for (int i = 0; i < TP; ++i) {
+            const int p = pl + i * 16;
+            float b[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (p + r < a.NP) b[r] = to_f32<T>(bias[p + r]);
+            }
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) {
+                const int q = ql + j * 16;
+                if (q >= a.NQ || p >= a.NP) continue;
+                uint16_t o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(bias != nullptr ? acc[i][j][r] + b[r] : acc[i][j][r]);
+                uint16_t *dst = a.Y + int64_t(q) * a.ldy + p;
+                if (vec_ok && p + 3 < a.NP) {
+                    u32x2_t v = {uint32_t(o[0]) | uint32_t(o[1]) << 16, uint32_t(o[2]) | uint32_t(o[3]) << 16};
+                    *reinterpret_cast<u32x2_t *>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (p + r < a.NP) dst[r] = o[r];
+                }
+            }
+        }
+    } else {
+        const bool vec_ok = (a.ldh & 3) == 0 && (reinterpret_cast<uintptr_t>(a.H) & 15u) == 0;
+#pragma unroll
+        for (int i = 0; i < TP; ++i) {
+            const int p = pl + i * 16;
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) {
+                const int q = ql + j * 16;
+                if (q >= a.NQ || p >= a.NP) continue;
+                float *dst = a.H + int64_t(q) * a.ldh + p;              // element (row q, column p): the lower triangle
+                if (vec_ok && p + 3 < a.NP) {
+                    f32x4_t h = {0.f, 0.f, 0.f, 0.f};
+                    if (a.alpha != 0.f) h = *reinterpret_cast<const f32x4_t *>(dst);
+                    f32x4_t o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = a.alpha != 0.f ? a.alpha * h[r] + a.beta * acc[i][j][r] : a.beta * acc[i][j][r];
+                    *reinterpret_cast<f32x4_t *>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (p + r < a.NP) dst[r] = a.alpha != 0.f ? a.alpha * dst[r] + a.beta * acc[i][j][r] : a.beta * acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int EPI, typename S>
 __global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(const GemmArgs a) {
     constexpr int BP = S::BP, BQ = S::BQ, NT = S::NT, TP = S::TP, TQ = S::TQ;
@@ -194,63 +257,113 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(const GemmArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds p = pbase + 16 i + 4 (lane >> 4) + r (r = 0..3), q = qbase + 16 j + (lane & 15) -----
-    const int pl = p0 + wp * (TP * 16) + (lane >> 4) * 4, ql = q0 + wq * (TQ * 16) + (lane & 15);
-    if constexpr (EPI == EPI_LINEAR) {
-        const uint16_t *bias = static_cast<const uint16_t *>(a.bias);
-        const bool vec_ok = (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 7u) == 0;
-#pragma unroll
-        for (int i = 0; i < TP; ++i) {
-            const int p = pl + i * 16;
-            float b[4] = {0.f, 0.f, 0.f, 0.f};
-            if (bias != nullptr) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (p + r < a.NP) b[r] = to_f32<T>(bias[p + r]);
-            }
-#pragma unroll
-            for (int j = 0; j < TQ; ++j) {
-                const int q = ql + j * 16;
-                if (q >= a.NQ || p >= a.NP) continue;
-                uint16_t o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(bias != nullptr ? acc[i][j][r] + b[r] : acc[i][j][r]);
-                uint16_t *dst = a.Y + int64_t(q) * a.ldy + p;
-                if (vec_ok && p + 3 < a.NP) {
-                    u32x2_t v = {uint32_t(o[0]) | uint32_t(o[1]) << 16, uint32_t(o[2]) | uint32_t(o[3]) << 16};
-                    *reinterpret_cast<u32x2_t *>(dst) = v;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (p + r < a.NP) dst[r] = o[r];
-                }
-            }
-        }
-    } else {
-        const bool vec_ok = (a.ldh & 3) == 0 && (reinterpret_cast<uintptr_t>(a.H) & 15u) == 0;
-#pragma unroll
-        for (int i = 0; i < TP; ++i) {
-            const int p = pl + i * 16;
-#pragma unroll
-            for (int j = 0; j < TQ; ++j) {
-                const int q = ql + j * 16;
-                if (q >= a.NQ || p >= a.NP) continue;
-                float *dst = a.H + int64_t(q) * a.ldh + p;              // element (row q, column p): the lower triangle
-                if (vec_ok && p + 3 < a.NP) {
-                    f32x4_t h = {0.f, 0.f, 0.f, 0.f};
-                    if (a.alpha != 0.f) h = *reinterpret_cast<const f32x4_t *>(dst);
-                    f32x4_t o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = a.alpha != 0.f ? a.alpha * h[r] + a.beta * acc[i][j][r] : a.beta * acc[i][j][r];
-                    *reinterpret_cast<f32x4_t *>(dst) = o;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (p + r < a.NP) dst[r] = a.alpha != 0.f ? a.alpha * dst[r] + a.beta * acc[i][j][r] : a.beta * acc[i][j][r];
-                }
-            }
+    gemm_epilogue<T, EPI, S>(a, acc, p0, q0, wp, wq, lane);
+}
+
+// ---- the same product with operands streamed straight into an LDS ring (global_load_lds, no register staging) ----------
+// K-steps of 32 (one MFMA k-step), four ring slots: the loads of step t + 3 are issued while step t is multiplied, so a
+// load has three steps of MFMAs (~3k cycles per SIMD) to come back through L2 / Infinity Cache before anybody waits for
+// it -- the register-staged kernel above has one, and waits.  The LDS-DMA writes a wave-instruction's 64 x 16 B
+// contiguously (16 tile rows of 64 B), so the bank swizzle is applied to the SOURCE address (which 16-B chunk of its row a
+// lane fetches) and again when the fragments are read.  hipcc knows nothing of these loads (inline asm): the waits are
+// counted by hand -- `s_waitcnt vmcnt(8)` leaves the two youngest steps (4 loads per lane each) in flight -- and the only
+// barrier per step is a raw s_barrier.  Rows past the operand's end are clamped to its last row (their products are never
+// stored); K must be a multiple of 32.  An output element sees the same MFMAs in the same order as in the kernel above.
+constexpr int RK = 32, RROW = RK * 2, NSLOT = 4;
+
+__device__ __forceinline__ int ring_perm(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }     // {0, 2, 3, 1}
+__device__ __forceinline__ int ring_off(int row, int ch) { return row * RROW + ((ch ^ ring_perm(row)) << 4); }
+
+__device__ __forceinline__ void glds16(const void *gptr, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(gptr) : "memory", "m0");
+}
+
+template <typename T, int EPI, typename S>
+__global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_kernel(const GemmArgs a) {
+    constexpr int BP = S::BP, BQ = S::BQ, TP = S::TP, TQ = S::TQ, NW = S::WP * S::WQ;
+    constexpr int P_BYTES = BP * RROW, Q_BYTES = BQ * RROW, SLOT = P_BYTES + Q_BYTES;
+    constexpr int GROUPS = (BP + BQ) / 16, PER_WAVE = GROUPS / NW;        // wave-instructions of 16 rows per step
+    static_assert(GROUPS % NW == 0, "whole load instructions per wave");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSLOT * SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bp, bq;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
+        int id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+        if constexpr (EPI == EPI_SYRK) {
+            int r = int((__builtin_sqrtf(8.0f * float(id) + 1.0f) - 1.0f) * 0.5f);
+            while ((r + 1) * (r + 2) / 2 <= id) ++r;
+            while (r * (r + 1) / 2 > id) --r;
+            bq = r;
+            bp = id - r * (r + 1) / 2;
+        } else {
+            const int G = 8;
+            const int per_group = G * a.nq_blocks;
+            const int g = id / per_group, in_g = id - g * per_group;
+            const int gp = min(G, a.np_blocks - g * G);
+            bq = in_g / gp;
+            bp = g * G + (in_g - bq * gp);
         }
     }
+    const int p0 = bp * BP, q0 = bq * BQ;
+
+    // ---- what this lane fetches: PER_WAVE pieces of 16 rows x 64 B per step ----------------------------------------
+    const uint32_t lds_base = uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)lds));   // LDS byte address
+    const uint16_t *src[PER_WAVE];
+    uint32_t dst[PER_WAVE];                                               // wave-uniform LDS byte offset inside a slot
+#pragma unroll
+    for (int u = 0; u < PER_WAVE; ++u) {
+        const int gidx = wave * PER_WAVE + u;                             // 16-row group of the step's [P | Q] image
+        const bool is_q = gidx >= BP / 16;
+        const int g = is_q ? gidx - BP / 16 : gidx;
+        const int r = g * 16 + (lane >> 2);                               // tile row
+        const int sc = (lane & 3) ^ ring_perm(r);                         // source chunk that belongs at LDS chunk (lane & 3)
+        const int grow = is_q ? min(q0 + r, a.NQ - 1) : min(p0 + r, a.NP - 1);
+        src[u] = (is_q ? a.Q + int64_t(grow) * a.ldq : a.P + int64_t(grow) * a.ldp) + sc * 8;
+        dst[u] = (is_q ? P_BYTES : 0) + g * 1024;
+    }
+    auto issue = [&](int step) {
+        const uint32_t slot = lds_base + (step & (NSLOT - 1)) * SLOT;
+#pragma unroll
+        for (int u = 0; u < PER_WAVE; ++u) glds16(src[u] + step * RK, slot + dst[u]);
+    };
+
+    const int wp = wave / S::WQ, wq = wave % S::WQ;
+    f32x4_t acc[TP][TQ];
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fch = lane >> 4;
+    const int foff = ring_off(frow, fch);                                 // (16-row offsets keep (row >> 2) & 3)
+
+    const int nk = a.K / RK;
+    for (int st = 0; st < NSLOT - 1 && st < nk; ++st) issue(st);
+    for (int t = 0; t < nk; ++t) {
+        const int rem = nk - 1 - t;
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                     // step t has landed for every wave; slot t - 1 is free
+        if (t + NSLOT - 1 < nk) issue(t + NSLOT - 1);
+        const unsigned char *tp = lds + (t & (NSLOT - 1)) * SLOT + wp * (TP * 16) * RROW + foff;
+        const unsigned char *tq = lds + (t & (NSLOT - 1)) * SLOT + P_BYTES + wq * (TQ * 16) * RROW + foff;
+        u32x4_t fp[TP], fq[TQ];
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) fq[j] = *reinterpret_cast<const u32x4_t *>(tq + j * 16 * RROW);
+#pragma unroll
+        for (int i = 0; i < TP; ++i) fp[i] = *reinterpret_cast<const u32x4_t *>(tp + i * 16 * RROW);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) acc[i][j] = mfma16<T>(fp[i], fq[j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    gemm_epilogue<T, EPI, S>(a, acc, p0, q0, wp, wq, lane);
 }
 
 // launch with the tile shape the problem size asks for
@@ -258,7 +371,12 @@ template <typename T, int EPI, typename S> static void launch_shape(GemmArgs a, 
     a.np_blocks = int((np_rows + S::BP - 1) / S::BP);
     a.nq_blocks = int((nq_rows + S::BQ - 1) / S::BQ);
     const int64_t nblocks = EPI == EPI_SYRK ? int64_t(a.np_blocks) * (a.np_blocks + 1) / 2 : int64_t(a.np_blocks) * a.nq_blocks;
-    VLMC_LAUNCH_TIMED((gemm_nt_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
+    static const bool ring = [] {
+        const char *e = getenv("VLMC_GEMM_RING");                 // 0: the register-staged kernel for every shape
+        return !(e && e[0] == '0');
+    }();
+    if (ring && a.K % RK == 0) VLMC_LAUNCH_TIMED((gemm_nt_ring_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
+    else VLMC_LAUNCH_TIMED((gemm_nt_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
 }
 template <typename T, int EPI> static void launch_gemm(const GemmArgs &a, hipStream_t s) {
     // big tiles once they still give every CU two workgroups' worth of tiles (512 on this 256-CU part)
