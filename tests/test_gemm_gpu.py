@@ -208,9 +208,10 @@ def test_hessian_of_the_reference_golden_inputs_through_the_syrk_kernel():
 
 
 def test_ring_and_register_staged_kernels_give_the_same_bits(tmp_path):
-    """Two kernels compute the product (operands streamed into an LDS ring by global_load_lds, K % 32 == 0; or staged through
-    registers, any K % 8 == 0) with two tile shapes each: an output element sees the same MFMAs in the same order in all of
-    them.  `VLMC_GEMM_RING` / `VLMC_GEMM_BIG_TILES` are read once per process, hence the child processes."""
+    """Three kernels compute the product (operands streamed into an LDS ring by global_load_lds, K % 32 == 0, with the two waves
+    of a SIMD in lockstep or half a step apart; or staged through registers, any K % 8 == 0) in two tile shapes: an output
+    element sees the same MFMAs in the same order in all of them.  `VLMC_GEMM_RING` / `VLMC_GEMM_BIG_TILES` /
+    `VLMC_GEMM_PINGPONG` are read once per process, hence the child processes."""
     import os
     import subprocess
     import sys
@@ -232,9 +233,10 @@ for dt, M, N, K in [(torch.bfloat16, 700, 1024, 2048), (torch.float16, 3000, 140
 torch.save(outs, sys.argv[1])
 """
     results = []
-    for ring, big in (("1", "384"), ("0", "384"), ("1", "1"), ("0", "0"), ("1", "0")):
-        out = tmp_path / f"r{ring}_b{big}.pt"
-        env = dict(os.environ, VLMC_GEMM_RING=ring, VLMC_GEMM_BIG_TILES=big)
+    # (ring, tiles needed for the 256 x 256 shape, the two waves of a SIMD half a step apart)
+    for ring, big, pp in (("1", "384", "1"), ("0", "384", "1"), ("1", "1", "1"), ("1", "1", "0"), ("0", "0", "1"), ("1", "0", "1")):
+        out = tmp_path / f"r{ring}_b{big}_p{pp}.pt"
+        env = dict(os.environ, VLMC_GEMM_RING=ring, VLMC_GEMM_BIG_TILES=big, VLMC_GEMM_PINGPONG=pp)
         r = subprocess.run([sys.executable, "-c", code, str(out)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         results.append(torch.load(out))

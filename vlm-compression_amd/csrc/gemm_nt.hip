@@ -366,6 +366,124 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_kernel(const GemmArgs a
     gemm_epilogue<T, EPI, S>(a, acc, p0, q0, wp, wq, lane);
 }
 
+// ---- ring kernel with the two waves of a SIMD half a step apart ------------------------------------------------------
+// An 8-wave workgroup puts waves w and w + 4 on one SIMD.  Run in lockstep (the kernel above) both fetch, both wait and
+// both multiply together: the matrix pipe idles while they fetch.  Here a step is two barrier-separated halves -- L: issue
+// the ring's next loads, read this step's fragments from LDS; M: the step's 32 MFMAs -- and waves 4..7 run one half behind
+// waves 0..3: in every interval between two barriers one wave of each SIMD multiplies while its partner fetches.
+//   interval      I0    I1    I2    I3    I4   ...
+//   waves 0..3    L0    M0    L1    M1    L2
+//   waves 4..7    --    L0    M0    L1    M1
+// Ring discipline (4 slots, step s in slot s & 3): a wave's own pieces of step s have landed (counted vmcnt) before the
+// barrier that opens I(2s), i.e. at the end of M(s-1) for waves 0..3 and of L(s-1) for waves 4..7; the pieces of step s + 3
+// go into the slot of step s - 1 during L(s), after both halves have finished reading it (their reads are waited for,
+// lgkmcnt(0), before the barrier that ends the L they were issued in).  Same MFMAs in the same order per output element.
+template <typename T, int EPI, typename S>
+__global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmArgs a) {
+    constexpr int BP = S::BP, BQ = S::BQ, TP = S::TP, TQ = S::TQ, NW = S::WP * S::WQ;
+    static_assert(NW == 8, "two waves per SIMD");
+    constexpr int P_BYTES = BP * RROW, Q_BYTES = BQ * RROW, SLOT = P_BYTES + Q_BYTES;
+    constexpr int GROUPS = (BP + BQ) / 16, PER_WAVE = GROUPS / NW;
+    static_assert(GROUPS % NW == 0, "whole load instructions per wave");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSLOT * SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool late = wave >= NW / 2;
+    int bp, bq;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
+        int id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+        if constexpr (EPI == EPI_SYRK) {
+            int r = int((__builtin_sqrtf(8.0f * float(id) + 1.0f) - 1.0f) * 0.5f);
+            while ((r + 1) * (r + 2) / 2 <= id) ++r;
+            while (r * (r + 1) / 2 > id) --r;
+            bq = r;
+            bp = id - r * (r + 1) / 2;
+        } else {
+            const int G = 8;
+            const int per_group = G * a.nq_blocks;
+            const int g = id / per_group, in_g = id - g * per_group;
+            const int gp = min(G, a.np_blocks - g * G);
+            bq = in_g / gp;
+            bp = g * G + (in_g - bq * gp);
+        }
+    }
+    const int p0 = bp * BP, q0 = bq * BQ;
+    const uint32_t lds_base = uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)lds));
+    const uint16_t *src[PER_WAVE];
+    uint32_t dst[PER_WAVE];
+#pragma unroll
+    for (int u = 0; u < PER_WAVE; ++u) {
+        const int gidx = wave * PER_WAVE + u;
+        const bool is_q = gidx >= BP / 16;
+        const int g = is_q ? gidx - BP / 16 : gidx;
+        const int r = g * 16 + (lane >> 2);
+        const int sc = (lane & 3) ^ ring_perm(r);
+        const int grow = is_q ? min(q0 + r, a.NQ - 1) : min(p0 + r, a.NP - 1);
+        src[u] = (is_q ? a.Q + int64_t(grow) * a.ldq : a.P + int64_t(grow) * a.ldp) + sc * 8;
+        dst[u] = (is_q ? P_BYTES : 0) + g * 1024;
+    }
+    auto issue = [&](int step) {
+        const uint32_t slot = lds_base + (step & (NSLOT - 1)) * SLOT;
+#pragma unroll
+        for (int u = 0; u < PER_WAVE; ++u) glds16(src[u] + step * RK, slot + dst[u]);
+    };
+    const int nk = a.K / RK;
+    // own pieces of step s landed; the steps after it that have been issued stay in flight
+    auto wait_landed = [&](int s, int issued_upto) {
+        const int later = min(issued_upto, nk - 1) - s;
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto barrier = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+    };
+
+    const int wp = wave / S::WQ, wq = wave % S::WQ;
+    f32x4_t acc[TP][TQ];
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int foff = ring_off(lane & 15, lane >> 4);
+
+    for (int st = 0; st < NSLOT - 1 && st < nk; ++st) issue(st);
+    wait_landed(0, NSLOT - 2);
+    if (late) barrier();                                                  // waves 4..7 sit out I0
+    for (int t = 0; t < nk; ++t) {
+        barrier();
+        // ---- L(t) ----
+        if (t + NSLOT - 1 < nk) issue(t + NSLOT - 1);
+        const unsigned char *tp = lds + (t & (NSLOT - 1)) * SLOT + wp * (TP * 16) * RROW + foff;
+        const unsigned char *tq = lds + (t & (NSLOT - 1)) * SLOT + P_BYTES + wq * (TQ * 16) * RROW + foff;
+        u32x4_t fp[TP], fq[TQ];
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) fq[j] = *reinterpret_cast<const u32x4_t *>(tq + j * 16 * RROW);
+#pragma unroll
+        for (int i = 0; i < TP; ++i) fp[i] = *reinterpret_cast<const u32x4_t *>(tp + i * 16 * RROW);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this wave is done with the slot
+        if (late && t + 1 < nk) wait_landed(t + 1, t + NSLOT - 1);
+        barrier();
+        // ---- M(t) ----
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) acc[i][j] = mfma16<T>(fp[i], fq[j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        if (!late && t + 1 < nk) wait_landed(t + 1, t + NSLOT - 1);
+    }
+    if (!late) barrier();                                                 // waves 4..7 still have M(nk - 1) behind this one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    gemm_epilogue<T, EPI, S>(a, acc, p0, q0, wp, wq, lane);
+}
+
 // launch with the tile shape the problem size asks for
 template <typename T, int EPI, typename S> static void launch_shape(GemmArgs a, int64_t np_rows, int64_t nq_rows, hipStream_t s) {
     a.np_blocks = int((np_rows + S::BP - 1) / S::BP);
@@ -375,6 +493,16 @@ template <typename T, int EPI, typename S> static void launch_shape(GemmArgs a, 
         const char *e = getenv("VLMC_GEMM_RING");                 // 0: the register-staged kernel for every shape
         return !(e && e[0] == '0');
     }();
+    static const bool pingpong = [] {
+        const char *e = getenv("VLMC_GEMM_PINGPONG");             // 0: both waves of a SIMD in lockstep (gemm_nt_ring_kernel)
+        return !(e && e[0] == '0');
+    }();
+    if constexpr (S::WP * S::WQ == 8) {
+        if (ring && pingpong && a.K % RK == 0) {
+            VLMC_LAUNCH_TIMED((gemm_nt_pingpong_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
+            return;
+        }
+    }
     if (ring && a.K % RK == 0) VLMC_LAUNCH_TIMED((gemm_nt_ring_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
     else VLMC_LAUNCH_TIMED((gemm_nt_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
 }
