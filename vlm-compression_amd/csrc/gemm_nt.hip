@@ -16,7 +16,7 @@
 //    `inp.float()` GEMM but its summation order.  fp32 activations are split into three bf16 planes
 //    (x = hi + mid + lo exactly) by the transposing pre-pass and all nine plane products are accumulated.
 //
-// Two tile shapes, picked by the number of tiles (a launch wants >= 2 workgroups per CU of work): 256 (p) x 256 (q) x 64 (k)
+// Two tile shapes, picked by the number of tiles: 256 (p) x 256 (q) x 64 (k)
 // per 512-thread workgroup (wave = 128 x 64: 8 x 4 MFMA tiles, 1/131 B of operand per flop -- a CU takes in ~70 GB/s from
 // L2, which caps 128 x 128 tiles near 0.8 PFLOP/s) and 128 x 128 x 64 per 256 threads (wave = 64 x 64) for the small
 // problems.  An output element is accumulated identically in both (same MFMA shape, same K order): the choice cannot be
@@ -507,12 +507,13 @@ template <typename T, int EPI, typename S> static void launch_shape(GemmArgs a, 
     else VLMC_LAUNCH_TIMED((gemm_nt_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
 }
 template <typename T, int EPI> static void launch_gemm(const GemmArgs &a, hipStream_t s) {
-    // big tiles once they still give every CU two workgroups' worth of tiles (512 on this 256-CU part)
+    // big tiles once there are about as many as CUs (256): measured, 8192 x 2048 x 5120 runs at 1.19 PFLOP/s on 256 big tiles
+    // and 0.78 on 1024 small ones; below that the small shape fills the chip better
     const int64_t bp = (a.NP + ShapeBig::BP - 1) / ShapeBig::BP, bq = (a.NQ + ShapeBig::BQ - 1) / ShapeBig::BQ;
     const int64_t big_tiles = EPI == EPI_SYRK ? bp * (bp + 1) / 2 : bp * bq;
     static const int min_big = [] {
         const char *e = getenv("VLMC_GEMM_BIG_TILES");            // tuning knob: tiles needed to pick 256 x 256 (0 = never)
-        return e ? atoi(e) : 384;
+        return e ? atoi(e) : 200;
     }();
     if (min_big > 0 && big_tiles >= min_big) launch_shape<T, EPI, ShapeBig>(a, a.NP, a.NQ, s);
     else launch_shape<T, EPI, ShapeSmall>(a, a.NP, a.NQ, s);
