@@ -376,8 +376,9 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_kernel(const GemmArgs a
 //   waves 4..7    --    L0    M0    L1    M1
 // Ring discipline (4 slots, step s in slot s & 3): a wave's own pieces of step s have landed (counted vmcnt) before the
 // barrier that opens I(2s), i.e. at the end of M(s-1) for waves 0..3 and of L(s-1) for waves 4..7; the pieces of step s + 3
-// go into the slot of step s - 1 during L(s), after both halves have finished reading it (their reads are waited for,
-// lgkmcnt(0), before the barrier that ends the L they were issued in).  Same MFMAs in the same order per output element.
+// go into the slot of step s - 1 during M(s), between the MFMAs, after both halves have finished reading it (their reads
+// are waited for, lgkmcnt(0), before the barrier that ends the L they were issued in).  Same MFMAs in the same order per
+// output element.
 template <typename T, int EPI, typename S>
 __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmArgs a) {
     constexpr int BP = S::BP, BQ = S::BQ, TP = S::TP, TQ = S::TQ, NW = S::WP * S::WQ;
@@ -424,10 +425,10 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
         src[u] = (is_q ? a.Q + int64_t(grow) * a.ldq : a.P + int64_t(grow) * a.ldp) + sc * 8;
         dst[u] = (is_q ? P_BYTES : 0) + g * 1024;
     }
+    auto issue_piece = [&](int step, int u) { glds16(src[u] + step * RK, lds_base + (step & (NSLOT - 1)) * SLOT + dst[u]); };
     auto issue = [&](int step) {
-        const uint32_t slot = lds_base + (step & (NSLOT - 1)) * SLOT;
 #pragma unroll
-        for (int u = 0; u < PER_WAVE; ++u) glds16(src[u] + step * RK, slot + dst[u]);
+        for (int u = 0; u < PER_WAVE; ++u) issue_piece(step, u);
     };
     const int nk = a.K / RK;
     // own pieces of step s landed; the steps after it that have been issued stay in flight
@@ -457,8 +458,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
     if (late) barrier();                                                  // waves 4..7 sit out I0
     for (int t = 0; t < nk; ++t) {
         barrier();
-        // ---- L(t) ----
-        if (t + NSLOT - 1 < nk) issue(t + NSLOT - 1);
+        // ---- L(t): this step's fragments ----
         const unsigned char *tp = lds + (t & (NSLOT - 1)) * SLOT + wp * (TP * 16) * RROW + foff;
         const unsigned char *tq = lds + (t & (NSLOT - 1)) * SLOT + P_BYTES + wq * (TQ * 16) * RROW + foff;
         u32x4_t fp[TP], fq[TQ];
@@ -467,14 +467,22 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
 #pragma unroll
         for (int i = 0; i < TP; ++i) fp[i] = *reinterpret_cast<const u32x4_t *>(tp + i * 16 * RROW);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this wave is done with the slot
-        if (late && t + 1 < nk) wait_landed(t + 1, t + NSLOT - 1);
+        if (late && t + 1 < nk) wait_landed(t + 1, t + NSLOT - 2);         // (its step t + 3 pieces go out in M(t), below)
         barrier();
-        // ---- M(t) ----
+        // ---- M(t): the MFMAs, with the ring's next loads issued between them (an LDS-DMA instruction costs the issuing
+        // ---- wave ~60 cycles among MFMAs and 100-185 next to other memory instructions: here they hide behind the pipe) --
+        const bool more = t + NSLOT - 1 < nk;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < TP; ++i)
+        for (int i = 0; i < TP; ++i) {
 #pragma unroll
             for (int j = 0; j < TQ; ++j) acc[i][j] = mfma16<T>(fp[i], fq[j], acc[i][j]);
+            if ((i + 1) % (TP / PER_WAVE) == 0 && more) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_piece(t + NSLOT - 1, (i + 1) / (TP / PER_WAVE) - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
         if (!late && t + 1 < nk) wait_landed(t + 1, t + NSLOT - 1);
     }
