@@ -99,38 +99,55 @@ struct GemmArgs {
 __device__ __forceinline__ int lds_off(int row, int ch) { return row * ROW_BYTES + ((ch ^ (row & 7)) << 4); }
 
 // ---- epilogue: lane holds p = pbase + 16 i + 4 (lane >> 4) + r (r = 0..3), q = qbase + 16 j + (lane & 15) ---------------
+// Linear: Y[q][p], p contiguous.  Straight from the accumulators a store instruction would put 8 B into each of 16 rows
+// (32 B per row and instruction: the epilogue of a 256 x 256 tile took about as long as 20 K-steps).  The wave's tile
+// goes through its own piece of the (now idle) LDS instead -- 32 rows of q at a time, rows 16 B longer than the data so
+// the 8-B writes of 16 rows spread over the banks -- and leaves as 16 B per lane, 256 B contiguous per row.
 template <typename T, int EPI, typename S>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4_t (&acc)[S::TP][S::TQ], int p0, int q0, int wp, int wq,
-                                              int lane) {
+                                              int lane, unsigned char *lds, int wave) {
     constexpr int TP = S::TP, TQ = S::TQ;
     const int pl = p0 + wp * (TP * 16) + (lane >> 4) * 4, ql = q0 + wq * (TQ * 16) + (lane & 15);
     if constexpr (EPI == EPI_LINEAR) {
+        constexpr int PW = TP * 16, PITCH = PW * 2 + 16, ROWS = 32, CPR = PW / 8;      // chunks of 16 B per row
+        static_assert(TQ * 16 % ROWS == 0, "whole passes");
+        unsigned char *wl = lds + wave * (ROWS * PITCH);
         const uint16_t *bias = static_cast<const uint16_t *>(a.bias);
-        const bool vec_ok = (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 7u) == 0;
+        const bool vec_ok = (a.ldy & 7) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15u) == 0;
+        float b[TP][4];
 #pragma unroll
-        for (int i = 0; i < TP; ++i) {
-            const int p = pl + i * 16;
-            float b[4] = {0.f, 0.f, 0.f, 0.f};
-            if (bias != nullptr) {
+        for (int i = 0; i < TP; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (p + r < a.NP) b[r] = to_f32<T>(bias[p + r]);
-            }
+            for (int r = 0; r < 4; ++r) b[i][r] = (bias != nullptr && pl + i * 16 + r < a.NP) ? to_f32<T>(bias[pl + i * 16 + r]) : 0.f;
+        __builtin_amdgcn_s_barrier();                                     // every wave is done with the operand ring
 #pragma unroll
-            for (int j = 0; j < TQ; ++j) {
-                const int q = ql + j * 16;
+        for (int pass = 0; pass < TQ * 16 / ROWS; ++pass) {
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int jj = 0; jj < ROWS / 16; ++jj) {
+                    const int j = pass * (ROWS / 16) + jj;
+                    uint16_t o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(bias != nullptr ? acc[i][j][r] + b[i][r] : acc[i][j][r]);
+                    const u32x2_t v = {uint32_t(o[0]) | uint32_t(o[1]) << 16, uint32_t(o[2]) | uint32_t(o[3]) << 16};
+                    *reinterpret_cast<u32x2_t *>(wl + (jj * 16 + (lane & 15)) * PITCH + (i * 16 + (lane >> 4) * 4) * 2) = v;
+                }
+#pragma unroll
+            for (int c = lane; c < ROWS * CPR; c += 64) {
+                const int row = c / CPR, ch = c - row * CPR;
+                const u32x4_t v = *reinterpret_cast<const u32x4_t *>(wl + row * PITCH + ch * 16);
+                const int q = q0 + wq * (TQ * 16) + pass * ROWS + row, p = p0 + wp * PW + ch * 8;
                 if (q >= a.NQ || p >= a.NP) continue;
-                uint16_t o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(bias != nullptr ? acc[i][j][r] + b[r] : acc[i][j][r]);
                 uint16_t *dst = a.Y + int64_t(q) * a.ldy + p;
-                if (vec_ok && p + 3 < a.NP) {
-                    u32x2_t v = {uint32_t(o[0]) | uint32_t(o[1]) << 16, uint32_t(o[2]) | uint32_t(o[3]) << 16};
-                    *reinterpret_cast<u32x2_t *>(dst) = v;
+                if (vec_ok && p + 7 < a.NP) {
+                    *reinterpret_cast<u32x4_t *>(dst) = v;
                 } else {
+                    uint16_t e[8];
+                    __builtin_memcpy(e, &v, 16);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (p + r < a.NP) dst[r] = o[r];
+                    for (int r = 0; r < 8; ++r)
+                        if (p + r < a.NP) dst[r] = e[r];
                 }
             }
         }
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(const GemmArgs a) {
         __syncthreads();
     }
 
-    gemm_epilogue<T, EPI, S>(a, acc, p0, q0, wp, wq, lane);
+    gemm_epilogue<T, EPI, S>(a, acc, p0, q0, wp, wq, lane, lds, wave);
 }
 
 // ---- the same product with operands streamed straight into an LDS ring (global_load_lds, no register staging) ----------
@@ -363,7 +380,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_kernel(const GemmArgs a
         __builtin_amdgcn_s_setprio(0);
     }
 
-    gemm_epilogue<T, EPI, S>(a, acc, p0, q0, wp, wq, lane);
+    gemm_epilogue<T, EPI, S>(a, acc, p0, q0, wp, wq, lane, lds, wave);
 }
 
 // ---- ring kernel with the two waves of a SIMD half a step apart ------------------------------------------------------
@@ -489,7 +506,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
     if (!late) barrier();                                                 // waves 4..7 still have M(nk - 1) behind this one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    gemm_epilogue<T, EPI, S>(a, acc, p0, q0, wp, wq, lane);
+    gemm_epilogue<T, EPI, S>(a, acc, p0, q0, wp, wq, lane, lds, wave);
 }
 
 // launch with the tile shape the problem size asks for
