@@ -393,9 +393,9 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_kernel(const GemmArgs a
 //   waves 4..7    --    L0    M0    L1    M1
 // Ring discipline (4 slots, step s in slot s & 3): a wave's own pieces of step s have landed (counted vmcnt) before the
 // barrier that opens I(2s), i.e. at the end of M(s-1) for waves 0..3 and of L(s-1) for waves 4..7; the pieces of step s + 3
-// go into the slot of step s - 1 during M(s), between the MFMAs, after both halves have finished reading it (their reads
-// are waited for, lgkmcnt(0), before the barrier that ends the L they were issued in).  Same MFMAs in the same order per
-// output element.
+// go into the slot of step s - 1 during L(s) (half of them, behind the fragment reads) and M(s) (the rest, between the
+// MFMAs), after both halves have finished reading it (their reads are waited for, lgkmcnt(0), before the barrier that ends
+// the L they were issued in).  Same MFMAs in the same order per output element.
 template <typename T, int EPI, typename S>
 __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmArgs a) {
     constexpr int BP = S::BP, BQ = S::BQ, TP = S::TP, TQ = S::TQ, NW = S::WP * S::WQ;
@@ -448,11 +448,13 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
         for (int u = 0; u < PER_WAVE; ++u) issue_piece(step, u);
     };
     const int nk = a.K / RK;
-    // own pieces of step s landed; the steps after it that have been issued stay in flight
-    auto wait_landed = [&](int s, int issued_upto) {
-        const int later = min(issued_upto, nk - 1) - s;
-        if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
-        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+    // wait until at most `n` of this wave's loads are outstanding (n = pieces issued after the step that must have landed)
+    auto wait_outstanding = [&](int n) {
+        static_assert(PER_WAVE == 4, "immediates below");
+        if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     auto barrier = [&]() {
@@ -470,8 +472,9 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
         for (int j = 0; j < TQ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int foff = ring_off(lane & 15, lane >> 4);
 
+    constexpr int HALF = PER_WAVE / 2;                                    // pieces issued in L, the rest in M
     for (int st = 0; st < NSLOT - 1 && st < nk; ++st) issue(st);
-    wait_landed(0, NSLOT - 2);
+    wait_outstanding(PER_WAVE * (min(NSLOT - 2, nk - 1)));                 // step 0 has landed
     if (late) barrier();                                                  // waves 4..7 sit out I0
     for (int t = 0; t < nk; ++t) {
         barrier();
@@ -483,25 +486,33 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
         for (int j = 0; j < TQ; ++j) fq[j] = *reinterpret_cast<const u32x4_t *>(tq + j * 16 * RROW);
 #pragma unroll
         for (int i = 0; i < TP; ++i) fp[i] = *reinterpret_cast<const u32x4_t *>(tp + i * 16 * RROW);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this wave is done with the slot
-        if (late && t + 1 < nk) wait_landed(t + 1, t + NSLOT - 2);         // (its step t + 3 pieces go out in M(t), below)
-        barrier();
-        // ---- M(t): the MFMAs, with the ring's next loads issued between them (an LDS-DMA instruction costs the issuing
-        // ---- wave ~60 cycles among MFMAs and 100-185 next to other memory instructions: here they hide behind the pipe) --
+        // half of the ring's next pieces go out here, behind the fragment reads (an LDS-DMA instruction costs its wave
+        // 60-180 cycles of issue: the reads' latency covers two of them), the other half between the MFMAs below
         const bool more = t + NSLOT - 1 < nk;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < HALF; ++u) issue_piece(t + NSLOT - 1, u);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this wave is done with the slot
+        // waves 4..7: step t + 1 must have landed before the next barrier; behind it in the queue are the whole steps up to
+        // t + 2 and the half of step t + 3 just issued
+        if (late && t + 1 < nk) wait_outstanding(PER_WAVE * (min(t + 2, nk - 1) - (t + 1)) + (more ? HALF : 0));
+        barrier();
+        // ---- M(t) ----
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < TP; ++i) {
 #pragma unroll
             for (int j = 0; j < TQ; ++j) acc[i][j] = mfma16<T>(fp[i], fq[j], acc[i][j]);
-            if ((i + 1) % (TP / PER_WAVE) == 0 && more) {
+            if ((i + 1) % (TP / HALF) == 0 && more) {
                 __builtin_amdgcn_sched_barrier(0);
-                issue_piece(t + NSLOT - 1, (i + 1) / (TP / PER_WAVE) - 1);
+                issue_piece(t + NSLOT - 1, HALF + (i + 1) / (TP / HALF) - 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        if (!late && t + 1 < nk) wait_landed(t + 1, t + NSLOT - 1);
+        // waves 0..3: the same for them here (whole steps up to t + 3 are behind step t + 1)
+        if (!late && t + 1 < nk) wait_outstanding(PER_WAVE * (min(t + 3, nk - 1) - (t + 1)));
     }
     if (!late) barrier();                                                 // waves 4..7 still have M(nk - 1) behind this one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
