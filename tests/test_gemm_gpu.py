@@ -222,7 +222,8 @@ sys.path.insert(0, {os.path.join(root, 'vlm-compression_amd')!r})
 from vlmc import ops
 g = torch.Generator(device='cuda:0').manual_seed(11)
 outs = []
-for dt, M, N, K in [(torch.bfloat16, 700, 1024, 2048), (torch.float16, 3000, 1408, 1408), (torch.bfloat16, 64, 5120, 2048)]:
+for dt, M, N, K in [(torch.bfloat16, 700, 1024, 2048), (torch.float16, 3000, 1408, 1408), (torch.bfloat16, 64, 5120, 2048),
+                    (torch.float16, 9000, 4224, 352)]:
     x = (torch.randn(M, K, generator=g, device='cuda:0') * 0.5 + 0.1).to(dt)
     w = (torch.randn(N, K, generator=g, device='cuda:0') * 0.05).to(dt)
     b = (torch.randn(N, generator=g, device='cuda:0') * 0.1).to(dt)
@@ -234,9 +235,11 @@ torch.save(outs, sys.argv[1])
 """
     results = []
     # (ring, tiles needed for the 256 x 256 shape, the two waves of a SIMD half a step apart)
-    for ring, big, pp in (("1", "384", "1"), ("0", "384", "1"), ("1", "1", "1"), ("1", "1", "0"), ("0", "0", "1"), ("1", "0", "1")):
-        out = tmp_path / f"r{ring}_b{big}_p{pp}.pt"
-        env = dict(os.environ, VLMC_GEMM_RING=ring, VLMC_GEMM_BIG_TILES=big, VLMC_GEMM_PINGPONG=pp)
+    # (ring, tiles needed for the 256 x 256 shape, the two waves of a SIMD half a step apart, persistent workgroups)
+    for ring, big, pp, persist in (("1", "200", "1", "1"), ("0", "200", "1", "1"), ("1", "1", "1", "1"), ("1", "1", "1", "0"),
+                                  ("1", "1", "0", "1"), ("0", "0", "1", "1"), ("1", "0", "1", "1")):
+        out = tmp_path / f"r{ring}_b{big}_p{pp}_s{persist}.pt"
+        env = dict(os.environ, VLMC_GEMM_RING=ring, VLMC_GEMM_BIG_TILES=big, VLMC_GEMM_PINGPONG=pp, VLMC_GEMM_PERSIST=persist)
         r = subprocess.run([sys.executable, "-c", code, str(out)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         results.append(torch.load(out))

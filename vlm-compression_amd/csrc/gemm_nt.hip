@@ -101,16 +101,16 @@ __device__ __forceinline__ int lds_off(int row, int ch) { return row * ROW_BYTES
 // ---- epilogue: lane holds p = pbase + 16 i + 4 (lane >> 4) + r (r = 0..3), q = qbase + 16 j + (lane & 15) ---------------
 // Linear: Y[q][p], p contiguous.  Straight from the accumulators a store instruction would put 8 B into each of 16 rows
 // (32 B per row and instruction: the epilogue of a 256 x 256 tile took about as long as 20 K-steps).  The wave's tile
-// goes through its own piece of the (now idle) LDS instead -- 32 rows of q at a time, rows 16 B longer than the data so
-// the 8-B writes of 16 rows spread over the banks -- and leaves as 16 B per lane, 256 B contiguous per row.
-template <typename T, int EPI, typename S>
+// goes through its own piece of the (now idle) LDS instead -- 16 or 32 rows of q at a time, the 16-B chunk index XOR-ed with
+// the row so the 8-B writes of 16 rows spread over the banks -- and leaves as 16 B per lane, 256 B contiguous per row.
+template <typename T, int EPI, typename S, int ROWS = 32, bool BARRIER = true>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4_t (&acc)[S::TP][S::TQ], int p0, int q0, int wp, int wq,
                                               int lane, unsigned char *lds, int wave) {
     constexpr int TP = S::TP, TQ = S::TQ;
     const int pl = p0 + wp * (TP * 16) + (lane >> 4) * 4, ql = q0 + wq * (TQ * 16) + (lane & 15);
     if constexpr (EPI == EPI_LINEAR) {
-        constexpr int PW = TP * 16, PITCH = PW * 2 + 16, ROWS = 32, CPR = PW / 8;      // chunks of 16 B per row
-        static_assert(TQ * 16 % ROWS == 0, "whole passes");
+        constexpr int PW = TP * 16, PITCH = PW * 2, CPR = PW / 8;     // 16-B chunks per row; chunk index XOR-ed with the row
+        static_assert(TQ * 16 % ROWS == 0 && ROWS % 16 == 0, "whole passes of whole MFMA tiles");
         unsigned char *wl = lds + wave * (ROWS * PITCH);
         const uint16_t *bias = static_cast<const uint16_t *>(a.bias);
         const bool vec_ok = (a.ldy & 7) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15u) == 0;
@@ -119,7 +119,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4_t (&acc)[
         for (int i = 0; i < TP; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) b[i][r] = (bias != nullptr && pl + i * 16 + r < a.NP) ? to_f32<T>(bias[pl + i * 16 + r]) : 0.f;
-        __builtin_amdgcn_s_barrier();                                     // every wave is done with the operand ring
+        if constexpr (BARRIER) __builtin_amdgcn_s_barrier();              // every wave is done with the operand ring
 #pragma unroll
         for (int pass = 0; pass < TQ * 16 / ROWS; ++pass) {
 #pragma unroll
@@ -131,12 +131,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4_t (&acc)[
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(bias != nullptr ? acc[i][j][r] + b[i][r] : acc[i][j][r]);
                     const u32x2_t v = {uint32_t(o[0]) | uint32_t(o[1]) << 16, uint32_t(o[2]) | uint32_t(o[3]) << 16};
-                    *reinterpret_cast<u32x2_t *>(wl + (jj * 16 + (lane & 15)) * PITCH + (i * 16 + (lane >> 4) * 4) * 2) = v;
+                    const int row = jj * 16 + (lane & 15), chunk = i * 2 + (lane >> 5), half = (lane >> 4) & 1;
+                    *reinterpret_cast<u32x2_t *>(wl + row * PITCH + ((chunk ^ (row & (CPR - 1))) << 4) + half * 8) = v;
                 }
 #pragma unroll
             for (int c = lane; c < ROWS * CPR; c += 64) {
                 const int row = c / CPR, ch = c - row * CPR;
-                const u32x4_t v = *reinterpret_cast<const u32x4_t *>(wl + row * PITCH + ch * 16);
+                const u32x4_t v = *reinterpret_cast<const u32x4_t *>(wl + row * PITCH + ((ch ^ (row & (CPR - 1))) << 4));
                 const int q = q0 + wq * (TQ * 16) + pass * ROWS + row, p = p0 + wp * PW + ch * 8;
                 if (q >= a.NQ || p >= a.NP) continue;
                 uint16_t *dst = a.Y + int64_t(q) * a.ldy + p;
@@ -397,21 +398,30 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_kernel(const GemmArgs a
 // MFMAs), after both halves have finished reading it (their reads are waited for, lgkmcnt(0), before the barrier that ends
 // the L they were issued in).  Same MFMAs in the same order per output element.
 template <typename T, int EPI, typename S>
-__global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmArgs a, const int ntiles) {
     constexpr int BP = S::BP, BQ = S::BQ, TP = S::TP, TQ = S::TQ, NW = S::WP * S::WQ;
     static_assert(NW == 8, "two waves per SIMD");
     constexpr int P_BYTES = BP * RROW, Q_BYTES = BQ * RROW, SLOT = P_BYTES + Q_BYTES;
     constexpr int GROUPS = (BP + BQ) / 16, PER_WAVE = GROUPS / NW;
     static_assert(GROUPS % NW == 0, "whole load instructions per wave");
+    constexpr int HALF = PER_WAVE / 2;                                    // pieces issued in L, the rest in M
+    constexpr int EPI_ROWS = 16;                                          // epilogue scratch: 16 rows x 8 waves = one ring slot
+    static_assert(EPI != EPI_LINEAR || NW * EPI_ROWS * (TP * 16) * 2 <= SLOT, "the epilogue's scratch is the ring's last slot");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NSLOT * SLOT];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool late = wave >= NW / 2;
-    int bp, bq;
-    {
-        const int nwg = gridDim.x, orig = blockIdx.x;
-        const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
-        int id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+    const uint32_t lds_base = uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)lds));   // LDS byte address
+
+    // ---- persistent: this workgroup's tiles.  Workgroups b, b + 8, .. share an XCD's L2 and take a contiguous run of tile
+    // ---- ids between them (run x: ids [start(x), start(x) + size(x))), each its every nx-th ----------------------------
+    const int G = gridDim.x, xcd = blockIdx.x & 7, lx = blockIdx.x >> 3;
+    const int tq8 = ntiles >> 3, tr8 = ntiles & 7;
+    const int run_start = xcd < tr8 ? xcd * (tq8 + 1) : tr8 * (tq8 + 1) + (xcd - tr8) * tq8;
+    const int run_end = run_start + (xcd < tr8 ? tq8 + 1 : tq8);
+    const int nx = (G - xcd + 7) >> 3;                                    // workgroups with this XCD label
+    auto tile_origin = [&](int id, int &p0, int &q0) {
+        int bp, bq;
         if constexpr (EPI == EPI_SYRK) {
             int r = int((__builtin_sqrtf(8.0f * float(id) + 1.0f) - 1.0f) * 0.5f);
             while ((r + 1) * (r + 2) / 2 <= id) ++r;
@@ -419,36 +429,40 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
             bq = r;
             bp = id - r * (r + 1) / 2;
         } else {
-            const int G = 8;
-            const int per_group = G * a.nq_blocks;
+            const int Gp = 8;
+            const int per_group = Gp * a.nq_blocks;
             const int g = id / per_group, in_g = id - g * per_group;
-            const int gp = min(G, a.np_blocks - g * G);
+            const int gp = min(Gp, a.np_blocks - g * Gp);
             bq = in_g / gp;
-            bp = g * G + (in_g - bq * gp);
+            bp = g * Gp + (in_g - bq * gp);
         }
-    }
-    const int p0 = bp * BP, q0 = bq * BQ;
-    const uint32_t lds_base = uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)lds));
-    const uint16_t *src[PER_WAVE];
-    uint32_t dst[PER_WAVE];
+        p0 = bp * BP;
+        q0 = bq * BQ;
+    };
+    uint32_t dst[PER_WAVE];                                               // wave-uniform LDS byte offset inside a slot
+    bool piece_q[PER_WAVE];
+    int piece_row[PER_WAVE], piece_sc[PER_WAVE];
 #pragma unroll
     for (int u = 0; u < PER_WAVE; ++u) {
-        const int gidx = wave * PER_WAVE + u;
-        const bool is_q = gidx >= BP / 16;
-        const int g = is_q ? gidx - BP / 16 : gidx;
-        const int r = g * 16 + (lane >> 2);
-        const int sc = (lane & 3) ^ ring_perm(r);
-        const int grow = is_q ? min(q0 + r, a.NQ - 1) : min(p0 + r, a.NP - 1);
-        src[u] = (is_q ? a.Q + int64_t(grow) * a.ldq : a.P + int64_t(grow) * a.ldp) + sc * 8;
-        dst[u] = (is_q ? P_BYTES : 0) + g * 1024;
+        const int gidx = wave * PER_WAVE + u;                             // 16-row group of the step's [P | Q] image
+        piece_q[u] = gidx >= BP / 16;
+        const int g = piece_q[u] ? gidx - BP / 16 : gidx;
+        piece_row[u] = g * 16 + (lane >> 2);                              // tile row
+        piece_sc[u] = (lane & 3) ^ ring_perm(piece_row[u]);               // source chunk that belongs at LDS chunk (lane & 3)
+        dst[u] = (piece_q[u] ? P_BYTES : 0) + g * 1024;
     }
-    auto issue_piece = [&](int step, int u) { glds16(src[u] + step * RK, lds_base + (step & (NSLOT - 1)) * SLOT + dst[u]); };
-    auto issue = [&](int step) {
+    const uint16_t *src[PER_WAVE];
+    auto tile_sources = [&](int p0, int q0, const uint16_t *(&out)[PER_WAVE]) {
 #pragma unroll
-        for (int u = 0; u < PER_WAVE; ++u) issue_piece(step, u);
+        for (int u = 0; u < PER_WAVE; ++u) {
+            const int grow = piece_q[u] ? min(q0 + piece_row[u], a.NQ - 1) : min(p0 + piece_row[u], a.NP - 1);
+            out[u] = (piece_q[u] ? a.Q + int64_t(grow) * a.ldq : a.P + int64_t(grow) * a.ldp) + piece_sc[u] * 8;
+        }
     };
+    auto issue_piece = [&](int step, int u) { glds16(src[u] + step * RK, lds_base + (step & (NSLOT - 1)) * SLOT + dst[u]); };
     const int nk = a.K / RK;
-    // wait until at most `n` of this wave's loads are outstanding (n = pieces issued after the step that must have landed)
+    // wait until at most `n` of this wave's memory operations are outstanding (n = ring pieces issued after the step that
+    // must have landed; an epilogue's stores in between only make the wait more conservative)
     auto wait_outstanding = [&](int n) {
         static_assert(PER_WAVE == 4, "immediates below");
         if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -463,61 +477,85 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");
     };
-
     const int wp = wave / S::WQ, wq = wave % S::WQ;
-    f32x4_t acc[TP][TQ];
-#pragma unroll
-    for (int i = 0; i < TP; ++i)
-#pragma unroll
-        for (int j = 0; j < TQ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int foff = ring_off(lane & 15, lane >> 4);
 
-    constexpr int HALF = PER_WAVE / 2;                                    // pieces issued in L, the rest in M
-    for (int st = 0; st < NSLOT - 1 && st < nk; ++st) issue(st);
-    wait_outstanding(PER_WAVE * (min(NSLOT - 2, nk - 1)));                 // step 0 has landed
-    if (late) barrier();                                                  // waves 4..7 sit out I0
-    for (int t = 0; t < nk; ++t) {
-        barrier();
-        // ---- L(t): this step's fragments ----
-        const unsigned char *tp = lds + (t & (NSLOT - 1)) * SLOT + wp * (TP * 16) * RROW + foff;
-        const unsigned char *tq = lds + (t & (NSLOT - 1)) * SLOT + P_BYTES + wq * (TQ * 16) * RROW + foff;
-        u32x4_t fp[TP], fq[TQ];
+    int id = run_start + lx;
+    if (id >= run_end) return;                                            // (whole workgroup: no barrier is left waiting)
+    int p0, q0;
+    tile_origin(id, p0, q0);
+    tile_sources(p0, q0, src);
+    for (int st = 0; st < NSLOT - 1 && st < nk; ++st) {
 #pragma unroll
-        for (int j = 0; j < TQ; ++j) fq[j] = *reinterpret_cast<const u32x4_t *>(tq + j * 16 * RROW);
+        for (int u = 0; u < PER_WAVE; ++u) issue_piece(st, u);
+    }
+    for (;;) {
+        f32x4_t acc[TP][TQ];
 #pragma unroll
-        for (int i = 0; i < TP; ++i) fp[i] = *reinterpret_cast<const u32x4_t *>(tp + i * 16 * RROW);
-        // half of the ring's next pieces go out here, behind the fragment reads (an LDS-DMA instruction costs its wave
-        // 60-180 cycles of issue: the reads' latency covers two of them), the other half between the MFMAs below
-        const bool more = t + NSLOT - 1 < nk;
-        if (more) {
+        for (int i = 0; i < TP; ++i)
 #pragma unroll
-            for (int u = 0; u < HALF; ++u) issue_piece(t + NSLOT - 1, u);
+            for (int j = 0; j < TQ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        wait_outstanding(PER_WAVE * (min(NSLOT - 2, nk - 1)));             // step 0 has landed
+        if (late) barrier();                                              // waves 4..7 sit out I0
+        for (int t = 0; t < nk; ++t) {
+            barrier();
+            // ---- L(t): this step's fragments ----
+            const unsigned char *tp = lds + (t & (NSLOT - 1)) * SLOT + wp * (TP * 16) * RROW + foff;
+            const unsigned char *tq = lds + (t & (NSLOT - 1)) * SLOT + P_BYTES + wq * (TQ * 16) * RROW + foff;
+            u32x4_t fp[TP], fq[TQ];
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) fq[j] = *reinterpret_cast<const u32x4_t *>(tq + j * 16 * RROW);
+#pragma unroll
+            for (int i = 0; i < TP; ++i) fp[i] = *reinterpret_cast<const u32x4_t *>(tp + i * 16 * RROW);
+            // half of the ring's next pieces go out here, behind the fragment reads (an LDS-DMA instruction costs its wave
+            // 60-180 cycles of issue: the reads' latency covers two of them), the other half between the MFMAs below
+            const bool more = t + NSLOT - 1 < nk;
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < HALF; ++u) issue_piece(t + NSLOT - 1, u);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this wave is done with the slot
+            // waves 4..7: step t + 1 must have landed before the next barrier; behind it in the queue are the whole steps up
+            // to t + 2 and the half of step t + 3 just issued
+            if (late && t + 1 < nk) wait_outstanding(PER_WAVE * (min(t + 2, nk - 1) - (t + 1)) + (more ? HALF : 0));
+            barrier();
+            // ---- M(t) ----
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TP; ++i) {
+#pragma unroll
+                for (int j = 0; j < TQ; ++j) acc[i][j] = mfma16<T>(fp[i], fq[j], acc[i][j]);
+                if ((i + 1) % (TP / HALF) == 0 && more) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_piece(t + NSLOT - 1, HALF + (i + 1) / (TP / HALF) - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            // waves 0..3: the same for them here (whole steps up to t + 3 are behind step t + 1)
+            if (!late && t + 1 < nk) wait_outstanding(PER_WAVE * (min(t + 3, nk - 1) - (t + 1)));
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this wave is done with the slot
-        // waves 4..7: step t + 1 must have landed before the next barrier; behind it in the queue are the whole steps up to
-        // t + 2 and the half of step t + 3 just issued
-        if (late && t + 1 < nk) wait_outstanding(PER_WAVE * (min(t + 2, nk - 1) - (t + 1)) + (more ? HALF : 0));
-        barrier();
-        // ---- M(t) ----
-        __builtin_amdgcn_s_setprio(1);
+        if (!late) barrier();                                             // waves 4..7 still have M(nk - 1) behind this one
+        // ---- every wave has left its last L: the ring is free.  The next tile's first steps go out BEFORE this tile's
+        // ---- epilogue (its stores and the workgroup's restart then overlap the loads' way through the memory system) -----
+        const int next = id + nx;
+        const bool has_next = next < run_end;
+        const int cp0 = p0, cq0 = q0;
+        if (has_next) {
+            id = next;
+            tile_origin(id, p0, q0);
+            tile_sources(p0, q0, src);
+            for (int st = 0; st < NSLOT - 1 && st < nk; ++st) {
 #pragma unroll
-        for (int i = 0; i < TP; ++i) {
-#pragma unroll
-            for (int j = 0; j < TQ; ++j) acc[i][j] = mfma16<T>(fp[i], fq[j], acc[i][j]);
-            if ((i + 1) % (TP / HALF) == 0 && more) {
-                __builtin_amdgcn_sched_barrier(0);
-                issue_piece(t + NSLOT - 1, HALF + (i + 1) / (TP / HALF) - 1);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int u = 0; u < PER_WAVE; ++u) issue_piece(st, u);
             }
         }
-        __builtin_amdgcn_s_setprio(0);
-        // waves 0..3: the same for them here (whole steps up to t + 3 are behind step t + 1)
-        if (!late && t + 1 < nk) wait_outstanding(PER_WAVE * (min(t + 3, nk - 1) - (t + 1)));
+        // (the linear epilogue's scratch is the ring's LAST slot: the next tile touches it in its L(0), behind a barrier that
+        // every wave reaches after its own epilogue)
+        gemm_epilogue<T, EPI, S, EPI_ROWS, false>(a, acc, cp0, cq0, wp, wq, lane, lds + (NSLOT - 1) * SLOT, wave);
+        if (!has_next) break;
     }
-    if (!late) barrier();                                                 // waves 4..7 still have M(nk - 1) behind this one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    gemm_epilogue<T, EPI, S>(a, acc, p0, q0, wp, wq, lane, lds, wave);
 }
 
 // launch with the tile shape the problem size asks for
@@ -535,7 +573,16 @@ template <typename T, int EPI, typename S> static void launch_shape(GemmArgs a, 
     }();
     if constexpr (S::WP * S::WQ == 8) {
         if (ring && pingpong && a.K % RK == 0) {
-            VLMC_LAUNCH_TIMED((gemm_nt_pingpong_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
+            // persistent: one workgroup per CU walks its share of the tiles
+            static const int n_cu = [] {
+                int dev = 0, n = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+                    n = 256;
+                const char *e = getenv("VLMC_GEMM_PERSIST");     // 0: one workgroup per tile
+                return (e && e[0] == '0') ? (1 << 30) : n;
+            }();
+            const unsigned grid = unsigned(nblocks < n_cu ? nblocks : n_cu);
+            VLMC_LAUNCH_TIMED((gemm_nt_pingpong_kernel<T, EPI, S>), dim3(grid), dim3(S::NT), s, a, int(nblocks));
             return;
         }
     }
