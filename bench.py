@@ -519,7 +519,7 @@ def main():
                     bytes_per_launch=round(units / max(1, n)))
 
     rows = [roof("gemm", "vlmc::gemm_nt_kernel (vlmc_linear_fwd: the dense calibration forward of the blocks' linears on "
-                         "v_mfma_f32_16x16x32, batch-invariant; algorithmic flops = 2 M N K)", "gemm_nt_kernel_bytes_per_launch", "mfma"),
+                         "v_mfma_f32_16x16x32, batch-invariant; algorithmic flops = 2 M N K)", "gemm_nt_bytes_per_launch", "mfma"),
             roof("stat", "vlmc::act_sqnorm_kernel (per-sample squared column norms of every distinct linear input of a block; one "
                          "launch per group of calibration samples)", "act_sqnorm_kernel_bytes_per_launch"),
             roof("rows", "vlmc::select_rows_mixed_kernel (score+select+apply, per-row rule; all linears of a T5 block in one "
