@@ -1126,15 +1126,28 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                 else:
                     b0 = cur_in[chunk[0]].shape[0]
                     _STACKED = (len(chunk), b0, tuple(chunk))
+                    key = tuple(chunk)
+                    # the group's inputs are usually the slices of ONE tensor -- the previous pass's stacked output -- and the
+                    # cached kwargs are the same for every block of the tower: neither needs concatenating again
+                    prev = getattr(cur_in[chunk[0]], "_vlmc_stack", None)
+                    if prev is not None and prev[1] == key and all(cur_in[j] is prev[2][t] for t, j in enumerate(chunk)):
+                        x = prev[0]
+                    else:
+                        x = torch.cat([cur_in[j] for j in chunk], dim=0)
+                    kw = stacked_kwargs.get(key)
+                    if kw is None:
+                        kw = stacked_kwargs[key] = _stack_caches([caches[j] for j in chunk])
                     try:
-                        y = layer(torch.cat([cur_in[j] for j in chunk], dim=0), **_stack_caches([caches[j] for j in chunk]))
+                        y = layer(x, **kw)
                     finally:
                         _STACKED = None
                     y = y[0] if tuple_output else y
+                    slices = [y[t * b0:(t + 1) * b0] for t in range(len(chunk))]
+                    slices[0]._vlmc_stack = (y, key, slices)
                     for t, j in enumerate(chunk):
-                        cur_out[j] = y[t * b0:(t + 1) * b0]
+                        cur_out[j] = slices[t]
 
-    graphs, plan = {}, {}
+    graphs, plan, stacked_kwargs = {}, {}, {}
     for i in range(len(layers)):
         layer = layers[i]
         subset = find_layers(layer)
