@@ -459,7 +459,16 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
             out[u] = (piece_q[u] ? a.Q + int64_t(grow) * a.ldq : a.P + int64_t(grow) * a.ldp) + piece_sc[u] * 8;
         }
     };
-    auto issue_piece = [&](int step, int u) { glds16(src[u] + step * RK, lds_base + (step & (NSLOT - 1)) * SLOT + dst[u]); };
+#ifndef VLMC_GEMM_DBG
+#define VLMC_GEMM_DBG 0              // diagnostic builds only (tools/gemm_ablate.sh): 1 no ring loads after the first steps,
+#endif                               // 2 no fragment reads, 4 no MFMAs -- results are garbage, only the pace is of interest
+    auto issue_piece = [&](int step, int u) {
+        if ((VLMC_GEMM_DBG & 1) && step >= NSLOT - 1) {
+            asm volatile("s_nop 0" ::: "memory");
+            return;
+        }
+        glds16(src[u] + step * RK, lds_base + (step & (NSLOT - 1)) * SLOT + dst[u]);
+    };
     const int nk = a.K / RK;
     // wait until at most `n` of this wave's memory operations are outstanding (n = ring pieces issued after the step that
     // must have landed; an epilogue's stores in between only make the wait more conservative)
@@ -503,10 +512,17 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
             const unsigned char *tp = lds + (t & (NSLOT - 1)) * SLOT + wp * (TP * 16) * RROW + foff;
             const unsigned char *tq = lds + (t & (NSLOT - 1)) * SLOT + P_BYTES + wq * (TQ * 16) * RROW + foff;
             u32x4_t fp[TP], fq[TQ];
+            if ((VLMC_GEMM_DBG & 2) && t > 0) {
 #pragma unroll
-            for (int j = 0; j < TQ; ++j) fq[j] = *reinterpret_cast<const u32x4_t *>(tq + j * 16 * RROW);
+                for (int j = 0; j < TQ; ++j) asm volatile("" : "=v"(fq[j]));
 #pragma unroll
-            for (int i = 0; i < TP; ++i) fp[i] = *reinterpret_cast<const u32x4_t *>(tp + i * 16 * RROW);
+                for (int i = 0; i < TP; ++i) asm volatile("" : "=v"(fp[i]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < TQ; ++j) fq[j] = *reinterpret_cast<const u32x4_t *>(tq + j * 16 * RROW);
+#pragma unroll
+                for (int i = 0; i < TP; ++i) fp[i] = *reinterpret_cast<const u32x4_t *>(tp + i * 16 * RROW);
+            }
             // half of the ring's next pieces go out here, behind the fragment reads (an LDS-DMA instruction costs its wave
             // 60-180 cycles of issue: the reads' latency covers two of them), the other half between the MFMAs below
             const bool more = t + NSLOT - 1 < nk;
@@ -524,7 +540,10 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
 #pragma unroll
             for (int i = 0; i < TP; ++i) {
 #pragma unroll
-                for (int j = 0; j < TQ; ++j) acc[i][j] = mfma16<T>(fp[i], fq[j], acc[i][j]);
+                for (int j = 0; j < TQ; ++j) {
+                    if (VLMC_GEMM_DBG & 4) asm volatile("" : "+v"(acc[i][j]) : "v"(fp[i]), "v"(fq[j]));
+                    else acc[i][j] = mfma16<T>(fp[i], fq[j], acc[i][j]);
+                }
                 if ((i + 1) % (TP / HALF) == 0 && more) {
                     __builtin_amdgcn_sched_barrier(0);
                     issue_piece(t + NSLOT - 1, HALF + (i + 1) / (TP / HALF) - 1);
