@@ -28,6 +28,7 @@
 #include "common.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace vlmc {
 
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
     };
 #ifndef VLMC_GEMM_DBG
 #define VLMC_GEMM_DBG 0              // diagnostic builds only (tools/gemm_ablate.sh): 1 no ring loads after the first steps,
-#endif                               // 2 no fragment reads, 4 no MFMAs -- results are garbage, only the pace is of interest
+#endif                               // 2 no fragment reads, 4 no MFMAs, 8 no epilogue -- results are garbage, only the pace is of interest
     auto issue_piece = [&](int step, int u) {
         if ((VLMC_GEMM_DBG & 1) && step >= NSLOT - 1) {
             asm volatile("s_nop 0" ::: "memory");
@@ -505,8 +506,12 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
 #pragma unroll
             for (int j = 0; j < TQ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         wait_outstanding(PER_WAVE * (min(NSLOT - 2, nk - 1)));             // step 0 has landed
-        if (late) barrier();                                              // waves 4..7 sit out I0
-        for (int t = 0; t < nk; ++t) {
+        // One K-step.  STEADY: at least three more steps follow (the ring's next pieces go out, the waits are the constants
+        // vmcnt(8) / vmcnt(6)); otherwise the tail's bookkeeping.  LATE: waves 4..7.  Both are compile-time so that the
+        // steady-state loop carries no scalar branching: the bare skeleton of a step (two barriers and their bookkeeping)
+        // measured 276 cycles per barrier with the bookkeeping branched at run time -- half of an MFMA half-step.
+        auto kstep = [&](auto steady_c, auto late_c, const int t) {
+            constexpr bool STEADY = decltype(steady_c)::value, LATE = decltype(late_c)::value;
             barrier();
             // ---- L(t): this step's fragments ----
             const unsigned char *tp = lds + (t & (NSLOT - 1)) * SLOT + wp * (TP * 16) * RROW + foff;
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
             }
             // half of the ring's next pieces go out here, behind the fragment reads (an LDS-DMA instruction costs its wave
             // 60-180 cycles of issue: the reads' latency covers two of them), the other half between the MFMAs below
-            const bool more = t + NSLOT - 1 < nk;
+            const bool more = STEADY || t + NSLOT - 1 < nk;
             if (more) {
 #pragma unroll
                 for (int u = 0; u < HALF; ++u) issue_piece(t + NSLOT - 1, u);
@@ -533,7 +538,10 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this wave is done with the slot
             // waves 4..7: step t + 1 must have landed before the next barrier; behind it in the queue are the whole steps up
             // to t + 2 and the half of step t + 3 just issued
-            if (late && t + 1 < nk) wait_outstanding(PER_WAVE * (min(t + 2, nk - 1) - (t + 1)) + (more ? HALF : 0));
+            if constexpr (LATE) {
+                if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE + HALF) : "memory");
+                else if (t + 1 < nk) wait_outstanding(PER_WAVE * (min(t + 2, nk - 1) - (t + 1)) + (more ? HALF : 0));
+            }
             barrier();
             // ---- M(t) ----
             __builtin_amdgcn_s_setprio(1);
@@ -552,7 +560,21 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
             }
             __builtin_amdgcn_s_setprio(0);
             // waves 0..3: the same for them here (whole steps up to t + 3 are behind step t + 1)
-            if (!late && t + 1 < nk) wait_outstanding(PER_WAVE * (min(t + 3, nk - 1) - (t + 1)));
+            if constexpr (!LATE) {
+                if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
+                else if (t + 1 < nk) wait_outstanding(PER_WAVE * (min(t + 3, nk - 1) - (t + 1)));
+            }
+        };
+        auto ksweep = [&](auto late_c) {
+            int t = 0;
+            for (; t + NSLOT - 1 < nk; ++t) kstep(std::true_type{}, late_c, t);
+            for (; t < nk; ++t) kstep(std::false_type{}, late_c, t);
+        };
+        if (late) {
+            barrier();                                                    // waves 4..7 sit out I0
+            ksweep(std::true_type{});
+        } else {
+            ksweep(std::false_type{});
         }
         if (!late) barrier();                                             // waves 4..7 still have M(nk - 1) behind this one
         // ---- every wave has left its last L: the ring is free.  The next tile's first steps go out BEFORE this tile's
@@ -571,7 +593,14 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
         }
         // (the linear epilogue's scratch is the ring's LAST slot: the next tile touches it in its L(0), behind a barrier that
         // every wave reaches after its own epilogue)
-        gemm_epilogue<T, EPI, S, EPI_ROWS, false>(a, acc, cp0, cq0, wp, wq, lane, lds + (NSLOT - 1) * SLOT, wave);
+        if (VLMC_GEMM_DBG & 8) {
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int j = 0; j < TQ; ++j) asm volatile("" ::"v"(acc[i][j]));
+        } else {
+            gemm_epilogue<T, EPI, S, EPI_ROWS, false>(a, acc, cp0, cq0, wp, wq, lane, lds + (NSLOT - 1) * SLOT, wave);
+        }
         if (!has_next) break;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
