@@ -360,13 +360,19 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_kernel(const GemmArgs a
 
     const int nk = a.K / RK;
     for (int st = 0; st < NSLOT - 1 && st < nk; ++st) issue(st);
-    for (int t = 0; t < nk; ++t) {
-        const int rem = nk - 1 - t;
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (STEADY: at least three more steps follow -- constant wait, unconditional issue: no scalar branching in the loop)
+    auto kstep = [&](auto steady_c, const int t) {
+        constexpr bool STEADY = decltype(steady_c)::value;
+        if constexpr (STEADY) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
+        } else {
+            const int rem = nk - 1 - t;
+            if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();                                     // step t has landed for every wave; slot t - 1 is free
-        if (t + NSLOT - 1 < nk) issue(t + NSLOT - 1);
+        if (STEADY || t + NSLOT - 1 < nk) issue(t + NSLOT - 1);
         const unsigned char *tp = lds + (t & (NSLOT - 1)) * SLOT + wp * (TP * 16) * RROW + foff;
         const unsigned char *tq = lds + (t & (NSLOT - 1)) * SLOT + P_BYTES + wq * (TQ * 16) * RROW + foff;
         u32x4_t fp[TP], fq[TQ];
@@ -380,6 +386,11 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_kernel(const GemmArgs a
 #pragma unroll
             for (int j = 0; j < TQ; ++j) acc[i][j] = mfma16<T>(fp[i], fq[j], acc[i][j]);
         __builtin_amdgcn_s_setprio(0);
+    };
+    {
+        int t = 0;
+        for (; t + NSLOT - 1 < nk; ++t) kstep(std::true_type{}, t);
+        for (; t < nk; ++t) kstep(std::false_type{}, t);
     }
 
     gemm_epilogue<T, EPI, S>(a, acc, p0, q0, wp, wq, lane, lds, wave);
