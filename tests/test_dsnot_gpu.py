@@ -93,7 +93,7 @@ def test_lora_mode_and_zero_ratio():
 
 
 # ---- list-based fast path vs the per-cycle reference kernel: identical events -------------------------
-def _refine_events(W, st, keep, n, m, mc, thr, lists, without_same_sign=1, wanda_init=1, pow_var=1.0):
+def _refine_events(W, st, keep, n, m, mc, thr, lists, without_same_sign=1, wanda_init=1, pow_var=1.0, radix_only=False):
     import os
     from vlmc import _lib
     from vlmc.ops import _dtype_code, _stream
@@ -101,6 +101,7 @@ def _refine_events(W, st, keep, n, m, mc, thr, lists, without_same_sign=1, wanda
     events = torch.zeros((out_f, mc), dtype=torch.int32, device=DEV)
     stop = torch.zeros(out_f, dtype=torch.int32, device=DEV)
     os.environ["VLMC_DSNOT_LISTS"] = "1" if lists else "0"
+    os.environ["VLMC_DSNOT_RADIX_ONLY"] = "1" if radix_only else "0"
     try:
         _lib.check(_lib.load().vlmc_dsnot_refine(W.data_ptr(), _dtype_code(W), out_f, in_f, W.stride(0), keep.data_ptr(),
                                                  st.sqrt_row.data_ptr(), st.sum_row.data_ptr(), st.var_row.data_ptr(), wanda_init,
@@ -108,6 +109,7 @@ def _refine_events(W, st, keep, n, m, mc, thr, lists, without_same_sign=1, wanda
                                                  _stream()))
     finally:
         os.environ.pop("VLMC_DSNOT_LISTS", None)
+        os.environ.pop("VLMC_DSNOT_RADIX_ONLY", None)
     torch.cuda.synchronize()
     return events.cpu(), stop.cpu()
 
@@ -142,6 +144,44 @@ def test_list_kernel_emits_the_same_events_as_the_cycle_kernel(shape, nm, dtype)
         assert torch.equal(stop_old, stop_new), (thr, wss)
         bad = (ev_old != ev_new).nonzero()
         assert bad.numel() == 0, (thr, wss, bad[:5].tolist(), ev_old[bad[0][0], bad[0][1]].item(), ev_new[bad[0][0], bad[0][1]].item())
+        # the list heads by the exact radix route alone (the counting-sort route's fallback for heavy ties)
+        ev_rdx, stop_rdx = _refine_events(Wd, st, keep, n, m, mc, thr, lists=True, without_same_sign=wss, radix_only=True)
+        assert torch.equal(stop_old, stop_rdx) and torch.equal(ev_old, ev_rdx), (thr, wss)
+
+
+@pytest.mark.parametrize("case", ["constant_rows", "few_values", "nan_inf", "one_outlier"])
+@pytest.mark.parametrize("in_f", [1408, 4096])
+def test_list_heads_with_degenerate_keys(case, in_f):
+    """Inputs that defeat the counting sort's bins (one value everywhere, a handful of values, NaN / Inf keys stretching the
+    key range, one huge outlier squeezing everything else into one bin) take the radix route: same events as the per-cycle
+    kernel either way."""
+    from vlmc import dsnot, ops
+    g = torch.Generator().manual_seed(in_f)
+    out_f = 12
+    W = (torch.randn(out_f, in_f, generator=g) * 0.02).half()
+    if case == "constant_rows":
+        W[:] = 0.0123
+        W[1::2] = -0.5
+    elif case == "few_values":
+        W = (torch.randint(-2, 3, (out_f, in_f), generator=g).float() * 0.01).half()
+    elif case == "nan_inf":
+        W[:, 5] = float("nan")
+        W[:, 77] = float("inf")
+        W[::2, 300] = float("-inf")
+    else:
+        W[:, 9] = 6e4
+    xs = [((torch.randn(1, 9, in_f, generator=g) * 0.5) + 0.2).half() for _ in range(3)]
+    st = dsnot.DsnotInputStat(in_f, DEV)
+    for x in xs:
+        st.add_call(x.to(DEV))
+    st.finalize()
+    Wd = W.to(DEV)
+    keep, _ = ops.wanda_select(Wd, st.sqrt_row, "row", k=in_f // 2, apply_zero=False)
+    for n, m in ((0, 0), (2, 4)):
+        kp = keep if not n else ops.wanda_select(Wd, st.sqrt_row, "nm", n=n, m=m, apply_zero=False)[0]
+        ev_old, stop_old = _refine_events(Wd, st, kp, n, m, 100, 0.01, lists=False)
+        ev_new, stop_new = _refine_events(Wd, st, kp, n, m, 100, 0.01, lists=True)
+        assert torch.equal(stop_old, stop_new) and torch.equal(ev_old, ev_new), (case, n, m)
 
 
 def test_list_kernel_capacity_falls_back_to_cycle_kernel():

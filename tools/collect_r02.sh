@@ -10,13 +10,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stats_r02 -- $BENCH
 python tools/summarize_rocprof.py stats /tmp/stats_r02 gpurun_out/r02/stats_bench.md > /dev/null
 cp $(find /tmp/stats_r02 -name '*kernel_stats.csv' | head -1) gpurun_out/r02/kernel_stats.csv
 fi
-# (counter collection + forwards on several side streams crashed rocprofv3's FETCH_SIZE pass twice inside a torch clone: the PMC
-#  passes run the capture on the caller's stream only -- bytes per launch do not depend on the stream)
-export VLMC_CAPTURE_STREAMS=1
+# (the PMC passes run a reduced command -- one timed prune + the phase-timer prune, no warm-up, no kernel pass: counter
+#  collection over the default command's ~150 k dispatches crashed rocprofv3 (SIGSEGV in a tool thread) three times out of four)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --kernel-pass ${KP:-auto} > gpurun_out/r02/pmc_$c.log 2>&1 || echo "rocprofv3 --pmc $c exited with $?" >> gpurun_out/r02/pmc_$c.log
+  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 --kernel-pass 0 > gpurun_out/r02/pmc_$c.log 2>&1 || echo "rocprofv3 --pmc $c exited with $?" >> gpurun_out/r02/pmc_$c.log
 done
 python tools/traffic_from_pmc.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE gpurun_out/r02/traffic.json > /dev/null 2> gpurun_out/r02/traffic.err || true
-unset VLMC_CAPTURE_STREAMS
 python bench.py > gpurun_out/r02/bench_default.json 2> gpurun_out/r02/bench_default.err
 ls -la gpurun_out/r02

@@ -5,8 +5,11 @@
 // prune: ascending / descending wanda metric among the kept columns with negative resp. positive D).  So only
 // the first max_cycle entries of each list matter.  One workgroup per row:
 //   1. keys in registers (as in dsnot.hip)
-//   2. per list: radix select (4 x 8 key bits, LDS histogram) of the max_cycle-th smallest key, ties cut by
-//      column with two more passes, gather of those <= 128 entries into LDS, rank sort -> sorted list in LDS.
+//   2. per list: a counting sort of the list's end (dl_extract): the occupied key range is cut into 1024 equal bins,
+//      the first bin at which the running count reaches max_cycle is the cut-off, the candidates at or below it are placed
+//      by bin and ranked inside their bin.  Heavy ties / NaN keys (more than 192 candidates) take the exact radix route:
+//      radix select (4 x 8 key bits) of the max_cycle-th smallest key, ties cut by column, gather, rank sort.
+//      (Round 2: the radix route alone was ~21 k vector instructions per wave and row, profiles/r02_dsnot_roofline.md.)
 //      n:m: each regrow entry carries its m-group's kept columns sorted by metric (the prune candidates).
 //   3. wave 0 walks the cycles reading the lists: O(1) per cycle.
 // Same events as dsnot_simulate_kernel (dsnot.hip), which remains the path for max_cycle > 128 and the
@@ -35,6 +38,19 @@ __device__ __forceinline__ uint32_t dl_wave_incl_scan(uint32_t v) {
     return v;
 }
 
+// The compiler otherwise keeps every per-element predicate (a 64-bit lane mask each) and every bin index of one pass alive
+// for the next pass over the same registers: hundreds of spilled SGPRs and 2x the VGPRs (occupancy 1-2 waves per SIMD).  A
+// pass starts from an opaque copy of its mask / range so that what it needs is recomputed (two instructions per element).
+__device__ __forceinline__ uint32_t dl_opaque(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t dl_uniform(uint32_t v) {          // a wave-uniform value, held in an SGPR
+    v = uint32_t(__builtin_amdgcn_readfirstlane(int(v)));
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
 constexpr int kListCap = 128;        // entries per list = max supported max_cycle
 constexpr int kGroupMax = 8;         // m of n:m
 
@@ -49,13 +65,17 @@ struct GroupInfo {                   // n:m: the kept columns of an entry's m-gr
     uint32_t n;
 };
 
+constexpr int kFastBinsLog2 = 10;
+constexpr int kFastBins = 1 << kFastBinsLog2;  // fast route: one linear histogram over the occupied key range
+constexpr int kRawCap = 192;                   // ... and up to this many candidates (the cut-off bin brings a few extra)
+
 template <int NW, bool NM> struct ListSmem {
-    uint32_t hist[256];
+    uint32_t hist[kFastBins + 1 + 64];
     uint32_t red[24];
-    uint32_t rawk[kListCap], rawc[kListCap];
-    float rawd[kListCap];
+    uint32_t rawk[kRawCap], rawc[kRawCap];
+    float rawd[kRawCap];
     ListEntry list[NM ? 2 : 6][kListCap];
-    GroupInfo rawg[NM ? kListCap : 1];
+    uint32_t wmin[NW], wmax[NW];
     GroupInfo grp[NM ? 2 : 1][NM ? kListCap : 1];
     uint32_t cyc_group[NM ? kListCap : 1];
     float fsum[NW];
@@ -75,17 +95,19 @@ template <int NW> __device__ __forceinline__ void dl_sync() {
 
 // rank-r (0-based) smallest value of f(i) over the elements with mask bit i; also the count of values below it.
 // f values are < 2^(8*PASSES).  All threads of the workgroup call it with the same r.
-template <int E, int NT, int NW, int PASSES, typename F, typename S>
-__device__ __forceinline__ uint32_t dl_radix_kth(F f, uint32_t mask, uint32_t r, S &sm, uint32_t &below) {
+template <int E, int NT, int NW, int PASSES, typename F, typename S, typename R>
+__device__ __forceinline__ uint32_t dl_radix_kth(F f, uint32_t mask, uint32_t r, S &sm, uint32_t &below, R new_pass) {
     const int tid = threadIdx.x;
     uint32_t prefix = 0, pmask = 0;
     below = 0;
     for (int sh = 8 * (PASSES - 1); sh >= 0; sh -= 8) {
         for (int i = tid; i < 256; i += NT) sm.hist[i] = 0;
         dl_sync<NW>();
+        const uint32_t mk = dl_opaque(mask);
+        new_pass();                                                  // (nothing of f is hoisted out of the loop over the passes)
 #pragma unroll
         for (int i = 0; i < E; ++i)
-            if ((mask >> i) & 1u) {
+            if ((mk >> i) & 1u) {
                 const uint32_t v = f(i);
                 if ((v & pmask) == prefix) atomicAdd(&sm.hist[(v >> sh) & 255u], 1u);
             }
@@ -132,45 +154,180 @@ template <int NT, int NW, typename S> __device__ __forceinline__ uint32_t dl_blo
     return v;
 }
 
+// wave-wide min / max of a 32-bit unsigned (result valid in every lane)
+__device__ __forceinline__ uint32_t dl_wave_min(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t o = uint32_t(__shfl_xor(int(v), off, 64));
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t dl_wave_max(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t o = uint32_t(__shfl_xor(int(v), off, 64));
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
 // The K smallest (want_max: largest) (key, column) pairs among the masked elements -> out[0..n) in that order.
-// Returns n = min(K, number of masked elements).  `emit(i, pos)` is called by the lane that owns element i when it
-// is gathered to raw position pos (n:m group payload); `place(pos, rank)` moves payloads to their sorted slot.
-template <int E, int NT, int NW, typename S, typename Emit, typename Place>
-__device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], const float (&D)[E], uint32_t mask, bool want_max, uint32_t K, S &sm,
-                               ListEntry *out, Emit emit, Place place) {
+// The mask, the direction and K are RUN-TIME values, so that the kernel holds one copy of this code per key vector and
+// loops over that vector's lists (seven inlined copies were 287 KB of code per kernel, 4.5 x the instruction cache).
+// Returns n = min(K, number of masked elements).  `place(col, rank)` is called by one thread for each list entry (n:m: it
+// builds the entry's group payload).
+//
+// Fast route (fast != 0): a counting sort.  The occupied key range [lo, hi] of the masked elements is cut into kFastBins
+// equal bins; wave 0 turns the histogram into bin start offsets and finds the cut-off bin (the first one at which the
+// running count reaches n); every element at or below it takes a slot inside its bin's range (LDS atomic), which orders
+// the candidates across bins, and each candidate's exact rank is its bin's start + its rank by (key, column) among the
+// few entries of its own bin.  Ranks >= n are dropped.  More than kRawCap candidates (heavy ties: zero weights, dead
+// channels; NaN keys stretching the range) -> the radix route below, which is exact for any input.
+template <int E, int NT, int NW, typename S, typename Place>
+__device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], const float (&D)[E], uint32_t mask, uint32_t want_max, uint32_t K, S &sm,
+                                               ListEntry *out, Place place, int fast) {
     const int tid = threadIdx.x;
     const uint32_t avail = dl_block_sum<NT, NW>(uint32_t(__popc(mask)), sm, 0);
     const uint32_t n = avail < K ? avail : K;
     if (n == 0) return 0;
-    const uint32_t flip = want_max ? 0xFFFFFFFFu : 0u;
-    auto colof = [&](int i) { return uint32_t((i / 8) * NT * 8 + tid * 8 + (i % 8)); };
+    uint32_t flip = want_max ? 0xFFFFFFFFu : 0u;
+    uint32_t tid8 = uint32_t(tid) * 8u;
+    auto colof = [&](int i) { return uint32_t((i / 8) * NT * 8 + (i % 8)) + tid8; };
     auto kf = [&](int i) { return key[i] ^ flip; };
     auto cf = [&](int i) { return (colof(i) ^ flip) & 0x3FFFu; };
+    // a pass starts from opaque copies of the direction and the lane's column base: no flipped key or column number of an
+    // earlier pass (or, hoisted out of the loop over the lists, of all of them) is kept in a register
+    auto new_pass = [&]() { flip = dl_uniform(flip); tid8 = dl_opaque(tid8); };
+    if (fast) {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        const uint32_t mk0 = dl_opaque(mask);
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const uint32_t kk = kf(i);
+            const bool in = (mk0 >> i) & 1u;
+            lo = (in && kk < lo) ? kk : lo;
+            hi = (in && kk > hi) ? kk : hi;
+        }
+        lo = dl_wave_min(lo);
+        hi = dl_wave_max(hi);
+        if constexpr (NW > 1) {
+            if ((tid & 63) == 0) { sm.wmin[tid >> 6] = lo; sm.wmax[tid >> 6] = hi; }
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const uint32_t a = sm.wmin[w], b = sm.wmax[w];
+                lo = a < lo ? a : lo;
+                hi = b > hi ? b : hi;
+            }
+        }
+        lo = dl_uniform(lo);
+        const uint32_t span = dl_uniform(hi) - lo;                      // (span >> shift) < kFastBins
+        uint32_t shift = span < uint32_t(kFastBins) ? 0u : uint32_t(32 - __builtin_clz(span)) - uint32_t(kFastBinsLog2);
+        for (int i = tid; i < kFastBins; i += NT) sm.hist[i] = 0;
+        dl_sync<NW>();
+        const uint32_t mk1 = dl_opaque(mask);
+        new_pass();
+#pragma unroll
+        for (int i = 0; i < E; ++i) {                                   // branch-free: the others count into a spare bin of their lane
+            const uint32_t bin = (kf(i) - lo) >> shift;
+            atomicAdd(&sm.hist[((mk1 >> i) & 1u) ? bin : uint32_t(kFastBins + 1 + (tid & 63))], 1u);
+        }
+        dl_sync<NW>();
+        lo = dl_uniform(lo);                                            // (the bins are recomputed in the gather, not kept)
+        shift = dl_uniform(shift);
+        if (tid < 64) {                                                 // wave 0: kFastBins / 64 bins per lane
+            constexpr int PER = kFastBins / 64;
+            uint32_t h[PER];
+            uint32_t ssum = 0;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) { h[i] = sm.hist[tid * PER + i]; ssum += h[i]; }
+            const uint32_t incl = dl_wave_incl_scan(ssum);
+            uint32_t cum = incl - ssum;
+            const bool mine = cum < n && n <= incl;                     // this lane's bins bring the count to n
+            bool found = false;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                cum += h[i];
+                sm.hist[tid * PER + i] = cum;                           // inclusive prefix: bin b's range is [hist[b-1] - cnt_b .. )
+                if (mine && !found && cum >= n) {
+                    found = true;
+                    sm.red[3] = uint32_t(tid * PER + i);                // the cut-off bin
+                    sm.red[4] = cum;                                    // candidates
+                }
+            }
+        }
+        dl_sync<NW>();
+        const uint32_t cut = sm.red[3], m = sm.red[4];
+        if (m <= uint32_t(kRawCap)) {
+            // slots are handed out from the END of each bin's range downwards: hist[b] (inclusive prefix) counts down to
+            // the bin's start, so afterwards start(b) = hist[b] and end(b) = start(b + 1) = hist[b + 1] (or m at the cut).
+            const uint32_t mk2 = dl_opaque(mask);
+            new_pass();
+#pragma unroll
+            for (int i = 0; i < E; ++i)
+                if ((mk2 >> i) & 1u) {
+                    const uint32_t kk = kf(i);
+                    const uint32_t bin = (kk - lo) >> shift;
+                    if (bin <= cut) {
+                        const uint32_t pos = atomicSub(&sm.hist[bin], 1u) - 1u;
+                        sm.rawk[pos] = kk;
+                        sm.rawc[pos] = cf(i);
+                        sm.rawd[pos] = D[i];
+                    }
+                }
+            dl_sync<NW>();
+            for (uint32_t p = tid; p < m; p += NT) {
+                const uint32_t kp = sm.rawk[p], cp = sm.rawc[p];
+                const uint32_t bin = (kp - lo) >> shift;
+                const uint32_t s0 = sm.hist[bin], e0 = bin == cut ? m : sm.hist[bin + 1];
+                uint32_t rank = s0;
+                for (uint32_t q = s0; q < e0; ++q) {
+                    const uint32_t kq = sm.rawk[q], cq = sm.rawc[q];
+                    rank += (kq < kp || (kq == kp && cq < cp)) ? 1u : 0u;
+                }
+                if (rank < n) {
+                    out[rank] = ListEntry{(cp ^ flip) & 0x3FFFu, sm.rawd[p]};
+                    place((cp ^ flip) & 0x3FFFu, rank);
+                }
+            }
+            dl_sync<NW>();
+            return n;
+        }
+        dl_sync<NW>();
+    }
+#ifdef DL_EXP_NORADIX
+    return n;
+#endif
+    // ---- exact route for any input: radix select of the n-th key, ties cut by column --------------------------------------
     uint32_t c_lt;
-    const uint32_t X = dl_radix_kth<E, NT, NW, 4>(kf, mask, n - 1, sm, c_lt);
+    const uint32_t X = dl_radix_kth<E, NT, NW, 4>(kf, mask, n - 1, sm, c_lt, new_pass);
     // ties with X: all of them, or the (n - c_lt) first by (flipped) column
     uint32_t tie = 0;
+    const uint32_t mk3 = dl_opaque(mask);
+    new_pass();
 #pragma unroll
     for (int i = 0; i < E; ++i)
-        if (((mask >> i) & 1u) && kf(i) == X) tie |= 1u << i;
+        if (((mk3 >> i) & 1u) && kf(i) == X) tie |= 1u << i;
     const uint32_t n_tie = dl_block_sum<NT, NW>(uint32_t(__popc(tie)), sm, 1);
     uint32_t Y = 0x3FFFu;
     if (n_tie > n - c_lt) {
         uint32_t dummy;
-        Y = dl_radix_kth<E, NT, NW, 2>(cf, tie, n - c_lt - 1, sm, dummy);
+        Y = dl_radix_kth<E, NT, NW, 2>(cf, tie, n - c_lt - 1, sm, dummy, new_pass);
     }
     if (tid == 0) sm.red[2] = 0;
     dl_sync<NW>();
+    const uint32_t mk4 = dl_opaque(mask);
+    new_pass();
 #pragma unroll
     for (int i = 0; i < E; ++i)
-        if ((mask >> i) & 1u) {
+        if ((mk4 >> i) & 1u) {
             const uint32_t kk = kf(i);
             if (kk < X || (kk == X && cf(i) <= Y)) {
                 const uint32_t pos = atomicAdd(&sm.red[2], 1u);
                 sm.rawk[pos] = kk;
                 sm.rawc[pos] = cf(i);
                 sm.rawd[pos] = D[i];
-                emit(i, pos);
             }
         }
     dl_sync<NW>();
@@ -186,7 +343,7 @@ __device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], const f
                 rank += (kq < kp || (kq == kp && cq < cp)) ? 1u : 0u;
             }
             out[rank] = ListEntry{(cp ^ flip) & 0x3FFFu, sm.rawd[p]};
-            place(p, rank);
+            place((cp ^ flip) & 0x3FFFu, rank);
         }
     } else if (tid < 64) {
         const uint32_t p0 = uint32_t(tid), p1 = uint32_t(tid) + 64u;
@@ -204,19 +361,21 @@ __device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], const f
             rank0 += (kq < k0 || (kq == k0 && cq < c0)) ? 1u : 0u;
             rank1 += (kq < k1 || (kq == k1 && cq < c1)) ? 1u : 0u;
         }
-        if (p0 < n) { out[rank0] = ListEntry{(c0 ^ flip) & 0x3FFFu, sm.rawd[p0]}; place(p0, rank0); }
-        if (p1 < n) { out[rank1] = ListEntry{(c1 ^ flip) & 0x3FFFu, sm.rawd[p1]}; place(p1, rank1); }
+        if (p0 < n) { out[rank0] = ListEntry{(c0 ^ flip) & 0x3FFFu, sm.rawd[p0]}; place((c0 ^ flip) & 0x3FFFu, rank0); }
+        if (p1 < n) { out[rank1] = ListEntry{(c1 ^ flip) & 0x3FFFu, sm.rawd[p1]}; place((c1 ^ flip) & 0x3FFFu, rank1); }
     }
     dl_sync<NW>();
     return n;
 }
 
+__device__ __attribute__((noinline)) float dl_powf(float v, float p) { return powf(v, p); }   // (32 inlined copies otherwise)
+
 template <typename T, int CH, int NW, bool NM>
-__global__ __launch_bounds__(64 * NW) void dsnot_lists_kernel(
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) void dsnot_lists_kernel(
     const typename T::raw *__restrict__ W, int64_t out_f, int64_t in_f, int64_t ldw, const uint8_t *__restrict__ keep0,
     const float *__restrict__ sqrt_scaler, const float *__restrict__ sum_row, const float *__restrict__ var_row, int use_wanda_init,
     int prune_m, int max_cycle, float thr, float pow_var, int without_same_sign, uint32_t *__restrict__ events,
-    int32_t *__restrict__ t_row) {
+    int32_t *__restrict__ t_row, int fast) {
     constexpr int NT = 64 * NW, E = CH * 8;
     __shared__ ListSmem<NW, NM> sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -252,7 +411,7 @@ __global__ __launch_bounds__(64 * NW) void dsnot_lists_kernel(
                 if (pr) part = ieee_add(part, d);
                 if (pow_var != 0.f) {
                     const float v = var_row[col0 + j];
-                    g = ieee_div(g, pow_var == 1.f ? v : powf(v, pow_var));
+                    g = ieee_div(g, pow_var == 1.f ? v : dl_powf(v, pow_var));
                 }
                 gk[i] = dl_signed_key(g);
             }
@@ -286,44 +445,52 @@ __global__ __launch_bounds__(64 * NW) void dsnot_lists_kernel(
     const uint32_t K = uint32_t(max_cycle);
 
     // ---- 2. the list heads ---------------------------------------------------------------------------------------
-    auto no_emit = [](int, uint32_t) {};
-    auto no_place = [](uint32_t, uint32_t) {};
-    uint32_t n_list[6] = {0, 0, 0, 0, 0, 0};
     uint32_t NP = 0, PP = 0, Z = 0, k0col = 0;
     float k0d = 0.f;
     if constexpr (NM) {
-        const int mshift = prune_m == 8 ? 3 : (prune_m == 4 ? 2 : 1);
-        // payload of a regrow entry: its m-group's kept columns in ascending (metric, column) order
-        auto emit = [&](int i, uint32_t pos) {
+        // payload of a regrow entry: its m-group's kept columns in ascending (metric, column) order, D of its first column.
+        // Built by the thread that places the entry, from the row in memory (same arithmetic as step 1; 2 x max_cycle
+        // groups per row, where the per-element version inlined at every gather site was most of the kernel's code).
+        const typename T::raw *wrow = W + row * ldw;
+        const uint8_t *krow = keep0 + row * in_f;
+        auto payload = [&](uint32_t li, uint32_t col, uint32_t rank) {
             GroupInfo gi;
-            gi.n = 0;
-            const int base = (i / 8) * 8;                      // the group lies inside the lane's 8-column chunk
-            const int gsel = (i % 8) >> mshift;
-            const uint32_t col_base = uint32_t((i / 8) * NT * 8 + tid * 8);
+            const uint32_t g0 = col - col % uint32_t(prune_m);
+            uint32_t key[kGroupMax];
+            float d[kGroupMax];
+            bool kept[kGroupMax];
 #pragma unroll
-            for (int a = 0; a < 8; ++a) { gi.col[a] = 0; gi.d[a] = 0.f; }
-            gi.d0 = 0.f;
-#pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                if ((a >> mshift) != gsel) continue;
-                if (a == (gsel << mshift)) gi.d0 = D[base + a];
-                if (!((kept0 >> (base + a)) & 1u)) continue;
-                uint32_t rank = 0;
-#pragma unroll
-                for (int b2 = 0; b2 < 8; ++b2) {
-                    if ((b2 >> mshift) != gsel || !((kept0 >> (base + b2)) & 1u)) continue;
-                    rank += (wk[base + b2] < wk[base + a] || (wk[base + b2] == wk[base + a] && b2 < a)) ? 1u : 0u;
-                }
-#pragma unroll
-                for (int slot = 0; slot < 8; ++slot)           // rank is a run-time value: select the slot by compare
-                    if (uint32_t(slot) == rank) { gi.col[slot] = uint16_t(col_base + a); gi.d[slot] = D[base + a]; }
-                ++gi.n;
+            for (int a = 0; a < kGroupMax; ++a) {
+                gi.col[a] = 0; gi.d[a] = 0.f;
+                const bool in = a < prune_m;
+                const uint32_t c = in ? g0 + uint32_t(a) : g0;
+                const float w = to_f32<T>(wrow[c]);
+                d[a] = ieee_mul(w, sum_row[c]);
+                key[a] = score_key(use_wanda_init ? ieee_mul(fabsf(w), sqrt_scaler[c]) : fabsf(w));
+                kept[a] = in && krow[c] != 0;
             }
-            sm.rawg[pos] = gi;
+            gi.d0 = d[0];
+            gi.n = 0;
+#pragma unroll
+            for (int a = 0; a < kGroupMax; ++a) {
+                uint32_t r = 0;
+#pragma unroll
+                for (int b2 = 0; b2 < kGroupMax; ++b2)
+                    r += (kept[b2] && (key[b2] < key[a] || (key[b2] == key[a] && b2 < a))) ? 1u : 0u;
+                if (kept[a]) {
+#pragma unroll
+                    for (int slot = 0; slot < kGroupMax; ++slot)       // r is a run-time value: select the slot by compare
+                        if (uint32_t(slot) == r) { gi.col[slot] = uint16_t(g0 + uint32_t(a)); gi.d[slot] = d[a]; }
+                    ++gi.n;
+                }
+            }
+            sm.grp[li][rank] = gi;
         };
-        for (int li = 0; li < 2; ++li) {
-            auto place = [&](uint32_t p, uint32_t rank) { sm.grp[li][rank] = sm.rawg[p]; };
-            n_list[li] = dl_extract<E, NT, NW>(gk, D, live, li == 1, K, sm, sm.list[li], emit, place);
+#pragma unroll 1
+        for (uint32_t li = 0; li < 2; ++li) {
+            auto place = [&](uint32_t col, uint32_t rank) { payload(li, col, rank); };
+            const uint32_t got = dl_extract<E, NT, NW>(gk, D, live, li, K, sm, sm.list[li], place, fast);
+            if (tid == 0) sm.nlist[li] = got;
         }
     } else {
         uint32_t negm = 0, posm = 0;
@@ -336,20 +503,28 @@ __global__ __launch_bounds__(64 * NW) void dsnot_lists_kernel(
         NP = dl_block_sum<NT, NW>(uint32_t(__popc(negm)), sm, 0);
         PP = dl_block_sum<NT, NW>(uint32_t(__popc(posm)), sm, 1);
         Z = dl_block_sum<NT, NW>(uint32_t(__popc(kept0)), sm, 2) - NP - PP;
-        n_list[0] = dl_extract<E, NT, NW>(gk, D, live, false, K, sm, sm.list[0], no_emit, no_place);
-        n_list[1] = dl_extract<E, NT, NW>(gk, D, live, true, K, sm, sm.list[1], no_emit, no_place);
-        n_list[2] = dl_extract<E, NT, NW>(wk, D, negm, false, K, sm, sm.list[2], no_emit, no_place);
-        n_list[3] = dl_extract<E, NT, NW>(wk, D, negm, true, K, sm, sm.list[3], no_emit, no_place);
-        n_list[4] = dl_extract<E, NT, NW>(wk, D, posm, false, K, sm, sm.list[4], no_emit, no_place);
-        n_list[5] = dl_extract<E, NT, NW>(wk, D, posm, true, K, sm, sm.list[5], no_emit, no_place);
-        // K0: the kept column with the smallest wanda metric (head of the ascending list over ALL kept columns)
-        const uint32_t nk0 = dl_extract<E, NT, NW>(wk, D, kept0, false, 1u, sm, sm.k0, no_emit, no_place);
+        auto no_place = [](uint32_t, uint32_t) {};
+        // lists 0/1: regrow candidates by G, ascending / descending; 2/3: kept columns with D < 0 by metric; 4/5: with D > 0;
+        // 6 (K0): the kept column with the smallest wanda metric (head of the ascending list over ALL kept columns)
+        uint32_t nk0 = 0;
+#pragma unroll 1
+        for (uint32_t li = 0; li < 2; ++li) {                          // (gk is dead after this loop: 32 registers less)
+            const uint32_t got = dl_extract<E, NT, NW>(gk, D, live, li & 1u, K, sm, sm.list[li], no_place, fast);
+            if (tid == 0) sm.nlist[li] = got;
+        }
+#pragma unroll 1
+        for (uint32_t li = 2; li < 7; ++li) {
+            const uint32_t msk = li < 4 ? negm : (li < 6 ? posm : kept0);
+            ListEntry *dst = li < 6 ? sm.list[li] : sm.k0;
+            const uint32_t got = dl_extract<E, NT, NW>(wk, D, msk, li & 1u, li < 6 ? K : 1u, sm, dst, no_place, fast);
+            if (li < 6) {
+                if (tid == 0) sm.nlist[li] = got;
+            } else {
+                nk0 = got;
+            }
+        }
         k0col = nk0 ? sm.k0[0].col : 0xFFFFFFFFu;
         k0d = nk0 ? sm.k0[0].d : 0.f;
-    }
-    if (tid == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) sm.nlist[i] = n_list[i];
     }
     dl_sync<NW>();
     if (wave != 0) return;
@@ -448,10 +623,12 @@ static int lists_dispatch(const void *W, int64_t out_f, int64_t in_f, int64_t ld
     }
     if (nchunks > int64_t(64) * nw * 4) return VLMC_EINVAL;
     const int ch = nchunks <= int64_t(64) * nw * 2 ? 2 : 4;
+    const char *radix_only = getenv("VLMC_DSNOT_RADIX_ONLY");      // the exact route alone (tests compare the two)
+    const int fast = (radix_only && atoi(radix_only)) ? 0 : 1;
 #define VLMC_DL(CH, NW)                                                                                                    \
     hipLaunchKernelGGL((dsnot_lists_kernel<T, CH, NW, NM>), dim3(unsigned(out_f)), dim3(64 * NW), 0, st,                    \
                        static_cast<const raw *>(W), out_f, in_f, ldw, keep0, sq, sum_row, var_row, use_wanda_init, prune_m, \
-                       max_cycle, thr, pow_var, without_same_sign, events, t_row)
+                       max_cycle, thr, pow_var, without_same_sign, events, t_row, fast)
 #define VLMC_DL_NW(NW) do { if (ch == 2) VLMC_DL(2, NW); else VLMC_DL(4, NW); } while (0)
     switch (nw) {
         case 1: VLMC_DL_NW(1); break;
