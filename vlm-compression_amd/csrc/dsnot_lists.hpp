@@ -73,7 +73,6 @@ template <int NW, bool NM> struct ListSmem {
     uint32_t hist[kFastBins + 1 + 64];
     uint32_t red[24];
     uint32_t rawk[kRawCap], rawc[kRawCap];
-    float rawd[kRawCap];
     ListEntry list[NM ? 2 : 6][kListCap];
     uint32_t wmin[NW], wmax[NW];
     GroupInfo grp[NM ? 2 : 1][NM ? kListCap : 1];
@@ -175,8 +174,9 @@ __device__ __forceinline__ uint32_t dl_wave_max(uint32_t v) {
 // The K smallest (want_max: largest) (key, column) pairs among the masked elements -> out[0..n) in that order.
 // The mask, the direction and K are RUN-TIME values, so that the kernel holds one copy of this code per key vector and
 // loops over that vector's lists (seven inlined copies were 287 KB of code per kernel, 4.5 x the instruction cache).
-// Returns n = min(K, number of masked elements).  `place(col, rank)` is called by one thread for each list entry (n:m: it
-// builds the entry's group payload).
+// Returns n = min(K, number of masked elements).  `dval(col)` gives the entry's D = w * mean (evaluated for the <= K placed
+// entries, from the row in memory: an array of D in registers cost a wave of occupancy); `place(col, rank)` is called by
+// one thread for each list entry (n:m: it builds the entry's group payload).
 //
 // Fast route (fast != 0): a counting sort.  The occupied key range [lo, hi] of the masked elements is cut into kFastBins
 // equal bins; wave 0 turns the histogram into bin start offsets and finds the cut-off bin (the first one at which the
@@ -184,8 +184,8 @@ __device__ __forceinline__ uint32_t dl_wave_max(uint32_t v) {
 // the candidates across bins, and each candidate's exact rank is its bin's start + its rank by (key, column) among the
 // few entries of its own bin.  Ranks >= n are dropped.  More than kRawCap candidates (heavy ties: zero weights, dead
 // channels; NaN keys stretching the range) -> the radix route below, which is exact for any input.
-template <int E, int NT, int NW, typename S, typename Place>
-__device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], const float (&D)[E], uint32_t mask, uint32_t want_max, uint32_t K, S &sm,
+template <int E, int NT, int NW, typename S, typename DVal, typename Place>
+__device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], DVal dval, uint32_t mask, uint32_t want_max, uint32_t K, S &sm,
                                                ListEntry *out, Place place, int fast) {
     const int tid = threadIdx.x;
     const uint32_t avail = dl_block_sum<NT, NW>(uint32_t(__popc(mask)), sm, 0);
@@ -273,7 +273,6 @@ __device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], const f
                         const uint32_t pos = atomicSub(&sm.hist[bin], 1u) - 1u;
                         sm.rawk[pos] = kk;
                         sm.rawc[pos] = cf(i);
-                        sm.rawd[pos] = D[i];
                     }
                 }
             dl_sync<NW>();
@@ -287,8 +286,9 @@ __device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], const f
                     rank += (kq < kp || (kq == kp && cq < cp)) ? 1u : 0u;
                 }
                 if (rank < n) {
-                    out[rank] = ListEntry{(cp ^ flip) & 0x3FFFu, sm.rawd[p]};
-                    place((cp ^ flip) & 0x3FFFu, rank);
+                    const uint32_t col = (cp ^ flip) & 0x3FFFu;
+                    out[rank] = ListEntry{col, dval(col)};
+                    place(col, rank);
                 }
             }
             dl_sync<NW>();
@@ -327,7 +327,6 @@ __device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], const f
                 const uint32_t pos = atomicAdd(&sm.red[2], 1u);
                 sm.rawk[pos] = kk;
                 sm.rawc[pos] = cf(i);
-                sm.rawd[pos] = D[i];
             }
         }
     dl_sync<NW>();
@@ -342,8 +341,9 @@ __device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], const f
                 const uint32_t kq = sm.rawk[q], cq = sm.rawc[q];
                 rank += (kq < kp || (kq == kp && cq < cp)) ? 1u : 0u;
             }
-            out[rank] = ListEntry{(cp ^ flip) & 0x3FFFu, sm.rawd[p]};
-            place((cp ^ flip) & 0x3FFFu, rank);
+            const uint32_t col = (cp ^ flip) & 0x3FFFu;
+            out[rank] = ListEntry{col, dval(col)};
+            place(col, rank);
         }
     } else if (tid < 64) {
         const uint32_t p0 = uint32_t(tid), p1 = uint32_t(tid) + 64u;
@@ -361,8 +361,8 @@ __device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], const f
             rank0 += (kq < k0 || (kq == k0 && cq < c0)) ? 1u : 0u;
             rank1 += (kq < k1 || (kq == k1 && cq < c1)) ? 1u : 0u;
         }
-        if (p0 < n) { out[rank0] = ListEntry{(c0 ^ flip) & 0x3FFFu, sm.rawd[p0]}; place((c0 ^ flip) & 0x3FFFu, rank0); }
-        if (p1 < n) { out[rank1] = ListEntry{(c1 ^ flip) & 0x3FFFu, sm.rawd[p1]}; place((c1 ^ flip) & 0x3FFFu, rank1); }
+        if (p0 < n) { const uint32_t col = (c0 ^ flip) & 0x3FFFu; out[rank0] = ListEntry{col, dval(col)}; place(col, rank0); }
+        if (p1 < n) { const uint32_t col = (c1 ^ flip) & 0x3FFFu; out[rank1] = ListEntry{col, dval(col)}; place(col, rank1); }
     }
     dl_sync<NW>();
     return n;
@@ -371,7 +371,7 @@ __device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], const f
 __device__ __attribute__((noinline)) float dl_powf(float v, float p) { return powf(v, p); }   // (32 inlined copies otherwise)
 
 template <typename T, int CH, int NW, bool NM>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) void dsnot_lists_kernel(
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) void dsnot_lists_kernel(
     const typename T::raw *__restrict__ W, int64_t out_f, int64_t in_f, int64_t ldw, const uint8_t *__restrict__ keep0,
     const float *__restrict__ sqrt_scaler, const float *__restrict__ sum_row, const float *__restrict__ var_row, int use_wanda_init,
     int prune_m, int max_cycle, float thr, float pow_var, int without_same_sign, uint32_t *__restrict__ events,
@@ -382,17 +382,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
     const int64_t row = blockIdx.x;
     const int64_t nchunks = in_f / 8;
     // ---- 1. keys (identical to dsnot_simulate_kernel) -------------------------------------------------------------
-    float D[E];
-    uint32_t gk[E], wk[E];
-    uint32_t live = 0, pruned0 = 0;
+    // One key vector lives in registers at a time: G (regrow) here; the wanda metric is computed from the row again
+    // (L2) after the regrow lists are cut.  D = w * mean is needed per element only for its sign (two bit masks).
+    const typename T::raw *wrow = W + row * ldw;
+    const uint8_t *krow = keep0 + row * in_f;
+    uint32_t live = 0, pruned0 = 0, negm = 0, posm = 0;
     float part = 0.f;
+    uint32_t gk[E];
 #pragma unroll
     for (int s = 0; s < CH; ++s) {
         const int64_t c = int64_t(s) * NT + tid;
         if (c < nchunks) {
             const int64_t col0 = c * 8;
-            Chunk8<T> raw = load_chunk8<T>(W + row * ldw + col0);
-            const uint2 mm = *reinterpret_cast<const uint2 *>(keep0 + row * in_f + col0);
+            Chunk8<T> raw = load_chunk8<T>(wrow + col0);
+            const uint2 mm = *reinterpret_cast<const uint2 *>(krow + col0);
             uint8_t m[8];
             __builtin_memcpy(m, &mm, 8);
 #pragma unroll
@@ -400,13 +403,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
                 const int i = s * 8 + j;
                 const float w = to_f32<T>(raw.v[j]);
                 const float d = ieee_mul(w, sum_row[col0 + j]);
-                D[i] = d;
                 const bool pr = m[j] == 0;
                 live |= 1u << i;
                 if (pr) pruned0 |= 1u << i;
-                const float init = use_wanda_init ? ieee_mul(fabsf(w), sqrt_scaler[col0 + j]) : fabsf(w);
-                const float wanda = NM ? init : ieee_mul(fabsf(w), sqrt_scaler[col0 + j]);
-                wk[i] = score_key(wanda);
+                else if (d < 0.f) negm |= 1u << i;
+                else if (d > 0.f) posm |= 1u << i;
                 float g = pr ? d : 0.f;
                 if (pr) part = ieee_add(part, d);
                 if (pow_var != 0.f) {
@@ -417,9 +418,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { D[s * 8 + j] = 0.f; gk[s * 8 + j] = 0; wk[s * 8 + j] = 0; }
+            for (int j = 0; j < 8; ++j) gk[s * 8 + j] = 0;
         }
     }
+    auto dval = [&](uint32_t col) { return ieee_mul(to_f32<T>(wrow[col]), sum_row[col]); };
     float err;
     {
         float v = part;
@@ -451,8 +453,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
         // payload of a regrow entry: its m-group's kept columns in ascending (metric, column) order, D of its first column.
         // Built by the thread that places the entry, from the row in memory (same arithmetic as step 1; 2 x max_cycle
         // groups per row, where the per-element version inlined at every gather site was most of the kernel's code).
-        const typename T::raw *wrow = W + row * ldw;
-        const uint8_t *krow = keep0 + row * in_f;
         auto payload = [&](uint32_t li, uint32_t col, uint32_t rank) {
             GroupInfo gi;
             const uint32_t g0 = col - col % uint32_t(prune_m);
@@ -489,17 +489,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
 #pragma unroll 1
         for (uint32_t li = 0; li < 2; ++li) {
             auto place = [&](uint32_t col, uint32_t rank) { payload(li, col, rank); };
-            const uint32_t got = dl_extract<E, NT, NW>(gk, D, live, li, K, sm, sm.list[li], place, fast);
+            const uint32_t got = dl_extract<E, NT, NW>(gk, dval, live, li, K, sm, sm.list[li], place, fast);
             if (tid == 0) sm.nlist[li] = got;
         }
     } else {
-        uint32_t negm = 0, posm = 0;
-#pragma unroll
-        for (int i = 0; i < E; ++i)
-            if ((kept0 >> i) & 1u) {
-                if (D[i] < 0.f) negm |= 1u << i;
-                else if (D[i] > 0.f) posm |= 1u << i;
-            }
         NP = dl_block_sum<NT, NW>(uint32_t(__popc(negm)), sm, 0);
         PP = dl_block_sum<NT, NW>(uint32_t(__popc(posm)), sm, 1);
         Z = dl_block_sum<NT, NW>(uint32_t(__popc(kept0)), sm, 2) - NP - PP;
@@ -509,14 +502,30 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
         uint32_t nk0 = 0;
 #pragma unroll 1
         for (uint32_t li = 0; li < 2; ++li) {                          // (gk is dead after this loop: 32 registers less)
-            const uint32_t got = dl_extract<E, NT, NW>(gk, D, live, li & 1u, K, sm, sm.list[li], no_place, fast);
+            const uint32_t got = dl_extract<E, NT, NW>(gk, dval, live, li & 1u, K, sm, sm.list[li], no_place, fast);
             if (tid == 0) sm.nlist[li] = got;
+        }
+        // the prune lists' key: the wanda metric |w| * sqrt(scaler), from the row again
+        uint32_t wk[E];
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            const int64_t c = int64_t(s) * NT + tid;
+            if (c < nchunks) {
+                const int64_t col0 = c * 8;
+                Chunk8<T> raw = load_chunk8<T>(wrow + col0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    wk[s * 8 + j] = score_key(ieee_mul(fabsf(to_f32<T>(raw.v[j])), sqrt_scaler[col0 + j]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wk[s * 8 + j] = 0;
+            }
         }
 #pragma unroll 1
         for (uint32_t li = 2; li < 7; ++li) {
             const uint32_t msk = li < 4 ? negm : (li < 6 ? posm : kept0);
             ListEntry *dst = li < 6 ? sm.list[li] : sm.k0;
-            const uint32_t got = dl_extract<E, NT, NW>(wk, D, msk, li & 1u, li < 6 ? K : 1u, sm, dst, no_place, fast);
+            const uint32_t got = dl_extract<E, NT, NW>(wk, dval, msk, li & 1u, li < 6 ? K : 1u, sm, dst, no_place, fast);
             if (li < 6) {
                 if (tid == 0) sm.nlist[li] = got;
             } else {
@@ -617,6 +626,7 @@ static int lists_dispatch(const void *W, int64_t out_f, int64_t in_f, int64_t ld
     // smallest workgroup that holds the row with <= 4 chunks per lane (fewest barriers per radix pass)
     int nw = 1;
     while (nw < 8 && nchunks > int64_t(64) * nw * 4) nw *= 2;
+    if (NM && nw == 1) nw = 2;      // n:m: 23 KB of LDS per row -> six one-wave workgroups per CU would leave the SIMDs at 1.5 waves
     if (const char *e = getenv("VLMC_DSNOT_NW")) {
         const int f = atoi(e);
         if ((f == 1 || f == 2 || f == 4 || f == 8) && nchunks <= int64_t(64) * f * 4) nw = f;
