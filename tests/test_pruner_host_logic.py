@@ -236,3 +236,100 @@ def test_grouped_replay_of_ragged_calibration_text_keeps_the_sample_order(method
     assert per_sample.keys() == grouped.keys() and len(grouped) == 2 * 4 + 2 * 7 + 2 * 11
     for k in per_sample:
         assert torch.equal(per_sample[k], grouped[k]), k
+
+
+# ---- the first pass ends where its last hook has fired -------------------------------------------------------------
+@pytest.mark.parametrize("method", ["wanda", "dsnot", "sparsegpt"])
+def test_statistics_pass_skips_the_dead_tail_and_changes_nothing(method, monkeypatch):
+    """The pass that feeds the hooks does not compute the block's last linear (nor what follows it) from the tower's
+    second block on -- the order of the linears is learned on the first block -- and the pruned model is the same, bit
+    for bit, as with VLMC_SKIP_DEAD_TAIL=0."""
+    import toy_models
+    from lavis.compression import load_pruner
+    {"wanda": oracle_ops.install, "dsnot": oracle_ops.install_dsnot, "sparsegpt": oracle_ops.install_sparsegpt}[method](monkeypatch)
+    torch.set_num_threads(1)
+    real_linear = torch.nn.functional.linear
+    computed = {}
+
+    def counting(x, weight, bias=None):                     # every product with a weight, whoever asks for it
+        computed[id(weight)] = computed.get(id(weight), 0) + 1
+        return real_linear(x, weight, bias)
+    monkeypatch.setattr(torch.nn.functional, "linear", counting)
+
+    def run(skip):
+        monkeypatch.setenv("VLMC_SKIP_DEAD_TAIL", "1" if skip else "0")
+        computed.clear()
+        model = toy_models.init_toy(toy_models.ToyBlipT5(), seed=11).eval()
+        batches = toy_models.make_batches(6, seed=5)
+        spec = "2-0.5-1.0-1.0"
+        cfg = dict(t5_prune_spec=spec, vit_prune_spec=spec, t5_pruning_method=method, vit_pruning_method=method,
+                   num_samples=6, max_sparsity_per_layer=1.01)
+        if method == "dsnot":
+            cfg["max_cycle_time"] = 8
+        pruned, _ = load_pruner(f"blipt5_{method}_pruner", model, batches, cfg=cfg).prune()
+        last = {n: computed.get(id(m.weight), 0) for n, m in pruned.named_modules()
+                if n.endswith((".mlp.fc2", "DenseReluDense.wo")) and ("blocks.1." in n or "block.1." in n)}
+        return {k: v.clone() for k, v in pruned.state_dict().items()}, last
+
+    full, n_full = run(False)
+    cut, n_cut = run(True)
+    assert full.keys() == cut.keys()
+    for k in full:
+        assert torch.equal(full[k], cut[k]), k
+    # second block of each tower: its last linear is computed once less per forward of the first pass
+    assert len(n_full) == 3 and n_cut.keys() == n_full.keys()
+    assert all(n_cut[k] == n_full[k] - 1 for k in n_full), (n_cut, n_full)      # one grouped forward less
+
+
+def test_statistics_pass_runs_to_the_end_when_the_order_is_not_the_learned_one():
+    """`statistics_only` cuts a forward only when its calls so far are exactly the learned sequence: a block that uses a
+    linear twice never learns an order; a block that calls its linears in another order than the first block computes
+    everything."""
+    from lavis.compression.pruners import calibration as cal
+
+    class Twice(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)
+
+        def forward(self, x):
+            return self.a(self.b(self.a(x)))
+
+    class Ordered(torch.nn.Module):
+        def __init__(self, flip=False):
+            super().__init__()
+            self.a, self.b, self.flip = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), flip
+
+        def forward(self, x):
+            return self.a(self.b(x)) if self.flip else self.b(self.a(x))
+
+    x = torch.randn(3, 4)
+    blk, learned = Twice(), {}
+    for _ in range(2):
+        with cal.statistics_only(cal.find_layers(blk), learned) as so:
+            so.new_forward()
+            y = blk(x)
+            so.end_forward(True)
+        assert torch.equal(y, blk.a(blk.b(blk.a(x))))
+    assert learned["order"] is False
+
+    first, same, flipped, learned = Ordered(), Ordered(), Ordered(flip=True), {}
+    seen_inputs = []
+    with cal.statistics_only(cal.find_layers(first), learned) as so:
+        so.new_forward()
+        first(x)
+        so.end_forward(True)
+    assert learned["order"] == ("a", "b")
+    h = same.b.register_forward_hook(lambda m, i, o: seen_inputs.append(i[0].clone()))
+    with cal.statistics_only(cal.find_layers(same), learned) as so:
+        so.new_forward()
+        with pytest.raises(cal._TailStop):
+            same(x)
+    h.remove()
+    assert len(seen_inputs) == 1 and torch.equal(seen_inputs[0], same.a(x))      # the hook saw b's input; b was not computed
+    assert "forward" not in same.b.__dict__ and not same.b._forward_hooks and not same.a._forward_pre_hooks
+    with cal.statistics_only(cal.find_layers(flipped), learned) as so:
+        so.new_forward()
+        y = flipped(x)                                                           # b first: not the learned order
+        so.end_forward(True)
+    assert torch.equal(y, flipped.a(flipped.b(x)))

@@ -910,6 +910,82 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
     return inps, [None] * len(inps), caches
 
 
+class _TailStop(ValueError):
+    """Raised by `statistics_only` when the block's last linear has handed its input to the statistics hooks."""
+
+
+def tail_skip_enabled():
+    """`VLMC_SKIP_DEAD_TAIL=0`: run the statistics pass to the end of the block like the reference (:308-311 writes
+    `outs[j]` in that pass too, and overwrites every one of them in the second pass before anything reads them)."""
+    return os.environ.get("VLMC_SKIP_DEAD_TAIL", "1") != "0"
+
+
+class statistics_only:
+    """The first pass over a block exists for the hooks on its linears' INPUTS (wanda_pruner.py:303-311,
+    sparsegpt_pruner.py add_batch(inp, out) never reads `out`): what the block computes after its last linear has been
+    given its input -- that linear's own product (fc2 of a ViT block is 27 % of the block's flops), the residual add
+    behind it -- is dead, the second pass overwrites `outs`.  Inside this context the block's forward ends there.
+
+    Which linear is the last one is LEARNED, not assumed: the first forward of a tower's first block runs to the end
+    while the call order of its linears is recorded; afterwards the tail is cut only in a forward whose calls so far
+    are exactly that order (each linear once, same sequence) -- a block that calls a linear twice, or in a different
+    order, or has other linears than the first block had, runs to the end.  The statistics are the same bits either
+    way (tests/test_pruner_host_logic.py, tests/test_replay_invariance_gpu.py)."""
+
+    def __init__(self, subset, learned):
+        self.subset, self.learned = subset, learned          # learned: dict shared by the tower's blocks
+        self.seen, self.handles, self.last = [], [], None
+
+    def __enter__(self):
+        if not tail_skip_enabled() or self.learned.get("order") is False:
+            return self
+        names = {id(m): n for n, m in self.subset.items()}
+
+        def note(mod, args):
+            self.seen.append(names[id(mod)])
+
+        self.handles = [m.register_forward_pre_hook(note) for m in self.subset.values()]
+        order = self.learned.get("order")
+        if order and set(order) == set(self.subset) and len(order) == len(self.subset):
+            last = self.subset[order[-1]]
+            inner = last.forward                             # (possibly forward.invariant_linears' patch)
+
+            def dead_product(x, *a, **kw):
+                if tuple(self.seen) != order:                # not the sequence that was learned: compute
+                    return inner(x, *a, **kw)
+                return x.new_empty(tuple(x.shape[:-1]) + (last.weight.shape[0],))
+
+            def stop(mod, args, out):
+                if tuple(self.seen) == order:
+                    raise _TailStop
+
+            self._had = "forward" in last.__dict__
+            self._inner = inner
+            last.forward = dead_product
+            self.handles.append(last.register_forward_hook(stop))     # after the pruner's hooks: they have seen the input
+            self.last = last
+        return self
+
+    def new_forward(self):
+        self.seen = []
+
+    def end_forward(self, completed):
+        """Called after every forward of the block; `completed` = it ran to the end (no _TailStop)."""
+        if completed and self.learned.get("order") is None:
+            ok = len(set(self.seen)) == len(self.seen) == len(self.subset) and len(self.seen) > 1
+            self.learned["order"] = tuple(self.seen) if ok else False
+
+    def __exit__(self, *exc):
+        for h in self.handles:
+            h.remove()
+        if self.last is not None:
+            if self._had:
+                self.last.forward = self._inner
+            else:
+                del self.last.__dict__["forward"]
+        return False
+
+
 REPLAY_GROUP_DEFAULT = 128
 REPLAY_TOKEN_BUDGET = 1 << 16
 
@@ -1065,11 +1141,16 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
     state = {"inps": inps, "outs": outs}
     group_max = replay_group_size()
 
-    def run_pass(before_sample=None):
+    def run_pass(before_sample=None, outputs=True):
+        """`outputs=False`: the caller only wants its hooks on the linears fed (the first pass of every pruner)."""
         with phases.phase("replay"):
-            _run_pass(before_sample)
+            if outputs or group_max == 1:
+                _run_pass(before_sample, None)
+            else:
+                with statistics_only(subset, tail_learned) as so:
+                    _run_pass(before_sample, so)
 
-    def _run_pass(before_sample):
+    def _run_pass(before_sample, so):
         global _STACKED
         cur_in, cur_out = state["inps"], state["outs"]
         keys = None
@@ -1118,10 +1199,17 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
         for chunk in chunks:
             if before_sample is not None:
                 before_sample(chunk[0])
+            if so is not None:
+                so.new_forward()
             with torch.no_grad(), autocast():
                 if len(chunk) == 1:
                     j = chunk[0]
-                    y = layer(cur_in[j], **caches[j])
+                    try:
+                        y = layer(cur_in[j], **caches[j])
+                    except _TailStop:
+                        continue
+                    if so is not None:
+                        so.end_forward(True)
                     cur_out[j] = y[0] if tuple_output else y
                 else:
                     b0 = cur_in[chunk[0]].shape[0]
@@ -1139,15 +1227,19 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                         kw = stacked_kwargs[key] = _stack_caches([caches[j] for j in chunk])
                     try:
                         y = layer(x, **kw)
+                    except _TailStop:
+                        continue
                     finally:
                         _STACKED = None
+                    if so is not None:
+                        so.end_forward(True)
                     y = y[0] if tuple_output else y
                     slices = [y[t * b0:(t + 1) * b0] for t in range(len(chunk))]
                     slices[0]._vlmc_stack = (y, key, slices)
                     for t, j in enumerate(chunk):
                         cur_out[j] = slices[t]
 
-    graphs, plan, stacked_kwargs = {}, {}, {}
+    graphs, plan, stacked_kwargs, tail_learned = {}, {}, {}, {}
     for i in range(len(layers)):
         layer = layers[i]
         subset = find_layers(layer)

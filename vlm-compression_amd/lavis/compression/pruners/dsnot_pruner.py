@@ -111,7 +111,7 @@ class _DsnotBlockMixin:
         from vlmc import dsnot
         col = DsnotStatCollector(subset)
         try:
-            run_pass(col.next_sample)
+            run_pass(col.next_sample, outputs=False)
         finally:
             col.close()
         stats = col.finalize()

@@ -63,7 +63,7 @@ class _SparseGPTBlockMixin:
 
         handles = [mod.register_forward_hook(make_hook(name)) for name, mod in subset.items()]
         try:
-            run_pass(lambda _j: fed.clear())
+            run_pass(lambda _j: fed.clear(), outputs=False)
         finally:
             for h in handles:
                 h.remove()

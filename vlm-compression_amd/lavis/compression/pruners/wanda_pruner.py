@@ -167,7 +167,7 @@ class _WandaBlockMixin:
         from vlmc import ops, wanda
         col = WandaStatCollector(subset)
         try:
-            run_pass(col.next_sample)
+            run_pass(col.next_sample, outputs=False)
         finally:
             col.close()
         with phases.phase("stat"):
