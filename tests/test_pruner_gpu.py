@@ -317,6 +317,45 @@ def test_tower_memo_in_a_whole_prune_is_bit_identical(monkeypatch):
     assert off.keys() == on.keys() and all(torch.equal(off[k], on[k]) for k in off)
 
 
+def test_capture_phase_runs_again_when_a_remembered_input_was_not_the_one_fed(monkeypatch):
+    """The comparisons of remembered inputs are answered at the end of a capture phase (`_LaterEqual`); when one of them
+    fails -- here the record of forward 0 is tampered with -- the records are dropped and the phase runs again comparing at
+    once: same pruned model as without any memo, and `later_failed` counts the event."""
+    from lavis.compression.pruners import calibration as cal
+
+    def state(model):
+        sd = dict(model.state_dict())
+        for n, mod in model.named_modules():
+            if hasattr(mod, "mask") and torch.is_tensor(mod.mask):
+                sd[n + ".mask*"] = mod.mask
+        return sd
+
+    monkeypatch.setenv("VLMC_TOWER_MEMO", "0")
+    want = state(H.run_pruner("fp32_r50", "cuda:0")[0])
+    monkeypatch.setenv("VLMC_TOWER_MEMO", "1")
+    real_begin = cal.TowerMemo.begin
+    tampered = []
+
+    def begin(self, mode):
+        real_begin(self, mode)
+        if mode == "replay" and self.entries and not tampered:
+            first = self.entries[min(self.entries)]
+            first[0][0][0].add_(1)                      # the remembered block-0 input of forward 0
+            tampered.append(self)
+    monkeypatch.setattr(cal.TowerMemo, "begin", begin)
+    before = cal.graph_stats.get("later_failed", 0)
+    got = state(H.run_pruner("fp32_r50", "cuda:0")[0])
+    assert tampered and cal.graph_stats.get("later_failed", 0) == before + 1
+    assert want.keys() == got.keys() and all(torch.equal(want[k], got[k]) for k in want)
+    # and with the answers taken at once there is nothing to run again: a plain miss for that forward
+    tampered.clear()
+    monkeypatch.setenv("VLMC_LATER_EQUAL", "0")
+    m0 = cal.graph_stats["memo_misses"]
+    got = state(H.run_pruner("fp32_r50", "cuda:0")[0])
+    assert tampered and cal.graph_stats.get("later_failed", 0) == before + 1 and cal.graph_stats["memo_misses"] == m0 + 1
+    assert all(torch.equal(want[k], got[k]) for k in want)
+
+
 def test_graphed_module_proxy_replays_identically_and_falls_back():
     """calibration.GraphedModule (stand-in for already pruned blocks during capture): eager first call, captured second,
     replayed afterwards, one graph per argument signature; gradients / odd arguments go straight to the module."""

@@ -97,6 +97,48 @@ graph_stats = {"captured": 0, "replayed": 0, "fallbacks": 0, "memo_recorded": 0,
 MEMO_MAX_BYTES = 4 << 30
 
 
+class _LaterEqual:
+    """Bit-for-bit comparisons whose answer is collected at the end of a capture phase instead of one device round trip
+    per calibration forward (`torch.equal` waits for the GPU: 2-3 of them per forward were 40 ms of a FlanT5-XL prune).
+    `same(r, v)` answers what can be answered on the host (shapes, dtypes, devices), assumes the bits agree and notes the
+    pair; `failed()` compares all noted pairs in one stacked `torch.equal` per shape -- and reports a tensor that was
+    written to since it was noted as a failure.  Only `capture_block_inputs` installs one: it can run the phase again
+    the plain way when the assumption turns out wrong."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def same(self, r, v):
+        if r.shape != v.shape or r.dtype != v.dtype or r.device != v.device:
+            return False
+        if r is not v:
+            self.pairs.append((r, r._version, v, v._version))
+        return True
+
+    def failed(self):
+        groups = {}
+        for r, rv, v, vv in self.pairs:
+            if r._version != rv or v._version != vv:
+                return True
+            groups.setdefault((tuple(r.shape), r.dtype, r.device), []).append((r, v))
+        self.pairs = []
+        for prs in groups.values():
+            for t in range(0, len(prs), 256):
+                part = prs[t:t + 256]
+                if not torch.equal(torch.stack([a for a, _ in part]), torch.stack([b for _, b in part])):
+                    return True
+        return False
+
+
+_LATER = None                 # the capture phase's _LaterEqual, or None: compare at once
+
+
+def _bits_equal(r, v):
+    if _LATER is not None and r.is_cuda:
+        return _LATER.same(r, v)
+    return r.shape == v.shape and r.dtype == v.dtype and r.device == v.device and bool(torch.equal(r, v))
+
+
 def tower_memo_enabled():
     """Outputs of a finished tower are remembered from one capture phase to the next (`VLMC_TOWER_MEMO=0`: off)."""
     return os.environ.get("VLMC_TOWER_MEMO", "1") != "0"
@@ -112,7 +154,7 @@ class TowerMemo:
     output of its last block; in the next phase the first block compares its inputs BIT FOR BIT with the record of
     the same forward and, if they agree, the blocks hand their input through and the last one returns the recorded
     output -- the tensor the blocks would compute again.  Guards: the tower's parameters and buffers must be where
-    they were and sum (float64, per tensor) to what they summed when the record was made; the blocks are in eval
+    they were and their absolute values sum (float64, per tensor) to what they summed when the record was made; the blocks are in eval
     mode; every recorded forward called the blocks exactly once each, in order, with a single tensor as output;
     anything else leaves the blocks to run."""
 
@@ -128,7 +170,19 @@ class TowerMemo:
         (tensors on several devices, exotic dtypes): then there is no memo."""
         ts = [t for b in blocks for t in list(b.parameters()) + list(b.buffers())]
         try:
-            sums = torch.stack([torch.sum(t.detach(), dtype=torch.float64) for t in ts]) if ts else torch.zeros(0)
+            # sum |x| in float64 per tensor, one fused launch per dtype (a reduction per tensor was 1 600 launches per prune)
+            by = {}
+            for n_, t in enumerate(ts):
+                by.setdefault((t.dtype, t.device), []).append(n_)
+            sums = [None] * len(ts)
+            for (dt, _dev), idx in by.items():
+                if dt.is_floating_point:
+                    vals = torch._foreach_norm([ts[n_].detach() for n_ in idx], 1, dtype=torch.float64)
+                else:
+                    vals = [torch.sum(ts[n_].detach(), dtype=torch.float64) for n_ in idx]
+                for n_, v in zip(idx, vals):
+                    sums[n_] = v
+            sums = torch.stack(sums) if ts else torch.zeros(0)
         except Exception:
             return None
         return tuple(t.data_ptr() for t in ts), sums
@@ -162,7 +216,7 @@ class TowerMemo:
             if isinstance(r, torch.Tensor) != isinstance(v, torch.Tensor):
                 return False
             if isinstance(r, torch.Tensor):
-                if r.shape != v.shape or r.dtype != v.dtype or r.device != v.device or not torch.equal(r, v):
+                if not _bits_equal(r, v):
                     return False
             elif r is not v and r != v:
                 return False
@@ -569,7 +623,7 @@ class TowerGraph:
     @staticmethod
     def _same_inputs(r, args, kwargs):
         a, b = TowerGraph._ext(r["args"], r["kwargs"]), TowerGraph._ext(args, kwargs)
-        return len(a) == len(b) and all(x.shape == y.shape and x.dtype == y.dtype and bool(torch.equal(x, y)) for x, y in zip(a, b))
+        return len(a) == len(b) and all(_bits_equal(x, y) for x, y in zip(a, b))
 
     @torch.no_grad()
     def run_deferred(self):
@@ -629,6 +683,11 @@ class GraphedModule(nn.Module):
 
     def __getattr__(self, name):
         return getattr(self.__dict__["_wrapped"], name)
+
+    def __call__(self, *args, **kwargs):
+        # (a proxy carries no hooks: nn.Module's call machinery in front of `forward` was a third of the cost of handing a
+        # remembered output through the 39 + 24 proxies of a calibration forward)
+        return self.forward(*args, **kwargs)
 
     @staticmethod
     def _sig(v):
@@ -780,8 +839,48 @@ def capture_block_inputs(model, dataloader, n_samples, module_to_process, forwar
                                      proxy_cache=proxy_cache)
 
 
+def later_check_enabled():
+    """`VLMC_LATER_EQUAL=0`: every comparison of a remembered input with the one at hand waits for its answer."""
+    return os.environ.get("VLMC_LATER_EQUAL", "1") != "0"
+
+
 def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forward_to_cache, lora_model, *, vit,
                           model_prefix, count_batches, done_towers, proxy_cache):
+    global _LATER
+    total, batches = 0, []
+    for batch in dataloader:                       # which batches the reference would consume
+        if total >= n_samples:
+            break
+        if count_batches:
+            total += 1
+        elif vit or "image" in batch:
+            total += batch["image"].shape[0]
+        else:
+            total += len(batch["text_input"])
+        batches.append(batch)
+    args = (model, batches, module_to_process, forward_to_cache, lora_model)
+    kw = dict(vit=vit, model_prefix=model_prefix, done_towers=done_towers, proxy_cache=proxy_cache)
+    p0 = next(model.parameters(), None)
+    if done_towers and proxy_cache is not None and later_check_enabled() and p0 is not None and p0.is_cuda and _LATER is None:
+        # what finished towers remember of the previous phase is trusted while the forwards run and verified afterwards
+        _LATER = _LaterEqual()
+        try:
+            res = _capture_once(*args, **kw)
+            bad = _LATER.failed()
+        finally:
+            _LATER = None
+        if not bad:
+            return res
+        # a remembered input was not what this phase fed its tower: forget the records, run the phase again, comparing at once
+        graph_stats["later_failed"] = graph_stats.get("later_failed", 0) + 1
+        for key, val in list(proxy_cache.items()):
+            if isinstance(val, TowerMemo):
+                val._drop()
+    return _capture_once(*args, **kw)
+
+
+def _capture_once(model, batches, module_to_process, forward_to_cache, lora_model, *, vit, model_prefix, done_towers,
+                  proxy_cache):
     layers = get_module_recursive(model, module_to_process)
     keys = None if vit else _keys_for(model_prefix)
     arrived = []                                   # (index of the calibration forward, block-0 input, cached kwargs)
@@ -831,18 +930,6 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
     # blocks of towers that were pruned before this one (`done_towers`: their module paths) replay from HIP graphs
     undo = _wrap_towers(model, [t for t in (done_towers or []) if t != module_to_process], proxy_cache)
     try:
-        total = 0
-        batches = []
-        for batch in dataloader:                       # which batches the reference would consume
-            if total >= n_samples:
-                break
-            if count_batches:
-                total += 1
-            elif vit or "image" in batch:
-                total += batch["image"].shape[0]
-            else:
-                total += len(batch["text_input"])
-            batches.append(batch)
         if world > 1 and len(batches) % world != 0:
             raise RuntimeError(f"calibration sharding needs the {len(batches)} calibration batches to divide evenly "
                                f"over {world} ranks (set VLMC_SHARD_CALIB=0 to run as replicas)")
