@@ -189,6 +189,8 @@ def install_dsnot(monkeypatch):
     """vlmc.dsnot's three C-ABI entry points replaced; DsnotInputStat / gather_stats stay the product's."""
     from vlmc import dsnot
     monkeypatch.setattr(dsnot, "act_moments", dsnot_act_moments)
+    monkeypatch.setattr(dsnot, "act_moments_calls", lambda x, calls: torch.stack(
+        [dsnot_act_moments(c) for c in x.reshape(calls, -1, x.shape[-1])], dim=1))
     monkeypatch.setattr(dsnot, "stats_update", dsnot_stats_update)
     monkeypatch.setattr(dsnot, "prune_linear", oracle_dsnot_prune_linear)
 

@@ -197,3 +197,23 @@ def test_list_kernel_capacity_falls_back_to_cycle_kernel():
     ev_a, stop_a = _refine_events(Wd, st, keep, 0, 0, 200, 0.01, lists=True)
     ev_b, stop_b = _refine_events(Wd, st, keep, 0, 0, 200, 0.01, lists=False)
     assert torch.equal(ev_a, ev_b) and torch.equal(stop_a, stop_b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+def test_moments_of_stacked_calls_equal_the_per_call_launches(dtype):
+    """One launch for the samples of a grouped replay forward (`act_moments_calls`) gives each sample the bits of its own
+    launch; `DsnotInputStat.ordered()` puts out-of-order groups back into sample order."""
+    from vlmc import dsnot
+    g = torch.Generator().manual_seed(5)
+    x = ((torch.randn(6 * 2, 9, 1408, generator=g) * 0.5) + 0.2).to(dtype).to(DEV)       # 6 calls of batch 2
+    one = torch.stack([dsnot.act_moments(x[2 * c:2 * c + 2].reshape(1, -1, 1408)) for c in range(6)], dim=1)
+    assert torch.equal(dsnot.act_moments_calls(x, 6), one)
+    a, b = dsnot.DsnotInputStat(1408, DEV), dsnot.DsnotInputStat(1408, DEV)
+    for c in range(6):
+        a.add_call(x[2 * c:2 * c + 2])
+    b.add_calls(torch.cat([x[8:12], x[0:4]]), 4, (4, 5, 0, 1))        # groups of non-neighbouring samples, late group first
+    b.add_calls(x[4:8], 2, (2, 3))
+    a.finalize(); b.finalize()
+    for k in ("scaler_row", "sum_row", "var_row", "sqrt_row"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert a.nsamples == b.nsamples == 12 and a.ntokens == b.ntokens

@@ -111,11 +111,15 @@ def test_dsnot_pruner_on_gpu_every_linear_matches_oracle(name, monkeypatch):
     from vlmc import dsnot
     real = dsnot.prune_linear
     counts = {"linears": 0, "moments": 0}
-    real_add = dsnot.DsnotInputStat.add_call
+    real_moments, real_moments_calls = dsnot.act_moments, dsnot.act_moments_calls
 
-    def counted_add(self, x):
+    def counted(x):
         counts["moments"] += 1
-        return real_add(self, x)
+        return real_moments(x)
+
+    def counted_calls(x, calls):
+        counts["moments"] += 1
+        return real_moments_calls(x, calls)
 
     def checked(weight, stat, ratio, **kw):
         W0 = weight.detach().clone().cpu()
@@ -137,10 +141,11 @@ def test_dsnot_pruner_on_gpu_every_linear_matches_oracle(name, monkeypatch):
         return keep
 
     monkeypatch.setattr(dsnot, "prune_linear", checked)
-    monkeypatch.setattr(dsnot.DsnotInputStat, "add_call", counted_add)
+    monkeypatch.setattr(dsnot, "act_moments", counted)
+    monkeypatch.setattr(dsnot, "act_moments_calls", counted_calls)
     pruned, _ = H.run_dsnot_pruner(name, "cuda:0")
     assert counts["linears"] == 2 * 4 + 2 * 7 + 2 * 11
-    assert counts["moments"] == 6 * (2 * 4 + 2 * 4 + 2 * 7)        # one launch per distinct input tensor
+    assert counts["moments"] == 2 * 4 + 2 * 4 + 2 * 7              # one launch per distinct input tensor, all 6 samples in it
     st = H.compare_with_golden(name, pruned, exact=False, min_mask_agreement=0.99, which="dsnot_e2e")
     print(name, st)
 

@@ -49,7 +49,7 @@ class DsnotStatCollector:
         from vlmc import dsnot
         self._dsnot = dsnot
         self.subset = subset
-        self.calls = {n: [] for n in subset}              # per linear: (sample index, single-call record) per hook call
+        self.calls = {n: [] for n in subset}              # per linear: one record (of one or more samples) per hook call
         self._cache = {}
         self._cur = -1
         self.handles = [m.register_forward_hook(self._make_hook(n)) for n, m in subset.items()]
@@ -63,15 +63,12 @@ class DsnotStatCollector:
             hit = self._cache.get(key)
             if hit is None:
                 stacked = cal.stacked_samples()              # batched replay: one record per stacked calibration sample
-                calls, b0, idx = stacked if stacked and stacked[0] * stacked[1] == x.shape[0] else (1, x.shape[0], (self._cur,))
-                recs = []
-                for c in range(calls):
-                    st = self._dsnot.DsnotInputStat(x.shape[-1], x.device)
-                    st.add_call(x[c * b0:(c + 1) * b0])      # one launch: sum of squares, sum, variance over tokens
-                    recs.append((idx[c], st))
-                hit = (x, recs)                              # `x` stays referenced until the next sample (see wanda collector)
+                calls, _b0, idx = stacked if stacked and stacked[0] * stacked[1] == x.shape[0] else (1, x.shape[0], (self._cur,))
+                st = self._dsnot.DsnotInputStat(x.shape[-1], x.device)
+                st.add_calls(x, calls, idx)                  # ONE launch: sum of squares, sum, variance over tokens, per sample
+                hit = (x, st)                                # `x` stays referenced until the next sample (see wanda collector)
                 self._cache[key] = hit
-            self.calls[name].extend(hit[1])
+            self.calls[name].append(hit[1])
         return hook
 
     def next_sample(self, j=None):
@@ -88,8 +85,7 @@ class DsnotStatCollector:
         """{name: DsnotInputStat}; linears whose hooks saw identical tensors share the object."""
         shared, out, order = {}, {}, []
         for name, calls in self.calls.items():
-            calls = [c for _, c in sorted(calls, key=lambda r: r[0])]      # the reference's sample order (grouped replay)
-            sig = tuple(id(c) for c in calls)
+            sig = tuple(id(c) for c in calls)                # (DsnotInputStat.ordered() restores the reference's sample order)
             st = shared.get(sig)
             if st is None:
                 mod = self.subset[name]

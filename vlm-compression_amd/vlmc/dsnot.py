@@ -43,34 +43,69 @@ def stats_update(in_features, device, normsq, sums, vars_, tokens, batch):
     return scaler, sum_row, var_row, sqrt_row, (normsq, sums, vars_, tok)
 
 
+def act_moments_calls(x: torch.Tensor, calls: int) -> torch.Tensor:
+    """[3, calls, in] fp32 for `calls` hook calls stacked along dim 0 of x [calls * b, tokens, in] (a grouped replay
+    forward, calibration.stacked_samples): the same per-call moments as `act_moments`, ONE launch for all of them
+    (a launch per sample and distinct linear input was 54 000 launches -- 0.7 s of host time -- per FlanT5-XL prune)."""
+    x = x.reshape(calls, -1, x.shape[-1])
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    _need_gpu(x)
+    out = torch.empty((3, calls, x.shape[-1]), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().vlmc_act_moments(x.data_ptr(), _dtype_code(x), calls, x.shape[1], x.shape[2], x.stride(1), x.stride(0),
+                                            out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), _stream()))
+    return out
+
+
 class DsnotInputStat:
     """Statistics of ONE distinct linear input (shared by the linears that receive it)."""
 
     def __init__(self, in_features: int, device):
         self.in_features, self.device = in_features, device
-        self.moments, self.tokens, self.batches = [], [], []           # per hook call: [3, in] tensor, #tokens, batch
+        # per launch: (moments [3, n, in], tokens per call [n], batch per call [n], calibration sample of each call [n] or None)
+        self.blocks = []
         self.scaler_row = self.sum_row = self.var_row = self.sqrt_row = None
         self.nsamples = self.ntokens = 0
 
-    def add_call(self, x: torch.Tensor):
+    def add_call(self, x: torch.Tensor, sample=None):
         b = x.shape[0] if x.dim() == 3 else 1
         x = x.reshape(1, -1, x.shape[-1])
-        self.moments.append(act_moments(x))
-        self.tokens.append(x.shape[1]); self.batches.append(b)
+        self.blocks.append((act_moments(x).unsqueeze(1), [x.shape[1]], [b], None if sample is None else [sample]))
+
+    def add_calls(self, x: torch.Tensor, calls: int, samples):
+        """x [calls * b, tokens, in]: `calls` hook calls of the reference in one tensor, for calibration samples `samples`."""
+        if calls == 1:
+            return self.add_call(x, samples[0])
+        b = x.shape[0] // calls
+        self.blocks.append((act_moments_calls(x, calls), [b * x.shape[1]] * calls, [b] * calls, list(samples)))
 
     def extend(self, other: "DsnotInputStat"):
         """Append the call records of `other` (used when hook-level records are merged per linear input)."""
-        self.moments += other.moments; self.tokens += other.tokens; self.batches += other.batches
+        self.blocks += other.blocks
+
+    def ordered(self):
+        """(moments [3, N, in], tokens [N], batches [N]) of all calls, in calibration-sample order (stable: calls without a
+        sample index keep their arrival order)."""
+        if not self.blocks:
+            return torch.zeros((3, 0, self.in_features), dtype=torch.float32, device=self.device), [], []
+        mom = self.blocks[0][0] if len(self.blocks) == 1 else torch.cat([b[0] for b in self.blocks], dim=1)
+        tokens = [t for b in self.blocks for t in b[1]]
+        batches = [t for b in self.blocks for t in b[2]]
+        if all(b[3] is not None for b in self.blocks):
+            sample = [t for b in self.blocks for t in b[3]]
+            order = sorted(range(len(sample)), key=lambda i: sample[i])
+            if order != list(range(len(sample))):
+                mom = mom.index_select(1, torch.tensor(order, dtype=torch.int64, device=mom.device))
+                tokens, batches = [tokens[i] for i in order], [batches[i] for i in order]
+        return mom, tokens, batches
 
     def finalize(self, gathered=None):
-        """gathered = (moments [n_calls, 3, in], tokens list, batches list) replaces the local records."""
-        mom = torch.stack(self.moments) if gathered is None else gathered[0]
-        tokens = self.tokens if gathered is None else gathered[1]
-        batches = self.batches if gathered is None else gathered[2]
+        """gathered = (moments [3, n_calls, in], tokens list, batches list) replaces the local records."""
+        mom, tokens, batches = self.ordered() if gathered is None else gathered
         assert len(set(batches)) <= 1, "DSnoT statistics expect a constant calibration batch size"
         b = batches[0] if batches else 1
         self.scaler_row, self.sum_row, self.var_row, self.sqrt_row, self._keep = stats_update(
-            self.in_features, self.device, mom[:, 0], mom[:, 1], mom[:, 2], tokens, b)
+            self.in_features, self.device, mom[0], mom[1], mom[2], tokens, b)
         self.nsamples = len(tokens) * b
         self.ntokens = int(sum(tokens))
         return self
@@ -86,13 +121,14 @@ def gather_stats(stats):
             st.finalize()
         return stats
     for st in stats:
-        local = torch.stack(st.moments).contiguous()                      # [calls, 3, in]
+        mom, tokens, batches = st.ordered()
+        local = mom.permute(1, 0, 2).contiguous()                         # [calls, 3, in]
         allm = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(allm, local)
-        tok = torch.tensor(st.tokens, dtype=torch.int64, device=local.device)
+        tok = torch.tensor(tokens, dtype=torch.int64, device=local.device)
         allt = torch.empty(world * tok.numel(), dtype=torch.int64, device=local.device)
         dist.all_gather_into_tensor(allt, tok)
-        st.finalize((allm, allt.cpu().tolist(), st.batches * world))
+        st.finalize((allm.permute(1, 0, 2), allt.cpu().tolist(), batches * world))
     return stats
 
 
