@@ -164,12 +164,21 @@ def test_matrix_select_model_shapes_vs_oracle(shape, ratio):
     assert abs(n - int(W.numel() * ratio)) <= 64                 # strict '<' may drop a few tied elements only
 
 
-def test_matrix_select_fallback_path_is_exact(monkeypatch):
+@pytest.mark.parametrize("when", ["1", "2"])
+def test_matrix_select_fallback_path_is_exact(when, monkeypatch):
+    """1: the job fails before anything is written.  2: it fails at barrier B, AFTER the chunks that the merged histogram
+    decides have been written (mask bytes and zeroed weights): the exact select of the job's last workgroup, reading a W
+    that is already partly zeroed, must still write the same mask and weights."""
+    monkeypatch.setenv("VLMC_MATRIX_FORCE_SLOW", when)
     W, s = _w(512, 1408, torch.float16, 12)
-    monkeypatch.setenv("VLMC_MATRIX_FORCE_SLOW", "1")
     _check_matrix(W, s, int(W.numel() * 0.5))
     _check_matrix(W, s, 0)
     _check_matrix(W, s, W.numel() - 1)
+    for seed, shape, ratio in ((41, (4224, 1408), 0.5), (42, (1408, 6144), 0.3), (43, (1000, 1001), 0.7)):
+        W, s = _w(shape[0], shape[1], torch.float16, seed)
+        _check_matrix(W, s, int(W.numel() * ratio))
+    W, s = _w(600, 1408, torch.bfloat16, 44, zero_frac=0.5)          # re-pruning half-zero weights
+    _check_matrix(W, s, int(W.numel() * 0.6))
 
 
 @pytest.mark.parametrize("zero_frac,ratio", [(0.5, 0.5), (0.5, 0.25), (0.5, 0.75), (0.9, 0.95)])

@@ -1034,7 +1034,7 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
     const SelJob &jb = b.job[find_job(b, blockIdx.x, wg)];
     const int tid = threadIdx.x;
     uint32_t *ws = jb.ws;
-    bool fail = b.p0 != 0;                                       // test hook: force the fallback
+    bool fail = b.p0 == 1;                                       // test hook: force the fallback
     const uint32_t in_f = jb.in_f;
     typename T::raw *W = static_cast<typename T::raw *>(jb.W);
     // ---- P0: the sample's loads go out first, its bracket is computed while the row chunks stream in ----------
@@ -1107,7 +1107,8 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
         }
     }
     VLMC_FSTAMP(1);
-    uint32_t thr = 0;
+    uint32_t thr = 0, deferred = 0;
+    bool early = false;                                          // decided register chunks were written before barrier B
     if (!fail) {
         const uint32_t wsum = wave_sum_u32_dpp(below);
         if ((tid & 63) == 0) red[tid >> 6] = wsum;
@@ -1123,7 +1124,9 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my atomics have been performed
         __syncthreads();
+#ifndef VLMC_FUSED_STAMP_SCAN
         VLMC_FSTAMP(2);
+#endif
         if (tid == 0) red[34] = grid_arrive_wait(ws, C_BAR_A, jb.nwg) ? 1u : 0u;      // ---- barrier A
         __syncthreads();
         fail = red[34] == 0;
@@ -1202,10 +1205,61 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
             }
             if (fail) bshift = 0;
             thr = lob;                                           // one-key bin: ties with the threshold are kept
+#ifdef VLMC_FUSED_STAMP_SCAN                                      // (diagnostic: the "flush" stamp marks the end of the scan instead)
+            VLMC_FSTAMP(2);
+#endif
             if (bshift) {
                 const uint32_t width = 1u << bshift;
                 if (tid == 0) red[35] = 0;
                 __syncthreads();
+                // ONE pass over the registers does both jobs.  A chunk with no key inside the undecided bin [lob, lob + width)
+                // is decided by the merged histogram alone -- key < lob: pruned, anything else kept, whatever the exact
+                // threshold inside the bin turns out to be -- and is written NOW: the 76 MB of stores drain while the
+                // candidates are exchanged (barrier B) and ranked (P3).  The few hundred chunks that do hold such a key
+                // give their keys to the candidate list and wait for the threshold (`deferred`, one bit per register chunk).
+                // (Before: a candidate pass with a branch per element, 19 us, and the stores only after P3.)
+                // A job that fails from here on has part of W and of the mask written: every such element is on its final
+                // side of any threshold inside the bin, and a pruned weight that reads as zero still ranks below the bin, so
+                // the last workgroup's exact select over the whole matrix decides -- and writes -- the same.
+                early = true;
+                auto early_chunk = [&](Chunk8<T> &c, uint32_t rowu, uint32_t col0) -> bool {
+                    float sq[8];
+                    load_sq(col0, sq);
+                    uint32_t key[8];
+                    uint32_t keepbits = 0, inb = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (ALIGNED || col0 + j < in_f) {
+                            key[j] = stream_key(ieee_mul(fabsf(to_f32<T>(c.v[j])), sq[j]));
+                            keepbits |= (key[j] >= lob ? 1u : 0u) << j;
+                            inb |= ((key[j] >= lob && key[j] - lob < width) ? 1u : 0u) << j;
+                        } else {
+                            key[j] = 0;
+                            keepbits |= 1u << j;
+                        }
+                    }
+                    if (inb) {                                               // rare: one branch per chunk
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if ((inb >> j) & 1u) {
+                                const uint32_t pos = atomicAdd(&red[35], 1u);
+                                if (pos < uint32_t(kFusedCand)) cand[pos] = key[j] - lob;
+                            }
+                        return true;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (!((keepbits >> j) & 1u)) c.v[j] = typename T::raw(0);
+#ifdef VLMC_FUSED_EXP                                             // diagnostic builds only (never shipped): which stores cost what
+                    if (!(VLMC_FUSED_EXP & 2)) store_mask_chunk<ALIGNED, !(VLMC_FUSED_EXP & 4)>(jb.mask + int64_t(rowu) * in_f, col0, in_f, keepbits);
+                    if (!(VLMC_FUSED_EXP & 1) && b.apply_zero && keepbits != 0xFFu)
+                        store_row_chunk<T, ALIGNED, !(VLMC_FUSED_EXP & 4)>(W + int64_t(rowu) * jb.ldw, col0, in_f, c);
+#else
+                    store_mask_chunk<ALIGNED, true>(jb.mask + int64_t(rowu) * in_f, col0, in_f, keepbits);
+                    if (b.apply_zero && keepbits != 0xFFu) store_row_chunk<T, ALIGNED, true>(W + int64_t(rowu) * jb.ldw, col0, in_f, c);
+#endif
+                    return false;
+                };
                 auto cand_chunk = [&](const Chunk8<T> &c, uint32_t col0) {
                     float sq[8];
                     load_sq(col0, sq);
@@ -1223,11 +1277,11 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
                 uint32_t row = row0, cir = cir0;
 #pragma unroll
                 for (int u = 0; u < R; ++u) {
-                    if (cb0 + uint32_t(u) * cw.step < cw.total) cand_chunk(raw[u], cir * 8);
+                    if (cb0 + uint32_t(u) * cw.step < cw.total && early_chunk(raw[u], row, cir * 8)) deferred |= 1u << u;
                     VLMC_WALK_NEXT(row, cir);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                for (uint32_t cb = cb0 + uint32_t(R) * cw.step; cb < cw.total; cb += cw.step) {
+                for (uint32_t cb = cb0 + uint32_t(R) * cw.step; cb < cw.total; cb += cw.step) {   // past the registers: keys only
                     cand_chunk(load_row_chunk<T, ALIGNED>(W + int64_t(row) * jb.ldw, cir * 8, in_f), cir * 8);
                     VLMC_WALK_NEXT(row, cir);
                 }
@@ -1245,7 +1299,7 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
                 VLMC_FSTAMP(4);
                 if (tid == 0) red[34] = grid_arrive_wait(ws, C_BAR_B, jb.nwg) ? 1u : 0u;     // ---- barrier B
                 __syncthreads();
-                fail = red[34] == 0;
+                fail = red[34] == 0 || b.p0 == 2;                // (test hook 2: fail with the decided chunks already written)
                 VLMC_FSTAMP(5);
                 // ---- P3: exact rank `rankb` among the candidates (keys relative to lob, < 2^bshift) ----------
                 uint32_t ncand = 0;
@@ -1306,14 +1360,20 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
             keepbits |= (pruned ? 0u : 1u) << j;
             if (pruned) c.v[j] = typename T::raw(0);
         }
+#ifdef VLMC_FUSED_EXP                                             // diagnostic builds only (never shipped): which stores cost what
+        if (!(VLMC_FUSED_EXP & 2)) store_mask_chunk<ALIGNED, !(VLMC_FUSED_EXP & 4)>(jb.mask + int64_t(rowu) * in_f, col0, in_f, keepbits);
+        if (!(VLMC_FUSED_EXP & 1) && b.apply_zero && keepbits != 0xFFu)
+            store_row_chunk<T, ALIGNED, !(VLMC_FUSED_EXP & 4)>(W + int64_t(rowu) * jb.ldw, col0, in_f, c);
+#else
         store_mask_chunk<ALIGNED, true>(jb.mask + int64_t(rowu) * in_f, col0, in_f, keepbits);
         if (b.apply_zero && keepbits != 0xFFu) store_row_chunk<T, ALIGNED, true>(W + int64_t(rowu) * jb.ldw, col0, in_f, c);
+#endif
     };
     if (!fail) {                                                 // (a failed job is written by its last workgroup, below)
         uint32_t row = row0, cir = cir0;
 #pragma unroll
-        for (int u = 0; u < R; ++u) {
-            if (cb0 + uint32_t(u) * cw.step < cw.total) apply_chunk(raw[u], row, cir * 8);
+        for (int u = 0; u < R; ++u) {                            // (after an early pass: only the chunks that waited for thr)
+            if (cb0 + uint32_t(u) * cw.step < cw.total && (!early || ((deferred >> u) & 1u))) apply_chunk(raw[u], row, cir * 8);
             VLMC_WALK_NEXT(row, cir);
             __builtin_amdgcn_sched_barrier(0);
         }
