@@ -880,8 +880,13 @@ __global__ __launch_bounds__(1024) void matrix_apply_kernel(const SelBatch b) {
 //             select, but streaming the matrix (4 x 8-bit radix over the keys inside [lob, lob + width))
 // WRITE_ALL (the fused kernel's own fallback): nothing has been written yet -- select over the whole matrix and
 // write EVERY mask byte, without looking at the control words.
+// `floor` (WRITE_ALL only): keys below it count as key 0.  The fused kernel hands over a job whose DECIDED chunks are already
+// being written -- weights with a key below the undecided bin are turning into zeros while this select makes its passes over
+// the matrix, and an element must not be one key in one pass and another in the next.  With every key below the bin's lower
+// edge read as 0, the original weight and its zeroed self are the same key in every pass; the threshold (>= the edge) and
+// what lies below it are unchanged.
 template <typename T, bool WRITE_ALL>
-__device__ void matrix_resolve_job(const SelBatch &b, const SelJob &jb, uint32_t *hist, uint32_t *red) {
+__device__ void matrix_resolve_job(const SelBatch &b, const SelJob &jb, uint32_t *hist, uint32_t *red, uint32_t floor = 0) {
     uint32_t *ws = jb.ws;
     const int tid = threadIdx.x;
     if (!WRITE_ALL && ws[kCtrl + C_NONE]) return;
@@ -895,7 +900,11 @@ __device__ void matrix_resolve_job(const SelBatch &b, const SelJob &jb, uint32_t
     const uint32_t numel = jb.out_f * jb.in_f;
     const uint32_t n_items = from_list ? ncand : numel;
     typename T::raw *W = static_cast<typename T::raw *>(jb.W);
-    auto key_of = [&](uint32_t i) -> uint32_t { return from_list ? ws[kCand + 2 * i + 1] : element_key<T>(jb, i); };
+    auto key_of = [&](uint32_t i) -> uint32_t {
+        if (from_list) return ws[kCand + 2 * i + 1];
+        const uint32_t key = element_key<T>(jb, i);
+        return key < floor ? 0u : key;
+    };
     auto undecided = [&](uint32_t key) -> bool { return fail || (key >= lob && key - lob < width); };
     // rank-r key among the undecided keys: MSD radix, 8 bits per pass
     uint32_t prefix = 0, pmask = 0;
@@ -1107,7 +1116,7 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
         }
     }
     VLMC_FSTAMP(1);
-    uint32_t thr = 0, deferred = 0;
+    uint32_t thr = 0, deferred = 0, early_floor = 0;
     bool early = false;                                          // decided register chunks were written before barrier B
     if (!fail) {
         const uint32_t wsum = wave_sum_u32_dpp(below);
@@ -1218,10 +1227,12 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
                 // candidates are exchanged (barrier B) and ranked (P3).  The few hundred chunks that do hold such a key
                 // give their keys to the candidate list and wait for the threshold (`deferred`, one bit per register chunk).
                 // (Before: a candidate pass with a branch per element, 19 us, and the stores only after P3.)
-                // A job that fails from here on has part of W and of the mask written: every such element is on its final
-                // side of any threshold inside the bin, and a pruned weight that reads as zero still ranks below the bin, so
-                // the last workgroup's exact select over the whole matrix decides -- and writes -- the same.
+                // A job that fails from here on has part of W and of the mask written (and still being written): every such
+                // element is on its final side of any threshold inside the bin; the last workgroup's exact select over the
+                // whole matrix reads every key below the bin as 0 (matrix_resolve_job's `floor`), so a weight and its zeroed
+                // self are one key to it, and it decides -- and writes -- the same.
                 early = true;
+                early_floor = lob;
                 auto early_chunk = [&](Chunk8<T> &c, uint32_t rowu, uint32_t col0) -> bool {
                     float sq[8];
                     load_sq(col0, sq);
@@ -1402,7 +1413,7 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
     // ---- of them has written W or the mask), then the histogram and control words go back to zero -------------------
     __syncthreads();
     if (red[37] != jb.nwg - 1) return;
-    if (fail) matrix_resolve_job<T, true>(b, jb, lh, red);
+    if (fail) matrix_resolve_job<T, true>(b, jb, lh, red, early ? early_floor : 0u);
     __syncthreads();
 #ifdef VLMC_FUSED_STAMPS
     for (int i = tid; i < kCtrl + 16; i += 1024)                 // (keep the phase clocks)
