@@ -335,6 +335,7 @@ def test_capture_phase_runs_again_when_a_remembered_input_was_not_the_one_fed(mo
                 sd[n + ".mask*"] = mod.mask
         return sd
 
+    monkeypatch.setenv("VLMC_LATER_EQUAL", "1")
     monkeypatch.setenv("VLMC_TOWER_MEMO", "0")
     want = state(H.run_pruner("fp32_r50", "cuda:0")[0])
     monkeypatch.setenv("VLMC_TOWER_MEMO", "1")
@@ -517,6 +518,7 @@ def test_tower_batching_gives_the_per_sample_forward_bit_for_bit(ragged, monkeyp
     for j, n in enumerate(lens):
         b = toy_models.make_batches(1, txt_len=n if ragged else 5, out_len=(2 + n % 3) if ragged else 4, seed=100 + j)[0]
         batches.append({k: t.to("cuda:0") for k, t in b.items()})
+    monkeypatch.setenv("VLMC_LINEAR_FWD", "1")              # (tower batching needs the invariant kernel)
     monkeypatch.setenv("VLMC_TOWER_MEMO", "0")
     monkeypatch.setenv("VLMC_TOWER_BATCH", "0")
     monkeypatch.setenv("VLMC_TOWER_GRAPH", "0")
