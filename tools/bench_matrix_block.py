@@ -7,11 +7,16 @@ import torch
 from vlmc import ops
 
 ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=30)
+ap.add_argument("--acts", action="store_true", help="sqrt(scaler_row) from synthetic activations N(0.1, 1) like bench.py's kernel pass "
+                "(nearly the same for every column) instead of a spread of values")
 args = ap.parse_args()
 dev = "cuda:0"
 shapes = [(4224, 1408), (1408, 1408), (6144, 1408), (1408, 6144)]
 W0 = [(torch.randn(o, i, device=dev) * 0.02).half() for o, i in shapes]
-sq = [ops.sqrt_scaler(torch.rand(i, device=dev) * 4 + 0.01) for o, i in shapes]
+if args.acts:
+    sq = [ops.sqrt_scaler((torch.randn(128 * 64, i, device=dev) + 0.1).pow(2).mean(0)) for o, i in shapes]
+else:
+    sq = [ops.sqrt_scaler(torch.rand(i, device=dev) * 4 + 0.01) for o, i in shapes]
 W = [w.clone() for w in W0]
 masks = [torch.empty(w.shape, dtype=torch.bool, device=dev) for w in W]
 parts = [torch.empty(ops.select_partials("matrix", *w.shape), dtype=torch.float64, device=dev) for w in W]

@@ -582,6 +582,38 @@ __device__ bool block_find_rank(const uint32_t (&h)[4], uint32_t need, uint32_t 
     return bin != 0xFFFFFFFFu;
 }
 
+// Two searches over the same histogram in one prefix scan (the sample bracket's two ends): bins of ranks need_a <= need_b.
+// A rank >= total gives bin 0xFFFFFFFF.  red: >= 24 words.
+__device__ void block_find_rank2(const uint32_t (&h)[4], uint32_t need_a, uint32_t need_b, uint32_t *red, uint32_t &bin_a,
+                                 uint32_t &bin_b) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t s = h[0] + h[1] + h[2] + h[3];
+    const uint32_t incl = wave_incl_scan_u32_dpp(s);
+    if (lane == 63) red[wave] = incl;
+    if (tid == 0) { red[16] = 0xFFFFFFFFu; red[20] = 0xFFFFFFFFu; }
+    __syncthreads();
+    uint32_t off = 0;
+    for (int w = 0; w < wave; ++w) off += red[w];
+    const uint32_t hi = off + incl, lo = hi - s;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const uint32_t need = which ? need_b : need_a;
+        if (lo <= need && need < hi) {
+            uint32_t cum = lo;
+            int i = 0;
+            for (; i < 3; ++i) {
+                if (cum + h[i] > need) break;
+                cum += h[i];
+            }
+            red[which ? 20 : 16] = uint32_t(tid * 4 + i);
+        }
+    }
+    __syncthreads();
+    bin_a = red[16];
+    bin_b = red[20];
+    __syncthreads();
+}
+
 // Key used inside the streaming passes: score >= +0 or NaN, so clearing the sign bit orders every finite score
 // and +inf like score_key() and leaves NaNs above +inf (0x7F800001..0x7FFFFFFF) -- one instruction.  A bin that
 // reaches above +inf is handed to the fallback, which uses score_key()'s single NaN key.
@@ -594,12 +626,6 @@ __device__ __forceinline__ uint32_t element_key(const SelJob &jb, uint32_t e) {
     return score_key(ieee_mul(fabsf(to_f32<T>(w)), jb.sq[col]));
 }
 
-// Coarse bin of a key for the sample histogram: sign/exponent + 3 mantissa bits (2^20 keys per bin).
-constexpr int kCoarseShift = 20;
-__device__ __forceinline__ uint32_t coarse_bin(uint32_t key) {
-    const uint32_t b = key >> kCoarseShift;
-    return b < uint32_t(kMatBins) ? b : uint32_t(kMatBins - 1);   // NaN keys (0xFFFFFFFF) -> last bin
-}
 
 // The sample of a job: kMatSample elements drawn uniformly with replacement, (row, col) = two multiplicative hashes
 // of the sample index scaled by mul-high (no integer division).  `issue` starts the loads, `finish` turns them into
@@ -629,18 +655,46 @@ __device__ __forceinline__ void sample_issue(const SelJob &jb, int tid, SampleRe
     }
 }
 // hist: kMatBins LDS counters, zeroed and synchronised by the caller; sq: sqrt(scaler_row) (global or LDS)
+//
+// The bracket [lo, hi] around rank k: the sample's keys at ranks rs -+ 6 sigma.  They are located in a histogram of kMatBins
+// EQUAL bins over the sample's own key range [min, max] (about one sample per bin).  (Round 1 binned by sign / exponent / 3
+// mantissa bits -- 2^20 keys, an eighth of an octave, per bin -- and snapped the bracket to those edges: it came out two to
+// three times as wide as the +-6 sigma it stands for, the bin of rank k then held more keys than the candidate slots take,
+// and three of the four linears of a ViT-g block paid for a refinement level: another pass, flush and barrier, ~12 us.)
 template <typename T>
 __device__ __forceinline__ void sample_finish(const SelJob &jb, int tid, const SampleRegs<T> &r, const float *sq, uint32_t *hist,
                                               uint32_t *red, uint32_t &lo, uint32_t &shift) {
     const uint32_t numel = jb.out_f * jb.in_f;
     const uint32_t S = numel < uint32_t(kMatSample) ? numel : uint32_t(kMatSample);
-    float sv[kSamplesPerThread];
+    uint32_t sk[kSamplesPerThread];
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
-    for (int j = 0; j < kSamplesPerThread; ++j) sv[j] = sq[r.col[j]];
+    for (int j = 0; j < kSamplesPerThread; ++j) {
+        sk[j] = score_key(ieee_mul(fabsf(to_f32<T>(r.wv[j])), sq[r.col[j]]));
+        if (uint32_t(tid) + 1024u * j < S) {
+            kmin = sk[j] < kmin ? sk[j] : kmin;
+            kmax = sk[j] > kmax ? sk[j] : kmax;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t a = uint32_t(__shfl_xor(int(kmin), off, 64)), c = uint32_t(__shfl_xor(int(kmax), off, 64));
+        kmin = a < kmin ? a : kmin;
+        kmax = c > kmax ? c : kmax;
+    }
+    __shared__ uint32_t wmin[16], wmax[16];
+    if ((tid & 63) == 0) { wmin[tid >> 6] = kmin; wmax[tid >> 6] = kmax; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        kmin = wmin[w] < kmin ? wmin[w] : kmin;
+        kmax = wmax[w] > kmax ? wmax[w] : kmax;
+    }
+    uint32_t sshift = 0;                                          // sample bins of 2^sshift keys: (kmax - kmin) >> sshift < kMatBins
+    while (((kmax - kmin) >> sshift) >= uint32_t(kMatBins)) ++sshift;
 #pragma unroll
     for (int j = 0; j < kSamplesPerThread; ++j)
-        if (uint32_t(tid) + 1024u * j < S)
-            atomicAdd(&hist[coarse_bin(score_key(ieee_mul(fabsf(to_f32<T>(r.wv[j])), sv[j])))], 1u);
+        if (uint32_t(tid) + 1024u * j < S) atomicAdd(&hist[(sk[j] - kmin) >> sshift], 1u);
     __syncthreads();
     const uint32_t rs = uint32_t((uint64_t(jb.k) * S) / numel);
     const float pr = float(jb.k) / float(numel);
@@ -650,15 +704,13 @@ __device__ __forceinline__ void sample_finish(const SelJob &jb, int tid, const S
 #pragma unroll
         for (int i = 0; i < 4; ++i) h[i] = hist[tid * 4 + i];
     }
-    uint32_t hi = 0xFFFFFFFFu, bin, before;
+    uint32_t hi = 0xFFFFFFFFu, bin_lo, bin_hi;
     lo = 0;
-    if (rs > margin) {
-        block_find_rank(h, rs - margin, red, bin, before);
-        lo = bin << kCoarseShift;
-    }
-    if (rs + margin < S) {
-        block_find_rank(h, rs + margin, red, bin, before);
-        if (bin < uint32_t(kMatBins - 1)) hi = ((bin + 1u) << kCoarseShift) - 1u;
+    block_find_rank2(h, rs > margin ? rs - margin : 0u, rs + margin, red, bin_lo, bin_hi);   // (rank >= S: no bin, open end)
+    if (rs > margin && bin_lo != 0xFFFFFFFFu) lo = kmin + (bin_lo << sshift);
+    if (bin_hi != 0xFFFFFFFFu) {
+        const uint64_t end = uint64_t(kmin) + (uint64_t(bin_hi + 1u) << sshift) - 1u;
+        if (end < 0x7F800000ull) hi = uint32_t(end);             // (a bracket reaching Inf / NaN keys stays open above)
     }
     shift = 0;
     while (((hi - lo) >> shift) >= uint32_t(kMatBins)) ++shift;
@@ -668,7 +720,7 @@ __device__ __forceinline__ void sample_finish(const SelJob &jb, int tid, const S
 template <typename T>
 __global__ __launch_bounds__(1024) void matrix_sample_kernel(const SelBatch b) {
     __shared__ uint32_t hist[kMatBins];
-    __shared__ uint32_t red[20];
+    __shared__ uint32_t red[24];
     const SelJob &jb = b.job[blockIdx.x];
     const int tid = threadIdx.x;
     uint32_t *ws = jb.ws;
@@ -950,7 +1002,7 @@ __device__ void matrix_resolve_job(const SelBatch &b, const SelJob &jb, uint32_t
 template <typename T>
 __global__ __launch_bounds__(1024) void matrix_resolve_kernel(const SelBatch b) {
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t red[20];
+    __shared__ uint32_t red[24];
     const SelJob &jb = b.job[blockIdx.x];
     matrix_resolve_job<T, false>(b, jb, hist, red);
     __syncthreads();
@@ -960,7 +1012,7 @@ __global__ __launch_bounds__(1024) void matrix_resolve_kernel(const SelBatch b) 
     for (int i = threadIdx.x; i < kCand; i += 1024) jb.ws[i] = 0;
 #endif
     // (the candidate pairs of this form overlap the fused kernel's refinement histograms, which it expects zeroed)
-    for (int i = threadIdx.x; i < 2 * kMatBins; i += 1024) jb.ws[kCand + 8192 + i] = 0;
+    for (int i = threadIdx.x; i < 2 * kMatBins; i += 1024) jb.ws[kCand + 12288 + i] = 0;      // (= kHist1 of the fused kernel)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -993,9 +1045,9 @@ __global__ __launch_bounds__(1024) void matrix_resolve_kernel(const SelBatch b) 
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kBarFail = 0x80000000u;
 constexpr int kFusedCand = 4096;                 // candidate keys a workgroup can hold (more => exact fallback)
-constexpr int kSlotArea = 8192;                  // words of the workspace's candidate area used for the slots
-constexpr int kSlotMax = 64;                     // candidate keys one workgroup may publish: min(64, kSlotArea / workgroups)
-constexpr int kMaxFusedWgs = 256;                // => at least 32 keys per slot
+constexpr int kSlotArea = 12288;                 // words of the workspace's candidate area used for the slots
+constexpr int kSlotMax = 128;                    // candidate keys one workgroup may publish: min(128, kSlotArea / workgroups)
+constexpr int kMaxFusedWgs = 256;                // => at least 48 keys per slot
 constexpr int kHist1 = kCand + kSlotArea;        // global histograms of the refinement levels 1 and 2 (2 x 2048 words)
 constexpr uint32_t kSlotEmpty = 0xFFFFFFFFu, kSlotOverflow = 0xFFFFFFFEu;   // (keys are relative to the bin: < 2^22)
 constexpr int kFusedMaxIn = 8192;                // in_features the LDS copy of sqrt(scaler_row) can hold
@@ -1156,12 +1208,19 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
         fail = bel > jb.k || !found || bin_end > 0x7F800001ull;
         if (!fail) {
             uint32_t lob = lo + (bin << bshift), rankb = jb.k - bel - before, pop = red[18];
-            const uint32_t slot = min(uint32_t(kSlotMax), uint32_t(kSlotArea) / jb.nwg);
+#ifdef VLMC_FUSED_STAMP_SCAN                                      // (diagnostic: see the stamp below)
+            const uint32_t dbg_pop0 = pop;
+            uint32_t dbg_levels = 0;
+#endif
+            const uint32_t slot_cap = min(uint32_t(kSlotMax), uint32_t(kSlotArea) / jb.nwg);
             // ---- refinement: a bin too crowded for the candidate slots (ties: re-pruning weights that are already half
             // ---- zero, dead input channels) is histogrammed again, 11 more key bits per level, from the registers; after
             // ---- at most two levels a bin is ONE key value and needs no candidates at all (ties with the threshold stay)
-            for (int level = 1; level <= 2 && !fail && bshift != 0 && (pop > (slot / 4u) * jb.nwg || pop > 2048u); ++level) {
+            for (int level = 1; level <= 2 && !fail && bshift != 0 && (pop > (slot_cap / 4u) * jb.nwg || pop > 2048u); ++level) {
                 const uint32_t nshift = bshift > 11u ? bshift - 11u : 0u, base = lob, width = 1u << bshift;
+#ifdef VLMC_FUSED_STAMP_SCAN
+                ++dbg_levels;
+#endif
                 uint32_t *gh = ws + kHist1 + (level - 1) * kMatBins;
                 for (int i = tid; i < kMatBins; i += 1024) lh[i] = 0;
                 __syncthreads();
@@ -1213,9 +1272,14 @@ __global__ __launch_bounds__(1024, 1) void matrix_fused_kernel(const SelBatch b)
                 }
             }
             if (fail) bshift = 0;
+            // the slot a workgroup publishes its candidates in: sized by the bin's population (the same number in every
+            // workgroup), 4 x its share + 16 -- P3 loads every slot of the job whatever they hold
+            const uint32_t slot = min(slot_cap, max(32u, 4u * (pop / jb.nwg) + 16u));
             thr = lob;                                           // one-key bin: ties with the threshold are kept
-#ifdef VLMC_FUSED_STAMP_SCAN                                      // (diagnostic: the "flush" stamp marks the end of the scan instead)
-            VLMC_FSTAMP(2);
+#ifdef VLMC_FUSED_STAMP_SCAN         // diagnostic: the "flush" stamp marks the end of the scan (refinement levels included) and
+            VLMC_FSTAMP(2);          // the "P1 count" slot shows keys in the first bin / 100 + 10 000 x refinement levels
+            if (tid == 0 && (wg == 0 || wg == jb.nwg - 1))
+                ws[kCtrl + 16 + (wg == 0 ? 0 : 8) + 1] = ws[kCtrl + 16 + (wg == 0 ? 0 : 8) + 0] + dbg_pop0 + 1000000u * dbg_levels;
 #endif
             if (bshift) {
                 const uint32_t width = 1u << bshift;
