@@ -123,8 +123,10 @@ class _LaterEqual:
             groups.setdefault((tuple(r.shape), r.dtype, r.device), []).append((r, v))
         self.pairs = []
         for prs in groups.values():
-            for t in range(0, len(prs), 256):
-                part = prs[t:t + 256]
+            nbytes = prs[0][0].numel() * prs[0][0].element_size()
+            per = max(1, min(256, (256 << 20) // max(1, nbytes)))      # two stacked copies of at most 256 MB each
+            for t in range(0, len(prs), per):
+                part = prs[t:t + per]
                 if not torch.equal(torch.stack([a for a, _ in part]), torch.stack([b for _, b in part])):
                     return True
         return False

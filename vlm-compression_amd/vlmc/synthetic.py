@@ -73,9 +73,12 @@ class RMSNorm(nn.Module):
         super().__init__()
         self.weight = nn.Parameter(torch.ones(dim))
 
-    def forward(self, x):
-        v = x.float().pow(2).mean(-1, keepdim=True)
-        return (x.float() * torch.rsqrt(v + 1e-6)).to(x.dtype) * self.weight
+    def forward(self, x):                  # (the op sequence of transformers' T5LayerNorm)
+        v = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
+        h = x * torch.rsqrt(v + 1e-6)
+        if self.weight.dtype in (torch.float16, torch.bfloat16):
+            h = h.to(self.weight.dtype)
+        return self.weight * h
 
 
 class _T5Sub(nn.Module):
