@@ -196,7 +196,7 @@ def install_probes(probe):
             (os.environ.get("VLMC_SELECT_MIXED", "1") != "0" and max(widths) <= 8192 and min(widths) <= 2048 < max(widths)
              and all(i % 8 == 0 for i in widths))
 
-    def gemm_flops(x, weight, bias=None):
+    def gemm_flops(x, weight, bias=None, **kw):
         return 2.0 * (x.numel() // x.shape[-1]) * weight.shape[0] * weight.shape[1]
 
     probe.wrap(ops, "act_sqnorm_batch", "stat", sq_bytes)

@@ -40,7 +40,7 @@ def linear(x, weight, bias=None):
             b = b.to(weight.dtype)
         if ops.linear_fwd_supported(xin, weight, b) and (not torch.is_autocast_enabled() or torch.get_autocast_gpu_dtype() == weight.dtype):
             stats["kernel"] += 1
-            return ops.linear_fwd(xin, weight, b)
+            return ops.linear_fwd(xin, weight, b, _checked=True)     # (linear_fwd_supported has just said yes)
     stats["library"] += 1
     return F.linear(x, weight, bias)
 
