@@ -48,10 +48,10 @@ class WandaStatCollector:
         from vlmc import ops
         self._ops = ops
         self.subset = subset
-        self.rows = {n: [] for n in subset}          # per linear: (sample index, holder [row tensor | None], batch), one per
-        self._cur = -1                               # hook call; index of the sample an unstacked forward belongs to
+        self.rows = {n: [] for n in subset}          # per linear and hook call: (sample indices, holder [rows | None], batch)
+        self._cur = -1                               # index of the sample an unstacked forward belongs to
         self._cache = {}                              # input signature -> (x kept alive, holder)
-        self._pending = []                            # (x [1, tokens, in], holder) not yet reduced
+        self._pending = []                            # (x [calls, tokens, in], holder) not yet reduced
         self.handles = [m.register_forward_hook(self._make_hook(n)) for n, m in subset.items()]
 
     def _make_hook(self, name):
@@ -66,11 +66,12 @@ class WandaStatCollector:
             if hit is None:
                 # `x` stays referenced until it has been reduced, so its memory cannot be recycled for a
                 # different activation with the same address/shape in the meantime
-                hit = (x, [[None] for _ in range(calls)])
+                hit = (x, [None])                    # the holder receives the [calls, in] statistic rows of this tensor
                 self._cache[key] = hit
                 self._pending.append((x.reshape(calls, -1, x.shape[-1]), hit[1]))
-            # one record per calibration sample, as in the reference; grouped replay visits samples out of order
-            self.rows[name].extend((j, h, b0) for j, h in zip(idx, hit[1]))
+            # one record per hook call: the calibration samples it stands for (grouped replay visits samples out of order;
+            # `finalize` puts the per-sample rows back into the reference's order)
+            self.rows[name].append((idx, hit[1], b0))
         return hook
 
     def _flush(self):
@@ -84,13 +85,12 @@ class WandaStatCollector:
             by_dtype.setdefault(x.dtype, []).append((x, holder))
         for items in by_dtype.values():
             by_calls = {}
-            for x, holders in items:
-                by_calls.setdefault(x.shape[0], []).append((x, holders))
+            for x, holder in items:
+                by_calls.setdefault(x.shape[0], []).append((x, holder))
             for same in by_calls.values():                     # one launch per group of inputs with equally many calls
                 outs = self._ops.act_sqnorm_batch([x for x, _ in same])
-                for (_, holders), rows in zip(same, outs):
-                    for c, holder in enumerate(holders):
-                        holder[0] = (rows, c)                  # row c of `rows`, sliced only where it is needed
+                for (_, holder), rows in zip(same, outs):
+                    holder[0] = rows                           # row c = the c-th sample of the call, sliced only where needed
         self._pending = []
 
     def next_sample(self, j=None):
@@ -110,14 +110,18 @@ class WandaStatCollector:
         from vlmc import wanda
         shared, out, order = {}, {}, []
         for name, recs in self.rows.items():
-            recs = sorted(recs, key=lambda r: r[0])            # the reference's sample order (stable: calls within a sample)
-            sig = tuple(id(h) for _, h, _ in recs)
+            sig = tuple(id(h) for _, h, _ in recs)             # linears fed by the same tensors share the statistic
             st = shared.get(sig)
             if st is None:
                 in_f = self.subset[name].weight.shape[1]
                 st = wanda.InputStat(in_f, self.subset[name].weight.device)
-                st.rows = _row_runs([h[0] for _, h, _ in recs])
-                st.batches = [b for _, _, b in recs]
+                if len(recs) == 1 and all(a < b for a, b in zip(recs[0][0], recs[0][0][1:])):
+                    idx, holder, b0 = recs[0]                  # one grouped call, samples in order: its rows as they are
+                    st.rows, st.batches = [holder[0][:len(idx)]], [b0] * len(idx)
+                else:                                          # the reference's sample order (stable: calls within a sample)
+                    flat = sorted(((j, h, c, b) for idx, h, b in recs for c, j in enumerate(idx)), key=lambda r: r[0])
+                    st.rows = _row_runs([(h[0], c) for _, h, c, _ in flat])
+                    st.batches = [b for _, _, _, b in flat]
                 shared[sig] = st
                 order.append(st)
             out[name] = st
