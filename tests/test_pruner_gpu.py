@@ -533,3 +533,68 @@ def test_tower_batching_gives_the_per_sample_forward_bit_for_bit(ragged, monkeyp
     for j, (a, b, ca, cb) in enumerate(zip(got, want, got_c, want_c)):
         assert a.shape == b.shape and torch.equal(a, b), j
         assert torch.equal(ca["encoder_hidden_states"], cb["encoder_hidden_states"]), j
+
+
+def test_finished_tower_that_hands_a_block_output_on_as_a_keyword(monkeypatch):
+    """transformers' T5Stack: block 0 computes the relative position bias and RETURNS it, the stack hands it to every later
+    block as `position_bias=`.  The capture machinery must wire that (an output of block 0 is a keyword argument of blocks
+    1..n) in all three ways a finished tower is traversed: eagerly, as one graph per sample, stacked for all samples."""
+    import torch.nn.functional as F
+    from lavis.compression.pruners import calibration as cal
+
+    class Block(torch.nn.Module):
+        def __init__(self, first, heads=4, dim=64):
+            super().__init__()
+            self.q, self.k, self.v, self.o = (torch.nn.Linear(dim, dim, bias=False) for _ in range(4))
+            self.heads = heads
+            self.rel = torch.nn.Parameter(torch.randn(heads, 16, 16) * 0.5) if first else None
+
+        def forward(self, x, position_bias=None, rel_pos_bias=None):
+            B, T, D = x.shape
+            if position_bias is None:
+                position_bias = self.rel[:, :T, :T].to(x.dtype).unsqueeze(0).expand(B, -1, -1, -1)
+            sh = lambda t: t.reshape(B, T, self.heads, -1).transpose(1, 2)
+            y = F.scaled_dot_product_attention(sh(self.q(x)), sh(self.k(x)), sh(self.v(x)), attn_mask=position_bias)
+            return x + self.o(y.transpose(1, 2).reshape(B, T, D)), position_bias
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.enc = torch.nn.Module()
+            self.enc.block = torch.nn.ModuleList([Block(i == 0) for i in range(4)])
+            self.dec = torch.nn.Module()
+            self.dec.block = torch.nn.ModuleList([Block(True) for _ in range(2)])
+
+        def forward(self, samples):
+            x, pb = samples["image"], None
+            for blk in self.enc.block:
+                x, pb = blk(x, position_bias=pb)
+            for blk in self.dec.block:
+                x = blk(x, None)[0]
+            return x
+
+    torch.manual_seed(3)
+    model = Model().to("cuda:0").half().eval()
+    lens = [12, 12, 9, 12, 9, 12, 12, 9, 12, 12]
+    batches = [{"image": (torch.randn(1, n, 64, device="cuda:0") * 0.5).half()} for n in lens]
+
+    def capture(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with torch.no_grad():
+            inps, _, _ = cal.capture_block_inputs(model, batches, len(batches), "dec.block", lambda m, b, _l=False: m(b), False,
+                                                  vit=True, done_towers=["enc.block"], proxy_cache={})
+        torch.cuda.synchronize()
+        return inps
+
+    want = capture(VLMC_GRAPH_REPLAY="0")
+    before = dict(cal.graph_stats)
+    stacked = capture(VLMC_GRAPH_REPLAY="1", VLMC_TOWER_BATCH="1", VLMC_TOWER_GRAPH="1", VLMC_LINEAR_FWD="1", VLMC_TOWER_MEMO="0")
+    assert cal.graph_stats.get("tower_batches", 0) > before.get("tower_batches", 0), "the tower was not run stacked"
+    before = dict(cal.graph_stats)
+    graphed = capture(VLMC_TOWER_BATCH="0")
+    assert cal.graph_stats.get("tower_graphs", 0) > before.get("tower_graphs", 0), "the tower was not run from a graph"
+    assert cal.graph_stats["fallbacks"] == before["fallbacks"]
+    assert len(want) == len(stacked) == len(graphed) == len(lens)
+    for a, b, c in zip(want, stacked, graphed):
+        assert torch.equal(a, b) and torch.equal(a, c)
