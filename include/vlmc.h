@@ -273,9 +273,9 @@ int vlmc_dsnot_apply(void *W, int dtype, int64_t out_features, int64_t in_featur
  * get_mask's per-layer cap (:111-118): scores >= the protect_k-th largest of the job count as FLT_MAX.
  * -0 == +0; NaN scores sort last and are never kept (NaN > t is false).  scope_k[s] must lie in
  * [1, elements of the scope] (k == 0 is an IndexError in the reference).
- * `jobs` and `scope_k` are HOST arrays; with more than 4 jobs this is the one entry point that waits on the
- * stream (for the upload of the job table into the workspace); up to 4 jobs travel as a kernel argument.  Nothing is concatenated or sorted: 3 histogram passes
- * over the operands + one apply pass.                                                            */
+ * `jobs` and `scope_k` are HOST arrays, read before the call returns (the table travels to the workspace as kernel
+ * arguments, 24 jobs per launch: nothing is copied from host memory asynchronously, nothing waits).  Nothing is
+ * concatenated or sorted: 3 histogram passes over the operands + one apply pass.                  */
 typedef struct {
     void *W;                  /* [numel] weight dtype; rewritten when apply_weights */
     const float *S;           /* [numel] fp32 or NULL (by score_mode) */

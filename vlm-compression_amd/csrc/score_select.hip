@@ -356,21 +356,25 @@ __global__ __launch_bounds__(kThreads) void score_apply_kernel(const DevJob *__r
         });
 }
 
-// Small job tables travel as a kernel argument (no host-to-device copy, no wait): SparseGPT's per-block thresholds
-// and other few-tensor calls stay fully asynchronous.
-constexpr int kInlineJobs = 4;
-struct InlineTable {
-    DevJob jobs[kInlineJobs];
-    SelState scope_st[kInlineJobs];
-    SelState prot_st[kInlineJobs];
+// The job table travels as kernel arguments, kTableChunk jobs per (tiny) launch: no host-to-device copy of pageable
+// memory, no wait -- SparseGPT's per-block thresholds (1 job) and a global threshold over all 588 linears of a model
+// (25 launches) alike stay fully asynchronous.  (Round 1 uploaded tables of more than 4 jobs with hipMemcpyAsync and
+// had to wait for the copy because the host buffer was freed on return: the one export that synchronised.)
+constexpr int kTableChunk = 24;                    // 24 x (DevJob + 2 SelState) < the 4 KB a launch may carry
+struct TableChunk {
+    DevJob jobs[kTableChunk];
+    SelState scope_st[kTableChunk];
+    SelState prot_st[kTableChunk];
 };
-__global__ void score_table_kernel(InlineTable t, int n_jobs, int n_scopes, DevJob *jobs, SelState *scope_st, SelState *prot_st) {
-    const int i = threadIdx.x;
-    if (i < n_jobs) {
-        jobs[i] = t.jobs[i];
-        prot_st[i] = t.prot_st[i];
+static_assert(sizeof(TableChunk) <= 3584, "kernel arguments are limited to 4 KB");
+__global__ void score_table_kernel(TableChunk t, int first, int n_jobs, int n_scopes, DevJob *jobs, SelState *scope_st,
+                                   SelState *prot_st) {
+    const int i = threadIdx.x, g = first + i;
+    if (i < kTableChunk && g < n_jobs) {
+        jobs[g] = t.jobs[i];
+        prot_st[g] = t.prot_st[i];
     }
-    if (i < n_scopes) scope_st[i] = t.scope_st[i];
+    if (i < kTableChunk && g < n_scopes) scope_st[g] = t.scope_st[i];
 }
 
 struct Layout {
@@ -472,18 +476,14 @@ extern "C" int vlmc_score_select(const vlmc_score_job *jobs, int n_jobs, const i
     char *ws = static_cast<char *>(workspace);
     DevJob *ddj = reinterpret_cast<DevJob *>(ws + l.jobs);
     SelState *dss = reinterpret_cast<SelState *>(ws + l.scope_st), *dps = reinterpret_cast<SelState *>(ws + l.prot_st);
-    if (n_jobs <= kInlineJobs) {
-        InlineTable t{};
-        for (int i = 0; i < n_jobs; ++i) {
-            t.jobs[i] = dj[i];
-            t.prot_st[i] = pst[i];
+    for (int first = 0; first < n_jobs; first += kTableChunk) {
+        TableChunk t{};
+        for (int i = 0; i < kTableChunk && first + i < n_jobs; ++i) {
+            t.jobs[i] = dj[first + i];
+            t.prot_st[i] = pst[first + i];
+            if (first + i < n_scopes) t.scope_st[i] = sst[first + i];
         }
-        for (int i = 0; i < n_scopes; ++i) t.scope_st[i] = sst[i];
-        hipLaunchKernelGGL(score_table_kernel, dim3(1), dim3(64), 0, st, t, n_jobs, n_scopes, ddj, dss, dps);
-    } else if (hipMemcpyAsync(ws, blob.data(), l.hist, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-        // the one place the library waits: the table lives in pageable host memory that is freed on return
-        set_error("vlmc_score_select: uploading the job table failed: %s", hipGetErrorString(hipGetLastError()));
-        return VLMC_EHIP;
+        hipLaunchKernelGGL(score_table_kernel, dim3(1), dim3(64), 0, st, t, first, n_jobs, n_scopes, ddj, dss, dps);
     }
     if (hipMemsetAsync(ws + l.hist, 0, l.total - l.hist, st) != hipSuccess) {
         set_error("vlmc_score_select: clearing the histograms failed: %s", hipGetErrorString(hipGetLastError()));
