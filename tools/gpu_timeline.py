@@ -24,6 +24,7 @@ for i, (s, e, n) in enumerate(rows):
         if run >= 300:
             starts.append(run0)
         run = 0
+hist = []
 lines = ["| step | wall ms (first kernel of the step to first kernel of the next) | GPU busy ms | busy | gaps > 0.5 ms (ms) |", "|---|---|---|---|---|"]
 for k in range(len(starts) - 1):
     seg = rows[starts[k]:starts[k + 1]]
@@ -39,5 +40,19 @@ for k in range(len(starts) - 1):
             cur_e = max(cur_e, e)
     busy += cur_e - cur_s
     lines.append(f"| {k} | {(t1 - t0) / 1e6:.1f} | {busy / 1e6:.1f} | {busy / (t1 - t0):.3f} | {', '.join(f'{g:.1f}' for g in gaps) or '-'} |")
+    # idle time by the length of the gap (stream-ordered kernels: gap = next start - latest end so far)
+    edges = [2, 5, 10, 50, 500, 10 ** 9]
+    cnt, tot, end = [0] * len(edges), [0.0] * len(edges), seg[0][1]
+    for s, e, _ in seg[1:]:
+        g = (s - end) / 1e3
+        if g > 0:
+            b = next(i for i, x in enumerate(edges) if g < x)
+            cnt[b] += 1
+            tot[b] += g
+        end = max(end, e)
+    hist.append((k, len(seg), cnt, tot))
+lines += ["", "| step | kernels | idle in gaps < 2 us: n, ms | 2-5 us | 5-10 us | 10-50 us | 50-500 us | > 500 us |", "|---|---|---|---|---|---|---|---|"]
+for k, n, cnt, tot in hist:
+    lines.append(f"| {k} | {n} | " + " | ".join(f"{c}, {t / 1e3:.1f}" for c, t in zip(cnt, tot)) + " |")
 open(out, "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))

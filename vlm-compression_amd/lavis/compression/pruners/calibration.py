@@ -399,6 +399,7 @@ class TowerGraph:
         self.plans, self.traces, self.wirings = {}, {}, {}
         self.deferred, self.ready = [], {}    # forwards postponed at block 0; their per-block outputs once the tower ran
         self.linears = [m for mod in self.mods for m in find_layers(mod).values()]
+        self._linears_ok = {}                     # autocast state -> every linear of the tower can run on the invariant kernel
         self.off = False
         self.live = None                      # replay in progress: {"plan", "given": id -> (tensor, version)}
         self.trace = None                     # recording in progress
@@ -577,10 +578,10 @@ class TowerGraph:
 
     def _serve(self, index, args, kwargs):
         live = self.live
-        wires, kwires = live["calls"][index][0], dict(live["calls"][index][1])
-        ok = len(args) == len(wires) and sorted(kwargs) == sorted(kwires)
+        wires, kwire_items = live["calls"][index][0], live["calls"][index][1]          # kwire_items: sorted (name, wire) pairs
+        ok = len(args) == len(wires) and len(kwargs) == len(kwire_items) and all(k in kwargs for k, _ in kwire_items)
         if ok:
-            for v, w in list(zip(args, wires)) + [(kwargs[k], kwires[k]) for k in kwires]:
+            for v, w in list(zip(args, wires)) + [(kwargs[k], w_) for k, w_ in kwire_items]:
                 if w[0] == "val":
                     ok = not isinstance(v, torch.Tensor) and (v is w[1] or v == w[1])
                 else:
@@ -614,11 +615,18 @@ class TowerGraph:
         if not (args and isinstance(args[0], torch.Tensor) and args[0].dim() >= 2 and fw.enabled() and self.linears):
             return False
         ctx = TowerMemo.context()
-        for m in self.linears:
-            w = getattr(m, "weight", None)
-            if type(m) is not nn.Linear or w is None or w.dtype not in (torch.float16, torch.bfloat16) or w.shape[1] % 8 or \
-                    (ctx[0] and ctx[1] != w.dtype):
-                return False
+        ok = self._linears_ok.get(ctx)                 # (168 linears of a Flan-T5-XL tower: asked once per autocast state)
+        if ok is None:
+            ok = True
+            for m in self.linears:
+                w = getattr(m, "weight", None)
+                if type(m) is not nn.Linear or w is None or w.dtype not in (torch.float16, torch.bfloat16) or w.shape[1] % 8 or \
+                        (ctx[0] and ctx[1] != w.dtype):
+                    ok = False
+                    break
+            self._linears_ok[ctx] = ok
+        if not ok:
+            return False
         b0 = args[0].shape[0]
         return all(e.dim() >= 1 and e.shape[0] == b0 for e in self._ext(args, kwargs))
 
