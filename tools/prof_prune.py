@@ -31,3 +31,7 @@ for key in ("cumulative", "tottime"):
     s = io.StringIO()
     pstats.Stats(pr, stream=s).sort_stats(key).print_stats(45)
     print(s.getvalue()[:9000])
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_callers("named_modules|_named_members|__getattr__|named_parameters", 12)
+print(s.getvalue()[:6000])
+
