@@ -190,8 +190,10 @@ class TowerMemo:
         return tuple(t.data_ptr() for t in ts), sums
 
     def matches(self, fp):
+        # (inside a capture phase the sums are compared with everything else at the end of the phase, _LaterEqual: asking
+        # now would make the host wait for whatever the GPU still has queued from the tower before)
         return fp is not None and self.ok and bool(self.entries) and self.fp[0] == fp[0] and self.fp[1].shape == fp[1].shape \
-            and bool(torch.equal(self.fp[1], fp[1]))
+            and _bits_equal(self.fp[1], fp[1])
 
     def begin(self, mode):
         self.mode, self.cursor, self.hit, self.pending, self.expect = mode, 0, None, None, 0

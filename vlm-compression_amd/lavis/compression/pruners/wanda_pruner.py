@@ -150,9 +150,11 @@ def _importance_backlog(backlog, subset, names, partial_rows, numels):
     backlog.append(([subset[n].weight for n in names], partial_rows.sum(dim=1), numels))
 
 
-def _importance_readback(backlog):
-    """ONE device->host copy per tower for the importance scores of all its linears."""
-    if not backlog:
+def _importance_readback(backlog, owner=None):
+    """ONE device->host copy per tower for the importance scores of all its linears -- or, when the towers are pruned by
+    a pruner that says so (`_defer_score_readback`, the three-tower BLIP pruner), ONE per prune: the copy waits for
+    everything the GPU has queued, and the host has the next tower's capture sweeps to issue meanwhile."""
+    if not backlog or (owner is not None and getattr(owner, "_defer_score_readback", False)):
         return
     sums = torch.cat([s for _, s, _ in backlog]).cpu().tolist()
     k = 0
@@ -275,7 +277,7 @@ class T5LayerWandaPruner(LayerWiseBasePruner, _WandaBlockMixin):
 
         cal.walk_blocks(model, inps, outs, caches, module_to_process, n_samples,
                         lambda: model.maybe_autocast(dtype=torch.bfloat16), prune_block, tuple_output=True)
-        _importance_readback(self.__dict__.setdefault("_score_backlog", []))
+        _importance_readback(self.__dict__.setdefault("_score_backlog", []), self)
         cfg.use_cache = use_cache
         cal.release_tower_memory()
         return model
@@ -327,7 +329,7 @@ class VITLayerWandaPruner(LayerWiseBasePruner, _WandaBlockMixin):
 
         cal.walk_blocks(model, inps, outs, caches, module_to_process, n_samples, lambda: model.maybe_autocast(),
                         prune_block, tuple_output=False, memo_cache=self.__dict__.get("_proxy_cache"))
-        _importance_readback(self.__dict__.setdefault("_score_backlog", []))
+        _importance_readback(self.__dict__.setdefault("_score_backlog", []), self)
         cal.release_tower_memory()
         return model
 
@@ -433,6 +435,7 @@ class BLIPT5LayerWandaPruner(LayerWiseBasePruner):
         # the calibration forward of a tower is DENSE exactly when that tower is pruned (:966-967)
         self.vit_dense = True if float(vit_keep_ratio) < 1. else False
         self.llm_dense = True if float(t5_keep_ratio) < 1. else False
+        self._defer_score_readback = True           # importance scores are read back once, below
 
         if self.vit_prune_spec is not None and float(vit_keep_ratio) < 1.:
             sd = global_sparsity_dict if global_sparsity_dict not in [None, "none"] else \
@@ -454,6 +457,8 @@ class BLIPT5LayerWandaPruner(LayerWiseBasePruner):
                                          module_to_process=f"{self.t5_model_prefix}{self.peft_postfix}.model.layers",
                                          n_samples=self.num_samples, sparsity_ratio=sd, lora_model=lora_model)
 
+        self._defer_score_readback = False
+        _importance_readback(self.__dict__.setdefault("_score_backlog", []))      # the towers' importance scores, one copy
         self.model_reset(self.model, dtype_record, requires_grad_record, device)
         return self.model, global_sparsity_dict
 
