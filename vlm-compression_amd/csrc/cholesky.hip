@@ -22,6 +22,11 @@ __device__ __forceinline__ float rl(float v, int lane) { return __int_as_float(_
 // (pivots and column entries travel by v_readlane), (b) every row below solves its 32 entries by forward substitution,
 // (c) the rest of the block gets its rank-32 update.  12 barriers per 128x128 block instead of 3 per column.
 // Then inv(L): the four 32x32 diagonal inverses by one wave each, the off-diagonal pieces block-diagonal by block-diagonal.
+#ifdef VLMC_CHOL_STAMPS                 // diagnostic build only: phase clocks (100 MHz) printed by lane 0
+#define CSTAMP(i) do { if (tid == 0) stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CSTAMP(i) do {} while (0)
+#endif
 __global__ __launch_bounds__(kCholThreads) void chol_block_kernel(const float *__restrict__ A, int64_t lda, int nb, float *__restrict__ L,
                                                          int64_t ldl, float *__restrict__ Linv, int64_t ldi,
                                                          int *__restrict__ info, int col0) {
@@ -29,6 +34,10 @@ __global__ __launch_bounds__(kCholThreads) void chol_block_kernel(const float *_
     float *a = sh;                          // [128][kCholLd] block being factorized (lower part)
     float *v = sh + kCholNb * kCholLd;      // [128][kCholLd] its inverse (upper pieces double as scratch)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef VLMC_CHOL_STAMPS
+    __shared__ unsigned long long stamps[24];
+#endif
+    CSTAMP(0);
     const bool vec4 = nb == kCholNb && (lda % 4 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0);
     if (vec4) {
         for (int e = tid; e < kCholNb * kCholNb / 4; e += kCholThreads) {
@@ -50,6 +59,7 @@ __global__ __launch_bounds__(kCholThreads) void chol_block_kernel(const float *_
         }
     }
     __syncthreads();
+    CSTAMP(1);
     for (int base = 0; base < kCholNb && base < nb; base += kSb) {
         if (wave == 0) {
             float row[kSb];                 // lane i < 32: row base + i of the diagonal piece
@@ -66,7 +76,7 @@ __global__ __launch_bounds__(kCholThreads) void chol_block_kernel(const float *_
 #pragma unroll
                 for (int k = j + 1; k < kSb; ++k) {
                     const float lkj = rl(lij, k);
-                    if (li >= k) row[k] = row[k] - ieee_mul(lij, lkj);
+                    row[k] = row[k] - ieee_mul(lij, lkj);          // (lanes li < k: the upper part, never stored -- no predicate)
                 }
             }
             if (lane < kSb) {
@@ -76,6 +86,7 @@ __global__ __launch_bounds__(kCholThreads) void chol_block_kernel(const float *_
             }
         }
         __syncthreads();
+        CSTAMP(2 + 3 * (base / kSb));
         const int below = base + kSb;
         for (int i = below + tid; i < kCholNb; i += kCholThreads) {      // (b) forward substitution, one row per lane
             float x[kSb];
@@ -90,6 +101,7 @@ __global__ __launch_bounds__(kCholThreads) void chol_block_kernel(const float *_
             for (int c = 0; c < kSb; ++c) a[i * kCholLd + base + c] = x[c];
         }
         __syncthreads();
+        CSTAMP(3 + 3 * (base / kSb));
         const int m2 = (kCholNb - below) / 2;                    // (c) rank-32 update of what is left, 2x2 tiles per lane
         for (int e = tid; e < m2 * m2; e += kCholThreads) {
             const int i = below + 2 * (e / m2), k = below + 2 * (e % m2);
@@ -109,6 +121,7 @@ __global__ __launch_bounds__(kCholThreads) void chol_block_kernel(const float *_
             }
         }
         __syncthreads();
+        CSTAMP(4 + 3 * (base / kSb));
     }
     // ---- inverse of the lower-triangular block ----------------------------------------------------------------
     if (wave < kCholNb / kSb) {   // diagonal pieces: wave w inverts piece w; lane c < 32 owns column c:
@@ -119,8 +132,8 @@ __global__ __launch_bounds__(kCholThreads) void chol_block_kernel(const float *_
         for (int r = 0; r < kSb; ++r) {
             float acc = (r == c) ? 1.f : 0.f;
 #pragma unroll
-            for (int k = 0; k < r; ++k)
-                if (k >= c) acc = acc - ieee_mul(a[(base + r) * kCholLd + base + k], x[k]);
+            for (int k = 0; k < r; ++k)          // (x[k] == 0 for k < c: no predicate needed, the same bits)
+                acc = acc - ieee_mul(a[(base + r) * kCholLd + base + k], x[k]);
             x[r] = (r >= c) ? ieee_div(acc, a[(base + r) * kCholLd + base + r]) : 0.f;
         }
         if (lane < kSb) {
@@ -129,37 +142,83 @@ __global__ __launch_bounds__(kCholThreads) void chol_block_kernel(const float *_
         }
     }
     __syncthreads();
+    CSTAMP(14);
     constexpr int NBLK = kCholNb / kSb;
     for (int d = 1; d < NBLK; ++d) {
         // pieces (rb, cb = rb - d): T = sum_{m=cb}^{rb-1} L[rb][m] V[m][cb], kept in the (cb, rb) mirror piece of v
         const int pairs = NBLK - d;
-        for (int e = tid; e < pairs * kSb * kSb; e += kCholThreads) {
-            const int pr = e / (kSb * kSb), r = (e / kSb) % kSb, c = e % kSb;
+        constexpr int H = kSb / 2;                   // 2 x 2 outputs per lane: two LDS reads feed two products each
+        for (int e = tid; e < pairs * H * H; e += kCholThreads) {
+            const int pr = e / (H * H), r = 2 * ((e / H) % H), c = 2 * (e % H);
             const int rb = pr + d, cb = pr;
-            float acc = 0.f;
+            float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
             for (int mb = cb; mb < rb; ++mb)
 #pragma unroll 8
-                for (int k = 0; k < kSb; ++k)
-                    acc = __builtin_fmaf(a[(rb * kSb + r) * kCholLd + mb * kSb + k], v[(mb * kSb + k) * kCholLd + cb * kSb + c], acc);
-            v[(cb * kSb + r) * kCholLd + rb * kSb + c] = acc;        // scratch in the upper part
+                for (int k = 0; k < kSb; ++k) {
+                    const float l0 = a[(rb * kSb + r) * kCholLd + mb * kSb + k], l1 = a[(rb * kSb + r + 1) * kCholLd + mb * kSb + k];
+                    const float v0 = v[(mb * kSb + k) * kCholLd + cb * kSb + c], v1 = v[(mb * kSb + k) * kCholLd + cb * kSb + c + 1];
+                    a00 = __builtin_fmaf(l0, v0, a00); a01 = __builtin_fmaf(l0, v1, a01);
+                    a10 = __builtin_fmaf(l1, v0, a10); a11 = __builtin_fmaf(l1, v1, a11);
+                }
+            v[(cb * kSb + r) * kCholLd + rb * kSb + c] = a00;        // scratch in the upper part
+            v[(cb * kSb + r) * kCholLd + rb * kSb + c + 1] = a01;
+            v[(cb * kSb + r + 1) * kCholLd + rb * kSb + c] = a10;
+            v[(cb * kSb + r + 1) * kCholLd + rb * kSb + c + 1] = a11;
         }
         __syncthreads();
-        for (int e = tid; e < pairs * kSb * kSb; e += kCholThreads) {         // V[rb][cb] = -V[rb][rb] T
-            const int pr = e / (kSb * kSb), r = (e / kSb) % kSb, c = e % kSb;
+        for (int e = tid; e < pairs * H * H; e += kCholThreads) {            // V[rb][cb] = -V[rb][rb] T
+            const int pr = e / (H * H), r = 2 * ((e / H) % H), c = 2 * (e % H);
             const int rb = pr + d, cb = pr;
-            float acc = 0.f;
+            float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
 #pragma unroll 8
-            for (int k = 0; k <= r; ++k)
-                acc = __builtin_fmaf(v[(rb * kSb + r) * kCholLd + rb * kSb + k], v[(cb * kSb + k) * kCholLd + rb * kSb + c], acc);
-            v[(rb * kSb + r) * kCholLd + cb * kSb + c] = -acc;
+            for (int k = 0; k <= r; ++k) {
+                const float l0 = v[(rb * kSb + r) * kCholLd + rb * kSb + k], l1 = v[(rb * kSb + r + 1) * kCholLd + rb * kSb + k];
+                const float t0 = v[(cb * kSb + k) * kCholLd + rb * kSb + c], t1 = v[(cb * kSb + k) * kCholLd + rb * kSb + c + 1];
+                a00 = __builtin_fmaf(l0, t0, a00); a01 = __builtin_fmaf(l0, t1, a01);
+                a10 = __builtin_fmaf(l1, t0, a10); a11 = __builtin_fmaf(l1, t1, a11);
+            }
+            {                                                                 // row r + 1 has one more term: k = r + 1
+                const float l1 = v[(rb * kSb + r + 1) * kCholLd + rb * kSb + r + 1];
+                a10 = __builtin_fmaf(l1, v[(cb * kSb + r + 1) * kCholLd + rb * kSb + c], a10);
+                a11 = __builtin_fmaf(l1, v[(cb * kSb + r + 1) * kCholLd + rb * kSb + c + 1], a11);
+            }
+            // (the products above read T = the (cb, rb) mirror piece; the results go to the (rb, cb) piece: no overlap)
+            v[(rb * kSb + r) * kCholLd + cb * kSb + c] = -a00;
+            v[(rb * kSb + r) * kCholLd + cb * kSb + c + 1] = -a01;
+            v[(rb * kSb + r + 1) * kCholLd + cb * kSb + c] = -a10;
+            v[(rb * kSb + r + 1) * kCholLd + cb * kSb + c + 1] = -a11;
         }
         __syncthreads();
+        CSTAMP(14 + d);
     }
-    for (int e = tid; e < nb * nb; e += kCholThreads) {
-        const int i = e / nb, k = e % nb;
-        L[int64_t(i) * ldl + k] = k <= i ? a[i * kCholLd + k] : 0.f;
-        Linv[int64_t(i) * ldi + k] = k <= i ? v[i * kCholLd + k] : 0.f;      // the upper part held scratch
+    const bool vec4o = nb == kCholNb && (ldl % 4 == 0) && (ldi % 4 == 0) && (reinterpret_cast<uintptr_t>(L) % 16 == 0) &&
+                       (reinterpret_cast<uintptr_t>(Linv) % 16 == 0);
+    if (vec4o) {                                       // full block: 16-byte stores, no division by a run-time nb
+        for (int e = tid; e < kCholNb * kCholNb / 4; e += kCholThreads) {
+            const int i = e / (kCholNb / 4), k = (e % (kCholNb / 4)) * 4;
+            float4 ql, qv;
+            ql.x = k <= i ? a[i * kCholLd + k] : 0.f;         qv.x = k <= i ? v[i * kCholLd + k] : 0.f;
+            ql.y = k + 1 <= i ? a[i * kCholLd + k + 1] : 0.f; qv.y = k + 1 <= i ? v[i * kCholLd + k + 1] : 0.f;
+            ql.z = k + 2 <= i ? a[i * kCholLd + k + 2] : 0.f; qv.z = k + 2 <= i ? v[i * kCholLd + k + 2] : 0.f;
+            ql.w = k + 3 <= i ? a[i * kCholLd + k + 3] : 0.f; qv.w = k + 3 <= i ? v[i * kCholLd + k + 3] : 0.f;
+            *reinterpret_cast<float4 *>(L + int64_t(i) * ldl + k) = ql;
+            *reinterpret_cast<float4 *>(Linv + int64_t(i) * ldi + k) = qv;   // the upper part held scratch
+        }
+    } else {
+        for (int e = tid; e < nb * nb; e += kCholThreads) {
+            const int i = e / nb, k = e % nb;
+            L[int64_t(i) * ldl + k] = k <= i ? a[i * kCholLd + k] : 0.f;
+            Linv[int64_t(i) * ldi + k] = k <= i ? v[i * kCholLd + k] : 0.f;      // the upper part held scratch
+        }
     }
+#ifdef VLMC_CHOL_STAMPS
+    __syncthreads();
+    CSTAMP(18);
+    if (tid == 0 && col0 == 0) {
+        for (int i = 1; i <= 18; ++i) printf("%d:%llu ", i, (stamps[i] - stamps[0]));
+        printf("\n");
+    }
+#endif
 }
 
 }  // namespace vlmc
