@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, "/root/repo/vlm-compression_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vlm-compression_amd"))
 import torch
 from vlmc import sparsegpt
 torch.manual_seed(0)
