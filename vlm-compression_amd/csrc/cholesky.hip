@@ -13,14 +13,18 @@ namespace vlmc {
 constexpr int kCholNb = 128;
 constexpr int kCholLd = kCholNb + 1;       // LDS row stride: column walks hit different banks
 
-constexpr int kSb = 32;                    // sub-block: factorized by ONE wave in registers (no workgroup barriers inside)
+constexpr int kSb = 32;                    // sub-block of the INVERSE (one wave per diagonal piece)
+constexpr int kFb = 16;                    // sub-block of the factorization: factorized by ONE wave in registers (no workgroup
+                                           // barriers inside).  The wave-level sweep costs ~ kFb^2 per piece: eight 16-wide pieces
+                                           // are 51 k cycles where four 32-wide ones were 93 k (and the forward substitutions 28 k
+                                           // instead of 41 k); every element still receives its updates in ascending column order
 constexpr int kCholThreads = 512;
 
 __device__ __forceinline__ float rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
-// 512 lanes.  Per 32-column sub-block: (a) wave 0 factorizes the 32x32 diagonal piece with its rows in registers
-// (pivots and column entries travel by v_readlane), (b) every row below solves its 32 entries by forward substitution,
-// (c) the rest of the block gets its rank-32 update.  12 barriers per 128x128 block instead of 3 per column.
+// 512 lanes.  Per 16-column sub-block: (a) wave 0 factorizes the 16x16 diagonal piece with its rows in registers
+// (pivots and column entries travel by v_readlane), (b) every row below solves its 16 entries by forward substitution,
+// (c) the rest of the block gets its rank-16 update.  24 barriers per 128x128 block instead of 3 per column.
 // Then inv(L): the four 32x32 diagonal inverses by one wave each, the off-diagonal pieces block-diagonal by block-diagonal.
 #ifdef VLMC_CHOL_STAMPS                 // diagnostic build only: phase clocks (100 MHz) printed by lane 0
 #define CSTAMP(i) do { if (tid == 0) stamps[i] = __builtin_readcyclecounter(); } while (0)
@@ -60,56 +64,54 @@ __global__ __launch_bounds__(kCholThreads) void chol_block_kernel(const float *_
     }
     __syncthreads();
     CSTAMP(1);
-    for (int base = 0; base < kCholNb && base < nb; base += kSb) {
+    for (int base = 0; base < kCholNb && base < nb; base += kFb) {
         if (wave == 0) {
-            float row[kSb];                 // lane i < 32: row base + i of the diagonal piece
-            const int li = lane & 31;
+            float row[kFb];                 // lane i < kFb: row base + i of the diagonal piece
+            const int li = lane & (kFb - 1);
 #pragma unroll
-            for (int k = 0; k < kSb; ++k) row[k] = (k <= li) ? a[(base + li) * kCholLd + base + k] : 0.f;
+            for (int k = 0; k < kFb; ++k) row[k] = (k <= li) ? a[(base + li) * kCholLd + base + k] : 0.f;
 #pragma unroll
-            for (int j = 0; j < kSb; ++j) {
+            for (int j = 0; j < kFb; ++j) {
                 const float d = rl(row[j], j);
                 if (lane == 0 && base + j < nb && !(d > 0.f) && *info == 0) *info = col0 + base + j + 1;   // not positive definite
                 const float r = ieee_sqrt(d);
                 const float lij = li > j ? ieee_div(row[j], r) : (li == j ? r : row[j]);
                 row[j] = lij;
 #pragma unroll
-                for (int k = j + 1; k < kSb; ++k) {
+                for (int k = j + 1; k < kFb; ++k) {
                     const float lkj = rl(lij, k);
                     row[k] = row[k] - ieee_mul(lij, lkj);          // (lanes li < k: the upper part, never stored -- no predicate)
                 }
             }
-            if (lane < kSb) {
+            if (lane < kFb) {
 #pragma unroll
-                for (int k = 0; k < kSb; ++k)
+                for (int k = 0; k < kFb; ++k)
                     if (k <= li) a[(base + li) * kCholLd + base + k] = row[k];
             }
         }
         __syncthreads();
-        CSTAMP(2 + 3 * (base / kSb));
-        const int below = base + kSb;
+        const int below = base + kFb;
         for (int i = below + tid; i < kCholNb; i += kCholThreads) {      // (b) forward substitution, one row per lane
-            float x[kSb];
+            float x[kFb];
 #pragma unroll
-            for (int c = 0; c < kSb; ++c) {
+            for (int c = 0; c < kFb; ++c) {
                 float acc = a[i * kCholLd + base + c];
 #pragma unroll
                 for (int k = 0; k < c; ++k) acc = acc - ieee_mul(x[k], a[(base + c) * kCholLd + base + k]);
                 x[c] = ieee_div(acc, a[(base + c) * kCholLd + base + c]);
             }
 #pragma unroll
-            for (int c = 0; c < kSb; ++c) a[i * kCholLd + base + c] = x[c];
+            for (int c = 0; c < kFb; ++c) a[i * kCholLd + base + c] = x[c];
         }
         __syncthreads();
-        CSTAMP(3 + 3 * (base / kSb));
-        const int m2 = (kCholNb - below) / 2;                    // (c) rank-32 update of what is left, 2x2 tiles per lane
+        const int m2 = (kCholNb - below) / 2;                    // (c) rank-16 update of what is left, 2x2 tiles per lane
         for (int e = tid; e < m2 * m2; e += kCholThreads) {
             const int i = below + 2 * (e / m2), k = below + 2 * (e % m2);
             if (k <= i) {
                 float acc00 = a[i * kCholLd + k], acc01 = a[i * kCholLd + k + 1];
                 float acc10 = a[(i + 1) * kCholLd + k], acc11 = a[(i + 1) * kCholLd + k + 1];
 #pragma unroll 8
-                for (int c = 0; c < kSb; ++c) {
+                for (int c = 0; c < kFb; ++c) {
                     const float li0 = a[i * kCholLd + base + c], li1 = a[(i + 1) * kCholLd + base + c];
                     const float lk0 = a[k * kCholLd + base + c], lk1 = a[(k + 1) * kCholLd + base + c];
                     acc00 = acc00 - ieee_mul(li0, lk0); acc01 = acc01 - ieee_mul(li0, lk1);
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(kCholThreads) void chol_block_kernel(const float *_
             }
         }
         __syncthreads();
-        CSTAMP(4 + 3 * (base / kSb));
+        CSTAMP(2 + base / kFb);
     }
     // ---- inverse of the lower-triangular block ----------------------------------------------------------------
     if (wave < kCholNb / kSb) {   // diagonal pieces: wave w inverts piece w; lane c < 32 owns column c:
