@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLMC_ABI_VERSION 3
+#define VLMC_ABI_VERSION 4
 
 #define VLMC_OK 0
 #define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
@@ -190,6 +190,21 @@ int vlmc_lora_grad(const void *G, int dtype, int64_t out_features, int64_t in_fe
  * samples per call, or any share of them on another GPU, yields identical rows.                     */
 int vlmc_linear_fwd(const void *X, const void *W, const void *bias, int dtype, int64_t M, int64_t N, int64_t K, int64_t ldx,
                     int64_t ldw, void *Y, int64_t ldy, void *stream);
+
+/* The same for up to 4 linears fed the SAME activations in ONE launch -- q / k / v of an attention (modeling_t5.py:546-572
+ * `self.q(hidden_states)`, `self.k(...)`, `self.v(...)`; modeling_llama.py:204-206), wi_0 / wi_1 of the gated FFN
+ * (modeling_t5.py:337-341), k / v of a cross-attention: job g computes Y_g[m, n] = wd(sum_k X[m, k] W_g[n, k] + bias_g[n]).
+ * Every output element is accumulated exactly as by vlmc_linear_fwd (same bits); what the launch shares is the chip:
+ * the tiles of all jobs are handed out together (three N = 2048 products of the T5 decoder are 3 x 64 tiles of 256 x 256
+ * in three launches, or 192 in one).                                                                     */
+typedef struct vlmc_linear_job {
+    const void *W;      /* [N, K], row stride ldw (multiple of 8 elements), 16-byte aligned */
+    const void *bias;   /* [N] in the operand dtype, or NULL                                */
+    void *Y;            /* [M, N], row stride ldy                                           */
+    int64_t N, ldw, ldy;
+} vlmc_linear_job;
+int vlmc_linear_fwd_group(const void *X, const vlmc_linear_job *jobs /* host array */, int n_jobs /* 1..4 */, int dtype,
+                          int64_t M, int64_t K, int64_t ldx, void *stream);
 
 /* ---- K8: SparseGPT Hessian accumulation (MFMA SYRK) -------------------------------------------------
  * Replaces the arithmetic of SparseGPT.add_batch, sparsegpt_pruner.py:76-79

@@ -85,6 +85,70 @@ def test_linear_fwd_is_batch_invariant(dtype, tokens, N, K):
     assert torch.equal(odd, whole[::2])
 
 
+@pytest.mark.parametrize("dtype,M,Ns,K", [
+    (torch.bfloat16, 2048, (2048, 2048, 2048), 2048),        # T5 decoder q / k / v: 192 tiles of 256 x 256 in one launch
+    (torch.bfloat16, 8192, (5120, 5120), 2048),              # T5 encoder wi_0 / wi_1: 1280 tiles, 5 whole rounds of the chip
+    (torch.float16, 257 * 9, (1408, 4224, 136, 1408), 1408), # half panels in three of four groups, half block of rows
+    (torch.bfloat16, 70, (40, 264, 8), 72),                  # register-staged kernel (K % 32 != 0), small tiles
+    (torch.float16, 300, (520,), 64),                        # one group through the group entry point
+])
+def test_linear_fwd_group_gives_every_job_the_bits_of_its_own_launch(dtype, M, Ns, K):
+    """vlmc_linear_fwd_group: up to 4 weights fed the same activations share ONE launch (q / k / v, wi_0 / wi_1).  What
+    a job computes must not depend on its neighbours: bit-identical to vlmc_linear_fwd per weight, with and without bias,
+    with a strided X."""
+    from vlmc import ops
+    g = torch.Generator(device=DEV).manual_seed(M + K + len(Ns))
+    xw = (torch.randn(M, K + 8, generator=g, device=DEV) * 0.5 + 0.1).to(dtype)
+    x = xw[:, :K]                                                          # row stride K + 8
+    ws = [(torch.randn(n, K, generator=g, device=DEV) * 0.05).to(dtype) for n in Ns]
+    bs = [(torch.randn(n, generator=g, device=DEV) * 0.1).to(dtype) if i % 2 == 0 else None for i, n in enumerate(Ns)]
+    got = ops.linear_fwd_group(x, ws, bs)
+    assert len(got) == len(Ns)
+    for y, w, b in zip(got, ws, bs):
+        assert y.shape == (M, w.shape[0]) and torch.equal(y, ops.linear_fwd(x, w, b))
+    ref = _ref64(x, ws[-1], bs[-1])
+    err = (got[-1].double() - ref).abs()
+    scale = x.double().abs() @ ws[-1].double().abs().t() + (bs[-1].double().abs() if bs[-1] is not None else 0)
+    assert bool((err <= ULP[dtype] * ref.abs() + 4e-7 * math.sqrt(K) * scale + 1e-30).all())
+    with pytest.raises(ValueError):
+        ops.linear_fwd_group(x, ws[:1] * 5)
+
+
+@pytest.mark.parametrize("dtype,M,N,K", [(torch.float16, 128 * 257, 6144, 1408),      # ViT-g fc1 of 128 samples: 3096 tiles
+                                         (torch.float16, 128 * 257, 1408, 6144),      # fc2: 5.5 panels x 128.5 blocks
+                                         (torch.bfloat16, 8192, 2048, 5120)])         # T5 wo: 256 tiles, K = 5120
+def test_persistent_256x256_kernel_against_fp64_at_prune_size(dtype, M, N, K):
+    """The kernel that carries a prune's GPU time -- gemm_nt_pingpong_kernel on 256 x 256 tiles, persistent workgroups,
+    half panels / half blocks handed out last -- held DIRECTLY against float64 at the calibration replay's own sizes
+    (128 samples per launch): 16 384 sampled entries plus the whole last rows / columns (the edge tiles), the stated
+    tolerance of test_linear_fwd_matches_fp64_reference."""
+    from vlmc import ops
+    g = torch.Generator(device=DEV).manual_seed(N + K)
+    x = (torch.randn(M, K, generator=g, device=DEV) * 0.5 + 0.1).to(dtype)
+    w = (torch.randn(N, K, generator=g, device=DEV) * 0.05).to(dtype)
+    b = (torch.randn(N, generator=g, device=DEV) * 0.1).to(dtype)
+    y = ops.linear_fwd(x, w, b)
+    assert y.shape == (M, N) and bool(torch.isfinite(y).all())
+
+    def check(rows, cols):
+        xr, wc = x[rows].double(), w[cols].double()
+        ref = (xr * wc).sum(-1) + b[cols].double()
+        scale = (xr.abs() * wc.abs()).sum(-1) + b[cols].double().abs()
+        err = (y[rows, cols].double() - ref).abs()
+        bound = ULP[dtype] * ref.abs() + 4e-7 * math.sqrt(K) * scale + 1e-30
+        assert bool((err <= bound).all()), float((err / bound).max())
+    check(torch.randint(0, M, (16384,), generator=g, device=DEV), torch.randint(0, N, (16384,), generator=g, device=DEV))
+    # the last block of rows and the last panel of columns, every element (edge tiles, masked waves)
+    rows = torch.arange(M - 40, M, device=DEV).repeat_interleave(N)
+    check(rows, torch.arange(N, device=DEV).repeat(40))
+    cols = torch.arange(N - 24, N, device=DEV).repeat(2048)
+    check(torch.randint(0, M, (2048,), generator=g, device=DEV).repeat_interleave(24), cols)
+    # a row of the big launch has the bits of its own sample's launch (batch invariance at full size)
+    for j in (0, 77, 127):
+        rows_j = slice(j * (M // 128), (j + 1) * (M // 128))
+        assert torch.equal(ops.linear_fwd(x[rows_j], w, b), y[rows_j])
+
+
 def test_linear_fwd_refuses_what_it_cannot_do():
     from vlmc import ops
     x = torch.randn(4, 16, device=DEV)
@@ -223,7 +287,7 @@ from vlmc import ops
 g = torch.Generator(device='cuda:0').manual_seed(11)
 outs = []
 for dt, M, N, K in [(torch.bfloat16, 700, 1024, 2048), (torch.float16, 3000, 1408, 1408), (torch.bfloat16, 64, 5120, 2048),
-                    (torch.float16, 9000, 4224, 352)]:
+                    (torch.float16, 9000, 4224, 352), (torch.float16, 20 * 257, 6144, 96)]:
     x = (torch.randn(M, K, generator=g, device='cuda:0') * 0.5 + 0.1).to(dt)
     w = (torch.randn(N, K, generator=g, device='cuda:0') * 0.05).to(dt)
     b = (torch.randn(N, generator=g, device='cuda:0') * 0.1).to(dt)
@@ -236,10 +300,13 @@ torch.save(outs, sys.argv[1])
     results = []
     # (ring, tiles needed for the 256 x 256 shape, the two waves of a SIMD half a step apart)
     # (ring, tiles needed for the 256 x 256 shape, the two waves of a SIMD half a step apart, persistent workgroups)
-    for ring, big, pp, persist in (("1", "200", "1", "1"), ("0", "200", "1", "1"), ("1", "1", "1", "1"), ("1", "1", "1", "0"),
-                                  ("1", "1", "0", "1"), ("0", "0", "1", "1"), ("1", "0", "1", "1")):
-        out = tmp_path / f"r{ring}_b{big}_p{pp}_s{persist}.pt"
-        env = dict(os.environ, VLMC_GEMM_RING=ring, VLMC_GEMM_BIG_TILES=big, VLMC_GEMM_PINGPONG=pp, VLMC_GEMM_PERSIST=persist)
+    # ... half panels / blocks handed out last)
+    for ring, big, pp, persist, edge in (("1", "200", "1", "1", "1"), ("0", "200", "1", "1", "1"), ("1", "1", "1", "1", "1"),
+                                        ("1", "1", "1", "0", "1"), ("1", "1", "0", "1", "1"), ("0", "0", "1", "1", "1"),
+                                        ("1", "0", "1", "1", "1"), ("1", "1", "1", "1", "0")):
+        out = tmp_path / f"r{ring}_b{big}_p{pp}_s{persist}_e{edge}.pt"
+        env = dict(os.environ, VLMC_GEMM_RING=ring, VLMC_GEMM_BIG_TILES=big, VLMC_GEMM_PINGPONG=pp, VLMC_GEMM_PERSIST=persist,
+                   VLMC_GEMM_EDGE=edge)
         r = subprocess.run([sys.executable, "-c", code, str(out)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         results.append(torch.load(out))

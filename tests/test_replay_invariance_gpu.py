@@ -23,7 +23,7 @@ def _blocks():
 
 
 @pytest.mark.parametrize("which", ["vit", "enc", "dec"])
-def test_block_forward_is_batch_invariant_at_model_width(which):
+def test_block_forward_is_batch_invariant_at_model_width(which, monkeypatch):
     """One transformer block at InstructBLIP-FlanT5-XL's dimensions: 6 samples per forward == 6 forwards of one sample,
     bit for bit, with the linears on vlmc_linear_fwd (attention, norms and activations are per-sample by nature)."""
     from vlmc import forward
@@ -52,6 +52,22 @@ def test_block_forward_is_batch_invariant_at_model_width(which):
     assert torch.equal(allg, torch.cat(one)), f"{which}: grouped forward differs from the per-sample forwards"
     assert torch.equal(torch.cat(three), allg)
     assert not any("forward" in m.__dict__ for m in subset.values())                 # patches are gone
+    # sibling linears (q / k / v, wi_0 / wi_1, cross-attention k / v) were learned from the first forward and shared launches
+    # in the later ones; with the grouping switched off the block computes the same bits
+    grouped = forward.stats["grouped_launches"] - before["grouped_launches"]
+    groups = forward.sibling_groups(subset.values())
+    if which == "vit":
+        assert grouped == 0 and not groups                                          # one fused qkv linear already
+    else:
+        want = [("q", "k", "v"), ("wi_0", "wi_1")] + ([("k", "v")] if which == "dec" else [])
+        names = {id(m): n.split(".")[-1] for n, m in subset.items()}
+        assert sorted(tuple(names[id(m)] for m in g) for g in groups) == sorted(want)
+        assert grouped == len(want) * (n + 2)                                       # every forward after the first
+        assert forward.stats["stash_dropped"] == before["stash_dropped"]
+    monkeypatch.setenv("VLMC_LINEAR_GROUP", "0")
+    with torch.no_grad(), forward.invariant_linears(subset.values()):
+        assert torch.equal(call(torch.cat(xs), stacked_kw), allg)
+    assert forward.stats["grouped_launches"] - before["grouped_launches"] == grouped
 
 
 def _run_16bit_toy(method, group, monkeypatch, ragged=False, sdpa=True):

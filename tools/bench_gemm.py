@@ -32,7 +32,12 @@ def main():
         ("t5enc.wo", torch.bfloat16, 128 * 64, 2048, 5120), ("t5dec.q", torch.bfloat16, 128 * 16, 2048, 2048),
         ("t5dec.wi", torch.bfloat16, 128 * 16, 5120, 2048), ("t5dec.wo", torch.bfloat16, 128 * 16, 2048, 5120),
         ("one sample t5enc.q", torch.bfloat16, 64, 2048, 2048), ("one sample vit.fc1", torch.float16, 257, 6144, 1408),
+        # one rank's share at 8 / 4 GPUs: 16 / 32 samples
+        ("N=8 vit.fc1", torch.float16, 16 * 257, 6144, 1408), ("N=8 vit.fc2", torch.float16, 16 * 257, 1408, 6144),
+        ("N=8 t5enc.wi", torch.bfloat16, 16 * 64, 5120, 2048), ("N=8 t5dec.q", torch.bfloat16, 16 * 16, 2048, 2048),
+        ("N=4 vit.fc1", torch.float16, 32 * 257, 6144, 1408), ("N=4 t5enc.wi", torch.bfloat16, 32 * 64, 5120, 2048),
     ]
+    print(f"(VLMC_GEMM_EDGE={os.environ.get('VLMC_GEMM_EDGE', '1')} VLMC_GEMM_BIG_TILES={os.environ.get('VLMC_GEMM_BIG_TILES', '200')})")
     print("| linear | M x N x K | vlmc_linear_fwd us | TFLOP/s | library us | TFLOP/s |")
     print("|---|---|---|---|---|---|")
     for name, dt, M, N, K in shapes:
@@ -45,6 +50,29 @@ def main():
         fl = 2.0 * M * N * K
         to, tl = statistics.median(ours), statistics.median(lib)
         print(f"| {name} {str(dt)[6:]} | {M} x {N} x {K} | {to * 1e3:.1f} | {fl / to / 1e9:.0f} | {tl * 1e3:.1f} | {fl / tl / 1e9:.0f} |", flush=True)
+    print()
+    print("| linears sharing one input | M x (N...) x K | one vlmc_linear_fwd_group launch us | TFLOP/s | separate vlmc_linear_fwd launches us | TFLOP/s | library us | TFLOP/s |")
+    print("|---|---|---|---|---|---|---|---|")
+    for name, dt, M, Ns, K in [("t5enc q/k/v", torch.bfloat16, 128 * 64, (2048,) * 3, 2048),
+                               ("t5enc wi_0/wi_1", torch.bfloat16, 128 * 64, (5120,) * 2, 2048),
+                               ("t5dec q/k/v", torch.bfloat16, 128 * 16, (2048,) * 3, 2048),
+                               ("t5dec cross k/v", torch.bfloat16, 128 * 64, (2048,) * 2, 2048),
+                               ("t5dec wi_0/wi_1", torch.bfloat16, 128 * 16, (5120,) * 2, 2048),
+                               ("vicuna q/k/v", torch.float16, 128 * 96, (4096,) * 3, 4096),
+                               ("vicuna gate/up", torch.float16, 128 * 96, (11008,) * 2, 4096)]:
+        x = (torch.randn(M, K, device=dev) * 0.5).to(dt)
+        ws = [(torch.randn(n, K, device=dev) * 0.05).to(dt) for n in Ns]
+        grp, sep, lib = [], [], []
+        for _ in range(5):
+            grp.append(timeit(lambda: ops.linear_fwd_group(x, ws), 10))
+            sep.append(timeit(lambda: [ops.linear_fwd(x, w) for w in ws], 10))
+            lib.append(timeit(lambda: [F.linear(x, w) for w in ws], 10))
+        fl = 2.0 * M * sum(Ns) * K
+        tg, ts, tl = statistics.median(grp), statistics.median(sep), statistics.median(lib)
+        print(f"| {name} {str(dt)[6:]} | {M} x {Ns} x {K} | {tg * 1e3:.1f} | {fl / tg / 1e9:.0f} | {ts * 1e3:.1f} | {fl / ts / 1e9:.0f} "
+              f"| {tl * 1e3:.1f} | {fl / tl / 1e9:.0f} |", flush=True)
+    if os.environ.get("BENCH_GEMM_ONLY_LINEAR") == "1":
+        return
     print()
     print("| Hessian | rows x in | vlmc_hessian_accum us (transpose + SYRK) | TFLOP/s (2 T in^2) | addmm_ fp32 us | TFLOP/s |")
     print("|---|---|---|---|---|---|")

@@ -1,0 +1,68 @@
+"""A/B of the GEMM engine's launch-time switches on one box: every configuration is a child process (the switches are read
+once per process), same shapes, interleaved rounds inside each child, median.  `python tools/gemm_ab.py [shape-set]`."""
+import itertools
+import json
+import os
+import statistics
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHAPES = {
+    "vit": [("vit.qkv", "float16", 128 * 257, 4224, 1408), ("vit.proj", "float16", 128 * 257, 1408, 1408),
+            ("vit.fc1", "float16", 128 * 257, 6144, 1408), ("vit.fc2", "float16", 128 * 257, 1408, 6144)],
+    "t5": [("t5enc.q", "bfloat16", 8192, 2048, 2048), ("t5enc.wi", "bfloat16", 8192, 5120, 2048), ("t5enc.wo", "bfloat16", 8192, 2048, 5120),
+           ("t5dec.wi", "bfloat16", 2048, 5120, 2048)],
+    "rank": [("N=8 vit.fc1", "float16", 16 * 257, 6144, 1408), ("N=8 vit.fc2", "float16", 16 * 257, 1408, 6144),
+             ("N=8 vit.qkv", "float16", 16 * 257, 4224, 1408), ("N=8 t5enc.wi", "bfloat16", 1024, 5120, 2048),
+             ("N=4 vit.fc2", "float16", 32 * 257, 1408, 6144), ("N=2 vit.fc2", "float16", 64 * 257, 1408, 6144)],
+}
+
+CHILD = r"""
+import json, os, statistics, sys, torch
+sys.path.insert(0, os.path.join(%r, 'vlm-compression_amd'))
+from vlmc import ops
+shapes = json.loads(sys.argv[1])
+dev = 'cuda:0'
+def timeit(fn, reps):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+out = {}
+data = []
+for name, dt, M, N, K in shapes:
+    dt = getattr(torch, dt)
+    data.append(((torch.randn(M, K, device=dev) * 0.5).to(dt), (torch.randn(N, K, device=dev) * 0.05).to(dt)))
+ts = [[] for _ in shapes]
+for r in range(5):
+    for i, (x, w) in enumerate(data):
+        ts[i].append(timeit(lambda: ops.linear_fwd(x, w), 10))
+print(json.dumps([statistics.median(t) * 1e3 for t in ts]))
+""" % ROOT
+
+
+def main():
+    sets = sys.argv[1:] or ["vit", "t5"]
+    shapes = [s for k in sets for s in SHAPES[k]]
+    configs = [{"VLMC_GEMM_EDGE": "0"}, {"VLMC_GEMM_EDGE": "1"}]
+    extra = os.environ.get("GEMM_AB_CONFIGS")
+    if extra:
+        configs = [dict(kv.split("=") for kv in c.split(",")) for c in extra.split(";")]
+    print("| " + " | ".join(["config"] + [f"{n} {M}x{N}x{K}" for n, _, M, N, K in shapes]) + " |")
+    print("|" + "---|" * (len(shapes) + 1))
+    for rep in range(2):
+        for cfg in configs:
+            env = dict(os.environ, **cfg)
+            r = subprocess.run([sys.executable, "-c", CHILD, json.dumps(shapes)], env=env, capture_output=True, text=True, timeout=900)
+            if r.returncode != 0:
+                print(cfg, "FAILED", r.stderr[-500:])
+                continue
+            us = json.loads(r.stdout.strip().splitlines()[-1])
+            cells = [f"{u:.1f} us ({2.0 * M * N * K / u / 1e6:.0f})" for u, (_, _, M, N, K) in zip(us, shapes)]
+            print("| " + " | ".join([" ".join(f"{k[10:]}={v}" for k, v in cfg.items())] + cells) + " |", flush=True)
+
+
+if __name__ == "__main__":
+    main()

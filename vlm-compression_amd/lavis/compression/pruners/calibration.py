@@ -1347,15 +1347,25 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                         cur_out[j] = slices[t]
 
     graphs, plan, stacked_kwargs, tail_learned = {}, {}, {}, {}
+    sibling_names = []
     for i in range(len(layers)):
         layer = layers[i]
         subset = find_layers(layer)
         graphs.clear()             # per block; the second pass reuses the first one's graphs when storage is unchanged
         # the block's linears run on the batch-invariant MFMA kernel in both passes (vlmc/forward.py): how the samples are
         # grouped -- or sharded over GPUs -- does not reach the statistics
+        # linears fed one tensor (q / k / v, wi_0 / wi_1) share a launch: the groups the first block's forward showed are
+        # carried over to the following blocks by name, so that their first pass is fused too (vlmc/forward.py)
+        for names in sibling_names:
+            if all(n in subset for n in names):
+                forward.register_siblings([subset[n] for n in names])
         with forward.invariant_linears(subset.values()):
             prune_block(i, layer, subset, run_pass, state)
             run_pass()
+        if i == 0:
+            by_id = {id(m): n for n, m in subset.items()}
+            sibling_names = [tuple(by_id[id(m)] for m in g) for g in forward.sibling_groups(subset.values())
+                             if all(id(m) in by_id for m in g)]
         state["inps"], state["outs"] = state["outs"], state["inps"]
     if memo_cache is not None and not tuple_output:
         seed_tower_memo(memo_cache, module_to_process, layers, state["inps"][:n_samples], autocast)

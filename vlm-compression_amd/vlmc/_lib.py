@@ -33,6 +33,10 @@ class SelectJob(_c.Structure):        # vlmc_select_job
                 ("mask", _p), ("score_partials", _p), ("workspace", _p), ("workspace_bytes", _sz)]
 
 
+class LinearJob(_c.Structure):        # vlmc_linear_job
+    _fields_ = [("W", _p), ("bias", _p), ("Y", _p), ("N", _i64), ("ldw", _i64), ("ldy", _i64)]
+
+
 class ScoreJob(_c.Structure):         # vlmc_score_job
     _fields_ = [("W", _p), ("S", _p), ("prev_keep", _p), ("keep", _p), ("numel", _i64), ("protect_k", _i64),
                 ("scope", _c.c_int32), ("dtype", _c.c_int32)]
@@ -59,6 +63,7 @@ SIGNATURES = {
     "vlmc_dsnot_refine": (_i, [_p, _i, _i64, _i64, _i64, _p, _p, _p, _p, _i, _i, _i, _i, _c.c_float, _c.c_float, _i, _p, _p, _p]),
     "vlmc_dsnot_apply": (_i, [_p, _i, _i64, _i64, _i64, _p, _p, _p, _i, _i, _i, _p]),
     "vlmc_linear_fwd": (_i, [_p, _p, _p, _i, _i64, _i64, _i64, _i64, _i64, _p, _i64, _p]),
+    "vlmc_linear_fwd_group": (_i, [_p, _p, _i, _i, _i64, _i64, _i64, _p]),
     "vlmc_hessian_workspace": (_sz, [_i, _i64, _i64]),
     "vlmc_hessian_accum": (_i, [_p, _i, _i64, _i64, _i64, _p, _i64, _c.c_float, _c.c_float, _p, _sz, _p]),
     "vlmc_symmetrize_lower": (_i, [_p, _i64, _i64, _p]),

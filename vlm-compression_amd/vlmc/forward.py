@@ -8,11 +8,23 @@ the same bits whatever else is in the launch.  A GEMM library picks its kernel b
 not (csrc/gemm_nt.hip).  While `invariant_linears(modules)` is active, the forward of those `nn.Linear` modules (and the
 dense branch of the SparseLoRA `Linear`) runs on it whenever it can: 16-bit weights and activations of one dtype (an
 active autocast to the weights' dtype casts the input like autocast would), no gradients.  Everything else -- fp32
-models, odd widths -- stays with `F.linear`.  `VLMC_LINEAR_FWD=0` switches the kernel off."""
+models, odd widths -- stays with `F.linear`.  `VLMC_LINEAR_FWD=0` switches the kernel off.
+
+Sibling linears share a launch (`VLMC_LINEAR_GROUP=0`: never).  The model calls `self.q(h)`, `self.k(h)`, `self.v(h)`
+one after the other on the SAME tensor (modeling_t5.py:546-572, modeling_llama.py:204-206; wi_0 / wi_1 of the gated FFN,
+modeling_t5.py:337-341; k / v of a cross-attention): three launches that each fill a fraction of the chip (a decoder
+projection of 128 x 16 tokens is 64 tiles of 256 x 256 on 256 CUs).  Which linears are siblings is LEARNED from the
+calls -- consecutive calls of patched linears whose input is the very same tensor (same storage, offset, shape, strides,
+version counter, kept alive in between) -- never assumed from names.  Once a group is known, the call of its first member
+computes every member's product in one `vlmc_linear_fwd_group` launch and keeps the others' outputs for their calls, which
+check that they are handed the tensor the products were computed from (anything else: the stash is dropped and the linear
+computes for itself).  The products are the bits the single launches give (tests/test_gemm_gpu.py); module hooks fire per
+module as before, only `forward` is replaced."""
 from __future__ import annotations
 
 import contextlib
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -21,28 +33,123 @@ import torch.nn.functional as F
 from . import ops
 
 _active = 0
-stats = {"kernel": 0, "library": 0}
+stats = {"kernel": 0, "library": 0, "grouped_launches": 0, "served_from_group": 0, "stash_dropped": 0}
+
+# first member of a learned sibling group -> tuple of weak references to all members, in call order
+_SIBLINGS = weakref.WeakKeyDictionary()
 
 
 def enabled():
     return os.environ.get("VLMC_LINEAR_FWD", "1") != "0"
 
 
+def grouping_enabled():
+    return os.environ.get("VLMC_LINEAR_GROUP", "1") != "0"
+
+
+def _prepare(x, weight, bias):
+    """What the kernel would be fed for `F.linear(x, weight, bias)`, or None if the call stays with the library."""
+    if not (_active and not torch.is_grad_enabled() and weight.is_cuda):
+        return None
+    xin = x
+    autocast = torch.is_autocast_enabled()
+    if autocast and x.is_floating_point() and x.dtype != weight.dtype and torch.get_autocast_gpu_dtype() == weight.dtype:
+        xin = x.to(weight.dtype)                                # what autocast does to the input of a linear
+    b = bias
+    if b is not None and b.dtype != weight.dtype and autocast and torch.get_autocast_gpu_dtype() == weight.dtype:
+        b = b.to(weight.dtype)
+    if ops.linear_fwd_supported(xin, weight, b) and (not autocast or torch.get_autocast_gpu_dtype() == weight.dtype):
+        return xin, b
+    return None
+
+
 def linear(x, weight, bias=None):
     """`F.linear` for a calibration forward: the invariant kernel when the replay engine asked for it and the call fits."""
-    if _active and not torch.is_grad_enabled() and weight.is_cuda:
-        xin = x
-        if torch.is_autocast_enabled() and x.is_floating_point() and x.dtype != weight.dtype and \
-                torch.get_autocast_gpu_dtype() == weight.dtype:
-            xin = x.to(weight.dtype)                            # what autocast does to the input of a linear
-        b = bias
-        if b is not None and b.dtype != weight.dtype and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == weight.dtype:
-            b = b.to(weight.dtype)
-        if ops.linear_fwd_supported(xin, weight, b) and (not torch.is_autocast_enabled() or torch.get_autocast_gpu_dtype() == weight.dtype):
-            stats["kernel"] += 1
-            return ops.linear_fwd(xin, weight, b, _checked=True)     # (linear_fwd_supported has just said yes)
+    p = _prepare(x, weight, bias)
+    if p is not None:
+        stats["kernel"] += 1
+        return ops.linear_fwd(p[0], weight, p[1], _checked=True)     # (linear_fwd_supported has just said yes)
     stats["library"] += 1
     return F.linear(x, weight, bias)
+
+
+def _input_key(x):
+    return (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()), x.dtype)
+
+
+def register_siblings(modules):
+    """Declare `modules` (in call order) linears that are fed one tensor -- what `_Tracker` learns by itself from a
+    forward; `walk_blocks` carries the groups it learned on a tower's first block over to the next blocks by name."""
+    modules = tuple(modules)
+    if len(modules) >= 2 and len(modules) <= ops.LINEAR_GROUP_MAX:
+        _SIBLINGS[modules[0]] = tuple(weakref.ref(m) for m in modules)
+
+
+def sibling_groups(modules):
+    """The learned groups whose first member is one of `modules`: list of tuples of modules."""
+    out = []
+    for m in modules:
+        refs = _SIBLINGS.get(m)
+        if refs:
+            group = tuple(r() for r in refs)
+            if all(g is not None for g in group):
+                out.append(group)
+    return out
+
+
+class _Tracker:
+    """Per `invariant_linears` context: learns sibling groups from the calls, serves them."""
+
+    def __init__(self, patched):
+        self.patched = {id(m) for m in patched}
+        self.run, self.run_x, self.run_key = [], None, None      # consecutive calls on one tensor (the tensor kept alive)
+        self.stash = {}                                          # id(module) -> (x, key, y)
+        self.grouping = grouping_enabled()
+
+    def _close_run(self):
+        if len(self.run) >= 2 and len({id(m) for m in self.run}) == len(self.run) and self.run[0] not in _SIBLINGS:
+            register_siblings(self.run[:ops.LINEAR_GROUP_MAX])
+        self.run, self.run_x, self.run_key = [], None, None
+
+    def call(self, mod, x):
+        if not self.grouping or not isinstance(x, torch.Tensor):
+            return linear(x, mod.weight, mod.bias)
+        key = _input_key(x)
+        # ---- served from a sibling's launch? --------------------------------------------------------------------------
+        kept = self.stash.pop(id(mod), None)
+        if kept is not None:
+            if kept[1] == key and kept[0].untyped_storage().data_ptr() == x.untyped_storage().data_ptr():
+                stats["served_from_group"] += 1
+                return kept[2]
+            stats["stash_dropped"] += 1
+        # ---- learn: consecutive calls on the very same tensor -------------------------------------------------------------
+        if self.run and key == self.run_key:
+            self.run.append(mod)
+        else:
+            self._close_run()
+            self.run, self.run_x, self.run_key = [mod], x, key
+        # ---- first member of a known group: one launch for all ------------------------------------------------------------
+        refs = _SIBLINGS.get(mod)
+        if refs:
+            group = [r() for r in refs]
+            if all(g is not None and id(g) in self.patched for g in group):
+                preps = [_prepare(x, g.weight, g.bias) for g in group]
+                if all(p is not None for p in preps) and all(p[0] is preps[0][0] or p[0].dtype == preps[0][0].dtype for p in preps) \
+                        and len({g.weight.shape[1] for g in group}) == 1:
+                    xin = preps[0][0]
+                    outs = ops.linear_fwd_group(xin, [g.weight for g in group], [p[1] for p in preps])
+                    stats["kernel"] += len(group)
+                    stats["grouped_launches"] += 1
+                    for g, y in zip(group[1:], outs[1:]):
+                        self.stash[id(g)] = (x, key, y)
+                    return outs[0]
+        return linear(x, mod.weight, mod.bias)
+
+    def close(self):
+        self._close_run()
+        if self.stash:
+            stats["stash_dropped"] += len(self.stash)
+        self.stash.clear()
 
 
 @contextlib.contextmanager
@@ -52,15 +159,15 @@ def invariant_linears(modules):
     if not enabled():
         yield
         return
-    patched = []
-    for m in modules:
-        if type(m) is nn.Linear and "forward" not in m.__dict__:
-            m.forward = (lambda mod: (lambda x: linear(x, mod.weight, mod.bias)))(m)
-            patched.append(m)
+    patched = [m for m in modules if type(m) is nn.Linear and "forward" not in m.__dict__]
+    tracker = _Tracker(patched)
+    for m in patched:
+        m.forward = (lambda mod: (lambda x: tracker.call(mod, x)))(m)
     _active += 1
     try:
-        yield
+        yield tracker
     finally:
         _active -= 1
+        tracker.close()
         for m in patched:
             m.__dict__.pop("forward", None)
