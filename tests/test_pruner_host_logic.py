@@ -162,9 +162,9 @@ def test_batched_replay_keeps_per_sample_statistics(method, monkeypatch):
     calls = {"n": 0, "stacked": 0}
     real = cal._stack_caches
 
-    def counting(group):
+    def counting(group, b0):
         calls["stacked"] += 1
-        return real(group)
+        return real(group, b0)
     monkeypatch.setattr(cal, "_stack_caches", counting)
     if method == "wanda":
         oracle_ops.install(monkeypatch)
@@ -304,7 +304,7 @@ def test_statistics_pass_runs_to_the_end_when_the_order_is_not_the_learned_one()
             return self.a(self.b(x)) if self.flip else self.b(self.a(x))
 
     x = torch.randn(3, 4)
-    blk, learned = Twice(), {}
+    blk, learned = Twice().eval(), {}
     for _ in range(2):
         with cal.statistics_only(cal.find_layers(blk), learned) as so:
             so.new_forward()
@@ -313,7 +313,7 @@ def test_statistics_pass_runs_to_the_end_when_the_order_is_not_the_learned_one()
         assert torch.equal(y, blk.a(blk.b(blk.a(x))))
     assert learned["order"] is False
 
-    first, same, flipped, learned = Ordered(), Ordered(), Ordered(flip=True), {}
+    first, same, flipped, learned = Ordered().eval(), Ordered().eval(), Ordered(flip=True).eval(), {}
     seen_inputs = []
     with cal.statistics_only(cal.find_layers(first), learned) as so:
         so.new_forward()
@@ -333,3 +333,114 @@ def test_statistics_pass_runs_to_the_end_when_the_order_is_not_the_learned_one()
         y = flipped(x)                                                           # b first: not the learned order
         so.end_forward(True)
     assert torch.equal(y, flipped.a(flipped.b(x)))
+
+
+# ---- round 3: advisor findings ----------------------------------------------------------------------------------------
+def test_dead_tail_hands_hooks_no_product_and_stays_off_in_training_mode():
+    """The cut linear's product is never formed: forward hooks get `None` for it (a hook that reads `out` fails loudly instead
+    of reading uninitialised memory), and a training-mode block is never cut."""
+    from lavis.compression.pruners import calibration as cal
+
+    class Two(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)
+
+        def forward(self, x):
+            return self.b(self.a(x))
+
+    x = torch.randn(3, 4)
+    first, second, learned = Two().eval(), Two().eval(), {}
+    with cal.statistics_only(cal.find_layers(first), learned) as so:
+        so.new_forward()
+        first(x)
+        so.end_forward(True)
+    outs = []
+    h = second.b.register_forward_hook(lambda m, i, o: outs.append(o))
+    with cal.statistics_only(cal.find_layers(second), learned) as so:
+        so.new_forward()
+        with pytest.raises(cal._TailStop):
+            second(x)
+    assert outs == [None]
+    second.train()
+    outs.clear()
+    with cal.statistics_only(cal.find_layers(second), learned) as so:
+        so.new_forward()
+        y = second(x)                                        # runs to the end
+        so.end_forward(True)
+    h.remove()
+    assert len(outs) == 1 and torch.equal(outs[0], y)
+
+
+def test_stacked_kwargs_only_concatenate_what_has_the_batch_dimension():
+    """`_stack_caches`: per-sample tensors are concatenated; a tensor without the samples' batch dimension (a ViT
+    rel_pos_bias [heads, N, N], a layer_head_mask [heads]) is passed once when all samples agree; disagreeing ones send the
+    group to the per-sample path (None)."""
+    from lavis.compression.pruners import calibration as cal
+    bias = torch.randn(4, 5, 5)
+    head_mask = torch.ones(4)
+    group = [dict(attention_mask=torch.full((1, 1, 1, 5), float(j)), rel_pos_bias=bias, layer_head_mask=head_mask.clone(),
+                  use_cache=False) for j in range(3)]
+    kw = cal._stack_caches(group, 1)
+    assert kw["attention_mask"].shape == (3, 1, 1, 5) and kw["rel_pos_bias"] is bias and kw["use_cache"] is False
+    assert kw["layer_head_mask"].shape == (4,)
+    group[1]["rel_pos_bias"] = bias + 1
+    assert cal._stack_caches(group, 1) is None
+
+
+def test_walk_blocks_replays_sample_by_sample_when_kwargs_cannot_be_stacked(monkeypatch):
+    """A block with a batch-free kwarg that differs between samples: the grouped replay falls back to the reference's
+    per-sample loop for that group and every sample meets ITS kwarg."""
+    from lavis.compression.pruners import calibration as cal
+    monkeypatch.setenv("VLMC_LINEAR_FWD", "0")
+
+    class Blk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(4, 4)
+
+        def forward(self, x, rel_pos_bias=None):
+            assert rel_pos_bias.shape == (2, 3, 3)
+            return self.lin(x) + rel_pos_bias.sum()
+
+    model = torch.nn.Module()
+    model.blocks = torch.nn.ModuleList([Blk(), Blk()]).eval()
+    xs = [torch.randn(1, 3, 4) for _ in range(4)]
+    caches = [dict(rel_pos_bias=torch.full((2, 3, 3), float(j))) for j in range(4)]
+    want = []
+    for x, c in zip(xs, caches):
+        with torch.no_grad():
+            want.append(model.blocks[1](model.blocks[0](x, **c), **c))
+    inps, outs = list(xs), [None] * 4
+    import contextlib
+    cal.walk_blocks(model, inps, outs, caches, "blocks", 4, contextlib.nullcontext, lambda i, layer, subset, run, state: run(), False)
+    final = inps if outs[0] is None or not torch.equal(outs[0], want[0]) else outs
+    got = final
+    for j in range(4):
+        assert torch.equal(got[j], want[j]), j
+
+
+def test_deferred_importance_scores_survive_a_failing_tower(monkeypatch):
+    """`prune()` postpones the importance-score readback to its end; if a tower raises, the flag must not outlive the call
+    and the towers already pruned still get their scores."""
+    import toy_models
+    from lavis.compression import load_pruner
+    from lavis.compression.pruners import wanda_pruner as wp
+    oracle_ops.install(monkeypatch)
+    model = toy_models.init_toy(toy_models.ToyBlipT5(), seed=3).eval()
+    batches = toy_models.make_batches(4, seed=1)
+    spec = "2-0.5-1.0-1.0"
+    pruner = load_pruner("blipt5_wanda_pruner", model, batches, cfg=dict(t5_prune_spec=spec, vit_prune_spec=spec, t5_pruning_method="wanda",
+                                                                         vit_pruning_method="wanda", num_samples=4, max_sparsity_per_layer=1.01))
+    real = wp.T5LayerWandaPruner._prune
+
+    def boom(self, *a, **k):
+        raise RuntimeError("tower failed")
+    monkeypatch.setattr(wp.T5LayerWandaPruner, "_prune", boom)
+    with pytest.raises(RuntimeError, match="tower failed"):
+        pruner.prune()
+    assert pruner._defer_score_readback is False and not pruner.__dict__.get("_score_backlog")
+    scored = [n for n, m in model.named_modules() if isinstance(m, torch.nn.Linear) and "visual_encoder.blocks" in n
+              and hasattr(m.weight, "importance_score")]
+    assert len(scored) == 2 * 4                                # the ViT tower was done: its scores are there
+    monkeypatch.setattr(wp.T5LayerWandaPruner, "_prune", real)

@@ -2,7 +2,7 @@
 # Round-2 profile collection on the GPU box (run from the repo root): kernel stats of the bench, PMC traffic (separate passes),
 # summaries into gpurun_out/r02/ -- the raw traces stay on the box (gpurun copies back at most 64 MiB).
 set -o pipefail
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 mkdir -p gpurun_out/r02
 BENCH="python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0"
 if [ "${SKIP_STATS:-0}" != "1" ]; then

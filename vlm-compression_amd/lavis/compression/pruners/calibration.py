@@ -1044,8 +1044,8 @@ class statistics_only:
         self.seen, self.handles, self.last = [], [], None
 
     def __enter__(self):
-        if not tail_skip_enabled() or self.learned.get("order") is False:
-            return self
+        if not tail_skip_enabled() or self.learned.get("order") is False or any(m.training for m in self.subset.values()):
+            return self                                      # (a training-mode block may draw random numbers behind the cut)
         names = {id(m): n for n, m in self.subset.items()}
 
         def note(mod, args):
@@ -1060,7 +1060,7 @@ class statistics_only:
             def dead_product(x, *a, **kw):
                 if tuple(self.seen) != order:                # not the sequence that was learned: compute
                     return inner(x, *a, **kw)
-                return x.new_empty(tuple(x.shape[:-1]) + (last.weight.shape[0],))
+                return None                                  # the product is never formed: a hook that reads `out` fails loudly
 
             def stop(mod, args, out):
                 if tuple(self.seen) == order:
@@ -1147,11 +1147,24 @@ def _stack_key(x, cache):
     return tuple(sig)
 
 
-def _stack_caches(group):
+def _stack_caches(group, b0):
+    """The cached kwargs of a group of samples as ONE set of kwargs for a stacked forward, or None if they cannot be:
+    tensors that carry the samples' batch dimension (`shape[0] == b0`: attention masks, encoder states, a per-sample
+    position bias) are concatenated along it; a tensor WITHOUT it (a ViT `rel_pos_bias` [heads, N, N], a `layer_head_mask`
+    [heads]) is passed once if every sample holds the same object or the same bits -- concatenating it would hand the
+    block a wrong shape, or broadcast silently where the sizes happen to line up; anything else sends the group to the
+    per-sample path."""
     out = {}
     for k in group[0]:
         v0 = group[0][k]
-        out[k] = torch.cat([c[k] for c in group], dim=0) if isinstance(v0, torch.Tensor) else v0
+        if not isinstance(v0, torch.Tensor):
+            out[k] = v0
+        elif v0.dim() >= 1 and v0.shape[0] == b0 and v0.dim() >= 2:
+            out[k] = torch.cat([c[k] for c in group], dim=0)
+        elif all(c[k] is v0 for c in group[1:]) or all(_bits_equal(c[k], v0) for c in group[1:]):
+            out[k] = v0
+        else:
+            return None
     return out
 
 
@@ -1331,7 +1344,21 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                         x = torch.cat([cur_in[j] for j in chunk], dim=0)
                     kw = stacked_kwargs.get(key)
                     if kw is None:
-                        kw = stacked_kwargs[key] = _stack_caches([caches[j] for j in chunk])
+                        kw = _stack_caches([caches[j] for j in chunk], b0)
+                        kw = stacked_kwargs[key] = kw if kw is not None else False
+                    if kw is False:                                 # kwargs that cannot be stacked: sample by sample
+                        _STACKED = None
+                        for j in chunk:
+                            if so is not None:
+                                so.new_forward()
+                            try:
+                                y = layer(cur_in[j], **caches[j])
+                            except _TailStop:
+                                continue
+                            if so is not None:
+                                so.end_forward(True)
+                            cur_out[j] = y[0] if tuple_output else y
+                        continue
                     try:
                         y = layer(x, **kw)
                     except _TailStop:

@@ -436,29 +436,31 @@ class BLIPT5LayerWandaPruner(LayerWiseBasePruner):
         self.vit_dense = True if float(vit_keep_ratio) < 1. else False
         self.llm_dense = True if float(t5_keep_ratio) < 1. else False
         self._defer_score_readback = True           # importance scores are read back once, below
-
-        if self.vit_prune_spec is not None and float(vit_keep_ratio) < 1.:
-            sd = global_sparsity_dict if global_sparsity_dict not in [None, "none"] else \
-                self.get_sparsity(1 - vit_keep_ratio, sparsity_ratio_granularity=None)
-            self.model = self._tower(VITLayerWandaPruner, model_prefix=self.vit_model_prefix,
-                                     module_to_process=f"{self.vit_model_prefix}.blocks",
-                                     n_samples=self.num_samples, sparsity_ratio=sd, lora_model=lora_model)
-
-        if self.t5_prune_spec is not None and float(t5_keep_ratio) < 1.:
-            sd = global_sparsity_dict if global_sparsity_dict is not None else \
-                self.get_sparsity(1 - t5_keep_ratio, sparsity_ratio_granularity=None)
-            if "t5_model" in self.t5_model_prefix:
-                for side in ("encoder", "decoder"):
-                    self.model = self._tower(T5LayerWandaPruner, model_prefix=self.t5_model_prefix,
-                                             module_to_process=f"{self.t5_model_prefix}.{side}.block",
-                                             n_samples=self.num_samples, sparsity_ratio=sd, lora_model=lora_model)
-            else:
-                self.model = self._tower(T5LayerWandaPruner, model_prefix=self.t5_model_prefix,
-                                         module_to_process=f"{self.t5_model_prefix}{self.peft_postfix}.model.layers",
+        try:
+            if self.vit_prune_spec is not None and float(vit_keep_ratio) < 1.:
+                sd = global_sparsity_dict if global_sparsity_dict not in [None, "none"] else \
+                    self.get_sparsity(1 - vit_keep_ratio, sparsity_ratio_granularity=None)
+                self.model = self._tower(VITLayerWandaPruner, model_prefix=self.vit_model_prefix,
+                                         module_to_process=f"{self.vit_model_prefix}.blocks",
                                          n_samples=self.num_samples, sparsity_ratio=sd, lora_model=lora_model)
 
-        self._defer_score_readback = False
-        _importance_readback(self.__dict__.setdefault("_score_backlog", []))      # the towers' importance scores, one copy
+            if self.t5_prune_spec is not None and float(t5_keep_ratio) < 1.:
+                sd = global_sparsity_dict if global_sparsity_dict is not None else \
+                    self.get_sparsity(1 - t5_keep_ratio, sparsity_ratio_granularity=None)
+                if "t5_model" in self.t5_model_prefix:
+                    for side in ("encoder", "decoder"):
+                        self.model = self._tower(T5LayerWandaPruner, model_prefix=self.t5_model_prefix,
+                                                 module_to_process=f"{self.t5_model_prefix}.{side}.block",
+                                                 n_samples=self.num_samples, sparsity_ratio=sd, lora_model=lora_model)
+                else:
+                    self.model = self._tower(T5LayerWandaPruner, model_prefix=self.t5_model_prefix,
+                                             module_to_process=f"{self.t5_model_prefix}{self.peft_postfix}.model.layers",
+                                             n_samples=self.num_samples, sparsity_ratio=sd, lora_model=lora_model)
+        finally:
+            # also when a tower raises: the towers done so far get their importance scores, the flag does not outlive
+            # the call (a later stand-alone tower prune on this object reads its scores back itself)
+            self._defer_score_readback = False
+            _importance_readback(self.__dict__.setdefault("_score_backlog", []))  # the towers' importance scores, one copy
         self.model_reset(self.model, dtype_record, requires_grad_record, device)
         return self.model, global_sparsity_dict
 

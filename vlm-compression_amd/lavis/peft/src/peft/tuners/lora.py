@@ -24,8 +24,7 @@ path (enable_lora is None in every script; bitsandbytes is absent) and are not b
 """
 import math
 import re
-from dataclasses import asdict, dataclass, field
-from enum import Enum
+from dataclasses import dataclass, field
 from typing import List, Optional, Union
 
 import torch
@@ -215,41 +214,30 @@ class LoraModel(torch.nn.Module):
         parent = self.model.get_submodule(".".join(key.split(".")[:-1]))
         return parent, self.model.get_submodule(key), key.split(".")[-1]
 
-    def _replace_module(self, parent_module, child_name, new_module, old_module):
-        setattr(parent_module, child_name, new_module)
-        new_module.weight = old_module.weight
-        if old_module.bias is not None:
-            new_module.bias = old_module.bias
-        if getattr(old_module, "state", None) is not None:
-            new_module.state = old_module.state
-            new_module.to(old_module.weight.device)
-        for name, module in new_module.named_modules():
-            if "lora_" in name:
-                module.to(old_module.weight.device)
+    @staticmethod
+    def _replace_module(parent, name, new, old):
+        """Put the SparseLoRA layer where the plain linear was.  W and b are SHARED with the original module (the pruner
+        zeroes `weight.data` in place and train.py:626-637 indexes it); only the adapters are new, and they follow the
+        weight to its device (lora.py:196-208)."""
+        new.weight = old.weight
+        if old.bias is not None:
+            new.bias = old.bias
+        device = old.weight.device
+        for adapter in (getattr(new, "lora_A", None), getattr(new, "lora_B", None)):
+            if adapter is not None:
+                adapter.to(device)
+        new.mask = new.mask.to(device)
+        setattr(parent, name, new)
 
-    def __getattr__(self, name: str):
+    def __getattr__(self, name):
+        """Anything the wrapper does not define is the wrapped model's (train.py reads `model.t5_model`, `.maybe_autocast`, ...
+        through it)."""
+        modules = self.__dict__.get("_modules", {})
+        if name in modules:
+            return modules[name]
         try:
             return super().__getattr__(name)
         except AttributeError:
-            return getattr(self.model, name)
-
-    @property
-    def modules_to_save(self):
-        return None
-
-    def get_peft_config_as_dict(self, inference: bool = False):
-        config = {k: v.value if isinstance(v, Enum) else v for k, v in asdict(self.peft_config).items()}
-        if inference:
-            config["inference_mode"] = True
-        return config
-
-    def _set_adapter_layers(self, enabled=True):
-        for module in self.model.modules():
-            if isinstance(module, LoraLayer):
-                module.disable_adapters = False if enabled else True
-
-    def enable_adapter_layers(self):
-        self._set_adapter_layers(enabled=True)
-
-    def disable_adapter_layers(self):
-        self._set_adapter_layers(enabled=False)
+            if "model" not in modules:
+                raise
+            return getattr(modules["model"], name)
