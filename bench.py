@@ -60,6 +60,13 @@ def parse():
                     help="HIP events on every N-th launch of a timed kernel (1 = every launch; a timed launch idles the "
                          "GPU for ~10 us)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds before self-launched ranks are killed")
+    ap.add_argument("--reference-ops", default="auto", choices=["auto", "0", "1"],
+                    help="second line: the same prune on a stand-in whose attention follows the reference's model files op for op "
+                         "(explicit q @ k^T, position bias, fp32 softmax, masks) with ragged calibration text (auto: only at N=1)")
+    ap.add_argument("--calib-local", type=int, default=0, choices=[0, 16, 32, 64],
+                    help="rehearse ONE rank's share of an N-GPU run on this GPU (16 / 32 / 64 samples = one rank of 8 / 4 / 2): "
+                         "every kernel a rank runs, the statistics exchange filled in with the rank's own rows "
+                         "(VLMC_SIMULATE_WORLD, vlmc/shard.py); reported as config.per_rank_floor, never as the headline")
     return ap.parse_args()
 
 
@@ -153,8 +160,8 @@ class LaunchProbe:
         probe = self
 
         def wrapped(*a, **k):
-            if not probe.active or not single_launch(*a, **k):
-                return real(*a, **k)
+            if not probe.active or torch.cuda.is_current_stream_capturing() or not single_launch(*a, **k):
+                return real(*a, **k)                   # (a launch recorded into a HIP graph cannot carry events)
             n = probe.calls[kind] = probe.calls.get(kind, 0) + 1
             if n % probe.stride:
                 return real(*a, **k)
@@ -199,23 +206,27 @@ def install_probes(probe):
     def gemm_flops(x, weight, bias=None, **kw):
         return 2.0 * (x.numel() // x.shape[-1]) * weight.shape[0] * weight.shape[1]
 
+    def group_flops(x, weights, biases=None, **kw):
+        return 2.0 * (x.numel() // x.shape[-1]) * sum(w.shape[0] for w in weights) * weights[0].shape[1]
+
     probe.wrap(ops, "act_sqnorm_batch", "stat", sq_bytes)
     probe.wrap(ops, "wanda_select_batch", "rows", sel_bytes, sel_single)
     probe.wrap(ops, "linear_fwd", "gemm", gemm_flops)
+    probe.wrap(ops, "linear_fwd_group", "gemm", group_flops)          # q / k / v, wi_0 / wi_1: one launch (vlmc/forward.py)
 
 
 # ----------------------------------------------------------------------------------------------------------------
 # the headline: whole prunes through the drop-in API
 # ----------------------------------------------------------------------------------------------------------------
 class PruneJob:
-    def __init__(self, dev):
+    def __init__(self, dev, reference_ops=False, ragged=False):
         from vlmc import synthetic
         self.dev = dev
-        self.model = synthetic.InstructBlipT5().to(dev).eval()
+        self.model = synthetic.InstructBlipT5(reference_ops=reference_ops).to(dev).eval()
         synthetic.randomize_(self.model, 0)
         self.params = [p for p in self.model.parameters()]
         self.dense = [p.detach().clone() for p in self.params]
-        self.batches = synthetic.calibration_batches(N_CALIB, dev, vocab=self.model.t5_model.shared.num_embeddings)
+        self.batches = synthetic.calibration_batches(N_CALIB, dev, vocab=self.model.t5_model.shared.num_embeddings, ragged=ragged)
         self.n_linears = synthetic.prunable_linears(self.model)
         keep = 1 - RATIO
         self.cfg = dict(t5_prune_spec=f"24-{keep!r}-1.0-1.0", vit_prune_spec=f"39-{keep!r}-1.0-1.0", t5_pruning_method="wanda",
@@ -228,6 +239,10 @@ class PruneJob:
         pruner = load_pruner(PRUNER, self.model, self.batches, cfg=dict(self.cfg))
         with contextlib.redirect_stdout(io.StringIO()):
             pruner.prune()
+
+    def masks(self):
+        return {n: m.mask.clone() for n, m in self.model.named_modules()
+                if isinstance(m, torch.nn.Linear) and isinstance(getattr(m, "mask", None), torch.Tensor)}
 
     def pruned_fraction(self):
         zeros = total = 0
@@ -350,6 +365,83 @@ def kernel_pass(dev, steps, warmup, stride):
                        roof("rows", "vlmc::select_rows_mixed_kernel", "select_rows_mixed_kernel_bytes_per_launch", traffic),
                        roof("matrix", "vlmc::matrix_fused_kernel", "matrix_fused_kernel_bytes_per_launch", traffic)]}
     del acts, sets, plans_per_set, state
+    torch.cuda.empty_cache()
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# second line: the reference's own op sequence in the blocks' attention, ragged calibration text
+# ----------------------------------------------------------------------------------------------------------------
+def reference_ops_leg(dev, steps):
+    """The headline's stand-in writes attention as F.scaled_dot_product_attention on text of one length: one group of 128
+    samples per block, attention per (sample, head).  The reference's model files (eva_vit.py:129-168,
+    modeling_t5.py:520-640) write it as batched `torch.matmul`s with a position bias, masks and an fp32 softmax, and real
+    calibration text is ragged.  Same prune on such a stand-in (vlmc/synthetic.py reference_ops=True, prompt lengths
+    8..128): seconds, groups per block forward, and how far the grouped replay's masks are from the reference's
+    one-sample-per-forward loop run on the same GPU (the batched matmuls are the GEMM library's: it may pick its kernel by
+    batch count)."""
+    from lavis.compression.pruners import calibration as cal
+    job = PruneJob(dev, reference_ops=True, ragged=True)
+    groups = []
+    real_plan = cal.plan_groups
+
+    def counting(*a, **k):
+        chunks = real_plan(*a, **k)
+        groups.append(len(chunks))
+        return chunks
+    cal.plan_groups = counting
+    try:
+        job.step()                                            # warm-up (code objects of the batched matmuls, allocator)
+        torch.cuda.synchronize()
+        groups.clear()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            job.step()
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / steps
+        plans = list(groups)
+    finally:
+        cal.plan_groups = real_plan
+    grouped = job.masks()
+    frac = job.pruned_fraction()
+    keep = {k: os.environ.get(k) for k in ("VLMC_BATCH_REPLAY", "VLMC_TOWER_BATCH")}
+    os.environ.update(VLMC_BATCH_REPLAY="1", VLMC_TOWER_BATCH="0")          # the reference's loop: one sample per forward
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        job.step()
+        torch.cuda.synchronize()
+        per_sample_sec = time.perf_counter() - t0
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    single = job.masks()
+    total = diff = 0
+    worst = (0.0, None)
+    for n, m in grouped.items():
+        d = int((m != single[n]).sum())
+        total += m.numel()
+        diff += d
+        if d / m.numel() > worst[0]:
+            worst = (d / m.numel(), n)
+    per_tower = {}
+    if plans:                                                   # one plan per tower and prune (the plan of the first pass holds)
+        per = len(plans) // steps
+        for t, name in enumerate(("visual_encoder.blocks", "t5_model.encoder.block", "t5_model.decoder.block")[:per]):
+            per_tower[name] = plans[t]
+    out = {"what": "the same whole prune on a stand-in whose attention follows the reference's op sequence (eva_vit.py:129-168: "
+                   "q / v bias, explicit q @ k^T, softmax, attn @ v; modeling_t5.py:520-640: torch.matmul scores, bucketed position "
+                   "bias of block 0, extended masks, fp32 softmax) with ragged calibration text (prompts of 8..128 tokens, outputs "
+                   "of 4..16)",
+           "seconds_per_prune": round(sec, 4), "layers_per_s": round(588 / sec, 1), "steps": steps,
+           "groups_per_block_forward": per_tower, "pruned_fraction": round(frac, 6),
+           "per_sample_loop_seconds": round(per_sample_sec, 3),
+           "mask_agreement_grouped_vs_per_sample": round(1.0 - diff / max(1, total), 9), "mask_elements": total,
+           "mask_elements_differing": diff, "worst_linear": {"name": worst[1], "fraction_differing": round(worst[0], 9)}}
+    del job, grouped, single
     torch.cuda.empty_cache()
     return out
 
@@ -529,9 +621,30 @@ def main():
     roofline = rows[0]
     roofline["other"] = rows[1:]
 
+    # ---- one rank's floor of an N-GPU run, rehearsed on this GPU (--calib-local) -----------------------------------
+    floor = None
+    if args.calib_local and world == 1:
+        os.environ["VLMC_SIMULATE_WORLD"] = str(N_CALIB // args.calib_local)
+        try:
+            job.step()                                            # warm-up at the rank's shapes (code objects, allocator)
+            torch.cuda.synchronize()
+            busy0 = time.perf_counter()
+            for _ in range(args.steps):
+                job.step()
+            torch.cuda.synchronize()
+            fsec = (time.perf_counter() - busy0) / args.steps
+            floor = {"calib_samples_on_this_rank": args.calib_local, "stands_for_world_size": N_CALIB // args.calib_local,
+                     "seconds_per_prune": round(fsec, 4), "layers_per_s_if_every_rank_kept_this_pace": round(588 / fsec, 1),
+                     "pruned_fraction": round(job.pruned_fraction(), 6),
+                     "what": "rank 0 of W: capture + replay + statistics of its 128 / W samples, selects of all 588 linears, the "
+                             "running-mean recurrence over all 128 rows; the per-block all-gather is filled in with the rank's own "
+                             "rows (VLMC_SIMULATE_WORLD) -- no RCCL, no arrival skew"}
+        finally:
+            os.environ.pop("VLMC_SIMULATE_WORLD", None)
+
     kp = None
     if args.kernel_pass == "1" or (args.kernel_pass == "auto" and world == 1):
-        del job
+        job = None
         torch.cuda.empty_cache()
         try:
             kp = kernel_pass(dev, args.kernel_steps, 2, max(1, args.event_stride))
@@ -541,6 +654,15 @@ def main():
                                                            "other launch there)"))
         except Exception as e:                    # never lose the bench line to the side measurement
             kp = {"error": f"{type(e).__name__}: {e}"}
+
+    ref_ops = None
+    if args.reference_ops == "1" or (args.reference_ops == "auto" and world == 1):
+        job = None
+        torch.cuda.empty_cache()
+        try:
+            ref_ops = reference_ops_leg(dev, max(1, min(args.steps, 3)))
+        except Exception as e:                    # never lose the bench line to the second measurement
+            ref_ops = {"error": f"{type(e).__name__}: {e}"}
 
     out = None
     if rank == 0:
@@ -559,7 +681,8 @@ def main():
                        "total_prune_wall_clock_s": round(sec, 4), "blocks_per_s": round(87 / sec, 1),
                        "pruned_fraction": round(pruned_fraction, 6), "subtotals_s": sub,
                        "replay": f"grouped: up to {os.environ.get('VLMC_BATCH_REPLAY', '128')} equal-shape samples per block forward",
-                       "parallelism": f"calib-dp{world}", "backend": backend,
+                       "parallelism": f"calib-dp{world}", "backend": backend, "per_rank_floor": floor,
+                       "reference_ops": ref_ops,
                        "world_size": dist.get_world_size() if world > 1 else 1},
             "roofline": roofline,
             "kernel_pass": kp,

@@ -51,33 +51,33 @@ def wrap_lora(model, r=4, alpha=16):
     return model
 
 
-def build(name, device="cpu", variants=None):
+def build(name, device="cpu", variants=None, n_samples=6):
     v = (variants or VARIANTS)[name]
     model = toy_models.init_toy(toy_models.ToyBlipT5(vit_dtype=v["vit_dtype"], t5_dtype=v["t5_dtype"]), seed=7)
     if v["lora"]:
         wrap_lora(model)
     model.eval().to(device)
-    batches = [{k: t.to(device) for k, t in b.items()} for b in toy_models.make_batches(6, seed=11)]
+    batches = [{k: t.to(device) for k, t in b.items()} for b in toy_models.make_batches(n_samples, seed=11)]
     return model, batches, v
 
 
-def run_pruner(name, device="cpu"):
+def run_pruner(name, device="cpu", n_samples=6):
     from lavis.compression import load_pruner
-    model, batches, v = build(name, device)
+    model, batches, v = build(name, device, n_samples=n_samples)
     spec = "2-%r-1.0-1.0" % (1 - v["ratio"])
     cfg = dict(t5_prune_spec=spec, vit_prune_spec=spec, t5_pruning_method="wanda", vit_pruning_method="wanda",
-               num_samples=6, prune_n=v["n"], prune_m=v["m"], max_sparsity_per_layer=1.01)
+               num_samples=n_samples, prune_n=v["n"], prune_m=v["m"], max_sparsity_per_layer=1.01)
     pruner = load_pruner("blipt5_wanda_pruner", model, batches, cfg=cfg)
     pruned, sd = pruner.prune(lora_model=True) if v["lora"] else pruner.prune()
     return pruned, sd
 
 
-def run_dsnot_pruner(name, device="cpu"):
+def run_dsnot_pruner(name, device="cpu", n_samples=6):
     from lavis.compression import load_pruner
-    model, batches, v = build(name, device, DSNOT_VARIANTS)
+    model, batches, v = build(name, device, DSNOT_VARIANTS, n_samples=n_samples)
     spec = "2-%r-1.0-1.0" % (1 - v["ratio"])
     cfg = dict(t5_prune_spec=spec, vit_prune_spec=spec, t5_pruning_method="dsnot", vit_pruning_method="dsnot",
-               num_samples=6, prune_n=v["n"], prune_m=v["m"], max_sparsity_per_layer=1.01, **v["kw"])
+               num_samples=n_samples, prune_n=v["n"], prune_m=v["m"], max_sparsity_per_layer=1.01, **v["kw"])
     pruner = load_pruner("blipt5_dsnot_pruner", model, batches, cfg=cfg)
     pruned, sd = pruner.prune(lora_model=True) if v["lora"] else pruner.prune()
     return pruned, sd

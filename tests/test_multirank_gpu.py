@@ -35,15 +35,16 @@ def _run(cmd, env=None, timeout=900):
 
 
 @pytest.mark.timeout(1200)
-def test_bench_launches_its_own_ranks_and_shards_the_prune():
-    r = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0", "--kernel-pass", "0"],
+@pytest.mark.parametrize("world", [2, 4])          # (8 ranks on one device would exceed the box's limit of 6 GPU processes:
+def test_bench_launches_its_own_ranks_and_shards_the_prune(world):      # tests/test_dist_world48.py covers 8 over gloo on the CPU)
+    r = _run([sys.executable, "bench.py", "--gpus", str(world), "--steps", "1", "--warmup", "1", "--cpu-seconds", "0", "--kernel-pass", "0"],
              env={"VLMC_BENCH_ONE_DEVICE": "1"})
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE json line
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["world_size"] == 2 and out["config"]["backend"] == "gloo"
-    assert out["config"]["parallelism"] == "calib-dp2" and out["scaling"] == "strong"
+    assert out["n_gpus"] == world and out["config"]["world_size"] == world and out["config"]["backend"] == "gloo"
+    assert out["config"]["parallelism"] == f"calib-dp{world}" and out["scaling"] == "strong"
     assert out["value"] > 0 and abs(out["value"] - 588 / (out["ms_per_step"] * 1e-3)) < 1.0
     assert out["config"]["pruned_fraction"] == pytest.approx(0.5, abs=1e-4)
     assert out["cpu_baseline"] is None and out["kernel_pass"] is None
@@ -109,8 +110,9 @@ _WORKER_GLOO = _WORKER.replace('torch.cuda.set_device(rank)', 'torch.cuda.set_de
 
 
 @pytest.mark.timeout(900)
-def test_sample_sharding_with_the_kernels_is_bit_identical_to_single_process(tmp_path):
-    """Two ranks sharing cuda:0 (collectives over gloo): each captures and replays its half of the calibration samples with
+@pytest.mark.parametrize("world", [2, 4])
+def test_sample_sharding_with_the_kernels_is_bit_identical_to_single_process(world, tmp_path):
+    """Two / four ranks sharing cuda:0 (collectives over gloo): each captures and replays its half of the calibration samples with
     the real kernels, one all-gather of statistics per block -- masks, weights and importance scores of both ranks equal the
     single-process run bit for bit (Wanda; DSnoT on ragged text)."""
     import pruner_helpers as H
@@ -120,14 +122,14 @@ def test_sample_sharding_with_the_kernels_is_bit_identical_to_single_process(tmp
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
               "--master-port", str(port), str(script)], timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     import toy_models
     toy_models.ToyAttention.use_sdpa = True        # (restored by the fixture below)
     for tag in ("wanda", "dsnot"):
         single = {k: v.cpu() for k, v in H.run_16bit_toy(tag, "cuda:0", ragged=(tag == "dsnot")).items()}
-        for rank in range(2):
+        for rank in range(world):
             got = torch.load(tmp_path / f"rank{rank}.pt")[tag]
             assert got.keys() == single.keys()
             for k in single:

@@ -57,15 +57,15 @@ import golden_io  # noqa: E402
 SG_E2E = golden_io.load("sparsegpt_e2e")
 
 
-def _run_sparsegpt_pruner(name, device="cpu"):
+def _run_sparsegpt_pruner(name, device="cpu", n_samples=6):
     import toy_models
     from lavis.compression import load_pruner
     v = {"fp32_u50": dict(ratio=0.5, n=0, m=0), "fp32_2_4": dict(ratio=0.5, n=2, m=4)}[name]
     model = toy_models.init_toy(toy_models.ToyBlipT5(), seed=7).eval().to(device)
-    batches = [{k: t.to(device) for k, t in b.items()} for b in toy_models.make_batches(6, seed=11)]
+    batches = [{k: t.to(device) for k, t in b.items()} for b in toy_models.make_batches(n_samples, seed=11)]
     spec = "2-%r-1.0-1.0" % (1 - v["ratio"])
     cfg = dict(t5_prune_spec=spec, vit_prune_spec=spec, t5_pruning_method="sparsegpt", vit_pruning_method="sparsegpt",
-               num_samples=6, prune_n=v["n"], prune_m=v["m"], max_sparsity_per_layer=1.01)
+               num_samples=n_samples, prune_n=v["n"], prune_m=v["m"], max_sparsity_per_layer=1.01)
     pruner = load_pruner("blipt5_sparsegpt_pruner", model, batches, cfg=cfg)
     return pruner.prune()
 
@@ -444,3 +444,32 @@ def test_deferred_importance_scores_survive_a_failing_tower(monkeypatch):
               and hasattr(m.weight, "importance_score")]
     assert len(scored) == 2 * 4                                # the ViT tower was done: its scores are there
     monkeypatch.setattr(wp.T5LayerWandaPruner, "_prune", real)
+
+
+@pytest.mark.parametrize("method", ["wanda", "dsnot"])
+def test_simulated_world_is_rank_0_of_w_with_its_own_rows_in_place_of_the_exchange(method, monkeypatch):
+    """`VLMC_SIMULATE_WORLD=2` (bench.py --calib-local): one process captures and replays samples 0..3 of 8 and fills the
+    statistics exchange with its own rows -- i.e. exactly the single-process prune of the sample list [0..3, 0..3]."""
+    import toy_models
+    from lavis.compression import load_pruner
+    (oracle_ops.install if method == "wanda" else oracle_ops.install_dsnot)(monkeypatch)
+    monkeypatch.setenv("VLMC_BATCH_REPLAY", "1")
+    torch.set_num_threads(1)
+
+    def run(batches, n):
+        model = toy_models.init_toy(toy_models.ToyBlipT5(), seed=5).eval()
+        spec = "2-0.5-1.0-1.0"
+        cfg = dict(t5_prune_spec=spec, vit_prune_spec=spec, t5_pruning_method=method, vit_pruning_method=method, num_samples=n,
+                   max_sparsity_per_layer=1.01)
+        if method == "dsnot":
+            cfg["max_cycle_time"] = 8
+        pruned, _ = load_pruner(f"blipt5_{method}_pruner", model, batches, cfg=cfg).prune()
+        return {k: v.clone() for k, v in pruned.state_dict().items()}
+
+    eight = toy_models.make_batches(8, seed=21)
+    want = run(eight[:4] + eight[:4], 8)
+    monkeypatch.setenv("VLMC_SIMULATE_WORLD", "2")
+    got = run(eight, 8)
+    assert want.keys() == got.keys()
+    for k in want:
+        assert torch.equal(want[k], got[k]), k

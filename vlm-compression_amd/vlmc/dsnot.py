@@ -114,7 +114,7 @@ class DsnotInputStat:
 def gather_stats(stats):
     """Multi-GPU: all-gather the per-call moments (rank-major = sample order), then finalise."""
     import torch.distributed as dist
-    from .shard import calibration_shard
+    from .shard import calibration_shard, simulated_world
     world = calibration_shard()[1]          # 1 for replicas (VLMC_SHARD_CALIB=0): they already hold every sample
     if world == 1:
         for st in stats:
@@ -123,11 +123,14 @@ def gather_stats(stats):
     for st in stats:
         mom, tokens, batches = st.ordered()
         local = mom.permute(1, 0, 2).contiguous()                         # [calls, 3, in]
-        allm = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(allm, local)
         tok = torch.tensor(tokens, dtype=torch.int64, device=local.device)
-        allt = torch.empty(world * tok.numel(), dtype=torch.int64, device=local.device)
-        dist.all_gather_into_tensor(allt, tok)
+        if simulated_world():                                             # one rank rehearsing W (vlmc/shard.py)
+            allm, allt = local.repeat(world, 1, 1), tok.repeat(world)
+        else:
+            allm = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(allm, local)
+            allt = torch.empty(world * tok.numel(), dtype=torch.int64, device=local.device)
+            dist.all_gather_into_tensor(allt, tok)
         st.finalize((allm.permute(1, 0, 2), allt.cpu().tolist(), batches * world))
     return stats
 

@@ -10,11 +10,25 @@ from __future__ import annotations
 import os
 
 
+def simulated_world():
+    """`VLMC_SIMULATE_WORLD=W` (bench.py --calib-local, W = 128 / L): ONE process stands for rank 0 of W -- it captures
+    and replays its share of the calibration samples and runs every kernel a rank runs; where the ranks would exchange
+    statistics it fills in W copies of its own rows (same bytes through the same recurrence).  What it measures is a
+    rank's floor: everything but the collectives and the other ranks' arrival skew.  0 = off."""
+    try:
+        w = int(os.environ.get("VLMC_SIMULATE_WORLD", "0"))
+    except ValueError:
+        return 0
+    return w if w > 1 else 0
+
+
 def calibration_shard():
     """(rank, world) for sample sharding, or (0, 1) when running as replicas."""
     import torch.distributed as dist
     if os.environ.get("VLMC_SHARD_CALIB", "1") == "0":
         return 0, 1
+    if simulated_world():
+        return 0, simulated_world()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         return dist.get_rank(), dist.get_world_size()
     return 0, 1

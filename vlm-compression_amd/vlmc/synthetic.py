@@ -53,18 +53,109 @@ class Attention(nn.Module):
         return _lin(self.proj if self.fused else self.o, y, dense)
 
 
-class ViTBlock(nn.Module):
-    def __init__(self, dim, hidden, heads):
+class EvaAttentionOps(nn.Module):
+    """EVA-ViT attention written with the reference's own op sequence (eva_vit.py:129-168): qkv linear without bias plus the
+    concatenated (q_bias, 0, v_bias), `q * scale`, an explicit batched `q @ k^T`, optional `rel_pos_bias`, softmax in the
+    activation dtype, `attn @ v`, proj.  The two products are batched `torch.matmul`s: the GEMM library's, not per sample."""
+
+    def __init__(self, dim, heads):
         super().__init__()
+        self.heads, self.scale = heads, (dim // heads) ** -0.5
+        self.qkv = nn.Linear(dim, 3 * dim, bias=False)
+        self.q_bias = nn.Parameter(torch.zeros(dim))
+        self.v_bias = nn.Parameter(torch.zeros(dim))
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x, rel_pos_bias=None, dense=False):
+        B, N, C = x.shape
+        qkv_bias = torch.cat((self.q_bias, torch.zeros_like(self.v_bias, requires_grad=False), self.v_bias))
+        qkv = _lin(self.qkv, x, dense) + qkv_bias
+        qkv = qkv.reshape(B, N, 3, self.heads, -1).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        q = q * self.scale
+        attn = q @ k.transpose(-2, -1)
+        if rel_pos_bias is not None:
+            attn = attn + rel_pos_bias
+        attn = attn.softmax(dim=-1)
+        x = (attn @ v).transpose(1, 2).reshape(B, N, -1)
+        return _lin(self.proj, x, dense)
+
+
+class T5AttentionOps(nn.Module):
+    """T5 attention with the reference's op sequence (modeling_t5.py:520-640): unscaled `torch.matmul(q, k^T)`, the position
+    bias -- the bucketed relative bias in the tower's first block, zeros in the others when none is handed over (the
+    pruners replay every block with block 0's kwargs: position_bias=None) -- plus the extended mask, softmax in fp32 cast
+    back, `torch.matmul(attn, v)`, o.  Returns (output, position_bias) like the reference returns it in its tuple."""
+
+    def __init__(self, dim, heads, d_kv, has_relative_attention_bias=False, is_decoder=False, num_buckets=32, max_distance=128):
+        super().__init__()
+        self.heads, self.d_kv, self.is_decoder = heads, d_kv, is_decoder
+        self.num_buckets, self.max_distance = num_buckets, max_distance
+        inner = heads * d_kv
+        self.q = nn.Linear(dim, inner, bias=False)
+        self.k = nn.Linear(dim, inner, bias=False)
+        self.v = nn.Linear(dim, inner, bias=False)
+        self.o = nn.Linear(inner, dim, bias=False)
+        self.has_relative_attention_bias = has_relative_attention_bias
+        if has_relative_attention_bias:
+            self.relative_attention_bias = nn.Embedding(num_buckets, heads)
+
+    def compute_bias(self, q_len, k_len, device):
+        """Bucketed relative position bias [1, heads, q_len, k_len] (modeling_t5.py:411-482: half of the buckets exact, half
+        logarithmic up to max_distance; bidirectional in the encoder)."""
+        rel = torch.arange(k_len, device=device)[None, :] - torch.arange(q_len, device=device)[:, None]
+        nb = self.num_buckets
+        buckets = torch.zeros_like(rel)
+        if not self.is_decoder:
+            nb //= 2
+            buckets = buckets + (rel > 0).long() * nb
+            rel = rel.abs()
+        else:
+            rel = -torch.min(rel, torch.zeros_like(rel))
+        exact = nb // 2
+        import math
+        large = exact + (torch.log(rel.float() / exact) / math.log(self.max_distance / exact) * (nb - exact)).long()
+        large = torch.min(large, torch.full_like(large, nb - 1))
+        buckets = buckets + torch.where(rel < exact, rel, large)
+        return self.relative_attention_bias(buckets).permute(2, 0, 1).unsqueeze(0)
+
+    def forward(self, x, mask=None, kv=None, position_bias=None, dense=False):
+        B, T, _ = x.shape
+        src = x if kv is None else kv
+
+        def shape(t):
+            return t.view(B, -1, self.heads, self.d_kv).transpose(1, 2)
+        q, k, v = shape(_lin(self.q, x, dense)), shape(_lin(self.k, src, dense)), shape(_lin(self.v, src, dense))
+        scores = torch.matmul(q, k.transpose(3, 2))
+        if position_bias is None:
+            if not self.has_relative_attention_bias:
+                position_bias = torch.zeros((1, self.heads, T, k.shape[2]), device=scores.device, dtype=scores.dtype)
+            else:
+                position_bias = self.compute_bias(T, k.shape[2], scores.device)
+            if mask is not None:
+                position_bias = position_bias + mask
+        scores += position_bias
+        attn = F.softmax(scores.float(), dim=-1).type_as(scores)
+        y = torch.matmul(attn, v).transpose(1, 2).contiguous().view(B, -1, self.heads * self.d_kv)
+        return _lin(self.o, y, dense), position_bias
+
+
+class ViTBlock(nn.Module):
+    def __init__(self, dim, hidden, heads, reference_ops=False):
+        super().__init__()
+        self.reference_ops = reference_ops
         self.norm1 = nn.LayerNorm(dim)
-        self.attn = Attention(dim, heads, dim // heads, fused_qkv=True)
+        self.attn = EvaAttentionOps(dim, heads) if reference_ops else Attention(dim, heads, dim // heads, fused_qkv=True)
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = nn.Module()
         self.mlp.fc1 = nn.Linear(dim, hidden)
         self.mlp.fc2 = nn.Linear(hidden, dim)
 
     def forward(self, x, rel_pos_bias=None, dense=False):
-        x = x + self.attn(self.norm1(x), dense=dense)
+        if self.reference_ops:                                # eva_vit.py:216-221 without layer scale / drop path
+            x = x + self.attn(self.norm1(x), rel_pos_bias=rel_pos_bias, dense=dense)
+        else:
+            x = x + self.attn(self.norm1(x), dense=dense)
         return x + _lin(self.mlp.fc2, F.gelu(_lin(self.mlp.fc1, self.norm2(x), dense)), dense)
 
 
@@ -88,18 +179,20 @@ class _T5Sub(nn.Module):
 class T5Block(nn.Module):
     """`layer[0].SelfAttention`, (`layer[1].EncDecAttention`,) `layer[-1].DenseReluDense` with T5 v1.1's gated GELU."""
 
-    def __init__(self, dim, d_ff, heads, d_kv, is_decoder):
+    def __init__(self, dim, d_ff, heads, d_kv, is_decoder, reference_ops=False, has_relative_attention_bias=False):
         super().__init__()
-        self.is_decoder = is_decoder
+        self.is_decoder, self.reference_ops = is_decoder, reference_ops
         subs = []
         sa = _T5Sub()
         sa.layer_norm = RMSNorm(dim)
-        sa.SelfAttention = Attention(dim, heads, d_kv, fused_qkv=False)
+        sa.SelfAttention = T5AttentionOps(dim, heads, d_kv, has_relative_attention_bias, is_decoder) if reference_ops else \
+            Attention(dim, heads, d_kv, fused_qkv=False)
         subs.append(sa)
         if is_decoder:
             ca = _T5Sub()
             ca.layer_norm = RMSNorm(dim)
-            ca.EncDecAttention = Attention(dim, heads, d_kv, fused_qkv=False)
+            ca.EncDecAttention = T5AttentionOps(dim, heads, d_kv, False, is_decoder) if reference_ops else \
+                Attention(dim, heads, d_kv, fused_qkv=False)
             subs.append(ca)
         ff = _T5Sub()
         ff.layer_norm = RMSNorm(dim)
@@ -115,32 +208,50 @@ class T5Block(nn.Module):
                 cross_attn_layer_head_mask=None, dense=False, **unused):
         x = hidden_states
         sa = self.layer[0]
-        x = x + sa.SelfAttention(sa.layer_norm(x), dense=dense)
+        biases = ()
+        if self.reference_ops:
+            y, position_bias = sa.SelfAttention(sa.layer_norm(x), mask=attention_mask, position_bias=position_bias, dense=dense)
+            x = x + y
+            biases = (position_bias,)
+        else:
+            x = x + sa.SelfAttention(sa.layer_norm(x), dense=dense)
         if self.is_decoder:
             ca = self.layer[1]
-            x = x + ca.EncDecAttention(ca.layer_norm(x), kv=encoder_hidden_states, dense=dense)
+            if self.reference_ops:
+                y, encoder_decoder_position_bias = ca.EncDecAttention(ca.layer_norm(x), mask=encoder_attention_mask, kv=encoder_hidden_states,
+                                                                      position_bias=encoder_decoder_position_bias, dense=dense)
+                x = x + y
+                biases = biases + (encoder_decoder_position_bias,)
+            else:
+                x = x + ca.EncDecAttention(ca.layer_norm(x), kv=encoder_hidden_states, dense=dense)
         ff = self.layer[-1]
         h = ff.layer_norm(x)
         d = ff.DenseReluDense
         x = x + _lin(d.wo, F.gelu(_lin(d.wi_0, h, dense)) * _lin(d.wi_1, h, dense), dense)
-        return (x,)
+        return (x,) + biases                       # (hidden, position bias[, cross-attention position bias]): use_cache is off
 
 
 class InstructBlipT5(nn.Module):
     def __init__(self, vit_dim=1408, vit_hidden=6144, vit_heads=16, vit_depth=39, d_model=2048, d_ff=5120, heads=32, d_kv=64,
-                 enc_depth=24, dec_depth=24, vocab=32128, query_tokens=32, vit_dtype=torch.float16, t5_dtype=torch.bfloat16):
+                 enc_depth=24, dec_depth=24, vocab=32128, query_tokens=32, vit_dtype=torch.float16, t5_dtype=torch.bfloat16,
+                 reference_ops=False):
+        """reference_ops=True: the blocks' attention follows the reference's model files op for op -- EVA attention as
+        eva_vit.py:129-168 (q / v bias, explicit `q @ k^T`, softmax, `attn @ v`), T5 attention as modeling_t5.py:520-640
+        (`torch.matmul` scores, bucketed position bias in block 0 handed on by the stack, fp32 softmax, extended masks) --
+        instead of `F.scaled_dot_product_attention`.  The products of attention are then batched library GEMMs."""
         super().__init__()
+        self.reference_ops = reference_ops
         self.visual_encoder = nn.Module()
-        self.visual_encoder.blocks = nn.ModuleList([ViTBlock(vit_dim, vit_hidden, vit_heads) for _ in range(vit_depth)])
+        self.visual_encoder.blocks = nn.ModuleList([ViTBlock(vit_dim, vit_hidden, vit_heads, reference_ops) for _ in range(vit_depth)])
         self.visual_encoder.to(vit_dtype)
         self.t5_proj = nn.Linear(vit_dim, d_model).to(t5_dtype)
         t5 = nn.Module()
         t5.config = types.SimpleNamespace(use_cache=True, d_model=d_model)
         t5.shared = nn.Embedding(vocab, d_model)
         t5.encoder = nn.Module()
-        t5.encoder.block = nn.ModuleList([T5Block(d_model, d_ff, heads, d_kv, False) for _ in range(enc_depth)])
+        t5.encoder.block = nn.ModuleList([T5Block(d_model, d_ff, heads, d_kv, False, reference_ops, i == 0) for i in range(enc_depth)])
         t5.decoder = nn.Module()
-        t5.decoder.block = nn.ModuleList([T5Block(d_model, d_ff, heads, d_kv, True) for _ in range(dec_depth)])
+        t5.decoder.block = nn.ModuleList([T5Block(d_model, d_ff, heads, d_kv, True, reference_ops, i == 0) for i in range(dec_depth)])
         self.t5_model = t5.to(t5_dtype)
         self.query_tokens, self.vit_dtype, self.t5_dtype = query_tokens, vit_dtype, t5_dtype
 
@@ -162,12 +273,28 @@ class InstructBlipT5(nn.Module):
         h = torch.cat([img, t5.shared(samples["text_input"])], dim=1)
         kw = dict(attention_mask=None, position_bias=None, encoder_hidden_states=None, encoder_attention_mask=None,
                   encoder_decoder_position_bias=None, layer_head_mask=None, cross_attn_layer_head_mask=None)
-        for blk in t5.encoder.block:
-            h = blk(h, dense=llm_dense, **kw)[0]
         d = t5.shared(samples["text_output"])
-        kw["encoder_hidden_states"] = h
-        for blk in t5.decoder.block:
-            d = blk(d, dense=llm_dense, **kw)[0]
+        if self.reference_ops:
+            # T5Stack.forward (modeling_t5.py:1060-1260): extended masks (0 where attended, dtype-min where not; all text is
+            # real at batch 1), the biases of block 0 handed to the following blocks
+            B, S, T = h.shape[0], h.shape[1], d.shape[1]
+            kw["attention_mask"] = torch.zeros((B, 1, 1, S), dtype=h.dtype, device=h.device)
+            for blk in t5.encoder.block:
+                out = blk(h, dense=llm_dense, **kw)
+                h, kw["position_bias"] = out[0], out[1]
+            causal = torch.ones((T, T), dtype=torch.bool, device=d.device).tril()
+            kw.update(attention_mask=torch.where(causal, 0.0, torch.finfo(d.dtype).min).to(d.dtype)[None, None].expand(B, 1, T, T).contiguous(),
+                      position_bias=None, encoder_hidden_states=h,
+                      encoder_attention_mask=torch.zeros((B, 1, 1, S), dtype=h.dtype, device=h.device))
+            for blk in t5.decoder.block:
+                out = blk(d, dense=llm_dense, **kw)
+                d, kw["position_bias"], kw["encoder_decoder_position_bias"] = out[0], out[1], out[2]
+        else:
+            for blk in t5.encoder.block:
+                h = blk(h, dense=llm_dense, **kw)[0]
+            kw["encoder_hidden_states"] = h
+            for blk in t5.decoder.block:
+                d = blk(d, dense=llm_dense, **kw)[0]
         logits = d @ t5.shared.weight.t()
         return {"loss": logits.float().logsumexp(-1).mean(), "logits": logits}
 
@@ -254,13 +381,21 @@ def randomize_(model, seed=0, std=0.02):
     return model
 
 
-def calibration_batches(n, device, vit_tokens=257, vit_dim=1408, text_len=32, out_len=16, vocab=32128, seed=1):
+RAGGED_TEXT = (8, 16, 24, 32, 32, 48, 64, 128)        # prompt lengths of a ragged calibration set, cycled (mean 44)
+RAGGED_OUT = (4, 8, 16, 16)
+
+
+def calibration_batches(n, device, vit_tokens=257, vit_dim=1408, text_len=32, out_len=16, vocab=32128, seed=1, ragged=False):
+    """`ragged`: prompt lengths 8..128 and output lengths 4..16, interleaved -- real calibration text is not of one length
+    (blip2_t5_instruct.py:49-53: max_txt_len 128, max_output_txt_len 256), so the replay forms several groups per block."""
     g = torch.Generator(device=device).manual_seed(seed)
     out = []
-    for _ in range(n):
+    for j in range(n):
+        tl = RAGGED_TEXT[j % len(RAGGED_TEXT)] if ragged else text_len
+        ol = RAGGED_OUT[(j // 3) % len(RAGGED_OUT)] if ragged else out_len
         out.append({"image": (torch.randn(1, vit_tokens, vit_dim, generator=g, device=device) * 0.5).half(),
-                    "text_input": torch.randint(0, vocab, (1, text_len), generator=g, device=device),
-                    "text_output": torch.randint(0, vocab, (1, out_len), generator=g, device=device)})
+                    "text_input": torch.randint(0, vocab, (1, tl), generator=g, device=device),
+                    "text_output": torch.randint(0, vocab, (1, ol), generator=g, device=device)})
     return out
 
 

@@ -108,8 +108,12 @@ def gather_stats(stats, group=None):
     n_local = local[0].shape[0]
     assert all(t.shape[0] == n_local for t in local), "every input must see the same number of calls"
     flat = torch.cat(local, dim=1).contiguous()                        # [n_local, sum(in)]
-    gathered = torch.empty((world * n_local, flat.shape[1]), dtype=flat.dtype, device=flat.device)
-    dist.all_gather_into_tensor(gathered, flat, group=group)           # rank-major == sample order
+    from .shard import simulated_world
+    if group is None and simulated_world():
+        gathered = flat.repeat(world, 1)                               # one rank rehearsing W: its own rows W times
+    else:
+        gathered = torch.empty((world * n_local, flat.shape[1]), dtype=flat.dtype, device=flat.device)
+        dist.all_gather_into_tensor(gathered, flat, group=group)       # rank-major == sample order
     parts, off = [], 0
     for st in stats:
         parts.append(gathered[:, off:off + st.in_features])            # column slices: the kernel takes a row stride
