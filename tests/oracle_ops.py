@@ -122,7 +122,7 @@ class OracleSparseGPT:
 
 
 def oracle_fasterprune(layer, H, sparsity, prune_n=0, prune_m=0, blocksize=128, percdamp=0.01, return_mask=False,
-                       factor_cache=None):
+                       factor_cache=None, score_sink=None):
     from oracle import sparsegpt as OS
     # the reference factorizes per linear; a shared Hessian must survive for the next linear that uses it
     Wn, imp, pruned = OS.prune(layer.weight.data, H.clone(), sparsity, prune_n, prune_m, blocksize, percdamp)
@@ -135,6 +135,7 @@ def install_sparsegpt(monkeypatch):
     from vlmc import sparsegpt
     monkeypatch.setattr(sparsegpt, "SparseGPT", OracleSparseGPT)
     monkeypatch.setattr(sparsegpt, "fasterprune", oracle_fasterprune)
+    monkeypatch.setattr(sparsegpt, "factorize_many", lambda items, percdamp=0.01, **kw: None)     # the oracle factorizes per linear
 
 
 # ---- DSnoT stand-ins (for vlmc.dsnot) -------------------------------------------------------

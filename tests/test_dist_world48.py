@@ -31,7 +31,9 @@ def _free_port():
     return p
 
 
-def _install():
+def _install(monkeypatch=None):
+    """Oracle stand-ins for the kernels: through pytest's monkeypatch in the test process (undone at the end of the test), by
+    plain assignment in a spawned worker (the process ends with it)."""
     for p in (ROOT, os.path.join(ROOT, "vlm-compression_amd"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -41,11 +43,15 @@ def _install():
         @staticmethod
         def setattr(obj, name, val):
             setattr(obj, name, val)
-    oracle_ops.install(MP)
-    oracle_ops.install_dsnot(MP)
-    oracle_ops.install_sparsegpt(MP)
+    mp_ = monkeypatch if monkeypatch is not None else MP
+    oracle_ops.install(mp_)
+    oracle_ops.install_dsnot(mp_)
+    oracle_ops.install_sparsegpt(mp_)
     torch.set_num_threads(1)
-    os.environ["VLMC_BATCH_REPLAY"] = "1"          # per-sample forwards: what a CPU BLAS computes does not depend on the sharding
+    if monkeypatch is not None:
+        monkeypatch.setenv("VLMC_BATCH_REPLAY", "1")
+    else:
+        os.environ["VLMC_BATCH_REPLAY"] = "1"      # per-sample forwards: what a CPU BLAS computes does not depend on the sharding
 
 
 def _state(pruned):
@@ -93,9 +99,12 @@ def _worker(rank, world, port, out_dir, method, shard_layers):
 @pytest.mark.parametrize("world", [4, 8])
 @pytest.mark.parametrize("method", ["wanda", "dsnot"])
 def test_samples_sharded_over_4_and_8_ranks_equal_the_single_process_run(method, world, tmp_path, monkeypatch):
-    monkeypatch.setenv("VLMC_BATCH_REPLAY", "1")
-    _install()
-    single, _ = _run(method)
+    nthreads = torch.get_num_threads()
+    _install(monkeypatch)
+    try:
+        single, _ = _run(method)
+    finally:
+        torch.set_num_threads(nthreads)
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), method, "1"), nprocs=world, join=True)
     assert sum(1 for k in single if k.endswith(".mask*")) == 2 * 4 + 2 * 7 + 2 * 11
     for rank in range(world):

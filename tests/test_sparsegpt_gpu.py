@@ -170,3 +170,66 @@ def test_direct_inverse_factor_flags_a_non_pd_hessian_and_the_damping_loop_recov
     Hi = torch.cholesky_inverse(ref_L)
     ref_U = sparsegpt._chol_with_damping(Hi, 0.01 * torch.mean(torch.diag(Hi).abs()), upper=True)
     assert torch.equal(U, ref_U.contiguous())
+
+
+def test_hessians_of_a_block_factorized_together_equal_one_by_one(monkeypatch):
+    """`factorize_many`: the 4-7 independent Cholesky chains of a block on streams of their own, equal sizes in separate
+    buffer slots, one host check for all (sparsegpt_pruner.py:112-150 runs them one after the other).  Clean Hessians: the
+    very factors and dead masks of `factorize`, bit for bit.  Hessians the reference would damp (not positive definite; fewer
+    rows than columns): the attempts H + k damp I, k = 0, 1, 2 run side by side and the first clean one is the upper factor
+    of (H + k damp I)^-1 -- the matrix the reference's damp / invert / factorize chain arrives at (same k, other roundings)."""
+    from vlmc import sparsegpt as SG
+    g = torch.Generator(device=DEV).manual_seed(3)
+
+    def hess(n, rows, dead=None):
+        x = torch.randn(rows, n, generator=g, device=DEV)
+        if dead is not None:
+            x[:, dead] = 0
+        return (x.t() @ x) * (2.0 / rows)
+    specs = [(256, 1024, None), (384, 2048, None), (256, 700, 5), (256, 1024, None), (640, 4096, None), (256, 1024, None),
+             (256, 100, None)]                                                  # the last one: rows < columns (singular)
+    Hs = [hess(*s) for s in specs]
+    bad = hess(256, 1024)
+    bad[7, 7] = -1.0                                                            # not positive definite
+    Hs.append(bad)
+    rows_seen = [s[1] for s in specs] + [1024]
+    one = []
+    s0 = dict(SG.factor_stats)
+    for H, r in zip(Hs, rows_seen):
+        one.append(SG.factorize(H.clone(), 0.01, rows_seen=r))
+    s1 = dict(SG.factor_stats)
+    assert s1["chain"] - s0["chain"] == 2 and s1["direct"] - s0["direct"] == 6
+    caches = [{"rows_seen": r} for r in rows_seen]
+    history = {}
+    SG.factorize_many([(H.clone(), c) for H, c in zip(Hs, caches)], percdamp=0.01, history=history)
+    s2 = dict(SG.factor_stats)
+    # the singular one comes out clean after ONE damping step; the one with a -1 on its diagonal needs ~50 (0.01 mean(diag)
+    # each): after four attempts it is left to the reference's own loop
+    assert s2["direct"] - s1["direct"] == 6 and s2["damped"] - s1["damped"] == 1 and s2["chain"] - s1["chain"] == 1
+    assert [history[i] for i in range(8)] == [0, 0, 0, 0, 0, 0, 1, 3]
+    for i, ((U, dead), c) in enumerate(zip(one, caches)):
+        assert torch.equal(c["dead"], dead)
+        if i != 6:
+            assert torch.equal(c["U"], U)                                        # clean, or left to the reference's loop: bit-identical
+        else:
+            Hd = Hs[i].double().clone()
+            Hd.diagonal().add_(0.01 * float(torch.diag(Hs[i]).double().mean()))   # k = 1
+            got = c["U"].double()
+            assert float((got.t() @ got @ Hd - torch.eye(Hd.shape[0], device=DEV, dtype=torch.float64)).abs().max()) < 2e-3
+            assert float((c["U"] - U).norm() / U.norm()) < 2e-3                  # and it tracks the three-step chain
+            assert bool((torch.tril(c["U"], -1) == 0).all())
+    assert int(one[2][1].sum()) == 1
+    # the next block: inputs that needed no damping are tried undamped only; same results
+    caches3 = [{"rows_seen": r} for r in rows_seen]
+    SG.factorize_many([(H.clone(), c) for H, c in zip(Hs, caches3)], percdamp=0.01, history=history)
+    for a, b in zip(caches, caches3):
+        assert torch.equal(a["U"], b["U"])
+    # an input that was clean before and is not now: the damped attempts follow in a second round
+    caches4 = [{"rows_seen": 100}]
+    SG.factorize_many([(Hs[6].clone(), caches4[0])], percdamp=0.01, history={0: 0})
+    assert torch.equal(caches4[0]["U"], caches[6]["U"])
+    monkeypatch.setenv("VLMC_SGPT_CONCURRENT", "0")
+    caches2 = [{"rows_seen": r} for r in rows_seen]
+    SG.factorize_many([(H.clone(), c) for H, c in zip(Hs, caches2)], percdamp=0.01)
+    for (U, dead), b in zip(one, caches2):
+        assert torch.equal(U, b["U"])                                            # switched off: the one-by-one route

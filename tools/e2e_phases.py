@@ -27,8 +27,8 @@ orig_walk = cal.walk_blocks
 
 def walk(model, inps, outs, caches, mtp, n, autocast, prune_block, tuple_output, **kw):
     def pb(i, layer, subset, run_pass, state):
-        def rp(before_sample=None):
-            return timed("replay pass with hooks" if before_sample is not None else "replay pass plain", run_pass)(before_sample)
+        def rp(before_sample=None, **kw):
+            return timed("replay pass with hooks" if before_sample is not None else "replay pass plain", run_pass)(before_sample, **kw)
         return timed("prune_block total (incl. hooked pass)", prune_block)(i, layer, subset, rp, state)
     return orig_walk(model, inps, outs, caches, mtp, n, autocast, pb, tuple_output, **kw)
 

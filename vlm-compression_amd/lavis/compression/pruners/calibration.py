@@ -1242,9 +1242,12 @@ class BlockGraph:
 
 
 def staged_graphs_enabled():
-    """`VLMC_STAGED_GRAPH=0`: every grouped block forward is issued eagerly (~40 kernel launches per forward).  Default:
-    structurally identical blocks of a tower share HIP graphs (`StagedGraphs`)."""
-    return os.environ.get("VLMC_STAGED_GRAPH", "1") != "0" and graph_replay_enabled()
+    """`VLMC_STAGED_GRAPH=1`: structurally identical blocks of a tower share HIP graphs of their grouped forwards
+    (`StagedGraphs`).  OFF by default -- measured (profiles/r03_scaling_floor.md): on ROCm 7.2 a replayed graph dispatches its
+    ~40 kernel nodes 10-50 us apart where an eager host that is ahead gets them 2-5 us apart, and every (signature, pass,
+    group) costs a capture; one rank's share of an 8-GPU prune took 0.155 s with the graphs against 0.145 s without, the
+    ragged reference-op stand-in 1.59 s against 1.53 s."""
+    return os.environ.get("VLMC_STAGED_GRAPH", "0") == "1" and graph_replay_enabled()
 
 
 _MODULE_FIELDS = frozenset(nn.Module().__dict__)

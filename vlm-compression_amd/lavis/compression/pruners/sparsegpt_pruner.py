@@ -71,6 +71,11 @@ class _SparseGPTBlockMixin:
         _allreduce_hessians(unique)
         owner = _shard_linears(subset, wrapped)
         rank = cal.calibration_shard()[0]
+        mine = [name for name in subset if owner is None or owner[name] == rank]
+        # the Hessians this rank prunes with: factorized together, each chain on a stream of its own, one host check for all
+        sparsegpt.factorize_many(list({id(wrapped[n]): (wrapped[n].H, wrapped[n].factor_cache) for n in mine}.values()), percdamp=0.01,
+                                 history=self.__dict__.setdefault("_damping_history", {}).setdefault(module_to_process, {}))
+        scores = []
         for name, mod in subset.items():
             acc = wrapped[name]
             assert acc.nsamples == n_inps                                          # :442
@@ -78,7 +83,8 @@ class _SparseGPTBlockMixin:
                 continue
             key = f"{module_to_process}.{i}.{name}.weight"
             sparsegpt.fasterprune(mod, acc.H, sparsity_ratio[key], prune_n=self.prune_n, prune_m=self.prune_m,
-                                  percdamp=0.01, blocksize=128, factor_cache=acc.factor_cache)
+                                  percdamp=0.01, blocksize=128, factor_cache=acc.factor_cache, score_sink=scores)
+        sparsegpt.flush_scores(scores)                                             # importance scores: one host copy per block
         if owner is not None:
             _exchange_pruned(subset, owner, rank)
         for acc in unique:

@@ -146,19 +146,44 @@ def _chol_steps(A, L, inv, info):
         _lib.check(lib.vlmc_chol_block(A.data_ptr() + off, n, nb, L.data_ptr() + off, n, inv_k.data_ptr(), _CHOL_NB,
                                        info.data_ptr(), k, _stream()))
         if k + nb < n:
+            L21 = L[k + nb:, k:k + nb]
             if _CHOL_PANEL_GEMM:
-                L21 = A[k + nb:, k:k + nb] @ inv_k[:nb, :nb].t()            # = A21 inv(L11)^T
+                torch.mm(A[k + nb:, k:k + nb], inv_k[:nb, :nb].t(), out=L21)            # = A21 inv(L11)^T, straight into L
             else:
-                L21 = torch.linalg.solve_triangular(L[k:k + nb, k:k + nb], A[k + nb:, k:k + nb].t(), upper=False).t()
-            L[k + nb:, k:k + nb] = L21
+                L21.copy_(torch.linalg.solve_triangular(L[k:k + nb, k:k + nb], A[k + nb:, k:k + nb].t(), upper=False).t())
             A[k + nb:, k + nb:].addmm_(L21, L21.t(), beta=1.0, alpha=-1.0)   # trailing update (the lower part is what is read)
 
 
-_chol_graphs = {}       # (n, device index) -> (graph, A, L, inv, info): the sweep is launch-bound when issued from Python
+_chol_graphs = {}       # (n, device index, slot) -> (graph, A, L, inv, info): the sweep is launch-bound when issued from Python
+
+
+def _chol_graph(n, dev, slot):
+    """The captured sweep for n x n matrices with its work buffers; `slot`: an instance of its own for every chain that may
+    run at the same time as another of the same size (factorize_many).  Captured on first use -- from the calling thread."""
+    key = (n, dev.index, slot)
+    ent = _chol_graphs.get(key)
+    if ent is None:
+        A = torch.empty((n, n), dtype=torch.float32, device=dev)
+        L = torch.zeros((n, n), dtype=torch.float32, device=dev)
+        inv = torch.empty((_CHOL_NB, _CHOL_NB), dtype=torch.float32, device=dev)
+        info = torch.zeros(1, dtype=torch.int32, device=dev)
+        A.copy_(torch.eye(n, device=dev))
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                      # one eager run before capture (library workspaces)
+            _chol_steps(A, L, inv, info)
+        cur.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            _chol_steps(A, L, inv, info)
+        cur.wait_stream(torch.cuda.current_stream(dev))
+        ent = _chol_graphs[key] = (graph, A, L, inv, info)
+    return ent
 
 
 @torch.no_grad()
-def blocked_cholesky(H: torch.Tensor, upper=False):
+def blocked_cholesky(H: torch.Tensor, upper=False, slot: int = 0):
     """(factor, info) like torch.linalg.cholesky_ex(H, upper=upper) for a symmetric fp32 matrix on the GPU.
     Right-looking, 128-column blocks: the diagonal block and its inverse in ONE one-workgroup kernel
     (`vlmc_chol_block`), the panel below it and the trailing update as library GEMMs; the ~5 launches per block
@@ -168,24 +193,7 @@ def blocked_cholesky(H: torch.Tensor, upper=False):
     n = H.shape[0]
     dev = H.device
     if _CHOL_GRAPH and n > _CHOL_NB:
-        key = (n, dev.index)
-        ent = _chol_graphs.get(key)
-        if ent is None:
-            A = torch.empty((n, n), dtype=torch.float32, device=dev)
-            L = torch.zeros((n, n), dtype=torch.float32, device=dev)
-            inv = torch.empty((_CHOL_NB, _CHOL_NB), dtype=torch.float32, device=dev)
-            info = torch.zeros(1, dtype=torch.int32, device=dev)
-            A.copy_(H)
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):                      # one eager run before capture (library workspaces)
-                _chol_steps(A, L, inv, info)
-            torch.cuda.current_stream(dev).wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                _chol_steps(A, L, inv, info)
-            ent = _chol_graphs[key] = (graph, A, L, inv, info)
-        graph, A, L, inv, info = ent
+        graph, A, L, inv, info = _chol_graph(n, dev, slot)
         A.copy_(H)                                              # also converts a column-major H
         info.zero_()
         graph.replay()
@@ -209,7 +217,7 @@ def release_caches():
 
 
 _SELECT_THRESHOLD = __import__("os").environ.get("VLMC_SGPT_SORT_THRESHOLD", "0") != "1"
-factor_stats = {"direct": 0, "chain": 0}     # how often each route produced the inverse factor
+factor_stats = {"direct": 0, "chain": 0, "damped": 0}     # how often each route produced the inverse factor (damped: k >= 1 failed attempts, one factorization of H + k damp I)
 _DIRECT_FACTOR = __import__("os").environ.get("VLMC_SGPT_DIRECT_FACTOR", "1") == "1"
 _inv_graphs = {}        # (n, device index) -> (graph, A, L, inv, X, U, info)
 
@@ -218,20 +226,32 @@ def _inverse_factor_steps(A, L, inv, X, U, info):
     """A = H with rows and columns reversed (consumed).  M = chol(A) (lower), X = M^-1 by block rows
     (X[i, :i] = -inv(M_ii) (M[i, :i] X[:i, :i]), the diagonal-block inverses come from vlmc_chol_block), and
     U = X with rows and columns reversed: upper triangular with U^T U = H^-1."""
-    _chol_steps(A, L, inv, info)
+    # One pass: the diagonal-block kernel writes inv(M_kk) straight into X's diagonal block, the panel product goes straight
+    # into L, and block row k of X follows as soon as block row k of M is final (it is: right-looking) -- five graph nodes per
+    # 128 columns (the separate factor / inverse passes with their slice copies were ten; a node costs 5-10 us of dispatch
+    # on top of its kernel, and the chain is nothing but dependent nodes).
     n = A.shape[0]
+    lib = _lib.load()
+    el = A.element_size()
     X.zero_()
     for k in range(0, n, _CHOL_NB):
         nb = min(_CHOL_NB, n - k)
-        ik = inv[k // _CHOL_NB][:nb, :nb]
-        X[k:k + nb, k:k + nb] = ik
+        off = (k * n + k) * el
+        ik = X[k:k + nb, k:k + nb]
+        _lib.check(lib.vlmc_chol_block(A.data_ptr() + off, n, nb, L.data_ptr() + off, n, X.data_ptr() + off, n, info.data_ptr(), k,
+                                       _stream()))
+        if k + nb < n:
+            L21 = L[k + nb:, k:k + nb]
+            torch.mm(A[k + nb:, k:k + nb], ik.t(), out=L21)                 # = A21 inv(M_kk)^T
+            A[k + nb:, k + nb:].addmm_(L21, L21.t(), beta=1.0, alpha=-1.0)
         if k:
-            X[k:k + nb, :k] = torch.mm(ik, torch.mm(L[k:k + nb, :k], X[:k, :k])).neg_()
+            row = X[k:k + nb, :k]
+            torch.addmm(row, ik, torch.mm(L[k:k + nb, :k], X[:k, :k]), beta=0.0, alpha=-1.0, out=row)
     U.copy_(torch.flip(X, (0, 1)))
 
 
 @torch.no_grad()
-def inverse_upper_factor(H: torch.Tensor):
+def inverse_upper_factor(H: torch.Tensor, slot: int = 0):
     """(U, info): the upper triangular U with U^T U = H^-1, i.e. what `cholesky(cholesky_inverse(cholesky(H)), upper=True)`
     (sparsegpt_pruner.py:112-150) arrives at, from ONE factorization: with J the index reversal, J H J = M M^T gives
     H = R R^T for the upper triangular R = J M J, hence H^-1 = (R^-1)^T R^-1 and U = R^-1 = J M^-1 J (the Cholesky
@@ -241,7 +261,7 @@ def inverse_upper_factor(H: torch.Tensor):
     assert H.dim() == 2 and H.shape[0] == H.shape[1] and H.dtype == torch.float32
     n = H.shape[0]
     dev = H.device
-    key = (n, dev.index)
+    key = (n, dev.index, slot)           # `slot`: chains of equal size that run at the same time need buffers of their own
     ent = _inv_graphs.get(key)
     if ent is None:
         nblk = (n + _CHOL_NB - 1) // _CHOL_NB
@@ -273,36 +293,141 @@ def inverse_upper_factor(H: torch.Tensor):
     return U.clone(), info.clone()
 
 
-def _chol_with_damping(H, damp, upper, max_tries=100):
+def _chol_with_damping(H, damp, upper, max_tries=100, slot=0):
     for _ in range(max_tries):
-        L, info = blocked_cholesky(H, upper=upper)
+        L, info = blocked_cholesky(H, upper=upper, slot=slot)
         if int(info.item()) == 0 and not bool(torch.isnan(L).any()):
             return L
         H.diagonal().add_(damp)                                        # only after a failure (:114-128)
     raise _lib.VlmcError(_lib.VLMC_ENOTPD, "Hessian not positive definite after %d damping steps" % max_tries)
 
 
+_FACTOR_STREAMS = {}       # device index -> side streams of factorize_many
+
+
+def concurrent_factor_enabled():
+    """`VLMC_SGPT_CONCURRENT=0`: the Hessians of a block are factorized one after the other, each with its own host checks."""
+    return __import__("os").environ.get("VLMC_SGPT_CONCURRENT", "1") != "0"
+
+
 @torch.no_grad()
-def factorize(H: torch.Tensor, percdamp=0.01, rows_seen=None):
+def factorize_many(items, percdamp=0.01, max_streams=8, history=None):
+    """Factorize the Hessians of one transformer block TOGETHER.  `items`: [(H, factor_cache)], one per distinct linear
+    input (4-7 per Flan-T5-XL / ViT-g block); fills `factor_cache["U"]`, `["dead"]`, where `fasterprune` finds them.
+
+    Each factorization is a serial chain of one-workgroup diagonal-block kernels and small GEMMs that leaves most of the
+    chip idle, and the chains of a block are independent, so every chain runs on a side stream of its own (chains of equal
+    size in separate buffer slots) and the host reads the outcome of ALL of them -- LAPACK info, NaN in the factor, +-inf in
+    H -- in ONE copy (the one-by-one route makes five synchronising checks per Hessian).
+
+    Damping (sparsegpt_pruner.py:112-150: `cholesky(H)`, retried with `H += damp I` while it fails, `cholesky_inverse`,
+    `cholesky(., upper)`).  With k the number of failed attempts, the reference's result is the upper Cholesky factor of
+    (H + k damp I)^-1 -- which `inverse_upper_factor` gives from ONE factorization (the factor is unique).  The attempts
+    k = 0, 1, .. are therefore launched side by side as independent chains (damp = percdamp mean(diag H) is formed on the
+    device; k = 0, 1 first, the next two in a second round if neither is clean) and the first clean one in k order is
+    taken: what the reference's loop would have stopped at, without a host decision between attempts.  `history` (a dict the caller keeps per tower) remembers which inputs needed damping in
+    the previous block: an input that did not is tried undamped only (the T5 decoder's 16-token samples give Hessians of
+    fewer rows than columns in every block, a ViT block's never do).  An input whose attempts all fail -- and the rare
+    factor that is clean here but whose second damping loop the reference would enter (NaN in it) -- takes `factorize`,
+    the reference's three steps with both loops, unchanged."""
+    todo = [(H, c) for H, c in items if "U" not in c]
+    if not todo:
+        return
+    if not (concurrent_factor_enabled() and _DIRECT_FACTOR and todo[0][0].is_cuda):
+        for H, c in todo:
+            c["U"], c["dead"] = factorize(H, percdamp, rows_seen=c.get("rows_seen"))
+        return
+    dev = todo[0][0].device
+    main = torch.cuda.current_stream(dev)
+    streams = _FACTOR_STREAMS.setdefault(dev.index, [])
+    while len(streams) < max_streams:
+        streams.append(torch.cuda.Stream(device=dev))
+    history = {} if history is None else history
+    slots, n_launched = {}, [0]
+
+    def launch(H, k, damp):
+        n = H.shape[0]
+        slot = slots.get(n, 0)
+        slots[n] = slot + 1
+        st = streams[n_launched[0] % len(streams)]
+        n_launched[0] += 1
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            if k:
+                Hk = H.clone()
+                Hk.diagonal().add_(damp * float(k))             # k failed attempts: H += damp, k times (:118-121)
+            else:
+                Hk = H
+            U, info = inverse_upper_factor(Hk, slot=slot)
+            bad = (info != 0).any() | torch.isnan(U).any() | torch.isinf(Hk).any()
+        for t in (U, bad):
+            t.record_stream(main)
+        return U, bad
+
+    prepared = []
+    for idx, (H, c) in enumerate(todo):
+        dead = torch.diag(H) == 0
+        H.diagonal().masked_fill_(dead, 1.0)                     # H[dead, dead] = 1 (:99-100) without the host round trip
+        damp = percdamp * torch.mean(torch.diag(H))              # (:110) a device scalar
+        ks = (0,) if history.get(idx, 1) == 0 else (0, 1)
+        prepared.append((H, c, dead, damp, ks))
+    attempts = [[(k,) + launch(H, k, damp) for k in ks] for H, c, dead, damp, ks in prepared]
+    for st in streams:
+        main.wait_stream(st)
+    flags = torch.stack([bad for att in attempts for _, _, bad in att]).cpu().tolist()       # the ONE host read
+    pos, retry = 0, []
+    for idx, ((H, c, dead, damp, ks), att) in enumerate(zip(prepared, attempts)):
+        fl = flags[pos:pos + len(att)]
+        pos += len(att)
+        ok = [k for (k, _, _), f in zip(att, fl) if not f]
+        if ok:
+            k = ok[0]
+            factor_stats["direct" if k == 0 else "damped"] = factor_stats.get("direct" if k == 0 else "damped", 0) + 1
+            c["U"], c["dead"] = att[ks.index(k)][1], dead
+            history[idx] = k
+        else:
+            retry.append((idx, H, c, dead, damp, ks))
+    if retry:                                                    # the next two attempts of what has not come out clean
+        second = [(idx, H, c, dead, [(k,) + launch(H, k, damp) for k in (ks[-1] + 1, ks[-1] + 2)]) for idx, H, c, dead, damp, ks in retry]
+        for st in streams:
+            main.wait_stream(st)
+        flat = [bad for *_, att in second for _, _, bad in att]
+        fl2 = torch.stack(flat).cpu().tolist() if flat else []
+        pos = 0
+        for idx, H, c, dead, att in second:
+            fl = fl2[pos:pos + len(att)]
+            pos += len(att)
+            ok = [k for (k, _, _), f in zip(att, fl) if not f]
+            if ok:
+                factor_stats["damped"] = factor_stats.get("damped", 0) + 1
+                c["U"], c["dead"] = att[[a[0] for a in att].index(ok[0])][1], dead
+                history[idx] = ok[0]
+            else:                                                # more than two damping steps, or a factor with NaN: the reference's route
+                history[idx] = 3
+                c["U"], c["dead"] = factorize(H, percdamp, rows_seen=c.get("rows_seen"), try_direct=False)
+
+
+@torch.no_grad()
+def factorize(H: torch.Tensor, percdamp=0.01, rows_seen=None, slot=0, try_direct=True):
     """(U, dead): upper Cholesky factor of H^-1 (`Hinv`, :92-160) and the dead-column mask; consumes H.
     Depends on H only, so linears fed by the same tensor (q/k/v, wi_0/wi_1) share one factorization."""
     dead = torch.diag(H) == 0
-    H[dead, dead] = 1
+    H.diagonal().masked_fill_(dead, 1.0)          # H[dead, dead] = 1 (:99-100): the diagonal entries, no host round trip
     _clamp_inf(H)
-    if _DIRECT_FACTOR and (rows_seen is None or rows_seen > H.shape[0]):
+    if try_direct and _DIRECT_FACTOR and (rows_seen is None or rows_seen > H.shape[0]):
         # (a Hessian of no more rows than columns is singular or nearly so: straight to the reference's chain)
         # one factorization of the index-reversed Hessian instead of cholesky -> cholesky_inverse -> cholesky: the same
         # matrix (the factor is unique) with other roundings.  A Hessian that is not positive definite takes the
         # reference's three-step chain below with its two damping loops, unchanged.
-        U, info = inverse_upper_factor(H)
+        U, info = inverse_upper_factor(H, slot=slot)
         if int(info.item()) == 0 and not bool(torch.isnan(U).any()):
             factor_stats["direct"] += 1
             return U, dead
     factor_stats["chain"] += 1
-    L = _chol_with_damping(H, percdamp * torch.mean(torch.diag(H)), upper=False)
+    L = _chol_with_damping(H, percdamp * torch.mean(torch.diag(H)), upper=False, slot=slot)
     Hi = torch.cholesky_inverse(L)
     _clamp_inf(Hi)
-    U = _chol_with_damping(Hi, percdamp * torch.mean(torch.diag(Hi).abs()), upper=True)
+    U = _chol_with_damping(Hi, percdamp * torch.mean(torch.diag(Hi).abs()), upper=True, slot=slot)
     return U.contiguous(), dead                          # the solver hands back a column-major factor
 
 
@@ -310,7 +435,7 @@ def factorize(H: torch.Tensor, percdamp=0.01, rows_seen=None):
 def inverse_factor(H: torch.Tensor, W: torch.Tensor, percdamp=0.01) -> torch.Tensor:
     """Upper Cholesky factor of H^-1; consumes H, zeroes W's dead columns (:92-160)."""
     U, dead = factorize(H, percdamp)
-    W[:, dead] = 0
+    W.masked_fill_(dead.unsqueeze(0), 0.0)
     return U
 
 
@@ -331,7 +456,7 @@ def sweep_block(W: torch.Tensor, i1: int, i2: int, U: torch.Tensor, mask1, prune
 
 @torch.no_grad()
 def fasterprune(layer, H: torch.Tensor, sparsity, prune_n=0, prune_m=0, blocksize=128, percdamp=0.01, return_mask=False,
-                factor_cache=None):
+                factor_cache=None, score_sink=None):
     """`SparseGPT.fasterprune` (:81-215): prunes `layer.weight` in place, sets
     `weight.importance_score`.  H is consumed.  `factor_cache` (a dict owned by the caller, one per distinct
     Hessian) lets linears with the same input reuse the factorization -- bit-identical to recomputing it."""
@@ -342,7 +467,7 @@ def fasterprune(layer, H: torch.Tensor, sparsity, prune_n=0, prune_m=0, blocksiz
         U, dead = factorize(H, percdamp, rows_seen=(factor_cache or {}).get("rows_seen"))
         if factor_cache is not None:
             factor_cache["U"], factor_cache["dead"] = U, dead
-    W[:, dead] = 0
+    W.masked_fill_(dead.unsqueeze(0), 0.0)                                                 # W[:, dead] = 0 (:101)
     diag = torch.diag(U)
     score_mean = (W ** 2 / diag.reshape(1, -1) ** 2).abs().mean()
     rows, cols = W.shape
@@ -365,6 +490,19 @@ def fasterprune(layer, H: torch.Tensor, sparsity, prune_n=0, prune_m=0, blocksiz
         sweep_block(W, i1, i2, U, mask1, prune_n, prune_m, err, pruned)
         if i2 < cols:
             W[:, i2:].addmm_(err[:, :i2 - i1], U[i1:i2, i2:], beta=1.0, alpha=-1.0)        # :210
-    setattr(layer.weight, "importance_score", score_mean.item())                           # :165
+    if score_sink is None:
+        setattr(layer.weight, "importance_score", score_mean.item())                       # :165
+    else:
+        score_sink.append((layer.weight, score_mean))              # read back by the caller, all linears of a block at once
     layer.weight.data = W.reshape(layer.weight.shape).to(layer.weight.data.dtype)          # :215
     return pruned
+
+
+def flush_scores(score_sink):
+    """`weight.importance_score` (a Python float, :165) for everything `fasterprune(..., score_sink=...)` has queued: one
+    host copy."""
+    if score_sink:
+        vals = torch.stack([s for _, s in score_sink]).cpu().tolist()
+        for (w, _), v in zip(score_sink, vals):
+            setattr(w, "importance_score", v)
+        score_sink.clear()
