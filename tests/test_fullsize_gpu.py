@@ -127,3 +127,62 @@ def test_baseline_config_0_end_to_end_vs_cpu_oracle(name, shape):
     assert np.array_equal(mask.cpu().numpy(), want["mask"])
     assert torch.equal(Wd.cpu(), want["weight"])
     assert float(parts.sum().item()) / W.numel() == pytest.approx(want["importance_score"], rel=1e-6)
+
+
+def test_full_width_blocks_through_the_grouped_walk_match_the_c_oracle(monkeypatch):
+    """ONE ViT-g block (1408 / 6144, fp16, matrix-wide rule), ONE Flan-T5-XL encoder and ONE decoder block (2048 / 5120, bf16,
+    per-row rule) at model width through the drop-in pruner's real `walk_blocks` with all 128 calibration samples in one
+    group: the per-sample statistics the hooks produce, the running mean over the 128 rows, and EVERY mask / pruned weight
+    of the 22 linears are held against the C restatement of the reference (oracle/wanda_oracle.c: wanda_pruner.py:68-81,
+    :316-341, :664-687) fed the GPU-captured statistics -- whole matrices for the ViT's global threshold, row subsets for
+    the per-row rule."""
+    from lavis.compression import load_pruner
+    from oracle import wanda_c as OC
+    from vlmc import ops, synthetic, wanda
+    if not OC.available():
+        pytest.skip("C oracle not built")
+    model = synthetic.InstructBlipT5(vit_depth=1, enc_depth=1, dec_depth=1).to(DEV).eval()
+    synthetic.randomize_(model, 3)
+    batches = synthetic.calibration_batches(128, DEV, vocab=model.t5_model.shared.num_embeddings)
+    real_sq, real_prune = ops.act_sqnorm_batch, wanda.prune_block
+    seen = {"stat_inputs": 0, "linears": 0, "groups": []}
+
+    def checked_sqnorm(xs, outs=None):
+        rows = real_sq(xs, outs)
+        for x, r in zip(xs, rows):
+            seen["groups"].append(x.shape[0])
+            for c in (0, x.shape[0] // 2, x.shape[0] - 1):
+                assert np.array_equal(r[c].cpu().numpy().view(np.uint32), OC.act_sqnorm(x[c].cpu()).view(np.uint32))
+            seen["stat_inputs"] += 1
+        return rows
+
+    def checked_block(weights, stats, mode, *, ratios=None, n=0, m=0, apply_zero=True, partials=None):
+        W0 = [w.detach().clone() for w in weights]
+        for st in {id(s): s for s in stats}.values():               # the running mean over the 128 per-sample rows
+            rows = st.local_normsq().cpu().numpy()
+            assert rows.shape[0] == 128
+            want, n_after = OC.scaler_update(np.zeros(st.in_features, np.float32), 0, rows, 1)
+            assert n_after == 128 and np.array_equal(st.scaler_row.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        masks = real_prune(weights, stats, mode, ratios=ratios, n=n, m=m, apply_zero=apply_zero, partials=partials)
+        for w0, w, st, mk, ratio in zip(W0, weights, stats, masks, ratios):
+            s = st.scaler_row.cpu().numpy()
+            if mode == "matrix":
+                m_c, W_c, _ = OC.select(w0.cpu(), s, "matrix", k=int(w0.numel() * ratio))
+                assert np.array_equal(mk.cpu().numpy(), m_c) and torch.equal(w.detach().cpu(), W_c)
+            else:
+                k = int(w0.shape[1] * ratio)
+                for r0 in (0, w0.shape[0] // 2 - 17, w0.shape[0] - 48):
+                    rows = slice(r0, r0 + 48)
+                    m_c, W_c, _ = OC.select(w0[rows].cpu(), s, "row", k=k)
+                    assert np.array_equal(mk[rows].cpu().numpy(), m_c) and torch.equal(w.detach()[rows].cpu(), W_c)
+                assert int((~mk).sum(1).min()) == k == int((~mk).sum(1).max())
+            seen["linears"] += 1
+        return masks
+
+    monkeypatch.setattr(ops, "act_sqnorm_batch", checked_sqnorm)
+    monkeypatch.setattr(wanda, "prune_block", checked_block)
+    cfg = dict(t5_prune_spec="1-0.5-1.0-1.0", vit_prune_spec="1-0.5-1.0-1.0", t5_pruning_method="wanda", vit_pruning_method="wanda",
+               num_samples=128, max_sparsity_per_layer=1.01)
+    load_pruner("blipt5_wanda_pruner", model, batches, cfg=cfg).prune()
+    assert seen["linears"] == 4 + 7 + 11
+    assert seen["stat_inputs"] == 4 + 4 + 7 and set(seen["groups"]) == {128}       # one grouped forward per block pass

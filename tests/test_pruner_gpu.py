@@ -57,7 +57,7 @@ def test_pruner_on_gpu_every_launch_matches_oracle(name, replay, monkeypatch):
     per_pass = 1 if replay == "grouped" else 6
     assert counts["sqnorm_inputs"] == per_pass * (2 * 4 + 2 * 4 + 2 * 7)
     assert counts["sqnorm_launches"] == per_pass * 6
-    st = H.compare_with_golden(name, pruned, exact=False, min_mask_agreement=0.99)
+    st = H.compare_with_golden(name, pruned, exact=False, min_mask_agreement=1.0)
     print(name, st)
     for mn, mod in pruned.named_modules():
         if hasattr(mod, "mask") and hasattr(mod, "weight"):
@@ -146,7 +146,7 @@ def test_dsnot_pruner_on_gpu_every_linear_matches_oracle(name, monkeypatch):
     pruned, _ = H.run_dsnot_pruner(name, "cuda:0")
     assert counts["linears"] == 2 * 4 + 2 * 7 + 2 * 11
     assert counts["moments"] == 2 * 4 + 2 * 4 + 2 * 7              # one launch per distinct input tensor, all 6 samples in it
-    st = H.compare_with_golden(name, pruned, exact=False, min_mask_agreement=0.99, which="dsnot_e2e")
+    st = H.compare_with_golden(name, pruned, exact=False, min_mask_agreement=1.0, which="dsnot_e2e")
     print(name, st)
 
 
@@ -166,10 +166,10 @@ def test_batched_replay_on_gpu_tracks_reference_run(method, monkeypatch):
         monkeypatch.setattr(ops, "act_sqnorm_batch", counting)
         pruned, _ = H.run_pruner("fp32_r50", "cuda:0")
         assert seen["calls"] == 6 * (2 * 4 + 2 * 4 + 2 * 7)          # still one statistics row per sample and distinct input
-        st = H.compare_with_golden("fp32_r50", pruned, exact=False, min_mask_agreement=0.99)
+        st = H.compare_with_golden("fp32_r50", pruned, exact=False, min_mask_agreement=1.0)
     else:
         pruned, _ = H.run_dsnot_pruner("fp32_r50", "cuda:0")
-        st = H.compare_with_golden("fp32_r50", pruned, exact=False, min_mask_agreement=0.99, which="dsnot_e2e")
+        st = H.compare_with_golden("fp32_r50", pruned, exact=False, min_mask_agreement=1.0, which="dsnot_e2e")
     print(method, st)
 
 
@@ -192,7 +192,7 @@ def test_replay_modes_agree_with_the_reference_side_by_side(monkeypatch):
         for mode, group in (("per_sample_graph", "1"), ("grouped", "128")):
             monkeypatch.setenv("VLMC_BATCH_REPLAY", group)
             pruned, _ = run(name, "cuda:0")
-            st = H.compare_with_golden(name, pruned, exact=False, min_mask_agreement=0.99, which=which)
+            st = H.compare_with_golden(name, pruned, exact=False, min_mask_agreement=1.0, which=which)
             got[mode] = (1 - st["mask_diff"] / st["mask_elems"], masks_of(pruned))
         a, b = got["per_sample_graph"][1], got["grouped"][1]
         tot = sum(m.numel() for m in a.values())
