@@ -303,10 +303,11 @@ torch.save(outs, sys.argv[1])
     # ... half panels / blocks handed out last)
     for ring, big, pp, persist, edge in (("1", "200", "1", "1", "1"), ("0", "200", "1", "1", "1"), ("1", "1", "1", "1", "1"),
                                         ("1", "1", "1", "0", "1"), ("1", "1", "0", "1", "1"), ("0", "0", "1", "1", "1"),
-                                        ("1", "0", "1", "1", "1"), ("1", "1", "1", "1", "0")):
+                                        ("1", "0", "1", "1", "1"), ("1", "1", "1", "1", "0"), ("1", "1", "1", "1", "w")):
+        # (edge "w": K-steps of 32 with half-line requests also where K % 64 == 0 -- the default there is the whole-line kernel)
         out = tmp_path / f"r{ring}_b{big}_p{pp}_s{persist}_e{edge}.pt"
         env = dict(os.environ, VLMC_GEMM_RING=ring, VLMC_GEMM_BIG_TILES=big, VLMC_GEMM_PINGPONG=pp, VLMC_GEMM_PERSIST=persist,
-                   VLMC_GEMM_EDGE=edge)
+                   VLMC_GEMM_EDGE="1" if edge == "w" else edge, VLMC_GEMM_WIDE="0" if edge == "w" else "1")
         r = subprocess.run([sys.executable, "-c", code, str(out)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         results.append(torch.load(out))

@@ -46,7 +46,7 @@ print(json.dumps([statistics.median(t) * 1e3 for t in ts]))
 def main():
     sets = sys.argv[1:] or ["vit", "t5"]
     shapes = [s for k in sets for s in SHAPES[k]]
-    configs = [{"VLMC_GEMM_EDGE": "0"}, {"VLMC_GEMM_EDGE": "1"}]
+    configs = [{"VLMC_GEMM_WIDE": "0"}, {"VLMC_GEMM_WIDE": "1"}]
     extra = os.environ.get("GEMM_AB_CONFIGS")
     if extra:
         configs = [dict(kv.split("=") for kv in c.split(",")) for c in extra.split(";")]

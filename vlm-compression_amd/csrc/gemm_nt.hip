@@ -703,6 +703,256 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- the same kernel with WHOLE-LINE loads ----------------------------------------------------------------------------
+// A K-step of 32 puts 64 B of each tile row in a request: half a 128-B line, so every line is asked for twice (by the
+// pieces of two consecutive steps).  The load stream by itself moves 13.6 TB/s that way and 16.0 TB/s in pieces of 8 rows x
+// 128 B (tools/micro/lds_dma_rows.hip), and the K loop is paced by the load stream (half_tile_cost.py).  Here the ring is two
+// DOUBLE slots of K = 64: rows of 128 B hold two K-steps side by side (16-B chunk index XOR-ed with row & 7: the fragment
+// reads of either step are conflict-free), a piece is 8 whole rows, and a wave issues its 8 pieces of double step d + 1
+// during K-step 2 d (4 behind the fragment reads, 4 between the MFMAs), two steps before they are needed.  The MFMAs of an
+// output element, and their order, are those of the kernels above.  K must be a multiple of 64.
+template <typename T, int EPI, typename S>
+__global__ __launch_bounds__(S::NT, 2) void gemm_nt_wide_kernel(const GemmArgs a, const int ntiles) {
+    constexpr int BP = S::BP, BQ = S::BQ, TP = S::TP, TQ = S::TQ, NW = S::WP * S::WQ;
+    static_assert(NW == 8 && S::WP == 2 && S::WQ == 4, "two waves per SIMD (w, w + 4): same q rows, the two p halves");
+    constexpr int WROW = 2 * RROW;                                        // 128 B per row: two K-steps side by side
+    constexpr int P_BYTES = BP * WROW, Q_BYTES = BQ * WROW, SLOT = P_BYTES + Q_BYTES;       // a double slot: 64 KiB
+    constexpr int GROUPS = (BP + BQ) / 8, PER_WAVE = GROUPS / NW;         // pieces of 8 rows x 128 B per double step
+    static_assert(GROUPS % NW == 0, "whole load instructions per wave");
+    static_assert(PER_WAVE * 8 == 64 && BP == 256 && BQ == 256, "wave w loads rows 64 (w & 3) .. of P (w < 4) or Q (w >= 4)");
+#ifndef VLMC_WIDE_HALF
+#define VLMC_WIDE_HALF 8             // pieces of a double step issued behind the fragment reads, the rest between the MFMAs (measured: 8 / 6 / 4 / 2 -> vit.fc1 494 / 506 / 513 / 517 us, profiles/r03_gemm.md)
+#endif
+    constexpr int HALF = VLMC_WIDE_HALF;                                  // pieces issued in L, the rest in M
+    constexpr int EPI_ROWS = 16;                                          // epilogue scratch: 16 rows x 8 waves = 32 KiB
+    static_assert(EPI != EPI_LINEAR || NW * EPI_ROWS * (TP * 16) * 2 <= Q_BYTES, "the epilogue's scratch is the Q half of the second double slot");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool late = wave >= NW / 2;
+    const uint32_t lds_base = uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)lds));   // LDS byte address
+
+    // ---- this workgroup's work ---------------------------------------------------------------------------------------
+    const int G = gridDim.x, xcd = blockIdx.x & 7, lx = blockIdx.x >> 3;
+    const int nx = (G - xcd + 7) >> 3;                                    // workgroups with this XCD label
+    const int n_full = EPI == EPI_LINEAR ? a.npf * a.nqf : ntiles, n_edge = ntiles - n_full;
+    auto share = [](int n, int x, int &start, int &count) {               // x-th of 8 near-equal contiguous shares of n
+        const int q8 = n >> 3, r8 = n & 7;
+        start = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8;
+        count = q8 + (x < r8 ? 1 : 0);
+    };
+    int fs, nf, es, ne;
+    share(n_full, xcd, fs, nf);
+    share(n_edge, 7 - xcd, es, ne);                                       // (the odd edge tiles go to the XCDs without an odd full one)
+    // full tiles in rounds of the XCD's nx workgroups (workgroup lx takes tile lx of every round: neighbours work on
+    // neighbouring tiles at the same time and share their operand panels in L2); the edge tiles are dealt out starting at
+    // the first workgroup that has no tile in the last, partial round
+    const int rounds = (nf + nx - 1) / nx, left = nf % nx;
+    int round = 0;
+    int e = lx - left;                                                    // edge tiles e, e + nx, ..
+    if (e < 0) e += nx;
+    // next piece of work: panel and first q row; false when done
+    auto advance = [&](Panel &pn, int &q0) {
+        int bp, bq;
+        if (round < rounds && round * nx + lx < nf) {
+            const int t = round * nx + lx;
+            ++round;
+            if constexpr (EPI == EPI_SYRK) triangle_order(fs + t, bp, bq);
+            else grid_order(fs + t, a.npf, a.nqf, bp, bq);
+        } else if (e < ne) {
+            round = rounds;
+            const int ee = es + e, ep = a.nph * a.nqf, eq = a.q_half * a.npf;
+            e += nx;
+            if (ee < ep) {                                                // half panel x full block
+                const int h = ee / a.nqf;
+                bq = ee - h * a.nqf;
+                bp = a.npf + h;
+            } else if (ee < ep + eq) {                                    // full panel x half block
+                bp = ee - ep;
+                bq = a.nqf;
+            } else {                                                      // half panel x half block
+                bp = a.npf + (ee - ep - eq);
+                bq = a.nqf;
+            }
+        } else {
+            return false;
+        }
+        pn = locate_panel(a, bp, BP);
+        q0 = bq * BQ;
+        return true;
+    };
+    uint32_t dst[PER_WAVE];                                               // wave-uniform LDS byte offset inside a double slot
+    int piece_row[PER_WAVE], piece_sc[PER_WAVE];
+    const bool piece_q = wave >= NW / 2;                                  // waves 0..3 load P, waves 4..7 load Q
+#pragma unroll
+    for (int v = 0; v < PER_WAVE; ++v) {
+        const int g = (wave & 3) * PER_WAVE + v;                          // 8-row group of the operand's image
+        piece_row[v] = g * 8 + (lane >> 3);                               // tile row
+        piece_sc[v] = (lane & 7) ^ (piece_row[v] & 7);                    // source chunk that belongs at LDS chunk (lane & 7)
+        dst[v] = (piece_q ? P_BYTES : 0) + g * 1024;
+    }
+    const uint16_t *src[PER_WAVE];
+    auto tile_sources = [&](const Panel &pn, int q0, const uint16_t *(&out)[PER_WAVE]) {
+#pragma unroll
+        for (int v = 0; v < PER_WAVE; ++v) {
+            const int grow = piece_q ? min(q0 + piece_row[v], a.NQ - 1) : min(pn.p0 + piece_row[v], pn.NP - 1);
+            out[v] = (piece_q ? a.Q + int64_t(grow) * a.ldq : pn.P + int64_t(grow) * pn.ldp) + piece_sc[v] * 8;
+        }
+    };
+#ifndef VLMC_GEMM_DBG
+#define VLMC_GEMM_DBG 0              // diagnostic builds only (tools/gemm_ablate.sh): 1 no ring loads after the first steps,
+#endif                               // 2 no fragment reads, 4 no MFMAs, 8 no epilogue -- results are garbage, only the pace is of interest
+    auto issue_piece = [&](int dstep, int v) {                            // piece v of double step dstep (K = 64 dstep .. + 63)
+        if ((VLMC_GEMM_DBG & 1) && dstep >= 1) {
+            asm volatile("s_nop 0" ::: "memory");
+            return;
+        }
+        glds16(src[v] + dstep * (2 * RK), lds_base + (dstep & 1) * SLOT + dst[v]);
+    };
+    const int nk = a.K / RK, nd = nk / 2;                                 // K-steps of 32 (even), double steps
+    auto barrier = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+    };
+    // SIMD s = wave & 3 holds waves s and s + 4: the same 64 q rows, different p halves
+    const int wp = wave / S::WQ, wq = wave % S::WQ;
+    // fragment of K-step t: chunks 4 (t & 1) + (lane >> 4) of rows (lane & 15) + 16 i; 16-B chunk index XOR-ed with row & 7
+    const int foff0 = (lane & 15) * WROW + (((lane >> 4) ^ (lane & 7)) << 4);
+    const int foff1 = (lane & 15) * WROW + (((4 + (lane >> 4)) ^ (lane & 7)) << 4);
+    // does this wave's 128 x 64 piece hold anything wanted?  are the 64 rows of the [P | Q] image this wave loads read by anyone?
+    auto roles = [&](const Panel &pn, int q0, bool &active, bool &loads) {
+        const int pv = pn.NP - pn.p0, qv = a.NQ - q0;
+        active = wp * (TP * 16) < pv && wq * (TQ * 16) < qv;
+        loads = wave < NW / 2 ? wave * 64 < pv : (wave - NW / 2) * 64 < qv;
+    };
+
+    Panel pn;
+    int q0;
+    if (!advance(pn, q0)) return;                                         // (whole workgroup: no barrier is left waiting)
+    bool active, loads;
+    roles(pn, q0, active, loads);
+    tile_sources(pn, q0, src);
+    if (loads) {
+#pragma unroll
+        for (int v = 0; v < PER_WAVE; ++v) issue_piece(0, v);
+    }
+    for (;;) {
+        f32x4_t acc[TP][TQ];
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // double step 0 has landed (and the last tile's stores)
+        // One K-step of 32.  ODD: the second half of its double slot (nothing to wait for, nothing to fetch).  An even step
+        // t issues the pieces of double step t / 2 + 1 into the slot that steps t - 2 and t - 1 were read from -- both wave
+        // groups left it before the barrier that opens this wave's L(t) -- and that double step must have landed two steps
+        // later: the wait at the end of the odd step is for everything this wave has in flight.  LATE: waves 4..7.
+        // ACTIVE / LOADS: see above.  All compile-time: no scalar branching in the loop.
+        auto kstep = [&](auto odd_c, auto late_c, auto active_c, auto loads_c, const int t) {
+            constexpr bool ODD = decltype(odd_c)::value, LATE = decltype(late_c)::value;
+            constexpr bool ACTIVE = decltype(active_c)::value, LOADS = decltype(loads_c)::value;
+            barrier();
+            // ---- L(t): this step's fragments ----
+            const unsigned char *slot = lds + ((t >> 1) & 1) * SLOT + (ODD ? foff1 : foff0);
+            const unsigned char *tp = slot + wp * (TP * 16) * WROW;
+            const unsigned char *tq = slot + P_BYTES + wq * (TQ * 16) * WROW;
+            u32x4_t fp[TP], fq[TQ];
+            if constexpr (ACTIVE) {
+                if ((VLMC_GEMM_DBG & 2) && t > 0) {
+#pragma unroll
+                    for (int j = 0; j < TQ; ++j) asm volatile("" : "=v"(fq[j]));
+#pragma unroll
+                    for (int i = 0; i < TP; ++i) asm volatile("" : "=v"(fp[i]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TQ; ++j) fq[j] = *reinterpret_cast<const u32x4_t *>(tq + j * 16 * WROW);
+#pragma unroll
+                    for (int i = 0; i < TP; ++i) fp[i] = *reinterpret_cast<const u32x4_t *>(tp + i * 16 * WROW);
+                }
+            }
+            const int dnext = (t >> 1) + 1;
+            const bool more = LOADS && !ODD && dnext < nd;
+            if (more) {
+#pragma unroll
+                for (int v = 0; v < HALF; ++v) issue_piece(dnext, v);
+            }
+            if constexpr (ACTIVE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done with the step's half of the slot
+            if constexpr (LATE && LOADS && ODD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // step t + 1 has landed
+            barrier();
+            // ---- M(t) ----
+            if constexpr (ACTIVE) {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < TP; ++i) {
+#pragma unroll
+                    for (int j = 0; j < TQ; ++j) {
+                        if (VLMC_GEMM_DBG & 4) asm volatile("" : "+v"(acc[i][j]) : "v"(fp[i]), "v"(fq[j]));
+                        else acc[i][j] = mfma16<T>(fp[i], fq[j], acc[i][j]);
+                    }
+                    constexpr int IN_M = PER_WAVE - HALF;                  // spread evenly over the TP row-iterations
+                    if (IN_M > 0 && more && ((i + 1) * IN_M) / TP != (i * IN_M) / TP) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_piece(dnext, HALF + (i * IN_M) / TP);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+            } else if (more) {
+#pragma unroll
+                for (int v = HALF; v < PER_WAVE; ++v) issue_piece(dnext, v);
+            }
+            if constexpr (!LATE && LOADS && ODD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // step t + 1 has landed
+        };
+        auto ksweep = [&](auto late_c, auto active_c, auto loads_c) {
+            for (int t = 0; t < nk; t += 2) {
+                kstep(std::false_type{}, late_c, active_c, loads_c, t);
+                kstep(std::true_type{}, late_c, active_c, loads_c, t + 1);
+            }
+        };
+        auto ksweep_roles = [&](auto late_c) {
+            if (active && loads) ksweep(late_c, std::true_type{}, std::true_type{});
+            else if (active) ksweep(late_c, std::true_type{}, std::false_type{});
+            else if (loads) ksweep(late_c, std::false_type{}, std::true_type{});
+            else ksweep(late_c, std::false_type{}, std::false_type{});
+        };
+        if (late) {
+            barrier();                                                    // waves 4..7 sit out I0
+            ksweep_roles(std::true_type{});
+        } else {
+            ksweep_roles(std::false_type{});
+        }
+        if (!late) barrier();                                             // waves 4..7 still have M(nk - 1) behind this one
+        // ---- every wave has left its last L: the ring is free.  The next tile's first steps go out BEFORE this tile's
+        // ---- epilogue (its stores and the workgroup's restart then overlap the loads' way through the memory system) -----
+        const Panel cpn = pn;
+        const int cq0 = q0;
+        const bool cactive = active;
+        const bool has_next = advance(pn, q0);
+        if (has_next) {
+            roles(pn, q0, active, loads);
+            tile_sources(pn, q0, src);
+            if (loads) {
+#pragma unroll
+                for (int v = 0; v < PER_WAVE; ++v) issue_piece(0, v);
+            }
+        }
+        // (the linear epilogue's scratch is the Q half of the SECOND double slot: the next tile's double step 1 goes there in
+        // its L(0) / M(0), behind a barrier that every wave reaches after its own epilogue; double step 0, above, does not)
+        if (VLMC_GEMM_DBG & 8) {
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int j = 0; j < TQ; ++j) asm volatile("" ::"v"(acc[i][j]));
+        } else if (cactive) {
+            gemm_epilogue<T, EPI, S, EPI_ROWS, false>(a, cpn, acc, cq0, wp, wq, lane, lds + SLOT + P_BYTES, wave);
+        }
+        if (!has_next) break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ---- host side: panel tables, tile shape, launch ---------------------------------------------------------------------
 // split_halves: a group's last panel with at most BP / 2 rows (and the last block of Q likewise) is listed as a "half"
 template <typename S> static int64_t plan_panels(GemmArgs &a, bool split_halves) {
@@ -749,7 +999,12 @@ template <typename T, int EPI, typename S> static void launch_shape(GemmArgs a, 
                 return (e && e[0] == '0') ? (1 << 30) : n;
             }();
             const unsigned grid = unsigned(nblocks < n_cu ? nblocks : n_cu);
-            VLMC_LAUNCH_TIMED((gemm_nt_pingpong_kernel<T, EPI, S>), dim3(grid), dim3(S::NT), s, a, int(nblocks));
+            static const bool wide = [] {
+                const char *e = getenv("VLMC_GEMM_WIDE");         // 0: K-steps of 32 with half-line requests for every K
+                return !(e && e[0] == '0');
+            }();
+            if (wide && a.K % (2 * RK) == 0) VLMC_LAUNCH_TIMED((gemm_nt_wide_kernel<T, EPI, S>), dim3(grid), dim3(S::NT), s, a, int(nblocks));
+            else VLMC_LAUNCH_TIMED((gemm_nt_pingpong_kernel<T, EPI, S>), dim3(grid), dim3(S::NT), s, a, int(nblocks));
             return;
         }
     }
