@@ -303,7 +303,8 @@ torch.save(outs, sys.argv[1])
     # ... half panels / blocks handed out last)
     for ring, big, pp, persist, edge in (("1", "200", "1", "1", "1"), ("0", "200", "1", "1", "1"), ("1", "1", "1", "1", "1"),
                                         ("1", "1", "1", "0", "1"), ("1", "1", "0", "1", "1"), ("0", "0", "1", "1", "1"),
-                                        ("1", "0", "1", "1", "1"), ("1", "1", "1", "1", "0"), ("1", "1", "1", "1", "w")):
+                                        ("1", "0", "1", "1", "1"), ("1", "1", "1", "1", "0"), ("1", "1", "1", "1", "w"),
+                                        ("1", "0", "1", "1", "w")):
         # (edge "w": K-steps of 32 with half-line requests also where K % 64 == 0 -- the default there is the whole-line kernel)
         out = tmp_path / f"r{ring}_b{big}_p{pp}_s{persist}_e{edge}.pt"
         env = dict(os.environ, VLMC_GEMM_RING=ring, VLMC_GEMM_BIG_TILES=big, VLMC_GEMM_PINGPONG=pp, VLMC_GEMM_PERSIST=persist,

@@ -422,6 +422,89 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_kernel(const GemmArgs a
     gemm_epilogue<T, EPI, S>(a, pn, acc, q0, wp, wq, lane, lds, wave);
 }
 
+// ---- the lockstep kernel with whole-line loads and ONE barrier per K = 64 ------------------------------------------------
+// For the problems that do not fill the chip with 256 x 256 tiles (the T5 decoder's 128 x 16 tokens; one rank's share of the
+// calibration samples on 8 GPUs): there the K loop is a chain of dependent steps -- wait for the loads, barrier, read the
+// fragments, multiply -- and what it costs is the number of steps, not their flops.  Two double slots of K = 64 (rows of 128 B:
+// two K-steps side by side, 16-B chunk index XOR-ed with row & 7), pieces of 8 whole rows, and per double step one wait,
+// one barrier, the next double step's loads, the 2 x (TP + TQ) fragment reads of BOTH K-steps and their 2 TP TQ MFMAs: half
+// the barriers and waits per K of gemm_nt_ring_kernel, whole-line requests.  Same MFMAs in the same order per output
+// element.  K must be a multiple of 64.
+template <typename T, int EPI, typename S>
+__global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_wide_kernel(const GemmArgs a) {
+    constexpr int BP = S::BP, BQ = S::BQ, TP = S::TP, TQ = S::TQ, NW = S::WP * S::WQ;
+    constexpr int WROW = 2 * RROW;
+    constexpr int P_BYTES = BP * WROW, Q_BYTES = BQ * WROW, SLOT = P_BYTES + Q_BYTES;
+    constexpr int GROUPS = (BP + BQ) / 8, PER_WAVE = GROUPS / NW;         // pieces of 8 rows x 128 B per wave and double step
+    static_assert(GROUPS % NW == 0, "whole load instructions per wave");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bp, bq;
+    grid_tile<EPI>(a, bp, bq);
+    const Panel pn = locate_panel(a, bp, BP);
+    const int p0 = pn.p0, q0 = bq * BQ;
+
+    const uint32_t lds_base = uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)lds));   // LDS byte address
+    const uint16_t *src[PER_WAVE];
+    uint32_t dst[PER_WAVE];
+#pragma unroll
+    for (int u = 0; u < PER_WAVE; ++u) {
+        const int gidx = wave * PER_WAVE + u;                             // 8-row group of the double step's [P | Q] image
+        const bool is_q = gidx >= BP / 8;
+        const int g = is_q ? gidx - BP / 8 : gidx;
+        const int r = g * 8 + (lane >> 3);                                // tile row
+        const int sc = (lane & 7) ^ (r & 7);                              // source chunk that belongs at LDS chunk (lane & 7)
+        const int grow = is_q ? min(q0 + r, a.NQ - 1) : min(p0 + r, pn.NP - 1);
+        src[u] = (is_q ? a.Q + int64_t(grow) * a.ldq : pn.P + int64_t(grow) * pn.ldp) + sc * 8;
+        dst[u] = (is_q ? P_BYTES : 0) + g * 1024;
+    }
+    auto issue = [&](int d) {
+        const uint32_t slot = lds_base + (d & 1) * SLOT;
+#pragma unroll
+        for (int u = 0; u < PER_WAVE; ++u) glds16(src[u] + d * (2 * RK), slot + dst[u]);
+    };
+
+    const int wp = wave / S::WQ, wq = wave % S::WQ;
+    f32x4_t acc[TP][TQ];
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int foff0 = (lane & 15) * WROW + (((lane >> 4) ^ (lane & 7)) << 4);
+    const int foff1 = (lane & 15) * WROW + (((4 + (lane >> 4)) ^ (lane & 7)) << 4);
+
+    const int nd = a.K / (2 * RK);
+    issue(0);
+    for (int d = 0; d < nd; ++d) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's pieces of double step d have landed
+        __builtin_amdgcn_s_barrier();                                     // everybody's have; everybody has left slot d - 1
+        if (d + 1 < nd) issue(d + 1);
+        const unsigned char *tp = lds + (d & 1) * SLOT + wp * (TP * 16) * WROW;
+        const unsigned char *tq = lds + (d & 1) * SLOT + P_BYTES + wq * (TQ * 16) * WROW;
+        u32x4_t fp[2][TP], fq[2][TQ];
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) fq[0][j] = *reinterpret_cast<const u32x4_t *>(tq + foff0 + j * 16 * WROW);
+#pragma unroll
+        for (int i = 0; i < TP; ++i) fp[0][i] = *reinterpret_cast<const u32x4_t *>(tp + foff0 + i * 16 * WROW);
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) fq[1][j] = *reinterpret_cast<const u32x4_t *>(tq + foff1 + j * 16 * WROW);
+#pragma unroll
+        for (int i = 0; i < TP; ++i) fp[1][i] = *reinterpret_cast<const u32x4_t *>(tp + foff1 + i * 16 * WROW);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int j = 0; j < TQ; ++j) acc[i][j] = mfma16<T>(fp[kk][i], fq[kk][j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        // (the reads above are complete before this wave reaches the next barrier: the MFMAs wait for them)
+    }
+    __builtin_amdgcn_s_barrier();                                         // every wave is done with the slots: the epilogue's scratch
+    gemm_epilogue<T, EPI, S, 32, false>(a, pn, acc, q0, wp, wq, lane, lds, wave);
+}
+
 // ---- ring kernel with the two waves of a SIMD half a step apart ------------------------------------------------------
 // An 8-wave workgroup puts waves w and w + 4 on one SIMD.  Run in lockstep (the kernel above) both fetch, both wait and
 // both multiply together: the matrix pipe idles while they fetch.  Here a step is two barrier-separated halves -- L: issue
@@ -1008,7 +1091,13 @@ template <typename T, int EPI, typename S> static void launch_shape(GemmArgs a, 
             return;
         }
     }
-    if (ring && a.K % RK == 0) VLMC_LAUNCH_TIMED((gemm_nt_ring_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
+    static const bool wide_small = [] {
+        const char *e = getenv("VLMC_GEMM_WIDE");                 // 0: K-steps of 32 with half-line requests for every K
+        return !(e && e[0] == '0');
+    }();
+    if (ring && wide_small && a.K % (2 * RK) == 0 && S::WP * S::WQ == 4)
+        VLMC_LAUNCH_TIMED((gemm_nt_ring_wide_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
+    else if (ring && a.K % RK == 0) VLMC_LAUNCH_TIMED((gemm_nt_ring_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
     else VLMC_LAUNCH_TIMED((gemm_nt_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
 }
 template <typename T, int EPI> static void launch_gemm(const GemmArgs &a, hipStream_t s) {
