@@ -13,6 +13,9 @@ SHAPES = {
             ("vit.fc1", "float16", 128 * 257, 6144, 1408), ("vit.fc2", "float16", 128 * 257, 1408, 6144)],
     "t5": [("t5enc.q", "bfloat16", 8192, 2048, 2048), ("t5enc.wi", "bfloat16", 8192, 5120, 2048), ("t5enc.wo", "bfloat16", 8192, 2048, 5120),
            ("t5dec.wi", "bfloat16", 2048, 5120, 2048)],
+    "dec": [("t5dec.q", "bfloat16", 2048, 2048, 2048), ("t5dec.wi", "bfloat16", 2048, 5120, 2048), ("t5dec.wo", "bfloat16", 2048, 2048, 5120),
+            ("t5dec.qkv-as-one", "bfloat16", 2048, 6144, 2048), ("N=8 t5dec.q", "bfloat16", 256, 2048, 2048),
+            ("N=8 t5enc.q", "bfloat16", 1024, 2048, 2048), ("N=8 t5enc.wo", "bfloat16", 1024, 2048, 5120)],
     "rank": [("N=8 vit.fc1", "float16", 16 * 257, 6144, 1408), ("N=8 vit.fc2", "float16", 16 * 257, 1408, 6144),
              ("N=8 vit.qkv", "float16", 16 * 257, 4224, 1408), ("N=8 t5enc.wi", "bfloat16", 1024, 5120, 2048),
              ("N=4 vit.fc2", "float16", 32 * 257, 1408, 6144), ("N=2 vit.fc2", "float16", 64 * 257, 1408, 6144)],

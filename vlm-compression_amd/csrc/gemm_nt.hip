@@ -1095,7 +1095,14 @@ template <typename T, int EPI, typename S> static void launch_shape(GemmArgs a, 
         const char *e = getenv("VLMC_GEMM_WIDE");                 // 0: K-steps of 32 with half-line requests for every K
         return !(e && e[0] == '0');
     }();
-    if (ring && wide_small && a.K % (2 * RK) == 0 && S::WP * S::WQ == 4)
+    // (one double step of loads in flight: with a second workgroup on the CU to cover the wait it is 8-45 % faster than the
+    // four-slot ring; alone on its CU -- no more tiles than CUs -- 2-7 % slower: measured, profiles/r03_gemm.md)
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    if (ring && wide_small && a.K % (2 * RK) == 0 && S::WP * S::WQ == 4 && nblocks > cus)
         VLMC_LAUNCH_TIMED((gemm_nt_ring_wide_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
     else if (ring && a.K % RK == 0) VLMC_LAUNCH_TIMED((gemm_nt_ring_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
     else VLMC_LAUNCH_TIMED((gemm_nt_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
