@@ -233,3 +233,39 @@ def test_hessians_of_a_block_factorized_together_equal_one_by_one(monkeypatch):
     SG.factorize_many([(H.clone(), c) for H, c in zip(Hs, caches2)], percdamp=0.01)
     for (U, dead), b in zip(one, caches2):
         assert torch.equal(U, b["U"])                                            # switched off: the one-by-one route
+
+
+@pytest.mark.parametrize("nm", [(0, 0), (2, 4)])
+def test_linears_sharing_a_factor_swept_together_equal_their_own_sweeps(nm):
+    """`fasterprune_group`: q / k / v (one Hessian, one factor) stacked along the rows and swept in ONE loop, with the per-block
+    threshold of the unstructured rule kept per linear (sparsegpt_pruner.py:183-185).  Sweep, compensation and trailing update
+    are row-wise: every linear ends with the weights of its own `fasterprune` (the trailing GEMM runs on more rows: allowed to
+    differ in the last bit of a few elements, nothing else), the zero pattern and importance scores included."""
+    import torch.nn as nn
+    from vlmc import sparsegpt as SG
+    g = torch.Generator(device=DEV).manual_seed(11)
+    n, rows_x = 512, 4096
+    x = torch.randn(rows_x, n, generator=g, device=DEV)
+    H = (x.t() @ x) * (2.0 / rows_x)
+    outs, spars = (384, 256, 640), (0.5, 0.5, 0.3)
+    def fresh():
+        torch.manual_seed(5)
+        return [nn.Linear(n, o, bias=False).to(DEV).to(torch.bfloat16) for o in outs]
+    single, grouped = fresh(), fresh()
+    cache = {"rows_seen": rows_x}
+    SG.factorize_many([(H.clone(), cache)])
+    s1, s2 = [], []
+    for lin, sp in zip(single, spars):
+        SG.fasterprune(lin, None, sp, prune_n=nm[0], prune_m=nm[1], factor_cache=cache, score_sink=s1)
+    SG.fasterprune_group(grouped, list(spars), cache, prune_n=nm[0], prune_m=nm[1], score_sink=s2)
+    for a, b, sp in zip(single, grouped, spars):
+        wa, wb = a.weight.data.float(), b.weight.data.float()
+        assert wa.shape == wb.shape and a.weight.dtype == b.weight.dtype == torch.bfloat16
+        assert float(((wa == 0) != (wb == 0)).float().mean()) < 1e-4                       # the same zero pattern
+        assert float((wa - wb).norm() / wa.norm()) < 1e-3
+        if nm[0]:
+            assert bool(((wb == 0).view(wb.shape[0], -1, 4).sum(-1) >= 2).all())
+        else:
+            assert abs(float((wb == 0).float().mean()) - sp) < 0.01
+    for (_, x1), (_, x2) in zip(s1, s2):
+        assert float((x1 - x2).abs() / x1.abs()) < 1e-6

@@ -76,14 +76,22 @@ class _SparseGPTBlockMixin:
         sparsegpt.factorize_many(list({id(wrapped[n]): (wrapped[n].H, wrapped[n].factor_cache) for n in mine}.values()), percdamp=0.01,
                                  history=self.__dict__.setdefault("_damping_history", {}).setdefault(module_to_process, {}))
         scores = []
-        for name, mod in subset.items():
-            acc = wrapped[name]
-            assert acc.nsamples == n_inps                                          # :442
-            if owner is not None and owner[name] != rank:
+        by_acc = {}
+        for name in mine:
+            assert wrapped[name].nsamples == n_inps                                # :442
+            by_acc.setdefault(id(wrapped[name]), []).append(name)
+        for names in by_acc.values():
+            acc = wrapped[names[0]]
+            keys = [f"{module_to_process}.{i}.{n}.weight" for n in names]
+            same = len({(subset[n].weight.dtype, subset[n].weight.shape[1]) for n in names}) == 1
+            if len(names) > 1 and same and "U" in acc.factor_cache and sparsegpt.stacked_sweeps_enabled():
+                # linears fed the same tensor share the factor: ONE column sweep over their stacked rows
+                sparsegpt.fasterprune_group([subset[n] for n in names], [sparsity_ratio[k] for k in keys], acc.factor_cache,
+                                            prune_n=self.prune_n, prune_m=self.prune_m, blocksize=128, score_sink=scores)
                 continue
-            key = f"{module_to_process}.{i}.{name}.weight"
-            sparsegpt.fasterprune(mod, acc.H, sparsity_ratio[key], prune_n=self.prune_n, prune_m=self.prune_m,
-                                  percdamp=0.01, blocksize=128, factor_cache=acc.factor_cache, score_sink=scores)
+            for name, key in zip(names, keys):
+                sparsegpt.fasterprune(subset[name], acc.H, sparsity_ratio[key], prune_n=self.prune_n, prune_m=self.prune_m,
+                                      percdamp=0.01, blocksize=128, factor_cache=acc.factor_cache, score_sink=scores)
         sparsegpt.flush_scores(scores)                                             # importance scores: one host copy per block
         if owner is not None:
             _exchange_pruned(subset, owner, rank)

@@ -219,10 +219,13 @@ def release_caches():
 _SELECT_THRESHOLD = __import__("os").environ.get("VLMC_SGPT_SORT_THRESHOLD", "0") != "1"
 factor_stats = {"direct": 0, "chain": 0, "damped": 0}     # how often each route produced the inverse factor (damped: k >= 1 failed attempts, one factorization of H + k damp I)
 _DIRECT_FACTOR = __import__("os").environ.get("VLMC_SGPT_DIRECT_FACTOR", "1") == "1"
-_inv_graphs = {}        # (n, device index) -> (graph, A, L, inv, X, U, info)
+_inv_graphs = {}        # (n, device index, slot) -> (graph, A, L, inv, X, U, info, fork stream)
+# the inverse's rows on a second stream inside the graph (off: measured 3.9 s against 3.2 s per prune -- the cross-stream edges of a
+# captured graph cost more than the two products they take off the critical path)
+_INVERSE_FORK = __import__("os").environ.get("VLMC_SGPT_INVERSE_FORK", "0") == "1"
 
 
-def _inverse_factor_steps(A, L, inv, X, U, info):
+def _inverse_factor_steps(A, L, inv, X, U, info, side=None):
     """A = H with rows and columns reversed (consumed).  M = chol(A) (lower), X = M^-1 by block rows
     (X[i, :i] = -inv(M_ii) (M[i, :i] X[:i, :i]), the diagonal-block inverses come from vlmc_chol_block), and
     U = X with rows and columns reversed: upper triangular with U^T U = H^-1."""
@@ -230,10 +233,17 @@ def _inverse_factor_steps(A, L, inv, X, U, info):
     # into L, and block row k of X follows as soon as block row k of M is final (it is: right-looking) -- five graph nodes per
     # 128 columns (the separate factor / inverse passes with their slice copies were ten; a node costs 5-10 us of dispatch
     # on top of its kernel, and the chain is nothing but dependent nodes).
+    # `side`: a second stream for the inverse's block rows.  Row k of the inverse needs inv(M_kk), row k of M (final once
+    # the panels of the earlier steps are written) and the rows of the inverse above it -- nothing of the trailing update,
+    # which is the factorization's critical path: the two products of row k run beside the panel and trailing GEMMs of
+    # steps k, k + 1, .. (forked after the diagonal-block kernel, joined at the end; captured into the graph as such).
     n = A.shape[0]
     lib = _lib.load()
     el = A.element_size()
     X.zero_()
+    main = torch.cuda.current_stream(A.device)
+    if side is not None:
+        side.wait_stream(main)
     for k in range(0, n, _CHOL_NB):
         nb = min(_CHOL_NB, n - k)
         off = (k * n + k) * el
@@ -243,10 +253,18 @@ def _inverse_factor_steps(A, L, inv, X, U, info):
         if k + nb < n:
             L21 = L[k + nb:, k:k + nb]
             torch.mm(A[k + nb:, k:k + nb], ik.t(), out=L21)                 # = A21 inv(M_kk)^T
-            A[k + nb:, k + nb:].addmm_(L21, L21.t(), beta=1.0, alpha=-1.0)
         if k:
             row = X[k:k + nb, :k]
-            torch.addmm(row, ik, torch.mm(L[k:k + nb, :k], X[:k, :k]), beta=0.0, alpha=-1.0, out=row)
+            if side is not None:
+                side.wait_stream(main)                                      # inv(M_kk) and (from step k - 1's panel) row k of M
+                with torch.cuda.stream(side):
+                    torch.addmm(row, ik, torch.mm(L[k:k + nb, :k], X[:k, :k]), beta=0.0, alpha=-1.0, out=row)
+            else:
+                torch.addmm(row, ik, torch.mm(L[k:k + nb, :k], X[:k, :k]), beta=0.0, alpha=-1.0, out=row)
+        if k + nb < n:
+            A[k + nb:, k + nb:].addmm_(L21, L21.t(), beta=1.0, alpha=-1.0)
+    if side is not None:
+        main.wait_stream(side)
     U.copy_(torch.flip(X, (0, 1)))
 
 
@@ -272,24 +290,25 @@ def inverse_upper_factor(H: torch.Tensor, slot: int = 0):
         inv = torch.zeros((nblk, _CHOL_NB, _CHOL_NB), dtype=torch.float32, device=dev)
         info = torch.zeros(1, dtype=torch.int32, device=dev)
         graph = None
+        fork = torch.cuda.Stream(device=dev) if _INVERSE_FORK else None
         if _CHOL_GRAPH and n > _CHOL_NB:
             A.copy_(torch.flip(H, (0, 1)))
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):                      # one eager run before capture (library workspaces)
-                _inverse_factor_steps(A, L, inv, X, U, info)
+                _inverse_factor_steps(A, L, inv, X, U, info, fork)
             torch.cuda.current_stream(dev).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                _inverse_factor_steps(A, L, inv, X, U, info)
-        ent = _inv_graphs[key] = (graph, A, L, inv, X, U, info)
-    graph, A, L, inv, X, U, info = ent
+                _inverse_factor_steps(A, L, inv, X, U, info, fork)
+        ent = _inv_graphs[key] = (graph, A, L, inv, X, U, info, fork)
+    graph, A, L, inv, X, U, info, fork = ent
     A.copy_(torch.flip(H, (0, 1)))
     info.zero_()
     if graph is not None:
         graph.replay()
     else:
-        _inverse_factor_steps(A, L, inv, X, U, info)
+        _inverse_factor_steps(A, L, inv, X, U, info, fork)
     return U.clone(), info.clone()
 
 
@@ -496,6 +515,55 @@ def fasterprune(layer, H: torch.Tensor, sparsity, prune_n=0, prune_m=0, blocksiz
         score_sink.append((layer.weight, score_mean))              # read back by the caller, all linears of a block at once
     layer.weight.data = W.reshape(layer.weight.shape).to(layer.weight.data.dtype)          # :215
     return pruned
+
+
+def stacked_sweeps_enabled():
+    """`VLMC_SGPT_STACK=0`: every linear runs its own column sweep (the reference's loop, one linear at a time)."""
+    return __import__("os").environ.get("VLMC_SGPT_STACK", "1") != "0"
+
+
+@torch.no_grad()
+def fasterprune_group(layers, sparsities, factor_cache, prune_n=0, prune_m=0, blocksize=128, score_sink=None):
+    """`fasterprune` for linears that share ONE factor (q / k / v, wi_0 / wi_1, a cross-attention's k / v: fed the same tensor,
+    hence the same Hessian): their weights are stacked along the rows and swept together -- the column sweep, the
+    compensation of the columns to the right and the trailing update are row-wise (sparsegpt_pruner.py:186-210), so a
+    row gets what its own sweep would give it, while the launches per 128 columns (~11 in unstructured mode) are issued once
+    for the group instead of once per linear.  The per-block threshold stays PER LINEAR (`sort(tmp.flatten())[k]` over the
+    linear's own [rows, 128] block, :183-185): one multi-tensor radix select with a scope per linear.  `factor_cache` must
+    hold the factor (factorize_many)."""
+    U, dead = factor_cache["U"], factor_cache["dead"]
+    rows = [l.weight.shape[0] for l in layers]
+    cols = layers[0].weight.shape[1]
+    W = torch.cat([l.weight.data.float() for l in layers], dim=0)
+    W.masked_fill_(dead.unsqueeze(0), 0.0)                                                 # W[:, dead] = 0 (:101)
+    diag = torch.diag(U)
+    dsq = diag.reshape(1, -1) ** 2
+    bounds = [0]
+    for r in rows:
+        bounds.append(bounds[-1] + r)
+    means = [(W[bounds[i]:bounds[i + 1]] ** 2 / dsq).abs().mean() for i in range(len(layers))]
+    err = torch.empty((W.shape[0], min(blocksize, cols)), dtype=torch.float32, device=W.device)
+    keep = torch.empty((W.shape[0], min(blocksize, cols)), dtype=torch.bool, device=W.device) if prune_n == 0 else None
+    for i1 in range(0, cols, blocksize):
+        i2 = min(i1 + blocksize, cols)
+        mask1 = None
+        if prune_n == 0:
+            tmp = W[:, i1:i2] ** 2 / dsq[:, i1:i2]                                          # :183
+            kb = keep if i2 - i1 == keep.shape[1] else torch.empty((W.shape[0], i2 - i1), dtype=torch.bool, device=W.device)
+            parts = [tmp[bounds[i]:bounds[i + 1]] for i in range(len(layers))]
+            ops.score_select(None, "score", scopes=list(range(len(layers))),
+                             scope_ks=[int(p.numel() * sp) + 1 for p, sp in zip(parts, sparsities)], scores=parts,
+                             apply_weights=False, keeps=[kb[bounds[i]:bounds[i + 1]] for i in range(len(layers))])
+            mask1 = torch.logical_not(kb)
+        sweep_block(W, i1, i2, U, mask1, prune_n, prune_m, err, None)
+        if i2 < cols:
+            W[:, i2:].addmm_(err[:, :i2 - i1], U[i1:i2, i2:], beta=1.0, alpha=-1.0)        # :210
+    for i, layer in enumerate(layers):
+        if score_sink is None:
+            setattr(layer.weight, "importance_score", means[i].item())                     # :165
+        else:
+            score_sink.append((layer.weight, means[i]))
+        layer.weight.data = W[bounds[i]:bounds[i + 1]].reshape(layer.weight.shape).to(layer.weight.data.dtype)   # :215
 
 
 def flush_scores(score_sink):
