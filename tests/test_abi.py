@@ -45,3 +45,17 @@ def test_ops_refuse_cpu_tensors():
         ops.act_sqnorm(torch.zeros(1, 4, 8))
     with pytest.raises(RuntimeError, match="GPU only"):
         ops.wanda_select(torch.zeros(4, 8), torch.zeros(8), "row", k=2)
+
+
+def test_crosscheck_list_turns_into_the_individual_switches():
+    """`VLMC_CROSSCHECK=a,b` is one spelling for the cross-check routes' individual variables; explicit ones win; typos raise."""
+    from vlmc import crosscheck
+    env = {"VLMC_CROSSCHECK": "gemm_staged, select_multi", "VLMC_SELECT_MIXED": "1"}
+    assert crosscheck.apply(env) == ["gemm_staged", "select_multi"]
+    assert env["VLMC_GEMM_RING"] == "0" and env["VLMC_MATRIX_FUSED"] == "0" and env["VLMC_SELECT_MIXED"] == "1"
+    env = {"VLMC_CROSSCHECK": "all"}
+    assert len(crosscheck.apply(env)) == len(crosscheck.ROUTES) and env["VLMC_BATCH_REPLAY"] == "1"
+    assert crosscheck.apply({}) == []
+    import pytest
+    with pytest.raises(ValueError):
+        crosscheck.apply({"VLMC_CROSSCHECK": "gemm_stagd"})

@@ -1,0 +1,51 @@
+"""`VLMC_CROSSCHECK=name[,name...]` -- ONE switch for the alternative code paths that exist to cross-check the default ones.
+
+Every kernel or host route that was replaced by a faster one is still in the library as the check of its successor (the tests
+compare them bit for bit); each has an individual `VLMC_*` variable that the code reads where it decides.  This module turns a
+comma-separated list of NAMES into those variables at import time (before the C library reads its own), so that a user who
+wants "the slow, obviously-correct routes" does not need to know twenty spellings:
+
+    VLMC_CROSSCHECK=all                      every route below
+    VLMC_CROSSCHECK=gemm_staged,select_multi a subset
+
+An individual variable set by the user wins over the list."""
+from __future__ import annotations
+
+import os
+
+ROUTES = {
+    # name: ({variable: value}, what it selects)
+    "gemm_staged": ({"VLMC_GEMM_RING": "0"}, "register-staged GEMM kernel instead of the LDS-DMA rings"),
+    "gemm_lockstep": ({"VLMC_GEMM_PINGPONG": "0"}, "both waves of a SIMD in lockstep (no ping-pong)"),
+    "gemm_half_lines": ({"VLMC_GEMM_WIDE": "0"}, "K-steps of 32 with half-line requests"),
+    "gemm_one_tile_per_workgroup": ({"VLMC_GEMM_PERSIST": "0"}, "no persistent workgroups"),
+    "gemm_plain_schedule": ({"VLMC_GEMM_EDGE": "0"}, "edge tiles scheduled like whole ones"),
+    "linear_single": ({"VLMC_LINEAR_GROUP": "0"}, "every linear its own launch"),
+    "linear_library": ({"VLMC_LINEAR_FWD": "0"}, "the GEMM library for the blocks' linears"),
+    "select_multi": ({"VLMC_MATRIX_FUSED": "0", "VLMC_SELECT_MIXED": "0"}, "multi-launch matrix-wide / per-width row selects"),
+    "dsnot_radix": ({"VLMC_DSNOT_RADIX_ONLY": "1"}, "DSnoT list heads by the exact radix route only"),
+    "dsnot_simulate": ({"VLMC_DSNOT_LISTS": "0"}, "DSnoT by the per-cycle arg-min kernel"),
+    "replay_per_sample": ({"VLMC_BATCH_REPLAY": "1", "VLMC_TOWER_BATCH": "0"}, "the reference's one-sample-per-forward loop"),
+    "replay_eager": ({"VLMC_GRAPH_REPLAY": "0"}, "no HIP graphs anywhere in the replay"),
+    "tail_full": ({"VLMC_SKIP_DEAD_TAIL": "0"}, "statistics pass runs every block to its end"),
+    "compare_at_once": ({"VLMC_LATER_EQUAL": "0"}, "remembered tower inputs compared at once"),
+    "tower_rerun": ({"VLMC_TOWER_MEMO": "0", "VLMC_TOWER_GRAPH": "0"}, "finished towers are run again in every capture phase"),
+    "sgpt_one_by_one": ({"VLMC_SGPT_CONCURRENT": "0", "VLMC_SGPT_STACK": "0"}, "one Hessian / one linear at a time"),
+    "sgpt_library": ({"VLMC_SGPT_SYRK": "0", "VLMC_SGPT_DIRECT_FACTOR": "0", "VLMC_CHOL_GRAPH": "0"}, "library GEMM Hessian, the reference's three-step factor chain"),
+    "sgpt_per_call": ({"VLMC_SGPT_DEFER": "0"}, "one Hessian update per hook call"),
+}
+
+
+def apply(environ=os.environ):
+    """Translate `VLMC_CROSSCHECK` into the individual variables (those already set are left alone).  Returns the names applied."""
+    spec = environ.get("VLMC_CROSSCHECK", "").strip()
+    if not spec:
+        return []
+    names = list(ROUTES) if spec == "all" else [n.strip() for n in spec.split(",") if n.strip()]
+    unknown = [n for n in names if n not in ROUTES]
+    if unknown:
+        raise ValueError(f"VLMC_CROSSCHECK: unknown route(s) {unknown}; known: {', '.join(ROUTES)}")
+    for n in names:
+        for k, v in ROUTES[n][0].items():
+            environ.setdefault(k, v)
+    return names
