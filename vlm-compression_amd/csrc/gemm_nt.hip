@@ -152,10 +152,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, const Panel &pn
         const uint16_t *bias = static_cast<const uint16_t *>(pn.bias);
         const bool vec_ok = (pn.ldy & 7) == 0 && (reinterpret_cast<uintptr_t>(pn.Y) & 15u) == 0;
         float b[TP][4];
+        const bool bias4 = bias != nullptr && (reinterpret_cast<uintptr_t>(bias) & 7u) == 0;      // pl is a multiple of 4: 8-byte loads
 #pragma unroll
-        for (int i = 0; i < TP; ++i)
+        for (int i = 0; i < TP; ++i) {
+            if (bias4 && pl + i * 16 + 3 < pn.NP) {
+                const u32x2_t v = *reinterpret_cast<const u32x2_t *>(bias + pl + i * 16);
+                b[i][0] = to_f32<T>(uint16_t(v[0] & 0xffffu));
+                b[i][1] = to_f32<T>(uint16_t(v[0] >> 16));
+                b[i][2] = to_f32<T>(uint16_t(v[1] & 0xffffu));
+                b[i][3] = to_f32<T>(uint16_t(v[1] >> 16));
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) b[i][r] = (bias != nullptr && pl + i * 16 + r < pn.NP) ? to_f32<T>(bias[pl + i * 16 + r]) : 0.f;
+                for (int r = 0; r < 4; ++r) b[i][r] = (bias != nullptr && pl + i * 16 + r < pn.NP) ? to_f32<T>(bias[pl + i * 16 + r]) : 0.f;
+            }
+        }
         if constexpr (BARRIER) __builtin_amdgcn_s_barrier();              // every wave is done with the operand ring
 #pragma unroll
         for (int pass = 0; pass < TQ * 16 / ROWS; ++pass) {
@@ -179,7 +189,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, const Panel &pn
                 if (q >= a.NQ || p >= pn.NP) continue;
                 uint16_t *dst = pn.Y + int64_t(q) * pn.ldy + p;
                 if (vec_ok && p + 7 < pn.NP) {
+#ifndef VLMC_GEMM_PLAIN_STORES
+                    // streaming stores: Y is written once and read by another kernel; plain stores cost the operand panels
+                    // their place in L2 (vit.qkv 345 -> 330 us, the other prune shapes 1-2 %: profiles/r03_gemm.md)
+                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t *>(dst));
+#else
                     *reinterpret_cast<u32x4_t *>(dst) = v;
+#endif
                 } else {
                     uint16_t e[8];
                     __builtin_memcpy(e, &v, 16);
@@ -807,8 +823,11 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_wide_kernel(const GemmArgs a
 #define VLMC_WIDE_HALF 8             // pieces of a double step issued behind the fragment reads, the rest between the MFMAs (measured: 8 / 6 / 4 / 2 -> vit.fc1 494 / 506 / 513 / 517 us, profiles/r03_gemm.md)
 #endif
     constexpr int HALF = VLMC_WIDE_HALF;                                  // pieces issued in L, the rest in M
-    constexpr int EPI_ROWS = 16;                                          // epilogue scratch: 16 rows x 8 waves = 32 KiB
-    static_assert(EPI != EPI_LINEAR || NW * EPI_ROWS * (TP * 16) * 2 <= Q_BYTES, "the epilogue's scratch is the Q half of the second double slot");
+#ifndef VLMC_WIDE_EPI_ROWS
+#define VLMC_WIDE_EPI_ROWS 32
+#endif
+    constexpr int EPI_ROWS = VLMC_WIDE_EPI_ROWS;                          // epilogue scratch: 32 rows x 8 waves x 256 B = 64 KiB
+    static_assert(EPI != EPI_LINEAR || NW * EPI_ROWS * (TP * 16) * 2 <= SLOT, "the epilogue's scratch is the second double slot");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * SLOT];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1021,15 +1040,15 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_wide_kernel(const GemmArgs a
                 for (int v = 0; v < PER_WAVE; ++v) issue_piece(0, v);
             }
         }
-        // (the linear epilogue's scratch is the Q half of the SECOND double slot: the next tile's double step 1 goes there in
-        // its L(0) / M(0), behind a barrier that every wave reaches after its own epilogue; double step 0, above, does not)
+        // (the linear epilogue's scratch is the SECOND double slot: the next tile's double step 1 goes there in its L(0),
+        // behind a barrier that every wave reaches after its own epilogue; double step 0, above, does not)
         if (VLMC_GEMM_DBG & 8) {
 #pragma unroll
             for (int i = 0; i < TP; ++i)
 #pragma unroll
                 for (int j = 0; j < TQ; ++j) asm volatile("" ::"v"(acc[i][j]));
         } else if (cactive) {
-            gemm_epilogue<T, EPI, S, EPI_ROWS, false>(a, cpn, acc, cq0, wp, wq, lane, lds + SLOT + P_BYTES, wave);
+            gemm_epilogue<T, EPI, S, EPI_ROWS, false>(a, cpn, acc, cq0, wp, wq, lane, lds + SLOT + (EPI_ROWS == 16 ? P_BYTES : 0), wave);
         }
         if (!has_next) break;
     }
