@@ -28,7 +28,15 @@ __device__ __forceinline__ void grid_barrier(uint32_t *ctr, uint32_t n) {
     __syncthreads();
 }
 
-template <int B, int FLUSH>
+__global__ void fill(uint32_t *p, size_t n) {                   // spread bit patterns: the LDS histogram must not see one bin only
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        uint32_t h = uint32_t(i) * 2654435761u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = h;
+    }
+}
+
+template <int B, int FLUSH, int COPIES = 1, int STAGGER = 0, int NATOM = 1024>
 __global__ __launch_bounds__(1024, 1) void resident(const u32x4 *__restrict__ in, u32x4 *__restrict__ out, u32x2 *__restrict__ mask,
                                                     size_t chunks, uint32_t *ctl, unsigned long long *hist) {
     __shared__ uint32_t lh[2048];
@@ -50,13 +58,14 @@ __global__ __launch_bounds__(1024, 1) void resident(const u32x4 *__restrict__ in
     }
     if (FLUSH) {
         __syncthreads();
-        const int i = threadIdx.x;                               // two bins per 64-bit atomic
+        const int i = STAGGER ? (threadIdx.x + blockIdx.x * 61) & 1023 : threadIdx.x;      // two bins per 64-bit atomic
         const unsigned long long two = (unsigned long long)lh[2 * i] | ((unsigned long long)lh[2 * i + 1] << 32);
-        if (two) atomicAdd(hist + i, two);
+        if (two && threadIdx.x < NATOM) atomicAdd(hist + (blockIdx.x % COPIES) * 1024 + i, two);
     }
     if (B >= 1) grid_barrier(ctl + 0, gridDim.x);
     uint32_t thr = acc;
-    if (B >= 1 && FLUSH) thr += uint32_t(__hip_atomic_load(hist + (threadIdx.x & 1023), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (B >= 1 && FLUSH)
+        for (int c = 0; c < COPIES; ++c) thr += uint32_t(__hip_atomic_load(hist + c * 1024 + (threadIdx.x & 1023), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (B >= 2) {
         if (threadIdx.x < 64) __hip_atomic_store(ctl + 64 + blockIdx.x * 64 + threadIdx.x, thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         grid_barrier(ctl + 1, gridDim.x);
@@ -76,7 +85,7 @@ __global__ __launch_bounds__(1024, 1) void resident(const u32x4 *__restrict__ in
     }
 }
 
-template <int B, int FLUSH>
+template <int B, int FLUSH, int COPIES = 1, int STAGGER = 0, int NATOM = 1024>
 static void run(const char *name, u32x4 **in, u32x4 **out, u32x2 **mask, size_t chunks, uint32_t *ctl, unsigned long long *hist, int sets) {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
@@ -84,9 +93,9 @@ static void run(const char *name, u32x4 **in, u32x4 **out, u32x2 **mask, size_t 
     for (int r = 0; r < 28; ++r) {
         const int i = r % sets;
         hipMemsetAsync(ctl, 0, 4 * (64 + 256 * 64));
-        hipMemsetAsync(hist, 0, 8 * 1024);
+        hipMemsetAsync(hist, 0, 8 * 1024 * 32);
         hipEventRecord(a);
-        resident<B, FLUSH><<<256, 1024>>>(in[i], out[i], mask[i], chunks, ctl, hist);
+        resident<B, FLUSH, COPIES, STAGGER, NATOM><<<256, 1024>>>(in[i], out[i], mask[i], chunks, ctl, hist);
         hipEventRecord(b);
         hipEventSynchronize(b);
         float ms;
@@ -107,16 +116,25 @@ int main() {
     u32x2 *mask[sets];
     for (int i = 0; i < sets; ++i) {
         hipMalloc(&in[i], chunks * 16); hipMalloc(&out[i], chunks * 16); hipMalloc(&mask[i], chunks * 8);
-        hipMemset(in[i], 0x3c, chunks * 16);
+        fill<<<1024, 256>>>(reinterpret_cast<uint32_t *>(in[i]), chunks * 4);
     }
     uint32_t *ctl;
     unsigned long long *hist;
     hipMalloc(&ctl, 4 * (64 + 256 * 64));
-    hipMalloc(&hist, 8 * 1024);
+    hipMalloc(&hist, 8 * 1024 * 32);
     printf("chunks per lane: %.2f of %d\n", double(chunks) / (256.0 * 1024.0), R);
     run<0, 0>("load -> store", in, out, mask, chunks, ctl, hist, sets);
     run<1, 0>("load -> barrier -> store", in, out, mask, chunks, ctl, hist, sets);
     run<1, 1>("load -> flush + barrier -> store", in, out, mask, chunks, ctl, hist, sets);
+    run<1, 1, 1, 1>("  same, staggered bins", in, out, mask, chunks, ctl, hist, sets);
+    run<1, 1, 4, 0>("  same, 4 histogram copies", in, out, mask, chunks, ctl, hist, sets);
+    run<1, 1, 8, 0>("  same, 8 histogram copies", in, out, mask, chunks, ctl, hist, sets);
+    run<1, 1, 8, 1>("  same, 8 copies, staggered", in, out, mask, chunks, ctl, hist, sets);
+    run<1, 1, 32, 1>("  same, 32 copies, staggered", in, out, mask, chunks, ctl, hist, sets);
+    run<1, 1, 1, 0, 512>("  same, 512 atomics / workgroup", in, out, mask, chunks, ctl, hist, sets);
+    run<1, 1, 1, 0, 128>("  same, 128 atomics / workgroup", in, out, mask, chunks, ctl, hist, sets);
+    run<1, 1, 1, 0, 16>("  same, 16 atomics / workgroup", in, out, mask, chunks, ctl, hist, sets);
+    run<1, 1, 1, 0, 0>("  same, LDS histogram only", in, out, mask, chunks, ctl, hist, sets);
     run<2, 0>("load -> 2 barriers -> store", in, out, mask, chunks, ctl, hist, sets);
     run<2, 1>("load -> flush + 2 barriers -> store", in, out, mask, chunks, ctl, hist, sets);
     return 0;
