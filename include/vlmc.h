@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLMC_ABI_VERSION 4
+#define VLMC_ABI_VERSION 5
 
 #define VLMC_OK 0
 #define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
@@ -246,6 +246,21 @@ int vlmc_chol_block(const float *A, int64_t lda, int nb, float *L, int64_t ldl, 
 int vlmc_sparsegpt_sweep(float *W, int64_t out_features, int64_t count, int64_t ldw, const float *U1, int64_t ldu,
                          const uint8_t *mask1, int64_t ldm, int prune_n, int prune_m, float *Err1, int64_t lde,
                          uint8_t *mask_out, int64_t ldmo, void *stream);
+
+/* vlmc_sparsegpt_select_sweep: unstructured mode, the block's threshold AND its sweep in one launch
+ * (sparsegpt_pruner.py:183-205):
+ *     tmp = W1 ** 2 / diag(Hinv1) ** 2;  thresh = sort(tmp.flatten())[rank];  mask1 = tmp <= thresh;  then the sweep above.
+ * The rows of W are n_scopes (<= 4) stacked linears that share the factor (q / k / v, wi_0 / wi_1): scope s owns the next
+ * scope_rows[s] rows and has its own 0-based scope_ranks[s] = int(tmp.numel() * sparsity) over ITS
+ * scope_rows[s] x count scores (NaN scores sort last; a NaN threshold prunes nothing).  scope_rows / scope_ranks are HOST
+ * arrays.  `workspace`: vlmc_sparsegpt_select_workspace_bytes() bytes of device memory, ZERO when first handed over; every
+ * call returns it zero.  The workgroups of the launch meet at grid barriers, so at most 2 x CUs workgroups of 4 x {1,2,4,8}
+ * rows are launched (about 16384 rows on an MI355X; VLMC_EINVAL beyond); if they cannot all be resident (CUs held by another
+ * stream) the bounded wait fails for all of them and the last one to finish does the block alone -- same result.        */
+int64_t vlmc_sparsegpt_select_workspace_bytes(void);
+int vlmc_sparsegpt_select_sweep(float *W, int64_t count, int64_t ldw, const float *U1, int64_t ldu, int n_scopes,
+                                const int64_t *scope_rows, const int64_t *scope_ranks, float *Err1, int64_t lde,
+                                uint8_t *mask_out, int64_t ldmo, void *workspace, void *stream);
 
 /* ---- K11-K13: DSnoT --------------------------------------------------------------------
  * vlmc_act_moments: per hook call and channel (layout as vlmc_act_sqnorm) the squared norm, the

@@ -269,3 +269,92 @@ def test_linears_sharing_a_factor_swept_together_equal_their_own_sweeps(nm):
             assert abs(float((wb == 0).float().mean()) - sp) < 0.01
     for (_, x1), (_, x2) in zip(s1, s2):
         assert float((x1 - x2).abs() / x1.abs()) < 1e-6
+
+
+def _select_sweep_case(rows_per_scope, count, spars, seed, ties=False, nans=False):
+    from vlmc import sparsegpt as SG
+    g = torch.Generator().manual_seed(seed)
+    rows = sum(rows_per_scope)
+    W1 = torch.randn(rows, count, generator=g) * 0.05
+    if ties:                                                     # a few distinct magnitudes: the threshold sits in a flood of ties
+        W1 = (W1 * 40).round() / 40
+    W1[torch.rand(rows, count, generator=g) < 0.1] = 0
+    if nans:
+        W1[1, 3] = float("nan")
+        W1[rows - 1, count - 1] = float("inf")
+    A = torch.randn(count, count * 2, generator=g)
+    U = torch.linalg.cholesky(A @ A.t() / count + 0.1 * torch.eye(count), upper=True)
+    Wd = torch.zeros(rows, count + 9, device=DEV)
+    Wd[:, 5:5 + count] = W1.to(DEV)
+    Ud = torch.zeros(count + 5, count + 5, device=DEV)
+    Ud[2:2 + count, 2:2 + count] = U.to(DEV)
+    # the route it replaces: scores and library sort on the GPU (bit-identical scores), the sweep kernel with the mask handed in
+    Wref = Wd.clone()
+    d = torch.diag(Ud[2:2 + count, 2:2 + count])
+    masks, ranks, r0 = [], [], 0
+    for r, sp in zip(rows_per_scope, spars):
+        tmp = Wref[r0:r0 + r, 5:5 + count] ** 2 / d.reshape(1, -1) ** 2
+        rank = min(int(tmp.numel() * sp), tmp.numel() - 1)
+        thresh = torch.sort(tmp.flatten())[0][rank]
+        masks.append(tmp <= thresh)
+        ranks.append(rank)
+        r0 += r
+    mask1 = torch.cat(masks, 0).contiguous()
+    err_ref = torch.empty(rows, count, device=DEV)
+    mref = torch.zeros(rows, count + 9, dtype=torch.bool, device=DEV)
+    SG.sweep_block(Wref[:, 5:], 0, count, Ud[2:, 2:], mask1, 0, 0, err_ref, mref[:, 5:])
+    return SG, Wd, Ud, ranks, Wref, err_ref, mref
+
+
+@pytest.mark.parametrize("rows_per_scope,count,spars", [
+    ((8,), 128, (0.5,)), ((37,), 96, (0.3,)), ((2052,), 128, (0.5,)), ((2051, 33), 128, (0.5, 0.5)), ((6144,), 128, (0.5,)),
+    ((1408, 1408, 1408), 128, (0.5, 0.5, 0.5)), ((384, 256, 640), 128, (0.5, 0.5, 0.3)), ((5120, 5120), 128, (0.5, 0.4)),
+    ((4, 4, 4, 4), 40, (0.0, 0.5, 0.99, 1.0))])
+@pytest.mark.parametrize("kind", ["random", "ties", "nan"])
+def test_select_sweep_one_launch_equals_threshold_then_sweep(rows_per_scope, count, spars, kind):
+    """`vlmc_sparsegpt_select_sweep` (threshold of sparsegpt_pruner.py:183-185 per stacked linear + the sweep of :186-205 in
+    one launch of co-resident workgroups) against the route it replaces: scores, `torch.sort`, `tmp <= thresh`, then
+    `vlmc_sparsegpt_sweep` with that mask.  Weights, errors and masks bit for bit; the workspace comes back zero."""
+    SG, Wd, Ud, ranks, Wref, err_ref, mref = _select_sweep_case(rows_per_scope, count, spars, seed=count + sum(rows_per_scope),
+                                                                 ties=kind == "ties", nans=kind == "nan")
+    rows = sum(rows_per_scope)
+    err = torch.empty(rows, count, device=DEV)
+    mout = torch.zeros(rows, count + 9, dtype=torch.bool, device=DEV)
+    SG.select_sweep_block(Wd[:, 5:], 0, count, Ud[2:, 2:], list(rows_per_scope), ranks, err, mout[:, 5:])
+    torch.cuda.synchronize()
+    assert torch.equal(mout, mref)
+    assert torch.equal(Wd.view(torch.int32), Wref.view(torch.int32))
+    assert torch.equal(err.view(torch.int32), err_ref.view(torch.int32))
+    assert int(SG._select_ws[torch.device(DEV).index].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_select_sweep_failed_grid_barrier_is_finished_by_the_last_workgroup(level, monkeypatch):
+    """A grid barrier that fails (workgroups not all resident: CUs held by another stream) fails for every workgroup, nothing
+    has been written, and the launch's last workgroup does thresholds and sweeps alone: same bits, workspace zero again."""
+    monkeypatch.setenv("VLMC_SGPT_SELECT_FORCE_FAIL", str(level))
+    SG, Wd, Ud, ranks, Wref, err_ref, mref = _select_sweep_case((384, 256, 640), 128, (0.5, 0.5, 0.3), seed=level, ties=level == 2)
+    err = torch.empty(1280, 128, device=DEV)
+    mout = torch.zeros(1280, 128 + 9, dtype=torch.bool, device=DEV)
+    SG.select_sweep_block(Wd[:, 5:], 0, 128, Ud[2:, 2:], [384, 256, 640], ranks, err, mout[:, 5:])
+    torch.cuda.synchronize()
+    assert torch.equal(mout, mref)
+    assert torch.equal(Wd.view(torch.int32), Wref.view(torch.int32))
+    assert torch.equal(err.view(torch.int32), err_ref.view(torch.int32))
+    assert int(SG._select_ws[torch.device(DEV).index].abs().sum()) == 0
+    monkeypatch.delenv("VLMC_SGPT_SELECT_FORCE_FAIL")
+    SG2, Wd2, Ud2, ranks2, Wref2, err_ref2, mref2 = _select_sweep_case((384, 256, 640), 128, (0.5, 0.5, 0.3), seed=level)
+    SG.select_sweep_block(Wd2[:, 5:], 0, 128, Ud2[2:, 2:], [384, 256, 640], ranks2, err, None)        # the next call finds it usable
+    assert torch.equal(Wd2.view(torch.int32), Wref2.view(torch.int32))
+
+
+def test_select_sweep_rejects_what_it_cannot_hold():
+    from vlmc import _lib, sparsegpt as SG
+    W = torch.zeros(20000, 128, device=DEV)
+    U = torch.eye(128, device=DEV)
+    err = torch.empty(20000, 128, device=DEV)
+    assert not SG.select_sweep_usable([20000]) and not SG.select_sweep_usable([4] * 5) and SG.select_sweep_usable([6])
+    with pytest.raises(_lib.VlmcError):
+        SG.select_sweep_block(W, 0, 128, U, [20000], [5], err)
+    with pytest.raises(_lib.VlmcError):
+        SG.select_sweep_block(W[:6], 0, 128, U, [6], [6 * 128], err[:6])                  # a rank outside the scope

@@ -11,6 +11,8 @@
 // (<= 128x128 fp32 = 64 KB) sits in LDS.  Every operation is an elementwise IEEE fp32 op in the
 // reference's order (no fma: -ffp-contract=off), so given the same factor the sweep is bit-exact.
 // The trailing update W[:, i2:] -= Err @ U[i1:i2, i2:] stays a library GEMM.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace vlmc {
@@ -178,6 +180,297 @@ __global__ __launch_bounds__(256) void sparsegpt_sweep_kernel(float *__restrict_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Unstructured mode in ONE launch: the block threshold (sparsegpt_pruner.py:183-185) AND the column sweep.
+//     tmp = W1^2 / diag(Hinv1)^2;  thresh = sort(tmp.flatten())[int(tmp.numel() * sparsity)];  mask1 = tmp <= thresh
+// used to be ~9 launches per 128 columns (pow, divide, the multi-tensor radix select's passes, logical_not) in front of
+// the sweep -- 0.5 s of host time per SparseGPT prune of FlanT5-XL.  Here the rows a wave sweeps are the rows whose scores
+// it ranks: lanes are columns, a wave holds R rows, the keys of its 2 R scores per lane stay in registers, and the
+// workgroups of the launch agree on the threshold key in three radix levels (11 / 11 / 10 key bits; per level: LDS
+// histogram -> device-scope atomics into the scope's global histogram -> grid barrier -> every workgroup scans the merged
+// bins itself).  Several linears that share a factor are stacked along the rows (vlmc/sparsegpt.py: fasterprune_group);
+// each is a SCOPE with its own rank.  Grid barriers as in wanda_select.hip (matrix_fused_kernel): arrival counters,
+// device-scope atomics only, a bounded wait whose failure is all-or-none -- then nothing has been written, and the last
+// workgroup to finish (done counter) does the whole block alone (thresholds by a streaming radix select, then every row
+// group).  The workspace (kSelWsWords words) must be zero on entry and is returned zero.
+// ------------------------------------------------------------------------------------------
+#ifndef VLMC_SEL_DBG
+#define VLMC_SEL_DBG 0
+#endif
+constexpr int kSelScopes = 4, kSelBins = 2048, kSelLevels = 3;
+constexpr int kSelHistWords = kSelScopes * kSelLevels * kSelBins;
+constexpr int kSelCtl = kSelHistWords;            // [0..2] the levels' barriers, [3] done counter
+constexpr int kSelWsWords = kSelHistWords + 16;
+constexpr uint32_t kSelBarFail = 0x80000000u;
+constexpr uint32_t kSelSpinMax = 1u << 12;        // x (device-scope load + s_sleep, ~2.2 us) ~ 9 ms
+
+struct SelScopes {
+    int n;
+    int wg0[kSelScopes + 1];                      // workgroups [wg0[s], wg0[s + 1]) own the rows of scope s
+    int row0[kSelScopes + 1];                     // rows [row0[s], row0[s + 1])
+    uint32_t rank[kSelScopes];                    // 0-based rank of the threshold among the scope's rows x count scores
+};
+
+__device__ __forceinline__ uint32_t sel_ld_dev(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// tid 0: arrive and wait for n arrivals; false = the barrier failed (for every workgroup or for none, see wanda_select.hip)
+__device__ __forceinline__ bool sel_arrive_wait(uint32_t *ctr, uint32_t n) {
+    uint32_t v = atomicAdd(ctr, 1u) + 1u;
+    for (uint32_t it = 0;; ++it) {
+        if (v & kSelBarFail) return false;
+        if (v >= n) return true;
+        if (it >= kSelSpinMax) {
+            const uint32_t seen = atomicCAS(ctr, v, v | kSelBarFail);
+            if (seen == v) return false;
+            v = seen;
+            continue;
+        }
+        __builtin_amdgcn_s_sleep(8);
+        v = sel_ld_dev(ctr);
+    }
+}
+
+__device__ __forceinline__ uint32_t sel_wave_incl_scan(uint32_t v) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = uint32_t(__shfl_up(int(v), off, 64));
+        if (int(threadIdx.x & 63) >= off) v += o;
+    }
+    return v;
+}
+
+// 256 threads, PER bins each (thread t holds bins t * PER ..): the bin with cum <= need < cum + h, and cum.
+template <int PER>
+__device__ __forceinline__ void sel_find_rank(const uint32_t (&h)[PER], uint32_t need, uint32_t *red, uint32_t &bin, uint32_t &before) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) s += h[i];
+    const uint32_t incl = sel_wave_incl_scan(s);
+    if (lane == 63) red[wave] = incl;
+    if (tid == 0) { red[8] = 0xFFFFFFFFu; red[9] = 0; }
+    __syncthreads();
+    uint32_t off = 0;
+    for (int w = 0; w < wave; ++w) off += red[w];
+    const uint32_t hi = off + incl, lo = hi - s;
+    if (lo <= need && need < hi) {
+        uint32_t cum = lo;
+        int i = 0;
+        for (; i < PER - 1; ++i) {
+            if (cum + h[i] > need) break;
+            cum += h[i];
+        }
+        red[8] = uint32_t(tid * PER + i);
+        red[9] = cum;
+    }
+    __syncthreads();
+    bin = red[8];
+    before = red[9];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void stage_factor_block(float *sU, const float *__restrict__ U1, int64_t ldu, int count) {
+    const int tid = threadIdx.x;
+    for (int e0 = tid; e0 < count * kSgBlock; e0 += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int e = e0 + b * 256, i = e / kSgBlock, j = e % kSgBlock;
+            v[b] = (e < count * kSgBlock && j < count) ? U1[int64_t(i) * ldu + j] : 0.f;
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int e = e0 + b * 256;
+            if (e < count * kSgBlock) sU[e] = v[b];
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t sel_score_key(float w, float dsq) { return score_key(ieee_div(ieee_mul(w, w), dsq)); }   // (:183)
+
+// the rows [r0, r0 + R) of one wave: mask from the threshold key, column sweep, stores
+template <int R>
+__device__ __forceinline__ void select_sweep_rows(float *__restrict__ W, int64_t r0, int64_t row_end, int count, int64_t ldw,
+                                                  const float *sU, uint32_t thrkey, float *__restrict__ Err1, int64_t lde,
+                                                  uint8_t *__restrict__ mask_out, int64_t ldmo) {
+    const int lane = threadIdx.x & 63;
+    const bool c0 = lane < count, c1 = lane + 64 < count;
+    const float d0 = c0 ? sU[lane * kSgBlock + lane] : 1.f, d1 = c1 ? sU[(lane + 64) * kSgBlock + lane + 64] : 1.f;
+    const float q0 = ieee_mul(d0, d0), q1 = ieee_mul(d1, d1);
+    const bool any = thrkey != 0xFFFFFFFFu;                      // a NaN threshold: `tmp <= thresh` holds nowhere
+    float w0[R], w1[R], e0[R], e1[R];
+    int m0[R], m1[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = r0 + r;
+        const bool live = row < row_end;
+        w0[r] = (live && c0) ? W[row * ldw + lane] : 0.f;
+        w1[r] = (live && c1) ? W[row * ldw + lane + 64] : 0.f;
+        m0[r] = (live && c0 && any && sel_score_key(w0[r], q0) <= thrkey) ? 1 : 0;
+        m1[r] = (live && c1 && any && sel_score_key(w1[r], q1) <= thrkey) ? 1 : 0;
+        e0[r] = e1[r] = 0.f;
+    }
+    float h0n = sU[lane], h1n = sU[lane + 64], dn = sU[0];
+    const int half = count < 64 ? count : 64;
+    for (int i = 0; i < half; ++i) {
+        const float h0 = h0n, h1 = h1n, d = dn;
+        if (i + 1 < count) {
+            h0n = sU[(i + 1) * kSgBlock + lane];
+            h1n = sU[(i + 1) * kSgBlock + lane + 64];
+            dn = sU[(i + 1) * kSgBlock + i + 1];
+        }
+        sweep_step<R, false>(i, lane, h0, h1, d, w0, w1, e0, e1, m0, m1);
+    }
+    for (int i = 64; i < count; ++i) {
+        const float h1 = h1n, d = dn;
+        if (i + 1 < count) {
+            h1n = sU[(i + 1) * kSgBlock + lane + 64];
+            dn = sU[(i + 1) * kSgBlock + i + 1];
+        }
+        sweep_step<R, true>(i, lane, 0.f, h1, d, w0, w1, e0, e1, m0, m1);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = r0 + r;
+        if (row >= row_end) continue;
+        if (c0) {
+            W[row * ldw + lane] = w0[r];
+            Err1[row * lde + lane] = e0[r];
+            if (mask_out) mask_out[row * ldmo + lane] = uint8_t(m0[r]);
+        }
+        if (c1) {
+            W[row * ldw + lane + 64] = w1[r];
+            Err1[row * lde + lane + 64] = e1[r];
+            if (mask_out) mask_out[row * ldmo + lane + 64] = uint8_t(m1[r]);
+        }
+    }
+}
+
+// the threshold key of one scope by ONE workgroup, streaming over W (the failed launch's last workgroup)
+__device__ uint32_t sel_scope_threshold_alone(const float *__restrict__ W, int64_t row_a, int64_t row_b, int count, int64_t ldw,
+                                              const float *sU, uint32_t need, uint32_t *lh, uint32_t *red) {
+    const int tid = threadIdx.x;
+    const int64_t total = (row_b - row_a) * count;
+    uint32_t prefix = 0, pmask = 0;
+    for (int sh = 24; sh >= 0; sh -= 8) {
+        lh[tid] = 0;
+        __syncthreads();
+        for (int64_t e = tid; e < total; e += 256) {
+            const int64_t row = row_a + e / count;
+            const int col = int(e % count);
+            const float d = sU[col * kSgBlock + col];
+            const uint32_t key = sel_score_key(W[row * ldw + col], ieee_mul(d, d));
+            if ((key & pmask) == prefix) atomicAdd(&lh[(key >> sh) & 255u], 1u);
+        }
+        __syncthreads();
+        uint32_t h[1] = {lh[tid]};
+        uint32_t bin, before;
+        sel_find_rank<1>(h, need, red, bin, before);
+        prefix |= bin << sh;
+        pmask |= 0xFFu << sh;
+        need -= before;
+    }
+    return prefix;
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void sgpt_select_sweep_kernel(float *__restrict__ W, int count, int64_t ldw,
+                                                                const float *__restrict__ U1, int64_t ldu, const SelScopes sc,
+                                                                float *__restrict__ Err1, int64_t lde, uint8_t *__restrict__ mask_out,
+                                                                int64_t ldmo, uint32_t *__restrict__ ws, int force_fail) {
+    extern __shared__ __attribute__((aligned(16))) float sU[];   // [count][kSgBlock]
+    __shared__ uint32_t lh[kSelBins];
+    __shared__ uint32_t red[16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    stage_factor_block(sU, U1, ldu, count);
+    __syncthreads();
+    int s = 0;
+    while (s + 1 < sc.n && int(blockIdx.x) >= sc.wg0[s + 1]) ++s;
+    const int64_t row_end = sc.row0[s + 1];
+    const int64_t r0 = sc.row0[s] + (int64_t(int(blockIdx.x) - sc.wg0[s]) * 4 + wave) * R;
+    const bool c0 = lane < count, c1 = lane + 64 < count;
+    // ---- the keys of my rows' scores ------------------------------------------------------------------------------
+    uint32_t k0[R], k1[R];
+    uint32_t valid = 0;                                          // bit 2 r: (row r, lane), bit 2 r + 1: (row r, lane + 64)
+    {
+        const float d0 = c0 ? sU[lane * kSgBlock + lane] : 1.f, d1 = c1 ? sU[(lane + 64) * kSgBlock + lane + 64] : 1.f;
+        const float q0 = ieee_mul(d0, d0), q1 = ieee_mul(d1, d1);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = r0 + r;
+            const bool live = row < row_end;
+            k0[r] = k1[r] = 0;
+            if (live && c0) { k0[r] = sel_score_key(W[row * ldw + lane], q0); valid |= 1u << (2 * r); }
+            if (live && c1) { k1[r] = sel_score_key(W[row * ldw + lane + 64], q1); valid |= 2u << (2 * r); }
+        }
+    }
+    // ---- three radix levels ------------------------------------------------------------------------------------------
+    uint32_t prefix = 0, pmask = 0, need = sc.rank[s];
+    bool fail = false;
+#pragma unroll 1
+    for (int lvl = 0; lvl < kSelLevels; ++lvl) {
+        const int shift = lvl == 0 ? 21 : (lvl == 1 ? 10 : 0);
+        const uint32_t bmask = lvl == 2 ? 1023u : 2047u;
+        for (int i = tid; i < kSelBins; i += 256) lh[i] = 0;
+        __syncthreads();
+#if !(VLMC_SEL_DBG & 1)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (((valid >> (2 * r)) & 1u) && (k0[r] & pmask) == prefix) atomicAdd(&lh[(k0[r] >> shift) & bmask], 1u);
+            if (((valid >> (2 * r + 1)) & 1u) && (k1[r] & pmask) == prefix) atomicAdd(&lh[(k1[r] >> shift) & bmask], 1u);
+        }
+#endif
+        __syncthreads();
+        uint32_t *gh = ws + (s * kSelLevels + lvl) * kSelBins;
+#if !(VLMC_SEL_DBG & 2)
+        for (int i = tid; i < kSelBins; i += 256) {
+            const uint32_t v = lh[i];
+            if (v) atomicAdd(&gh[i], v);
+        }
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my atomics have been performed
+        __syncthreads();
+#if !(VLMC_SEL_DBG & 4)
+        if (tid == 0) red[10] = sel_arrive_wait(ws + kSelCtl + lvl, gridDim.x) ? 1u : 0u;
+#else
+        if (tid == 0) red[10] = 1;
+#endif
+        __syncthreads();
+        fail = red[10] == 0 || force_fail == lvl + 1;            // (test hook: every workgroup sees the same value)
+        if (fail) break;
+        uint32_t h[8];
+#pragma unroll
+#if !(VLMC_SEL_DBG & 8)
+        for (int i = 0; i < 8; ++i) h[i] = sel_ld_dev(&gh[tid * 8 + i]);
+#else
+        for (int i = 0; i < 8; ++i) h[i] = lh[tid * 8 + i] + (tid == 0 && i == 0 ? 0x7FFFFFFFu : 0u);
+#endif
+        uint32_t bin, before;
+        sel_find_rank<8>(h, need, red, bin, before);
+        prefix |= bin << shift;
+        pmask |= bmask << shift;
+        need -= before;
+    }
+    // my last look at the workspace is behind me
+    if (tid == 0) red[11] = atomicAdd(&ws[kSelCtl + 3], 1u);
+    if (!fail) select_sweep_rows<R>(W, r0, row_end, count, ldw, sU, prefix, Err1, lde, mask_out, ldmo);
+    __syncthreads();
+    if (red[11] != gridDim.x - 1) return;
+    // ---- the launch's last workgroup: a failed launch is done here, alone; then the workspace goes back to zero ----
+    if (fail) {
+        for (int q = 0; q < sc.n; ++q) {
+            const uint32_t thr = sel_scope_threshold_alone(W, sc.row0[q], sc.row0[q + 1], count, ldw, sU, sc.rank[q], lh, red);
+            for (int64_t g0 = sc.row0[q] + int64_t(wave) * R; g0 < sc.row0[q + 1]; g0 += 4 * R)
+                select_sweep_rows<R>(W, g0, sc.row0[q + 1], count, ldw, sU, thr, Err1, lde, mask_out, ldmo);
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < kSelWsWords; i += 256) __hip_atomic_store(&ws[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace vlmc
 
 using namespace vlmc;
@@ -237,5 +530,83 @@ extern "C" int vlmc_sparsegpt_sweep(float *W, int64_t out_features, int64_t coun
 #undef VLMC_SWEEP_ROWS
 #undef VLMC_SWEEP
     VLMC_HIP_CHECK_LAUNCH("vlmc_sparsegpt_sweep");
+    return VLMC_OK;
+}
+
+extern "C" int64_t vlmc_sparsegpt_select_workspace_bytes(void) { return int64_t(kSelWsWords) * 4; }
+
+extern "C" int vlmc_sparsegpt_select_sweep(float *W, int64_t count, int64_t ldw, const float *U1, int64_t ldu, int n_scopes,
+                                           const int64_t *scope_rows, const int64_t *scope_ranks, float *Err1, int64_t lde,
+                                           uint8_t *mask_out, int64_t ldmo, void *workspace, void *stream) {
+    VLMC_REQUIRE(W && U1 && Err1 && workspace && scope_rows && scope_ranks, "vlmc_sparsegpt_select_sweep: null pointer");
+    VLMC_REQUIRE(count > 0 && count <= kSgBlock && ldw >= count && ldu >= count && lde >= count,
+                 "vlmc_sparsegpt_select_sweep: bad shape count=%lld (max %d columns per block)", (long long)count, kSgBlock);
+    VLMC_REQUIRE(n_scopes >= 1 && n_scopes <= kSelScopes, "vlmc_sparsegpt_select_sweep: 1..%d scopes, got %d", kSelScopes, n_scopes);
+    int64_t total = 0;
+    for (int q = 0; q < n_scopes; ++q) {
+        VLMC_REQUIRE(scope_rows[q] > 0 && scope_rows[q] * count < (int64_t(1) << 31),
+                     "vlmc_sparsegpt_select_sweep: scope %d has %lld rows", q, (long long)scope_rows[q]);
+        VLMC_REQUIRE(scope_ranks[q] >= 0 && scope_ranks[q] < scope_rows[q] * count,
+                     "vlmc_sparsegpt_select_sweep: rank %lld outside scope %d", (long long)scope_ranks[q], q);
+        total += scope_rows[q];
+    }
+    // every workgroup of the launch must be resident at once (grid barriers): two workgroups per CU (72 KB of LDS each)
+    int dev = 0;
+    static int cus[64] = {0};
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev < 64 && cus[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 64;
+        cus[dev] = v;
+    }
+    const int64_t max_wgs = 2 * int64_t(dev < 64 ? cus[dev] : 64);
+    int rows = 0;
+    for (int r : {1, 2, 4, 8}) {
+        int64_t wgs = 0;
+        for (int q = 0; q < n_scopes; ++q) wgs += (scope_rows[q] + 4 * r - 1) / (4 * r);
+        if (wgs <= max_wgs) { rows = r; break; }
+    }
+    VLMC_REQUIRE(rows != 0, "vlmc_sparsegpt_select_sweep: %lld rows do not fit %lld co-resident workgroups of 4 x {1,2,4,8} rows",
+                 (long long)total, (long long)max_wgs);
+    SelScopes sc;
+    sc.n = n_scopes;
+    sc.wg0[0] = 0;
+    sc.row0[0] = 0;
+    for (int q = 0; q < n_scopes; ++q) {
+        sc.wg0[q + 1] = sc.wg0[q] + int((scope_rows[q] + 4 * rows - 1) / (4 * rows));
+        sc.row0[q + 1] = sc.row0[q] + int(scope_rows[q]);
+        sc.rank[q] = uint32_t(scope_ranks[q]);
+    }
+    for (int q = n_scopes; q < kSelScopes; ++q) { sc.wg0[q + 1] = sc.wg0[q]; sc.row0[q + 1] = sc.row0[q]; sc.rank[q] = 0; }
+    const size_t lds = size_t(count) * kSgBlock * sizeof(float);
+    static PerDeviceOnce once;
+    int d2;
+    if (once.needed(&d2)) {
+        const int bytes = kSgBlock * kSgBlock * int(sizeof(float));
+        bool ok = true;
+#define VLMC_SELSWEEP_ATTR(R)                                                                                              \
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(sgpt_select_sweep_kernel<R>),                             \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
+        VLMC_SELSWEEP_ATTR(1); VLMC_SELSWEEP_ATTR(2); VLMC_SELSWEEP_ATTR(4); VLMC_SELSWEEP_ATTR(8);
+#undef VLMC_SELSWEEP_ATTR
+        if (!ok) {
+            set_error("vlmc_sparsegpt_select_sweep: cannot reserve 64 KB of LDS");
+            return VLMC_EHIP;
+        }
+        once.mark(d2);
+    }
+    int force_fail = 0;
+    if (const char *e = getenv("VLMC_SGPT_SELECT_FORCE_FAIL")) force_fail = atoi(e);       // tests: 1..3 = fail at that level
+#define VLMC_SELSWEEP(R)                                                                                                      \
+    hipLaunchKernelGGL((sgpt_select_sweep_kernel<R>), dim3(unsigned(sc.wg0[n_scopes])), dim3(256), lds, as_stream(stream), W,   \
+                       int(count), ldw, U1, ldu, sc, Err1, lde, mask_out, ldmo, static_cast<uint32_t *>(workspace), force_fail)
+    switch (rows) {
+        case 1: VLMC_SELSWEEP(1); break;
+        case 2: VLMC_SELSWEEP(2); break;
+        case 4: VLMC_SELSWEEP(4); break;
+        default: VLMC_SELSWEEP(8); break;
+    }
+#undef VLMC_SELSWEEP
+    VLMC_HIP_CHECK_LAUNCH("vlmc_sparsegpt_select_sweep");
     return VLMC_OK;
 }

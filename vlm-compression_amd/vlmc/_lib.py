@@ -69,6 +69,8 @@ SIGNATURES = {
     "vlmc_symmetrize_lower": (_i, [_p, _i64, _i64, _p]),
     "vlmc_chol_block": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, _p, _i, _p]),
     "vlmc_sparsegpt_sweep": (_i, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i, _i, _p, _i64, _p, _i64, _p]),
+    "vlmc_sparsegpt_select_workspace_bytes": (_i64, []),
+    "vlmc_sparsegpt_select_sweep": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _p, _p, _i64, _p, _i64, _p, _p]),
     "vlmc_score_select_workspace": (_sz, [_i, _i]),
     "vlmc_score_select": (_i, [_p, _i, _p, _i, _i, _i, _p, _sz, _p]),
     "vlmc_wanda_select": (_i, [_p, _i, _i64, _i64, _i64, _p, _i, _i64, _i, _i, _i, _p, _p, _p, _sz, _p]),

@@ -473,6 +473,42 @@ def sweep_block(W: torch.Tensor, i1: int, i2: int, U: torch.Tensor, mask1, prune
         mask_out.stride(0) if mask_out is not None else 0, _stream()))
 
 
+_SELECT_SWEEP = __import__("os").environ.get("VLMC_SGPT_SELECT_SWEEP", "1") != "0"
+_select_ws = {}            # device index -> the zero-filled workspace of vlmc_sparsegpt_select_sweep (returned zero by every call)
+SELECT_SWEEP_MAX_ROWS = 16384
+
+
+def select_sweep_usable(rows_per_scope):
+    """The one-launch threshold + sweep takes up to 4 stacked linears and as many rows as 2 x CUs workgroups of 32 hold
+    (include/vlmc.h; a scope's last workgroup may be partly empty, hence the margin)."""
+    return (_SELECT_SWEEP and 1 <= len(rows_per_scope) <= 4 and all(r > 0 for r in rows_per_scope)
+            and sum(rows_per_scope) + 32 * len(rows_per_scope) <= SELECT_SWEEP_MAX_ROWS)
+
+
+def select_sweep_block(W: torch.Tensor, i1: int, i2: int, U: torch.Tensor, rows_per_scope, ranks, err: torch.Tensor,
+                       mask_out: torch.Tensor | None = None):
+    """Unstructured mode: block threshold (:183-185, per stacked linear) and column sweep (:186-205) of W[:, i1:i2] in ONE
+    launch (`vlmc_sparsegpt_select_sweep`); `ranks[s]` = int(rows_s * (i2 - i1) * sparsity_s)."""
+    _need_gpu(W, U, err, mask_out)
+    assert W.dtype == torch.float32 and U.dtype == torch.float32 and err.dtype == torch.float32
+    assert W.stride(1) == 1 and U.stride(1) == 1 and err.stride(1) == 1 and sum(rows_per_scope) == W.shape[0]
+    lib = _lib.load()
+    ws = _select_ws.get(W.device.index)
+    if ws is None:
+        ws = _select_ws[W.device.index] = torch.zeros(int(lib.vlmc_sparsegpt_select_workspace_bytes()) // 4, dtype=torch.int32,
+                                                      device=W.device)
+    import ctypes
+    n = len(rows_per_scope)
+    rows_c = (ctypes.c_int64 * n)(*[int(r) for r in rows_per_scope])
+    ranks_c = (ctypes.c_int64 * n)(*[int(r) for r in ranks])
+    count = i2 - i1
+    el = W.element_size()
+    _lib.check(lib.vlmc_sparsegpt_select_sweep(
+        W.data_ptr() + i1 * el, count, W.stride(0), U.data_ptr() + (i1 * U.stride(0) + i1) * el, U.stride(0), n, rows_c, ranks_c,
+        err.data_ptr(), err.stride(0), mask_out.data_ptr() + i1 if mask_out is not None else None,
+        mask_out.stride(0) if mask_out is not None else 0, ws.data_ptr(), _stream()))
+
+
 @torch.no_grad()
 def fasterprune(layer, H: torch.Tensor, sparsity, prune_n=0, prune_m=0, blocksize=128, percdamp=0.01, return_mask=False,
                 factor_cache=None, score_sink=None):
@@ -492,9 +528,16 @@ def fasterprune(layer, H: torch.Tensor, sparsity, prune_n=0, prune_m=0, blocksiz
     rows, cols = W.shape
     err = torch.empty((rows, min(blocksize, cols)), dtype=torch.float32, device=W.device)
     pruned = torch.zeros((rows, cols), dtype=torch.bool, device=W.device) if return_mask else None
+    fused = prune_n == 0 and _SELECT_THRESHOLD and select_sweep_usable([rows])
     for i1 in range(0, cols, blocksize):
         i2 = min(i1 + blocksize, cols)
         mask1 = None
+        if fused:                                                                          # :183-205 in one launch
+            rank = min(int(rows * (i2 - i1) * sparsity), rows * (i2 - i1) - 1)
+            select_sweep_block(W, i1, i2, U, [rows], [rank], err, pruned)
+            if i2 < cols:
+                W[:, i2:].addmm_(err[:, :i2 - i1], U[i1:i2, i2:], beta=1.0, alpha=-1.0)    # :210
+            continue
         if prune_n == 0:
             tmp = W[:, i1:i2] ** 2 / diag[i1:i2].reshape(1, -1) ** 2                       # :183
             if _SELECT_THRESHOLD:
@@ -544,9 +587,16 @@ def fasterprune_group(layers, sparsities, factor_cache, prune_n=0, prune_m=0, bl
     means = [(W[bounds[i]:bounds[i + 1]] ** 2 / dsq).abs().mean() for i in range(len(layers))]
     err = torch.empty((W.shape[0], min(blocksize, cols)), dtype=torch.float32, device=W.device)
     keep = torch.empty((W.shape[0], min(blocksize, cols)), dtype=torch.bool, device=W.device) if prune_n == 0 else None
+    fused = prune_n == 0 and _SELECT_THRESHOLD and select_sweep_usable(rows)
     for i1 in range(0, cols, blocksize):
         i2 = min(i1 + blocksize, cols)
         mask1 = None
+        if fused:                                                                          # :183-205 in one launch, a scope per linear
+            ranks = [min(int(r * (i2 - i1) * sp), r * (i2 - i1) - 1) for r, sp in zip(rows, sparsities)]
+            select_sweep_block(W, i1, i2, U, rows, ranks, err, None)
+            if i2 < cols:
+                W[:, i2:].addmm_(err[:, :i2 - i1], U[i1:i2, i2:], beta=1.0, alpha=-1.0)    # :210
+            continue
         if prune_n == 0:
             tmp = W[:, i1:i2] ** 2 / dsq[:, i1:i2]                                          # :183
             kb = keep if i2 - i1 == keep.shape[1] else torch.empty((W.shape[0], i2 - i1), dtype=torch.bool, device=W.device)
