@@ -72,7 +72,7 @@ constexpr int kRawCap = 192;                   // ... and up to this many candid
 template <int NW, bool NM> struct ListSmem {
     uint32_t hist[kFastBins + 1 + 64];
     uint32_t red[24];
-    uint32_t rawk[kRawCap], rawc[kRawCap];
+    uint32_t rawk[2][kRawCap], rawc[2][kRawCap];     // [1]: the descending list of dl_extract_both
     ListEntry list[NM ? 2 : 6][kListCap];
     uint32_t wmin[NW], wmax[NW];
     GroupInfo grp[NM ? 2 : 1][NM ? kListCap : 1];
@@ -80,7 +80,6 @@ template <int NW, bool NM> struct ListSmem {
     float fsum[NW];
     uint32_t cnt3[3][NW];
     uint32_t nlist[6];
-    ListEntry k0[2];
 };
 
 template <int NW> __device__ __forceinline__ void dl_sync() {
@@ -271,18 +270,18 @@ __device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], DVal dv
                     const uint32_t bin = (kk - lo) >> shift;
                     if (bin <= cut) {
                         const uint32_t pos = atomicSub(&sm.hist[bin], 1u) - 1u;
-                        sm.rawk[pos] = kk;
-                        sm.rawc[pos] = cf(i);
+                        sm.rawk[0][pos] = kk;
+                        sm.rawc[0][pos] = cf(i);
                     }
                 }
             dl_sync<NW>();
             for (uint32_t p = tid; p < m; p += NT) {
-                const uint32_t kp = sm.rawk[p], cp = sm.rawc[p];
+                const uint32_t kp = sm.rawk[0][p], cp = sm.rawc[0][p];
                 const uint32_t bin = (kp - lo) >> shift;
                 const uint32_t s0 = sm.hist[bin], e0 = bin == cut ? m : sm.hist[bin + 1];
                 uint32_t rank = s0;
                 for (uint32_t q = s0; q < e0; ++q) {
-                    const uint32_t kq = sm.rawk[q], cq = sm.rawc[q];
+                    const uint32_t kq = sm.rawk[0][q], cq = sm.rawc[0][q];
                     rank += (kq < kp || (kq == kp && cq < cp)) ? 1u : 0u;
                 }
                 if (rank < n) {
@@ -325,8 +324,8 @@ __device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], DVal dv
             const uint32_t kk = kf(i);
             if (kk < X || (kk == X && cf(i) <= Y)) {
                 const uint32_t pos = atomicAdd(&sm.red[2], 1u);
-                sm.rawk[pos] = kk;
-                sm.rawc[pos] = cf(i);
+                sm.rawk[0][pos] = kk;
+                sm.rawc[0][pos] = cf(i);
             }
         }
     dl_sync<NW>();
@@ -335,10 +334,10 @@ __device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], DVal dv
     // linear); several waves: every lane ranks one entry against the LDS copy (faster than serialising on wave 0).
     if constexpr (NW > 1) {
         for (uint32_t p = tid; p < n; p += NT) {
-            const uint32_t kp = sm.rawk[p], cp = sm.rawc[p];
+            const uint32_t kp = sm.rawk[0][p], cp = sm.rawc[0][p];
             uint32_t rank = 0;
             for (uint32_t q = 0; q < n; ++q) {
-                const uint32_t kq = sm.rawk[q], cq = sm.rawc[q];
+                const uint32_t kq = sm.rawk[0][q], cq = sm.rawc[0][q];
                 rank += (kq < kp || (kq == kp && cq < cp)) ? 1u : 0u;
             }
             const uint32_t col = (cp ^ flip) & 0x3FFFu;
@@ -347,8 +346,8 @@ __device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], DVal dv
         }
     } else if (tid < 64) {
         const uint32_t p0 = uint32_t(tid), p1 = uint32_t(tid) + 64u;
-        const uint32_t k0 = p0 < n ? sm.rawk[p0] : 0xFFFFFFFFu, c0 = p0 < n ? sm.rawc[p0] : 0xFFFFFFFFu;
-        const uint32_t k1 = p1 < n ? sm.rawk[p1] : 0xFFFFFFFFu, c1 = p1 < n ? sm.rawc[p1] : 0xFFFFFFFFu;
+        const uint32_t k0 = p0 < n ? sm.rawk[0][p0] : 0xFFFFFFFFu, c0 = p0 < n ? sm.rawc[0][p0] : 0xFFFFFFFFu;
+        const uint32_t k1 = p1 < n ? sm.rawk[0][p1] : 0xFFFFFFFFu, c1 = p1 < n ? sm.rawc[0][p1] : 0xFFFFFFFFu;
         uint32_t rank0 = 0, rank1 = 0;
         const uint32_t n_lo = n < 64u ? n : 64u;
         for (uint32_t q = 0; q < n_lo; ++q) {
@@ -366,6 +365,148 @@ __device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], DVal dv
     }
     dl_sync<NW>();
     return n;
+}
+
+// BOTH ends of one key vector's order among the masked elements in one go: outA[0..n) = the n smallest (key, column)
+// pairs ascending, outD[0..n) = the n largest, descending in key and, among equal keys, in column -- what dl_extract gives
+// for want_max = 0 and 1 -- from ONE min / max reduction, ONE histogram pass, one scan and one gather pass (the two lists of
+// a key vector were two full extractions: seven per row, now three of these and a min-reduction for K0).  The bins are cut
+// from the unflipped keys; the ascending list takes the bins up to the one at which the running count reaches n, the
+// descending list the bins from the one that holds ascending position avail - n upwards; an element's exact rank is its
+// bin's offset + its rank among the few entries of its own bin.  Falls back to two dl_extract calls when the two ends meet
+// (few masked elements) or either end brings more than kRawCap candidates (ties, NaN / Inf keys).
+// `place(which, col, rank)`: called by one thread per entry; which = 0 the ascending list, 1 the descending one.
+template <int E, int NT, int NW, typename S, typename DVal, typename Place>
+__device__ __forceinline__ uint32_t dl_extract_both(const uint32_t (&key)[E], DVal dval, uint32_t mask, uint32_t K, S &sm, ListEntry *outA,
+                                                    ListEntry *outD, Place place, int fast) {
+    const int tid = threadIdx.x;
+    const uint32_t avail = dl_block_sum<NT, NW>(uint32_t(__popc(mask)), sm, 0);
+    const uint32_t n = avail < K ? avail : K;
+    if (n == 0) return 0;
+    if (fast && avail >= 2u * n) {
+        uint32_t tid8 = uint32_t(tid) * 8u;
+        auto colof = [&](int i) { return uint32_t((i / 8) * NT * 8 + (i % 8)) + tid8; };
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        const uint32_t mk0 = dl_opaque(mask);
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const uint32_t kk = key[i];
+            const bool in = (mk0 >> i) & 1u;
+            lo = (in && kk < lo) ? kk : lo;
+            hi = (in && kk > hi) ? kk : hi;
+        }
+        lo = dl_wave_min(lo);
+        hi = dl_wave_max(hi);
+        if constexpr (NW > 1) {
+            if ((tid & 63) == 0) { sm.wmin[tid >> 6] = lo; sm.wmax[tid >> 6] = hi; }
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const uint32_t a = sm.wmin[w], b = sm.wmax[w];
+                lo = a < lo ? a : lo;
+                hi = b > hi ? b : hi;
+            }
+        }
+        lo = dl_uniform(lo);
+        const uint32_t span = dl_uniform(hi) - lo;
+        uint32_t shift = span < uint32_t(kFastBins) ? 0u : uint32_t(32 - __builtin_clz(span)) - uint32_t(kFastBinsLog2);
+        for (int i = tid; i < kFastBins; i += NT) sm.hist[i] = 0;
+        dl_sync<NW>();
+        const uint32_t mk1 = dl_opaque(mask);
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const uint32_t bin = (key[i] - lo) >> shift;
+            atomicAdd(&sm.hist[((mk1 >> i) & 1u) ? bin : uint32_t(kFastBins + 1 + (tid & 63))], 1u);
+        }
+        dl_sync<NW>();
+        lo = dl_uniform(lo);
+        shift = dl_uniform(shift);
+        const uint32_t need_d = avail - n;                              // ascending position of the descending list's last entry
+        if (tid < 64) {
+            constexpr int PER = kFastBins / 64;
+            uint32_t h[PER];
+            uint32_t ssum = 0;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) { h[i] = sm.hist[tid * PER + i]; ssum += h[i]; }
+            const uint32_t incl = dl_wave_incl_scan(ssum);
+            uint32_t cum = incl - ssum;
+            const bool mine_a = cum < n && n <= incl;
+            const bool mine_d = cum <= need_d && need_d < incl;
+            bool found_a = false, found_d = false;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const uint32_t excl = cum;
+                cum += h[i];
+                sm.hist[tid * PER + i] = cum;                           // inclusive prefix
+                if (mine_a && !found_a && cum >= n) {
+                    found_a = true;
+                    sm.red[3] = uint32_t(tid * PER + i);                // the ascending list's cut-off bin
+                    sm.red[4] = cum;                                    // ... and its candidates
+                }
+                if (mine_d && !found_d && need_d < cum) {
+                    found_d = true;
+                    sm.red[5] = uint32_t(tid * PER + i);                // the descending list's lowest bin
+                    sm.red[6] = avail - excl;                           // ... and its candidates
+                }
+            }
+        }
+        dl_sync<NW>();
+        const uint32_t cut_a = sm.red[3], m_a = sm.red[4], cut_d = sm.red[5], m_d = sm.red[6];
+        if (m_a <= uint32_t(kRawCap) && m_d <= uint32_t(kRawCap) && cut_a < cut_d) {
+            // slots are handed out from the END of each bin's range downwards (hist[b] counts down from the inclusive prefix to the
+            // bin's start): ascending position p of a candidate; the descending list stores it at avail - 1 - p
+            const uint32_t mk2 = dl_opaque(mask);
+            tid8 = dl_opaque(tid8);
+#pragma unroll
+            for (int i = 0; i < E; ++i)
+                if ((mk2 >> i) & 1u) {
+                    const uint32_t kk = key[i];
+                    const uint32_t bin = (kk - lo) >> shift;
+                    if (bin <= cut_a || bin >= cut_d) {
+                        const uint32_t p = atomicSub(&sm.hist[bin], 1u) - 1u;
+                        const uint32_t which = bin <= cut_a ? 0u : 1u;
+                        const uint32_t pos = which ? avail - 1u - p : p;
+                        sm.rawk[which][pos] = kk;
+                        sm.rawc[which][pos] = colof(i);
+                    }
+                }
+            dl_sync<NW>();
+            for (uint32_t p = tid; p < m_a + m_d; p += NT) {
+                const bool desc = p >= m_a;
+                const uint32_t q0 = desc ? p - m_a : p;
+                const uint32_t kp = sm.rawk[desc ? 1 : 0][q0], cp = sm.rawc[desc ? 1 : 0][q0];
+                const uint32_t bin = (kp - lo) >> shift;
+                const uint32_t excl = sm.hist[bin];                     // (counted down to the bin's start)
+                uint32_t rank;
+                if (!desc) {
+                    const uint32_t e0 = bin == cut_a ? m_a : sm.hist[bin + 1];
+                    rank = excl;
+                    for (uint32_t q = excl; q < e0; ++q) {
+                        const uint32_t kq = sm.rawk[0][q], cq = sm.rawc[0][q];
+                        rank += (kq < kp || (kq == kp && cq < cp)) ? 1u : 0u;
+                    }
+                } else {
+                    const uint32_t incl = bin == uint32_t(kFastBins - 1) ? avail : sm.hist[bin + 1];
+                    rank = avail - incl;
+                    for (uint32_t q = avail - incl; q < avail - excl; ++q) {
+                        const uint32_t kq = sm.rawk[1][q], cq = sm.rawc[1][q];
+                        rank += (kq > kp || (kq == kp && cq > cp)) ? 1u : 0u;
+                    }
+                }
+                if (rank < n) {                                         // (one copy of dval / place for both lists: lanes of a wave hold both kinds)
+                    (desc ? outD : outA)[rank] = ListEntry{cp, dval(cp)};
+                    place(desc ? 1u : 0u, cp, rank);
+                }
+            }
+            dl_sync<NW>();
+            return n;
+        }
+        dl_sync<NW>();
+    }
+    auto place_a = [&](uint32_t col, uint32_t rank) { place(0u, col, rank); };
+    auto place_d = [&](uint32_t col, uint32_t rank) { place(1u, col, rank); };
+    dl_extract<E, NT, NW>(key, dval, mask, 0u, K, sm, outA, place_a, fast);
+    return dl_extract<E, NT, NW>(key, dval, mask, 1u, K, sm, outD, place_d, fast);
 }
 
 __device__ __attribute__((noinline)) float dl_powf(float v, float p) { return powf(v, p); }   // (32 inlined copies otherwise)
@@ -486,24 +627,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) vo
             }
             sm.grp[li][rank] = gi;
         };
-#pragma unroll 1
-        for (uint32_t li = 0; li < 2; ++li) {
-            auto place = [&](uint32_t col, uint32_t rank) { payload(li, col, rank); };
-            const uint32_t got = dl_extract<E, NT, NW>(gk, dval, live, li, K, sm, sm.list[li], place, fast);
-            if (tid == 0) sm.nlist[li] = got;
+        {
+            auto place = [&](uint32_t which, uint32_t col, uint32_t rank) { payload(which, col, rank); };
+            const uint32_t got = dl_extract_both<E, NT, NW>(gk, dval, live, K, sm, sm.list[0], sm.list[1], place, fast);
+            if (tid == 0) { sm.nlist[0] = got; sm.nlist[1] = got; }
         }
     } else {
         NP = dl_block_sum<NT, NW>(uint32_t(__popc(negm)), sm, 0);
         PP = dl_block_sum<NT, NW>(uint32_t(__popc(posm)), sm, 1);
         Z = dl_block_sum<NT, NW>(uint32_t(__popc(kept0)), sm, 2) - NP - PP;
-        auto no_place = [](uint32_t, uint32_t) {};
+        auto no_place = [](uint32_t, uint32_t, uint32_t) {};
         // lists 0/1: regrow candidates by G, ascending / descending; 2/3: kept columns with D < 0 by metric; 4/5: with D > 0;
         // 6 (K0): the kept column with the smallest wanda metric (head of the ascending list over ALL kept columns)
-        uint32_t nk0 = 0;
-#pragma unroll 1
-        for (uint32_t li = 0; li < 2; ++li) {                          // (gk is dead after this loop: 32 registers less)
-            const uint32_t got = dl_extract<E, NT, NW>(gk, dval, live, li & 1u, K, sm, sm.list[li], no_place, fast);
-            if (tid == 0) sm.nlist[li] = got;
+        {                                                              // (gk is dead after this: 32 registers less)
+            const uint32_t got = dl_extract_both<E, NT, NW>(gk, dval, live, K, sm, sm.list[0], sm.list[1], no_place, fast);
+            if (tid == 0) { sm.nlist[0] = got; sm.nlist[1] = got; }
         }
         // the prune lists' key: the wanda metric |w| * sqrt(scaler), from the row again
         uint32_t wk[E];
@@ -522,18 +660,45 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) vo
             }
         }
 #pragma unroll 1
-        for (uint32_t li = 2; li < 7; ++li) {
-            const uint32_t msk = li < 4 ? negm : (li < 6 ? posm : kept0);
-            ListEntry *dst = li < 6 ? sm.list[li] : sm.k0;
-            const uint32_t got = dl_extract<E, NT, NW>(wk, dval, msk, li & 1u, li < 6 ? K : 1u, sm, dst, no_place, fast);
-            if (li < 6) {
-                if (tid == 0) sm.nlist[li] = got;
-            } else {
-                nk0 = got;
-            }
+        for (uint32_t li = 2; li < 6; li += 2) {                       // both ends of the negative-D pool, then of the positive-D pool
+            const uint32_t msk = li < 4 ? negm : posm;
+            const uint32_t got = dl_extract_both<E, NT, NW>(wk, dval, msk, K, sm, sm.list[li], sm.list[li + 1], no_place, fast);
+            if (tid == 0) { sm.nlist[li] = got; sm.nlist[li + 1] = got; }
         }
-        k0col = nk0 ? sm.k0[0].col : 0xFFFFFFFFu;
-        k0d = nk0 ? sm.k0[0].d : 0.f;
+        // K0, the kept column with the smallest (metric, column): a min-reduction of key : column pairs
+        {
+            uint32_t bk = 0xFFFFFFFFu, bc = 0xFFFFFFFFu;
+            const uint32_t tid8 = uint32_t(tid) * 8u;
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const uint32_t c = uint32_t((i / 8) * NT * 8 + (i % 8)) + tid8;
+                const bool in = (kept0 >> i) & 1u;
+                const bool better = in && (wk[i] < bk || (wk[i] == bk && c < bc));
+                bk = better ? wk[i] : bk;
+                bc = better ? c : bc;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const uint32_t ok = uint32_t(__shfl_xor(int(bk), off, 64)), oc = uint32_t(__shfl_xor(int(bc), off, 64));
+                const bool better = ok < bk || (ok == bk && oc < bc);
+                bk = better ? ok : bk;
+                bc = better ? oc : bc;
+            }
+            if constexpr (NW > 1) {
+                __syncthreads();
+                if (lane == 0) { sm.wmin[wave] = bk; sm.wmax[wave] = bc; }
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const uint32_t ok = sm.wmin[w], oc = sm.wmax[w];
+                    const bool better = ok < bk || (ok == bk && oc < bc);
+                    bk = better ? ok : bk;
+                    bc = better ? oc : bc;
+                }
+            }
+            k0col = bc;                                                // 0xFFFFFFFF: no kept column
+            k0d = bc != 0xFFFFFFFFu ? dval(bc) : 0.f;
+        }
     }
     dl_sync<NW>();
     if (wave != 0) return;
@@ -626,10 +791,11 @@ static int lists_dispatch(const void *W, int64_t out_f, int64_t in_f, int64_t ld
     // smallest workgroup that holds the row with <= 4 chunks per lane (fewest barriers per radix pass)
     int nw = 1;
     while (nw < 8 && nchunks > int64_t(64) * nw * 4) nw *= 2;
+    if (nw == 1 && nchunks > 128) nw = 2;   // 129..256 chunks: two waves with 2 chunks per lane (one wave with 4: 174 VGPRs, 2 waves per SIMD; 6144 x 1408: 339 -> 277 us)
     if (NM && nw == 1) nw = 2;      // n:m: 23 KB of LDS per row -> six one-wave workgroups per CU would leave the SIMDs at 1.5 waves
     if (const char *e = getenv("VLMC_DSNOT_NW")) {
         const int f = atoi(e);
-        if ((f == 1 || f == 2 || f == 4 || f == 8) && nchunks <= int64_t(64) * f * 4) nw = f;
+        if ((f == 1 || f == 2 || f == 4 || f == 8) && nchunks <= int64_t(64) * f * 4 && !(NM && f == 1)) nw = f;
     }
     if (nchunks > int64_t(64) * nw * 4) return VLMC_EINVAL;
     const int ch = nchunks <= int64_t(64) * nw * 2 ? 2 : 4;
@@ -641,7 +807,10 @@ static int lists_dispatch(const void *W, int64_t out_f, int64_t in_f, int64_t ld
                        max_cycle, thr, pow_var, without_same_sign, events, t_row, fast)
 #define VLMC_DL_NW(NW) do { if (ch == 2) VLMC_DL(2, NW); else VLMC_DL(4, NW); } while (0)
     switch (nw) {
-        case 1: VLMC_DL_NW(1); break;
+        case 1:
+            if constexpr (!NM) VLMC_DL_NW(1);      // (n:m never runs one wave per row: those instantiations compiled to 2 waves per SIMD)
+            else return VLMC_EINVAL;
+            break;
         case 2: VLMC_DL_NW(2); break;
         case 4: VLMC_DL_NW(4); break;
         default: VLMC_DL_NW(8); break;
