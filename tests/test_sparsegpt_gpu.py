@@ -358,3 +358,33 @@ def test_select_sweep_rejects_what_it_cannot_hold():
         SG.select_sweep_block(W, 0, 128, U, [20000], [5], err)
     with pytest.raises(_lib.VlmcError):
         SG.select_sweep_block(W[:6], 0, 128, U, [6], [6 * 128], err[:6])                  # a rank outside the scope
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+def test_fasterprune_with_one_launch_blocks_equals_the_multi_launch_route(grouped, monkeypatch):
+    """`fasterprune` / `fasterprune_group` through `vlmc_sparsegpt_select_sweep` (default) against `VLMC_SGPT_SELECT_SWEEP=0`
+    (scores, multi-tensor radix select, logical_not, sweep with the mask handed in): the same weights bit for bit."""
+    import torch.nn as nn
+    from vlmc import sparsegpt as SG
+    g = torch.Generator(device=DEV).manual_seed(23)
+    n, rows_x = 640, 4096
+    x = torch.randn(rows_x, n, generator=g, device=DEV)
+    H = (x.t() @ x) * (2.0 / rows_x)
+    outs, spars = ((384, 256, 644), (0.5, 0.5, 0.3)) if grouped else ((1030,), (0.45,))
+
+    def run(fused):
+        monkeypatch.setattr(SG, "_SELECT_SWEEP", fused)
+        torch.manual_seed(5)
+        lins = [nn.Linear(n, o, bias=False).to(DEV).to(torch.bfloat16) for o in outs]
+        cache = {"rows_seen": rows_x}
+        SG.factorize_many([(H.clone(), cache)])
+        sink = []
+        if grouped:
+            SG.fasterprune_group(lins, list(spars), cache, score_sink=sink)
+        else:
+            SG.fasterprune(lins[0], None, spars[0], factor_cache=cache, score_sink=sink)
+        return [l.weight.data.clone() for l in lins]
+    a, b = run(True), run(False)
+    for wa, wb, sp in zip(a, b, spars):
+        assert torch.equal(wa.view(torch.int16), wb.view(torch.int16))
+        assert abs(float((wa == 0).float().mean()) - sp) < 0.01

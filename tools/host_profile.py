@@ -36,3 +36,7 @@ print(s.getvalue()[:9000])
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(30)
 print(s.getvalue()[:7000])
+buf = io.StringIO()
+st = pstats.Stats(pr, stream=buf)
+st.print_callers(r"module.py:\d+\((parameters|named_parameters|named_modules|_named_members)\)")
+print(buf.getvalue()[:6000])

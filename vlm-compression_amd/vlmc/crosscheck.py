@@ -31,6 +31,7 @@ ROUTES = {
     "compare_at_once": ({"VLMC_LATER_EQUAL": "0"}, "remembered tower inputs compared at once"),
     "tower_rerun": ({"VLMC_TOWER_MEMO": "0", "VLMC_TOWER_GRAPH": "0"}, "finished towers are run again in every capture phase"),
     "sgpt_one_by_one": ({"VLMC_SGPT_CONCURRENT": "0", "VLMC_SGPT_STACK": "0"}, "one Hessian / one linear at a time"),
+    "sgpt_select_multi": ({"VLMC_SGPT_SELECT_SWEEP": "0"}, "SparseGPT block threshold by the multi-launch radix select, sweep with the mask handed in"),
     "sgpt_library": ({"VLMC_SGPT_SYRK": "0", "VLMC_SGPT_DIRECT_FACTOR": "0", "VLMC_CHOL_GRAPH": "0"}, "library GEMM Hessian, the reference's three-step factor chain"),
     "sgpt_per_call": ({"VLMC_SGPT_DEFER": "0"}, "one Hessian update per hook call"),
 }
