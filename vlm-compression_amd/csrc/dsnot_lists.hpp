@@ -67,12 +67,16 @@ struct GroupInfo {                   // n:m: the kept columns of an entry's m-gr
 
 constexpr int kFastBinsLog2 = 10;
 constexpr int kFastBins = 1 << kFastBinsLog2;  // fast route: one linear histogram over the occupied key range
-constexpr int kRawCap = 192;                   // ... and up to this many candidates (the cut-off bin brings a few extra)
+constexpr int kRawCap = 192;                   // ... and up to this many candidates (the cut-off bin brings a few extra); 512 for wide rows, see ListSmem
 
 template <int NW, bool NM> struct ListSmem {
+    // Rows of more than 4096 columns (4+ waves) put several hundred keys into the half-octave bin that completes a list of 100
+    // (the signed regrow keys span the whole key range: 1024 bins = half an octave each): 192 slots sent 11008-column rows to
+    // the radix route for most lists (4096 x 11008: 1384 -> 1100 us with 512); narrow rows keep 192 (LDS is their occupancy).
+    static constexpr int RAWCAP = NW >= 4 ? 512 : kRawCap;
     uint32_t hist[kFastBins + 1 + 64];
     uint32_t red[24];
-    uint32_t rawk[2][kRawCap], rawc[2][kRawCap];     // [1]: the descending list of dl_extract_both
+    uint32_t rawk[2][RAWCAP], rawc[2][RAWCAP];       // [1]: the descending list of dl_extract_both
     ListEntry list[NM ? 2 : 6][kListCap];
     uint32_t wmin[NW], wmax[NW];
     GroupInfo grp[NM ? 2 : 1][NM ? kListCap : 1];
@@ -258,7 +262,7 @@ __device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], DVal dv
         }
         dl_sync<NW>();
         const uint32_t cut = sm.red[3], m = sm.red[4];
-        if (m <= uint32_t(kRawCap)) {
+        if (m <= uint32_t(S::RAWCAP)) {
             // slots are handed out from the END of each bin's range downwards: hist[b] (inclusive prefix) counts down to
             // the bin's start, so afterwards start(b) = hist[b] and end(b) = start(b + 1) = hist[b + 1] (or m at the cut).
             const uint32_t mk2 = dl_opaque(mask);
@@ -452,7 +456,7 @@ __device__ __forceinline__ uint32_t dl_extract_both(const uint32_t (&key)[E], DV
         }
         dl_sync<NW>();
         const uint32_t cut_a = sm.red[3], m_a = sm.red[4], cut_d = sm.red[5], m_d = sm.red[6];
-        if (m_a <= uint32_t(kRawCap) && m_d <= uint32_t(kRawCap) && cut_a < cut_d) {
+        if (m_a <= uint32_t(S::RAWCAP) && m_d <= uint32_t(S::RAWCAP) && cut_a < cut_d) {
             // slots are handed out from the END of each bin's range downwards (hist[b] counts down from the inclusive prefix to the
             // bin's start): ascending position p of a candidate; the descending list stores it at avail - 1 - p
             const uint32_t mk2 = dl_opaque(mask);
@@ -702,6 +706,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) vo
     }
     dl_sync<NW>();
     if (wave != 0) return;
+#ifdef DL_EXP_NOWALK
+    if (max_cycle > 0) { if (tid == 0) t_row[row] = 1; return; }
+#endif
 
     // ---- 3. the cycles, by wave 0 (uniform control flow) ------------------------------------------------------------
     bool u = true;
