@@ -86,6 +86,35 @@ __device__ __forceinline__ void nm_decide(int i, int count, int lane, int prune_
     }
 }
 
+// The same decision for m = 4 / 8 (a group never straddles the two 64-column halves) with every lane scoring ITS OWN column:
+// one division per lane and group instead of m (the version above computes the m scores of the group in every lane), the
+// group's keys gathered by v_readlane, and a lane ranks only its own key: m compares instead of m^2.  Same arithmetic per
+// score, same (key, column) order: the same mask.
+template <int kSgRows, int M>
+__device__ __forceinline__ void nm_decide_lanes(int i, int count, int lane, int prune_n, float dsq0, float dsq1,
+                                                const float (&w0)[kSgRows], const float (&w1)[kSgRows], int (&m0)[kSgRows],
+                                                int (&m1)[kSgRows]) {
+    static_assert(64 % M == 0, "a group lies inside one half");
+    const bool hi = i >= 64;
+    const int l0 = i & 63;
+    const bool mine = lane >= l0 && lane < l0 + M;                     // this lane's column belongs to the group
+    const bool incount = (hi ? 64 : 0) + lane < count;
+#pragma unroll
+    for (int r = 0; r < kSgRows; ++r) {
+        const float wv = hi ? w1[r] : w0[r];
+        const uint32_t key = incount ? score_key(ieee_div(ieee_mul(wv, wv), hi ? dsq1 : dsq0)) : 0xFFFFFFFFu;
+        int rank = 0;
+#pragma unroll
+        for (int b = 0; b < M; ++b) {
+            const uint32_t tb = uint32_t(__builtin_amdgcn_readlane(int(key), l0 + b));
+            rank += (tb < key || (tb == key && l0 + b < lane)) ? 1 : 0;
+        }
+        if (mine && incount && rank < prune_n) {
+            if (hi) m1[r] = 1; else m0[r] = 1;
+        }
+    }
+}
+
 template <int kSgRows, int NM>     // NM: 0 = unstructured (block mask given), 4 / 8 = n:m with that m, 1 = n:m, m at run time
 __global__ __launch_bounds__(256) void sparsegpt_sweep_kernel(float *__restrict__ W, int64_t out_f, int count, int64_t ldw,
                                                               const float *__restrict__ U1, int64_t ldu,
@@ -143,8 +172,21 @@ __global__ __launch_bounds__(256) void sparsegpt_sweep_kernel(float *__restrict_
         }
         float h0n = sU[lane], h1n = sU[lane + 64], dn = sU[0];      // factor row of the NEXT step, read one step ahead
         const int half = count < 64 ? count : 64;
+        float dsq0 = 1.f, dsq1 = 1.f;                                // squared diagonal entries of this lane's two columns (n:m scores)
+        if constexpr (NM > 1) {
+            const float d0 = c0 ? sU[lane * kSgBlock + lane] : 1.f, d1 = c1 ? sU[(lane + 64) * kSgBlock + lane + 64] : 1.f;
+            dsq0 = ieee_mul(d0, d0);
+            dsq1 = ieee_mul(d1, d1);
+        }
+        auto decide = [&](int i) {
+            if constexpr (NM > 1) {
+                if (i % NM == 0) nm_decide_lanes<kSgRows, NM>(i, count, lane, prune_n, dsq0, dsq1, w0, w1, m0, m1);
+            } else if constexpr (NM == 1) {
+                if (i % prune_m == 0) nm_decide<kSgRows, 0>(i, count, lane, prune_n, prune_m, sU, w0, w1, m0, m1);
+            }
+        };
         for (int i = 0; i < half; ++i) {
-            if (NM && i % (NM > 1 ? NM : prune_m) == 0) nm_decide<kSgRows, (NM > 1 ? NM : 0)>(i, count, lane, prune_n, prune_m, sU, w0, w1, m0, m1);
+            decide(i);
             const float h0 = h0n, h1 = h1n, d = dn;
             if (i + 1 < count) {
                 h0n = sU[(i + 1) * kSgBlock + lane];
@@ -154,7 +196,7 @@ __global__ __launch_bounds__(256) void sparsegpt_sweep_kernel(float *__restrict_
             sweep_step<kSgRows, false>(i, lane, h0, h1, d, w0, w1, e0, e1, m0, m1);
         }
         for (int i = 64; i < count; ++i) {
-            if (NM && i % (NM > 1 ? NM : prune_m) == 0) nm_decide<kSgRows, (NM > 1 ? NM : 0)>(i, count, lane, prune_n, prune_m, sU, w0, w1, m0, m1);
+            decide(i);
             const float h1 = h1n, d = dn;
             if (i + 1 < count) {
                 h1n = sU[(i + 1) * kSgBlock + lane + 64];
