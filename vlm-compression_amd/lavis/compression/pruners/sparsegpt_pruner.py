@@ -75,7 +75,9 @@ class _SparseGPTBlockMixin:
         # the Hessians this rank prunes with: factorized together, each chain on a stream of its own, one host check for all
         sparsegpt.factorize_many(list({id(wrapped[n]): (wrapped[n].H, wrapped[n].factor_cache) for n in mine}.values()), percdamp=0.01,
                                  history=self.__dict__.setdefault("_damping_history", {}).setdefault(module_to_process, {}))
-        scores = []
+        # importance scores (:165: a Python float per linear) are queued on the pruner and read back once per tower: a host
+        # copy per block made the host wait for the block's sweeps before it could issue the next block's replay
+        scores = self.__dict__.setdefault("_score_backlog", [])
         by_acc = {}
         for name in mine:
             assert wrapped[name].nsamples == n_inps                                # :442
@@ -92,11 +94,17 @@ class _SparseGPTBlockMixin:
             for name, key in zip(names, keys):
                 sparsegpt.fasterprune(subset[name], acc.H, sparsity_ratio[key], prune_n=self.prune_n, prune_m=self.prune_m,
                                       percdamp=0.01, blocksize=128, factor_cache=acc.factor_cache, score_sink=scores)
-        sparsegpt.flush_scores(scores)                                             # importance scores: one host copy per block
         if owner is not None:
+            _flush_score_backlog(self)                                             # (the exchange sends the scores along)
             _exchange_pruned(subset, owner, rank)
         for acc in unique:
             acc.free()
+
+
+def _flush_score_backlog(pruner):
+    """`weight.importance_score` for every linear pruned since the last flush: one host copy (end of a tower, also on error)."""
+    from vlmc import sparsegpt
+    sparsegpt.flush_scores(pruner.__dict__.get("_score_backlog", []))
 
 
 def _shard_linears(subset, wrapped):
@@ -187,8 +195,11 @@ class T5LayerSparseGPTPruner(LayerWiseBasePruner, _SparseGPTBlockMixin):
         def prune_block(i, layer, subset, run_pass, state):
             self._sparsegpt_block(i, subset, run_pass, n_inps, module_to_process, sparsity_ratio)
 
-        cal.walk_blocks(model, inps, outs, caches, module_to_process, n_samples,
-                        lambda: model.maybe_autocast(dtype=torch.bfloat16), prune_block, tuple_output=True)
+        try:
+            cal.walk_blocks(model, inps, outs, caches, module_to_process, n_samples,
+                            lambda: model.maybe_autocast(dtype=torch.bfloat16), prune_block, tuple_output=True)
+        finally:
+            _flush_score_backlog(self)
         cfg.use_cache = use_cache
         cal.release_tower_memory()
         return model
@@ -215,8 +226,11 @@ class VITLayerSparseGPTPruner(LayerWiseBasePruner, _SparseGPTBlockMixin):
         def prune_block(i, layer, subset, run_pass, state):
             self._sparsegpt_block(i, subset, run_pass, n_inps, module_to_process, sparsity_ratio)
 
-        cal.walk_blocks(model, inps, outs, caches, module_to_process, n_samples, lambda: model.maybe_autocast(),
-                        prune_block, tuple_output=False, memo_cache=self.__dict__.get("_proxy_cache"))
+        try:
+            cal.walk_blocks(model, inps, outs, caches, module_to_process, n_samples, lambda: model.maybe_autocast(),
+                            prune_block, tuple_output=False, memo_cache=self.__dict__.get("_proxy_cache"))
+        finally:
+            _flush_score_backlog(self)
         cal.release_tower_memory()
         return model
 
