@@ -389,9 +389,17 @@ __global__ void lora_grad_reduce_kernel(const float *__restrict__ part, int slab
     out[i] = round_code(v, ab_code);
 }
 
+// Row splits of the gradient pass: strips x splits workgroups, ALL resident at once -- two per CU (56 KB of LDS each).  (The
+// first version aimed at ">= 768 = 3 per CU": 512 ran, the other 256 made a second, half-empty round -- 4096 x 4096: 68 -> 54 us,
+// 11008 x 4096: 134 -> 101 us with one full round.)
 static int64_t grad_row_splits(int64_t out_f, int64_t in_f) {
+    static const int64_t resident = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return int64_t(2) * n;
+    }();
     const int64_t strips = (in_f + kTN - 1) / kTN, tiles = (out_f + kTM - 1) / kTM;
-    int64_t s = (768 + strips - 1) / strips;          // aim at >= 768 workgroups (3 per CU)
+    int64_t s = resident / strips;                   // the most splits that still fit one round
     if (s > tiles) s = tiles;
     if (s < 1) s = 1;
     return s;
