@@ -107,7 +107,18 @@ struct GemmArgs {
     float *H;                     // [N, N], lower-triangle tiles are updated
     int64_t ldh;
     float alpha, beta;
+    // EPI_SYRK, split along the reduction (rows of X): gridDim.y slabs of K columns of X^T each; slab y writes its raw
+    // sums to Hpart + y * slab_h (row stride ldh_part); syrk_combine_kernel adds them up in slab order.  slab_h = 0: no slabs.
+    float *Hpart;
+    int64_t slab_h, ldh_part;
+    int slabs;                    // (host side: gridDim.y; 0 or 1 = none)
 };
+
+// first column of X^T that slab blockIdx.y of a split SYRK reduces over (0 otherwise)
+template <int EPI> __device__ __forceinline__ int64_t slab_k0(const GemmArgs &a) {
+    if constexpr (EPI == EPI_SYRK) return a.slab_h != 0 ? int64_t(blockIdx.y) * a.K : 0;
+    return 0;
+}
 
 // one panel of P and where its products go
 struct Panel {
@@ -206,7 +217,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, const Panel &pn
             }
         }
     } else {
-        const bool vec_ok = (a.ldh & 3) == 0 && (reinterpret_cast<uintptr_t>(a.H) & 15u) == 0;
+        // (a slab of a split SYRK writes its raw sums to its own partial matrix: syrk_combine_kernel scales and adds them)
+        const bool slab = a.slab_h != 0;
+        float *Hb = slab ? a.Hpart + int64_t(blockIdx.y) * a.slab_h : a.H;
+        const int64_t ldh = slab ? a.ldh_part : a.ldh;
+        const float alpha = slab ? 0.f : a.alpha, beta = slab ? 1.f : a.beta;
+        const bool vec_ok = (ldh & 3) == 0 && (reinterpret_cast<uintptr_t>(Hb) & 15u) == 0;
 #pragma unroll
         for (int i = 0; i < TP; ++i) {
             const int p = pl + i * 16;
@@ -214,18 +230,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, const Panel &pn
             for (int j = 0; j < TQ; ++j) {
                 const int q = ql + j * 16;
                 if (q >= a.NQ || p >= pn.NP) continue;
-                float *dst = a.H + int64_t(q) * a.ldh + p;              // element (row q, column p): the lower triangle
+                float *dst = Hb + int64_t(q) * ldh + p;                 // element (row q, column p): the lower triangle
                 if (vec_ok && p + 3 < pn.NP) {
                     f32x4_t h = {0.f, 0.f, 0.f, 0.f};
-                    if (a.alpha != 0.f) h = *reinterpret_cast<const f32x4_t *>(dst);
+                    if (alpha != 0.f) h = *reinterpret_cast<const f32x4_t *>(dst);
                     f32x4_t o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = a.alpha != 0.f ? a.alpha * h[r] + a.beta * acc[i][j][r] : a.beta * acc[i][j][r];
+                    for (int r = 0; r < 4; ++r) o[r] = alpha != 0.f ? alpha * h[r] + beta * acc[i][j][r] : beta * acc[i][j][r];
                     *reinterpret_cast<f32x4_t *>(dst) = o;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (p + r < pn.NP) dst[r] = a.alpha != 0.f ? a.alpha * dst[r] + a.beta * acc[i][j][r] : a.beta * acc[i][j][r];
+                        if (p + r < pn.NP) dst[r] = alpha != 0.f ? alpha * dst[r] + beta * acc[i][j][r] : beta * acc[i][j][r];
                 }
             }
         }
@@ -267,6 +283,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(const GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bp, bq;
     grid_tile<EPI>(a, bp, bq);
+    const int64_t koff = slab_k0<EPI>(a);
     const Panel pn = locate_panel(a, bp, BP);
     const int p0 = pn.p0, q0 = bq * BQ;
 
@@ -277,12 +294,12 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(const GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < S::CP; ++i) {
             const int c = tid + i * NT, row = p0 + (c >> 3), k = k0 + (c & 7) * 8;
-            stage_p[i] = (row < pn.NP && k < a.K) ? *reinterpret_cast<const u32x4_t *>(pn.P + int64_t(row) * pn.ldp + k) : zero;
+            stage_p[i] = (row < pn.NP && k < a.K) ? *reinterpret_cast<const u32x4_t *>(pn.P + int64_t(row) * pn.ldp + koff + k) : zero;
         }
 #pragma unroll
         for (int i = 0; i < S::CQ; ++i) {
             const int c = tid + i * NT, row = q0 + (c >> 3), k = k0 + (c & 7) * 8;
-            stage_q[i] = (row < a.NQ && k < a.K) ? *reinterpret_cast<const u32x4_t *>(a.Q + int64_t(row) * a.ldq + k) : zero;
+            stage_q[i] = (row < a.NQ && k < a.K) ? *reinterpret_cast<const u32x4_t *>(a.Q + int64_t(row) * a.ldq + koff + k) : zero;
         }
     };
     auto store_tiles = [&](int buf) {
@@ -367,6 +384,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_kernel(const GemmArgs a
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bp, bq;
     grid_tile<EPI>(a, bp, bq);
+    const int64_t koff = slab_k0<EPI>(a);
     const Panel pn = locate_panel(a, bp, BP);
     const int p0 = pn.p0, q0 = bq * BQ;
 
@@ -382,7 +400,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_kernel(const GemmArgs a
         const int r = g * 16 + (lane >> 2);                               // tile row
         const int sc = (lane & 3) ^ ring_perm(r);                         // source chunk that belongs at LDS chunk (lane & 3)
         const int grow = is_q ? min(q0 + r, a.NQ - 1) : min(p0 + r, pn.NP - 1);
-        src[u] = (is_q ? a.Q + int64_t(grow) * a.ldq : pn.P + int64_t(grow) * pn.ldp) + sc * 8;
+        src[u] = (is_q ? a.Q + int64_t(grow) * a.ldq : pn.P + int64_t(grow) * pn.ldp) + koff + sc * 8;
         dst[u] = (is_q ? P_BYTES : 0) + g * 1024;
     }
     auto issue = [&](int step) {
@@ -458,6 +476,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_wide_kernel(const GemmA
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bp, bq;
     grid_tile<EPI>(a, bp, bq);
+    const int64_t koff = slab_k0<EPI>(a);
     const Panel pn = locate_panel(a, bp, BP);
     const int p0 = pn.p0, q0 = bq * BQ;
 
@@ -472,7 +491,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_wide_kernel(const GemmA
         const int r = g * 8 + (lane >> 3);                                // tile row
         const int sc = (lane & 7) ^ (r & 7);                              // source chunk that belongs at LDS chunk (lane & 7)
         const int grow = is_q ? min(q0 + r, a.NQ - 1) : min(p0 + r, pn.NP - 1);
-        src[u] = (is_q ? a.Q + int64_t(grow) * a.ldq : pn.P + int64_t(grow) * pn.ldp) + sc * 8;
+        src[u] = (is_q ? a.Q + int64_t(grow) * a.ldq : pn.P + int64_t(grow) * pn.ldp) + koff + sc * 8;
         dst[u] = (is_q ? P_BYTES : 0) + g * 1024;
     }
     auto issue = [&](int d) {
@@ -563,6 +582,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
 
     // ---- this workgroup's work ---------------------------------------------------------------------------------------
     const int G = gridDim.x, xcd = blockIdx.x & 7, lx = blockIdx.x >> 3;
+    const int64_t koff = slab_k0<EPI>(a);
     const int nx = (G - xcd + 7) >> 3;                                    // workgroups with this XCD label
     const int n_full = EPI == EPI_LINEAR ? a.npf * a.nqf : ntiles, n_edge = ntiles - n_full;
     auto share = [](int n, int x, int &start, int &count) {               // x-th of 8 near-equal contiguous shares of n
@@ -627,7 +647,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
 #pragma unroll
         for (int v = 0; v < PER_WAVE; ++v) {
             const int grow = piece_q[v] ? min(q0 + piece_row[v], a.NQ - 1) : min(pn.p0 + piece_row[v], pn.NP - 1);
-            out[v] = (piece_q[v] ? a.Q + int64_t(grow) * a.ldq : pn.P + int64_t(grow) * pn.ldp) + piece_sc[v] * 8;
+            out[v] = (piece_q[v] ? a.Q + int64_t(grow) * a.ldq : pn.P + int64_t(grow) * pn.ldp) + koff + piece_sc[v] * 8;
         }
     };
 #ifndef VLMC_GEMM_DBG
@@ -836,6 +856,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_wide_kernel(const GemmArgs a
 
     // ---- this workgroup's work ---------------------------------------------------------------------------------------
     const int G = gridDim.x, xcd = blockIdx.x & 7, lx = blockIdx.x >> 3;
+    const int64_t koff = slab_k0<EPI>(a);
     const int nx = (G - xcd + 7) >> 3;                                    // workgroups with this XCD label
     const int n_full = EPI == EPI_LINEAR ? a.npf * a.nqf : ntiles, n_edge = ntiles - n_full;
     auto share = [](int n, int x, int &start, int &count) {               // x-th of 8 near-equal contiguous shares of n
@@ -898,7 +919,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_wide_kernel(const GemmArgs a
 #pragma unroll
         for (int v = 0; v < PER_WAVE; ++v) {
             const int grow = piece_q ? min(q0 + piece_row[v], a.NQ - 1) : min(pn.p0 + piece_row[v], pn.NP - 1);
-            out[v] = (piece_q ? a.Q + int64_t(grow) * a.ldq : pn.P + int64_t(grow) * pn.ldp) + piece_sc[v] * 8;
+            out[v] = (piece_q ? a.Q + int64_t(grow) * a.ldq : pn.P + int64_t(grow) * pn.ldp) + koff + piece_sc[v] * 8;
         }
     };
 #ifndef VLMC_GEMM_DBG
@@ -1082,6 +1103,7 @@ template <typename T, int EPI, typename S> static void launch_shape(GemmArgs a, 
     }();
     int64_t nblocks = plan_panels<S>(a, EPI == EPI_LINEAR && edges);
     if (EPI == EPI_SYRK) nblocks = int64_t(a.npf) * (a.npf + 1) / 2;
+    const unsigned ny = (EPI == EPI_SYRK && a.slabs > 1) ? unsigned(a.slabs) : 1u;      // slabs of a split SYRK (slab_view)
     static const bool ring = [] {
         const char *e = getenv("VLMC_GEMM_RING");                 // 0: the register-staged kernel for every shape
         return !(e && e[0] == '0');
@@ -1105,8 +1127,8 @@ template <typename T, int EPI, typename S> static void launch_shape(GemmArgs a, 
                 const char *e = getenv("VLMC_GEMM_WIDE");         // 0: K-steps of 32 with half-line requests for every K
                 return !(e && e[0] == '0');
             }();
-            if (wide && a.K % (2 * RK) == 0) VLMC_LAUNCH_TIMED((gemm_nt_wide_kernel<T, EPI, S>), dim3(grid), dim3(S::NT), s, a, int(nblocks));
-            else VLMC_LAUNCH_TIMED((gemm_nt_pingpong_kernel<T, EPI, S>), dim3(grid), dim3(S::NT), s, a, int(nblocks));
+            if (wide && a.K % (2 * RK) == 0) VLMC_LAUNCH_TIMED((gemm_nt_wide_kernel<T, EPI, S>), dim3(grid, ny), dim3(S::NT), s, a, int(nblocks));
+            else VLMC_LAUNCH_TIMED((gemm_nt_pingpong_kernel<T, EPI, S>), dim3(grid, ny), dim3(S::NT), s, a, int(nblocks));
             return;
         }
     }
@@ -1122,9 +1144,9 @@ template <typename T, int EPI, typename S> static void launch_shape(GemmArgs a, 
         return n;
     }();
     if (ring && wide_small && a.K % (2 * RK) == 0 && S::WP * S::WQ == 4 && nblocks > cus)
-        VLMC_LAUNCH_TIMED((gemm_nt_ring_wide_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
-    else if (ring && a.K % RK == 0) VLMC_LAUNCH_TIMED((gemm_nt_ring_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
-    else VLMC_LAUNCH_TIMED((gemm_nt_kernel<T, EPI, S>), dim3(unsigned(nblocks)), dim3(S::NT), s, a);
+        VLMC_LAUNCH_TIMED((gemm_nt_ring_wide_kernel<T, EPI, S>), dim3(unsigned(nblocks), ny), dim3(S::NT), s, a);
+    else if (ring && a.K % RK == 0) VLMC_LAUNCH_TIMED((gemm_nt_ring_kernel<T, EPI, S>), dim3(unsigned(nblocks), ny), dim3(S::NT), s, a);
+    else VLMC_LAUNCH_TIMED((gemm_nt_kernel<T, EPI, S>), dim3(unsigned(nblocks), ny), dim3(S::NT), s, a);
 }
 template <typename T, int EPI> static void launch_gemm(const GemmArgs &a, hipStream_t s) {
     // big tiles once there are about as many as CUs (256): measured, 8192 x 2048 x 5120 runs at 1.19 PFLOP/s on 256 big tiles
@@ -1200,6 +1222,45 @@ __global__ __launch_bounds__(256) void symmetrize_kernel(float *H, int64_t ldh, 
     }
 }
 
+// 16-bit activations: the same transposition with 16-byte global accesses on both sides (the kernel above moves 2 bytes
+// per lane: 148 us for a [32896, 1408] input, 1.25 TB/s).  A workgroup takes 64 rows x 64 columns: every thread loads two
+// 16-byte pieces of a row (8 consecutive channels), the tile sits in LDS as 16-bit [64][72], and every thread writes two
+// 16-byte pieces of a transposed row (8 consecutive tokens of one channel, gathered by eight 2-byte LDS reads).
+// Needs ldx % 8 == 0 and 16-byte aligned pointers; tokens past T_rows are written as zeros up to Tpad.
+__global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t *__restrict__ x, int64_t ldx, int T_rows, int C,
+                                                          uint16_t *__restrict__ pt, int64_t ldt, int Tpad) {
+    __shared__ uint16_t tile[64][72];
+    const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int piece = tid + h * 256, r = piece >> 3, cc = (piece & 7) * 8;
+        const int t = t0 + r, c = c0 + cc;
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (t < T_rows && c + 7 < C) {
+            v = *reinterpret_cast<const u32x4_t *>(x + int64_t(t) * ldx + c);
+        } else if (t < T_rows && c < C) {
+            uint16_t e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < 8 && c + j < C; ++j) e[j] = x[int64_t(t) * ldx + c + j];
+            __builtin_memcpy(&v, e, 16);
+        }
+        *reinterpret_cast<u32x4_t *>(&tile[r][cc]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int piece = tid + h * 256, cr = piece >> 3, tt = (piece & 7) * 8;       // channel row of the output, 8 tokens
+        const int c = c0 + cr, t = t0 + tt;
+        if (c >= C || t >= Tpad) continue;
+        uint16_t e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = tile[tt + j][cr];
+        u32x4_t v;
+        __builtin_memcpy(&v, e, 16);
+        *reinterpret_cast<u32x4_t *>(pt + int64_t(c) * ldt + t) = v;                   // (Tpad and ldt are multiples of 64)
+    }
+}
+
 static int dtype_ok16(int dtype) { return dtype == VLMC_F16 || dtype == VLMC_BF16; }
 
 }  // namespace vlmc
@@ -1253,12 +1314,46 @@ extern "C" int vlmc_linear_fwd_group(const void *X, const vlmc_linear_job *jobs,
     return linear_group_launch("vlmc_linear_fwd_group", X, jobs, n_jobs, dtype, M, K, ldx, stream);
 }
 
+// Split of the SYRK along the rows of X.  A Hessian of 1408 columns is 66 tiles of 128 x 128 (21 of 256 x 256) on a 256-CU
+// chip, each looping over all T = 32896 rows: 369 us at 0.35 PFLOP/s.  S slabs of T / S rows give S times the workgroups; slab
+// sums are written raw and added up in slab order by syrk_combine_kernel (fixed order: deterministic, and the same for
+// every kernel variant -- the rule looks at the shape only).  16-bit activations only (fp32 ones are nine plane products
+// along K already); slabs of at least 1024 rows, a multiple of 64.
+static int syrk_slabs(int dtype, int64_t rows, int64_t n) {
+    if (dtype == VLMC_F32) return 1;
+    const int64_t tpad = (rows + 63) / 64 * 64;
+    const int64_t nb = (n + 127) / 128, tiles = nb * (nb + 1) / 2;
+    if (tiles >= 256) return 1;
+    for (int s : {8, 4, 2})
+        if (tiles * s <= 1024 && tpad % (int64_t(s) * 64) == 0 && tpad / s >= 1024) return s;
+    return 1;
+}
+
 extern "C" size_t vlmc_hessian_workspace(int dtype, int64_t rows, int64_t in_features) {
     if (rows <= 0 || in_features <= 0) return 0;
     const int64_t tpad = (rows + 63) / 64 * 64;
     const int64_t planes = dtype == VLMC_F32 ? 9 : 1;
     const int64_t one = in_features * tpad * planes * 2;
-    return size_t(dtype == VLMC_F32 ? 2 * one : one);
+    const int s = syrk_slabs(dtype, rows, in_features);
+    const int64_t ldp = (in_features + 3) / 4 * 4;
+    const int64_t parts = s > 1 ? int64_t(s) * in_features * ldp * 4 : 0;
+    return size_t((dtype == VLMC_F32 ? 2 * one : one + 15) / 16 * 16 + parts);
+}
+
+// H = alpha * H + beta * (part[0] + part[1] + ..) on the 128-blocks on and below the diagonal (what the slabs wrote)
+__global__ __launch_bounds__(256) void syrk_combine_kernel(float *__restrict__ H, int64_t ldh, int n, const float *__restrict__ part,
+                                                           int64_t slab_h, int64_t ldp, int slabs, float alpha, float beta) {
+    const int p = (blockIdx.x * 64 + (threadIdx.x & 63)), q0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
+    if (p >= n) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q = q0 + r;
+        if (q >= n || (q >> 7) < (p >> 7)) continue;
+        float sum = part[int64_t(q) * ldp + p];
+        for (int s = 1; s < slabs; ++s) sum += part[int64_t(s) * slab_h + int64_t(q) * ldp + p];
+        float *dst = H + int64_t(q) * ldh + p;
+        *dst = alpha != 0.f ? alpha * *dst + beta * sum : beta * sum;
+    }
 }
 
 extern "C" int vlmc_hessian_accum(const void *X, int dtype, int64_t rows, int64_t in_features, int64_t ldx, float *H,
@@ -1284,6 +1379,9 @@ extern "C" int vlmc_hessian_accum(const void *X, int dtype, int64_t rows, int64_
     if (dtype == VLMC_F32)
         hipLaunchKernelGGL(transpose_planes_kernel<f32_t>, tgrid, tblock, 0, s, static_cast<const float *>(X), ldx, int(rows),
                            int(in_features), pt, qt, ldt, tpad);
+    else if ((ldx & 7) == 0 && aligned16(X))
+        hipLaunchKernelGGL(transpose16_kernel, tgrid, tblock, 0, s, static_cast<const uint16_t *>(X), ldx, int(rows), int(in_features), pt,
+                           ldt, tpad);
     else if (dtype == VLMC_BF16)
         hipLaunchKernelGGL(transpose_planes_kernel<bf16_t>, tgrid, tblock, 0, s, static_cast<const uint16_t *>(X), ldx, int(rows),
                            int(in_features), pt, qt, ldt, tpad);
@@ -1302,8 +1400,21 @@ extern "C" int vlmc_hessian_accum(const void *X, int dtype, int64_t rows, int64_
     a.ldh = ldh;
     a.alpha = alpha;
     a.beta = beta;
+    const int slabs = syrk_slabs(dtype, rows, in_features);
+    if (slabs > 1) {
+        const int64_t ldp = (in_features + 3) / 4 * 4;
+        const size_t planes_bytes = (size_t(in_features) * size_t(ldt) * 2 + 15) / 16 * 16;
+        a.Hpart = reinterpret_cast<float *>(static_cast<char *>(workspace) + planes_bytes);
+        a.ldh_part = ldp;
+        a.slab_h = in_features * ldp;
+        a.slabs = slabs;
+        a.K = int(ldt / slabs);
+    }
     if (dtype == VLMC_F16) launch_gemm<f16_t, EPI_SYRK>(a, s);
     else launch_gemm<bf16_t, EPI_SYRK>(a, s);
+    if (slabs > 1)
+        hipLaunchKernelGGL(syrk_combine_kernel, dim3(unsigned((in_features + 63) / 64), unsigned((in_features + 15) / 16)), dim3(256), 0, s, H,
+                           ldh, int(in_features), a.Hpart, a.slab_h, a.ldh_part, slabs, alpha, beta);
     VLMC_HIP_CHECK_LAUNCH("vlmc_hessian_accum");
     return VLMC_OK;
 }
