@@ -100,6 +100,13 @@ class SparseGPT:
         self.factor_cache["rows_seen"] = self.factor_cache.get("rows_seen", 0) + x.shape[0]
         if _DEFER:
             self.nsamples += b
+            if not self._staged and x.numel() * 4 > _DEFER_BYTES:
+                # a grouped forward hands over all its samples in ONE call: folded in at once with the very formula `_fold`
+                # would apply to it alone -- no copy of the activations (92-404 MB per ViT-g input) is kept
+                n = self.nsamples
+                self._accumulate(x, self._folded / n, 2.0 / n)                  # :76-79 with b = this call's samples
+                self._folded = n
+                return
             self._staged.append(x.clone())               # the caller may reuse the activation's memory (graph replay)
             self._staged_elems += x.numel()
             if self._staged_elems * 4 > _DEFER_BYTES:
