@@ -426,15 +426,25 @@ __global__ __launch_bounds__(256) void dsnot_apply_kernel(typename T::raw *__res
                                                           uint8_t *__restrict__ keep, const uint32_t *__restrict__ events,
                                                           const int32_t *__restrict__ ncycles, int max_cycle, int nm_mode,
                                                           int apply_zero) {
-    extern __shared__ uint8_t row_keep[];
+    extern __shared__ __attribute__((aligned(16))) uint8_t row_keep[];     // [in_f rounded up to 16] mask bytes, then max_cycle events
     const int64_t row = blockIdx.x;
-    for (int64_t c = threadIdx.x; c < in_f; c += blockDim.x) row_keep[c] = keep[row * in_f + c];
+    uint32_t *ev = reinterpret_cast<uint32_t *>(row_keep + ((in_f + 15) & ~int64_t(15)));
+    int C = *ncycles;
+    if (C > max_cycle) C = max_cycle;
+    // 16 mask bytes (and 16 weights) per lane when the row allows it: the byte-wise version moved 64 B per wave-instruction
+    const bool vec = (in_f & 15) == 0 && (ldw & 7) == 0 && (reinterpret_cast<uintptr_t>(keep) & 15u) == 0 &&
+                     (reinterpret_cast<uintptr_t>(W) & 15u) == 0 && sizeof(typename T::raw) == 2;
+    if (vec) {
+        for (int64_t c = int64_t(threadIdx.x) * 16; c < in_f; c += int64_t(blockDim.x) * 16)
+            *reinterpret_cast<u32x4_t *>(row_keep + c) = *reinterpret_cast<const u32x4_t *>(keep + row * in_f + c);
+    } else {
+        for (int64_t c = threadIdx.x; c < in_f; c += blockDim.x) row_keep[c] = keep[row * in_f + c];
+    }
+    for (int t = threadIdx.x; t < C; t += blockDim.x) ev[t] = events[row * max_cycle + t];
     __syncthreads();
     if (threadIdx.x == 0) {
-        int C = *ncycles;
-        if (C > max_cycle) C = max_cycle;
         for (int t = 0; t < C; ++t) {
-            const uint32_t e = events[row * max_cycle + t];
+            const uint32_t e = ev[t];
             const uint32_t p = e & 0x3FFFu, r = (e >> 14) & 0x3FFFu, u = (e >> 28) & 1u;
             if (nm_mode) {
                 row_keep[p] = u ? 0 : 1;      // weight_mask[p] = update_mask   (pruned <=> keep = 0)  (:533)
@@ -446,6 +456,33 @@ __global__ __launch_bounds__(256) void dsnot_apply_kernel(typename T::raw *__res
         }
     }
     __syncthreads();
+    if (vec) {
+        for (int64_t c = int64_t(threadIdx.x) * 16; c < in_f; c += int64_t(blockDim.x) * 16) {
+            const u32x4_t kv = *reinterpret_cast<const u32x4_t *>(row_keep + c);
+            *reinterpret_cast<u32x4_t *>(keep + row * in_f + c) = kv;
+            if (apply_zero) {
+                uint8_t kb[16];
+                __builtin_memcpy(kb, &kv, 16);
+                bool all = true;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) all = all && kb[j] != 0;
+                if (!all) {
+                    typename T::raw *wp = W + row * ldw + c;
+                    u32x4_t w0 = *reinterpret_cast<const u32x4_t *>(wp), w1 = *reinterpret_cast<const u32x4_t *>(wp + 8);
+                    uint16_t e[16];
+                    __builtin_memcpy(e, &w0, 16);
+                    __builtin_memcpy(e + 8, &w1, 16);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) e[j] = kb[j] ? e[j] : uint16_t(0);
+                    __builtin_memcpy(&w0, e, 16);
+                    __builtin_memcpy(&w1, e + 8, 16);
+                    *reinterpret_cast<u32x4_t *>(wp) = w0;
+                    *reinterpret_cast<u32x4_t *>(wp + 8) = w1;
+                }
+            }
+        }
+        return;
+    }
     for (int64_t c = threadIdx.x; c < in_f; c += blockDim.x) {
         const uint8_t k = row_keep[c];
         keep[row * in_f + c] = k;
@@ -590,7 +627,7 @@ extern "C" int vlmc_dsnot_apply(void *W, int dtype, int64_t out_features, int64_
     VLMC_REQUIRE(W && keep_mask && events && ncycles, "vlmc_dsnot_apply: null pointer");
     VLMC_REQUIRE(out_features > 0 && in_features > 0 && in_features <= 16384, "vlmc_dsnot_apply: bad shape");
     hipStream_t st = as_stream(stream);
-    const size_t lds = size_t(in_features);
+    const size_t lds = ((size_t(in_features) + 15) & ~size_t(15)) + size_t(max_cycle > 0 ? max_cycle : 1) * 4;
 #define VLMC_AP(T) hipLaunchKernelGGL((dsnot_apply_kernel<T>), dim3(unsigned(out_features)), dim3(256), lds, st,              \
                                       static_cast<T::raw *>(W), out_features, in_features, ldw, keep_mask, events, ncycles,     \
                                       max_cycle, nm_mode, apply_zero)
