@@ -382,12 +382,18 @@ __device__ __forceinline__ uint32_t dl_extract(const uint32_t (&key)[E], DVal dv
 // `place(which, col, rank)`: called by one thread per entry; which = 0 the ascending list, 1 the descending one.
 template <int E, int NT, int NW, typename S, typename DVal, typename Place>
 __device__ __forceinline__ uint32_t dl_extract_both(const uint32_t (&key)[E], DVal dval, uint32_t mask, uint32_t K, S &sm, ListEntry *outA,
-                                                    ListEntry *outD, Place place, int fast) {
+                                                    ListEntry *outD, Place place, int fast, uint32_t flood_key, uint32_t wlog) {
+    // `wlog` != 0: WINDOWED bins.  Signed keys (the regrow vector G) span the whole 32-bit range -- 1024 linear bins are a quarter
+    // of an octave each, the 100 largest of a few thousand values share two or three of them (hundreds of candidates, LDS
+    // atomics on a handful of addresses).  Both lists of G end at LARGE magnitudes, so only the 2^wlog keys next to the
+    // minimum (512 bins) and next to the maximum (512 bins) are binned, 1/128 octave each for wlog = 25; everything between
+    // is one uncounted gap.  An end whose window holds fewer than K elements falls back to the single-list code.
     const int tid = threadIdx.x;
     const uint32_t avail = dl_block_sum<NT, NW>(uint32_t(__popc(mask)), sm, 0);
     const uint32_t n = avail < K ? avail : K;
     if (n == 0) return 0;
     if (fast && avail >= 2u * n) {
+        constexpr uint32_t kNoBin = 0xFFFFFFFFu;
         uint32_t tid8 = uint32_t(tid) * 8u;
         auto colof = [&](int i) { return uint32_t((i / 8) * NT * 8 + (i % 8)) + tid8; };
         uint32_t lo = 0xFFFFFFFFu, hi = 0u;
@@ -412,18 +418,34 @@ __device__ __forceinline__ uint32_t dl_extract_both(const uint32_t (&key)[E], DV
             }
         }
         lo = dl_uniform(lo);
-        const uint32_t span = dl_uniform(hi) - lo;
+        hi = dl_uniform(hi);
+        const uint32_t span = hi - lo;
         uint32_t shift = span < uint32_t(kFastBins) ? 0u : uint32_t(32 - __builtin_clz(span)) - uint32_t(kFastBinsLog2);
+        const bool win = wlog != 0 && (span >> 1) >= (1u << wlog);        // the two windows do not meet
+        const uint32_t W = 1u << wlog, wsh = wlog - 9u;
+        auto binof = [&](uint32_t k) -> uint32_t {
+            if (!win) return (k - lo) >> shift;
+            const uint32_t da = k - lo, dd = hi - k;
+            return da < W ? da >> wsh : (dd < W ? uint32_t(kFastBins - 1) - (dd >> wsh) : kNoBin);
+        };
         for (int i = tid; i < kFastBins; i += NT) sm.hist[i] = 0;
+        if (tid == 0) { sm.red[3] = kNoBin; sm.red[5] = kNoBin; }
         dl_sync<NW>();
+        // `flood_key`: the ONE key half of the elements may share (the regrow keys of all kept columns are G = 0; zero weights have
+        // metric 0): counted in a register and added to its bin once per thread.
         const uint32_t mk1 = dl_opaque(mask);
+        uint32_t flood = 0;
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const uint32_t bin = (key[i] - lo) >> shift;
-            atomicAdd(&sm.hist[((mk1 >> i) & 1u) ? bin : uint32_t(kFastBins + 1 + (tid & 63))], 1u);
+            const uint32_t bin = binof(key[i]);
+            const bool in = (mk1 >> i) & 1u, fl = in && key[i] == flood_key;
+            flood += fl ? 1u : 0u;
+            atomicAdd(&sm.hist[(in && !fl && bin != kNoBin) ? bin : uint32_t(kFastBins + 1 + (tid & 63))], 1u);
         }
+        if (flood && binof(flood_key) != kNoBin) atomicAdd(&sm.hist[binof(flood_key)], flood);
         dl_sync<NW>();
         lo = dl_uniform(lo);
+        hi = dl_uniform(hi);
         shift = dl_uniform(shift);
         const uint32_t need_d = avail - n;                              // ascending position of the descending list's last entry
         if (tid < 64) {
@@ -432,7 +454,11 @@ __device__ __forceinline__ uint32_t dl_extract_both(const uint32_t (&key)[E], DV
             uint32_t ssum = 0;
 #pragma unroll
             for (int i = 0; i < PER; ++i) { h[i] = sm.hist[tid * PER + i]; ssum += h[i]; }
-            const uint32_t incl = dl_wave_incl_scan(ssum);
+            const uint32_t incl0 = dl_wave_incl_scan(ssum);
+            const uint32_t counted = uint32_t(__builtin_amdgcn_readlane(int(incl0), 63));
+            // windowed: the uncounted gap sits between bins 511 and 512 (lanes 31 and 32) of the ascending order
+            const uint32_t gap = (win && tid >= 32) ? avail - counted : 0u;
+            const uint32_t incl = incl0 + gap;
             uint32_t cum = incl - ssum;
             const bool mine_a = cum < n && n <= incl;
             const bool mine_d = cum <= need_d && need_d < incl;
@@ -456,7 +482,9 @@ __device__ __forceinline__ uint32_t dl_extract_both(const uint32_t (&key)[E], DV
         }
         dl_sync<NW>();
         const uint32_t cut_a = sm.red[3], m_a = sm.red[4], cut_d = sm.red[5], m_d = sm.red[6];
-        if (m_a <= uint32_t(S::RAWCAP) && m_d <= uint32_t(S::RAWCAP) && cut_a < cut_d) {
+        const bool ends_ok = cut_a != kNoBin && cut_d != kNoBin && cut_a < cut_d &&
+                             (!win || (cut_a < uint32_t(kFastBins / 2) && cut_d >= uint32_t(kFastBins / 2)));
+        if (ends_ok && m_a <= uint32_t(S::RAWCAP) && m_d <= uint32_t(S::RAWCAP)) {
             // slots are handed out from the END of each bin's range downwards (hist[b] counts down from the inclusive prefix to the
             // bin's start): ascending position p of a candidate; the descending list stores it at avail - 1 - p
             const uint32_t mk2 = dl_opaque(mask);
@@ -465,8 +493,8 @@ __device__ __forceinline__ uint32_t dl_extract_both(const uint32_t (&key)[E], DV
             for (int i = 0; i < E; ++i)
                 if ((mk2 >> i) & 1u) {
                     const uint32_t kk = key[i];
-                    const uint32_t bin = (kk - lo) >> shift;
-                    if (bin <= cut_a || bin >= cut_d) {
+                    const uint32_t bin = binof(kk);
+                    if (bin != kNoBin && (bin <= cut_a || bin >= cut_d)) {
                         const uint32_t p = atomicSub(&sm.hist[bin], 1u) - 1u;
                         const uint32_t which = bin <= cut_a ? 0u : 1u;
                         const uint32_t pos = which ? avail - 1u - p : p;
@@ -479,7 +507,7 @@ __device__ __forceinline__ uint32_t dl_extract_both(const uint32_t (&key)[E], DV
                 const bool desc = p >= m_a;
                 const uint32_t q0 = desc ? p - m_a : p;
                 const uint32_t kp = sm.rawk[desc ? 1 : 0][q0], cp = sm.rawc[desc ? 1 : 0][q0];
-                const uint32_t bin = (kp - lo) >> shift;
+                const uint32_t bin = binof(kp);
                 const uint32_t excl = sm.hist[bin];                     // (counted down to the bin's start)
                 uint32_t rank;
                 if (!desc) {
@@ -633,7 +661,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) vo
         };
         {
             auto place = [&](uint32_t which, uint32_t col, uint32_t rank) { payload(which, col, rank); };
-            const uint32_t got = dl_extract_both<E, NT, NW>(gk, dval, live, K, sm, sm.list[0], sm.list[1], place, fast);
+            const uint32_t got = dl_extract_both<E, NT, NW>(gk, dval, live, K, sm, sm.list[0], sm.list[1], place, fast, 0x80000000u, 25u);
             if (tid == 0) { sm.nlist[0] = got; sm.nlist[1] = got; }
         }
     } else {
@@ -644,7 +672,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) vo
         // lists 0/1: regrow candidates by G, ascending / descending; 2/3: kept columns with D < 0 by metric; 4/5: with D > 0;
         // 6 (K0): the kept column with the smallest wanda metric (head of the ascending list over ALL kept columns)
         {                                                              // (gk is dead after this: 32 registers less)
-            const uint32_t got = dl_extract_both<E, NT, NW>(gk, dval, live, K, sm, sm.list[0], sm.list[1], no_place, fast);
+            const uint32_t got = dl_extract_both<E, NT, NW>(gk, dval, live, K, sm, sm.list[0], sm.list[1], no_place, fast, 0x80000000u, 25u);
             if (tid == 0) { sm.nlist[0] = got; sm.nlist[1] = got; }
         }
         // the prune lists' key: the wanda metric |w| * sqrt(scaler), from the row again
@@ -666,7 +694,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) vo
 #pragma unroll 1
         for (uint32_t li = 2; li < 6; li += 2) {                       // both ends of the negative-D pool, then of the positive-D pool
             const uint32_t msk = li < 4 ? negm : posm;
-            const uint32_t got = dl_extract_both<E, NT, NW>(wk, dval, msk, K, sm, sm.list[li], sm.list[li + 1], no_place, fast);
+            const uint32_t got = dl_extract_both<E, NT, NW>(wk, dval, msk, K, sm, sm.list[li], sm.list[li + 1], no_place, fast, 0u, 0u);
             if (tid == 0) { sm.nlist[li] = got; sm.nlist[li + 1] = got; }
         }
         // K0, the kept column with the smallest (metric, column): a min-reduction of key : column pairs
