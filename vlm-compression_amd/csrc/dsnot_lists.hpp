@@ -761,12 +761,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) vo
         if constexpr (NM) {
             const uint32_t g0 = rcol - rcol % uint32_t(prune_m);
             // visits of this group so far = entries of its sorted kept list already taken
-            uint32_t cnt = 0;
-            for (int base = 0; base < t; base += 64) {
-                const int q = base + lane;
-                const bool hit = q < t && sm.cyc_group[q] == g0;
-                cnt += uint32_t(__popcll(__ballot(hit)));
-            }
+            // (both halves of the history are requested at once -- max_cycle <= 128 = 2 x 64 lanes -- instead of one LDS round trip
+            //  per 64 cycles inside the chain)
+            const uint32_t h0 = sm.cyc_group[lane], h1 = sm.cyc_group[lane + 64];
+            const uint32_t cnt = uint32_t(__popcll(__ballot(lane < t && h0 == g0))) + uint32_t(__popcll(__ballot(lane + 64 < t && h1 == g0)));
             const GroupInfo &gi = sm.grp[r_tail ? 1 : 0][ridx];
             if (cnt < gi.n) {
                 pcol = gi.col[cnt]; pd = gi.d[cnt];
