@@ -38,26 +38,31 @@ def _clamp_inf(H):
         H[neg] = torch.quantile(H, 0.001)
 
 
-def _chol_with_damping(H, damp, upper):
+def _chol_with_damping(H, damp, upper, trace=None, which=None):
     idx = torch.arange(H.shape[0])
+    steps = 0
     while True:
         L, info = torch.linalg.cholesky_ex(H, upper=upper)
         if int(info) == 0 and not torch.isnan(L).any():
+            if trace is not None:
+                trace[which] = steps            # how often this loop damped: the route the reference took
             return L
         H[idx, idx] += damp                     # damping is added ONLY after a failure (:114-128)
+        steps += 1
 
 
-def inverse_factor(H: torch.Tensor, W: torch.Tensor, percdamp=0.01):
-    """Upper Cholesky factor U of H^-1 (U^T U = H^-1); zeroes W's dead columns in place."""
+def inverse_factor(H: torch.Tensor, W: torch.Tensor, percdamp=0.01, trace=None):
+    """Upper Cholesky factor U of H^-1 (U^T U = H^-1); zeroes W's dead columns in place.  `trace` (a dict) receives the
+    number of damping steps of the two loops (:112-128, :139-150) as "damp_H" / "damp_Hinv"."""
     H = H.clone()
     dead = torch.diag(H) == 0
     H[dead, dead] = 1
     W[:, dead] = 0
     _clamp_inf(H)
-    L = _chol_with_damping(H, percdamp * torch.mean(torch.diag(H)), upper=False)
+    L = _chol_with_damping(H, percdamp * torch.mean(torch.diag(H)), upper=False, trace=trace, which="damp_H")
     Hi = torch.cholesky_inverse(L)
     _clamp_inf(Hi)
-    return _chol_with_damping(Hi, percdamp * torch.mean(torch.diag(Hi).abs()), upper=True)
+    return _chol_with_damping(Hi, percdamp * torch.mean(torch.diag(Hi).abs()), upper=True, trace=trace, which="damp_Hinv")
 
 
 def block_mask_unstructured(W1, diag1, sparsity):
@@ -90,10 +95,10 @@ def sweep_block(W1, U1, mask1, prune_n, prune_m):
 
 
 @torch.no_grad()
-def prune(weight: torch.Tensor, H: torch.Tensor, sparsity, prune_n=0, prune_m=0, blocksize=128, percdamp=0.01):
+def prune(weight: torch.Tensor, H: torch.Tensor, sparsity, prune_n=0, prune_m=0, blocksize=128, percdamp=0.01, trace=None):
     """`fasterprune`: returns (new weight in weight.dtype, importance_score, pruned mask bool)."""
     W = weight.detach().clone().float()
-    U = inverse_factor(H, W, percdamp)
+    U = inverse_factor(H, W, percdamp, trace)
     score = W ** 2 / torch.diag(U).reshape(1, -1) ** 2
     importance = score.abs().mean().item()
     cols = W.shape[1]

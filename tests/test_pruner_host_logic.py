@@ -420,6 +420,64 @@ def test_walk_blocks_replays_sample_by_sample_when_kwargs_cannot_be_stacked(monk
         assert torch.equal(got[j], want[j]), j
 
 
+@pytest.mark.parametrize("method", ["wanda", "dsnot", "sparsegpt"])
+def test_unstackable_kwargs_keep_per_sample_statistics_of_every_method(method, monkeypatch):
+    """when a group's kwargs cannot be stacked (`_stack_caches` -> None) the chunk is replayed sample by sample and
+    every sample must be announced to the collectors (`before_sample(j)`), as in the `group_max == 1` loop: the pruned
+    model equals the per-sample loop's bit for bit, for ragged (non-contiguous) chunks too."""
+    import toy_models
+    from lavis.compression import load_pruner
+    from lavis.compression.pruners import calibration as cal
+    {"wanda": oracle_ops.install, "dsnot": oracle_ops.install_dsnot, "sparsegpt": oracle_ops.install_sparsegpt}[method](monkeypatch)
+    torch.set_num_threads(1)
+    lens = [5, 7, 5, 5, 7, 3]                                        # interleaved shapes: chunks of non-neighbouring samples
+
+    def run(group, unstackable):
+        monkeypatch.setenv("VLMC_BATCH_REPLAY", str(group))
+        if unstackable:
+            monkeypatch.setattr(cal, "_stack_caches", lambda grp, b0: None)
+        model = toy_models.init_toy(toy_models.ToyBlipT5(), seed=3).eval()
+        batches = [toy_models.make_batches(1, txt_len=n, out_len=2 + n % 3, seed=40 + j)[0] for j, n in enumerate(lens)]
+        spec = "2-0.5-1.0-1.0"
+        cfg = dict(t5_prune_spec=spec, vit_prune_spec=spec, t5_pruning_method=method, vit_pruning_method=method,
+                   num_samples=len(lens), max_sparsity_per_layer=1.01)
+        if method == "dsnot":
+            cfg["max_cycle_time"] = 8
+        pruned, _ = load_pruner(f"blipt5_{method}_pruner", model, batches, cfg=cfg).prune()
+        return {k: v.clone() for k, v in pruned.state_dict().items()}
+
+    announced = []
+    if method != "sparsegpt":
+        from lavis.compression.pruners import dsnot_pruner, wanda_pruner
+        klass = wanda_pruner.WandaStatCollector if method == "wanda" else dsnot_pruner.DsnotStatCollector
+        real_next = klass.next_sample
+
+        def spy(self, j=None):
+            announced.append(j)
+            return real_next(self, j)
+        monkeypatch.setattr(klass, "next_sample", spy)
+    per_sample = run(1, False)
+    n_loop = len(announced)
+    forced = run(128, True)
+    if method != "sparsegpt":
+        # every sample of every statistics pass is announced, exactly as often as in the per-sample loop
+        assert n_loop and len(announced) == 2 * n_loop
+        assert sorted(announced[:n_loop]) == sorted(announced[n_loop:])
+    assert per_sample.keys() == forced.keys()
+    if method == "sparsegpt":
+        # the Hessian's running mean takes the samples chunk by chunk (0, 2, 3 | 1, 4 | 5): another fp32 summation order,
+        # the same matrix -- every sample counted once (the pruner asserts nsamples), masks agree up to near-ties
+        tot = agree = 0
+        for k in per_sample:
+            if per_sample[k].dim() == 2 and ".block" in k:
+                tot += per_sample[k].numel()
+                agree += int(((per_sample[k] == 0) == (forced[k] == 0)).sum())
+        assert tot and agree / tot > 0.97
+        return
+    for k in per_sample:
+        assert torch.equal(per_sample[k], forced[k]), k
+
+
 def test_deferred_importance_scores_survive_a_failing_tower(monkeypatch):
     """`prune()` postpones the importance-score readback to its end; if a tower raises, the flag must not outlive the call
     and the towers already pruned still get their scores."""

@@ -1570,7 +1570,9 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                         _STACKED = (len(chunk), b0, tuple(chunk))
                     if kw is False:                                 # kwargs that cannot be stacked: sample by sample
                         _STACKED = None
-                        for j in chunk:
+                        for t, j in enumerate(chunk):
+                            if t and before_sample is not None:     # (chunk[0] was announced above; the per-sample
+                                before_sample(j)                    # loop announces every sample, like group_max == 1)
                             if so is not None:
                                 so.new_forward()
                             try:

@@ -353,9 +353,14 @@ def factorize_many(items, percdamp=0.01, max_streams=8, history=None):
     device; k = 0, 1 first, the next two in a second round if neither is clean) and the first clean one in k order is
     taken: what the reference's loop would have stopped at, without a host decision between attempts.  `history` (a dict the caller keeps per tower) remembers which inputs needed damping in
     the previous block: an input that did not is tried undamped only (the T5 decoder's 16-token samples give Hessians of
-    fewer rows than columns in every block, a ViT block's never do).  An input whose attempts all fail -- and the rare
-    factor that is clean here but whose second damping loop the reference would enter (NaN in it) -- takes `factorize`,
-    the reference's three steps with both loops, unchanged."""
+    fewer rows than columns in every block, a ViT block's never do).  An input whose attempts all fail -- and one whose
+    attempt factorizes without a failing pivot but leaves NaN in the inverse factor (the reference's first loop passes such
+    an H and its second loop damps Hinv) -- takes `factorize`, the reference's three steps with both loops, unchanged; the
+    dead-column mask is the one computed here, before the diagonal was filled.
+    Hessians of no more rows than columns (`rows_seen <= n`: singular, or nearly) stay on THIS route, unlike in `factorize`:
+    a singular H fails at k = 0 and is clean at k = 1 -- the reference's own decision on its rank-deficient golden
+    (tests/test_oracle_golden.py::test_sparsegpt_damping_route_of_the_reference_on_the_rank_deficient_golden: one damping step
+    on H, none on Hinv) and fp64's; tests/test_sparsegpt_gpu.py holds the route taken here against both."""
     todo = [(H, c) for H, c in items if "U" not in c]
     if not todo:
         return
@@ -385,7 +390,11 @@ def factorize_many(items, percdamp=0.01, max_streams=8, history=None):
             else:
                 Hk = H
             U, info = inverse_upper_factor(Hk, slot=slot)
-            bad = (info != 0).any() | torch.isnan(U).any() | torch.isinf(Hk).any()
+            failed = (info != 0).any()
+            nan = torch.isnan(U).any()
+            # [not clean, "factorized without a failing pivot but the inverse factor holds NaN"]: the second is not a case
+            # for more damping of H -- the reference's first loop would pass such an H and damp Hinv in its second (:139-150)
+            bad = torch.stack([failed | nan | torch.isinf(Hk).any(), nan & ~failed])
         for t in (U, bad):
             t.record_stream(main)
         return U, bad
@@ -402,14 +411,24 @@ def factorize_many(items, percdamp=0.01, max_streams=8, history=None):
         main.wait_stream(st)
     flags = torch.stack([bad for att in attempts for _, _, bad in att]).cpu().tolist()       # the ONE host read
     pos, retry = 0, []
+
+    def reference_chain(idx, H, c, dead):
+        # the reference's three steps with both damping loops, from the undamped H (its dead diagonal already filled: the
+        # mask computed up front is the one to keep -- `factorize` would find none)
+        history[idx] = 3
+        U, _ = factorize(H, percdamp, rows_seen=c.get("rows_seen"), try_direct=False)
+        c["U"], c["dead"] = U, dead
+
     for idx, ((H, c, dead, damp, ks), att) in enumerate(zip(prepared, attempts)):
         fl = flags[pos:pos + len(att)]
         pos += len(att)
-        ok = [k for (k, _, _), f in zip(att, fl) if not f]
-        if ok:
-            k = ok[0]
+        first_ok = next((i for i, f in enumerate(fl) if not f[0]), None)
+        if any(f[1] for f in (fl if first_ok is None else fl[:first_ok])):
+            reference_chain(idx, H, c, dead)                     # an earlier attempt factorized but its inverse holds NaN
+        elif first_ok is not None:
+            k = att[first_ok][0]
             factor_stats["direct" if k == 0 else "damped"] = factor_stats.get("direct" if k == 0 else "damped", 0) + 1
-            c["U"], c["dead"] = att[ks.index(k)][1], dead
+            c["U"], c["dead"] = att[first_ok][1], dead
             history[idx] = k
         else:
             retry.append((idx, H, c, dead, damp, ks))
@@ -423,14 +442,13 @@ def factorize_many(items, percdamp=0.01, max_streams=8, history=None):
         for idx, H, c, dead, att in second:
             fl = fl2[pos:pos + len(att)]
             pos += len(att)
-            ok = [k for (k, _, _), f in zip(att, fl) if not f]
-            if ok:
+            first_ok = next((i for i, f in enumerate(fl) if not f[0]), None)
+            if first_ok is not None and not any(f[1] for f in fl[:first_ok]):
                 factor_stats["damped"] = factor_stats.get("damped", 0) + 1
-                c["U"], c["dead"] = att[[a[0] for a in att].index(ok[0])][1], dead
-                history[idx] = ok[0]
-            else:                                                # more than two damping steps, or a factor with NaN: the reference's route
-                history[idx] = 3
-                c["U"], c["dead"] = factorize(H, percdamp, rows_seen=c.get("rows_seen"), try_direct=False)
+                c["U"], c["dead"] = att[first_ok][1], dead
+                history[idx] = att[first_ok][0]
+            else:                                                # more than three damping steps, or a factor with NaN: the reference's route
+                reference_chain(idx, H, c, dead)
 
 
 @torch.no_grad()
@@ -482,14 +500,23 @@ def sweep_block(W: torch.Tensor, i1: int, i2: int, U: torch.Tensor, mask1, prune
 
 _SELECT_SWEEP = __import__("os").environ.get("VLMC_SGPT_SELECT_SWEEP", "1") != "0"
 _select_ws = {}            # device index -> the zero-filled workspace of vlmc_sparsegpt_select_sweep (returned zero by every call)
-SELECT_SWEEP_MAX_ROWS = 16384
+_sweep_rows = {}          # device index -> rows the one-launch threshold + sweep takes on that part
 
 
-def select_sweep_usable(rows_per_scope):
+def select_sweep_max_rows(device=None):
+    """2 workgroups of 32 rows per CU of the device (the C entry point computes the same limit from the CU count and
+    returns VLMC_EINVAL above it): 16 384 on an MI355X."""
+    idx = torch.cuda.current_device() if device is None or torch.device(device).index is None else torch.device(device).index
+    if idx not in _sweep_rows:
+        _sweep_rows[idx] = 2 * 32 * torch.cuda.get_device_properties(idx).multi_processor_count
+    return _sweep_rows[idx]
+
+
+def select_sweep_usable(rows_per_scope, device=None):
     """The one-launch threshold + sweep takes up to 4 stacked linears and as many rows as 2 x CUs workgroups of 32 hold
     (include/vlmc.h; a scope's last workgroup may be partly empty, hence the margin)."""
     return (_SELECT_SWEEP and 1 <= len(rows_per_scope) <= 4 and all(r > 0 for r in rows_per_scope)
-            and sum(rows_per_scope) + 32 * len(rows_per_scope) <= SELECT_SWEEP_MAX_ROWS)
+            and sum(rows_per_scope) + 32 * len(rows_per_scope) <= select_sweep_max_rows(device))
 
 
 def select_sweep_block(W: torch.Tensor, i1: int, i2: int, U: torch.Tensor, rows_per_scope, ranks, err: torch.Tensor,
@@ -535,7 +562,7 @@ def fasterprune(layer, H: torch.Tensor, sparsity, prune_n=0, prune_m=0, blocksiz
     rows, cols = W.shape
     err = torch.empty((rows, min(blocksize, cols)), dtype=torch.float32, device=W.device)
     pruned = torch.zeros((rows, cols), dtype=torch.bool, device=W.device) if return_mask else None
-    fused = prune_n == 0 and _SELECT_THRESHOLD and select_sweep_usable([rows])
+    fused = prune_n == 0 and _SELECT_THRESHOLD and select_sweep_usable([rows], W.device)
     for i1 in range(0, cols, blocksize):
         i2 = min(i1 + blocksize, cols)
         mask1 = None
@@ -594,7 +621,7 @@ def fasterprune_group(layers, sparsities, factor_cache, prune_n=0, prune_m=0, bl
     means = [(W[bounds[i]:bounds[i + 1]] ** 2 / dsq).abs().mean() for i in range(len(layers))]
     err = torch.empty((W.shape[0], min(blocksize, cols)), dtype=torch.float32, device=W.device)
     keep = torch.empty((W.shape[0], min(blocksize, cols)), dtype=torch.bool, device=W.device) if prune_n == 0 else None
-    fused = prune_n == 0 and _SELECT_THRESHOLD and select_sweep_usable(rows)
+    fused = prune_n == 0 and _SELECT_THRESHOLD and select_sweep_usable(rows, W.device)
     for i1 in range(0, cols, blocksize):
         i2 = min(i1 + blocksize, cols)
         mask1 = None
