@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLMC_ABI_VERSION 5
+#define VLMC_ABI_VERSION 6
 
 #define VLMC_OK 0
 #define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
@@ -52,8 +52,8 @@ int vlmc_abi_version(void);
 const char *vlmc_last_error(void);
 
 /* Timing hook for benchmarks (no reference counterpart): the next statistics or select kernel launched from the
- * calling thread -- vlmc_act_sqnorm[_batch], vlmc_wanda_select[_batch] (first launch of the call), vlmc_linear_fwd,
- * vlmc_hessian_accum (its matrix-core kernel) -- records its own
+ * calling thread -- vlmc_act_sqnorm[_batch], vlmc_wanda_select[_batch] (first launch of the call), vlmc_linear_fwd[_group],
+ * vlmc_attn_matmul, vlmc_hessian_accum (its matrix-core kernel) -- records its own
  * begin / end timestamps into the caller's HIP events (hipEvent_t, created by the caller with timing enabled) through
  * hipExtLaunchKernel: hipEventElapsedTime(start, stop) is then the kernel's duration, and no marker packet sits
  * between kernels (hipEventRecord between two kernels idles an MI355X for ~5 us).  Either event may be NULL; the pair
@@ -205,6 +205,21 @@ typedef struct vlmc_linear_job {
 } vlmc_linear_job;
 int vlmc_linear_fwd_group(const void *X, const vlmc_linear_job *jobs /* host array */, int n_jobs /* 1..4 */, int dtype,
                           int64_t M, int64_t K, int64_t ldx, void *stream);
+
+/* ---- batched attention products of the calibration forward (MFMA) ---------------------------------
+ * Replaces the batched matmuls inside the attention of a replayed block -- `attn = q @ k.transpose(-2, -1)` and `attn @ v`
+ * (eva_vit.py:147,164), `torch.matmul(query_states, key_states.transpose(3, 2))` and `torch.matmul(attn_weights,
+ * value_states)` (modeling_t5.py:590,638; modeling_llama.py likewise) -- for 16-bit operands of one dtype:
+ *     C[b0, b1, m, n] = wd(sum_k A[b0, b1, m, k] * B[b0, b1, k, n])        fp32 accumulation, ONE rounding to the dtype
+ * Operands are read in place through their ELEMENT strides (sa_* for A's batch dims and rows, A's k stride is 1;
+ * sb_* for B: either sb_k == 1 -- B is a transposed view of K-contiguous rows, q @ k^T -- or sb_n == 1 -- attn @ v;
+ * sc_* for C, whose n stride is 1).  A batch stride of 0 broadcasts.  Rows need not be 16-byte aligned (2-byte aligned
+ * pointers suffice).  Batch-invariant like vlmc_linear_fwd: every output element is ONE accumulator fed the K-steps of 32
+ * in ascending order (tail zero-padded) by v_mfma_f32_16x16x32, whatever batch0 x batch1, M and N are -- the products of
+ * one calibration sample have the same bits alone, in a group of 128, or on another GPU.                     */
+int vlmc_attn_matmul(const void *A, const void *B, void *C, int dtype, int64_t batch0, int64_t batch1, int64_t M, int64_t N,
+                     int64_t K, int64_t sa_b0, int64_t sa_b1, int64_t sa_m, int64_t sb_b0, int64_t sb_b1, int64_t sb_k,
+                     int64_t sb_n, int64_t sc_b0, int64_t sc_b1, int64_t sc_m, void *stream);
 
 /* ---- K8: SparseGPT Hessian accumulation (MFMA SYRK) -------------------------------------------------
  * Replaces the arithmetic of SparseGPT.add_batch, sparsegpt_pruner.py:76-79

@@ -69,7 +69,7 @@ rank = int(os.environ["RANK"])
 torch.cuda.set_device(rank)
 dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
 import pruner_helpers as H, toy_models
-toy_models.ToyAttention.use_sdpa = True
+toy_models.ToyAttention.use_sdpa = {attention!r}
 out = {{tag: {{k: v.cpu() for k, v in H.run_16bit_toy(tag, f"cuda:{{rank}}", ragged=(tag == "dsnot")).items()}} for tag in ("wanda", "dsnot")}}
 torch.save(out, os.path.join({out!r}, f"rank{{rank}}.pt"))
 dist.barrier()
@@ -83,7 +83,7 @@ def test_sample_sharded_pruners_over_rccl_equal_single_process(tmp_path):
         pytest.skip("RCCL needs one GPU per rank; this box has one")
     import pruner_helpers as H
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER.format(root=ROOT, out=str(tmp_path)))
+    script.write_text(_WORKER.format(root=ROOT, out=str(tmp_path), attention=True))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -110,14 +110,16 @@ _WORKER_GLOO = _WORKER.replace('torch.cuda.set_device(rank)', 'torch.cuda.set_de
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world", [2, 4])
-def test_sample_sharding_with_the_kernels_is_bit_identical_to_single_process(world, tmp_path):
-    """Two / four ranks sharing cuda:0 (collectives over gloo): each captures and replays its half of the calibration samples with
-    the real kernels, one all-gather of statistics per block -- masks, weights and importance scores of both ranks equal the
-    single-process run bit for bit (Wanda; DSnoT on ragged text)."""
+@pytest.mark.parametrize("world,attention", [(2, True), (2, "matmul16"), (4, "matmul16")])
+def test_sample_sharding_with_the_kernels_is_bit_identical_to_single_process(world, attention, tmp_path):
+    """Two / four ranks sharing cuda:0 (collectives over gloo): each captures and replays its share of the calibration samples with
+    the real kernels, one all-gather of statistics per block -- masks, weights and importance scores of every rank equal the
+    single-process run bit for bit (Wanda; DSnoT on ragged text).  `attention`: SDPA, or the reference's own op sequence --
+    batched 16-bit `torch.matmul`s (modeling_t5.py:590,638), which run on vlmc_attn_matmul during the replay: ranks form other
+    groups than one process does, and the masks still do not depend on the world size."""
     import pruner_helpers as H
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER_GLOO.format(root=ROOT, out=str(tmp_path)))
+    script.write_text(_WORKER_GLOO.format(root=ROOT, out=str(tmp_path), attention=attention))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -126,7 +128,7 @@ def test_sample_sharding_with_the_kernels_is_bit_identical_to_single_process(wor
               "--master-port", str(port), str(script)], timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     import toy_models
-    toy_models.ToyAttention.use_sdpa = True        # (restored by the fixture below)
+    toy_models.ToyAttention.use_sdpa = attention   # (restored by the fixture below)
     for tag in ("wanda", "dsnot"):
         single = {k: v.cpu() for k, v in H.run_16bit_toy(tag, "cuda:0", ragged=(tag == "dsnot")).items()}
         for rank in range(world):

@@ -36,6 +36,8 @@ class ToyAttention(nn.Module):
     # False (the goldens were generated this way): explicit fp32 matmul + softmax, like the reference's T5 / EVA attention.
     # True: F.scaled_dot_product_attention in the input dtype -- per (sample, head) by construction, which a batched
     # `torch.matmul` is not (the GEMM library picks its kernel by batch count); the batch-invariance tests set it.
+    # "matmul16": batched matmuls in the activation dtype, the reference's own op sequence -- on the GPU these run on
+    # vlmc_attn_matmul during the replay (vlmc/forward.py: invariant_matmuls).
     use_sdpa = False
 
     def __init__(self, dim, heads, fused_qkv, cross=False):
@@ -59,9 +61,17 @@ class ToyAttention(nn.Module):
             src = x if kv is None else kv
             q, k, v = _lin(self.q, x, dense), _lin(self.k, src, dense), _lin(self.v, src, dense)
         S = k.shape[1]
-        if self.use_sdpa:
+        if self.use_sdpa is True:
             q, k, v = (t.reshape(B, -1, h, D // h).transpose(1, 2) for t in (q, k, v))
             y = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, T, D)
+            return _lin(self.proj if self.fused else self.o, y, dense)
+        if self.use_sdpa == "matmul16":
+            # the reference's op sequence in the activation dtype (modeling_t5.py:590-638: `torch.matmul` scores, fp32 softmax
+            # cast back, `torch.matmul(attn, v)`; eva_vit.py:144-164 with `q * scale` first): batched 16-bit matmuls
+            q, k, v = (t.reshape(B, -1, h, D // h).transpose(1, 2) for t in (q, k, v))
+            scores = torch.matmul(q * (D // h) ** -0.5, k.transpose(3, 2))
+            a = torch.softmax(scores.float(), dim=-1).type_as(scores)
+            y = (a @ v).transpose(1, 2).reshape(B, T, D)
             return _lin(self.proj if self.fused else self.o, y, dense)
         q = q.reshape(B, T, h, D // h).transpose(1, 2).float()
         k = k.reshape(B, S, h, D // h).transpose(1, 2).float()

@@ -1,0 +1,282 @@
+// Batched attention products of the calibration forward (gfx950): vlmc_attn_matmul.
+//
+//   C[b0][b1][m][n] = wd( sum_k A[b0][b1][m][k] * B[b0][b1][k][n] )          16-bit operands of one dtype, fp32 accumulate
+//
+// The reference's model files write attention as batched matmuls -- `attn = q @ k.transpose(-2, -1)`, `attn @ v`
+// (eva_vit.py:147,164), `torch.matmul(query_states, key_states.transpose(3, 2))`, `torch.matmul(attn_weights, value_states)`
+// (modeling_t5.py:590,638; modeling_llama.py likewise) -- and the pruners replay every block one calibration sample per
+// forward (wanda_pruner.py:308-311, :343-346).  The replay engine forwards groups of samples instead; a GEMM library picks
+// its batched kernel by batch count and problem size, so the grouped products differ from the per-sample ones in the last
+// bit and the masks in near-ties.  Here an output element is ONE fp32 accumulator that takes the K-steps of 32 in ascending
+// order through one MFMA shape (v_mfma_f32_16x16x32), the tail zero-padded: it depends on its row of A, its column of B and
+// K only -- not on the batch count, not on M or N, not on the tile it happens to sit in.  Replaying 1 or 128 samples per
+// forward, or any share of them on another GPU, gives the same bits (the argument of vlmc_linear_fwd, gemm_nt.hip).
+//
+// Two operand layouts, read in place through their strides (no `contiguous()` copy of a transposed or permuted view):
+//   NT  B's k stride is 1:  B[k][n] = Kmat[n][k], rows of K-contiguous keys            (q @ k^T; K = head_dim 64 / 88)
+//   NN  B's n stride is 1:  rows of n-contiguous values, the reduction runs DOWN them   (attn @ v; K = key tokens)
+// A is K-contiguous in both.  Rows need not be 16-byte aligned (attention rows of 257 keys are not): gfx9 under amdhsa runs
+// with unaligned access mode, and hipcc itself emits global_load_dwordx4 for a 2-byte aligned 16-byte access.
+//
+// HBM-bound (ViT-g: 2 x 270 MB of scores per block and pass): one 256-thread workgroup per 64 x 64 output tile of one
+// (b0, b1) problem, K in chunks of 64 staged through registers into LDS (the next chunk's loads in flight during the
+// MFMAs), 16 KB of LDS and < 64 VGPRs so that 8 workgroups share a CU.  The tiles of one problem run on ONE XCD (workgroup
+// ids congruent mod 8 share an L2), so the operand rows they share are fetched from HBM once.  The NN operand is staged as
+// it lies in memory ([k][n], 16-byte chunks) and read with ds_read_b64_tr_b16, gfx950's transposing LDS read, straight into
+// the MFMA operand layout; VLMC_ATTN_TR=0 transposes while writing LDS instead (same bits, the cross-check).
+#include "common.hpp"
+#include "mfma.hpp"
+
+#include <cstdlib>
+
+namespace vlmc {
+namespace {
+
+constexpr int TM = 64, TN = 64, KC = 64, NT_ = 256;
+constexpr int ROWB = KC * 2;                           // 128-byte rows in LDS
+
+struct BmmArgs {
+    const uint16_t *A, *B;
+    uint16_t *C;
+    int64_t sa_b0, sa_b1, sa_m;                        // elements; A's k stride is 1
+    int64_t sb_b0, sb_b1, sb_k, sb_n;                  // one of sb_k, sb_n is 1
+    int64_t sc_b0, sc_b1, sc_m;                        // C's n stride is 1
+    int nb1, M, N, K;
+    int tiles_m, tiles_n, nprob;
+};
+
+struct __attribute__((packed, aligned(2))) U16x8 { u32x4_t v; };
+__device__ __forceinline__ u32x4_t load16_a2(const uint16_t *p) { return reinterpret_cast<const U16x8 *>(p)->v; }
+__device__ __forceinline__ void store16_a2(uint16_t *p, const u32x4_t &v) { reinterpret_cast<U16x8 *>(p)->v = v; }
+
+// up to 8 elements p[0 .. count), the rest zero (the last chunk of a row: nothing past the row's end is touched)
+__device__ __forceinline__ u32x4_t load_partial(const uint16_t *p, int count) {
+    uint16_t e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = j < count ? p[j] : uint16_t(0);
+    u32x4_t v;
+    __builtin_memcpy(&v, e, 16);
+    return v;
+}
+
+// [rows][64 k] image, 16-byte chunk index XOR-ed with row & 7: the 16-row x 4-chunk fragment reads are conflict-free
+__device__ __forceinline__ int row_off(int row, int ch) { return row * ROWB + ((ch ^ (row & 7)) << 4); }
+// [64 k][64 n] image of the NN operand for the transposing reads: a 32-lane half reads rows q, 8 + q (q = 0..3) of one
+// 16-column block -- chunk pairs XOR-ed with (k & 3) | ((k >> 3) & 1) << 2 put its eight 32-byte pieces on all 64 banks once
+__device__ __forceinline__ int tr_swz(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+__device__ __forceinline__ int tr_off(int k, int ch) { return k * ROWB + ((ch ^ tr_swz(k)) << 4); }
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+template <typename T, bool NN, bool TR>
+__global__ __launch_bounds__(NT_) void attn_matmul_kernel(const BmmArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(TM + TN) * ROWB];         // [m-operand tile | n-operand tile]
+    unsigned char *lq = lds, *lp = lds + TM * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the tiles of one problem on one XCD: ids congruent mod 8 share an L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tpp = a.tiles_m * a.tiles_n;
+    const int prob = (slot / tpp) * 8 + xcd, tile = slot % tpp;
+    if (prob >= a.nprob) return;                                                        // (whole workgroup)
+    const int b0 = prob / a.nb1, b1 = prob - b0 * a.nb1;
+    const int tm = tile / a.tiles_n, tn = tile - tm * a.tiles_n;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const uint16_t *Ap = a.A + b0 * a.sa_b0 + b1 * a.sa_b1;
+    const uint16_t *Bp = a.B + b0 * a.sb_b0 + b1 * a.sb_b1;
+    uint16_t *Cp = a.C + b0 * a.sc_b0 + b1 * a.sc_b1;
+    const int M = a.M, N = a.N, K = a.K;
+
+    // ---- staging: two 16-byte chunks per thread and operand tile -------------------------------------------------------
+    u32x4_t sq[2], sp[2];
+    const u32x4_t zero = {0u, 0u, 0u, 0u};
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                                                   // m operand: rows m, 8 chunks of k
+            const int c = tid + i * NT_, r = m0 + (c >> 3), k = k0 + (c & 7) * 8;
+            const uint16_t *p = Ap + int64_t(r) * a.sa_m + k;
+            sq[i] = (r < M && k < K) ? (k + 8 <= K ? load16_a2(p) : load_partial(p, K - k)) : zero;
+        }
+        if constexpr (!NN) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {                                               // n operand, K-contiguous rows n
+                const int c = tid + i * NT_, r = n0 + (c >> 3), k = k0 + (c & 7) * 8;
+                const uint16_t *p = Bp + int64_t(r) * a.sb_n + k;
+                sp[i] = (r < N && k < K) ? (k + 8 <= K ? load16_a2(p) : load_partial(p, K - k)) : zero;
+            }
+        } else if constexpr (TR) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {                                               // n operand as it lies: rows k, 8 chunks of n
+                const int c = tid + i * NT_, k = k0 + (c >> 3), n = n0 + (c & 7) * 8;
+                const uint16_t *p = Bp + int64_t(k) * a.sb_k + n;
+                sp[i] = (k < K && n < N) ? (n + 8 <= N ? load16_a2(p) : load_partial(p, N - n)) : zero;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {                                               // rows k0 + 2 kp, + 1 of n chunk nc
+                const int k = k0 + 2 * (tid >> 3) + i, n = n0 + (tid & 7) * 8;
+                const uint16_t *p = Bp + int64_t(k) * a.sb_k + n;
+                sp[i] = (k < K && n < N) ? (n + 8 <= N ? load16_a2(p) : load_partial(p, N - n)) : zero;
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * NT_;
+            *reinterpret_cast<u32x4_t *>(lq + row_off(c >> 3, c & 7)) = sq[i];
+        }
+        if constexpr (!NN) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = tid + i * NT_;
+                *reinterpret_cast<u32x4_t *>(lp + row_off(c >> 3, c & 7)) = sp[i];
+            }
+        } else if constexpr (TR) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = tid + i * NT_;
+                *reinterpret_cast<u32x4_t *>(lp + tr_off(c >> 3, c & 7)) = sp[i];
+            }
+        } else {
+            // transposing write: element pairs (k, k + 1) of column n become one dword of row n of the [n][k] image
+            uint16_t e0[8], e1[8];
+            __builtin_memcpy(e0, &sp[0], 16);
+            __builtin_memcpy(e1, &sp[1], 16);
+            const int kk = 2 * (tid >> 3), nb = (tid & 7) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *reinterpret_cast<uint32_t *>(lp + row_off(nb + j, kk >> 3) + (kk & 7) * 2) = uint32_t(e0[j]) | uint32_t(e1[j]) << 16;
+        }
+    };
+
+    // ---- wave (wm, wn) owns 32 rows of m and 32 columns of n: 2 x 2 MFMA tiles; lanes hold 4 consecutive n for one m -----
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fch = lane >> 4;
+    const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;                      // transposing read: group, row, piece
+
+    const int nks = (K + 31) / 32;                                                      // K-steps of 32, the last zero-padded
+    fetch(0);
+    for (int k0 = 0, ks = 0; k0 < K; k0 += KC) {
+        __syncthreads();                                                                // everybody has left the previous chunk
+        stash();
+        __syncthreads();
+        if (k0 + KC < K) fetch(k0 + KC);                                                // in flight during the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk, ++ks) {
+            if (ks >= nks) break;                                                       // (uniform)
+            u32x4_t fq[2], fp[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                fq[j] = *reinterpret_cast<const u32x4_t *>(lq + row_off(wm * 32 + j * 16 + frow, fch + 4 * kk));
+            if constexpr (NN && TR) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int t = wn * 2 + i;                                           // 16-column block of the tile
+                    s16x4_t h[2];
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int row = 32 * kk + 8 * tg + 4 * half + tq;
+                        const unsigned char *p = lp + tr_off(row, 2 * t + (tp >> 1)) + 8 * (tp & 1);
+                        h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4_t *)(const_cast<unsigned char *>(p)));
+                    }
+                    __builtin_memcpy(&fp[i], h, 16);                                    // k = 8 tg + 0..3 | + 4..7 of column 16 t + (lane & 15)
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    fp[i] = *reinterpret_cast<const u32x4_t *>(lp + row_off(wn * 32 + i * 16 + frow, fch + 4 * kk));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<T>(fp[i], fq[j], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue: the tile through LDS ([64 m][64 n], chunk index XOR-ed with the row), out as 16 bytes per lane ----------
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint16_t o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(acc[i][j][r]);
+            const u32x2_t v = {uint32_t(o[0]) | uint32_t(o[1]) << 16, uint32_t(o[2]) | uint32_t(o[3]) << 16};
+            const int row = wm * 32 + j * 16 + (lane & 15), col = wn * 32 + i * 16 + 4 * (lane >> 4);
+            *reinterpret_cast<u32x2_t *>(lds + row_off(row, col >> 3) + (col & 7) * 2) = v;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + i * NT_, row = c >> 3, ch = c & 7;
+        const int m = m0 + row, n = n0 + ch * 8;
+        if (m >= M || n >= N) continue;
+        const u32x4_t v = *reinterpret_cast<const u32x4_t *>(lds + row_off(row, ch));
+        uint16_t *dst = Cp + int64_t(m) * a.sc_m + n;
+        if (n + 8 <= N) {
+            store16_a2(dst, v);
+        } else {
+            uint16_t e[8];
+            __builtin_memcpy(e, &v, 16);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (n + r < N) dst[r] = e[r];
+        }
+    }
+}
+
+}  // namespace
+}  // namespace vlmc
+
+using namespace vlmc;
+
+extern "C" int vlmc_attn_matmul(const void *A, const void *B, void *C, int dtype, int64_t batch0, int64_t batch1, int64_t M, int64_t N,
+                                int64_t K, int64_t sa_b0, int64_t sa_b1, int64_t sa_m, int64_t sb_b0, int64_t sb_b1, int64_t sb_k,
+                                int64_t sb_n, int64_t sc_b0, int64_t sc_b1, int64_t sc_m, void *stream) {
+    VLMC_REQUIRE(dtype == VLMC_F16 || dtype == VLMC_BF16, "vlmc_attn_matmul: dtype must be VLMC_F16 or VLMC_BF16");
+    VLMC_REQUIRE(A && B && C, "vlmc_attn_matmul: null pointer");
+    VLMC_REQUIRE(batch0 > 0 && batch1 > 0 && M > 0 && N > 0 && K > 0, "vlmc_attn_matmul: empty product");
+    VLMC_REQUIRE(batch0 * batch1 < (int64_t(1) << 28) && M < (int64_t(1) << 24) && N < (int64_t(1) << 24) && K < (int64_t(1) << 24),
+                 "vlmc_attn_matmul: shape too large");
+    VLMC_REQUIRE(sb_k == 1 || sb_n == 1, "vlmc_attn_matmul: B must be contiguous along k (a transposed view, q @ k^T) or along n (attn @ v)");
+    VLMC_REQUIRE(sa_m >= 0 && sb_k >= 0 && sb_n >= 0 && sc_m >= N, "vlmc_attn_matmul: bad row strides");
+    VLMC_REQUIRE((reinterpret_cast<uintptr_t>(A) & 1u) == 0 && (reinterpret_cast<uintptr_t>(B) & 1u) == 0 &&
+                     (reinterpret_cast<uintptr_t>(C) & 1u) == 0, "vlmc_attn_matmul: pointers must be 2-byte aligned");
+    BmmArgs a{};
+    a.A = static_cast<const uint16_t *>(A);
+    a.B = static_cast<const uint16_t *>(B);
+    a.C = static_cast<uint16_t *>(C);
+    a.sa_b0 = sa_b0, a.sa_b1 = sa_b1, a.sa_m = sa_m;
+    a.sb_b0 = sb_b0, a.sb_b1 = sb_b1, a.sb_k = sb_k, a.sb_n = sb_n;
+    a.sc_b0 = sc_b0, a.sc_b1 = sc_b1, a.sc_m = sc_m;
+    a.nb1 = int(batch1), a.M = int(M), a.N = int(N), a.K = int(K);
+    a.tiles_m = int((M + TM - 1) / TM), a.tiles_n = int((N + TN - 1) / TN);
+    a.nprob = int(batch0 * batch1);
+    const int64_t groups = (a.nprob + 7) / 8;                                            // problems per XCD label
+    const int64_t grid = groups * 8 * a.tiles_m * a.tiles_n;
+    VLMC_REQUIRE(grid < (int64_t(1) << 31), "vlmc_attn_matmul: too many tiles");
+    // B with K == 1 or N == 1 satisfies both layouts: take the one whose stride says so (sb_k == 1 first: no transposition)
+    const bool nn = sb_k != 1;
+    const char *e = getenv("VLMC_ATTN_TR");                        // 0: transpose the NN operand while writing LDS (the cross-check;
+    const bool tr = !(e && e[0] == '0');                           // read per call so that a test can hold both against each other)
+    hipStream_t s = as_stream(stream);
+    const dim3 g{unsigned(grid)}, b{unsigned(NT_)};
+    if (dtype == VLMC_BF16) {
+        if (!nn) VLMC_LAUNCH_TIMED((attn_matmul_kernel<bf16_t, false, false>), g, b, s, a);
+        else if (tr) VLMC_LAUNCH_TIMED((attn_matmul_kernel<bf16_t, true, true>), g, b, s, a);
+        else VLMC_LAUNCH_TIMED((attn_matmul_kernel<bf16_t, true, false>), g, b, s, a);
+    } else {
+        if (!nn) VLMC_LAUNCH_TIMED((attn_matmul_kernel<f16_t, false, false>), g, b, s, a);
+        else if (tr) VLMC_LAUNCH_TIMED((attn_matmul_kernel<f16_t, true, true>), g, b, s, a);
+        else VLMC_LAUNCH_TIMED((attn_matmul_kernel<f16_t, true, false>), g, b, s, a);
+    }
+    VLMC_HIP_CHECK_LAUNCH("vlmc_attn_matmul");
+    return VLMC_OK;
+}

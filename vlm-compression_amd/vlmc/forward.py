@@ -33,7 +33,8 @@ import torch.nn.functional as F
 from . import ops
 
 _active = 0
-stats = {"kernel": 0, "library": 0, "grouped_launches": 0, "served_from_group": 0, "stash_dropped": 0}
+stats = {"kernel": 0, "library": 0, "grouped_launches": 0, "served_from_group": 0, "stash_dropped": 0, "attn_kernel": 0,
+         "attn_library": 0}
 
 # first member of a learned sibling group -> tuple of weak references to all members, in call order
 _SIBLINGS = weakref.WeakKeyDictionary()
@@ -152,9 +153,69 @@ class _Tracker:
         self.stash.clear()
 
 
+# ---- the batched matmuls of attention (q @ k^T, attn @ v) on the batch-invariant kernel -----------------------------------
+# The reference's model files write attention as batched `torch.matmul`s / `@` (eva_vit.py:147,164; modeling_t5.py:590,638;
+# modeling_llama.py likewise).  The GEMM library picks its batched kernel by batch count, so a grouped block forward gives a
+# sample other last bits than its own forward would -- and near-tie mask bits follow.  While a block is replayed, `torch.matmul`,
+# `torch.bmm`, `Tensor.__matmul__`, `Tensor.matmul` and `Tensor.bmm` are plain attribute patches (no `TorchFunctionMode`: that
+# would tax every op of a host-bound loop) that send 3-D / 4-D 16-bit products without gradients to `vlmc_attn_matmul`
+# (csrc/attn_matmul.hip) and everything else to the original.  `VLMC_ATTN_MATMUL=0`: off.
+_mm_depth = 0
+_mm_saved = {}
+
+
+def attn_matmul_enabled():
+    return os.environ.get("VLMC_ATTN_MATMUL", "1") != "0"
+
+
+def _make_matmul(orig):
+    plan_of, run = ops.attn_matmul_plan, ops.attn_matmul
+    Tensor = torch.Tensor
+
+    def matmul(a, b, *args, **kw):
+        if not args and not kw and type(a) is Tensor and type(b) is Tensor and a.dim() >= 3 and not torch.is_grad_enabled():
+            if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() != a.dtype:
+                return orig(a, b)                                   # (autocast would cast the operands: the library's call)
+            plan = plan_of(a, b)
+            if plan is not None:
+                stats["attn_kernel"] += 1
+                return run(a, b, plan)
+            stats["attn_library"] += 1
+        return orig(a, b, *args, **kw)
+    return matmul
+
+
+@contextlib.contextmanager
+def invariant_matmuls():
+    """Batched 16-bit `matmul`s run on `vlmc_attn_matmul` for the duration (nestable)."""
+    global _mm_depth
+    if not (enabled() and attn_matmul_enabled()):
+        yield
+        return
+    if _mm_depth == 0:
+        base = torch._C.TensorBase
+        _mm_saved.update(matmul=torch.matmul, bmm=torch.bmm)
+        torch.matmul = _make_matmul(torch.matmul)
+        torch.bmm = _make_matmul(torch.bmm)
+        for name in ("__matmul__", "matmul", "bmm"):              # (inherited from TensorBase: the patch shadows, `del` restores)
+            if name not in torch.Tensor.__dict__:
+                setattr(torch.Tensor, name, _make_matmul(getattr(base, name)))
+                _mm_saved.setdefault("tensor", []).append(name)
+    _mm_depth += 1
+    try:
+        yield
+    finally:
+        _mm_depth -= 1
+        if _mm_depth == 0:
+            torch.matmul, torch.bmm = _mm_saved.pop("matmul"), _mm_saved.pop("bmm")
+            for name in _mm_saved.pop("tensor", []):
+                delattr(torch.Tensor, name)
+
+
 @contextlib.contextmanager
 def invariant_linears(modules):
-    """Route the forward of the given `nn.Linear` modules (exact type) through `linear` for the duration."""
+    """Route the forward of the given `nn.Linear` modules (exact type) through `linear` for the duration -- and the batched
+    matmuls of the blocks' attention through `vlmc_attn_matmul` (`invariant_matmuls`)."""
     global _active
     if not enabled():
         yield
@@ -165,7 +226,8 @@ def invariant_linears(modules):
         m.forward = (lambda mod: (lambda x: tracker.call(mod, x)))(m)
     _active += 1
     try:
-        yield tracker
+        with invariant_matmuls():
+            yield tracker
     finally:
         _active -= 1
         tracker.close()

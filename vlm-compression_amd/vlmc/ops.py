@@ -121,6 +121,64 @@ def linear_fwd_group(x: torch.Tensor, weights, biases=None) -> list:
     return [y.reshape(*x.shape[:-1], y.shape[1]) for y in outs]
 
 
+_16BIT = (torch.float16, torch.bfloat16)
+
+
+def attn_matmul_plan(a: torch.Tensor, b: torch.Tensor, _cuda_only: bool = True):
+    """The arguments `vlmc_attn_matmul` takes for `torch.matmul(a, b)`, or None if the call is not one it computes: 3-D or
+    4-D CUDA tensors of one 16-bit dtype, equal (or broadcast) batch dimensions, `a` contiguous along its last dimension,
+    `b` along its last (attn @ v) or its second to last (q @ k.transpose(-2, -1)) -- read in place through their strides."""
+    nd = a.dim()
+    if nd != b.dim() or nd < 3 or nd > 4 or a.dtype != b.dtype or a.dtype not in _16BIT or \
+            (_cuda_only and not (a.is_cuda and b.is_cuda)):
+        return None
+    ash, bsh = a.shape, b.shape
+    M, K, N = ash[-2], ash[-1], bsh[-1]
+    if K != bsh[-2] or M == 0 or N == 0 or K == 0:
+        return None
+    sa, sb = a.stride(), b.stride()
+    if sa[-1] != 1 and K != 1:
+        return None
+    if K == 1 or sb[-2] == 1:
+        sbk, sbn = 1, sb[-1]
+    elif sb[-1] == 1 or N == 1:
+        sbk, sbn = sb[-2], 1
+    else:
+        return None
+    if sa[-2] < 0 or sbk < 0 or sbn < 0:
+        return None
+    batch, sab, sbb = [], [], []
+    for i in range(nd - 2):
+        x, y = ash[i], bsh[i]
+        if x != y and x != 1 and y != 1:
+            return None
+        n = x if x != 1 else y
+        if n == 0:
+            return None
+        batch.append(n)
+        sab.append(sa[i] if x != 1 else 0)
+        sbb.append(sb[i] if y != 1 else 0)
+    if nd == 3:
+        batch, sab, sbb = [1] + batch, [0] + sab, [0] + sbb
+    return (batch, M, N, K, sab[0], sab[1], sa[-2], sbb[0], sbb[1], sbk, sbn)
+
+
+def attn_matmul(a: torch.Tensor, b: torch.Tensor, _plan=None) -> torch.Tensor:
+    """`torch.matmul(a, b)` for the batched products of attention (q @ k^T, attn @ v: eva_vit.py:147,164;
+    modeling_t5.py:590,638) on the batch-invariant MFMA kernel: an output element has the same bits whatever the batch
+    count, M or N (include/vlmc.h: vlmc_attn_matmul)."""
+    plan = _plan if _plan is not None else attn_matmul_plan(a, b)
+    if plan is None:
+        _need_gpu(a, b)
+        raise TypeError("vlmc.attn_matmul: 3-D / 4-D fp16 / bf16 tensors of one dtype expected, a contiguous along k, b along k or n")
+    batch, M, N, K, sa0, sa1, sam, sb0, sb1, sbk, sbn = plan
+    nb0, nb1 = batch
+    out = torch.empty((*(batch if a.dim() == 4 else batch[1:]), M, N), dtype=a.dtype, device=a.device)
+    _lib.check(_lib.load().vlmc_attn_matmul(a.data_ptr(), b.data_ptr(), out.data_ptr(), _DT[a.dtype], nb0, nb1, M, N, K, sa0, sa1, sam,
+                                            sb0, sb1, sbk, sbn, nb1 * M * N, M * N, N, _stream()))
+    return out
+
+
 def hessian_accum(H: torch.Tensor, x: torch.Tensor, alpha: float, beta: float) -> torch.Tensor:
     """H = alpha * H + beta * x^T x on the tiles on and below the diagonal (SparseGPT.add_batch, sparsegpt_pruner.py:76-79,
     with alpha = n/(n+b) and beta = 2/(n+b)); x [rows, in] fp16 / bf16 / fp32.  `symmetrize_lower(H)` completes H."""
