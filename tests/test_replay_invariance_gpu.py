@@ -135,3 +135,31 @@ def test_attention_written_as_batched_matmuls_is_identical_for_every_grouping(me
     again = _run_16bit_toy(method, 128, monkeypatch, ragged=ragged, sdpa="matmul16")       # and run to run
     for k in ref:
         assert torch.equal(again[k], ref[k]), k
+
+
+def test_a_sibling_group_whose_products_are_wasted_is_forgotten():
+    """once q / k / v are a known group, a call pattern in which q is called alone would keep computing k's and v's
+    products for nothing.  After three forwards whose stash was dropped the group is forgotten (and learned again when the
+    calls show it again)."""
+    from vlmc import forward
+    torch.manual_seed(0)
+    q, k, v = (torch.nn.Linear(64, 64, bias=False).to(DEV).half() for _ in range(3))
+    x = torch.randn(5, 64, device=DEV).half()
+    mods = [q, k, v]
+    with torch.no_grad():
+        with forward.invariant_linears(mods):
+            want = [m(x) for m in mods]                      # learned here
+        assert forward.sibling_groups(mods) == [(q, k, v)]
+        before = dict(forward.stats)
+        for _ in range(3):                                   # q alone: one grouped launch each, two products dropped
+            with forward.invariant_linears(mods):
+                assert torch.equal(q(x), want[0])
+        assert forward.stats["grouped_launches"] - before["grouped_launches"] == 3
+        assert forward.stats["stash_dropped"] - before["stash_dropped"] == 6
+        assert forward.sibling_groups(mods) == []            # forgotten
+        with forward.invariant_linears(mods):
+            assert torch.equal(q(x), want[0])                # a single launch now
+        assert forward.stats["grouped_launches"] - before["grouped_launches"] == 3
+        with forward.invariant_linears(mods):
+            got = [m(x) for m in mods]                       # the calls show the group again
+        assert forward.sibling_groups(mods) == [(q, k, v)] and all(torch.equal(a, b) for a, b in zip(got, want))

@@ -18,10 +18,11 @@
 // A is K-contiguous in both.  Rows need not be 16-byte aligned (attention rows of 257 keys are not): gfx9 under amdhsa runs
 // with unaligned access mode, and hipcc itself emits global_load_dwordx4 for a 2-byte aligned 16-byte access.
 //
-// HBM-bound (ViT-g: 2 x 270 MB of scores per block and pass): one 256-thread workgroup per 64 x 64 output tile of one
-// (b0, b1) problem, K in chunks of 64 staged through registers into LDS (the next chunk's loads in flight during the
-// MFMAs), 16 KB of LDS and < 64 VGPRs so that 8 workgroups share a CU.  The tiles of one problem run on ONE XCD (workgroup
-// ids congruent mod 8 share an L2), so the operand rows they share are fetched from HBM once.  The NN operand is staged as
+// HBM-bound (ViT-g: 2 x 270 MB of scores per block and pass): one 256-thread workgroup per block of 64 rows of one
+// (b0, b1) problem walks that block's 64 x 64 output tiles -- (n tile, two K chunks of 64) steps staged through registers into
+// LDS, the next step's 32 KB in flight during the MFMAs and the tile's stores --, 32 KB of LDS, 4 workgroups per CU.  The row
+// blocks of one problem run on ONE XCD (workgroup ids congruent mod 8 share an L2): the n operand they all read is fetched
+// from HBM once.  The NN operand is staged as
 // it lies in memory ([k][n], 16-byte chunks) and read with ds_read_b64_tr_b16, gfx950's transposing LDS read, straight into
 // the MFMA operand layout; VLMC_ATTN_TR=0 transposes while writing LDS instead (same bits, the cross-check).
 #include "common.hpp"
@@ -70,82 +71,94 @@ typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
 template <typename T, bool NN, bool TR>
 __global__ __launch_bounds__(NT_) void attn_matmul_kernel(const BmmArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[(TM + TN) * ROWB];         // [m-operand tile | n-operand tile]
-    unsigned char *lq = lds, *lp = lds + TM * ROWB;
+    // two K chunks of 64 per step, each its own [m-operand tile | n-operand tile] image of 128-byte rows
+    constexpr int BUF = (TM + TN) * ROWB;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // the tiles of one problem on one XCD: ids congruent mod 8 share an L2
+    // one workgroup per (problem, block of 64 rows of m); the row blocks of one problem run on ONE XCD (ids congruent mod 8
+    // share an L2): they all read the problem's whole n operand
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int tpp = a.tiles_m * a.tiles_n;
-    const int prob = (slot / tpp) * 8 + xcd, tile = slot % tpp;
+    const int prob = (slot / a.tiles_m) * 8 + xcd, tm = slot % a.tiles_m;
     if (prob >= a.nprob) return;                                                        // (whole workgroup)
     const int b0 = prob / a.nb1, b1 = prob - b0 * a.nb1;
-    const int tm = tile / a.tiles_n, tn = tile - tm * a.tiles_n;
-    const int m0 = tm * TM, n0 = tn * TN;
+    const int m0 = tm * TM;
     const uint16_t *Ap = a.A + b0 * a.sa_b0 + b1 * a.sa_b1;
     const uint16_t *Bp = a.B + b0 * a.sb_b0 + b1 * a.sb_b1;
     uint16_t *Cp = a.C + b0 * a.sc_b0 + b1 * a.sc_b1;
     const int M = a.M, N = a.N, K = a.K;
 
-    // ---- staging: two 16-byte chunks per thread and operand tile -------------------------------------------------------
-    u32x4_t sq[2], sp[2];
+    // ---- staging: per K chunk two 16-byte pieces per thread and operand tile ----------------------------------------------
+    // (a step moves 32 KB: with one chunk of 64 per step a workgroup had 16 KB on its way from L2 / HBM, waited the round trip
+    // out every step, and the ViT-g scores ran at 2.1 TB/s)
+    u32x4_t sq[2][2], sp[2][2];
     const u32x4_t zero = {0u, 0u, 0u, 0u};
-    auto fetch = [&](int k0) {
+    auto fetch = [&](int n0, int kbase, bool with_m) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {                                                   // m operand: rows m, 8 chunks of k
-            const int c = tid + i * NT_, r = m0 + (c >> 3), k = k0 + (c & 7) * 8;
-            const uint16_t *p = Ap + int64_t(r) * a.sa_m + k;
-            sq[i] = (r < M && k < K) ? (k + 8 <= K ? load16_a2(p) : load_partial(p, K - k)) : zero;
-        }
-        if constexpr (!NN) {
+        for (int b = 0; b < 2; ++b) {
+            const int k0 = kbase + b * KC;
+            if (with_m)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {                                               // n operand, K-contiguous rows n
-                const int c = tid + i * NT_, r = n0 + (c >> 3), k = k0 + (c & 7) * 8;
-                const uint16_t *p = Bp + int64_t(r) * a.sb_n + k;
-                sp[i] = (r < N && k < K) ? (k + 8 <= K ? load16_a2(p) : load_partial(p, K - k)) : zero;
+            for (int i = 0; i < 2; ++i) {                                               // m operand: rows m, 8 pieces of k
+                const int c = tid + i * NT_, r = m0 + (c >> 3), k = k0 + (c & 7) * 8;
+                const uint16_t *p = Ap + int64_t(r) * a.sa_m + k;
+                sq[b][i] = (r < M && k < K) ? (k + 8 <= K ? load16_a2(p) : load_partial(p, K - k)) : zero;
             }
-        } else if constexpr (TR) {
+            if constexpr (!NN) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {                                               // n operand as it lies: rows k, 8 chunks of n
-                const int c = tid + i * NT_, k = k0 + (c >> 3), n = n0 + (c & 7) * 8;
-                const uint16_t *p = Bp + int64_t(k) * a.sb_k + n;
-                sp[i] = (k < K && n < N) ? (n + 8 <= N ? load16_a2(p) : load_partial(p, N - n)) : zero;
-            }
-        } else {
+                for (int i = 0; i < 2; ++i) {                                           // n operand, K-contiguous rows n
+                    const int c = tid + i * NT_, r = n0 + (c >> 3), k = k0 + (c & 7) * 8;
+                    const uint16_t *p = Bp + int64_t(r) * a.sb_n + k;
+                    sp[b][i] = (r < N && k < K) ? (k + 8 <= K ? load16_a2(p) : load_partial(p, K - k)) : zero;
+                }
+            } else if constexpr (TR) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {                                               // rows k0 + 2 kp, + 1 of n chunk nc
-                const int k = k0 + 2 * (tid >> 3) + i, n = n0 + (tid & 7) * 8;
-                const uint16_t *p = Bp + int64_t(k) * a.sb_k + n;
-                sp[i] = (k < K && n < N) ? (n + 8 <= N ? load16_a2(p) : load_partial(p, N - n)) : zero;
+                for (int i = 0; i < 2; ++i) {                                           // n operand as it lies: rows k, 8 pieces of n
+                    const int c = tid + i * NT_, k = k0 + (c >> 3), n = n0 + (c & 7) * 8;
+                    const uint16_t *p = Bp + int64_t(k) * a.sb_k + n;
+                    sp[b][i] = (k < K && n < N) ? (n + 8 <= N ? load16_a2(p) : load_partial(p, N - n)) : zero;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {                                           // rows k0 + 2 kp, + 1 of n piece nc
+                    const int k = k0 + 2 * (tid >> 3) + i, n = n0 + (tid & 7) * 8;
+                    const uint16_t *p = Bp + int64_t(k) * a.sb_k + n;
+                    sp[b][i] = (k < K && n < N) ? (n + 8 <= N ? load16_a2(p) : load_partial(p, N - n)) : zero;
+                }
             }
         }
     };
-    auto stash = [&]() {
+    auto stash = [&](bool with_m) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + i * NT_;
-            *reinterpret_cast<u32x4_t *>(lq + row_off(c >> 3, c & 7)) = sq[i];
-        }
-        if constexpr (!NN) {
+        for (int b = 0; b < 2; ++b) {
+            unsigned char *lq = lds + b * BUF, *lp = lq + TM * ROWB;
+            if (with_m)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int c = tid + i * NT_;
-                *reinterpret_cast<u32x4_t *>(lp + row_off(c >> 3, c & 7)) = sp[i];
+                *reinterpret_cast<u32x4_t *>(lq + row_off(c >> 3, c & 7)) = sq[b][i];
             }
-        } else if constexpr (TR) {
+            if constexpr (!NN) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int c = tid + i * NT_;
-                *reinterpret_cast<u32x4_t *>(lp + tr_off(c >> 3, c & 7)) = sp[i];
+                for (int i = 0; i < 2; ++i) {
+                    const int c = tid + i * NT_;
+                    *reinterpret_cast<u32x4_t *>(lp + row_off(c >> 3, c & 7)) = sp[b][i];
+                }
+            } else if constexpr (TR) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int c = tid + i * NT_;
+                    *reinterpret_cast<u32x4_t *>(lp + tr_off(c >> 3, c & 7)) = sp[b][i];
+                }
+            } else {
+                // transposing write: element pairs (k, k + 1) of column n become one dword of row n of the [n][k] image
+                uint16_t e0[8], e1[8];
+                __builtin_memcpy(e0, &sp[b][0], 16);
+                __builtin_memcpy(e1, &sp[b][1], 16);
+                const int kk = 2 * (tid >> 3), nb = (tid & 7) * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    *reinterpret_cast<uint32_t *>(lp + row_off(nb + j, kk >> 3) + (kk & 7) * 2) = uint32_t(e0[j]) | uint32_t(e1[j]) << 16;
             }
-        } else {
-            // transposing write: element pairs (k, k + 1) of column n become one dword of row n of the [n][k] image
-            uint16_t e0[8], e1[8];
-            __builtin_memcpy(e0, &sp[0], 16);
-            __builtin_memcpy(e1, &sp[1], 16);
-            const int kk = 2 * (tid >> 3), nb = (tid & 7) * 8;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                *reinterpret_cast<uint32_t *>(lp + row_off(nb + j, kk >> 3) + (kk & 7) * 2) = uint32_t(e0[j]) | uint32_t(e1[j]) << 16;
         }
     };
 
@@ -159,20 +172,32 @@ __global__ __launch_bounds__(NT_) void attn_matmul_kernel(const BmmArgs a) {
     const int frow = lane & 15, fch = lane >> 4;
     const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;                      // transposing read: group, row, piece
 
+    // ---- the workgroup's steps: (n tile, pair of K chunks) in order, the next step's operands in flight during the MFMAs and
+    // ---- the tile's stores; a tile's last step is followed by its epilogue (the m operand's chunks come from L1 / L2 again
+    // ---- for every n tile)
     const int nks = (K + 31) / 32;                                                      // K-steps of 32, the last zero-padded
-    fetch(0);
-    for (int k0 = 0, ks = 0; k0 < K; k0 += KC) {
-        __syncthreads();                                                                // everybody has left the previous chunk
-        stash();
+    const int nstep = (K + 2 * KC - 1) / (2 * KC), steps = a.tiles_n * nstep;
+    // K <= 128 (a head dimension: q @ k^T): the m operand's one step stays in LDS for all n tiles -- fetched and written once
+    // (the epilogue's scratch is then the n operand's region of the first image)
+    const bool resident = nstep == 1;
+    unsigned char *scratch = lds + (resident ? TM * ROWB : 0);
+    fetch(0, 0, true);
+    for (int s = 0, tn = 0, kc = 0; s < steps; ++s) {
+        __syncthreads();                                                                // everybody has left the previous step
+        stash(!resident || s == 0);
         __syncthreads();
-        if (k0 + KC < K) fetch(k0 + KC);                                                // in flight during the MFMAs below
+        const bool last = kc == nstep - 1;
+        const int n0 = tn * TN;
+        if (s + 1 < steps) fetch(last ? n0 + TN : n0, last ? 0 : (kc + 1) * 2 * KC, !resident);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk, ++ks) {
-            if (ks >= nks) break;                                                       // (uniform)
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kc * 4 + kk >= nks) break;                                              // (uniform)
+            const unsigned char *lq = lds + (kk >> 1) * BUF, *lp = lq + TM * ROWB;
+            const int kh = kk & 1;                                                      // which half of the chunk's 64 k
             u32x4_t fq[2], fp[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                fq[j] = *reinterpret_cast<const u32x4_t *>(lq + row_off(wm * 32 + j * 16 + frow, fch + 4 * kk));
+                fq[j] = *reinterpret_cast<const u32x4_t *>(lq + row_off(wm * 32 + j * 16 + frow, fch + 4 * kh));
             if constexpr (NN && TR) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -180,7 +205,7 @@ __global__ __launch_bounds__(NT_) void attn_matmul_kernel(const BmmArgs a) {
                     s16x4_t h[2];
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
-                        const int row = 32 * kk + 8 * tg + 4 * half + tq;
+                        const int row = 32 * kh + 8 * tg + 4 * half + tq;
                         const unsigned char *p = lp + tr_off(row, 2 * t + (tp >> 1)) + 8 * (tp & 1);
                         h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                             (__attribute__((address_space(3))) s16x4_t *)(const_cast<unsigned char *>(p)));
@@ -190,45 +215,51 @@ __global__ __launch_bounds__(NT_) void attn_matmul_kernel(const BmmArgs a) {
             } else {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    fp[i] = *reinterpret_cast<const u32x4_t *>(lp + row_off(wn * 32 + i * 16 + frow, fch + 4 * kk));
+                    fp[i] = *reinterpret_cast<const u32x4_t *>(lp + row_off(wn * 32 + i * 16 + frow, fch + 4 * kh));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<T>(fp[i], fq[j], acc[i][j]);
         }
-    }
-
-    // ---- epilogue: the tile through LDS ([64 m][64 n], chunk index XOR-ed with the row), out as 16 bytes per lane ----------
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            uint16_t o[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(acc[i][j][r]);
-            const u32x2_t v = {uint32_t(o[0]) | uint32_t(o[1]) << 16, uint32_t(o[2]) | uint32_t(o[3]) << 16};
-            const int row = wm * 32 + j * 16 + (lane & 15), col = wn * 32 + i * 16 + 4 * (lane >> 4);
-            *reinterpret_cast<u32x2_t *>(lds + row_off(row, col >> 3) + (col & 7) * 2) = v;
+        if (!last) {
+            ++kc;
+            continue;
         }
-    __syncthreads();
+        // ---- epilogue of tile tn: through LDS ([64 m][64 n], chunk index XOR-ed with the row), out as 16 bytes per lane ----
+        __syncthreads();                                                                // every wave has read its fragments
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = tid + i * NT_, row = c >> 3, ch = c & 7;
-        const int m = m0 + row, n = n0 + ch * 8;
-        if (m >= M || n >= N) continue;
-        const u32x4_t v = *reinterpret_cast<const u32x4_t *>(lds + row_off(row, ch));
-        uint16_t *dst = Cp + int64_t(m) * a.sc_m + n;
-        if (n + 8 <= N) {
-            store16_a2(dst, v);
-        } else {
-            uint16_t e[8];
-            __builtin_memcpy(e, &v, 16);
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-                if (n + r < N) dst[r] = e[r];
+            for (int j = 0; j < 2; ++j) {
+                uint16_t o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(acc[i][j][r]);
+                const u32x2_t v = {uint32_t(o[0]) | uint32_t(o[1]) << 16, uint32_t(o[2]) | uint32_t(o[3]) << 16};
+                const int row = wm * 32 + j * 16 + (lane & 15), col = wn * 32 + i * 16 + 4 * (lane >> 4);
+                *reinterpret_cast<u32x2_t *>(scratch + row_off(row, col >> 3) + (col & 7) * 2) = v;
+                acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * NT_, row = c >> 3, ch = c & 7;
+            const int m = m0 + row, n = n0 + ch * 8;
+            if (m >= M || n >= N) continue;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t *>(scratch + row_off(row, ch));
+            uint16_t *dst = Cp + int64_t(m) * a.sc_m + n;
+            if (n + 8 <= N) {
+                store16_a2(dst, v);
+            } else {
+                uint16_t e[8];
+                __builtin_memcpy(e, &v, 16);
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (n + r < N) dst[r] = e[r];
+            }
         }
+        ++tn;
+        kc = 0;
     }
 }
 
@@ -260,7 +291,7 @@ extern "C" int vlmc_attn_matmul(const void *A, const void *B, void *C, int dtype
     a.tiles_m = int((M + TM - 1) / TM), a.tiles_n = int((N + TN - 1) / TN);
     a.nprob = int(batch0 * batch1);
     const int64_t groups = (a.nprob + 7) / 8;                                            // problems per XCD label
-    const int64_t grid = groups * 8 * a.tiles_m * a.tiles_n;
+    const int64_t grid = groups * 8 * a.tiles_m;
     VLMC_REQUIRE(grid < (int64_t(1) << 31), "vlmc_attn_matmul: too many tiles");
     // B with K == 1 or N == 1 satisfies both layouts: take the one whose stride says so (sb_k == 1 first: no transposition)
     const bool nn = sb_k != 1;

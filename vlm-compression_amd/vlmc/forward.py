@@ -74,6 +74,22 @@ def linear(x, weight, bias=None):
     return F.linear(x, weight, bias)
 
 
+# first member of a group -> consecutive launches whose products were wasted (a sibling was not called on the tensor, or the
+# group could not be formed): after three the group is forgotten -- a later call pattern in which the first member is
+# called alone would otherwise keep computing its siblings' products for nothing; it is learned again if the
+# calls show it again
+_TROUBLE = weakref.WeakKeyDictionary()
+
+
+def _trouble(first):
+    n = _TROUBLE.get(first, 0) + 1
+    if n >= 3:
+        _SIBLINGS.pop(first, None)
+        _TROUBLE.pop(first, None)
+    else:
+        _TROUBLE[first] = n
+
+
 def _input_key(x):
     return (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()), x.dtype)
 
@@ -121,8 +137,10 @@ class _Tracker:
         if kept is not None:
             if kept[1] == key and kept[0].untyped_storage().data_ptr() == x.untyped_storage().data_ptr():
                 stats["served_from_group"] += 1
+                _TROUBLE.pop(kept[3], None)
                 return kept[2]
             stats["stash_dropped"] += 1
+            _trouble(kept[3])
         # ---- learn: consecutive calls on the very same tensor -------------------------------------------------------------
         if self.run and key == self.run_key:
             self.run.append(mod)
@@ -134,22 +152,43 @@ class _Tracker:
         if refs:
             group = [r() for r in refs]
             if all(g is not None and id(g) in self.patched for g in group):
-                preps = [_prepare(x, g.weight, g.bias) for g in group]
-                if all(p is not None for p in preps) and all(p[0] is preps[0][0] or p[0].dtype == preps[0][0].dtype for p in preps) \
-                        and len({g.weight.shape[1] for g in group}) == 1:
-                    xin = preps[0][0]
-                    outs = ops.linear_fwd_group(xin, [g.weight for g in group], [p[1] for p in preps])
-                    stats["kernel"] += len(group)
-                    stats["grouped_launches"] += 1
-                    for g, y in zip(group[1:], outs[1:]):
-                        self.stash[id(g)] = (x, key, y)
-                    return outs[0]
+                # the activation is cast (autocast) and checked ONCE, against the first member; the others must agree with it
+                # in dtype, width and bias handling -- `_prepare` on each would cast x again per member
+                p0 = _prepare(x, mod.weight, mod.bias)
+                if p0 is not None:
+                    xin, w0 = p0[0], mod.weight
+                    biases = [p0[1]]
+                    ok = True
+                    for g in group[1:]:
+                        w, b = g.weight, g.bias
+                        if w.dtype != w0.dtype or w.shape[1] != w0.shape[1] or not w.is_cuda:
+                            ok = False
+                            break
+                        if b is not None and b.dtype != w.dtype:
+                            if not (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == w.dtype):
+                                ok = False
+                                break
+                            b = b.to(w.dtype)
+                        if not ops.linear_fwd_supported(xin, w, b):
+                            ok = False
+                            break
+                        biases.append(b)
+                    if ok:
+                        outs = ops.linear_fwd_group(xin, [g.weight for g in group], biases, _checked=True)
+                        stats["kernel"] += len(group)
+                        stats["grouped_launches"] += 1
+                        for g, y in zip(group[1:], outs[1:]):
+                            self.stash[id(g)] = (x, key, y, mod)
+                        return outs[0]
+            _trouble(mod)                                        # (the group could not be formed for this call)
         return linear(x, mod.weight, mod.bias)
 
     def close(self):
         self._close_run()
         if self.stash:
             stats["stash_dropped"] += len(self.stash)
+            for first in {id(k[3]): k[3] for k in self.stash.values()}.values():
+                _trouble(first)
         self.stash.clear()
 
 

@@ -93,32 +93,45 @@ def linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None 
 LINEAR_GROUP_MAX = 4
 
 
-def linear_fwd_group(x: torch.Tensor, weights, biases=None) -> list:
+_group_jobs = {}           # (W pointer, N, ldw, bias pointer) per member -> the launch's job table, everything but Y filled in
+
+
+def linear_fwd_group(x: torch.Tensor, weights, biases=None, _checked: bool = False) -> list:
     """[x @ w.T + b for w, b in zip(weights, biases)] in ONE launch of the batch-invariant kernel: up to 4 linears fed the
     same activations (q / k / v, wi_0 / wi_1, cross-attention k / v).  Every output has the bits `linear_fwd` gives it;
     the launch shares the chip between the products (include/vlmc.h: vlmc_linear_fwd_group)."""
-    weights = list(weights)
-    biases = [None] * len(weights) if biases is None else list(biases)
-    if not 1 <= len(weights) <= LINEAR_GROUP_MAX or len(biases) != len(weights):
-        raise ValueError(f"linear_fwd_group takes 1..{LINEAR_GROUP_MAX} weights and as many biases")
-    _need_gpu(x, *weights, *[b for b in biases if b is not None])
-    for w, b in zip(weights, biases):
-        if not linear_fwd_supported(x, w, b):
-            raise TypeError("vlmc.linear_fwd_group: fp16/bf16 tensors of one dtype with in_features % 8 == 0 expected")
+    n = len(weights)
+    if biases is None:
+        biases = [None] * n
+    if not _checked:
+        if not 1 <= n <= LINEAR_GROUP_MAX or len(biases) != n:
+            raise ValueError(f"linear_fwd_group takes 1..{LINEAR_GROUP_MAX} weights and as many biases")
+        _need_gpu(x, *weights, *[b for b in biases if b is not None])
+        for w, b in zip(weights, biases):
+            if not linear_fwd_supported(x, w, b):
+                raise TypeError("vlmc.linear_fwd_group: fp16/bf16 tensors of one dtype with in_features % 8 == 0 expected")
     K = weights[0].shape[1]
     x2 = x.reshape(-1, K)
     if x2.stride(1) != 1 or x2.stride(0) % 8 != 0 or x2.stride(0) < K or x2.data_ptr() % 16 != 0:
         x2 = x2.contiguous()
     M = x2.shape[0]
-    jobs = (_lib.LinearJob * len(weights))()
+    # the table holds nothing but what its key says (a recycled address of an equal shape describes the same job)
+    key = tuple((w.data_ptr(), w.shape[0], w.stride(0), b.data_ptr() if b is not None else 0) for w, b in zip(weights, biases))
+    jobs = _group_jobs.get(key)
+    if jobs is None:
+        if len(_group_jobs) > 4096:
+            _group_jobs.clear()
+        jobs = _group_jobs[key] = (_lib.LinearJob * n)()
+        for g, (wp, N, ldw, bp) in enumerate(key):
+            jobs[g] = _lib.LinearJob(wp, bp or None, None, N, ldw, N)
     outs = []
-    for g, (w, b) in enumerate(zip(weights, biases)):
-        y = torch.empty((M, w.shape[0]), dtype=x.dtype, device=x.device)
+    lead = x.shape[:-1]
+    for g in range(n):
+        y = torch.empty((M, key[g][1]), dtype=x.dtype, device=x.device)
+        jobs[g].Y = y.data_ptr()
         outs.append(y)
-        jobs[g] = _lib.LinearJob(w.data_ptr(), b.data_ptr() if b is not None else None, y.data_ptr(), w.shape[0], w.stride(0),
-                                 w.shape[0])
-    _lib.check(_lib.load().vlmc_linear_fwd_group(x2.data_ptr(), jobs, len(weights), _dtype_code(x), M, K, x2.stride(0), _stream()))
-    return [y.reshape(*x.shape[:-1], y.shape[1]) for y in outs]
+    _lib.check(_lib.load().vlmc_linear_fwd_group(x2.data_ptr(), jobs, n, _DT[x.dtype], M, K, x2.stride(0), _stream()))
+    return [y.reshape(*lead, y.shape[1]) for y in outs]
 
 
 _16BIT = (torch.float16, torch.bfloat16)
