@@ -641,7 +641,43 @@ def gen_vicuna_e2e():
     print("vicuna_e2e.npz:", len(out), "arrays")
 
 
-GROUPS = {"wanda": gen_wanda, "wanda_e2e": gen_wanda_e2e, "sparse_lora": gen_sparse_lora, "sparsegpt": gen_sparsegpt,
+def gen_nm_ties():
+    """n:m selection with TIES inside the m-groups (wanda_pruner.py:326-329: `torch.topk(tmp, n, dim=1, largest=False)`).  Which
+    of several equal scores torch.topk returns is implementation-defined: the reference's CPU answer (this container's torch;
+    its CUDA kernel differs again) is RECORDED here, so that the repo's own policy -- lowest column first, the stable order of
+    the per-row rule -- is held against it explicitly instead of being avoided (tests/test_nm_ties.py)."""
+    out = {}
+    k = 0
+    for name, dt, n, m, tower in [("bf16_2_4_t5", torch.bfloat16, 2, 4, "t5"), ("fp16_4_8_vit", torch.float16, 4, 8, "vit"),
+                                  ("fp32_2_4_vit", torch.float32, 2, 4, "vit"), ("bf16_4_8_t5", torch.bfloat16, 4, 8, "t5")]:
+        W = craft_weight(32, 64, dt, seed=900 + k, ties=True)
+        W[9, :] = 0.01                                 # a whole row of one value
+        W[10, 0::4] = W[10, 1::4]                       # pairs inside every 4-group
+        xs = make_xs(5, 11, 64, dt, seed=950 + k, equal_cols=True)
+        for x in xs:
+            x[..., 32:64] = x[..., 32:33]              # 32 identical channels: every group there ties on the activation side
+        mask, Wn, imp = ref_prune_one_linear(W, xs, tower, n=n, m=m)
+        out.update({f"{name}/W": W, f"{name}/xs": torch.cat(xs), f"{name}/n": n, f"{name}/m": m,
+                    f"{name}/mask": mask, f"{name}/Wn": Wn, f"{name}/imp": imp})
+        k += 1
+    # DSnoT n:m (dsnot_pruner.py:407-552): a walk long enough to come back to m-groups both of whose kept entries were
+    # already swapped out (their metrics sit at rowmax + 1): `torch.topk(pruning_block, 1, largest=False)` (:517-519) then
+    # picks one of two EQUAL values
+    for name, tower, dt, out_f in [("dsnot_t5_fp32_2_4", "t5", torch.float32, 32), ("dsnot_vit_bf16_2_4", "vit", torch.bfloat16, 24)]:
+        W = craft_weight(out_f, 64, dt, seed=990 + k, ties=False)
+        xs = make_xs(6, 12, 64, dt, seed=995 + k, mean=0.3, equal_cols=False)
+        kw = dict(max_cycle_time=19, update_threshold=0.0)
+        mask, Wn = ref_dsnot_one_linear(W, xs, tower, ratio=0.5, n=2, m=4, **kw)
+        out.update({f"{name}/W": W, f"{name}/xs": torch.cat(xs), f"{name}/mask": mask, f"{name}/Wn": Wn, f"{name}/n": 2, f"{name}/m": 4,
+                    f"{name}/tower": np.array(tower)})
+        for k_, v_ in kw.items():
+            out[f"{name}/kw/{k_}"] = np.array(v_)
+        k += 1
+    golden_io.save("nm_ties", out)
+    print("nm_ties.npz:", len(out), "arrays")
+
+
+GROUPS = {"nm_ties": gen_nm_ties, "wanda": gen_wanda, "wanda_e2e": gen_wanda_e2e, "sparse_lora": gen_sparse_lora, "sparsegpt": gen_sparsegpt,
           "sparsegpt_e2e": gen_sparsegpt_e2e, "dsnot": gen_dsnot,
           "dsnot_e2e": gen_dsnot_e2e, "ressa": gen_ressa, "ecoflap": gen_ecoflap, "global": gen_global, "vicuna_e2e": gen_vicuna_e2e}
 
