@@ -1,0 +1,75 @@
+"""The compiled host path (csrc/fastpath/fast_bind.cpp -> vlmc/_fast) and the ctypes route call the same C ABI: same bits, same
+refusals."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _both(monkeypatch, fn):
+    from vlmc import ops
+    assert ops._fast is not None, "vlmc/_fast is not built (python -c 'import __graft_entry__ as g; g.build()')"
+    fast = fn()
+    monkeypatch.setattr(ops, "_fast", None)
+    slow = fn()
+    monkeypatch.undo()
+    return fast, slow
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_linear_routes_agree(dtype, monkeypatch):
+    from vlmc import ops
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(3, 37, 256, generator=g, device=DEV).to(dtype)
+    ws = [torch.randn(n, 256, generator=g, device=DEV).to(dtype) for n in (64, 200, 96)]
+    bs = [torch.randn(64, generator=g, device=DEV).to(dtype), None, torch.randn(96, generator=g, device=DEV).to(dtype)]
+    for w, b in zip(ws, bs):
+        a, c = _both(monkeypatch, lambda: ops.linear_fwd(x, w, b))
+        assert a.shape == (3, 37, w.shape[0]) and torch.equal(a, c)
+    a, c = _both(monkeypatch, lambda: ops.linear_fwd_group(x, ws, bs))
+    assert len(a) == 3 and all(torch.equal(p, q) for p, q in zip(a, c))
+    assert all(torch.equal(p, ops.linear_fwd(x, w, b)) for p, w, b in zip(a, ws, bs))
+    # a strided input (column slice of a wider buffer) and an expanded one
+    wide = torch.randn(37, 512, generator=g, device=DEV).to(dtype)
+    a, c = _both(monkeypatch, lambda: ops.linear_fwd(wide[:, 256:], ws[0], bs[0]))
+    assert torch.equal(a, c) and torch.equal(a, ops.linear_fwd(wide[:, 256:].contiguous(), ws[0], bs[0]))
+    row = torch.randn(1, 256, generator=g, device=DEV).to(dtype).expand(5, 256)
+    a, c = _both(monkeypatch, lambda: ops.linear_fwd(row, ws[1]))
+    assert torch.equal(a, c)
+
+
+def test_attention_products_routes_agree(monkeypatch):
+    from vlmc import ops
+    g = torch.Generator(device=DEV).manual_seed(1)
+    qkv = (torch.randn(2, 33, 3 * 4 * 88, generator=g, device=DEV) * 0.5).half().reshape(2, 33, 3, 4, 88).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    a, c = _both(monkeypatch, lambda: ops.attn_matmul(q, k.transpose(-2, -1)))
+    assert torch.equal(a, c)
+    p = a.softmax(-1)
+    a, c = _both(monkeypatch, lambda: ops.attn_matmul(p, v))
+    assert torch.equal(a, c)
+    a, c = _both(monkeypatch, lambda: ops.attn_matmul(p[0], v[0]))                     # 3-D
+    assert torch.equal(a, c) and a.shape == (4, 33, 88)
+    a, c = _both(monkeypatch, lambda: ops.attn_matmul(p[:1], v))                       # broadcast batch
+    assert torch.equal(a, c) and a.shape == (2, 4, 33, 88)
+
+
+def test_both_routes_refuse_the_same_calls(monkeypatch):
+    from vlmc import ops
+    x = torch.randn(4, 64, device=DEV)
+    w = torch.randn(8, 64, device=DEV)
+    for fast in (True, False):
+        if not fast:
+            monkeypatch.setattr(ops, "_fast", None)
+        with pytest.raises(TypeError):
+            ops.linear_fwd(x, w)                                         # fp32
+        assert ops.linear_fwd(x, w, _try=True) is None
+        with pytest.raises(TypeError):
+            ops.linear_fwd_group(x.half(), [w.half(), w])                # mixed dtypes
+        with pytest.raises(ValueError):
+            ops.linear_fwd_group(x.half(), [w.half()] * 5)               # more than 4 members
+        with pytest.raises(TypeError):
+            ops.attn_matmul(x.half()[None], w.half().t()[None].float())
+        with pytest.raises(RuntimeError):
+            ops.linear_fwd(x.cpu().half(), w.cpu().half())               # no CPU fallback on either route

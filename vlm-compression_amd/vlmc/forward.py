@@ -66,10 +66,17 @@ def _prepare(x, weight, bias):
 
 def linear(x, weight, bias=None):
     """`F.linear` for a calibration forward: the invariant kernel when the replay engine asked for it and the call fits."""
-    p = _prepare(x, weight, bias)
-    if p is not None:
-        stats["kernel"] += 1
-        return ops.linear_fwd(p[0], weight, p[1], _checked=True)     # (linear_fwd_supported has just said yes)
+    if _active and not torch.is_grad_enabled() and weight.is_cuda:
+        if not torch.is_autocast_enabled():
+            y = ops.linear_fwd(x, weight, bias, _try=True)           # (the entry point checks; None: not one it takes)
+            if y is not None:
+                stats["kernel"] += 1
+                return y
+        else:
+            p = _prepare(x, weight, bias)                            # what autocast would do to x and the bias
+            if p is not None:
+                stats["kernel"] += 1
+                return ops.linear_fwd(p[0], weight, p[1], _checked=True)
     stats["library"] += 1
     return F.linear(x, weight, bias)
 
@@ -208,17 +215,23 @@ def attn_matmul_enabled():
 
 
 def _make_matmul(orig):
-    plan_of, run = ops.attn_matmul_plan, ops.attn_matmul
+    plan_of, run, fast, stream = ops.attn_matmul_plan, ops.attn_matmul, ops._fast, ops._stream
     Tensor = torch.Tensor
 
     def matmul(a, b, *args, **kw):
         if not args and not kw and type(a) is Tensor and type(b) is Tensor and a.dim() >= 3 and not torch.is_grad_enabled():
             if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() != a.dtype:
                 return orig(a, b)                                   # (autocast would cast the operands: the library's call)
-            plan = plan_of(a, b)
-            if plan is not None:
-                stats["attn_kernel"] += 1
-                return run(a, b, plan)
+            if fast is not None:
+                out = fast.attn_matmul(a, b, stream()) if a.is_cuda else None      # None: not a product the kernel computes
+                if out is not None:
+                    stats["attn_kernel"] += 1
+                    return out
+            else:
+                plan = plan_of(a, b)
+                if plan is not None:
+                    stats["attn_kernel"] += 1
+                    return run(a, b, plan)
             stats["attn_library"] += 1
         return orig(a, b, *args, **kw)
     return matmul

@@ -65,6 +65,26 @@ _MODES = {"row": _lib.SEL_ROW, "matrix": _lib.SEL_MATRIX, "nm": _lib.SEL_NM}
 _hessian_ws = Workspace()
 
 
+def _load_fast():
+    """The compiled host path (csrc/fastpath/fast_bind.cpp -> vlmc/_fast*.so) for linear_fwd / linear_fwd_group / attn_matmul:
+    the same C ABI, ~2 us of host time per call instead of 8-22 through ctypes.  None when it has not been built, when
+    `VLMC_FAST=0`, or when `VLMC_LIB` points at another build of the library (the module links the in-tree one)."""
+    import os
+    if os.environ.get("VLMC_FAST", "1") == "0" or os.environ.get("VLMC_LIB"):
+        return None
+    try:
+        from . import _fast
+    except ImportError:
+        return None
+    if _fast.abi_version() != _lib.header_abi_version():
+        raise ImportError("vlmc/_fast was built against another ABI version of libvlmc_hip.so; rebuild (make -C vlm-compression_amd/csrc/fastpath)")
+    _lib.load()
+    return _fast
+
+
+_fast = _load_fast()
+
+
 def linear_fwd_supported(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> bool:
     """Whether `linear_fwd` takes this call: 16-bit activations and weights of one dtype on the GPU, K a multiple of 8."""
     return (x.is_cuda and weight.is_cuda and x.dtype == weight.dtype and x.dtype in (torch.float16, torch.bfloat16)
@@ -73,11 +93,23 @@ def linear_fwd_supported(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tens
             and (bias is None or (bias.is_cuda and bias.dtype == weight.dtype and bias.is_contiguous())))
 
 
-def linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None, _checked: bool = False) -> torch.Tensor:
+def linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None, _checked: bool = False,
+               _try: bool = False) -> torch.Tensor:
     """y = x @ weight.T + bias on the batch-invariant MFMA kernel (`F.linear` inside the calibration replay's block
-    forwards, wanda_pruner.py:308-311,343-346): a row of y depends on its row of x only, whatever else is in the call."""
+    forwards, wanda_pruner.py:308-311,343-346): a row of y depends on its row of x only, whatever else is in the call.
+    `_try`: return None instead of raising when the call is not one the kernel takes."""
+    if _fast is not None:
+        if not x.is_cuda:
+            _need_gpu(x, weight, bias)
+        y = _fast.linear_fwd(x, weight, bias, _stream())
+        if y is None and not _try:
+            _need_gpu(x, weight, bias)
+            raise TypeError("vlmc.linear_fwd: fp16/bf16 tensors of one dtype with in_features % 8 == 0 expected")
+        return y
+    if _try and not (x.is_cuda and linear_fwd_supported(x, weight, bias)):
+        return None
     _need_gpu(x, weight, bias)
-    if not _checked and not linear_fwd_supported(x, weight, bias):
+    if not _checked and not _try and not linear_fwd_supported(x, weight, bias):
         raise TypeError("vlmc.linear_fwd: fp16/bf16 tensors of one dtype with in_features % 8 == 0 expected")
     N, K = weight.shape
     x2 = x.reshape(-1, K)
@@ -103,6 +135,16 @@ def linear_fwd_group(x: torch.Tensor, weights, biases=None, _checked: bool = Fal
     n = len(weights)
     if biases is None:
         biases = [None] * n
+    if _fast is not None:
+        if not x.is_cuda:
+            _need_gpu(x, *weights)
+        outs = _fast.linear_fwd_group(x, list(weights), list(biases), _stream())
+        if outs is None:
+            if not 1 <= n <= LINEAR_GROUP_MAX or len(biases) != n:
+                raise ValueError(f"linear_fwd_group takes 1..{LINEAR_GROUP_MAX} weights and as many biases")
+            _need_gpu(x, *weights, *[b for b in biases if b is not None])
+            raise TypeError("vlmc.linear_fwd_group: fp16/bf16 tensors of one dtype with in_features % 8 == 0 expected")
+        return outs
     if not _checked:
         if not 1 <= n <= LINEAR_GROUP_MAX or len(biases) != n:
             raise ValueError(f"linear_fwd_group takes 1..{LINEAR_GROUP_MAX} weights and as many biases")
@@ -180,6 +222,14 @@ def attn_matmul(a: torch.Tensor, b: torch.Tensor, _plan=None) -> torch.Tensor:
     """`torch.matmul(a, b)` for the batched products of attention (q @ k^T, attn @ v: eva_vit.py:147,164;
     modeling_t5.py:590,638) on the batch-invariant MFMA kernel: an output element has the same bits whatever the batch
     count, M or N (include/vlmc.h: vlmc_attn_matmul)."""
+    if _fast is not None:
+        if not a.is_cuda:
+            _need_gpu(a, b)
+        out = _fast.attn_matmul(a, b, _stream())
+        if out is None:
+            _need_gpu(a, b)
+            raise TypeError("vlmc.attn_matmul: 3-D / 4-D fp16 / bf16 tensors of one dtype expected, a contiguous along k, b along k or n")
+        return out
     plan = _plan if _plan is not None else attn_matmul_plan(a, b)
     if plan is None:
         _need_gpu(a, b)
