@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLMC_ABI_VERSION 6
+#define VLMC_ABI_VERSION 7
 
 #define VLMC_OK 0
 #define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
@@ -220,6 +220,15 @@ int vlmc_linear_fwd_group(const void *X, const vlmc_linear_job *jobs /* host arr
 int vlmc_attn_matmul(const void *A, const void *B, void *C, int dtype, int64_t batch0, int64_t batch1, int64_t M, int64_t N,
                      int64_t K, int64_t sa_b0, int64_t sa_b1, int64_t sa_m, int64_t sb_b0, int64_t sb_b1, int64_t sb_k,
                      int64_t sb_n, int64_t sc_b0, int64_t sc_b1, int64_t sc_m, void *stream);
+
+/* ---- batch-invariant mean over the last dimension (the norms of a replayed block) -----------------
+ * Replaces `x.mean(-1, keepdim=True)` on the fp32 squares inside the language models' norms --
+ * `hidden_states.to(torch.float32).pow(2).mean(-1, keepdim=True)` (transformers' T5LayerNorm / LlamaRMSNorm, called from
+ * the blocks of modeling_t5.py / modeling_llama.py) -- while a block is replayed: torch's reduction kernel chooses how many
+ * threads share an output by the NUMBER of outputs, so a 4-token sample alone and inside a group of 128 get other last bits.
+ *     out[r] = (sum over c of x[r * ldx + c]) / n        one wave per row, a fixed order that depends on n only
+ * x [rows, n] fp32 (row stride ldx elements), out [rows] fp32.                                                 */
+int vlmc_row_mean(const float *x, int64_t rows, int64_t n, int64_t ldx, float *out, void *stream);
 
 /* ---- K8: SparseGPT Hessian accumulation (MFMA SYRK) -------------------------------------------------
  * Replaces the arithmetic of SparseGPT.add_batch, sparsegpt_pruner.py:76-79

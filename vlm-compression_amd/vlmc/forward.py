@@ -34,7 +34,7 @@ from . import ops
 
 _active = 0
 stats = {"kernel": 0, "library": 0, "grouped_launches": 0, "served_from_group": 0, "stash_dropped": 0, "attn_kernel": 0,
-         "attn_library": 0}
+         "attn_library": 0, "mean_kernel": 0}
 
 # first member of a learned sibling group -> tuple of weak references to all members, in call order
 _SIBLINGS = weakref.WeakKeyDictionary()
@@ -237,9 +237,31 @@ def _make_matmul(orig):
     return matmul
 
 
+def _make_mean(orig):
+    """`x.mean(-1[, keepdim])` / `torch.mean(x, -1[, keepdim])` of an fp32 CUDA tensor on `vlmc_row_mean` (the fp32 mean of
+    squares inside T5LayerNorm / LlamaRMSNorm: torch's reduction kernel is configured by the number of outputs, so a 4-token
+    sample gets other last bits alone than in a group); every other call goes to the original."""
+    run = ops.row_mean
+    Tensor, f32 = torch.Tensor, torch.float32
+
+    def mean(x, *args, **kw):
+        if type(x) is Tensor and x.dtype is f32 and x.is_cuda and not torch.is_grad_enabled() and x.dim() >= 2:
+            dim = args[0] if args else kw.get("dim")
+            if type(dim) in (tuple, list) and len(dim) == 1:
+                dim = dim[0]
+            if type(dim) is int and (dim == -1 or dim == x.dim() - 1) and len(args) <= 2 and not (set(kw) - {"dim", "keepdim"}) \
+                    and x.shape[-1] > 0:
+                keepdim = args[1] if len(args) > 1 else kw.get("keepdim", False)
+                stats["mean_kernel"] += 1
+                return run(x, bool(keepdim))
+        return orig(x, *args, **kw)
+    return mean
+
+
 @contextlib.contextmanager
 def invariant_matmuls():
-    """Batched 16-bit `matmul`s run on `vlmc_attn_matmul` for the duration (nestable)."""
+    """Batched 16-bit `matmul`s run on `vlmc_attn_matmul`, fp32 means over the last dimension on `vlmc_row_mean`, for the
+    duration (nestable)."""
     global _mm_depth
     if not (enabled() and attn_matmul_enabled()):
         yield
@@ -253,6 +275,12 @@ def invariant_matmuls():
             if name not in torch.Tensor.__dict__:
                 setattr(torch.Tensor, name, _make_matmul(getattr(base, name)))
                 _mm_saved.setdefault("tensor", []).append(name)
+        if os.environ.get("VLMC_ROW_MEAN", "1") != "0":           # the fp32 mean inside the norms (batch-variant in torch)
+            _mm_saved["mean"] = torch.mean
+            torch.mean = _make_mean(torch.mean)
+            if "mean" not in torch.Tensor.__dict__:
+                setattr(torch.Tensor, "mean", _make_mean(base.mean))
+                _mm_saved.setdefault("tensor", []).append("mean")
     _mm_depth += 1
     try:
         yield
@@ -260,6 +288,8 @@ def invariant_matmuls():
         _mm_depth -= 1
         if _mm_depth == 0:
             torch.matmul, torch.bmm = _mm_saved.pop("matmul"), _mm_saved.pop("bmm")
+            if "mean" in _mm_saved:
+                torch.mean = _mm_saved.pop("mean")
             for name in _mm_saved.pop("tensor", []):
                 delattr(torch.Tensor, name)
 

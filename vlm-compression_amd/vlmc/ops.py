@@ -242,6 +242,22 @@ def attn_matmul(a: torch.Tensor, b: torch.Tensor, _plan=None) -> torch.Tensor:
     return out
 
 
+def row_mean(x: torch.Tensor, keepdim: bool = False) -> torch.Tensor:
+    """`x.mean(-1, keepdim=keepdim)` for fp32 CUDA tensors with a fixed, batch-invariant summation order (the norms of a
+    replayed block: include/vlmc.h: vlmc_row_mean)."""
+    _need_gpu(x)
+    if x.dtype != torch.float32 or x.dim() < 1 or x.shape[-1] == 0:
+        raise TypeError("vlmc.row_mean: a non-empty fp32 tensor expected")
+    n = x.shape[-1]
+    x2 = x.reshape(-1, n)
+    if x2.stride(1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < n):
+        x2 = x2.contiguous()
+    rows = x2.shape[0]
+    out = torch.empty(x.shape[:-1] + ((1,) if keepdim else ()), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().vlmc_row_mean(x2.data_ptr(), rows, n, x2.stride(0) if rows > 1 else n, out.data_ptr(), _stream()))
+    return out
+
+
 def hessian_accum(H: torch.Tensor, x: torch.Tensor, alpha: float, beta: float) -> torch.Tensor:
     """H = alpha * H + beta * x^T x on the tiles on and below the diagonal (SparseGPT.add_batch, sparsegpt_pruner.py:76-79,
     with alpha = n/(n+b) and beta = 2/(n+b)); x [rows, in] fp16 / bf16 / fp32.  `symmetrize_lower(H)` completes H."""
