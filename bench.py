@@ -378,8 +378,9 @@ def reference_ops_leg(dev, steps):
     modeling_t5.py:520-640) write it as batched `torch.matmul`s with a position bias, masks and an fp32 softmax, and real
     calibration text is ragged.  Same prune on such a stand-in (vlmc/synthetic.py reference_ops=True, prompt lengths
     8..128): seconds, groups per block forward, and how far the grouped replay's masks are from the reference's
-    one-sample-per-forward loop run on the same GPU (the batched matmuls are the GEMM library's: it may pick its kernel by
-    batch count)."""
+    one-sample-per-forward loop run on the same GPU.  Since round 4 the blocks' batched matmuls run on vlmc_attn_matmul and
+    the norms' fp32 mean on vlmc_row_mean during the replay (vlmc/forward.py: invariant_matmuls), batch-invariant like the
+    linears: the agreement is expected to be exactly 1.0 (round 3, library matmuls: 0.9971-0.99997, run to run)."""
     from lavis.compression.pruners import calibration as cal
     job = PruneJob(dev, reference_ops=True, ragged=True)
     groups = []

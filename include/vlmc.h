@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLMC_ABI_VERSION 7
+#define VLMC_ABI_VERSION 8
 
 #define VLMC_OK 0
 #define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
@@ -253,6 +253,24 @@ int vlmc_symmetrize_lower(float *H, int64_t n, int64_t ldh, void *stream);
  * positive (LAPACK convention); it is left untouched otherwise.                                    */
 int vlmc_chol_block(const float *A, int64_t lda, int nb, float *L, int64_t ldl, float *Linv, int64_t ldi, int *info,
                     int col0, void *stream);
+
+/* ---- K9': factor AND inverse factor of a whole Hessian in ONE persistent launch ---------------------------
+ * Replaces the chain `torch.linalg.cholesky(H)` -> `torch.cholesky_inverse` -> `torch.linalg.cholesky(., upper=True)`
+ * (sparsegpt_pruner.py:112-150) together with vlmc/sparsegpt.py's index reversal: for the symmetric positive definite A
+ * (n x n fp32, n a multiple of 128, lower 128 x 128 tiles read) it writes the lower Cholesky factor M (A = M M^T) and
+ * X = M^-1 (lower tiles; the tiles above the diagonal of M and X are NOT written).  With A = J H J (rows and columns
+ * reversed), U = J X J is the upper factor of H^-1 that the sweep needs.  One grid of persistent workgroups draws 128 x 128
+ * tile tasks (left-looking; products on v_mfma_f32_32x32x2_f32) from a ticket counter and hands tiles over through
+ * flags -- no host round trip, no launch per 128 columns.  `*info` (device int, zero on entry) receives the 1-based
+ * index of the first non-positive pivot (LAPACK convention; the factor is then garbage), or stays 0; -1: a workgroup gave
+ * up waiting for a tile (bounded polls; never expected) and every workgroup left.  `workspace`:
+ * vlmc_chol_inverse_workspace(n) bytes of device memory, cleared by the call.
+ * `max_workgroups` bounds the grid (0: one workgroup per tile task of a column pair, at most n/128 squared) so that
+ * several factorizations can share the chip (each workgroup takes a whole CU's LDS).  The summation order of every tile
+ * is fixed: the result does not depend on the number of workgroups.                                              */
+size_t vlmc_chol_inverse_workspace(int64_t n);
+int vlmc_chol_inverse(const float *A, int64_t n, int64_t lda, float *M, int64_t ldm, float *X, int64_t ldx, int *info,
+                      void *workspace, size_t workspace_bytes, int max_workgroups, void *stream);
 
 /* ---- K10: SparseGPT blocked OBS sweep ----------------------------------------------------
  * Replaces the per-column Python loop of sparsegpt_pruner.py:186-205 for ONE block of

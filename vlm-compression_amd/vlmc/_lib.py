@@ -70,6 +70,8 @@ SIGNATURES = {
     "vlmc_hessian_accum": (_i, [_p, _i, _i64, _i64, _i64, _p, _i64, _c.c_float, _c.c_float, _p, _sz, _p]),
     "vlmc_symmetrize_lower": (_i, [_p, _i64, _i64, _p]),
     "vlmc_chol_block": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, _p, _i, _p]),
+    "vlmc_chol_inverse_workspace": (_sz, [_i64]),
+    "vlmc_chol_inverse": (_i, [_p, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _sz, _i, _p]),
     "vlmc_sparsegpt_sweep": (_i, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i, _i, _p, _i64, _p, _i64, _p]),
     "vlmc_sparsegpt_select_workspace_bytes": (_i64, []),
     "vlmc_sparsegpt_select_sweep": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _p, _p, _i64, _p, _i64, _p, _p]),

@@ -221,6 +221,7 @@ def release_caches():
     the same process starts without them; the next prune captures again."""
     _chol_graphs.clear()
     _inv_graphs.clear()
+    _persist_bufs.clear()
 
 
 _SELECT_THRESHOLD = __import__("os").environ.get("VLMC_SGPT_SORT_THRESHOLD", "0") != "1"
@@ -275,8 +276,43 @@ def _inverse_factor_steps(A, L, inv, X, U, info, side=None):
     U.copy_(torch.flip(X, (0, 1)))
 
 
+_PERSISTENT = __import__("os").environ.get("VLMC_SGPT_PERSISTENT", "1") != "0"
+_persist_bufs = {}      # (n, device index, slot) -> (A, M, X, U, info, workspace)
+PERSISTENT_MAX_WORKGROUPS = int(__import__("os").environ.get("VLMC_SGPT_PERSISTENT_WGS", "128"))
+
+
+def persistent_factor_usable(n: int) -> bool:
+    """`vlmc_chol_inverse` takes n a multiple of 128 (every width of ViT-g / Flan-T5-XL / Vicuna-7B); `VLMC_SGPT_PERSISTENT=0`
+    keeps the chain of launches per 128 columns (the cross-check)."""
+    return _PERSISTENT and n % _CHOL_NB == 0 and n >= 2 * _CHOL_NB
+
+
+def _inverse_upper_factor_persistent(H: torch.Tensor, slot: int, max_workgroups: int | None = None):
+    """(U, info) from ONE persistent launch (csrc/chol_persistent.hip): A = J H J, M M^T = A, X = M^-1, U = J X J."""
+    n, dev = H.shape[0], H.device
+    key = (n, dev.index, slot)
+    ent = _persist_bufs.get(key)
+    lib = _lib.load()
+    if ent is None:
+        A = torch.empty((n, n), dtype=torch.float32, device=dev)
+        M = torch.empty((n, n), dtype=torch.float32, device=dev)
+        X = torch.zeros((n, n), dtype=torch.float32, device=dev)       # tiles above the diagonal are never written: stay zero
+        U = torch.empty((n, n), dtype=torch.float32, device=dev)
+        info = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = torch.empty(int(lib.vlmc_chol_inverse_workspace(n)), dtype=torch.uint8, device=dev)
+        ent = _persist_bufs[key] = (A, M, X, U, info, ws)
+    A, M, X, U, info, ws = ent
+    A.copy_(torch.flip(H, (0, 1)))
+    info.zero_()
+    wgs = PERSISTENT_MAX_WORKGROUPS if max_workgroups is None else int(max_workgroups)
+    _lib.check(lib.vlmc_chol_inverse(A.data_ptr(), n, n, M.data_ptr(), n, X.data_ptr(), n, info.data_ptr(), ws.data_ptr(), ws.numel(),
+                                     wgs, _stream()))
+    U.copy_(torch.flip(X, (0, 1)))
+    return U.clone(), info.clone()
+
+
 @torch.no_grad()
-def inverse_upper_factor(H: torch.Tensor, slot: int = 0):
+def inverse_upper_factor(H: torch.Tensor, slot: int = 0, max_workgroups: int | None = None):
     """(U, info): the upper triangular U with U^T U = H^-1, i.e. what `cholesky(cholesky_inverse(cholesky(H)), upper=True)`
     (sparsegpt_pruner.py:112-150) arrives at, from ONE factorization: with J the index reversal, J H J = M M^T gives
     H = R R^T for the upper triangular R = J M J, hence H^-1 = (R^-1)^T R^-1 and U = R^-1 = J M^-1 J (the Cholesky
@@ -286,6 +322,8 @@ def inverse_upper_factor(H: torch.Tensor, slot: int = 0):
     assert H.dim() == 2 and H.shape[0] == H.shape[1] and H.dtype == torch.float32
     n = H.shape[0]
     dev = H.device
+    if persistent_factor_usable(n):
+        return _inverse_upper_factor_persistent(H, slot, max_workgroups)
     key = (n, dev.index, slot)           # `slot`: chains of equal size that run at the same time need buffers of their own
     ent = _inv_graphs.get(key)
     if ent is None:
@@ -376,6 +414,19 @@ def factorize_many(items, percdamp=0.01, max_streams=8, history=None):
     history = {} if history is None else history
     slots, n_launched = {}, [0]
 
+    budget = {}             # n -> workgroups a persistent factorization of that size may take (they share the chip's CUs)
+
+    def plan_budget(sizes):
+        """One persistent workgroup holds a whole CU (132 KB of LDS): the chains launched together share the CUs in proportion
+        to their tile counts (n / 128)^2, at least 8 each -- the largest chain is throughput-bound below ~128-256 workgroups,
+        the small ones are bound by their critical path whatever they get (tools/chain_probe2.py)."""
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        tot = sum((n // _CHOL_NB) ** 2 for n in sizes) or 1
+        budget.clear()
+        for n in set(sizes):
+            tiles = (n // _CHOL_NB) ** 2
+            budget[n] = max(8, min(tiles, (cus * tiles) // tot))
+
     def launch(H, k, damp):
         n = H.shape[0]
         slot = slots.get(n, 0)
@@ -389,7 +440,7 @@ def factorize_many(items, percdamp=0.01, max_streams=8, history=None):
                 Hk.diagonal().add_(damp * float(k))             # k failed attempts: H += damp, k times (:118-121)
             else:
                 Hk = H
-            U, info = inverse_upper_factor(Hk, slot=slot)
+            U, info = inverse_upper_factor(Hk, slot=slot, max_workgroups=budget.get(n))
             failed = (info != 0).any()
             nan = torch.isnan(U).any()
             # [not clean, "factorized without a failing pivot but the inverse factor holds NaN"]: the second is not a case
@@ -406,7 +457,13 @@ def factorize_many(items, percdamp=0.01, max_streams=8, history=None):
         damp = percdamp * torch.mean(torch.diag(H))              # (:110) a device scalar
         ks = (0,) if history.get(idx, 1) == 0 else (0, 1)
         prepared.append((H, c, dead, damp, ks))
-    attempts = [[(k,) + launch(H, k, damp) for k in ks] for H, c, dead, damp, ks in prepared]
+    plan_budget([H.shape[0] for H, c, dead, damp, ks in prepared for _ in ks])
+    # (the largest chains first: a persistent grid that finds no free CU waits for one)
+    order = sorted(range(len(prepared)), key=lambda i: -prepared[i][0].shape[0])
+    attempts = [None] * len(prepared)
+    for i in order:
+        H, c, dead, damp, ks = prepared[i]
+        attempts[i] = [(k,) + launch(H, k, damp) for k in ks]
     for st in streams:
         main.wait_stream(st)
     flags = torch.stack([bad for att in attempts for _, _, bad in att]).cpu().tolist()       # the ONE host read
@@ -433,6 +490,7 @@ def factorize_many(items, percdamp=0.01, max_streams=8, history=None):
         else:
             retry.append((idx, H, c, dead, damp, ks))
     if retry:                                                    # the next two attempts of what has not come out clean
+        plan_budget([H.shape[0] for idx, H, c, dead, damp, ks in retry for _ in range(2)])
         second = [(idx, H, c, dead, [(k,) + launch(H, k, damp) for k in (ks[-1] + 1, ks[-1] + 2)]) for idx, H, c, dead, damp, ks in retry]
         for st in streams:
             main.wait_stream(st)
