@@ -388,3 +388,75 @@ def test_fasterprune_with_one_launch_blocks_equals_the_multi_launch_route(groupe
     for wa, wb, sp in zip(a, b, spars):
         assert torch.equal(wa.view(torch.int16), wb.view(torch.int16))
         assert abs(float((wa == 0).float().mean()) - sp) < 0.01
+
+
+# ---- round 4: the damping ROUTE held against the reference's own decision and against fp64 ---------------------------------
+def test_damping_route_on_the_goldens_is_the_references_and_fp64s():
+    """sparsegpt_pruner.py:112-150 damps H only while its Cholesky fails.  On the reference's golden Hessians the route is
+    known (tests/test_oracle_golden.py::test_sparsegpt_damping_route_of_the_reference_on_the_rank_deficient_golden: the oracle
+    that reproduces the reference's pruned weights bit for bit damps the rank-deficient H ONCE, the clean one never; fp64
+    arithmetic decides the same).  `factorize_many` -- attempts k = 0, 1 side by side, the first clean one in k order -- must take
+    the same route, through the chain of launches and through the persistent kernel alike, and its factor must be the factor
+    of (H + k damp I)^-1."""
+    from vlmc import sparsegpt as SG
+    for name, want_k in (("fp32_rankdef", 1), ("fp32_u50", 0)):
+        H0 = G[f"{name}/H"].clone()
+        # fp64: the smallest k for which H + k damp I has a Cholesky factor
+        Hd = H0.double()
+        damp = 0.01 * Hd.diagonal().mean()
+        k64 = 0
+        while int(torch.linalg.cholesky_ex(Hd + k64 * damp * torch.eye(Hd.shape[0], dtype=torch.float64))[1]) != 0:
+            k64 += 1
+        assert k64 == want_k
+        trace = {}
+        OS.inverse_factor(H0.clone(), G[f"{name}/W"].clone().float(), 0.01, trace)
+        assert trace == {"damp_H": want_k, "damp_Hinv": 0}                         # the reference's own route (CPU oracle)
+        for persistent in (True, False):
+            SG._PERSISTENT = persistent
+            try:
+                hist, cache = {}, {"rows_seen": 18 if want_k else 288}
+                before = dict(SG.factor_stats)
+                SG.factorize_many([(H0.clone().to(DEV), cache)], percdamp=0.01, history=hist)
+            finally:
+                SG._PERSISTENT = True
+            assert hist == {0: want_k}, (name, persistent, hist)
+            assert SG.factor_stats["chain"] == before["chain"]                       # decided without the fallback chain
+            U = cache["U"].double().cpu()
+            target = Hd + want_k * damp * torch.eye(Hd.shape[0], dtype=torch.float64)
+            assert float((U.t() @ U @ target - torch.eye(Hd.shape[0], dtype=torch.float64)).abs().max()) < 5e-3
+            assert bool((torch.tril(cache["U"], -1) == 0).all()) and not bool(cache["dead"].any())
+
+
+@pytest.mark.parametrize("n", [256, 1408, 2048])
+def test_persistent_factorization_equals_the_chain_and_any_workgroup_count(n):
+    """`vlmc_chol_inverse` (ONE persistent launch, csrc/chol_persistent.hip) against the chain of launches per 128 columns:
+    the same factor up to fp32 summation order, the same accuracy against fp64, bit-identical for any number of workgroups;
+    a matrix that is not positive definite is flagged with LAPACK's column (and every workgroup leaves)."""
+    from vlmc import sparsegpt as SG
+    g = torch.Generator(device=DEV).manual_seed(n)
+    X = torch.randn(3 * n, n, generator=g, device=DEV)
+    H = (X.t() @ X) / (3 * n) + 0.01 * torch.eye(n, device=DEV)
+    outs = {}
+    for wgs in (None, 7, 1):
+        U, info = SG.inverse_upper_factor(H, max_workgroups=wgs)
+        assert int(info) == 0
+        outs[wgs] = U
+    assert torch.equal(outs[7], outs[None]) and torch.equal(outs[1], outs[None])
+    SG._PERSISTENT = False
+    try:
+        Uc, info = SG.inverse_upper_factor(H)
+    finally:
+        SG._PERSISTENT = True
+    assert float((outs[None] - Uc).norm() / Uc.norm()) < 2e-6
+    Hd, Ud = H.double(), outs[None].double()
+    assert float((Ud.t() @ Ud @ Hd - torch.eye(n, device=DEV, dtype=torch.float64)).abs().max()) < 5e-5
+    bad = H.clone()
+    bad[200, 200] = -1.0                          # (reversed inside: the failing column is reported in the reversed order)
+    U, info = SG.inverse_upper_factor(bad)
+    assert int(info) > 0
+    SG._PERSISTENT = False
+    try:
+        _, info_c = SG.inverse_upper_factor(bad)
+    finally:
+        SG._PERSISTENT = True
+    assert int(info) == int(info_c)
