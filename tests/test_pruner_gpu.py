@@ -598,83 +598,3 @@ def test_finished_tower_that_hands_a_block_output_on_as_a_keyword(monkeypatch):
     assert len(want) == len(stacked) == len(graphed) == len(lens)
     for a, b, c in zip(want, stacked, graphed):
         assert torch.equal(a, b) and torch.equal(a, c)
-
-
-# ---- round 3: one HIP graph per block signature, replayed for every block through staged weights --------------------------
-def _deep_toy_prune(method, ragged, lora=False):
-    """4 blocks per tower (first eager, second captured, the rest replayed), 16-bit like the real model, 8 samples."""
-    import toy_models
-    from lavis.compression import load_pruner
-    model = toy_models.init_toy(toy_models.ToyBlipT5(vit_depth=4, enc_depth=4, dec_depth=4, vit_dtype=torch.float16,
-                                                     t5_dtype=torch.bfloat16), seed=7)
-    if lora:
-        H.wrap_lora(model)
-    model = model.eval().to("cuda:0")
-    lens = [5, 7, 5, 5, 7, 3, 5, 7]
-    batches = []
-    for j in range(8):
-        ln = lens[j]
-        b = toy_models.make_batches(1, txt_len=ln if ragged else 5, out_len=(2 + ln % 3) if ragged else 4, seed=100 + j)[0]
-        batches.append({k: t.to("cuda:0") for k, t in b.items()})
-    spec = "4-0.5-1.0-1.0"
-    cfg = dict(t5_prune_spec=spec, vit_prune_spec=spec, t5_pruning_method=method, vit_pruning_method=method, num_samples=8,
-               max_sparsity_per_layer=1.01)
-    if method == "dsnot":
-        cfg["max_cycle_time"] = 8
-    pruner = load_pruner(f"blipt5_{method}_pruner", model, batches, cfg=cfg)
-    pruned, _ = pruner.prune(lora_model=True) if lora else pruner.prune()
-    sd = {k: v.clone() for k, v in pruned.state_dict().items()}
-    for n, m in pruned.named_modules():
-        if hasattr(m, "mask") and torch.is_tensor(m.mask):
-            sd[n + ".mask*"] = m.mask.clone()
-        if hasattr(m, "weight") and getattr(m.weight, "importance_score", None) is not None:
-            sd[n + ".importance*"] = torch.tensor(m.weight.importance_score, dtype=torch.float64)
-    return sd
-
-
-@pytest.mark.parametrize("method,ragged,lora", [("wanda", False, False), ("wanda", True, False), ("wanda", True, True),
-                                                ("dsnot", True, False), ("sparsegpt", False, False)])
-def test_staged_graphs_give_the_eager_block_forwards_bit_for_bit(method, ragged, lora, monkeypatch):
-    """Blocks with the same signature share ONE captured forward whose weights are read from a staging set
-    (`calibration.StagedGraphs`): weights, masks and importance scores of the whole prune equal the eager grouped replay."""
-    from lavis.compression.pruners import calibration as cal
-    import toy_models
-    monkeypatch.setattr(toy_models.ToyAttention, "use_sdpa", True)
-    monkeypatch.setenv("VLMC_STAGED_GRAPH", "0")
-    before = dict(cal.graph_stats)
-    eager = _deep_toy_prune(method, ragged, lora)
-    assert cal.graph_stats.get("staged_captures", 0) == before.get("staged_captures", 0)
-    monkeypatch.setenv("VLMC_STAGED_GRAPH", "1")
-    staged = _deep_toy_prune(method, ragged, lora)
-    assert cal.graph_stats.get("staged_captures", 0) > before.get("staged_captures", 0)
-    assert cal.graph_stats.get("staged_replays", 0) >= 2 * (cal.graph_stats["staged_captures"] - before.get("staged_captures", 0))
-    assert cal.graph_stats["fallbacks"] == before["fallbacks"]
-    assert eager.keys() == staged.keys()
-    for k in eager:
-        assert torch.equal(eager[k], staged[k]), k
-    monkeypatch.setenv("VLMC_STAGED_ROWS", "1")                           # nothing is small enough: all eager again
-    mid = dict(cal.graph_stats)
-    again = _deep_toy_prune(method, ragged, lora)
-    assert cal.graph_stats.get("staged_captures", 0) == mid.get("staged_captures", 0)
-    for k in eager:
-        assert torch.equal(eager[k], again[k]), k
-
-
-def test_block_signature_tells_blocks_apart_that_one_graph_cannot_serve():
-    from lavis.compression.pruners import calibration as cal
-    import toy_models
-    a, b, c = toy_models.ToyT5Block(32, 64), toy_models.ToyT5Block(32, 64), toy_models.ToyT5Block(32, 64, is_decoder=True)
-    sa, sb, sc = (cal.block_signature(m, cal.find_layers(m)) for m in (a, b, c))
-    assert sa == sb and sa != sc
-    b.some_flag = 3                                                         # a scalar attribute: by value
-    assert cal.block_signature(b, cal.find_layers(b)) != sa
-    del b.some_flag
-    b.table = torch.zeros(3)                                                # a plain tensor attribute: by identity
-    assert cal.block_signature(b, cal.find_layers(b)) != sa
-    del b.table
-    h = b.ln0.register_forward_hook(lambda *x: None)
-    assert cal.block_signature(b, cal.find_layers(b)) is None               # a hook outside the prunable linears
-    h.remove()
-    assert cal.block_signature(b, cal.find_layers(b)) == sa
-    b.half()
-    assert cal.block_signature(b, cal.find_layers(b)) != sa                 # dtype

@@ -544,7 +544,9 @@ __device__ __forceinline__ uint32_t dl_extract_both(const uint32_t (&key)[E], DV
 __device__ __attribute__((noinline)) float dl_powf(float v, float p) { return powf(v, p); }   // (32 inlined copies otherwise)
 
 template <typename T, int CH, int NW, bool NM>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) void dsnot_lists_kernel(
+// (one wave per row -- rows of <= 1024 columns -- and the two-wave n:m form end at 3 waves per SIMD at their register footprint; the
+// wider forms reach 4: the attribute states what each instantiation achieves)
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((NW == 1 || (NM && NW == 2)) ? 3 : 4))) void dsnot_lists_kernel(
     const typename T::raw *__restrict__ W, int64_t out_f, int64_t in_f, int64_t ldw, const uint8_t *__restrict__ keep0,
     const float *__restrict__ sqrt_scaler, const float *__restrict__ sum_row, const float *__restrict__ var_row, int use_wanda_init,
     int prune_m, int max_cycle, float thr, float pow_var, int without_same_sign, uint32_t *__restrict__ events,
@@ -841,8 +843,14 @@ static int lists_dispatch(const void *W, int64_t out_f, int64_t in_f, int64_t ld
 #define VLMC_DL_NW(NW) do { if (ch == 2) VLMC_DL(2, NW); else VLMC_DL(4, NW); } while (0)
     switch (nw) {
         case 1:
-            if constexpr (!NM) VLMC_DL_NW(1);      // (n:m never runs one wave per row: those instantiations compiled to 2 waves per SIMD)
-            else return VLMC_EINVAL;
+            // (one wave per row exists for rows of <= 128 chunks only -- with 4 chunks per lane it compiled to 2 waves per
+            // SIMD and two waves per row are faster: above -- and never for n:m)
+            if constexpr (!NM) {
+                if (ch == 2) VLMC_DL(2, 1);
+                else VLMC_DL(4, 2);
+            } else {
+                return VLMC_EINVAL;
+            }
             break;
         case 2: VLMC_DL_NW(2); break;
         case 4: VLMC_DL_NW(4); break;

@@ -1241,204 +1241,6 @@ class BlockGraph:
         return self.y.clone()
 
 
-def staged_graphs_enabled():
-    """`VLMC_STAGED_GRAPH=1`: structurally identical blocks of a tower share HIP graphs of their grouped forwards
-    (`StagedGraphs`).  OFF by default -- measured (profiles/r03_scaling_floor.md): on ROCm 7.2 a replayed graph dispatches its
-    ~40 kernel nodes 10-50 us apart where an eager host that is ahead gets them 2-5 us apart, and every (signature, pass,
-    group) costs a capture; one rank's share of an 8-GPU prune took 0.155 s with the graphs against 0.145 s without, the
-    ragged reference-op stand-in 1.59 s against 1.53 s."""
-    return os.environ.get("VLMC_STAGED_GRAPH", "0") == "1" and graph_replay_enabled()
-
-
-_MODULE_FIELDS = frozenset(nn.Module().__dict__)
-# A group forward with fewer activation rows than this goes through a staged graph (`VLMC_STAGED_ROWS`).  From ~8k rows on
-# the block's kernels are long enough (a 8192 x 2048 x 2048 product is 70 us) for the GPU to stay ahead of an eager host:
-# 128 equal-length samples per forward stay eager (32 896 / 8192 rows per ViT / encoder forward), the decoder's 2048 rows,
-# ragged text's groups of 16 samples and every forward of one rank of eight do not.
-STAGED_ROWS_DEFAULT = 8192
-
-
-def _attr_signature(v):
-    if v is None or isinstance(v, (bool, int, float, str, torch.dtype, torch.device, torch.Size)):
-        return ("v", v)
-    if isinstance(v, (tuple, list)) and all(x is None or isinstance(x, (bool, int, float, str)) for x in v):
-        return ("t", tuple(v))
-    if isinstance(v, type(lambda: 0)) or isinstance(v, type(len)):          # plain functions / lambdas / builtins
-        return ("f", getattr(v, "__qualname__", "?"))
-    return ("id", id(v))                                                    # tensors, containers, objects: shared or not at all
-
-
-def block_signature(layer, subset):
-    """What must agree between two blocks for one captured forward to stand for both: classes, the names, shapes, dtypes and
-    strides of every parameter and buffer, training flags and every plain attribute of every submodule (scalars by value --
-    `is_decoder`, `has_relative_attention_bias`, a layer index --, anything else by identity).  None: the block has hooks
-    outside its prunable linears (they would not fire in a replay)."""
-    hooked = {id(m) for m in subset.values()}
-    sig = []
-    for name, mod in layer.named_modules():
-        if mod._forward_pre_hooks or mod._backward_hooks or (id(mod) not in hooked and mod._forward_hooks):
-            return None
-        entry = [name, type(mod).__module__, type(mod).__qualname__, mod.training, id(mod) in hooked]
-        for k, v in mod.__dict__.items():
-            if k not in _MODULE_FIELDS:
-                entry.append((k, _attr_signature(v)))
-        for kind, table in (("p", mod._parameters), ("b", mod._buffers)):
-            for k, t in table.items():
-                entry.append((kind, k, None if t is None else (tuple(t.shape), t.dtype, str(t.device), tuple(t.stride()))))
-        sig.append(tuple(entry))
-    return tuple(sig)
-
-
-def _block_tensors(layer):
-    return [t for _, t in layer.named_parameters()] + [t for _, t in layer.named_buffers()]
-
-
-class StagedGraphs:
-    """HIP graphs of a tower's grouped block forwards, shared by all blocks with the same `block_signature`.
-
-    A grouped forward of a block is ~40 kernel launches (the model's own norms, attention, activations around the linears),
-    each 5-10 us of host time: with 128 equal-shape samples the GPU hides that, with ragged calibration text (7-18 groups
-    per block) or one rank's share of an 8-GPU run it does not -- the prune is then paced by the host.  A graph captured
-    from one block cannot be replayed for the next one as it stands: its kernels hold the first block's weight addresses.
-    Here the block that is captured has its parameters and buffers pointed at STAGING tensors for the duration of the
-    capture; replaying the graph for another block is then: copy that block's tensors into the staging set (one
-    multi-tensor copy, ~100 MB per Flan-T5-XL block: ~40 us), copy the group's input into the graph's input, replay, run
-    the block's statistics hooks on the graph's recorded linear inputs -- the very kernels of the eager forward with the
-    very same arguments but the weights' addresses, so the activations are the eager forward's bit for bit
-    (tests/test_pruner_gpu.py::test_staged_graphs_*).  The first block of a signature runs eagerly (and warms up whatever
-    initialises lazily for the shapes); the second is captured; one graph per (signature, pass kind, group of samples)."""
-
-    def __init__(self, autocast, tuple_output):
-        self.autocast, self.tuple_output = autocast, tuple_output
-        self.classes = {}
-        try:
-            self.max_rows = int(os.environ.get("VLMC_STAGED_ROWS", str(STAGED_ROWS_DEFAULT)))
-        except ValueError:
-            self.max_rows = STAGED_ROWS_DEFAULT
-
-    def _class(self, sig):
-        c = self.classes.get(sig)
-        if c is None:
-            c = self.classes[sig] = {"staging": None, "graphs": {}, "seen": set(), "loaded": None}
-        return c
-
-    def weights_changed(self):
-        """The caller has (possibly) written to a block's weights: the select kernels zero them through raw pointers, which no
-        version counter sees -- the next replay copies the block's tensors into the staging set again."""
-        for cls in self.classes.values():
-            cls["loaded"] = None
-
-    def _load(self, cls, layer, tensors):
-        """This block's current parameters and buffers into the staging set (once per block and pass: `weights_changed`)."""
-        tag = (id(layer), tuple(t.data_ptr() for t in tensors))
-        if cls["loaded"] != tag:
-            with torch.no_grad():
-                torch._foreach_copy_(cls["staging"], [t.detach() for t in tensors])
-            cls["loaded"] = tag
-
-    def run(self, layer, subset, sig, gkey, x, kw, kind, learned):
-        """The forward of `layer` over the stacked group `x` (kwargs `kw`), pass `kind` ("stat": hooks only, may stop at the
-        last hooked linear; "full").  Returns (True, y or None) when served from a graph, (False, None) when the caller
-        must run it eagerly."""
-        if x.numel() // max(1, x.shape[-1]) >= self.max_rows:      # enough rows for the GPU to hide the host: eager
-            return False, None
-        cls = self._class(sig)
-        ent = cls["graphs"].get((kind, gkey))
-        if ent is False:
-            return False, None
-        tensors = _block_tensors(layer)
-        if ent is None:
-            if (kind, gkey) not in cls["seen"]:              # first block of this signature: eager (doubles as the warm-up)
-                cls["seen"].add((kind, gkey))
-                return False, None
-            try:
-                if cls["staging"] is None:
-                    cls["staging"] = [torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device) for t in tensors]
-                self._load(cls, layer, tensors)
-                ent = cls["graphs"][(kind, gkey)] = self._capture(layer, subset, tensors, cls["staging"], x, kw, kind, learned)
-            except Exception as e:                           # not capturable (host sync, data-dependent control flow): eager
-                cls["graphs"][(kind, gkey)] = False
-                graph_stats["fallbacks"] += 1
-                print(f"staged graph disabled for this block signature ({type(e).__name__}: {e})")
-                return False, None
-        self._load(cls, layer, tensors)
-        if x is not ent["x"]:
-            ent["x"].copy_(x)
-        ent["graph"].replay()
-        graph_stats["staged_replays"] = graph_stats.get("staged_replays", 0) + 1
-        for name, xin, out in ent["records"]:
-            mod = subset[name]
-            for hook in list(mod._forward_hooks.values()):
-                if not getattr(hook, "_vlmc_engine_hook", False):
-                    hook(mod, (xin,), out)
-        if ent["y"] is not None and os.environ.get("VLMC_STAGED_VERIFY", "0") == "1":
-            self._verify(layer, subset, x, kw, ent)
-        return True, (None if ent["y"] is None else ent["y"].clone())
-
-    def _verify(self, layer, subset, x, kw, ent):
-        """`VLMC_STAGED_VERIFY=1` (tests, bring-up): the eager forward of the same block next to every full-pass replay."""
-        from collections import OrderedDict
-        modules = list(subset.values())
-        saved = [m._forward_hooks for m in modules]
-        seen = []
-        names = {id(m): n for n, m in subset.items()}
-        try:
-            for m in modules:
-                m._forward_hooks = OrderedDict({0: (lambda mod, inp, out: seen.append((names[id(mod)], inp[0].clone())))})
-            with torch.no_grad(), self.autocast():
-                y = layer(x, **kw)
-        finally:
-            for m, h in zip(modules, saved):
-                m._forward_hooks = h
-        y = y[0] if self.tuple_output else y
-        for (name, xin), (rname, rxin, _) in zip(seen, ent["records"]):
-            if name != rname or not torch.equal(xin, rxin):
-                raise RuntimeError(f"staged graph: input of linear {rname} differs from the eager forward's ({name})")
-        if not torch.equal(y, ent["y"]):
-            raise RuntimeError("staged graph: block output differs from the eager forward's")
-
-    def _capture(self, layer, subset, tensors, staging, x, kw, kind, learned):
-        from collections import OrderedDict
-        names = {id(m): n for n, m in subset.items()}
-        modules = list(subset.values())
-        saved_hooks = [m._forward_hooks for m in modules]
-        saved_data = [t.data for t in tensors]
-        records, versions = [], []
-        xs = x.clone()
-
-        def recorder(mod, inp, out):
-            records.append((names[id(mod)], inp[0], out))
-            versions.append((inp[0], inp[0]._version))
-
-        def body():
-            with torch.no_grad(), self.autocast():
-                if kind == "stat":
-                    with statistics_only(subset, learned) as so:
-                        so.new_forward()
-                        try:
-                            return layer(xs, **kw)
-                        except _TailStop:
-                            return None
-                return layer(xs, **kw)
-        try:
-            for t, st in zip(tensors, staging):
-                t.data = st
-            for m in modules:
-                m._forward_hooks = OrderedDict({0: recorder})
-            graph, y = capture_graph(body, x.device)
-            if any(t._version != v for t, v in versions):
-                raise RuntimeError("the block modifies a hooked linear's input in place after the linear ran")
-        finally:
-            for m, h in zip(modules, saved_hooks):
-                m._forward_hooks = h
-            for t, d in zip(tensors, saved_data):
-                t.data = d
-        graph_stats["staged_captures"] = graph_stats.get("staged_captures", 0) + 1
-        if y is not None:
-            y = y[0] if self.tuple_output else y
-        return {"graph": graph, "x": xs, "y": None if kind == "stat" else y, "records": records}
-
-
 def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocast, prune_block, tuple_output,
                 memo_cache=None):
     """The block loop of `_prune`: for every block, `prune_block(i, layer, subset, run)`
@@ -1462,8 +1264,6 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
 
     def run_pass(before_sample=None, outputs=True):
         """`outputs=False`: the caller only wants its hooks on the linears fed (the first pass of every pruner)."""
-        if staged is not None:
-            staged.weights_changed()                         # (pruned in between, or another block: stage the weights again)
         with phases.phase("replay"):
             if outputs or group_max == 1:
                 _run_pass(before_sample, None, True)
@@ -1526,13 +1326,6 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
             with torch.no_grad(), autocast():
                 if len(chunk) == 1:
                     j = chunk[0]
-                    if staged is not None and block_sig is not None and cur_in[j].is_cuda:
-                        _STACKED = None
-                        done, y = staged.run(layer, subset, block_sig, (j,), cur_in[j], caches[j], kind, tail_learned)
-                        if done:
-                            if y is not None:
-                                cur_out[j] = y
-                            continue
                     try:
                         y = layer(cur_in[j], **caches[j])
                     except _TailStop:
@@ -1555,19 +1348,6 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                     if kw is None:
                         kw = _stack_caches([caches[j] for j in chunk], b0)
                         kw = stacked_kwargs[key] = kw if kw is not None else False
-                    if kw is not False and staged is not None and block_sig is not None and x.is_cuda:
-                        try:
-                            done, y = staged.run(layer, subset, block_sig, key, x, kw, kind, tail_learned)
-                        finally:
-                            _STACKED = None
-                        if done:
-                            if y is not None:
-                                slices = [y[t * b0:(t + 1) * b0] for t in range(len(chunk))]
-                                slices[0]._vlmc_stack = (y, key, slices)
-                                for t, j in enumerate(chunk):
-                                    cur_out[j] = slices[t]
-                            continue
-                        _STACKED = (len(chunk), b0, tuple(chunk))
                     if kw is False:                                 # kwargs that cannot be stacked: sample by sample
                         _STACKED = None
                         for t, j in enumerate(chunk):
@@ -1599,8 +1379,6 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
 
     graphs, plan, stacked_kwargs, tail_learned = {}, {}, {}, {}
     sibling_names = []
-    staged = StagedGraphs(autocast, tuple_output) if group_max > 1 and staged_graphs_enabled() and n_samples and inps[0].is_cuda else None
-    block_sig = None
     for i in range(len(layers)):
         layer = layers[i]
         subset = find_layers(layer)
@@ -1613,7 +1391,6 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
             if all(n in subset for n in names):
                 forward.register_siblings([subset[n] for n in names])
         with forward.invariant_linears(subset.values()):
-            block_sig = block_signature(layer, subset) if staged is not None else None
             prune_block(i, layer, subset, run_pass, state)
             run_pass()
         if i == 0:

@@ -68,6 +68,8 @@ class _SparseGPTBlockMixin:
             for h in handles:
                 h.remove()
         unique = list({id(a): a for a in wrapped.values()}.values())
+        from vlmc.shard import require_real_exchange
+        require_real_exchange("blipt5_sparsegpt_pruner")
         _allreduce_hessians(unique)
         owner = _shard_linears(subset, wrapped)
         rank = cal.calibration_shard()[0]

@@ -34,6 +34,10 @@ ROUTES = {
     "sgpt_select_multi": ({"VLMC_SGPT_SELECT_SWEEP": "0"}, "SparseGPT block threshold by the multi-launch radix select, sweep with the mask handed in"),
     "sgpt_library": ({"VLMC_SGPT_SYRK": "0", "VLMC_SGPT_DIRECT_FACTOR": "0", "VLMC_CHOL_GRAPH": "0"}, "library GEMM Hessian, the reference's three-step factor chain"),
     "sgpt_per_call": ({"VLMC_SGPT_DEFER": "0"}, "one Hessian update per hook call"),
+    "sgpt_chain": ({"VLMC_SGPT_PERSISTENT": "0"}, "the factorization as a chain of launches per 128 columns instead of one persistent launch"),
+    "attn_library": ({"VLMC_ATTN_MATMUL": "0", "VLMC_ROW_MEAN": "0"}, "the blocks' batched matmuls and the norms' mean left to torch during the replay"),
+    "attn_transposing_write": ({"VLMC_ATTN_TR": "0"}, "attn @ v with the operand transposed while writing LDS (no ds_read_b64_tr_b16)"),
+    "host_ctypes": ({"VLMC_FAST": "0"}, "every launch through the ctypes route (no compiled host path)"),
 }
 
 

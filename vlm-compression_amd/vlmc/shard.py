@@ -19,7 +19,24 @@ def simulated_world():
         w = int(os.environ.get("VLMC_SIMULATE_WORLD", "0"))
     except ValueError:
         return 0
+    if w > 1 and not _warned:
+        import warnings
+        _warned.append(w)
+        warnings.warn(f"VLMC_SIMULATE_WORLD={w}: this process REHEARSES rank 0 of {w} -- statistics of the other ranks are filled in "
+                      "with copies of this rank's rows, so the masks are NOT those of a real prune (a measurement aid of bench.py "
+                      "--calib-local; unset the variable for real runs)", RuntimeWarning, stacklevel=2)
     return w if w > 1 else 0
+
+
+_warned = []
+
+
+def require_real_exchange(what):
+    """Paths whose exchange cannot be rehearsed by repeating this rank's rows (SparseGPT's Hessian all-reduce and weight
+    broadcast) refuse to run under VLMC_SIMULATE_WORLD instead of crashing inside torch.distributed without a process group."""
+    if simulated_world():
+        raise RuntimeError(f"{what}: VLMC_SIMULATE_WORLD rehearses the Wanda / DSnoT statistics exchange only; run it under a real "
+                           "torch.distributed launch (or unset VLMC_SIMULATE_WORLD)")
 
 
 def calibration_shard():
