@@ -325,7 +325,7 @@ def test_select_sweep_one_launch_equals_threshold_then_sweep(rows_per_scope, cou
     assert torch.equal(mout, mref)
     assert torch.equal(Wd.view(torch.int32), Wref.view(torch.int32))
     assert torch.equal(err.view(torch.int32), err_ref.view(torch.int32))
-    assert int(SG._select_ws[torch.device(DEV).index].abs().sum()) == 0
+    assert all(int(ws.abs().sum()) == 0 for ws in SG._select_ws.values()) and SG._select_ws      # (one per device and stream)
 
 
 @pytest.mark.parametrize("level", [1, 2, 3])
@@ -341,7 +341,7 @@ def test_select_sweep_failed_grid_barrier_is_finished_by_the_last_workgroup(leve
     assert torch.equal(mout, mref)
     assert torch.equal(Wd.view(torch.int32), Wref.view(torch.int32))
     assert torch.equal(err.view(torch.int32), err_ref.view(torch.int32))
-    assert int(SG._select_ws[torch.device(DEV).index].abs().sum()) == 0
+    assert all(int(ws.abs().sum()) == 0 for ws in SG._select_ws.values()) and SG._select_ws      # (one per device and stream)
     monkeypatch.delenv("VLMC_SGPT_SELECT_FORCE_FAIL")
     SG2, Wd2, Ud2, ranks2, Wref2, err_ref2, mref2 = _select_sweep_case((384, 256, 640), 128, (0.5, 0.5, 0.3), seed=level)
     SG.select_sweep_block(Wd2[:, 5:], 0, 128, Ud2[2:, 2:], [384, 256, 640], ranks2, err, None)        # the next call finds it usable

@@ -84,7 +84,7 @@ class _SparseGPTBlockMixin:
         for name in mine:
             assert wrapped[name].nsamples == n_inps                                # :442
             by_acc.setdefault(id(wrapped[name]), []).append(name)
-        for names in by_acc.values():
+        def sweep(names):
             acc = wrapped[names[0]]
             keys = [f"{module_to_process}.{i}.{n}.weight" for n in names]
             same = len({(subset[n].weight.dtype, subset[n].weight.shape[1]) for n in names}) == 1
@@ -92,10 +92,40 @@ class _SparseGPTBlockMixin:
                 # linears fed the same tensor share the factor: ONE column sweep over their stacked rows
                 sparsegpt.fasterprune_group([subset[n] for n in names], [sparsity_ratio[k] for k in keys], acc.factor_cache,
                                             prune_n=self.prune_n, prune_m=self.prune_m, blocksize=128, score_sink=scores)
-                continue
+                return
             for name, key in zip(names, keys):
                 sparsegpt.fasterprune(subset[name], acc.H, sparsity_ratio[key], prune_n=self.prune_n, prune_m=self.prune_m,
                                       percdamp=0.01, blocksize=128, factor_cache=acc.factor_cache, score_sink=scores)
+
+        # The sweeps of linears with DIFFERENT inputs are independent chains of (cols / 128) x [latency-bound sweep kernel +
+        # trailing GEMM] (the reference prunes them one after the other, :430-446): each chain on a stream of its own, the
+        # longest first (`VLMC_SGPT_SWEEP_STREAMS=1`: one after the other).  Same kernels on the same data: bit-identical.
+        # configs[2] (2:4): 2.10 -> 1.90 s per prune.
+        groups = sorted(by_acc.values(), key=lambda g: -(subset[g[0]].weight.shape[1] * sum(subset[n].weight.shape[0] for n in g)))
+        dev = subset[groups[0][0]].weight.device if groups else None
+        # (n:m mode only: the unstructured block threshold is agreed on through grid barriers between co-resident workgroups --
+        # vlmc_sparsegpt_select_sweep -- and two such launches side by side strand each other: measured 8.6 s against 2.5 s)
+        streams = sparsegpt.sweep_streams(dev) if groups and dev.type == "cuda" and len(groups) > 1 and self.prune_n != 0 else []
+        if not streams:
+            for names in groups:
+                sweep(names)
+        else:
+            main = torch.cuda.current_stream(dev)
+            n0 = len(scores)
+            for g, names in enumerate(groups):
+                st = streams[g % len(streams)]
+                st.wait_stream(main)
+                for t in (wrapped[names[0]].factor_cache.get("U"), wrapped[names[0]].factor_cache.get("dead")):
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(st)
+                with torch.cuda.stream(st):
+                    sweep(names)
+            for st in streams:
+                main.wait_stream(st)
+            for name in mine:                                   # made on a side stream, used on the caller's from here on
+                subset[name].weight.data.record_stream(main)
+            for _w, sc in scores[n0:]:
+                sc.record_stream(main)
         if owner is not None:
             _flush_score_backlog(self)                                             # (the exchange sends the scores along)
             _exchange_pruned(subset, owner, rank)

@@ -367,6 +367,18 @@ def _chol_with_damping(H, damp, upper, max_tries=100, slot=0):
 
 
 _FACTOR_STREAMS = {}       # device index -> side streams of factorize_many
+_SWEEP_STREAMS = {}        # device index -> side streams for the column sweeps of a block's independent linears
+
+
+def sweep_streams(dev):
+    """Side streams for the sweeps of a block's linears (`VLMC_SGPT_SWEEP_STREAMS=n`, default 4; 1: none)."""
+    n = int(__import__("os").environ.get("VLMC_SGPT_SWEEP_STREAMS", "4"))
+    if n <= 1:
+        return []
+    sts = _SWEEP_STREAMS.setdefault(dev.index, [])
+    while len(sts) < n:
+        sts.append(torch.cuda.Stream(device=dev))
+    return sts[:n]
 
 
 def concurrent_factor_enabled():
@@ -585,10 +597,11 @@ def select_sweep_block(W: torch.Tensor, i1: int, i2: int, U: torch.Tensor, rows_
     assert W.dtype == torch.float32 and U.dtype == torch.float32 and err.dtype == torch.float32
     assert W.stride(1) == 1 and U.stride(1) == 1 and err.stride(1) == 1 and sum(rows_per_scope) == W.shape[0]
     lib = _lib.load()
-    ws = _select_ws.get(W.device.index)
+    wkey = (W.device.index, torch.cuda.current_stream(W.device).cuda_stream)       # sweeps on different streams run side by side
+    ws = _select_ws.get(wkey)
     if ws is None:
-        ws = _select_ws[W.device.index] = torch.zeros(int(lib.vlmc_sparsegpt_select_workspace_bytes()) // 4, dtype=torch.int32,
-                                                      device=W.device)
+        ws = _select_ws[wkey] = torch.zeros(int(lib.vlmc_sparsegpt_select_workspace_bytes()) // 4, dtype=torch.int32,
+                                            device=W.device)
     import ctypes
     n = len(rows_per_scope)
     rows_c = (ctypes.c_int64 * n)(*[int(r) for r in rows_per_scope])
