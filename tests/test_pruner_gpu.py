@@ -102,6 +102,24 @@ def test_sparsegpt_pruner_on_gpu_tracks_reference_run(name):
     assert (num / den) ** 0.5 < 2e-2
 
 
+def test_sparsegpt_sweeps_on_side_streams_change_nothing(monkeypatch):
+    """n:m mode: the column sweeps of a block's independent linears run on streams of their own (sparsegpt_pruner.py:430-446
+    prunes them one after the other): the same kernels on the same data, so the pruned model equals the one-after-the-other
+    run bit for bit -- weights and importance scores."""
+    import test_pruner_host_logic as T
+    monkeypatch.setenv("VLMC_SGPT_SWEEP_STREAMS", "1")
+    a, _ = T._run_sparsegpt_pruner("fp32_2_4", "cuda:0")
+    monkeypatch.setenv("VLMC_SGPT_SWEEP_STREAMS", "4")
+    b, _ = T._run_sparsegpt_pruner("fp32_2_4", "cuda:0")
+    sa, sb = a.state_dict(), b.state_dict()
+    assert sa.keys() == sb.keys()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    ia = {n: m.weight.importance_score for n, m in a.named_modules() if hasattr(getattr(m, "weight", None), "importance_score")}
+    ib = {n: m.weight.importance_score for n, m in b.named_modules() if hasattr(getattr(m, "weight", None), "importance_score")}
+    assert ia and ia == ib
+
+
 @pytest.mark.parametrize("name", list(H.DSNOT_VARIANTS))
 def test_dsnot_pruner_on_gpu_every_linear_matches_oracle(name, monkeypatch):
     """Whole blipt5_dsnot_pruner on the GPU: every per-linear refinement is re-checked bit-for-bit against

@@ -1,6 +1,6 @@
 """A/B of environment switches that are read per prune, inside ONE process: whole Wanda prunes of the synthetic
 InstructBLIP-FlanT5-XL, the configurations interleaved, median of the rounds.
-   python tools/ab_prune_env.py "VLMC_STAGED_GRAPH=0" "VLMC_STAGED_GRAPH=1" "VLMC_STAGED_GRAPH=1,VLMC_STAGED_ROWS=4096" """
+   python tools/ab_prune_env.py "VLMC_ROW_MEAN=1" "VLMC_ROW_MEAN=0" "VLMC_ATTN_MATMUL=0,VLMC_ROW_MEAN=0" """
 import os
 import statistics
 import sys

@@ -1,5 +1,5 @@
-// Compiled host path for the three entry points a calibration replay calls thousands of times: vlmc_linear_fwd,
-// vlmc_linear_fwd_group and vlmc_attn_matmul (include/vlmc.h).
+// Compiled host path for the entry points a calibration replay calls thousands of times: vlmc_linear_fwd,
+// vlmc_linear_fwd_group, vlmc_attn_matmul and vlmc_row_mean (include/vlmc.h).
 //
 // The replay of the reference's per-sample block forwards (wanda_pruner.py:308-311, :343-346) issues 1 000 - 15 000 of these
 // launches per prune, most of them on a few hundred rows when the calibration text is ragged or the samples are sharded over
@@ -138,6 +138,21 @@ py::object attn_matmul(const at::Tensor &a, const at::Tensor &b, int64_t stream)
     return py::cast(out);
 }
 
+// x.mean(-1, keepdim) of an fp32 CUDA tensor on vlmc_row_mean; None when the call is not one it takes
+py::object row_mean(const at::Tensor &x, bool keepdim, int64_t stream) {
+    if (!x.is_cuda() || x.scalar_type() != at::kFloat || x.dim() < 1 || x.size(-1) == 0) return py::none();
+    const int64_t n = x.size(-1);
+    at::Tensor x2 = x.reshape({-1, n});
+    if (x2.stride(1) != 1 || (x2.size(0) > 1 && x2.stride(0) < n)) x2 = x2.contiguous();
+    const int64_t rows = x2.size(0);
+    std::vector<int64_t> oshape(x.sizes().begin(), x.sizes().end() - 1);
+    if (keepdim) oshape.push_back(1);
+    at::Tensor out = at::empty(oshape, x.options());
+    check(vlmc_row_mean(static_cast<const float *>(x2.data_ptr()), rows, n, rows > 1 ? x2.stride(0) : n, static_cast<float *>(out.data_ptr()),
+                        reinterpret_cast<void *>(stream)));
+    return py::cast(out);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -145,5 +160,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("linear_fwd", &linear_fwd, py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("stream"));
     m.def("linear_fwd_group", &linear_fwd_group, py::arg("x"), py::arg("weights"), py::arg("biases"), py::arg("stream"));
     m.def("attn_matmul", &attn_matmul, py::arg("a"), py::arg("b"), py::arg("stream"));
+    m.def("row_mean", &row_mean, py::arg("x"), py::arg("keepdim"), py::arg("stream"));
     m.def("abi_version", []() { return vlmc_abi_version(); });
 }

@@ -246,6 +246,11 @@ def row_mean(x: torch.Tensor, keepdim: bool = False) -> torch.Tensor:
     """`x.mean(-1, keepdim=keepdim)` for fp32 CUDA tensors with a fixed, batch-invariant summation order (the norms of a
     replayed block: include/vlmc.h: vlmc_row_mean)."""
     _need_gpu(x)
+    if _fast is not None:
+        out = _fast.row_mean(x, bool(keepdim), _stream())
+        if out is None:
+            raise TypeError("vlmc.row_mean: a non-empty fp32 tensor expected")
+        return out
     if x.dtype != torch.float32 or x.dim() < 1 or x.shape[-1] == 0:
         raise TypeError("vlmc.row_mean: a non-empty fp32 tensor expected")
     n = x.shape[-1]
