@@ -391,18 +391,40 @@ def reference_ops_leg(dev, steps):
         groups.append(len(chunks))
         return chunks
     cal.plan_groups = counting
+    # the attention products' kernel inside these prunes: every 4th launch carries HIP events in its own dispatch
+    from vlmc import ops
+    probe = LaunchProbe(4)
+
+    def attn_bytes(a, b, *rest, **kw):                        # operands once + the output once, 2 bytes per element
+        lead = 1
+        for x, y in zip(a.shape[:-2], b.shape[:-2]):
+            lead *= max(x, y)
+        return 2.0 * lead * (a.shape[-2] * a.shape[-1] + b.shape[-2] * b.shape[-1] + a.shape[-2] * b.shape[-1])
+    probe.wrap(ops, "attn_matmul", "attn", attn_bytes, lambda a, b, *r, **k: a.is_cuda and a.dim() >= 3 and a.dtype in (torch.float16, torch.bfloat16))
     try:
         job.step()                                            # warm-up (code objects of the batched matmuls, allocator)
         torch.cuda.synchronize()
         groups.clear()
+        probe.active = True
         t0 = time.perf_counter()
         for _ in range(steps):
             job.step()
         torch.cuda.synchronize()
         sec = (time.perf_counter() - t0) / steps
+        probe.active = False
         plans = list(groups)
     finally:
         cal.plan_groups = real_plan
+        probe.restore()
+    a_ms, a_bytes, a_n = probe.summary("attn")
+    attn_kernel = None
+    if a_n:
+        gbs = a_bytes / (a_ms * 1e-3) / 1e9
+        attn_kernel = {"kernel": "vlmc::attn_matmul_kernel (vlmc_attn_matmul: q @ k^T and attn @ v of the replayed blocks, batch-invariant; "
+                                 "algorithmic bytes = both operands once + the output once)",
+                       "bound": "hbm", "timed_launches": a_n, "launches_per_step": round(probe.calls.get("attn", 0) / steps, 1),
+                       "avg_launch_us": round(a_ms * 1e3 / a_n, 2), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_launch": round(a_bytes / a_n)}
     grouped = job.masks()
     frac = job.pruned_fraction()
     keep = {k: os.environ.get(k) for k in ("VLMC_BATCH_REPLAY", "VLMC_TOWER_BATCH")}
@@ -438,7 +460,7 @@ def reference_ops_leg(dev, steps):
                    "bias of block 0, extended masks, fp32 softmax) with ragged calibration text (prompts of 8..128 tokens, outputs "
                    "of 4..16)",
            "seconds_per_prune": round(sec, 4), "layers_per_s": round(588 / sec, 1), "steps": steps,
-           "groups_per_block_forward": per_tower, "pruned_fraction": round(frac, 6),
+           "groups_per_block_forward": per_tower, "pruned_fraction": round(frac, 6), "attention_kernel": attn_kernel,
            "per_sample_loop_seconds": round(per_sample_sec, 3),
            "mask_agreement_grouped_vs_per_sample": round(1.0 - diff / max(1, total), 9), "mask_elements": total,
            "mask_elements_differing": diff, "worst_linear": {"name": worst[1], "fraction_differing": round(worst[0], 9)}}

@@ -12,7 +12,7 @@ def find(d, pat):
 
 
 def short(name):
-    n = name.split("(")[0]
+    n = name.replace("(anonymous namespace)::", "").split("(")[0]
     return n.replace("void ", "")[:110]
 
 

@@ -69,6 +69,8 @@ __device__ __forceinline__ int tr_off(int k, int ch) { return k * ROWB + ((ch ^ 
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
+}  // namespace
+
 template <typename T, bool NN, bool TR>
 __global__ __launch_bounds__(NT_) void attn_matmul_kernel(const BmmArgs a) {
     // two K chunks of 64 per step, each its own [m-operand tile | n-operand tile] image of 128-byte rows
@@ -263,7 +265,6 @@ __global__ __launch_bounds__(NT_) void attn_matmul_kernel(const BmmArgs a) {
     }
 }
 
-}  // namespace
 }  // namespace vlmc
 
 using namespace vlmc;

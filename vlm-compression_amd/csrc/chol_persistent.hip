@@ -164,6 +164,8 @@ __device__ __forceinline__ void publish(unsigned *flag, int tid) {
     if (tid == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+}  // namespace
+
 __global__ __launch_bounds__(NTH) void chol_inverse_persistent_kernel(const PArgs p) {
     extern __shared__ float sh[];
     float *ta = sh, *tb = sh + BUF;                                     // two operand tiles [128][LD]
@@ -260,7 +262,6 @@ __global__ __launch_bounds__(NTH) void chol_inverse_persistent_kernel(const PArg
     }
 }
 
-}  // namespace
 }  // namespace vlmc
 
 using namespace vlmc;

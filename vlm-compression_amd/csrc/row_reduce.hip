@@ -16,6 +16,8 @@ namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+}  // namespace
+
 __global__ __launch_bounds__(256) void row_mean_kernel(const float *__restrict__ x, int64_t rows, int n, int64_t ldx, float *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -39,7 +41,6 @@ __global__ __launch_bounds__(256) void row_mean_kernel(const float *__restrict__
     if (lane == 0) out[row] = ieee_div(acc, float(n));
 }
 
-}  // namespace
 }  // namespace vlmc
 
 using namespace vlmc;

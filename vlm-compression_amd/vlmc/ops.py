@@ -218,20 +218,24 @@ def attn_matmul_plan(a: torch.Tensor, b: torch.Tensor, _cuda_only: bool = True):
     return (batch, M, N, K, sab[0], sab[1], sa[-2], sbb[0], sbb[1], sbk, sbn)
 
 
-def attn_matmul(a: torch.Tensor, b: torch.Tensor, _plan=None) -> torch.Tensor:
+def attn_matmul(a: torch.Tensor, b: torch.Tensor, _plan=None, _try: bool = False) -> torch.Tensor:
     """`torch.matmul(a, b)` for the batched products of attention (q @ k^T, attn @ v: eva_vit.py:147,164;
     modeling_t5.py:590,638) on the batch-invariant MFMA kernel: an output element has the same bits whatever the batch
-    count, M or N (include/vlmc.h: vlmc_attn_matmul)."""
+    count, M or N (include/vlmc.h: vlmc_attn_matmul).  `_try`: None instead of an error for a call the kernel does not take."""
     if _fast is not None:
         if not a.is_cuda:
+            if _try:
+                return None
             _need_gpu(a, b)
         out = _fast.attn_matmul(a, b, _stream())
-        if out is None:
+        if out is None and not _try:
             _need_gpu(a, b)
             raise TypeError("vlmc.attn_matmul: 3-D / 4-D fp16 / bf16 tensors of one dtype expected, a contiguous along k, b along k or n")
         return out
     plan = _plan if _plan is not None else attn_matmul_plan(a, b)
     if plan is None:
+        if _try:
+            return None
         _need_gpu(a, b)
         raise TypeError("vlmc.attn_matmul: 3-D / 4-D fp16 / bf16 tensors of one dtype expected, a contiguous along k, b along k or n")
     batch, M, N, K, sa0, sa1, sam, sb0, sb1, sbk, sbn = plan
