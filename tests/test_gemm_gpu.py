@@ -273,8 +273,9 @@ def test_hessian_of_the_reference_golden_inputs_through_the_syrk_kernel():
 
 def test_ring_and_register_staged_kernels_give_the_same_bits(tmp_path):
     """Three kernels compute the product (operands streamed into an LDS ring by global_load_lds, K % 32 == 0, with the two waves
-    of a SIMD in lockstep or half a step apart; or staged through registers, any K % 8 == 0) in two tile shapes: an output
-    element sees the same MFMAs in the same order in all of them.  `VLMC_GEMM_RING` / `VLMC_GEMM_BIG_TILES` /
+    of a SIMD in lockstep or half a step apart; or staged through registers, any K % 8 == 0) in five tile shapes (256 x 256,
+    128 x 128, and for few rows of X 64 x 64, 32 x 64 and 32 x 32): an output element sees the same MFMAs in the same order in all
+    of them.  `VLMC_GEMM_RING` / `VLMC_GEMM_BIG_TILES` /
     `VLMC_GEMM_PINGPONG` are read once per process, hence the child processes."""
     import os
     import subprocess
@@ -287,7 +288,8 @@ from vlmc import ops
 g = torch.Generator(device='cuda:0').manual_seed(11)
 outs = []
 for dt, M, N, K in [(torch.bfloat16, 700, 1024, 2048), (torch.float16, 3000, 1408, 1408), (torch.bfloat16, 64, 5120, 2048),
-                    (torch.float16, 9000, 4224, 352), (torch.float16, 20 * 257, 6144, 96)]:
+                    (torch.float16, 9000, 4224, 352), (torch.float16, 20 * 257, 6144, 96), (torch.bfloat16, 301, 2048, 5120),
+                    (torch.float16, 40, 1000, 1408), (torch.bfloat16, 16, 2048, 2048), (torch.bfloat16, 100, 520, 200)]:
     x = (torch.randn(M, K, generator=g, device='cuda:0') * 0.5 + 0.1).to(dt)
     w = (torch.randn(N, K, generator=g, device='cuda:0') * 0.05).to(dt)
     b = (torch.randn(N, generator=g, device='cuda:0') * 0.1).to(dt)
@@ -298,20 +300,27 @@ for dt, M, N, K in [(torch.bfloat16, 700, 1024, 2048), (torch.float16, 3000, 140
 torch.save(outs, sys.argv[1])
 """
     results = []
-    # (ring, tiles needed for the 256 x 256 shape, the two waves of a SIMD half a step apart)
-    # (ring, tiles needed for the 256 x 256 shape, the two waves of a SIMD half a step apart, persistent workgroups)
-    # ... half panels / blocks handed out last)
-    for ring, big, pp, persist, edge in (("1", "200", "1", "1", "1"), ("0", "200", "1", "1", "1"), ("1", "1", "1", "1", "1"),
-                                        ("1", "1", "1", "0", "1"), ("1", "1", "0", "1", "1"), ("0", "0", "1", "1", "1"),
-                                        ("1", "0", "1", "1", "1"), ("1", "1", "1", "1", "0"), ("1", "1", "1", "1", "w"),
-                                        ("1", "0", "1", "1", "w")):
-        # (edge "w": K-steps of 32 with half-line requests also where K % 64 == 0 -- the default there is the whole-line kernel)
-        out = tmp_path / f"r{ring}_b{big}_p{pp}_s{persist}_e{edge}.pt"
-        env = dict(os.environ, VLMC_GEMM_RING=ring, VLMC_GEMM_BIG_TILES=big, VLMC_GEMM_PINGPONG=pp, VLMC_GEMM_PERSIST=persist,
-                   VLMC_GEMM_EDGE="1" if edge == "w" else edge, VLMC_GEMM_WIDE="0" if edge == "w" else "1")
-        r = subprocess.run([sys.executable, "-c", code, str(out)], env=env, capture_output=True, text=True, timeout=600)
+    # (ring, tiles needed for the 256 x 256 shape, the two waves of a SIMD half a step apart, persistent workgroups,
+    #  half panels / blocks handed out last; edge "w": K-steps of 32 with half-line requests also where K % 64 == 0 -- the default
+    #  there is the whole-line kernel)
+    combos = [("1", "200", "1", "1", "1"), ("0", "200", "1", "1", "1"), ("1", "1", "1", "1", "1"), ("1", "1", "1", "0", "1"),
+              ("1", "1", "0", "1", "1"), ("0", "0", "1", "1", "1"), ("1", "0", "1", "1", "1"), ("1", "1", "1", "1", "0"),
+              ("1", "1", "1", "1", "w"), ("1", "0", "1", "1", "w")]
+    envs = [dict(VLMC_GEMM_RING=ring, VLMC_GEMM_BIG_TILES=big, VLMC_GEMM_PINGPONG=pp, VLMC_GEMM_PERSIST=persist,
+                 VLMC_GEMM_EDGE="1" if edge == "w" else edge, VLMC_GEMM_WIDE="0" if edge == "w" else "1")
+            for ring, big, pp, persist, edge in combos]
+    # the tile shapes for few rows of X (round 4): the default picks among them by the number of workgroups; here 128 x 128
+    # everywhere, and every shape forced on every launch below the 256 x 256 threshold, ring and register-staged
+    envs.append(dict(VLMC_GEMM_SMALL_TILES="0"))
+    # (ring kernel of whole lines with three double steps in flight -- the default for the small shapes --, with one, the
+    #  four-slot ring of half lines, the register-staged kernel)
+    envs += [dict(VLMC_GEMM_SHAPE=sh, VLMC_GEMM_RING=ring, VLMC_GEMM_WIDE=wide, VLMC_GEMM_WIDE_SLOTS=slots)
+             for sh in ("128", "64", "p32", "32") for ring, wide, slots in (("1", "1", "0"), ("1", "1", "2"), ("1", "0", "0"), ("0", "1", "0"))]
+    for i, extra in enumerate(envs):
+        out = tmp_path / f"variant{i}.pt"
+        r = subprocess.run([sys.executable, "-c", code, str(out)], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         results.append(torch.load(out))
-    for other in results[1:]:
+    for extra, other in zip(envs[1:], results[1:]):
         for a, b in zip(results[0], other):
-            assert torch.equal(a, b)
+            assert torch.equal(a, b), extra

@@ -29,6 +29,7 @@
 #include "mfma.hpp"
 
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace vlmc {
@@ -47,6 +48,10 @@ template <int TP_, int TQ_, int WP_, int WQ_> struct Shape {
 };
 using ShapeBig = Shape<8, 4, 2, 4>;                   // 256 x 256, 512 threads, 128 KiB of LDS
 using ShapeSmall = Shape<4, 4, 2, 2>;                 // 128 x 128, 256 threads, 64 KiB
+// few rows of X (round 4, launch_gemm)
+using Shape64 = Shape<2, 2, 2, 2>;                    //  64 x 64, 256 threads
+using ShapeP32 = Shape<1, 4, 2, 1>;                   //  32 (p) x 64 (q), 128 threads
+using Shape32 = Shape<1, 1, 2, 2>;                    //  32 x 32, 256 threads
 
 enum { EPI_LINEAR = 0, EPI_SYRK = 1 };
 
@@ -119,7 +124,7 @@ __device__ __forceinline__ int lds_off(int row, int ch) { return row * ROW_BYTES
 // (32 B per row and instruction: the epilogue of a 256 x 256 tile took about as long as 20 K-steps).  The wave's tile
 // goes through its own piece of the (now idle) LDS instead -- 16 or 32 rows of q at a time, the 16-B chunk index XOR-ed with
 // the row so the 8-B writes of 16 rows spread over the banks -- and leaves as 16 B per lane, 256 B contiguous per row.
-template <typename T, int EPI, typename S, int ROWS = 32, bool BARRIER = true>
+template <typename T, int EPI, typename S, int ROWS = (S::TQ >= 2 ? 32 : 16), bool BARRIER = true>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, const Panel &pn, f32x4_t (&acc)[S::TP][S::TQ], int q0, int wp,
                                               int wq, int lane, unsigned char *lds, int wave) {
     constexpr int TP = S::TP, TQ = S::TQ;
@@ -433,14 +438,19 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_kernel(const GemmArgs a
 // one barrier, the next double step's loads, the 2 x (TP + TQ) fragment reads of BOTH K-steps and their 2 TP TQ MFMAs: half
 // the barriers and waits per K of gemm_nt_ring_kernel, whole-line requests.  Same MFMAs in the same order per output
 // element.  K must be a multiple of 64.
-template <typename T, int EPI, typename S>
+// NDS double slots, NDS - 1 double steps of loads in flight.  2: 32 KiB for a 128 x 128 tile, a second workgroup on the CU covers
+// the wait.  4 (round 4, the tiles of at most 64 x 64 that launches with few rows of X get): their weights come COLD from HBM --
+// every launch of a replay reads another matrix -- and with one double step in flight a workgroup's K loop is a chain of K / 64
+// DRAM round trips (32 x 32 tiles, 256 x 2048 x 2048: 11 us with W in the Infinity Cache, 23 us in a replay).
+template <typename T, int EPI, typename S, int NDS = 2>
 __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_wide_kernel(const GemmArgs a) {
     constexpr int BP = S::BP, BQ = S::BQ, TP = S::TP, TQ = S::TQ, NW = S::WP * S::WQ;
     constexpr int WROW = 2 * RROW;
     constexpr int P_BYTES = BP * WROW, Q_BYTES = BQ * WROW, SLOT = P_BYTES + Q_BYTES;
     constexpr int GROUPS = (BP + BQ) / 8, PER_WAVE = GROUPS / NW;         // pieces of 8 rows x 128 B per wave and double step
     static_assert(GROUPS % NW == 0, "whole load instructions per wave");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * SLOT];
+    static_assert(NDS == 2 || NDS == 4, "slot index is d & (NDS - 1)");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NDS * SLOT];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bp, bq;
@@ -464,7 +474,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_wide_kernel(const GemmA
         dst[u] = (is_q ? P_BYTES : 0) + g * 1024;
     }
     auto issue = [&](int d) {
-        const uint32_t slot = lds_base + (d & 1) * SLOT;
+        const uint32_t slot = lds_base + (d & (NDS - 1)) * SLOT;
 #pragma unroll
         for (int u = 0; u < PER_WAVE; ++u) glds16(src[u] + d * (2 * RK), slot + dst[u]);
     };
@@ -479,13 +489,21 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_wide_kernel(const GemmA
     const int foff1 = (lane & 15) * WROW + (((4 + (lane >> 4)) ^ (lane & 7)) << 4);
 
     const int nd = a.K / (2 * RK);
-    issue(0);
+    for (int d = 0; d < NDS - 1 && d < nd; ++d) issue(d);
     for (int d = 0; d < nd; ++d) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's pieces of double step d have landed
+        // this wave's pieces of double step d have landed: behind them in the queue are the double steps up to d + NDS - 2
+        if constexpr (NDS == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            const int behind = min(NDS - 2, nd - 1 - d);
+            if (behind >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
+            else if (behind == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();                                     // everybody's have; everybody has left slot d - 1
-        if (d + 1 < nd) issue(d + 1);
-        const unsigned char *tp = lds + (d & 1) * SLOT + wp * (TP * 16) * WROW;
-        const unsigned char *tq = lds + (d & 1) * SLOT + P_BYTES + wq * (TQ * 16) * WROW;
+        if (d + NDS - 1 < nd) issue(d + NDS - 1);
+        const unsigned char *tp = lds + (d & (NDS - 1)) * SLOT + wp * (TP * 16) * WROW;
+        const unsigned char *tq = lds + (d & (NDS - 1)) * SLOT + P_BYTES + wq * (TQ * 16) * WROW;
         u32x4_t fp[2][TP], fq[2][TQ];
 #pragma unroll
         for (int j = 0; j < TQ; ++j) fq[0][j] = *reinterpret_cast<const u32x4_t *>(tq + foff0 + j * 16 * WROW);
@@ -506,7 +524,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_wide_kernel(const GemmA
         // (the reads above are complete before this wave reaches the next barrier: the MFMAs wait for them)
     }
     __builtin_amdgcn_s_barrier();                                         // every wave is done with the slots: the epilogue's scratch
-    gemm_epilogue<T, EPI, S, 32, false>(a, pn, acc, q0, wp, wq, lane, lds, wave);
+    gemm_epilogue<T, EPI, S, (TQ >= 2 ? 32 : 16), false>(a, pn, acc, q0, wp, wq, lane, lds, wave);
 }
 
 // ---- ring kernel with the two waves of a SIMD half a step apart ------------------------------------------------------
@@ -1071,6 +1089,9 @@ template <typename T, int EPI, typename S> static void launch_shape(GemmArgs a, 
         return !(e && e[0] == '0');
     }();
     int64_t nblocks = plan_panels<S>(a, EPI == EPI_LINEAR && edges);
+    // (the persistent kernels deal the edge tiles to XCD labels 7, 6, ..: with fewer than 8 workgroups some of those labels do
+    // not exist and their tiles would never be computed -- only reachable with VLMC_GEMM_BIG_TILES lowered, found in round 4)
+    if (S::WP * S::WQ == 8 && EPI == EPI_LINEAR && nblocks < 8) nblocks = plan_panels<S>(a, false);
     if (EPI == EPI_SYRK) nblocks = int64_t(a.npf) * (a.npf + 1) / 2;
     const unsigned ny = (EPI == EPI_SYRK && a.slabs > 1) ? unsigned(a.slabs) : 1u;      // slabs of a split SYRK (slab_view)
     static const bool ring = [] {
@@ -1112,9 +1133,23 @@ template <typename T, int EPI, typename S> static void launch_shape(GemmArgs a, 
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
     }();
-    if (ring && wide_small && a.K % (2 * RK) == 0 && S::WP * S::WQ == 4 && nblocks > cus)
-        VLMC_LAUNCH_TIMED((gemm_nt_ring_wide_kernel<T, EPI, S>), dim3(unsigned(nblocks), ny), dim3(S::NT), s, a);
-    else if (ring && a.K % RK == 0) VLMC_LAUNCH_TIMED((gemm_nt_ring_kernel<T, EPI, S>), dim3(unsigned(nblocks), ny), dim3(S::NT), s, a);
+    static const int wide_slots = [] {
+        const char *e = getenv("VLMC_GEMM_WIDE_SLOTS");            // A/B: 2 = the shallow ring also for the tiles of at most 64 x 64
+        return e ? atoi(e) : 0;
+    }();
+    // tiles of at most 64 x 64: always the whole-line kernel with three double steps in flight (measured with every launch
+    // reading another copy of W, as a replay does: 256 x 2048 x 2048 in 32 x 32 tiles 11.4 us, 14.2 on the four-slot ring of
+    // half lines, 22.1 with one double step in flight; profiles/r04_gemm_shapes.md)
+    constexpr bool deep = EPI == EPI_LINEAR && (S::BP + S::BQ) <= 128;
+    if (ring && wide_small && a.K % (2 * RK) == 0 && S::WP * S::WQ <= 4 && (deep || nblocks > cus)) {
+        if constexpr (deep) {
+            if (wide_slots != 2) {
+                VLMC_LAUNCH_TIMED((gemm_nt_ring_wide_kernel<T, EPI, S, 4>), dim3(unsigned(nblocks), ny), dim3(S::NT), s, a);
+                return;
+            }
+        }
+        VLMC_LAUNCH_TIMED((gemm_nt_ring_wide_kernel<T, EPI, S, 2>), dim3(unsigned(nblocks), ny), dim3(S::NT), s, a);
+    } else if (ring && a.K % RK == 0) VLMC_LAUNCH_TIMED((gemm_nt_ring_kernel<T, EPI, S>), dim3(unsigned(nblocks), ny), dim3(S::NT), s, a);
     else VLMC_LAUNCH_TIMED((gemm_nt_kernel<T, EPI, S>), dim3(unsigned(nblocks), ny), dim3(S::NT), s, a);
 }
 template <typename T, int EPI> static void launch_gemm(const GemmArgs &a, hipStream_t s) {
@@ -1128,8 +1163,57 @@ template <typename T, int EPI> static void launch_gemm(const GemmArgs &a, hipStr
         const char *e = getenv("VLMC_GEMM_BIG_TILES");            // tuning knob: tiles needed to pick 256 x 256 (0 = never)
         return e ? atoi(e) : 200;
     }();
-    if (min_big > 0 && big_tiles >= min_big) launch_shape<T, EPI, ShapeBig>(a, s);
-    else launch_shape<T, EPI, ShapeSmall>(a, s);
+    if (min_big > 0 && big_tiles >= min_big) {
+        launch_shape<T, EPI, ShapeBig>(a, s);
+        return;
+    }
+    // Few rows of X -- one rank's share of the decoder's tokens, a group of ragged calibration samples, a single sample -- leave
+    // 128 x 128 tiles to a fraction of the CUs, and what a workgroup costs there is the LDS-DMA stream of its (BP + BQ) x K
+    // operand rows at the ~50 GB/s one workgroup draws (two or more on a CU: 65-90 GB/s).  Smaller tiles put the same product
+    // on more CUs with fewer rows each.  Measured with W cold, as in a replay (profiles/r04_gemm_shapes.md, every shape x every
+    // tile): 64 x 2048 x 2048 takes 26 us in 16 tiles of 128 x 128 and 10 us in 128 of 32 x 32; 256 x 2048 x 5120 78 -> 23 us;
+    // 1024 x 2048 x 2048 28.5 -> 19.9 us.  The rule that table supports: the LARGEST tile that still makes one workgroup per
+    // CU, else the smallest.  Same MFMA shape, same K order per output element in every tile shape: the same bits
+    // (tests/test_gemm_gpu.py).  VLMC_GEMM_SMALL_TILES=0: 128 x 128 always.  VLMC_GEMM_SHAPE=<name>: that shape for every
+    // launch below the 256 x 256 threshold (A/B, tests).
+    if constexpr (EPI == EPI_LINEAR) {
+        static const bool small_tiles = [] {
+            const char *e = getenv("VLMC_GEMM_SMALL_TILES");
+            return !(e && e[0] == '0');
+        }();
+        static const int forced = [] {
+            const char *e = getenv("VLMC_GEMM_SHAPE");
+            if (!e) return 0;
+            const char *names[] = {"", "128", "64", "p32", "32"};
+            for (int i = 1; i < 5; ++i)
+                if (!strcmp(e, names[i])) return i;
+            return 0;
+        }();
+        static const int cus = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            return n;
+        }();
+        auto wgs = [&](int BP, int BQ) {
+            int64_t p = 0;
+            for (int g = 0; g < a.ng; ++g) p += (a.NP[g] + BP - 1) / BP;
+            return p * ((a.NQ + BQ - 1) / BQ);
+        };
+        int pick = forced;
+        if (!pick) {
+            if (!small_tiles || wgs(ShapeSmall::BP, ShapeSmall::BQ) >= cus) pick = 1;
+            else if (wgs(Shape64::BP, Shape64::BQ) >= cus) pick = 2;
+            else if (wgs(ShapeP32::BP, ShapeP32::BQ) >= cus) pick = 3;
+            else pick = 4;
+        }
+        switch (pick) {
+            case 2: launch_shape<T, EPI, Shape64>(a, s); return;
+            case 3: launch_shape<T, EPI, ShapeP32>(a, s); return;
+            case 4: launch_shape<T, EPI, Shape32>(a, s); return;
+            default: break;
+        }
+    }
+    launch_shape<T, EPI, ShapeSmall>(a, s);
 }
 
 // ---- transposing pre-pass of the Hessian: X [T, C] (any of the three dtypes) -> X^T planes [C, ldt] 16-bit -------------

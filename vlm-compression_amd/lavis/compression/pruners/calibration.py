@@ -170,7 +170,7 @@ class TowerMemo:
     def fingerprint(blocks):
         """(addresses, per-tensor float64 sums) of the tower's parameters and buffers, or None if they cannot be taken
         (tensors on several devices, exotic dtypes): then there is no memo."""
-        ts = [t for b in blocks for t in list(b.parameters()) + list(b.buffers())]
+        ts = [t for b in blocks for t in (b if isinstance(b, list) else block_tensors(b)[0])]    # (blocks or their tensor lists)
         try:
             # sum |x| in float64 per tensor, one fused launch per dtype (a reduction per tensor was 1 600 launches per prune)
             by = {}
@@ -292,12 +292,14 @@ def seed_tower_memo(proxy_cache, module_to_process, layers, final_outs, autocast
     if not (calls and tower_memo_enabled() and graph_replay_enabled() and len(layers) >= 2):
         return False
     n = min(len(calls), len(final_outs))
-    if n == 0 or not all(isinstance(o, torch.Tensor) and o.is_cuda for o in final_outs[:n]) or \
-            any(m.training for mod in layers for m in mod.modules()):
+    if n == 0 or not all(isinstance(o, torch.Tensor) and o.is_cuda for o in final_outs[:n]):
+        return False
+    states = [block_tensors(mod) for mod in layers]
+    if any(tr for _, tr in states):
         return False
     with autocast():
         ctx = TowerMemo.context()                    # the walk's forwards ran under this autocast state
-    fp = TowerMemo.fingerprint(list(layers))
+    fp = TowerMemo.fingerprint([ts for ts, _ in states])
     if fp is None:
         return False
     memo = TowerMemo(fp, len(layers))
@@ -796,12 +798,17 @@ def _wrap_towers(model, towers, proxy_cache=None):
             blocks = get_module_recursive(model, path)
         except AttributeError:
             continue
-        proxies, originals = [], []
+        proxies, originals, states = [], [], []
         for i in range(len(blocks)):
-            if not isinstance(blocks[i], GraphedModule) and next(blocks[i].parameters(), torch.empty(0)).is_cuda:
+            if isinstance(blocks[i], GraphedModule):
+                continue
+            ts, training = block_tensors(blocks[i])                # one walk per block and phase (was six)
+            if (ts[0] if ts else torch.empty(0)).is_cuda:
                 mod = blocks[i]
+                sig = storage_signature(mod, ts)
+                states.append((ts, training, sig))
                 proxy = proxy_cache.get(id(mod)) if proxy_cache is not None else None
-                if proxy is None or proxy.__dict__["_wrapped"] is not mod or proxy._storage != storage_signature(mod):
+                if proxy is None or proxy.__dict__["_wrapped"] is not mod or proxy._storage != sig:
                     proxy = GraphedModule(mod)
                     if proxy_cache is not None:
                         proxy_cache[id(mod)] = proxy
@@ -811,12 +818,14 @@ def _wrap_towers(model, towers, proxy_cache=None):
                 proxies.append(proxy)
                 originals.append(mod)
         # the whole tower as one graph per calibration forward (TowerGraph), kept with the proxies from phase to phase
-        if tower_graph_enabled() and len(proxies) == len(blocks) >= 2 and not any(m.training for mod in originals for m in mod.modules()):
+        any_training = any(tr for _, tr, _ in states)
+        sigs = tuple(sig for _, _, sig in states)
+        if tower_graph_enabled() and len(proxies) == len(blocks) >= 2 and not any_training:
             tg = proxy_cache.get(("tower_graph", path)) if proxy_cache is not None else None
             if tg is None or len(tg.mods) != len(originals) or any(a is not b for a, b in zip(tg.mods, originals)) or \
-                    tg.storage != tuple(storage_signature(m) for m in originals):
+                    tg.storage != sigs:
                 tg = TowerGraph(originals)
-                tg.storage = tuple(storage_signature(m) for m in originals)
+                tg.storage = sigs
                 if proxy_cache is not None:
                     proxy_cache[("tower_graph", path)] = tg
             for i, proxy in enumerate(proxies):
@@ -826,9 +835,8 @@ def _wrap_towers(model, towers, proxy_cache=None):
                 proxy.__dict__["_tower"] = None
         # the tower's outputs of this phase are remembered for the next one (TowerMemo)
         # (a block in training mode may draw dropout / drop-path masks: its output is not a function of its inputs)
-        if proxy_cache is not None and tower_memo_enabled() and len(proxies) == len(blocks) >= 2 \
-                and not any(m.training for mod in originals for m in mod.modules()):
-            fp = TowerMemo.fingerprint(originals)
+        if proxy_cache is not None and tower_memo_enabled() and len(proxies) == len(blocks) >= 2 and not any_training:
+            fp = TowerMemo.fingerprint([ts for ts, _, _ in states])
             memo = proxy_cache.get(("memo", path))
             if memo is not None and memo.matches(fp):
                 memo.begin("replay")
@@ -1169,10 +1177,32 @@ def _stack_caches(group, b0):
     return out
 
 
-def storage_signature(layer):
+def block_tensors(layer):
+    """(parameters and buffers of a block in a fixed order, whether any of its modules is in training mode): ONE walk over
+    `_modules` / `_parameters` / `_buffers`.  `Module.parameters()` + `.buffers()` + `.modules()` are three generator walks
+    with a de-duplication set each; a capture phase asks this of every block of every finished tower, and on one rank's
+    share of the calibration set those walks were ~8 ms of a 130 ms prune (profiles/r04_scaling_floor.md).  A tensor shared
+    by two modules is listed twice: fine for a signature."""
+    ts, training, stack = [], False, [layer]
+    while stack:
+        m = stack.pop()
+        training = training or m.training
+        for p_ in m._parameters.values():
+            if p_ is not None:
+                ts.append(p_)
+        for b_ in m._buffers.values():
+            if b_ is not None:
+                ts.append(b_)
+        for c_ in reversed(list(m._modules.values())):
+            if c_ is not None:
+                stack.append(c_)
+    return ts, training
+
+
+def storage_signature(layer, tensors=None):
     """Addresses of every parameter and buffer of a block: a captured graph stays valid exactly as long as these do
     (Wanda / DSnoT prune in place; SparseGPT and the LoRA masks replace tensors)."""
-    return tuple(t.data_ptr() for t in list(layer.parameters()) + list(layer.buffers()))
+    return tuple(t.data_ptr() for t in (block_tensors(layer)[0] if tensors is None else tensors))
 
 
 class BlockGraph:

@@ -31,22 +31,32 @@ class LayerWiseBasePruner(BasePruner):
         self.model_stem = getattr(self.model, model_prefix, None)
 
     def model_setup_and_record_attributes(self, model):
-        """layer_single_base_pruner.py:72-87: dtypes are only recorded (no bf16 cast here)."""
-        dtype_record, requires_grad_record = {}, {}
+        """layer_single_base_pruner.py:72-87: dtypes are only recorded (no bf16 cast here).  One walk over the parameters
+        instead of the reference's three: on one rank's share of the calibration set the host, not the GPU, sets the pace
+        (profiles/r04_scaling_floor.md)."""
+        dtype_record, requires_grad_record, device = {}, {}, None
         for n, p in model.named_parameters():
             dtype_record[n] = p.data.dtype
-        for n, p in model.named_parameters():
             requires_grad_record[n] = p.requires_grad
             p.requires_grad = True
-        device = next(iter(model.parameters())).device
+            if device is None:
+                device = p.device
+        if device is None:
+            raise StopIteration("model without parameters")       # (what the reference's next(iter(...)) raises)
         return dtype_record, requires_grad_record, device
 
     def model_reset(self, model, dtype_record, requires_grad_record, device):
+        """layer_single_base_pruner.py:89-97: requires_grad and dtypes back to what was recorded, the model to its device.
+        `p.data.type(dtype)` returns the tensor itself when the dtype is unchanged and `model.to(device)` is a walk that moves
+        nothing when every tensor is there already: both are skipped in exactly those cases."""
+        moved = False
         for n, p in model.named_parameters():
             p.requires_grad = requires_grad_record[n]
-        for n, p in model.named_parameters():
-            p.data = p.data.type(dtype_record[n])
-        model.to(device)
+            if p.data.dtype != dtype_record[n]:
+                p.data = p.data.type(dtype_record[n])
+            moved = moved or p.device != device
+        if moved or any(b.device != device for b in model.buffers()):
+            model.to(device)
         # what the replay engine kept for THIS prune (graph proxies of finished towers, their recorded outputs, the list of
         # finished towers): released with it, so a later prune() -- or a training stage -- starts from the model alone
         self.__dict__.pop("_proxy_cache", None)

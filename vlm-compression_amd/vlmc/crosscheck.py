@@ -20,6 +20,8 @@ ROUTES = {
     "gemm_half_lines": ({"VLMC_GEMM_WIDE": "0"}, "K-steps of 32 with half-line requests"),
     "gemm_one_tile_per_workgroup": ({"VLMC_GEMM_PERSIST": "0"}, "no persistent workgroups"),
     "gemm_plain_schedule": ({"VLMC_GEMM_EDGE": "0"}, "edge tiles scheduled like whole ones"),
+    "gemm_square_tiles": ({"VLMC_GEMM_SMALL_TILES": "0"}, "128 x 128 tiles also where a launch makes few workgroups of them"),
+    "gemm_shallow_ring": ({"VLMC_GEMM_WIDE_SLOTS": "2"}, "one double step of loads in flight also for the tiles of at most 64 x 64"),
     "linear_single": ({"VLMC_LINEAR_GROUP": "0"}, "every linear its own launch"),
     "linear_library": ({"VLMC_LINEAR_FWD": "0"}, "the GEMM library for the blocks' linears"),
     "select_multi": ({"VLMC_MATRIX_FUSED": "0", "VLMC_SELECT_MIXED": "0"}, "multi-launch matrix-wide / per-width row selects"),
