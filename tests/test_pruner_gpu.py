@@ -616,3 +616,60 @@ def test_finished_tower_that_hands_a_block_output_on_as_a_keyword(monkeypatch):
     assert len(want) == len(stacked) == len(graphed) == len(lens)
     for a, b, c in zip(want, stacked, graphed):
         assert torch.equal(a, b) and torch.equal(a, c)
+
+
+# ---- finished towers: the stacked pass from the block-0 arguments remembered from the tower's own capture phase ----------
+@pytest.mark.parametrize("ragged", [False, True])
+def test_predicted_tower_pass_gives_the_aborted_and_repeated_forwards_result(ragged, monkeypatch):
+    """Decoder capture of the 16-bit toy InstructBLIP: the T5 encoder (just pruned) runs stacked for all samples from the
+    block-0 arguments its own capture phase saw (`TowerGraph.run_predicted`), every sample then needs ONE forward instead of
+    an aborted one plus a repeated one.  Same pruned model, masks and importance scores, bit for bit."""
+    import toy_models
+    from lavis.compression.pruners import calibration as cal
+    monkeypatch.setattr(toy_models.ToyAttention, "use_sdpa", True)
+    monkeypatch.setenv("VLMC_LINEAR_FWD", "1")
+    monkeypatch.setenv("VLMC_TOWER_PREDICT", "0")
+    b0 = dict(cal.graph_stats)
+    want = H.run_16bit_toy("wanda", "cuda:0", n_samples=8, ragged=ragged)
+    assert cal.graph_stats.get("tower_predicted", 0) == b0.get("tower_predicted", 0)
+    monkeypatch.setenv("VLMC_TOWER_PREDICT", "1")
+    b1 = dict(cal.graph_stats)
+    got = H.run_16bit_toy("wanda", "cuda:0", n_samples=8, ragged=ragged)
+    assert cal.graph_stats.get("tower_predicted", 0) > b1.get("tower_predicted", 0), "no tower ran from remembered arguments"
+    assert cal.graph_stats.get("later_failed", 0) == b1.get("later_failed", 0)
+    assert cal.graph_stats["fallbacks"] == b1["fallbacks"]
+    assert want.keys() == got.keys()
+    for k in want:
+        assert torch.equal(want[k], got[k]), k
+
+
+def test_a_wrong_prediction_is_noticed_and_the_phase_runs_again(monkeypatch):
+    """The remembered block-0 arguments of one sample are tampered with between the phases: the stacked pass ran on the wrong
+    input, the end-of-phase comparison says so (`later_failed`), the phase is repeated without memos or predictions, and the
+    pruned model is the one the plain route gives."""
+    import toy_models
+    from lavis.compression.pruners import calibration as cal
+    monkeypatch.setattr(toy_models.ToyAttention, "use_sdpa", True)
+    monkeypatch.setenv("VLMC_LINEAR_FWD", "1")
+    monkeypatch.setenv("VLMC_LATER_EQUAL", "1")
+    monkeypatch.setenv("VLMC_TOWER_PREDICT", "0")
+    want = H.run_16bit_toy("wanda", "cuda:0", n_samples=8)
+    monkeypatch.setenv("VLMC_TOWER_PREDICT", "1")
+    real = cal.TowerGraph.run_predicted
+    tampered = []
+
+    def run_predicted(self, samples):
+        if self.predicted and not self.memo_serves and not tampered and any(w for w in self.wirings.values()):
+            j = max(self.predicted)
+            args, kwargs, ctx, versions = self.predicted[j]
+            fake = args[0].clone().add_(1)
+            self.predicted[j] = ((fake,) + tuple(args[1:]), kwargs, ctx, [(fake, fake._version)] + versions[1:])
+            tampered.append(j)
+        return real(self, samples)
+    monkeypatch.setattr(cal.TowerGraph, "run_predicted", run_predicted)
+    before = cal.graph_stats.get("later_failed", 0)
+    got = H.run_16bit_toy("wanda", "cuda:0", n_samples=8)
+    assert tampered and cal.graph_stats.get("later_failed", 0) == before + 1
+    assert want.keys() == got.keys()
+    for k in want:
+        assert torch.equal(want[k], got[k]), k

@@ -36,17 +36,30 @@ def main():
         ("N=8 vit.fc1", torch.float16, 16 * 257, 6144, 1408), ("N=8 vit.fc2", torch.float16, 16 * 257, 1408, 6144),
         ("N=8 t5enc.wi", torch.bfloat16, 16 * 64, 5120, 2048), ("N=8 t5dec.q", torch.bfloat16, 16 * 16, 2048, 2048),
         ("N=4 vit.fc1", torch.float16, 32 * 257, 6144, 1408), ("N=4 t5enc.wi", torch.bfloat16, 32 * 64, 5120, 2048),
+        ("N=8 t5enc.q", torch.bfloat16, 16 * 64, 2048, 2048), ("N=8 t5enc.wo", torch.bfloat16, 16 * 64, 2048, 5120),
+        ("N=8 t5dec.wi", torch.bfloat16, 16 * 16, 5120, 2048), ("N=8 t5dec.wo", torch.bfloat16, 16 * 16, 2048, 5120),
+        ("N=4 t5dec.q", torch.bfloat16, 32 * 16, 2048, 2048), ("N=4 t5dec.wo", torch.bfloat16, 32 * 16, 2048, 5120),
+        ("one sample t5dec.q", torch.bfloat16, 16, 2048, 2048), ("one sample t5enc.wo", torch.bfloat16, 64, 2048, 5120),
     ]
     print(f"(VLMC_GEMM_EDGE={os.environ.get('VLMC_GEMM_EDGE', '1')} VLMC_GEMM_BIG_TILES={os.environ.get('VLMC_GEMM_BIG_TILES', '200')})")
     print("| linear | M x N x K | vlmc_linear_fwd us | TFLOP/s | library us | TFLOP/s |")
     print("|---|---|---|---|---|---|")
+    cold = os.environ.get("BENCH_GEMM_COLD", "1") == "1"      # every launch reads another copy of W (as a replay does), not the
+    print(f"(weights {'cold: a pool of copies > 768 MB per shape' if cold else 'hot: the same W every launch'})")     # Infinity Cache's
     for name, dt, M, N, K in shapes:
         x = (torch.randn(M, K, device=dev) * 0.5).to(dt)
-        w = (torch.randn(N, K, device=dev) * 0.05).to(dt)
+        w0 = (torch.randn(N, K, device=dev) * 0.05).to(dt)
+        pool = [w0] + [w0.clone() for _ in range((max(2, min(128, -(-(768 << 20) // (N * K * 2)))) if cold else 1) - 1)]
+        reps = max(10, len(pool))
+        state = {"i": 0}
+
+        def nxt():
+            state["i"] = (state["i"] + 1) % len(pool)
+            return pool[state["i"]]
         ours, lib = [], []
         for _ in range(5):
-            ours.append(timeit(lambda: ops.linear_fwd(x, w), 10))
-            lib.append(timeit(lambda: F.linear(x, w), 10))
+            ours.append(timeit(lambda: ops.linear_fwd(x, nxt()), reps))
+            lib.append(timeit(lambda: F.linear(x, nxt()), reps))
         fl = 2.0 * M * N * K
         to, tl = statistics.median(ours), statistics.median(lib)
         print(f"| {name} {str(dt)[6:]} | {M} x {N} x {K} | {to * 1e3:.1f} | {fl / to / 1e9:.0f} | {tl * 1e3:.1f} | {fl / tl / 1e9:.0f} |", flush=True)

@@ -369,6 +369,12 @@ def tower_batch_enabled():
     return os.environ.get("VLMC_TOWER_BATCH", "1") != "0"
 
 
+def tower_predict_enabled():
+    """A finished tower's stacked pass starts from the block-0 arguments remembered from its own capture phase
+    (TowerGraph.run_predicted; `VLMC_TOWER_PREDICT=0`: every forward is aborted at block 0 and repeated, as in round 3)."""
+    return os.environ.get("VLMC_TOWER_PREDICT", "1") != "0"
+
+
 def tower_graph_enabled():
     """One HIP graph per finished TOWER and calibration forward (`VLMC_TOWER_GRAPH=0`: one per block)."""
     return os.environ.get("VLMC_TOWER_GRAPH", "1") != "0"
@@ -396,12 +402,23 @@ class TowerGraph:
     batch-invariant kernel (16-bit weights, vlmc/forward.py) and every outside tensor has the hidden states' batch
     dimension: the stacked pass then gives every sample the bits its own pass would."""
 
-    NEED = 2                                  # identical traces before a graph is built
+    # Traces of a wiring before it is used.  One: every later forward is checked against it call by call (`_serve`: the very
+    # tensors that were handed out, unmodified, the same plain values) and leaves the traced path the moment the model does
+    # something else, so a second trace buys no safety -- and a traced forward is an eager batch-1 pass through the whole tower
+    # (9 ms for the 24 T5 encoder blocks: two of them were 18 of the 26 ms a rank of 8 spends capturing the decoder's inputs).
+    # `VLMC_TOWER_TRACES=2`: rounds 2-4's two identical traces.
+    try:
+        NEED = max(1, int(os.environ.get("VLMC_TOWER_TRACES", "1")))
+    except ValueError:
+        NEED = 1
 
     def __init__(self, modules):
         self.mods, self.n = list(modules), len(modules)
         self.plans, self.traces, self.wirings = {}, {}, {}
         self.deferred, self.ready = [], {}    # forwards postponed at block 0; their per-block outputs once the tower ran
+        # block-0 calls of this tower as its OWN capture phase saw them, by sample (capture_block_inputs): what the model
+        # will hand block 0 again in the next phase, if nothing upstream changed -- run_predicted()
+        self.predicted, self.memo_serves, self.path = {}, False, None
         self.linears = [m for mod in self.mods for m in find_layers(mod).values()]
         self._linears_ok = {}                     # autocast state -> every linear of the tower can run on the invariant kernel
         self.off = False
@@ -413,9 +430,9 @@ class TowerGraph:
     def _flat(out):
         return list(out) if isinstance(out, (tuple, list)) else [out]
 
-    def _key0(self, args, kwargs):
+    def _key0(self, args, kwargs, ctx=None):
         """What decides the tower's kernels and the wiring, from block 0's arguments (the stream slot is not part of it)."""
-        sig = [TowerMemo.context(), self.mods[0].training]
+        sig = [TowerMemo.context() if ctx is None else ctx, self.mods[0].training]
         first = {}
         for pos, v in enumerate(list(args) + [kwargs[k] for k in sorted(kwargs)]):
             s_ = GraphedModule._sig(v)
@@ -460,7 +477,7 @@ class TowerGraph:
             if _CAPTURE_SAMPLE is not None and tower_batch_enabled():
                 r = self.ready.pop(_CAPTURE_SAMPLE, None)
                 if r is not None:
-                    if self._same_inputs(r, args, kwargs):
+                    if r.get("key", key) == key and self._same_inputs(r, args, kwargs):
                         given, k, seen = {}, 0, set()
                         for v in list(args) + [kwargs[kk] for kk in sorted(kwargs)]:
                             if isinstance(v, torch.Tensor) and id(v) not in seen:
@@ -613,12 +630,12 @@ class TowerGraph:
                 out.append(v)
         return out
 
-    def _batchable(self, args, kwargs):
+    def _batchable(self, args, kwargs, ctx=None):
         """Every linear of the tower on the batch-invariant kernel, every outside tensor stackable along the batch."""
         from vlmc import forward as fw
         if not (args and isinstance(args[0], torch.Tensor) and args[0].dim() >= 2 and fw.enabled() and self.linears):
             return False
-        ctx = TowerMemo.context()
+        ctx = TowerMemo.context() if ctx is None else ctx
         ok = self._linears_ok.get(ctx)                 # (168 linears of a Flan-T5-XL tower: asked once per autocast state)
         if ok is None:
             ok = True
@@ -638,6 +655,61 @@ class TowerGraph:
     def _same_inputs(r, args, kwargs):
         a, b = TowerGraph._ext(r["args"], r["kwargs"]), TowerGraph._ext(args, kwargs)
         return len(a) == len(b) and all(_bits_equal(x, y) for x, y in zip(a, b))
+
+    def scouts(self, samples):
+        """Samples to send through the tower FIRST: per argument signature among the remembered block-0 calls whose wiring is
+        not known yet, the NEED forwards that trace it (they would run eagerly in any order: a wiring is only trusted after
+        NEED identical traces)."""
+        if not self.predicted or self.memo_serves or self.off or not (tower_batch_enabled() and tower_predict_enabled()):
+            return set()
+        out, count = set(), {}
+        for j in samples:
+            rec = self.predicted.get(j)
+            if rec is None:
+                continue
+            key = self._key0(rec[0], rec[1], rec[2])
+            if key is None or self.wirings.get(key) is not None:
+                continue
+            have = count.get(key, len(self.traces.get(key, [])))
+            if have < self.NEED:
+                out.add(j)
+                count[key] = have + 1
+        return out
+
+    def run_predicted(self, samples):
+        """The stacked tower pass BEFORE the forwards that will ask for it.
+
+        A finished tower normally learns a sample's block-0 arguments by running the model's forward up to block 0 and
+        aborting it there (`_Defer`), and the forward is repeated once the stacked pass has run: two walks of the model's
+        Python per sample, the GPU idle during the first (128 samples: 2 x 25 ms of host around 28 ms of GPU in the T5
+        decoder's capture phase).  But block 0 of this tower was called with those arguments before -- when the tower's own
+        inputs were captured, one phase ago -- and nothing upstream of it has been pruned since.  So: run the stacked pass
+        on the REMEMBERED arguments, let every sample's single forward pick its slices up, and check the assumption the way
+        every other remembered tensor is checked (`_same_inputs` -> `_bits_equal`: shapes at once, bits at the end of the
+        phase; a mismatch reruns the phase without memos or predictions).  Same kernels on the same bits."""
+        if not self.predicted or self.memo_serves or self.off or not tower_batch_enabled() or not tower_predict_enabled():
+            return 0
+        recs = []
+        for j in samples:
+            rec = self.predicted.get(j)
+            if rec is None or j in self.ready:
+                continue
+            args, kwargs, ctx, versions = rec
+            if any(t._version != v for t, v in versions):               # written to since it was captured
+                continue
+            key = self._key0(args, kwargs, ctx)
+            wiring = self.wirings.get(key) if key is not None else None
+            if not wiring or not self._batchable(args, kwargs, ctx):
+                continue
+            recs.append({"j": j, "key": key, "args": args, "kwargs": kwargs, "ctx": ctx})
+        if recs:
+            held, self.deferred = self.deferred, recs
+            try:
+                self.run_deferred()
+            finally:
+                self.deferred = held
+            graph_stats["tower_predicted"] = graph_stats.get("tower_predicted", 0) + len(recs)
+        return len(recs)
 
     @torch.no_grad()
     def run_deferred(self):
@@ -677,7 +749,7 @@ class TowerGraph:
                         flat = [(o[t * b0:(t + 1) * b0] if o.dim() >= 1 and o.shape[0] == g * b0 else o) if isinstance(o, torch.Tensor)
                                 else o for o in self._flat(out)]
                         mine.append(tuple(flat) if isinstance(out, tuple) else flat if isinstance(out, list) else flat[0])
-                    self.ready[rec["j"]] = {"outs": mine, "args": rec["args"], "kwargs": rec["kwargs"]}
+                    self.ready[rec["j"]] = {"outs": mine, "args": rec["args"], "kwargs": rec["kwargs"], "key": key}
                 graph_stats["tower_batches"] = graph_stats.get("tower_batches", 0) + 1
         return [rec["j"] for rec in todo]
 
@@ -828,6 +900,8 @@ def _wrap_towers(model, towers, proxy_cache=None):
                 tg.storage = sigs
                 if proxy_cache is not None:
                     proxy_cache[("tower_graph", path)] = tg
+            tg.path, tg.memo_serves = path, False
+            tg.predicted = (proxy_cache.get(("block0", path)) or {}) if proxy_cache is not None else {}
             for i, proxy in enumerate(proxies):
                 proxy.__dict__["_tower"] = (tg, i)
         else:
@@ -840,6 +914,9 @@ def _wrap_towers(model, towers, proxy_cache=None):
             memo = proxy_cache.get(("memo", path))
             if memo is not None and memo.matches(fp):
                 memo.begin("replay")
+                tg_ = proxies[0].__dict__.get("_tower")
+                if tg_ is not None:
+                    tg_[0].memo_serves = True                    # the memo hands out the tower's outputs: nothing to predict
             elif fp is not None:
                 memo = proxy_cache[("memo", path)] = TowerMemo(fp, len(proxies))
                 memo.begin("record")
@@ -904,6 +981,8 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
         for key, val in list(proxy_cache.items()):
             if isinstance(val, TowerMemo):
                 val._drop()
+            elif isinstance(key, tuple) and key and key[0] == "block0":
+                del proxy_cache[key]                       # ... nor the block-0 arguments remembered for run_predicted
     return _capture_once(*args, **kw)
 
 
@@ -917,12 +996,20 @@ def _capture_once(model, batches, module_to_process, forward_to_cache, lora_mode
     calls = [] if (vit and proxy_cache is not None and tower_memo_enabled() and graph_replay_enabled()
                    and torch.cuda.is_available()) else None
 
+    # how the model calls block 0 of THIS tower, by sample: the next phase's stacked pass through it starts from these
+    # (TowerGraph.run_predicted).  References, not copies: the walk replaces `inps[j]`, it never writes into it.
+    first = {} if (proxy_cache is not None and graph_replay_enabled() and tower_batch_enabled() and tower_graph_enabled()
+                   and tower_predict_enabled() and torch.cuda.is_available()) else None
+
     class Catcher(nn.Module):
         def __init__(self, module):
             super().__init__()
             self.module = module
 
         def forward(self, inp, *args, **kwargs):
+            if first is not None and _CAPTURE_SAMPLE is not None and not torch.is_grad_enabled():
+                a_, k_ = (inp,) + tuple(args), dict(kwargs)
+                first[_CAPTURE_SAMPLE] = (a_, k_, TowerMemo.context(), [(t, t._version) for t in TowerGraph._ext(a_, k_)])
             if calls is not None:
                 calls.append((_CAPTURE_SAMPLE if _CAPTURE_SAMPLE is not None else len(calls),
                               TowerMemo._snapshot((inp,) + tuple(args), kwargs)))
@@ -974,10 +1061,20 @@ def _capture_once(model, batches, module_to_process, forward_to_cache, lora_mode
             pending, sweeps = list(range(len(mine))), 0
             while pending:
                 sweeps += 1
+                # towers whose block-0 arguments are remembered from their own capture phase run stacked NOW, on the caller's
+                # stream, and every sample below gets through them in its first forward; a tower no forward has been traced
+                # through yet (its wiring is unknown) is shown its scouts first
+                scouts = set()
+                if sweeps == 1:
+                    for t in towers:
+                        scouts |= t.scouts(pending)
+                for t in towers:
+                    t.run_predicted(pending)
                 if sides:
                     for st in sides:
                         st.wait_stream(main_stream)
-                for n_, j in enumerate(pending):
+                later = [j for j in pending if j not in scouts] if scouts else []
+                for n_, j in enumerate([j for j in pending if j in scouts] if scouts else pending):
                     _CAPTURE_SAMPLE = j
                     if sides:
                         _CAPTURE_SLOT = n_ % len(sides)
@@ -990,7 +1087,7 @@ def _capture_once(model, batches, module_to_process, forward_to_cache, lora_mode
                 if sides:
                     for st in sides:
                         main_stream.wait_stream(st)
-                pending = []
+                pending = list(later)
                 for t in towers:
                     if t.deferred:
                         if main_stream is not None:            # arguments made on the side streams, used on the caller's
@@ -999,7 +1096,7 @@ def _capture_once(model, batches, module_to_process, forward_to_cache, lora_mode
                                     e.record_stream(main_stream)
                         pending += t.run_deferred()
                 pending = sorted(set(pending))
-                if sweeps > 2 * len(towers) + 2 and pending:   # cannot happen with towers in sequence; never loop forever
+                if sweeps > 2 * len(towers) + 3 and pending:   # cannot happen with towers in sequence; never loop forever
                     raise RuntimeError("calibration capture: postponed forwards do not get through the finished towers "
                                        "(set VLMC_TOWER_BATCH=0)")
     finally:
@@ -1022,6 +1119,8 @@ def _capture_once(model, batches, module_to_process, forward_to_cache, lora_mode
         calls = [c[1] for c in calls]
     if calls is not None:
         proxy_cache[("calls", module_to_process)] = calls
+    if first is not None:
+        proxy_cache[("block0", module_to_process)] = first
     return inps, [None] * len(inps), caches
 
 
