@@ -1,0 +1,105 @@
+"""vlmc_sdpa_fwd (csrc/sdpa.hip): the fused attention `F.scaled_dot_product_attention(q, k, v)` stands for inside a replayed
+block -- eva_vit.py:129-168 / modeling_t5.py:520-640 written fused.  Held against the unfused fp32 form with the probabilities
+rounded to the operand dtype (what the kernel computes), for the shapes of the models (ViT-g: 16 heads x 257 tokens x 88; T5:
+32 heads x 64 / 16 tokens x 64, cross attention 16 x 64), strided q / k / v views, ragged tails; and for batch invariance."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ref(q, k, v, scale=None):
+    d = q.shape[-1]
+    s = (q.float() @ k.float().transpose(-2, -1)) * (d ** -0.5 if scale is None else scale)
+    p = torch.softmax(s, dim=-1).to(q.dtype).float()
+    return (p @ v.float())
+
+
+def _qkv(B, H, Tq, Tk, d, dtype, seed, spread=1.0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    mk = lambda T: (torch.randn(B, H, T, d, generator=g, device=DEV) * spread).to(dtype)
+    return mk(Tq), mk(Tk), mk(Tk)
+
+
+SHAPES = [(3, 16, 257, 257, 88, torch.float16), (2, 32, 64, 64, 64, torch.bfloat16), (2, 32, 16, 64, 64, torch.bfloat16),
+          (5, 4, 16, 16, 64, torch.bfloat16), (2, 3, 1, 1, 8, torch.float16), (1, 2, 33, 47, 40, torch.float16),
+          (2, 2, 100, 288, 96, torch.bfloat16), (1, 2, 70, 256, 128, torch.float16), (1, 3, 31, 255, 32, torch.bfloat16),
+          (2, 5, 96, 96, 128, torch.float16), (1, 1, 200, 17, 72, torch.float16)]
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,d,dtype", SHAPES)
+def test_sdpa_matches_the_unfused_fp32_form(B, H, Tq, Tk, d, dtype):
+    from vlmc import ops
+    q, k, v = _qkv(B, H, Tq, Tk, d, dtype, seed=Tq * 131 + Tk)
+    out = ops.sdpa(q, k, v)
+    assert out.shape == (B, H, Tq, d) and out.dtype == dtype
+    want = _ref(q, k, v)
+    # one rounding of O to the dtype, P rounded to the dtype: half an ulp of the output plus the P rounding carried through
+    eps = 2.0 ** -10 if dtype is torch.float16 else 2.0 ** -7
+    err = (out.float() - want).abs()
+    bound = eps * (want.abs() + v.float().abs().amax(dim=2, keepdim=True)) + 1e-6
+    assert bool((err <= bound).all()), float((err / bound).max())
+    # and against torch's own fused kernel, loosely (another order of operations)
+    lib = F.scaled_dot_product_attention(q, k, v).float()
+    assert float((out.float() - lib).abs().max()) <= 8 * eps * float(v.float().abs().max())
+
+
+def test_sdpa_reads_strided_views_in_place_and_takes_a_scale():
+    """q, k, v as the model files make them: slices of one qkv projection, [B, T, 3, H, d] -> transpose(1, 2)."""
+    from vlmc import ops
+    B, T, H, d = 4, 257, 16, 88
+    g = torch.Generator(device=DEV).manual_seed(3)
+    qkv = torch.randn(B, T, 3 * H * d, generator=g, device=DEV).to(torch.float16)
+    q, k, v = (t.reshape(B, T, H, d).transpose(1, 2) for t in qkv.reshape(B, T, 3, H * d).unbind(2))
+    assert not q.is_contiguous()
+    out = ops.sdpa(q, k, v)
+    assert torch.equal(out, ops.sdpa(q.contiguous(), k.contiguous(), v.contiguous()))
+    # the result is laid out [B, T, H, d]: the reshape every model file does next is a view
+    y = out.transpose(1, 2).reshape(B, T, H * d)
+    assert y.data_ptr() == out.data_ptr()
+    got = ops.sdpa(q, k, v, scale=0.05)
+    want = _ref(q, k, v, scale=0.05)
+    assert float((got.float() - want).abs().max()) < 4e-3
+    # extreme scores: no overflow, the row maximum is subtracted
+    q2 = q * 40
+    o2 = ops.sdpa(q2, k, v)
+    assert bool(torch.isfinite(o2).all())
+    assert float((o2.float() - _ref(q2, k, v)).abs().max()) < 2e-2
+
+
+def test_sdpa_is_batch_invariant():
+    """A sample's heads alone, in a group, at another position of the batch: the same bits."""
+    from vlmc import ops
+    for (B, H, Tq, Tk, d, dtype) in [(9, 16, 257, 257, 88, torch.float16), (12, 32, 16, 64, 64, torch.bfloat16)]:
+        q, k, v = _qkv(B, H, Tq, Tk, d, dtype, seed=5)
+        whole = ops.sdpa(q, k, v)
+        for j in (0, 4, B - 1):
+            alone = ops.sdpa(q[j:j + 1], k[j:j + 1], v[j:j + 1])
+            assert torch.equal(alone[0], whole[j]), (j, Tq)
+        perm = torch.randperm(B, device=DEV)
+        assert torch.equal(ops.sdpa(q[perm], k[perm], v[perm]), whole[perm])
+        # one head alone
+        assert torch.equal(ops.sdpa(q[:, 3:4], k[:, 3:4], v[:, 3:4])[:, 0], whole[:, 3])
+
+
+def test_calls_the_kernel_does_not_take_are_refused_or_left_to_torch(monkeypatch):
+    from vlmc import forward, ops
+    q, k, v = _qkv(1, 2, 8, 300, 64, torch.float16, seed=1)                  # more keys than LDS holds
+    assert ops.sdpa(q, k, v, _try=True) is None
+    with pytest.raises(TypeError):
+        ops.sdpa(q, k, v)
+    with pytest.raises(TypeError):
+        ops.sdpa(q.float(), k.float(), v.float())
+    monkeypatch.setenv("VLMC_LINEAR_FWD", "1")
+    q, k, v = _qkv(2, 4, 20, 20, 64, torch.bfloat16, seed=2)
+    s0 = dict(forward.stats)
+    with torch.no_grad(), forward.invariant_matmuls():
+        a = F.scaled_dot_product_attention(q, k, v)
+        b = F.scaled_dot_product_attention(q, k, v, is_causal=True)              # torch's
+        c = F.scaled_dot_product_attention(q, k, v, attn_mask=torch.zeros(20, 20, device=DEV, dtype=q.dtype))
+    assert forward.stats["sdpa_kernel"] == s0["sdpa_kernel"] + 1
+    assert torch.equal(a, ops.sdpa(q, k, v))
+    assert b.shape == a.shape and c.shape == a.shape
+    assert F.scaled_dot_product_attention.__module__ != forward.__name__        # the patch is gone

@@ -34,7 +34,7 @@ from . import ops
 
 _active = 0
 stats = {"kernel": 0, "library": 0, "grouped_launches": 0, "served_from_group": 0, "stash_dropped": 0, "attn_kernel": 0,
-         "attn_library": 0, "mean_kernel": 0}
+         "attn_library": 0, "mean_kernel": 0, "sdpa_kernel": 0, "sdpa_library": 0}
 
 # first member of a learned sibling group -> tuple of weak references to all members, in call order
 _SIBLINGS = weakref.WeakKeyDictionary()
@@ -230,6 +230,23 @@ def _make_matmul(orig):
     return matmul
 
 
+def _make_sdpa(orig):
+    """`F.scaled_dot_product_attention(q, k, v)` without mask, dropout or causality on `vlmc_sdpa_fwd` (fused, batch-invariant,
+    no [T, T] scores in HBM); every other call goes to the original."""
+    Tensor = torch.Tensor
+
+    def sdpa(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, scale=None, **kw):
+        if attn_mask is None and dropout_p == 0.0 and not is_causal and not kw and type(q) is Tensor and \
+                not torch.is_grad_enabled() and not (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() != q.dtype):
+            out = ops.sdpa(q, k, v, scale, True)
+            if out is not None:
+                stats["sdpa_kernel"] += 1
+                return out
+            stats["sdpa_library"] += 1
+        return orig(q, k, v, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal, scale=scale, **kw)
+    return sdpa
+
+
 def _make_mean(orig):
     """`x.mean(-1[, keepdim])` / `torch.mean(x, -1[, keepdim])` of an fp32 CUDA tensor on `vlmc_row_mean` (the fp32 mean of
     squares inside T5LayerNorm / LlamaRMSNorm: torch's reduction kernel is configured by the number of outputs, so a 4-token
@@ -268,6 +285,10 @@ def invariant_matmuls():
             if name not in torch.Tensor.__dict__:
                 setattr(torch.Tensor, name, _make_matmul(getattr(base, name)))
                 _mm_saved.setdefault("tensor", []).append(name)
+        if os.environ.get("VLMC_SDPA", "1") != "0":               # fused attention written as F.scaled_dot_product_attention
+            import torch.nn.functional as F_
+            _mm_saved["sdpa"] = F_.scaled_dot_product_attention
+            F_.scaled_dot_product_attention = _make_sdpa(F_.scaled_dot_product_attention)
         if os.environ.get("VLMC_ROW_MEAN", "1") != "0":           # the fp32 mean inside the norms (batch-variant in torch)
             _mm_saved["mean"] = torch.mean
             torch.mean = _make_mean(torch.mean)
@@ -283,6 +304,9 @@ def invariant_matmuls():
             torch.matmul, torch.bmm = _mm_saved.pop("matmul"), _mm_saved.pop("bmm")
             if "mean" in _mm_saved:
                 torch.mean = _mm_saved.pop("mean")
+            if "sdpa" in _mm_saved:
+                import torch.nn.functional as F_
+                F_.scaled_dot_product_attention = _mm_saved.pop("sdpa")
             for name in _mm_saved.pop("tensor", []):
                 delattr(torch.Tensor, name)
 

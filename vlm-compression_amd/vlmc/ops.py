@@ -246,6 +246,50 @@ def attn_matmul(a: torch.Tensor, b: torch.Tensor, _plan=None, _try: bool = False
     return out
 
 
+_sdpa_max_keys = {}
+
+
+def sdpa_plan(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor):
+    """(B, H, Tq, Tk, d) if `vlmc_sdpa_fwd` computes `F.scaled_dot_product_attention(q, k, v)` for these operands, else None:
+    4-D CUDA tensors [B, H, T, d] of one 16-bit dtype, unit stride along d, d a multiple of 8 up to 128, the head's keys
+    within what its K and V may take of LDS."""
+    if q.dim() != 4 or k.dim() != 4 or v.dim() != 4 or q.dtype not in _16BIT or k.dtype != q.dtype or v.dtype != q.dtype or \
+            not (q.is_cuda and k.is_cuda and v.is_cuda):
+        return None
+    B, H, Tq, d = q.shape
+    Tk = k.shape[2]
+    if k.shape != (B, H, Tk, d) or v.shape != (B, H, Tk, d) or d % 8 or d > 128 or min(B, H, Tq, Tk, d) <= 0:
+        return None
+    if q.stride(3) != 1 or k.stride(3) != 1 or v.stride(3) != 1 or min(q.stride(2), k.stride(2), v.stride(2)) < 0:
+        return None
+    mk = _sdpa_max_keys.get(d)
+    if mk is None:
+        mk = _sdpa_max_keys[d] = int(_lib.load().vlmc_sdpa_max_keys(d))
+    if Tk > mk:
+        return None
+    return B, H, Tq, Tk, d
+
+
+def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale=None, _try: bool = False):
+    """`F.scaled_dot_product_attention(q, k, v)` (no mask, no dropout, not causal) on the fused, batch-invariant MFMA kernel
+    (include/vlmc.h: vlmc_sdpa_fwd).  The result is a [B, H, Tq, d] view of a [B, Tq, H, d] buffer: the `transpose(1, 2)
+    .reshape(B, Tq, H * d)` that follows in every model file is then free.  `_try`: None for a call the kernel does not take."""
+    plan = sdpa_plan(q, k, v)
+    if plan is None:
+        if _try:
+            return None
+        _need_gpu(q, k, v)
+        raise TypeError("vlmc.sdpa: [B, H, T, d] fp16 / bf16 CUDA tensors of one dtype expected, d a multiple of 8 up to 128, "
+                        "unit stride along d, at most vlmc_sdpa_max_keys(d) keys")
+    B, H, Tq, Tk, d = plan
+    out = torch.empty((B, Tq, H, d), dtype=q.dtype, device=q.device)
+    sq, sk, sv = q.stride(), k.stride(), v.stride()
+    _lib.check(_lib.load().vlmc_sdpa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _DT[q.dtype], B, H, Tq, Tk, d,
+                                         sq[0], sq[1], sq[2], sk[0], sk[1], sk[2], sv[0], sv[1], sv[2], Tq * H * d, d, H * d,
+                                         float(d ** -0.5 if scale is None else scale), _stream()))
+    return out.transpose(1, 2)
+
+
 def row_mean(x: torch.Tensor, keepdim: bool = False) -> torch.Tensor:
     """`x.mean(-1, keepdim=keepdim)` for fp32 CUDA tensors with a fixed, batch-invariant summation order (the norms of a
     replayed block: include/vlmc.h: vlmc_row_mean)."""
