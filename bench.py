@@ -214,6 +214,13 @@ def install_probes(probe):
     probe.wrap(ops, "linear_fwd", "gemm", gemm_flops)
     probe.wrap(ops, "linear_fwd_group", "gemm", group_flops)          # q / k / v, wi_0 / wi_1: one launch (vlmc/forward.py)
 
+    def sdpa_flops(q, k, v, *a, **kw):                                  # both products: 4 B H Tq Tk d
+        return 4.0 * q.shape[0] * q.shape[1] * q.shape[2] * k.shape[2] * q.shape[3]
+
+    def sdpa_single(q, k, v, *a, **kw):
+        return ops.sdpa_plan(q, k, v) is not None
+    probe.wrap(ops, "sdpa", "attn", sdpa_flops, sdpa_single)            # F.scaled_dot_product_attention of a replayed block
+
 
 # ----------------------------------------------------------------------------------------------------------------
 # the headline: whole prunes through the drop-in API
@@ -638,7 +645,10 @@ def main():
             roof("stat", "vlmc::act_sqnorm_kernel (per-sample squared column norms of every distinct linear input of a block; one "
                          "launch per group of calibration samples)", "act_sqnorm_kernel_bytes_per_launch"),
             roof("rows", "vlmc::select_rows_mixed_kernel (score+select+apply, per-row rule; all linears of a T5 block in one "
-                         "launch)", "select_rows_mixed_kernel_bytes_per_launch")]
+                         "launch)", "select_rows_mixed_kernel_bytes_per_launch"),
+            roof("attn", "vlmc::sdpa_fwd_kernel (vlmc_sdpa_fwd: the fused attention of a replayed block, K and V of a head in LDS; "
+                         "algorithmic flops = 4 B H Tq Tk d; what paces it is LDS bandwidth and the softmax's VALU work, "
+                         "not the matrix cores)", "sdpa_fwd_kernel_bytes_per_launch", "mfma")]
     # the dominant kernel = the product kernel with the most GPU time per step (measured, not assumed)
     rows.sort(key=lambda r: -r["gpu_ms_per_step"])
     roofline = rows[0]

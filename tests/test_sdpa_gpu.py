@@ -103,3 +103,38 @@ def test_calls_the_kernel_does_not_take_are_refused_or_left_to_torch(monkeypatch
     assert torch.equal(a, ops.sdpa(q, k, v))
     assert b.shape == a.shape and c.shape == a.shape
     assert F.scaled_dot_product_attention.__module__ != forward.__name__        # the patch is gone
+
+
+def test_lds_dma_and_register_staging_give_the_same_bits(tmp_path):
+    """K and V reach LDS by LDS-DMA when their rows are 16-byte aligned, through registers otherwise (`VLMC_SDPA_DMA=0` forces
+    the latter; read once per process, hence the child processes); a misaligned view takes the register route by itself."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys, torch
+sys.path.insert(0, {os.path.join(root, 'vlm-compression_amd')!r})
+from vlmc import ops
+g = torch.Generator(device='cuda:0').manual_seed(11)
+outs = []
+for B, H, Tq, Tk, d, dt in [(3, 16, 257, 257, 88, torch.float16), (4, 8, 16, 64, 64, torch.bfloat16), (2, 4, 40, 100, 40, torch.float16)]:
+    q, k, v = ((torch.randn(B, H, T, d, generator=g, device='cuda:0')).to(dt) for T in (Tq, Tk, Tk))
+    outs.append(ops.sdpa(q, k, v).cpu())
+torch.save(outs, sys.argv[1])
+"""
+    res = []
+    for dma in ("1", "0"):
+        out = tmp_path / f"dma{dma}.pt"
+        r = subprocess.run([sys.executable, "-c", code, str(out)], env=dict(os.environ, VLMC_SDPA_DMA=dma), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(torch.load(out))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # rows that are not 16-byte aligned (a view that starts 4 elements into a buffer): the same values as an aligned copy
+    from vlmc import ops
+    B, H, T, d = 2, 4, 50, 64
+    buf = torch.randn(3, B * H * T * d + 8, device=DEV).to(torch.float16)
+    q, k, v = (buf[i, 4:4 + B * H * T * d].view(B, H, T, d) for i in range(3))
+    assert k.data_ptr() % 16 != 0
+    assert torch.equal(ops.sdpa(q, k, v), ops.sdpa(q.clone(), k.clone(), v.clone()))

@@ -27,7 +27,12 @@
 #include "mfma.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
+
+#ifndef VLMC_SDPA_DBG
+#define VLMC_SDPA_DBG 0              // diagnostic builds only (tools/sdpa_ablate.sh): 1 no exp, 2 no P V MFMAs, 4 no K Q MFMAs,
+#endif                               // 8 no K / V staging loads, 16 no V fragment reads -- results are garbage, only the pace is of interest
 
 namespace vlmc {
 
@@ -38,10 +43,18 @@ struct SdpaArgs {
     int H, Tq, Tk, d;
     int qsplit;                 // workgroups per head; workgroup y takes the 32-query blocks y, y + qsplit, ..
     int hpw, nheads;            // heads per workgroup (1, 2 or 4: few queries per head), heads in all
+    int dma;                    // K and V rows are 16-byte aligned: staged by LDS-DMA (global_load_lds), no registers in between
     float scale_log2e;          // scale * log2(e)
 };
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __attribute__((aligned(16))) const uint32_t sdpa_zero_chunk[4] = {0u, 0u, 0u, 0u};      // what padding is "loaded" from
+
+// 64 lanes x 16 B from global memory straight into 1 KiB of LDS at `lds_addr` (wave-uniform), lane l at lds_addr + 16 l
+__device__ __forceinline__ void sdpa_glds16(const void *gptr, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(gptr) : "memory", "m0");
+}
 
 struct __attribute__((packed, aligned(2))) SU16x8 { u32x4_t v; };
 __device__ __forceinline__ u32x4_t sdpa_load16(const uint16_t *p) { return reinterpret_cast<const SU16x8 *>(p)->v; }
@@ -55,7 +68,8 @@ template <typename T, int DS, int MAXKT, bool FULL>
 __global__ __launch_bounds__(256) void sdpa_fwd_kernel(const SdpaArgs a) {
     constexpr int DP = 32 * DS, RS = DP * 2 + 16, DT = 2 * DS;                // padded d, row bytes, 16-wide d tiles
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                 // (wave-uniform: LDS-DMA addresses go through m0)
     const int l15 = lane & 15, c = lane >> 4;
     // hpw heads per workgroup: the head's 4 / hpw waves stage its K and V and share its blocks of queries
     const int wph = 4 / a.hpw, sub = wave / wph, hw = wave - sub * wph;         // waves per head, head slot, wave inside the head
@@ -64,11 +78,30 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(const SdpaArgs a) {
     const int bh = live ? bh_raw : a.nheads - 1, b = bh / a.H, h = bh - b * a.H;
     const int KT = ((a.Tk + 31) >> 5) << 1;                                   // key tiles, even (K-steps of 32 keys)
     const int rows = KT * 16;
-    unsigned char *lk = lds + sub * (2 * rows * RS), *lv = lk + rows * RS;
+    const int image = (rows * RS + 1023) & ~1023;                              // bytes of one K or V image (whole LDS-DMA pieces)
+    unsigned char *lk = lds + sub * (2 * image), *lv = lk + image;
     const uint16_t *Kp = a.K + int64_t(b) * a.sk_b + int64_t(h) * a.sk_h;
     const uint16_t *Vp = a.V + int64_t(b) * a.sv_b + int64_t(h) * a.sv_h;
-    // ---- the head's K and V into LDS, zero where there is no key / no d; 8 + 8 loads in flight per lane -----------------
-    {
+    // ---- the head's K and V into LDS, zero where there is no key / no d ------------------------------------------------
+    // LDS-DMA when the rows are 16-byte aligned (they are for d % 8 == 0 views of 16-byte aligned tensors): a wave instruction
+    // fills 1 KiB = 64 consecutive 16-byte slots of the image (rows of RS / 16 slots, the last one padding), every slot's
+    // lane points at its chunk of K / V or at 16 bytes of zeros; all of a wave's pieces are in flight at once, no register
+    // holds anything (staged through registers the 2 x 27 chunks per lane went in four waits: 6 of a head's 23 us).
+    if (a.dma) {
+        constexpr int SPR = RS / 16;                                           // slots per row
+        const int total = image / 16;
+        const uint32_t lds_k = uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)lk));
+        const uint32_t lds_v = uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)lv));
+        for (int base = hw * 64; base < total; base += wph * 64) {
+            const int j = base + lane, r = j / SPR, ch = j - r * SPR;
+            const bool in = !(VLMC_SDPA_DBG & 8) && r < a.Tk && ch * 8 < a.d;     // (rows past the image: r >= rows >= Tk)
+            const void *srck = in ? static_cast<const void *>(Kp + int64_t(r) * a.sk_t + ch * 8) : static_cast<const void *>(sdpa_zero_chunk);
+            const void *srcv = in ? static_cast<const void *>(Vp + int64_t(r) * a.sv_t + ch * 8) : static_cast<const void *>(sdpa_zero_chunk);
+            sdpa_glds16(srck, __builtin_amdgcn_readfirstlane(lds_k + base * 16));
+            sdpa_glds16(srcv, __builtin_amdgcn_readfirstlane(lds_v + base * 16));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
         constexpr int CPR = DP / 8;                                            // 16-byte chunks per row
         const int total = rows * CPR, nth = 64 * wph, t0 = hw * 64 + lane;
         const u32x4_t zero = {0u, 0u, 0u, 0u};
@@ -77,7 +110,7 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(const SdpaArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int i = base + j * nth, r = i / CPR, ch = i - r * CPR;
-                const bool in = i < total && r < a.Tk && ch * 8 < a.d;
+                const bool in = !(VLMC_SDPA_DBG & 8) && i < total && r < a.Tk && ch * 8 < a.d;
                 kv[j] = in ? sdpa_load16(Kp + int64_t(r) * a.sk_t + ch * 8) : zero;
                 vv[j] = in ? sdpa_load16(Vp + int64_t(r) * a.sv_t + ch * 8) : zero;
             }
@@ -98,7 +131,6 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(const SdpaArgs a) {
     const int nblk = (a.Tq + 31) >> 5;
     const int tq_ = (lane >> 2) & 3, tp_ = lane & 3;                          // transposing read: row and 8-byte piece inside a group
     const int KTc = FULL ? MAXKT : KT;                                        // (FULL: a compile-time constant, no guards below)
-    const int dtiles = (a.d + 15) >> 4;                                       // d tiles that hold anything
     // One block of 32 queries (TWO) or of at most 16 (the tail of a head).  TWO is a compile-time constant inside: the K loop
     // is straight-line code, fragment reads of the next key tile are in flight during the MFMAs of this one.
     auto block = [&](auto two_c, const int q0, const u32x4_t (&qnow)[2][DS]) {
@@ -129,15 +161,17 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(const SdpaArgs a) {
 #pragma unroll
             for (int ds = 0; ds < DS; ++ds)
 #pragma unroll
-                for (int u = 0; u < NU; ++u) acc[u][kt] = mfma16<T>(fk[kt & 1][ds], fq[u][ds], acc[u][kt]);
+                for (int u = 0; u < NU; ++u) {
+                    if (VLMC_SDPA_DBG & 4) asm volatile("" : "+v"(acc[u][kt]) : "v"(fk[kt & 1][ds]), "v"(fq[u][ds]));
+                    else acc[u][kt] = mfma16<T>(fk[kt & 1][ds], fq[u][ds], acc[u][kt]);
+                }
         }
         // ---- softmax over the keys of a query: the lane's 4 KT values, then the 4 lane groups ------------------------------
         // max over the raw scores (the scale is positive), e = exp2(score * k - max * k) in one fma + v_exp, the sum; the
         // probabilities go to the second product UNNORMALISED (e <= 1: the relative rounding is that of e / sum) and the
         // accumulators of O are divided by the sum at the end -- 16 x 6 multiplies instead of 72 x 4.
         // FULL: 16 (MAXKT - 2) key tiles hold real keys whatever Tk is: only the last two are checked for padding.
-        u32x4_t fp[NU][MAXKT / 2];                                            // P^T as the B operand: K-step s = key tiles 2 s, 2 s + 1
-        float inv[NU];
+        float mk[NU], sum[NU], inv[NU];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             float m = -INFINITY;
@@ -152,27 +186,12 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(const SdpaArgs a) {
             }
             m = fmaxf(m, __shfl_xor(m, 16));
             m = fmaxf(m, __shfl_xor(m, 32));
-            const float mk = -m * a.scale_log2e;
-            float sum = 0.f;
-#pragma unroll
-            for (int s = 0; s < MAXKT / 2; ++s) {
-                if (!FULL && 2 * s >= KTc) continue;
-                uint16_t e[8];
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float ex = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[u][2 * s + t][g], a.scale_log2e, mk));   // exp2(-inf) = 0
-                        sum += ex;
-                        e[4 * t + g] = from_f32<T>(ex);
-                    }
-                __builtin_memcpy(&fp[u][s], e, 16);
-            }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
-            inv[u] = 1.0f / sum;
+            mk[u] = -m * a.scale_log2e;
+            sum[u] = 0.f;
         }
         // ---- O^T[d][query] = V^T P^T: oacc[u][dt][g] = d 16 dt + 4 c + g, query 16 u + l15 -------------------------------
+        // K-step s = key tiles 2 s, 2 s + 1: its probabilities are made (fma, v_exp, rounding: VALU) right before its MFMAs,
+        // so that the matrix pipe works on step s while the vector pipe makes step s + 1.
         f32x4_t oacc[NU][DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -186,20 +205,45 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(const SdpaArgs a) {
             s16x4_t hv[DT][2];
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                if (dt >= dtiles) continue;                                   // (uniform) d tiles that hold nothing are skipped
 #pragma unroll
-                for (int half = 0; half < 2; ++half)
-                    hv[dt][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t *)(
+                for (int half = 0; half < 2; ++half) {
+                    if (VLMC_SDPA_DBG & 16) asm volatile("" : "=v"(hv[dt][half]));
+                    else hv[dt][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t *)(
                         const_cast<unsigned char *>(vbase + (32 * s + 16 * half) * RS + 32 * dt)));
+                }
+            }
+            u32x4_t fp[NU];                                                   // P^T as the B operand of this K-step
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                uint16_t e[8];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float arg = __builtin_fmaf(acc[u][2 * s + t][g], a.scale_log2e, mk[u]);
+                        const float ex = (VLMC_SDPA_DBG & 1) ? arg : __builtin_amdgcn_exp2f(arg);                           // exp2(-inf) = 0
+                        sum[u] += ex;
+                        e[4 * t + g] = from_f32<T>(ex);
+                    }
+                __builtin_memcpy(&fp[u], e, 16);
             }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                if (dt >= dtiles) continue;
                 u32x4_t fv;
                 __builtin_memcpy(&fv, hv[dt], 16);
 #pragma unroll
-                for (int u = 0; u < NU; ++u) oacc[u][dt] = mfma16<T>(fv, fp[u][s], oacc[u][dt]);
+                for (int u = 0; u < NU; ++u) {
+                    if (VLMC_SDPA_DBG & 2) asm volatile("" : "+v"(oacc[u][dt]) : "v"(fv), "v"(fp[u]));
+                    else oacc[u][dt] = mfma16<T>(fv, fp[u], oacc[u][dt]);
+                }
             }
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            float t = sum[u];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            inv[u] = 1.0f / t;
         }
         // ---- store: lane holds 4 consecutive d of one query -------------------------------------------------------------
 #pragma unroll
@@ -214,15 +258,9 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(const SdpaArgs a) {
                 uint16_t e[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) e[g] = from_f32<T>(oacc[u][dt][g] * inv[u]);
-                if (e0 + 3 < a.d) {
-                    SU16x4 v;
-                    __builtin_memcpy(&v, e, 8);
-                    *reinterpret_cast<SU16x4 *>(orow + e0) = v;
-                } else {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        if (e0 + g < a.d) orow[e0 + g] = e[g];
-                }
+                SU16x4 v;                                                     // (d is a multiple of 8: e0 < d means e0 + 3 < d)
+                __builtin_memcpy(&v, e, 8);
+                *reinterpret_cast<SU16x4 *>(orow + e0) = v;
             }
         }
     };
@@ -280,7 +318,7 @@ template <typename T, int DS, int MAXKT, bool FULL> static int sdpa_launch2(cons
 template <typename T, int DS> static int sdpa_launch(const SdpaArgs &a, int64_t bh, hipStream_t s) {
     constexpr int RS = 32 * DS * 2 + 16, BIG = DS == 3 ? 18 : 16;
     const int KT = ((a.Tk + 31) >> 5) << 1;
-    const size_t lds = size_t(a.hpw) * 2 * KT * 16 * RS;
+    const size_t lds = size_t(a.hpw) * 2 * ((size_t(KT) * 16 * RS + 1023) & ~size_t(1023));
     if (KT <= 4) return KT == 4 ? sdpa_launch2<T, DS, 4, true>(a, bh, lds, s) : sdpa_launch2<T, DS, 4, false>(a, bh, lds, s);
     return KT == BIG ? sdpa_launch2<T, DS, BIG, true>(a, bh, lds, s) : sdpa_launch2<T, DS, BIG, false>(a, bh, lds, s);
 }
@@ -309,7 +347,7 @@ extern "C" int vlmc_sdpa_fwd(const void *Q, const void *K, const void *V, void *
     VLMC_REQUIRE(sq_t >= 0 && sk_t >= 0 && sv_t >= 0 && so_t >= head_dim, "vlmc_sdpa_fwd: bad row strides");
     VLMC_REQUIRE(((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V) |
                    reinterpret_cast<uintptr_t>(O)) & 1u) == 0, "vlmc_sdpa_fwd: pointers must be 2-byte aligned");
-    VLMC_REQUIRE(std::isfinite(scale), "vlmc_sdpa_fwd: scale must be finite");
+    VLMC_REQUIRE(std::isfinite(scale) && scale > 0.f, "vlmc_sdpa_fwd: scale must be finite and positive");
     SdpaArgs a{};
     a.Q = static_cast<const uint16_t *>(Q), a.K = static_cast<const uint16_t *>(K), a.V = static_cast<const uint16_t *>(V);
     a.O = static_cast<uint16_t *>(O);
@@ -325,13 +363,21 @@ extern "C" int vlmc_sdpa_fwd(const void *Q, const void *K, const void *V, void *
     // K / V image and its own waves, as long as the images fit
     {
         const int ds_ = int((head_dim + 31) / 32), kt_ = int(((Tk + 31) >> 5) << 1);
-        const size_t per_head = size_t(2) * kt_ * 16 * (64 * ds_ + 16);
+        const size_t per_head = size_t(2) * ((size_t(kt_) * 16 * (64 * ds_ + 16) + 1023) & ~size_t(1023));
         int hpw = nblk <= 1 ? 4 : (nblk <= 2 ? 2 : 1);
         while (hpw > 1 && per_head * hpw > size_t(72) * 1024) hpw >>= 1;      // (at least two workgroups per CU)
         a.hpw = hpw;
         a.nheads = int(batch * heads);
     }
     a.scale_log2e = scale * 1.44269504088896340736f;
+    {
+        static const bool dma_ok = [] {
+            const char *e = getenv("VLMC_SDPA_DMA");                          // 0: K and V staged through registers (the cross-check)
+            return !(e && e[0] == '0');
+        }();
+        const uintptr_t bits = reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V) | uintptr_t(2 * (sk_b | sk_h | sk_t | sv_b | sv_h | sv_t));
+        a.dma = dma_ok && (bits & 15u) == 0;
+    }
     hipStream_t s = as_stream(stream);
     const int ds = int((head_dim + 31) / 32);
     int rc;

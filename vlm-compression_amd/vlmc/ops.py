@@ -274,7 +274,7 @@ def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale=None, _try: bo
     """`F.scaled_dot_product_attention(q, k, v)` (no mask, no dropout, not causal) on the fused, batch-invariant MFMA kernel
     (include/vlmc.h: vlmc_sdpa_fwd).  The result is a [B, H, Tq, d] view of a [B, Tq, H, d] buffer: the `transpose(1, 2)
     .reshape(B, Tq, H * d)` that follows in every model file is then free.  `_try`: None for a call the kernel does not take."""
-    plan = sdpa_plan(q, k, v)
+    plan = sdpa_plan(q, k, v) if (scale is None or 0.0 < float(scale) < float("inf")) else None
     if plan is None:
         if _try:
             return None
