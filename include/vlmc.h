@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLMC_ABI_VERSION 9
+#define VLMC_ABI_VERSION 10
 
 #define VLMC_OK 0
 #define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
@@ -248,6 +248,18 @@ int vlmc_sdpa_fwd(const void *Q, const void *K, const void *V, void *O, int dtyp
  *     out[r] = (sum over c of x[r * ldx + c]) / n        one wave per row, a fixed order that depends on n only
  * x [rows, n] fp32 (row stride ldx elements), out [rows] fp32.                                                 */
 int vlmc_row_mean(const float *x, int64_t rows, int64_t n, int64_t ldx, float *out, void *stream);
+
+/* ---- the RMS norm of a language-model block in one launch ---------------------------------------------
+ * Replaces the op sequence of transformers' T5LayerNorm.forward / LlamaRMSNorm.forward inside a replayed block
+ *     variance = x.to(torch.float32).pow(2).mean(-1, keepdim=True);  h = (x * torch.rsqrt(variance + eps)).to(dtype);  y = weight * h
+ * (seven launches, ~15 x the activation's bytes in traffic) for 16-bit x [rows, n] (row stride ldx) and weight [n] of one dtype,
+ * rounding every intermediate where the op sequence rounds it; the mean is vlmc_row_mean's (same order, same division), so
+ * the result equals the op sequence under the replay's patches bit for bit -- provided `rsqrt_mode` (0: 1 / sqrt in double rounded
+ * to float -- torch.rsqrt(float) on ROCm, where ATen's `::rsqrt(a)` resolves to the double overload; 1: v_rsq_f32; 2: IEEE fp32
+ * 1 / sqrt) is the one that reproduces torch.rsqrt, which the caller establishes once (vlmc/forward.py: against torch.rsqrt itself and
+ * against the module's own forward; the kernel is installed only for modules whose own forward it reproduces exactly).  y [rows, n], row stride ldy. */
+int vlmc_rms_norm(const void *x, int dtype, int64_t rows, int64_t n, int64_t ldx, const void *weight, float eps, int rsqrt_mode,
+                  void *y, int64_t ldy, void *stream);
 
 /* ---- K8: SparseGPT Hessian accumulation (MFMA SYRK) -------------------------------------------------
  * Replaces the arithmetic of SparseGPT.add_batch, sparsegpt_pruner.py:76-79

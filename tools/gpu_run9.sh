@@ -4,3 +4,4 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/t_all.log 2>&1 || { tail -60 gpurun_out/t_all.log; exit 1; }
 tail -3 gpurun_out/t_all.log
+timeout -k 10 600 python bench.py --steps 10 --warmup 2 --cpu-seconds 0 2>&1 | tail -1 > gpurun_out/bench_norm.json

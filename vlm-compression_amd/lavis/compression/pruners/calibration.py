@@ -739,7 +739,7 @@ class TowerGraph:
                         return self._flat(outs[w[1]])[w[2]]
                     return w[1]
                 with torch.autocast(device_type="cuda", dtype=ctx[1], enabled=ctx[0]) if ctx[0] else contextlib.nullcontext(), \
-                        fw.invariant_linears(self.linears):
+                        fw.invariant_linears(self.linears, roots=self.mods):
                     for i, (wires, kwires, _t, _l, _n) in enumerate(calls):
                         outs.append(self.mods[i](*[resolve(w) for w in wires], **{k: resolve(w) for k, w in kwires}))
                 g = len(chunk)
@@ -1057,7 +1057,7 @@ def _capture_once(model, batches, module_to_process, forward_to_cache, lora_mode
                 towers.append(tg_[0])
         # the finished towers' linears run on the batch-invariant kernel whichever way a sample gets through them (alone,
         # from a graph, or stacked with others): the captured inputs do not depend on the route
-        with forward.invariant_linears([m for t in towers for m in t.linears]):
+        with forward.invariant_linears([m for t in towers for m in t.linears], roots=[b for t in towers for b in t.mods]):
             pending, sweeps = list(range(len(mine))), 0
             while pending:
                 sweeps += 1
@@ -1519,7 +1519,7 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
         for names in sibling_names:
             if all(n in subset for n in names):
                 forward.register_siblings([subset[n] for n in names])
-        with forward.invariant_linears(subset.values()):
+        with forward.invariant_linears(subset.values(), roots=(layer,)):
             prune_block(i, layer, subset, run_pass, state)
             run_pass()
         if i == 0:

@@ -39,6 +39,7 @@ ROUTES = {
     "sgpt_library": ({"VLMC_SGPT_SYRK": "0", "VLMC_SGPT_DIRECT_FACTOR": "0", "VLMC_CHOL_GRAPH": "0"}, "library GEMM Hessian, the reference's three-step factor chain"),
     "sgpt_per_call": ({"VLMC_SGPT_DEFER": "0"}, "one Hessian update per hook call"),
     "sgpt_chain": ({"VLMC_SGPT_PERSISTENT": "0"}, "the factorization as a chain of launches per 128 columns instead of one persistent launch"),
+    "norm_op_sequence": ({"VLMC_RMS_NORM": "0"}, "the language-model blocks' RMS norms run as the model files' seven launches"),
     "sdpa_register_staging": ({"VLMC_SDPA_DMA": "0"}, "K and V of a head staged into LDS through registers instead of LDS-DMA"),
     "sdpa_library": ({"VLMC_SDPA": "0"}, "F.scaled_dot_product_attention inside a replayed block left to torch"),
     "attn_library": ({"VLMC_ATTN_MATMUL": "0", "VLMC_ROW_MEAN": "0"}, "the blocks' batched matmuls and the norms' mean left to torch during the replay"),

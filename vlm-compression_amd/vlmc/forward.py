@@ -34,7 +34,7 @@ from . import ops
 
 _active = 0
 stats = {"kernel": 0, "library": 0, "grouped_launches": 0, "served_from_group": 0, "stash_dropped": 0, "attn_kernel": 0,
-         "attn_library": 0, "mean_kernel": 0, "sdpa_kernel": 0, "sdpa_library": 0}
+         "attn_library": 0, "mean_kernel": 0, "sdpa_kernel": 0, "sdpa_library": 0, "norm_kernel": 0}
 
 # first member of a learned sibling group -> tuple of weak references to all members, in call order
 _SIBLINGS = weakref.WeakKeyDictionary()
@@ -311,10 +311,102 @@ def invariant_matmuls():
                 delattr(torch.Tensor, name)
 
 
+# ---- RMS norms of the language-model blocks: one launch instead of seven ------------------------------------------------------
+# A module qualifies by what it IS -- no children, exactly one parameter `weight` [n] in fp16 / bf16, no buffers, an epsilon
+# attribute -- and is only ever replaced after its OWN forward has been reproduced bit for bit by `vlmc_rms_norm` on random rows
+# (once per class, dtype, width and epsilon, under the replay's patches; that comparison also picks the rsqrt flavour that is
+# torch's).  A norm that scales by (1 + weight), keeps fp32, adds a bias or differs in any rounding fails the comparison and keeps
+# its own forward.  `VLMC_RMS_NORM=0`: never.
+_NORM_OK = {}                 # (class, dtype, n, eps) -> rsqrt_mode, or None: the module's forward is not this op sequence
+_NORM_SCAN = weakref.WeakKeyDictionary()      # root module -> its norm candidates (the walk is done once per root)
+
+
+def rms_norm_enabled():
+    return os.environ.get("VLMC_RMS_NORM", "1") != "0"
+
+
+def _norm_eps(m):
+    for name in ("variance_epsilon", "eps", "epsilon"):
+        v = m.__dict__.get(name)
+        if isinstance(v, float) and 0.0 < v < 1.0:
+            return v
+    return None
+
+
+def _norm_candidates(root):
+    found = _NORM_SCAN.get(root)
+    if found is None:
+        found = []
+        for m in root.modules():
+            if m._modules or len(m._parameters) != 1 or any(b is not None for b in m._buffers.values()) or type(m) is nn.Linear:
+                continue
+            w = m._parameters.get("weight")
+            if w is None or w.dim() != 1 or w.dtype not in (torch.float16, torch.bfloat16) or not w.is_cuda or _norm_eps(m) is None:
+                continue
+            found.append(m)
+        _NORM_SCAN[root] = found
+    return found
+
+
+_RSQRT_MODES = {}             # device index -> the rsqrt flavours worth trying, torch's first
+
+
+def _rsqrt_modes(device):
+    """torch.rsqrt(float) on ROCm is 1 / sqrt in DOUBLE rounded to float (ATen's `::rsqrt(a)` picks the double overload): if that
+    holds on this build -- checked on 2^18 values against torch.rsqrt itself -- it is the only flavour tried; otherwise the two
+    fp32 ones, and the module-level comparison below decides on more rows."""
+    modes = _RSQRT_MODES.get(device.index)
+    if modes is None:
+        g = torch.Generator(device=device).manual_seed(7)
+        v = torch.cat([torch.rand(1 << 17, generator=g, device=device) * 4 + 1e-6, torch.randn(1 << 17, generator=g, device=device).abs() * 1e3 + 1e-8])
+        modes = (0,) if torch.equal(torch.rsqrt(v), (1.0 / torch.sqrt(v.double())).float()) else (1, 2)
+        _RSQRT_MODES[device.index] = modes
+    return modes
+
+
+def _norm_mode(m):
+    """rsqrt flavour with which `vlmc_rms_norm` IS `m.forward` (bitwise, on random rows), or None.  Called inside the replay's
+    patches (the module's own forward takes its mean from `vlmc_row_mean`, as it will in the replay), outside any graph capture."""
+    w, eps = m.weight, _norm_eps(m)
+    key = (type(m), w.dtype, w.shape[0], eps)
+    if key in _NORM_OK:
+        return _NORM_OK[key]
+    mode = None
+    try:
+        g = torch.Generator(device=w.device).manual_seed(20240917)
+        modes = _rsqrt_modes(w.device)
+        rows = 37 if modes == (0,) else 1500                                  # (flavours that differ in 1 ulp of r show in ~1 element per 10 rows)
+        x = (torch.randn(3, rows, w.shape[0], generator=g, device=w.device) * torch.tensor([0.02, 1.0, 30.0], device=w.device)[:, None, None]).to(w.dtype)
+        with torch.no_grad():
+            want = m.forward(x)
+            if isinstance(want, torch.Tensor) and want.dtype == w.dtype and want.shape == x.shape:
+                for cand in modes:
+                    if torch.equal(ops.rms_norm(x, w.detach(), eps, cand), want):
+                        mode = cand
+                        break
+    except Exception:
+        mode = None
+    _NORM_OK[key] = mode
+    return mode
+
+
+def _make_norm(m, mode, eps):
+    own = m.forward
+
+    def forward(x, *a, **kw):
+        if not a and not kw and type(x) is torch.Tensor and x.is_cuda and x.dtype == m.weight.dtype and x.shape[-1] == m.weight.shape[0] \
+                and not torch.is_grad_enabled() and not (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() != x.dtype):
+            stats["norm_kernel"] += 1
+            return ops.rms_norm(x, m.weight, eps, mode)
+        return own(x, *a, **kw)
+    return forward
+
+
 @contextlib.contextmanager
-def invariant_linears(modules):
+def invariant_linears(modules, roots=()):
     """Route the forward of the given `nn.Linear` modules (exact type) through `linear` for the duration -- and the batched
-    matmuls of the blocks' attention through `vlmc_attn_matmul` (`invariant_matmuls`)."""
+    matmuls of the blocks' attention through `vlmc_attn_matmul` (`invariant_matmuls`).  `roots`: the blocks those linears live
+    in; their RMS norms run on `vlmc_rms_norm` where that reproduces the norm's own forward exactly (above)."""
     global _active
     if not enabled():
         yield
@@ -324,11 +416,24 @@ def invariant_linears(modules):
     for m in patched:
         m.forward = (lambda mod: (lambda x: tracker.call(mod, x)))(m)
     _active += 1
+    norms = []
     try:
         with invariant_matmuls():
+            if roots and rms_norm_enabled() and attn_matmul_enabled() and os.environ.get("VLMC_ROW_MEAN", "1") != "0" \
+                    and not torch.cuda.is_current_stream_capturing():
+                for root in roots:
+                    for m in _norm_candidates(root):
+                        if "forward" in m.__dict__ or m.training:
+                            continue
+                        mode = _norm_mode(m)
+                        if mode is not None:
+                            m.forward = _make_norm(m, mode, _norm_eps(m))
+                            norms.append(m)
             yield tracker
     finally:
         _active -= 1
         tracker.close()
         for m in patched:
+            m.__dict__.pop("forward", None)
+        for m in norms:
             m.__dict__.pop("forward", None)

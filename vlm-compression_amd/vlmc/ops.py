@@ -246,6 +246,23 @@ def attn_matmul(a: torch.Tensor, b: torch.Tensor, _plan=None, _try: bool = False
     return out
 
 
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float, rsqrt_mode: int = 0) -> torch.Tensor:
+    """`weight * (x * rsqrt(x.float().pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype)` -- T5LayerNorm / LlamaRMSNorm, op for op --
+    in one launch (include/vlmc.h: vlmc_rms_norm); the mean is `row_mean`'s.  16-bit CUDA x [.., n] and weight [n] of one dtype."""
+    _need_gpu(x, weight)
+    n = x.shape[-1]
+    if x.dtype not in _16BIT or weight.dtype != x.dtype or weight.shape != (n,) or not weight.is_contiguous() or n == 0:
+        raise TypeError("vlmc.rms_norm: fp16 / bf16 x [.., n] and a contiguous weight [n] of the same dtype expected")
+    x2 = x.reshape(-1, n)
+    if x2.stride(1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < n):
+        x2 = x2.contiguous()
+    rows = x2.shape[0]
+    out = torch.empty((rows, n), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().vlmc_rms_norm(x2.data_ptr(), _DT[x.dtype], rows, n, x2.stride(0) if rows > 1 else n, weight.data_ptr(), float(eps),
+                                         int(rsqrt_mode), out.data_ptr(), n, _stream()))
+    return out.reshape(x.shape)
+
+
 _sdpa_max_keys = {}
 
 

@@ -160,13 +160,14 @@ class ViTBlock(nn.Module):
 
 
 class RMSNorm(nn.Module):
-    def __init__(self, dim):
+    def __init__(self, dim, eps=1e-6):     # (transformers' T5LayerNorm: the same attribute names, the same op sequence)
         super().__init__()
         self.weight = nn.Parameter(torch.ones(dim))
+        self.variance_epsilon = eps
 
-    def forward(self, x):                  # (the op sequence of transformers' T5LayerNorm)
+    def forward(self, x):
         v = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
-        h = x * torch.rsqrt(v + 1e-6)
+        h = x * torch.rsqrt(v + self.variance_epsilon)
         if self.weight.dtype in (torch.float16, torch.bfloat16):
             h = h.to(self.weight.dtype)
         return self.weight * h
