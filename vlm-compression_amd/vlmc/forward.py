@@ -420,7 +420,7 @@ def invariant_linears(modules, roots=()):
     try:
         with invariant_matmuls():
             if roots and rms_norm_enabled() and attn_matmul_enabled() and os.environ.get("VLMC_ROW_MEAN", "1") != "0" \
-                    and not torch.cuda.is_current_stream_capturing():
+                    and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
                 for root in roots:
                     for m in _norm_candidates(root):
                         if "forward" in m.__dict__ or m.training:
