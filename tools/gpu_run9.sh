@@ -1,7 +1,9 @@
 set -e
 cd /root/repo
 export TMPDIR=/tmp
-mkdir -p gpurun_out
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/t_all.log 2>&1 || { tail -60 gpurun_out/t_all.log; exit 1; }
-tail -3 gpurun_out/t_all.log
-timeout -k 10 600 python bench.py --steps 10 --warmup 2 --cpu-seconds 0 2>&1 | tail -1 > gpurun_out/bench_norm.json
+for rep in 1 2; do
+for f in 0 1; do
+echo "== VLMC_RMS_NORM=$f"
+VLMC_RMS_NORM=$f RANK_TIMELINE_ITERS=6 timeout -k 10 300 python tools/rank_timeline.py 1 2>&1 | grep prune_ms | tail -3 | cut -c1-200
+done
+done

@@ -743,11 +743,13 @@ class TowerGraph:
                     for i, (wires, kwires, _t, _l, _n) in enumerate(calls):
                         outs.append(self.mods[i](*[resolve(w) for w in wires], **{k: resolve(w) for k, w in kwires}))
                 g = len(chunk)
+                # per-sample views of every block output: one split per tensor (not one Python slice per tensor and sample)
+                parts = [[(o.split(b0, dim=0) if o.dim() >= 1 and o.shape[0] == g * b0 else None) if isinstance(o, torch.Tensor) else None
+                          for o in self._flat(out)] for out in outs]
                 for t, rec in enumerate(chunk):
                     mine = []
-                    for out in outs:
-                        flat = [(o[t * b0:(t + 1) * b0] if o.dim() >= 1 and o.shape[0] == g * b0 else o) if isinstance(o, torch.Tensor)
-                                else o for o in self._flat(out)]
+                    for out, pp in zip(outs, parts):
+                        flat = [(sp[t] if sp is not None else o) for o, sp in zip(self._flat(out), pp)]
                         mine.append(tuple(flat) if isinstance(out, tuple) else flat if isinstance(out, list) else flat[0])
                     self.ready[rec["j"]] = {"outs": mine, "args": rec["args"], "kwargs": rec["kwargs"], "key": key}
                 graph_stats["tower_batches"] = graph_stats.get("tower_batches", 0) + 1
@@ -1501,7 +1503,7 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                     if so is not None:
                         so.end_forward(True)
                     y = y[0] if tuple_output else y
-                    slices = [y[t * b0:(t + 1) * b0] for t in range(len(chunk))]
+                    slices = list(y.split(b0, dim=0))                   # (one call: 128 Python-level slices were 0.1 ms per block pass)
                     slices[0]._vlmc_stack = (y, key, slices)
                     for t, j in enumerate(chunk):
                         cur_out[j] = slices[t]
