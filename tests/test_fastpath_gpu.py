@@ -73,3 +73,36 @@ def test_both_routes_refuse_the_same_calls(monkeypatch):
             ops.attn_matmul(x.half()[None], w.half().t()[None].float())
         with pytest.raises(RuntimeError):
             ops.linear_fwd(x.cpu().half(), w.cpu().half())               # no CPU fallback on either route
+
+
+def test_sdpa_and_rms_norm_routes_agree(monkeypatch):
+    from vlmc import ops
+    g = torch.Generator(device=DEV).manual_seed(3)
+    qkv = torch.randn(3, 70, 3 * 8 * 64, generator=g, device=DEV).to(torch.bfloat16)
+    q, k, v = (t.reshape(3, 70, 8, 64).transpose(1, 2) for t in qkv.reshape(3, 70, 3, 8 * 64).unbind(2))
+    a, c = _both(monkeypatch, lambda: ops.sdpa(q, k, v))
+    assert a.shape == (3, 8, 70, 64) and torch.equal(a, c) and a.stride() == c.stride()
+    a, c = _both(monkeypatch, lambda: ops.sdpa(q[:, :, :16], k, v, scale=0.2))
+    assert torch.equal(a, c)
+    big = torch.randn(1, 2, 8, 300, 64, generator=g, device=DEV).to(torch.float16)       # more keys than a head may have
+    a, c = _both(monkeypatch, lambda: ops.sdpa(big[0, :, :, :8], big[0], big[0], _try=True))
+    assert a is None and c is None
+    for fn in (lambda: ops.sdpa(q.float(), k.float(), v.float()), lambda: ops.sdpa(q, k, v, scale=-1.0)):
+        for route in (True, False):
+            if not route:
+                monkeypatch.setattr(ops, "_fast", None)
+            with pytest.raises(TypeError):
+                fn()
+            monkeypatch.undo()
+    x = torch.randn(4, 9, 520, generator=g, device=DEV).to(torch.float16)
+    w = (torch.randn(520, generator=g, device=DEV) * 0.2 + 1).to(torch.float16)
+    a, c = _both(monkeypatch, lambda: ops.rms_norm(x, w, 1e-6, 0))
+    assert a.shape == x.shape and torch.equal(a, c)
+    a, c = _both(monkeypatch, lambda: ops.rms_norm(x[:, :, :], w, 1e-5, 1))
+    assert torch.equal(a, c)
+    for route in (True, False):
+        if not route:
+            monkeypatch.setattr(ops, "_fast", None)
+        with pytest.raises(TypeError):
+            ops.rms_norm(x, w.float(), 1e-6, 0)
+        monkeypatch.undo()

@@ -1,5 +1,5 @@
 // Compiled host path for the entry points a calibration replay calls thousands of times: vlmc_linear_fwd,
-// vlmc_linear_fwd_group, vlmc_attn_matmul and vlmc_row_mean (include/vlmc.h).
+// vlmc_linear_fwd_group, vlmc_attn_matmul, vlmc_row_mean, vlmc_sdpa_fwd and vlmc_rms_norm (include/vlmc.h).
 //
 // The replay of the reference's per-sample block forwards (wanda_pruner.py:308-311, :343-346) issues 1 000 - 15 000 of these
 // launches per prune, most of them on a few hundred rows when the calibration text is ragged or the samples are sharded over
@@ -153,6 +153,39 @@ py::object row_mean(const at::Tensor &x, bool keepdim, int64_t stream) {
     return py::cast(out);
 }
 
+// F.scaled_dot_product_attention(q, k, v) on vlmc_sdpa_fwd; None when the kernel does not take the call (vlmc/ops.py: sdpa_plan)
+py::object sdpa(const at::Tensor &q, const at::Tensor &k, const at::Tensor &v, double scale, int64_t stream) {
+    if (q.dim() != 4 || k.dim() != 4 || v.dim() != 4 || dtype_code(q.scalar_type()) < 0 || k.scalar_type() != q.scalar_type() ||
+        v.scalar_type() != q.scalar_type() || !q.is_cuda() || !k.is_cuda() || !v.is_cuda())
+        return py::none();
+    const int64_t B = q.size(0), H = q.size(1), Tq = q.size(2), d = q.size(3), Tk = k.size(2);
+    if (k.size(0) != B || k.size(1) != H || k.size(3) != d || v.size(0) != B || v.size(1) != H || v.size(2) != Tk || v.size(3) != d ||
+        d % 8 != 0 || d > 128 || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || d <= 0)
+        return py::none();
+    if (q.stride(3) != 1 || k.stride(3) != 1 || v.stride(3) != 1 || q.stride(2) < 0 || k.stride(2) < 0 || v.stride(2) < 0) return py::none();
+    if (Tk > vlmc_sdpa_max_keys(d) || !(scale > 0.0) || !(scale < 1e30)) return py::none();
+    at::Tensor out = at::empty({B, Tq, H, d}, q.options());
+    check(vlmc_sdpa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dtype_code(q.scalar_type()), B, H, Tq, Tk, d, q.stride(0), q.stride(1),
+                        q.stride(2), k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1), v.stride(2), Tq * H * d, d, H * d, float(scale),
+                        reinterpret_cast<void *>(stream)));
+    return py::cast(out.transpose(1, 2));
+}
+
+// weight * (x * rsqrt(mean(x.float()^2) + eps)).to(dtype) on vlmc_rms_norm; None when the call is not one it takes
+py::object rms_norm(const at::Tensor &x, const at::Tensor &w, double eps, int64_t rsqrt_mode, int64_t stream) {
+    if (!x.is_cuda() || !w.is_cuda() || dtype_code(x.scalar_type()) < 0 || w.scalar_type() != x.scalar_type() || x.dim() < 1 || w.dim() != 1 ||
+        x.size(-1) != w.size(0) || w.size(0) == 0 || !w.is_contiguous())
+        return py::none();
+    const int64_t n = w.size(0);
+    at::Tensor x2 = x.reshape({-1, n});
+    if (x2.stride(1) != 1 || (x2.size(0) > 1 && x2.stride(0) < n)) x2 = x2.contiguous();
+    const int64_t rows = x2.size(0);
+    at::Tensor out = at::empty({rows, n}, x.options());
+    check(vlmc_rms_norm(x2.data_ptr(), dtype_code(x.scalar_type()), rows, n, rows > 1 ? x2.stride(0) : n, w.data_ptr(), float(eps), int(rsqrt_mode),
+                        out.data_ptr(), n, reinterpret_cast<void *>(stream)));
+    return py::cast(out.reshape(x.sizes()));
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -161,5 +194,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("linear_fwd_group", &linear_fwd_group, py::arg("x"), py::arg("weights"), py::arg("biases"), py::arg("stream"));
     m.def("attn_matmul", &attn_matmul, py::arg("a"), py::arg("b"), py::arg("stream"));
     m.def("row_mean", &row_mean, py::arg("x"), py::arg("keepdim"), py::arg("stream"));
+    m.def("sdpa", &sdpa, py::arg("q"), py::arg("k"), py::arg("v"), py::arg("scale"), py::arg("stream"));
+    m.def("rms_norm", &rms_norm, py::arg("x"), py::arg("weight"), py::arg("eps"), py::arg("rsqrt_mode"), py::arg("stream"));
     m.def("abi_version", []() { return vlmc_abi_version(); });
 }

@@ -250,6 +250,11 @@ def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float, rsqrt_mode: int 
     """`weight * (x * rsqrt(x.float().pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype)` -- T5LayerNorm / LlamaRMSNorm, op for op --
     in one launch (include/vlmc.h: vlmc_rms_norm); the mean is `row_mean`'s.  16-bit CUDA x [.., n] and weight [n] of one dtype."""
     _need_gpu(x, weight)
+    if _fast is not None and hasattr(_fast, "rms_norm"):
+        out = _fast.rms_norm(x, weight, float(eps), int(rsqrt_mode), _stream())
+        if out is None:
+            raise TypeError("vlmc.rms_norm: fp16 / bf16 x [.., n] and a contiguous weight [n] of the same dtype expected")
+        return out
     n = x.shape[-1]
     if x.dtype not in _16BIT or weight.dtype != x.dtype or weight.shape != (n,) or not weight.is_contiguous() or n == 0:
         raise TypeError("vlmc.rms_norm: fp16 / bf16 x [.., n] and a contiguous weight [n] of the same dtype expected")
@@ -291,6 +296,12 @@ def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale=None, _try: bo
     """`F.scaled_dot_product_attention(q, k, v)` (no mask, no dropout, not causal) on the fused, batch-invariant MFMA kernel
     (include/vlmc.h: vlmc_sdpa_fwd).  The result is a [B, H, Tq, d] view of a [B, Tq, H, d] buffer: the `transpose(1, 2)
     .reshape(B, Tq, H * d)` that follows in every model file is then free.  `_try`: None for a call the kernel does not take."""
+    if _fast is not None and q.is_cuda and hasattr(_fast, "sdpa"):
+        out = _fast.sdpa(q, k, v, float(q.shape[-1] ** -0.5 if scale is None else scale), _stream())
+        if out is None and not _try:
+            raise TypeError("vlmc.sdpa: [B, H, T, d] fp16 / bf16 CUDA tensors of one dtype expected, d a multiple of 8 up to 128, "
+                            "unit stride along d, at most vlmc_sdpa_max_keys(d) keys, a positive scale")
+        return out
     plan = sdpa_plan(q, k, v) if (scale is None or 0.0 < float(scale) < float("inf")) else None
     if plan is None:
         if _try:
