@@ -2,9 +2,9 @@ set -e
 cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_fastpath_gpu.py tests/test_sdpa_gpu.py tests/test_rms_norm_gpu.py -m gpu -x -q > gpurun_out/t_fast.log 2>&1 || { tail -60 gpurun_out/t_fast.log; exit 1; }
-tail -3 gpurun_out/t_fast.log
-for f in 0 1; do
-echo "== VLMC_FAST=$f"
-VLMC_FAST=$f RANK_TIMELINE_ITERS=6 timeout -k 10 300 python tools/rank_timeline.py 8 2>&1 | grep prune_ms | tail -3 | cut -c1-200
+timeout -k 10 600 python -m pytest tests/test_sparse_lora_gpu.py tests/test_ressa.py -m gpu -x -q > gpurun_out/t_lora.log 2>&1 || { tail -40 gpurun_out/t_lora.log; exit 1; }
+tail -2 gpurun_out/t_lora.log
+for t in 1 0 2 4 8; do
+echo "== VLMC_LORA_TPW=$t"
+VLMC_LORA_TPW=$t timeout -k 10 300 python tools/bench_methods.py --only lora 2>&1 | grep -v amdgpu | grep -i "lora\|weff\|eff" | head -8
 done

@@ -389,6 +389,30 @@ __global__ void lora_grad_reduce_kernel(const float *__restrict__ part, int slab
     out[i] = round_code(v, ab_code);
 }
 
+// both reductions of a gradient pass in ONE launch (two launches of ~5 us each per layer were 2 ms of a 160 ms RESSA step)
+__global__ void lora_grad_reduce2_kernel(const float *__restrict__ part_a, int slabs_a, int64_t n_a, float *__restrict__ out_a,
+                                         const float *__restrict__ part_b, int slabs_b, int64_t n_b, float *__restrict__ out_b,
+                                         int ab_code, unsigned blocks_a) {
+    const bool is_a = blockIdx.x < blocks_a;
+    const float *part = is_a ? part_a : part_b;
+    const int slabs = is_a ? slabs_a : slabs_b;
+    const int64_t n = is_a ? n_a : n_b;
+    float *out = is_a ? out_a : out_b;
+    const int64_t i = int64_t(is_a ? blockIdx.x : blockIdx.x - blocks_a) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = 0.f;
+    int s = 0;
+    for (; s + 8 <= slabs; s += 8) {                 // 8 loads in flight, summed in slab order (as lora_grad_reduce_kernel)
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = part[int64_t(s + u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v = ieee_add(v, t[u]);
+    }
+    for (; s < slabs; ++s) v = ieee_add(v, part[int64_t(s) * n + i]);
+    out[i] = round_code(v, ab_code);
+}
+
 // Row splits of the gradient pass: strips x splits workgroups, ALL resident at once -- two per CU (56 KB of LDS each).  (The
 // first version aimed at ">= 768 = 3 per CU": 512 ran, the other 256 made a second, half-empty round -- 4096 x 4096: 68 -> 54 us,
 // 11008 x 4096: 134 -> 101 us with one full round.)
@@ -456,6 +480,14 @@ static int grad_typed(const void *G, int64_t out_f, int64_t in_f, int64_t ldg, c
         default: VLMC_GRAD(4); break;
     }
 #undef VLMC_GRAD
+    if (dA && dB) {
+        const int64_t na = int64_t(r) * in_f, nb = out_f * int64_t(r);
+        const unsigned ba = unsigned((na + 255) / 256), bb = unsigned((nb + 255) / 256);
+        hipLaunchKernelGGL(lora_grad_reduce2_kernel, dim3(ba + bb), dim3(256), 0, st, part_a, int(splits), na, dA, part_b, int(strips), nb, dB,
+                           ab_code, ba);
+        VLMC_HIP_CHECK_LAUNCH("vlmc_lora_grad");
+        return VLMC_OK;
+    }
     if (dA) {
         const int64_t n = int64_t(r) * in_f;
         hipLaunchKernelGGL(lora_grad_reduce_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, part_a, int(splits), n,
