@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLMC_ABI_VERSION 10
+#define VLMC_ABI_VERSION 11
 
 #define VLMC_OK 0
 #define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
@@ -222,7 +222,7 @@ int vlmc_attn_matmul(const void *A, const void *B, void *C, int dtype, int64_t b
                      int64_t sb_n, int64_t sc_b0, int64_t sc_b1, int64_t sc_m, void *stream);
 
 /* ---- fused attention of the calibration forward (MFMA) --------------------------------------------
- * Replaces `F.scaled_dot_product_attention(q, k, v)` -- no mask, no dropout, not causal -- inside a replayed block: the
+ * Replaces `F.scaled_dot_product_attention(q, k, v[, is_causal=True])` -- no mask, no dropout -- inside a replayed block: the
  * fused form of the reference models' `softmax(q @ k^T * scale) @ v` (eva_vit.py:129-168; modeling_t5.py:520-640 without
  * position bias), for 16-bit operands of one dtype:
  *     O[b, h, q, :] = sum_k softmax_k(scale * Q[b, h, q, :] . K[b, h, k, :]) V[b, h, k, :]
@@ -231,14 +231,15 @@ int vlmc_attn_matmul(const void *A, const void *B, void *C, int dtype, int64_t b
  * their ELEMENT strides (batch, head, token; the head_dim stride is 1): `qkv.reshape(B, T, 3, H, d).unbind(2)` views and
  * `[B, T, H, d]` outputs need no copy.  head_dim: a multiple of 8, at most 128; keys per head: at most
  * vlmc_sdpa_max_keys(head_dim) (256; 288 for 65 <= head_dim <= 96) -- a head's K and V live in LDS for the whole head;
- * scale: finite and positive.
+ * scale: finite and positive; causal = 1: key j counts for query i iff j <= i (torch's is_causal: aligned to the top left), the
+ * self-attention of decoder-only towers (modeling_llama.py).
  * Batch-invariant like vlmc_linear_fwd: an output row depends on its own query row and its head's K and V only, through a
  * fixed order of operations -- a sample's outputs have the same bits alone, in a group of 128, or on another GPU.   */
 int vlmc_sdpa_max_keys(int64_t head_dim);
 int vlmc_sdpa_fwd(const void *Q, const void *K, const void *V, void *O, int dtype, int64_t batch, int64_t heads, int64_t Tq,
                   int64_t Tk, int64_t head_dim, int64_t sq_b, int64_t sq_h, int64_t sq_t, int64_t sk_b, int64_t sk_h,
                   int64_t sk_t, int64_t sv_b, int64_t sv_h, int64_t sv_t, int64_t so_b, int64_t so_h, int64_t so_t,
-                  float scale, void *stream);
+                  float scale, int causal, void *stream);
 
 /* ---- batch-invariant mean over the last dimension (the norms of a replayed block) -----------------
  * Replaces `x.mean(-1, keepdim=True)` on the fp32 squares inside the language models' norms --

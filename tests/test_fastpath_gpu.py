@@ -84,6 +84,8 @@ def test_sdpa_and_rms_norm_routes_agree(monkeypatch):
     assert a.shape == (3, 8, 70, 64) and torch.equal(a, c) and a.stride() == c.stride()
     a, c = _both(monkeypatch, lambda: ops.sdpa(q[:, :, :16], k, v, scale=0.2))
     assert torch.equal(a, c)
+    a, c = _both(monkeypatch, lambda: ops.sdpa(q, k, v, causal=True))
+    assert torch.equal(a, c) and not torch.equal(a, ops.sdpa(q, k, v))
     big = torch.randn(1, 2, 8, 300, 64, generator=g, device=DEV).to(torch.float16)       # more keys than a head may have
     a, c = _both(monkeypatch, lambda: ops.sdpa(big[0, :, :, :8], big[0], big[0], _try=True))
     assert a is None and c is None

@@ -97,10 +97,11 @@ def test_calls_the_kernel_does_not_take_are_refused_or_left_to_torch(monkeypatch
     s0 = dict(forward.stats)
     with torch.no_grad(), forward.invariant_matmuls():
         a = F.scaled_dot_product_attention(q, k, v)
-        b = F.scaled_dot_product_attention(q, k, v, is_causal=True)              # torch's
-        c = F.scaled_dot_product_attention(q, k, v, attn_mask=torch.zeros(20, 20, device=DEV, dtype=q.dtype))
-    assert forward.stats["sdpa_kernel"] == s0["sdpa_kernel"] + 1
-    assert torch.equal(a, ops.sdpa(q, k, v))
+        b = F.scaled_dot_product_attention(q, k, v, is_causal=True)              # the kernel's causal form
+        c = F.scaled_dot_product_attention(q, k, v, attn_mask=torch.zeros(20, 20, device=DEV, dtype=q.dtype))    # torch's
+        d = F.scaled_dot_product_attention(q, k, v, dropout_p=0.1)              # torch's
+    assert forward.stats["sdpa_kernel"] == s0["sdpa_kernel"] + 2
+    assert torch.equal(a, ops.sdpa(q, k, v)) and torch.equal(b, ops.sdpa(q, k, v, causal=True)) and d.shape == a.shape
     assert b.shape == a.shape and c.shape == a.shape
     assert F.scaled_dot_product_attention.__module__ != forward.__name__        # the patch is gone
 
@@ -138,3 +139,25 @@ torch.save(outs, sys.argv[1])
     q, k, v = (buf[i, 4:4 + B * H * T * d].view(B, H, T, d) for i in range(3))
     assert k.data_ptr() % 16 != 0
     assert torch.equal(ops.sdpa(q, k, v), ops.sdpa(q.clone(), k.clone(), v.clone()))
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,d,dtype", [(3, 32, 96, 96, 128, torch.float16), (2, 4, 50, 50, 64, torch.bfloat16), (2, 16, 257, 257, 88, torch.float16),
+                                               (2, 3, 16, 16, 32, torch.float16), (1, 2, 40, 100, 64, torch.bfloat16), (1, 2, 130, 70, 96, torch.float16)])
+def test_causal_attention_matches_the_masked_fp32_form(B, H, Tq, Tk, d, dtype):
+    """is_causal=True (the self-attention of decoder-only towers, modeling_llama.py): key j counts for query i iff j <= i, the
+    mask aligned to the top left as torch's is, also when Tq != Tk."""
+    from vlmc import ops
+    q, k, v = _qkv(B, H, Tq, Tk, d, dtype, seed=Tq + 3 * Tk)
+    out = ops.sdpa(q, k, v, causal=True)
+    s = (q.float() @ k.float().transpose(-2, -1)) * d ** -0.5
+    keep = torch.ones(Tq, Tk, dtype=torch.bool, device=DEV).tril()
+    p = torch.softmax(s.masked_fill(~keep, float("-inf")), dim=-1).to(dtype).float()
+    want = p @ v.float()
+    eps = 2.0 ** -10 if dtype is torch.float16 else 2.0 ** -7
+    err = (out.float() - want).abs()
+    bound = eps * (want.abs() + v.float().abs().amax(dim=2, keepdim=True)) + 1e-6
+    assert bool((err <= bound).all()), float((err / bound).max())
+    lib = F.scaled_dot_product_attention(q, k, v, is_causal=True).float()
+    assert float((out.float() - lib).abs().max()) <= 8 * eps * float(v.float().abs().max())
+    # batch-invariant like the plain form
+    assert torch.equal(ops.sdpa(q[1:2] if B > 1 else q, k[1:2] if B > 1 else k, v[1:2] if B > 1 else v, causal=True)[0], out[1 if B > 1 else 0])

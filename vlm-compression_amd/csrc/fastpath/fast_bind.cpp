@@ -154,7 +154,7 @@ py::object row_mean(const at::Tensor &x, bool keepdim, int64_t stream) {
 }
 
 // F.scaled_dot_product_attention(q, k, v) on vlmc_sdpa_fwd; None when the kernel does not take the call (vlmc/ops.py: sdpa_plan)
-py::object sdpa(const at::Tensor &q, const at::Tensor &k, const at::Tensor &v, double scale, int64_t stream) {
+py::object sdpa(const at::Tensor &q, const at::Tensor &k, const at::Tensor &v, double scale, bool causal, int64_t stream) {
     if (q.dim() != 4 || k.dim() != 4 || v.dim() != 4 || dtype_code(q.scalar_type()) < 0 || k.scalar_type() != q.scalar_type() ||
         v.scalar_type() != q.scalar_type() || !q.is_cuda() || !k.is_cuda() || !v.is_cuda())
         return py::none();
@@ -167,7 +167,7 @@ py::object sdpa(const at::Tensor &q, const at::Tensor &k, const at::Tensor &v, d
     at::Tensor out = at::empty({B, Tq, H, d}, q.options());
     check(vlmc_sdpa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dtype_code(q.scalar_type()), B, H, Tq, Tk, d, q.stride(0), q.stride(1),
                         q.stride(2), k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1), v.stride(2), Tq * H * d, d, H * d, float(scale),
-                        reinterpret_cast<void *>(stream)));
+                        causal ? 1 : 0, reinterpret_cast<void *>(stream)));
     return py::cast(out.transpose(1, 2));
 }
 
@@ -194,7 +194,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("linear_fwd_group", &linear_fwd_group, py::arg("x"), py::arg("weights"), py::arg("biases"), py::arg("stream"));
     m.def("attn_matmul", &attn_matmul, py::arg("a"), py::arg("b"), py::arg("stream"));
     m.def("row_mean", &row_mean, py::arg("x"), py::arg("keepdim"), py::arg("stream"));
-    m.def("sdpa", &sdpa, py::arg("q"), py::arg("k"), py::arg("v"), py::arg("scale"), py::arg("stream"));
+    m.def("sdpa", &sdpa, py::arg("q"), py::arg("k"), py::arg("v"), py::arg("scale"), py::arg("causal"), py::arg("stream"));
     m.def("rms_norm", &rms_norm, py::arg("x"), py::arg("weight"), py::arg("eps"), py::arg("rsqrt_mode"), py::arg("stream"));
     m.def("abi_version", []() { return vlmc_abi_version(); });
 }

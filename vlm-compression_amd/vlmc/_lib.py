@@ -68,7 +68,7 @@ SIGNATURES = {
     "vlmc_row_mean": (_i, [_p, _i64, _i64, _i64, _p, _p]),
     "vlmc_rms_norm": (_i, [_p, _i, _i64, _i64, _i64, _p, _c.c_float, _i, _p, _i64, _p]),
     "vlmc_sdpa_max_keys": (_i, [_i64]),
-    "vlmc_sdpa_fwd": (_i, [_p, _p, _p, _p, _i] + [_i64] * 17 + [_c.c_float, _p]),
+    "vlmc_sdpa_fwd": (_i, [_p, _p, _p, _p, _i] + [_i64] * 17 + [_c.c_float, _i, _p]),
     "vlmc_hessian_workspace": (_sz, [_i, _i64, _i64]),
     "vlmc_hessian_accum": (_i, [_p, _i, _i64, _i64, _i64, _p, _i64, _c.c_float, _c.c_float, _p, _sz, _p]),
     "vlmc_symmetrize_lower": (_i, [_p, _i64, _i64, _p]),

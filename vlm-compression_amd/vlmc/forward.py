@@ -231,14 +231,14 @@ def _make_matmul(orig):
 
 
 def _make_sdpa(orig):
-    """`F.scaled_dot_product_attention(q, k, v)` without mask, dropout or causality on `vlmc_sdpa_fwd` (fused, batch-invariant,
-    no [T, T] scores in HBM); every other call goes to the original."""
+    """`F.scaled_dot_product_attention(q, k, v[, is_causal=True])` without mask or dropout on `vlmc_sdpa_fwd` (fused,
+    batch-invariant, no [T, T] scores in HBM); every other call goes to the original."""
     Tensor = torch.Tensor
 
     def sdpa(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, scale=None, **kw):
-        if attn_mask is None and dropout_p == 0.0 and not is_causal and not kw and type(q) is Tensor and \
+        if attn_mask is None and dropout_p == 0.0 and type(is_causal) is bool and not kw and type(q) is Tensor and \
                 not torch.is_grad_enabled() and not (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() != q.dtype):
-            out = ops.sdpa(q, k, v, scale, True)
+            out = ops.sdpa(q, k, v, scale, True, is_causal)
             if out is not None:
                 stats["sdpa_kernel"] += 1
                 return out

@@ -292,12 +292,12 @@ def sdpa_plan(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor):
     return B, H, Tq, Tk, d
 
 
-def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale=None, _try: bool = False):
-    """`F.scaled_dot_product_attention(q, k, v)` (no mask, no dropout, not causal) on the fused, batch-invariant MFMA kernel
+def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale=None, _try: bool = False, causal: bool = False):
+    """`F.scaled_dot_product_attention(q, k, v[, is_causal=True])` (no mask, no dropout) on the fused, batch-invariant MFMA kernel
     (include/vlmc.h: vlmc_sdpa_fwd).  The result is a [B, H, Tq, d] view of a [B, Tq, H, d] buffer: the `transpose(1, 2)
     .reshape(B, Tq, H * d)` that follows in every model file is then free.  `_try`: None for a call the kernel does not take."""
     if _fast is not None and q.is_cuda and hasattr(_fast, "sdpa"):
-        out = _fast.sdpa(q, k, v, float(q.shape[-1] ** -0.5 if scale is None else scale), _stream())
+        out = _fast.sdpa(q, k, v, float(q.shape[-1] ** -0.5 if scale is None else scale), bool(causal), _stream())
         if out is None and not _try:
             raise TypeError("vlmc.sdpa: [B, H, T, d] fp16 / bf16 CUDA tensors of one dtype expected, d a multiple of 8 up to 128, "
                             "unit stride along d, at most vlmc_sdpa_max_keys(d) keys, a positive scale")
@@ -314,7 +314,7 @@ def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale=None, _try: bo
     sq, sk, sv = q.stride(), k.stride(), v.stride()
     _lib.check(_lib.load().vlmc_sdpa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _DT[q.dtype], B, H, Tq, Tk, d,
                                          sq[0], sq[1], sq[2], sk[0], sk[1], sk[2], sv[0], sv[1], sv[2], Tq * H * d, d, H * d,
-                                         float(d ** -0.5 if scale is None else scale), _stream()))
+                                         float(d ** -0.5 if scale is None else scale), int(bool(causal)), _stream()))
     return out.transpose(1, 2)
 
 
