@@ -636,37 +636,57 @@ def test_predicted_tower_pass_gives_the_aborted_and_repeated_forwards_result(rag
     b1 = dict(cal.graph_stats)
     got = H.run_16bit_toy("wanda", "cuda:0", n_samples=8, ragged=ragged)
     assert cal.graph_stats.get("tower_predicted", 0) > b1.get("tower_predicted", 0), "no tower ran from remembered arguments"
+    assert cal.graph_stats.get("batched_traces", 0) > b1.get("batched_traces", 0), "no wiring was traced while the tower ran stacked"
     assert cal.graph_stats.get("later_failed", 0) == b1.get("later_failed", 0)
     assert cal.graph_stats["fallbacks"] == b1["fallbacks"]
     assert want.keys() == got.keys()
     for k in want:
         assert torch.equal(want[k], got[k]), k
+    # the forward that traces the wiring running the tower for its one sample (rounds 2-4's trace): the same again
+    monkeypatch.setenv("VLMC_TOWER_BATCHED_TRACE", "0")
+    b2 = dict(cal.graph_stats)
+    eager = H.run_16bit_toy("wanda", "cuda:0", n_samples=8, ragged=ragged)
+    assert cal.graph_stats.get("batched_traces", 0) == b2.get("batched_traces", 0)
+    for k in want:
+        assert torch.equal(want[k], eager[k]), k
 
 
-def test_a_wrong_prediction_is_noticed_and_the_phase_runs_again(monkeypatch):
+@pytest.mark.parametrize("batched_trace", ["1", "0"])
+def test_a_wrong_prediction_is_noticed_and_the_phase_runs_again(batched_trace, monkeypatch):
     """The remembered block-0 arguments of one sample are tampered with between the phases: the stacked pass ran on the wrong
     input, the end-of-phase comparison says so (`later_failed`), the phase is repeated without memos or predictions, and the
-    pruned model is the one the plain route gives."""
+    pruned model is the one the plain route gives.  Both ways the stacked pass can start: from the forward that traces the wiring
+    (`_begin_batched_trace`) and, with an eager trace, from `run_predicted`."""
     import toy_models
     from lavis.compression.pruners import calibration as cal
     monkeypatch.setattr(toy_models.ToyAttention, "use_sdpa", True)
     monkeypatch.setenv("VLMC_LINEAR_FWD", "1")
     monkeypatch.setenv("VLMC_LATER_EQUAL", "1")
+    monkeypatch.setenv("VLMC_TOWER_BATCHED_TRACE", batched_trace)
     monkeypatch.setenv("VLMC_TOWER_PREDICT", "0")
     want = H.run_16bit_toy("wanda", "cuda:0", n_samples=8)
     monkeypatch.setenv("VLMC_TOWER_PREDICT", "1")
-    real = cal.TowerGraph.run_predicted
     tampered = []
 
+    def tamper(tg):
+        j = max(tg.predicted)
+        args, kwargs, ctx, versions = tg.predicted[j]
+        fake = args[0].clone().add_(1)
+        tg.predicted[j] = ((fake,) + tuple(args[1:]), kwargs, ctx, [(fake, fake._version)] + versions[1:])
+        tampered.append(j)
+    real_run, real_begin = cal.TowerGraph.run_predicted, cal.TowerGraph._begin_batched_trace
+
     def run_predicted(self, samples):
-        if self.predicted and not self.memo_serves and not tampered and any(w for w in self.wirings.values()):
-            j = max(self.predicted)
-            args, kwargs, ctx, versions = self.predicted[j]
-            fake = args[0].clone().add_(1)
-            self.predicted[j] = ((fake,) + tuple(args[1:]), kwargs, ctx, [(fake, fake._version)] + versions[1:])
-            tampered.append(j)
-        return real(self, samples)
+        if batched_trace == "0" and self.predicted and not self.memo_serves and not tampered and any(w for w in self.wirings.values()):
+            tamper(self)
+        return real_run(self, samples)
+
+    def begin(self, key, args, kwargs, ext):
+        if batched_trace == "1" and self.predicted and not self.memo_serves and not tampered:
+            tamper(self)
+        return real_begin(self, key, args, kwargs, ext)
     monkeypatch.setattr(cal.TowerGraph, "run_predicted", run_predicted)
+    monkeypatch.setattr(cal.TowerGraph, "_begin_batched_trace", begin)
     before = cal.graph_stats.get("later_failed", 0)
     got = H.run_16bit_toy("wanda", "cuda:0", n_samples=8)
     assert tampered and cal.graph_stats.get("later_failed", 0) == before + 1

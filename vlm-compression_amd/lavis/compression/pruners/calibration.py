@@ -419,6 +419,7 @@ class TowerGraph:
         # block-0 calls of this tower as its OWN capture phase saw them, by sample (capture_block_inputs): what the model
         # will hand block 0 again in the next phase, if nothing upstream changed -- run_predicted()
         self.predicted, self.memo_serves, self.path = {}, False, None
+        self.btrace = None                    # a trace that runs the tower STACKED for a whole group of remembered calls (_begin_batched_trace)
         self.linears = [m for mod in self.mods for m in find_layers(mod).values()]
         self._linears_ok = {}                     # autocast state -> every linear of the tower can run on the invariant kernel
         self.off = False
@@ -460,7 +461,7 @@ class TowerGraph:
             self.live = self.trace = None
             return False, None
         if index == 0:
-            self.live = self.trace = None
+            self.live = self.trace = self.btrace = None
             key = self._key0(args, kwargs)
             wiring = self.wirings.get(key) if key is not None else False
             if wiring is False or key is None:
@@ -473,6 +474,9 @@ class TowerGraph:
                         known[id(v)] = (v, ("ext", len(ext)))
                         ext.append(v)
                 self.trace = {"key": key, "known": known, "calls": [], "next": 0}
+                self.btrace = self._begin_batched_trace(key, args, kwargs, ext)
+                if self.btrace is not None:
+                    return self._batched_step(0, args, kwargs)
                 return False, None
             if _CAPTURE_SAMPLE is not None and tower_batch_enabled():
                 r = self.ready.pop(_CAPTURE_SAMPLE, None)
@@ -498,7 +502,107 @@ class TowerGraph:
             return self._replay(plan, args, kwargs)
         if self.live is not None:
             return self._serve(index, args, kwargs)
+        if self.btrace is not None and self.trace is not None:
+            return self._batched_step(index, args, kwargs)
         return False, None
+
+    # -- tracing the wiring WHILE the tower runs stacked ---------------------------------------------------------------------
+    # The forward that traces a tower's wiring used to run the tower eagerly for its one sample (24 T5 blocks: 7-9 ms of host
+    # time, the GPU idle) and the stacked pass for everybody came afterwards.  With the block-0 arguments of the other samples
+    # remembered (run_predicted), the tracing forward can BE the stacked pass: every block it calls is run once for the whole
+    # group -- its arguments resolved through the wiring learnt so far to the stacked outputs of earlier blocks / the stacked
+    # remembered arguments -- and the forward is handed its own slices.  When its last block returns, the wiring is known and
+    # every sample of the group has its outputs.  Anything the wiring cannot express (an argument that is neither an earlier
+    # output nor an outside tensor nor a plain value, a handed-out tensor written to, blocks out of order) ends the batched
+    # trace: from that block on the forward runs eagerly, as a plain trace does, and nothing is kept for the others.
+    def _begin_batched_trace(self, key, args, kwargs, ext):
+        j = _CAPTURE_SAMPLE
+        if self.NEED != 1 or j is None or not (tower_batch_enabled() and tower_predict_enabled()) or self.memo_serves or \
+                os.environ.get("VLMC_TOWER_BATCHED_TRACE", "1") == "0" or j not in self.predicted or not self._batchable(args, kwargs):
+            return None
+        group = []
+        for jj in sorted(self.predicted):
+            pa, pk, ctx, versions = self.predicted[jj]
+            if jj in self.ready or any(t._version != v for t, v in versions) or ctx != TowerMemo.context():
+                continue
+            if self._key0(pa, pk, ctx) == key:
+                group.append({"j": jj, "key": key, "args": pa, "kwargs": pk, "ctx": ctx})
+        pos = next((i for i, r in enumerate(group) if r["j"] == j), None)
+        if pos is None or len(group) < 2:
+            return None
+        x0 = args[0]
+        rows = max(1, x0.numel() // max(1, x0.shape[-1]))
+        per = max(1, min(replay_group_size(), REPLAY_TOKEN_BUDGET // rows))
+        c0 = (pos // per) * per
+        chunk = group[c0:c0 + per]
+        if len(chunk) < 2 or not self._same_inputs(chunk[pos - c0], args, kwargs):       # (bits: checked at the end of the phase)
+            return None
+        exts = [self._ext(r["args"], r["kwargs"]) for r in chunk]
+        if any(len(e) != len(ext) for e in exts):
+            return None
+        try:
+            stacked = [torch.cat([e[k] for e in exts], dim=0) for k in range(len(ext))]
+        except Exception:
+            return None
+        return {"chunk": chunk, "t": pos - c0, "b0": x0.shape[0], "g": len(chunk), "ext": stacked, "outs": [],
+                "ver": {id(v): v._version for v in ext}}
+
+    def _batched_step(self, index, args, kwargs):
+        tr, bt = self.trace, self.btrace
+
+        def give_up(forget_wiring):
+            if forget_wiring:
+                self.wirings[tr["key"]] = False
+            self.trace = self.btrace = None
+            return False, None
+        if index != tr["next"]:
+            return give_up(False)
+        vals = list(args) + list(kwargs.values())
+        if any(isinstance(v, torch.Tensor) and id(v) in bt["ver"] and v._version != bt["ver"][id(v)] for v in vals):
+            return give_up(True)                                          # the model wrote into a tensor it was handed
+        wires = [self._wire(v, tr["known"]) for v in args]
+        kwires = {k: self._wire(v, tr["known"]) for k, v in kwargs.items()}
+        if any(w is None for w in wires) or any(w is None for w in kwires.values()):
+            return give_up(True)
+
+        def resolve(w):
+            if w[0] == "ext":
+                return bt["ext"][w[1]]
+            if w[0] == "out":
+                return self._flat(bt["outs"][w[1]])[w[2]]
+            return w[1]
+        out = self.mods[index](*[resolve(w) for w in wires], **{k: resolve(w) for k, w in kwires.items()})
+        flat = self._flat(out)
+        if not all(o is None or isinstance(o, torch.Tensor) for o in flat):
+            return give_up(True)
+        b0, g, t = bt["b0"], bt["g"], bt["t"]
+        parts = [(o.split(b0, dim=0) if isinstance(o, torch.Tensor) and o.dim() >= 1 and o.shape[0] == g * b0 else None) for o in flat]
+        mine = [(sp[t] if sp is not None else o) for o, sp in zip(flat, parts)]
+        for pos, o in enumerate(mine):
+            if isinstance(o, torch.Tensor):
+                tr["known"][id(o)] = (o, ("out", index, pos))
+                bt["ver"][id(o)] = o._version
+        tr["calls"].append((tuple(wires), tuple(sorted(kwires.items())), isinstance(out, tuple), isinstance(out, list),
+                            tuple(o is None for o in flat)))
+        tr["next"] = index + 1
+        bt["outs"].append(out)
+        bt.setdefault("parts", []).append(parts)
+        if index == self.n - 1:
+            self._finish_trace(tr)
+            if self.wirings.get(tr["key"]):                               # every other sample of the group has its outputs now
+                for t2, rec in enumerate(bt["chunk"]):
+                    if t2 == t:
+                        continue
+                    outs2 = []
+                    for o_, pp in zip(bt["outs"], bt["parts"]):
+                        fl = [(sp[t2] if sp is not None else o) for o, sp in zip(self._flat(o_), pp)]
+                        outs2.append(tuple(fl) if isinstance(o_, tuple) else fl if isinstance(o_, list) else fl[0])
+                    self.ready[rec["j"]] = {"outs": outs2, "args": rec["args"], "kwargs": rec["kwargs"], "key": tr["key"]}
+                graph_stats["tower_predicted"] = graph_stats.get("tower_predicted", 0) + len(bt["chunk"]) - 1
+                graph_stats["tower_batches"] = graph_stats.get("tower_batches", 0) + 1
+                graph_stats["batched_traces"] = graph_stats.get("batched_traces", 0) + 1
+            self.trace = self.btrace = None
+        return True, (tuple(mine) if isinstance(out, tuple) else mine if isinstance(out, list) else mine[0])
 
     def leave(self, index, args, kwargs, out):
         tr = self.trace
@@ -1110,7 +1214,7 @@ def _capture_once(model, batches, module_to_process, forward_to_cache, lora_mode
         for blocks, i, orig in undo:
             tg = blocks[i].__dict__.get("_tower")
             if tg is not None:
-                tg[0].deferred, tg[0].ready, tg[0].live, tg[0].trace = [], {}, None, None
+                tg[0].deferred, tg[0].ready, tg[0].live, tg[0].trace, tg[0].btrace = [], {}, None, None, None
             blocks[i].__dict__["_memo"] = None
             blocks[i].__dict__["_tower"] = None
             blocks[i] = orig

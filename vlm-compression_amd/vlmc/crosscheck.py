@@ -31,6 +31,7 @@ ROUTES = {
     "replay_eager": ({"VLMC_GRAPH_REPLAY": "0"}, "no HIP graphs anywhere in the replay"),
     "tail_full": ({"VLMC_SKIP_DEAD_TAIL": "0"}, "statistics pass runs every block to its end"),
     "compare_at_once": ({"VLMC_LATER_EQUAL": "0"}, "remembered tower inputs compared at once"),
+    "tower_eager_trace": ({"VLMC_TOWER_BATCHED_TRACE": "0"}, "the forward that traces a finished tower's wiring runs the tower for its one sample"),
     "tower_two_traces": ({"VLMC_TOWER_TRACES": "2"}, "a finished tower's wiring is used after two identical traces"),
     "tower_no_prediction": ({"VLMC_TOWER_PREDICT": "0"}, "finished towers learn every sample's block-0 arguments from an aborted forward"),
     "tower_rerun": ({"VLMC_TOWER_MEMO": "0", "VLMC_TOWER_GRAPH": "0"}, "finished towers are run again in every capture phase"),
