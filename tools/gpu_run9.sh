@@ -1,9 +1,7 @@
-set -e
 cd /root/repo
 export TMPDIR=/tmp
-mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_wanda_gpu.py tests/test_pruner_gpu.py tests/test_multirank_gpu.py tests/test_batch_gpu.py -m gpu -x -q > gpurun_out/t_w.log 2>&1 || { tail -60 gpurun_out/t_w.log; exit 1; }
-tail -2 gpurun_out/t_w.log
-for i in 1 2; do
-RANK_TIMELINE_ITERS=7 timeout -k 10 300 python tools/rank_timeline.py 8 2>&1 | grep prune_ms | tail -2 | cut -c1-560
-done
+mkdir -p gpurun_out/r04c
+python bench.py --steps 20 --warmup 5 > gpurun_out/r04c/bench_line_steps20.json 2> gpurun_out/r04c/bench_line_steps20.err
+python bench.py --calib-local 16 --cpu-seconds 0 --kernel-pass 0 --reference-ops 0 > gpurun_out/r04c/bench_line_floor16.json 2> gpurun_out/r04c/bench_line_floor16.err
+python tools/tower_times.py 1 2 4 8 2>&1 | grep -v amdgpu | grep -E "^world|^   [vt]" > gpurun_out/r04c/tower_times.txt
+tail -2 gpurun_out/r04c/bench_line_steps20.err
