@@ -125,3 +125,25 @@ def test_whole_prune_is_bit_identical_with_and_without_the_fused_norm(monkeypatc
     assert outs[0].keys() == outs[1].keys()
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_rms_norm_entry_point_on_odd_shapes_and_strided_rows():
+    """Widths that are not multiples of 4 or 256, one row, 8192 columns, rows that are slices of a wider buffer: against the op
+    sequence written with torch ops (the mean through vlmc_row_mean, as during a replay)."""
+    from vlmc import forward, ops
+
+    def ref(x, w, eps):
+        with forward.invariant_matmuls():
+            v = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
+            return w * (x * torch.rsqrt(v + eps)).to(w.dtype)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    for shape, dt, eps in [((7, 1001), torch.float16, 1e-6), ((1, 8192), torch.bfloat16, 1e-5), ((3, 5, 130), torch.float16, 1e-6),
+                           ((2, 2050), torch.bfloat16, 1e-6), ((4, 6), torch.float16, 1e-3)]:
+        x = (torch.randn(*shape, generator=g, device=DEV) * 2).to(dt)
+        w = (torch.randn(shape[-1], generator=g, device=DEV) * 0.3 + 1).to(dt)
+        with torch.no_grad():
+            assert torch.equal(ops.rms_norm(x, w, eps, 0), ref(x, w, eps)), (shape, dt)
+    wide = (torch.randn(9, 4096, generator=g, device=DEV)).to(torch.float16)
+    w = torch.ones(2048, device=DEV, dtype=torch.float16)
+    with torch.no_grad():
+        assert torch.equal(ops.rms_norm(wide[:, 1024:3072], w, 1e-6, 0), ref(wide[:, 1024:3072].contiguous(), w, 1e-6))

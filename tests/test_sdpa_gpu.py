@@ -26,7 +26,11 @@ def _qkv(B, H, Tq, Tk, d, dtype, seed, spread=1.0):
 SHAPES = [(3, 16, 257, 257, 88, torch.float16), (2, 32, 64, 64, 64, torch.bfloat16), (2, 32, 16, 64, 64, torch.bfloat16),
           (5, 4, 16, 16, 64, torch.bfloat16), (2, 3, 1, 1, 8, torch.float16), (1, 2, 33, 47, 40, torch.float16),
           (2, 2, 100, 288, 96, torch.bfloat16), (1, 2, 70, 256, 128, torch.float16), (1, 3, 31, 255, 32, torch.bfloat16),
-          (2, 5, 96, 96, 128, torch.float16), (1, 1, 200, 17, 72, torch.float16)]
+          (2, 5, 96, 96, 128, torch.float16), (1, 1, 200, 17, 72, torch.float16),
+          (1, 5, 16, 16, 64, torch.bfloat16),            # 5 heads, 4 per workgroup: the last workgroup has empty slots
+          (1, 3, 40, 64, 64, torch.float16),             # 3 heads, 2 per workgroup
+          (1, 2, 900, 100, 64, torch.bfloat16),          # many queries: a head's blocks on three workgroups
+          (2, 2, 33, 129, 32, torch.float16)]            # head_dim 32 in the 64-wide instantiation, 129 keys
 
 
 @pytest.mark.parametrize("B,H,Tq,Tk,d,dtype", SHAPES)
