@@ -965,9 +965,10 @@ class GraphedModule(nn.Module):
         return out.clone()
 
 
-def _wrap_towers(model, towers, proxy_cache=None):
+def _wrap_towers(model, towers, proxy_cache=None, record=True):
     """Replace the blocks of the given module lists by GraphedModule proxies; returns the undo list.  `proxy_cache`
-    (owned by the pruner) keeps the proxies -- and their graphs -- from one capture phase to the next."""
+    (owned by the pruner) keeps the proxies -- and their graphs -- from one capture phase to the next.  `record=False` (the
+    last capture phase of a prune): a tower whose outputs are not remembered yet is not recorded either -- nobody would ask."""
     undo = []
     if not (towers and graph_replay_enabled() and torch.cuda.is_available()):
         return undo
@@ -1016,14 +1017,14 @@ def _wrap_towers(model, towers, proxy_cache=None):
         # the tower's outputs of this phase are remembered for the next one (TowerMemo)
         # (a block in training mode may draw dropout / drop-path masks: its output is not a function of its inputs)
         if proxy_cache is not None and tower_memo_enabled() and len(proxies) == len(blocks) >= 2 and not any_training:
-            fp = TowerMemo.fingerprint([ts for ts, _, _ in states])
             memo = proxy_cache.get(("memo", path))
+            fp = TowerMemo.fingerprint([ts for ts, _, _ in states]) if (memo is not None or record) else None
             if memo is not None and memo.matches(fp):
                 memo.begin("replay")
                 tg_ = proxies[0].__dict__.get("_tower")
                 if tg_ is not None:
                     tg_[0].memo_serves = True                    # the memo hands out the tower's outputs: nothing to predict
-            elif fp is not None:
+            elif fp is not None and record:
                 memo = proxy_cache[("memo", path)] = TowerMemo(fp, len(proxies))
                 memo.begin("record")
             else:
@@ -1104,7 +1105,8 @@ def _capture_once(model, batches, module_to_process, forward_to_cache, lora_mode
 
     # how the model calls block 0 of THIS tower, by sample: the next phase's stacked pass through it starts from these
     # (TowerGraph.run_predicted).  References, not copies: the walk replaces `inps[j]`, it never writes into it.
-    first = {} if (proxy_cache is not None and graph_replay_enabled() and tower_batch_enabled() and tower_graph_enabled()
+    final = proxy_cache is not None and proxy_cache.get(("last_tower",)) == module_to_process   # (the pruner says so: no phase follows)
+    first = {} if (proxy_cache is not None and not final and graph_replay_enabled() and tower_batch_enabled() and tower_graph_enabled()
                    and tower_predict_enabled() and torch.cuda.is_available()) else None
 
     class Catcher(nn.Module):
@@ -1149,7 +1151,7 @@ def _capture_once(model, batches, module_to_process, forward_to_cache, lora_mode
             sides = holder[("streams", p0.device.index)] = [torch.cuda.Stream(device=p0.device) for _ in range(capture_streams())]
     layers[0] = Catcher(layers[0])
     # blocks of towers that were pruned before this one (`done_towers`: their module paths) replay from HIP graphs
-    undo = _wrap_towers(model, [t for t in (done_towers or []) if t != module_to_process], proxy_cache)
+    undo = _wrap_towers(model, [t for t in (done_towers or []) if t != module_to_process], proxy_cache, record=not final)
     try:
         if world > 1 and len(batches) % world != 0:
             raise RuntimeError(f"calibration sharding needs the {len(batches)} calibration batches to divide evenly "

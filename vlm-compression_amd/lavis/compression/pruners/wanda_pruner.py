@@ -416,8 +416,10 @@ class BLIPT5LayerWandaPruner(LayerWiseBasePruner):
             return model(batch, vit_dense=self.vit_dense, llm_dense=self.llm_dense)      # :941-945
         return model(batch)
 
-    def _tower(self, cls, **kw):
+    def _tower(self, cls, last=False, **kw):
         self.prepare_calibration_input_encoder = lambda *a, **k: cls.prepare_calibration_input_encoder(self, *a, **k)
+        if last:          # nothing is captured after this tower: what a capture phase records for the NEXT one is not recorded
+            self.__dict__.setdefault("_proxy_cache", {})[("last_tower",)] = kw["module_to_process"]
         out = cls._prune(self, self.model, self.data_loader, **kw)
         # the finished tower's blocks may replay from HIP graphs while the next tower's inputs are captured
         self._done_towers = getattr(self, "_done_towers", []) + [kw["module_to_process"]]
@@ -437,23 +439,24 @@ class BLIPT5LayerWandaPruner(LayerWiseBasePruner):
         self.llm_dense = True if float(t5_keep_ratio) < 1. else False
         self._defer_score_readback = True           # importance scores are read back once, below
         try:
+            prune_t5 = self.t5_prune_spec is not None and float(t5_keep_ratio) < 1.
             if self.vit_prune_spec is not None and float(vit_keep_ratio) < 1.:
                 sd = global_sparsity_dict if global_sparsity_dict not in [None, "none"] else \
                     self.get_sparsity(1 - vit_keep_ratio, sparsity_ratio_granularity=None)
-                self.model = self._tower(VITLayerWandaPruner, model_prefix=self.vit_model_prefix,
+                self.model = self._tower(VITLayerWandaPruner, last=not prune_t5, model_prefix=self.vit_model_prefix,
                                          module_to_process=f"{self.vit_model_prefix}.blocks",
                                          n_samples=self.num_samples, sparsity_ratio=sd, lora_model=lora_model)
 
-            if self.t5_prune_spec is not None and float(t5_keep_ratio) < 1.:
+            if prune_t5:
                 sd = global_sparsity_dict if global_sparsity_dict is not None else \
                     self.get_sparsity(1 - t5_keep_ratio, sparsity_ratio_granularity=None)
                 if "t5_model" in self.t5_model_prefix:
                     for side in ("encoder", "decoder"):
-                        self.model = self._tower(T5LayerWandaPruner, model_prefix=self.t5_model_prefix,
+                        self.model = self._tower(T5LayerWandaPruner, last=side == "decoder", model_prefix=self.t5_model_prefix,
                                                  module_to_process=f"{self.t5_model_prefix}.{side}.block",
                                                  n_samples=self.num_samples, sparsity_ratio=sd, lora_model=lora_model)
                 else:
-                    self.model = self._tower(T5LayerWandaPruner, model_prefix=self.t5_model_prefix,
+                    self.model = self._tower(T5LayerWandaPruner, last=True, model_prefix=self.t5_model_prefix,
                                              module_to_process=f"{self.t5_model_prefix}{self.peft_postfix}.model.layers",
                                              n_samples=self.num_samples, sparsity_ratio=sd, lora_model=lora_model)
         finally:
