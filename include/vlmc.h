@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLMC_ABI_VERSION 11
+#define VLMC_ABI_VERSION 12
 
 #define VLMC_OK 0
 #define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
@@ -177,6 +177,35 @@ size_t vlmc_lora_grad_workspace(int64_t out_features, int64_t in_features, int r
 int vlmc_lora_grad(const void *G, int dtype, int64_t out_features, int64_t in_features, int64_t ldg, const float *A,
                    const float *B, int r, float scaling, const uint8_t *mask, int sparse, int autocast, float *dA,
                    float *dB, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- K14 / K15 fused: the layer's three products with the masked low-rank algebra inside the MFMA GEMM -------------------
+ * Replaces `F.linear(x, (W + (B@A).to(wd) * s) * M, bias)` (lora.py:362-368; :369-375 for sparse=False) AND its autograd
+ * for 16-bit weights when the autocast dtype is the weight dtype: neither W_eff [out,in] nor G = dY^T x [out,in] is ever
+ * written to memory.  Restrictions (else the entry points return VLMC_EINVAL and the caller uses
+ * vlmc_lora_effective_weight / vlmc_lora_grad with library GEMMs): dtype VLMC_F16 / VLMC_BF16, autocast == dtype,
+ * r <= 16, out_features and in_features multiples of 64, 16-byte aligned operands, row strides multiples of 8.
+ *
+ * vlmc_sparse_lora_prep: 16-bit images of A [r,in] and B [out,r] (rounded to the autocast dtype, rank padded to 16) that
+ *   the three kernels read; `prep` holds vlmc_sparse_lora_prep_bytes() bytes and stays valid while A and B do.
+ * vlmc_sparse_lora_fwd:        Y [M,out]  = wd(X [M,in] W_eff^T + bias)
+ * vlmc_sparse_lora_bwd_input:  dX [M,in]  = wd(dY [M,out] W_eff)
+ * vlmc_sparse_lora_bwd_weight: G = wd(dY^T X); Gm = wd((sparse ? G . M : G) * s); dB [out,r] = wd(Gm A16^T),
+ *   dA [r,in] = wd(B16^T Gm), fp32 (dA or dB may be NULL); workspace of vlmc_sparse_lora_bwd_weight_workspace() bytes,
+ *   256-byte aligned (transposed operands + per-tile partial sums, combined in a fixed order: deterministic).        */
+size_t vlmc_sparse_lora_prep_bytes(int64_t out_features, int64_t in_features);
+int vlmc_sparse_lora_prep(const float *A, const float *B, int64_t out_features, int64_t in_features, int r, int autocast,
+                          void *prep, void *stream);
+int vlmc_sparse_lora_fwd(const void *X, int64_t M, int64_t ldx, const void *W, int dtype, int64_t out_features,
+                         int64_t in_features, int64_t ldw, const uint8_t *mask, const void *prep, int r, float scaling,
+                         int sparse, int autocast, const void *bias, void *Y, int64_t ldy, void *stream);
+int vlmc_sparse_lora_bwd_input(const void *dY, int64_t M, int64_t lddy, const void *W, int dtype, int64_t out_features,
+                               int64_t in_features, int64_t ldw, const uint8_t *mask, const void *prep, int r,
+                               float scaling, int sparse, int autocast, void *dX, int64_t lddx, void *stream);
+size_t vlmc_sparse_lora_bwd_weight_workspace(int64_t M, int64_t out_features, int64_t in_features);
+int vlmc_sparse_lora_bwd_weight(const void *dY, int64_t lddy, const void *X, int64_t ldx, int64_t M, int dtype,
+                                int64_t out_features, int64_t in_features, const uint8_t *mask, const void *prep, int r,
+                                float scaling, int sparse, int autocast, float *dA, float *dB, void *workspace,
+                                size_t workspace_bytes, void *stream);
 
 /* ---- dense calibration forward of one linear (MFMA) ---------------------------------------------
  * Replaces `F.linear(x, weight, bias)` inside the block forwards of the calibration replay,

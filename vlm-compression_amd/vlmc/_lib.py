@@ -58,6 +58,12 @@ SIGNATURES = {
     "vlmc_lora_effective_weight": (_i, [_p, _i, _i64, _i64, _i64, _p, _p, _i, _c.c_float, _p, _i, _i, _p, _i64, _p]),
     "vlmc_lora_grad_workspace": (_sz, [_i64, _i64, _i]),
     "vlmc_lora_grad": (_i, [_p, _i, _i64, _i64, _i64, _p, _p, _i, _c.c_float, _p, _i, _i, _p, _p, _p, _sz, _p]),
+    "vlmc_sparse_lora_prep_bytes": (_sz, [_i64, _i64]),
+    "vlmc_sparse_lora_prep": (_i, [_p, _p, _i64, _i64, _i, _i, _p, _p]),
+    "vlmc_sparse_lora_fwd": (_i, [_p, _i64, _i64, _p, _i, _i64, _i64, _i64, _p, _p, _i, _c.c_float, _i, _i, _p, _p, _i64, _p]),
+    "vlmc_sparse_lora_bwd_input": (_i, [_p, _i64, _i64, _p, _i, _i64, _i64, _i64, _p, _p, _i, _c.c_float, _i, _i, _p, _i64, _p]),
+    "vlmc_sparse_lora_bwd_weight_workspace": (_sz, [_i64, _i64, _i64]),
+    "vlmc_sparse_lora_bwd_weight": (_i, [_p, _i64, _p, _i64, _i64, _i, _i64, _i64, _p, _p, _i, _c.c_float, _i, _i, _p, _p, _p, _sz, _p]),
     "vlmc_act_moments": (_i, [_p, _i, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p]),
     "vlmc_dsnot_stats_update": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p]),
     "vlmc_dsnot_refine": (_i, [_p, _i, _i64, _i64, _i64, _p, _p, _p, _p, _i, _i, _i, _i, _c.c_float, _c.c_float, _i, _p, _p, _p]),

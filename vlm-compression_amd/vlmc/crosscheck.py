@@ -45,6 +45,7 @@ ROUTES = {
     "sdpa_library": ({"VLMC_SDPA": "0"}, "F.scaled_dot_product_attention inside a replayed block left to torch"),
     "attn_library": ({"VLMC_ATTN_MATMUL": "0", "VLMC_ROW_MEAN": "0"}, "the blocks' batched matmuls and the norms' mean left to torch during the replay"),
     "attn_transposing_write": ({"VLMC_ATTN_TR": "0"}, "attn @ v with the operand transposed while writing LDS (no ds_read_b64_tr_b16)"),
+    "lora_unfused": ({"VLMC_LORA_FUSED": "0"}, "SparseLoRA through a materialised W_eff, library GEMMs and a G = dY^T x in memory"),
     "host_ctypes": ({"VLMC_FAST": "0"}, "every launch through the ctypes route (no compiled host path)"),
 }
 
