@@ -677,7 +677,104 @@ def gen_nm_ties():
     print("nm_ties.npz:", len(out), "arrays")
 
 
-GROUPS = {"nm_ties": gen_nm_ties, "wanda": gen_wanda, "wanda_e2e": gen_wanda_e2e, "sparse_lora": gen_sparse_lora, "sparsegpt": gen_sparsegpt,
+def _main_statements(path, keep):
+    """The top-level statements of `main()` in one of the reference's drivers for which `keep(node, source_segment)` holds,
+    compiled from the file where it lies (nothing of it is stored): the save block of train.py and the reload blocks of
+    evaluate_new.py are straight-line code over `args`, `model`, `job_id`, ... and can be driven on a toy model."""
+    import ast
+    src = open(path).read()
+    tree = ast.parse(src)
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    picked = [n for n in main.body if keep(n, ast.get_source_segment(src, n) or "")]
+    assert picked, path
+    return compile(ast.Module(body=picked, type_ignores=[]), path, "exec")
+
+
+def gen_formats():
+    """On-disk formats: the artefacts the reference's OWN save block writes (train.py:677-714) for a toy
+    InstructBLIP whose towers went through the reference's `get_peft_model` (train.py:413-486), and what the reference's OWN
+    reload blocks (evaluate_new.py:226-276) make of that checkpoint -- key lists, dtypes, shapes, yaml texts, reloaded tensors.
+    Also `return_reorder_indice` on its docstring example and more inputs (dsnot_pruner.py:1881-1925)."""
+    import tempfile
+    import time
+    import types as _types
+    from lavis.peft.src.peft.mapping import get_peft_model
+    from lavis.peft.src.peft.tuners.lora import LoraConfig
+    out = {}
+    model = toy_models.init_toy(toy_models.ToyBlipT5(), seed=3)
+    model.t5_model.config.to_dict = lambda: {"model_type": "t5"}       # what get_peft_model asks a tower for (mapping.py:195-196)
+    model.visual_encoder.model_type = "vit"
+    model.t5_model = get_peft_model(model.t5_model, LoraConfig(r=4, lora_alpha=16, target_modules=[".q", ".k", ".v", ".o", ".wi_0", "wi_1", "wo"],
+                                                               lora_dropout=0.0, bias="none", task_type="CAUSAL_LM"))
+    model.visual_encoder = get_peft_model(model.visual_encoder, LoraConfig(r=2, lora_alpha=16, target_modules=[".qkv", ".proj", ".fc1", ".fc2"],
+                                                                           lora_dropout=0.0, bias="none", task_type="ViT"))
+    g = torch.Generator().manual_seed(11)
+    k = 0
+    for name, mod in model.named_modules():
+        if hasattr(mod, "lora_A") and hasattr(mod, "mask"):
+            mod.mask = torch.rand(mod.weight.shape, generator=g) > 0.5          # what prune(lora_model=True) leaves (wanda_pruner.py:339)
+            mod.weight.importance_score = float(k) * 0.25 + 0.125               # (:320)
+            with torch.no_grad():
+                mod.lora_B.weight.copy_(torch.randn(mod.lora_B.weight.shape, generator=g) * 0.01)
+            k += 1
+    sparsity_dict = {"t5_model.base_model.model.encoder.block.0.layer.0.SelfAttention.q.weight": 0.5, "visual_encoder.blocks.1.mlp.fc2.weight": 0.25}
+    save_block = _main_statements(REF + "/train.py", lambda n, seg: seg.startswith("if args.save_pruned_model"))
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            import yaml
+            env = {"args": _types.SimpleNamespace(save_pruned_model=True, pruning_method="blipt5_wanda_pruner"), "model": model, "job_id": "job42",
+                   "sparsity_dict": sparsity_dict, "start": time.time() - 1.5, "os": os, "torch": torch, "time": time}
+            saved_cuda = torch.cuda.max_memory_allocated
+            torch.cuda.max_memory_allocated = lambda *a, **k: 3 * 1024 ** 3        # (a CPU-only box)
+            exec(save_block, env)
+            torch.cuda.max_memory_allocated = saved_cuda
+            listing = sorted(os.path.join(d, f)[2:] for d, _, fs in os.walk(".") for f in fs)
+            out["files"] = np.array(listing)
+            ckpt = "pruned_checkpoint/V+L/blipt5_wanda_pruner/job42.pth"
+            state = torch.load(ckpt)
+            out["ckpt/keys"] = np.array(list(state.keys()))
+            out["ckpt/dtypes"] = np.array([str(v.dtype) for v in state.values()])
+            out["ckpt/shapes"] = np.array([",".join(map(str, v.shape)) for v in state.values()])
+            out["sparsity_yaml"] = np.array(open("sparsity_dict/job42.yaml").read())
+            stats = yaml.safe_load(open("training_statistics/job42.yaml"))
+            out["stats/keys"] = np.array(sorted(stats))
+            out["stats/memory"] = float(stats["memory"])
+            scores = torch.load("importance_scores/job42.pth")
+            out["scores/keys"] = np.array(list(scores.keys()))
+            out["scores/values"] = np.array([float(v) for v in scores.values()])
+            # ---- the reference's reload of that checkpoint into a fresh, unwrapped model --------------------------------
+            fresh = toy_models.init_toy(toy_models.ToyBlipT5(), seed=99)
+            eva = _types.ModuleType("lavis.models.eva_vit")
+            eva.interpolate_pos_embed = lambda m, sd: None                     # (timm-based file; positions do not change here)
+            sys.modules.setdefault("lavis.models", _types.ModuleType("lavis.models"))
+            sys.modules["lavis.models.eva_vit"] = eva
+            reload_blocks = _main_statements(REF + "/evaluate_new.py", lambda n, seg: seg.startswith("if args.t5_pruned_checkpoint is not None")
+                                             or seg.startswith("if args.vit_pruned_checkpoint is not None"))
+            exec(reload_blocks, {"args": _types.SimpleNamespace(t5_pruned_checkpoint=ckpt, vit_pruned_checkpoint=ckpt), "model": fresh, "torch": torch,
+                                 "print": lambda *a, **k: None})
+            for key, v in fresh.state_dict().items():
+                out["reloaded/" + key] = v
+            for key, v in state.items():
+                out["ckpt/tensor/" + key] = v
+        finally:
+            os.chdir(cwd)
+    # ---- return_reorder_indice ----------------------------------------------------------------------------------------------
+    from lavis.compression.pruners.dsnot_pruner import return_reorder_indice
+    doc = torch.tensor([[-2.0, 1.0, -3.0, 4.0, 0.5], [1.0, -1.0, 2.0, -2.0, 3.0]])
+    cases = {"doc_like": doc, "zeros_and_ties": torch.tensor([[0.0, -1.0, 0.0, 2.0, -1.0, 2.0], [3.0, 0.0, 0.0, 0.0, -4.0, 1.0]]),
+             "all_negative": -torch.rand(3, 7, generator=g) - 0.1, "all_positive": torch.rand(3, 7, generator=g) + 0.1,
+             "random": torch.randn(8, 33, generator=g)}
+    cases["docstring"] = torch.tensor([[1., -2., 3.], [-2., 2., -4.], [5., 6., -7.], [-6., -7., -4.]])      # the example of :1883-1892
+    for name, t in cases.items():
+        out[f"reorder/{name}/in"] = t
+        out[f"reorder/{name}/out"] = return_reorder_indice(t.clone())
+    golden_io.save("formats", out)
+    print("formats.npz:", len(out), "arrays")
+
+
+GROUPS = {"formats": gen_formats, "nm_ties": gen_nm_ties, "wanda": gen_wanda, "wanda_e2e": gen_wanda_e2e, "sparse_lora": gen_sparse_lora, "sparsegpt": gen_sparsegpt,
           "sparsegpt_e2e": gen_sparsegpt_e2e, "dsnot": gen_dsnot,
           "dsnot_e2e": gen_dsnot_e2e, "ressa": gen_ressa, "ecoflap": gen_ecoflap, "global": gen_global, "vicuna_e2e": gen_vicuna_e2e}
 

@@ -77,3 +77,82 @@ def test_language_tower_probe_order_and_missing_tower(tmp_path):
     assert formats.load_pruned_language_model(m, path) == "llm_model"
     assert torch.equal(m.llm_model.weight.data, ref.weight.data)
     assert formats.load_pruned_language_model(torch.nn.Module(), path) is None
+
+
+# ---- pinned to what the REFERENCE's own statements wrote and read (tests/golden/formats.npz; make_golden.py: gen_formats drives the save block of
+# ---- train.py:677-714 and the reload blocks of evaluate_new.py:226-276 on the PEFT-wrapped toy) ----------------------------------------------------
+def _wrapped_toy():
+    """The model of gen_formats, built with the DROP-IN peft package (same seeds, same order of draws)."""
+    from lavis.peft.src.peft import LoraConfig, get_peft_model
+    model = toy_models.init_toy(toy_models.ToyBlipT5(), seed=3)
+    model.t5_model = get_peft_model(model.t5_model, LoraConfig(r=4, lora_alpha=16, target_modules=[".q", ".k", ".v", ".o", ".wi_0", "wi_1", "wo"],
+                                                               lora_dropout=0.0, bias="none", task_type="CAUSAL_LM"))
+    model.visual_encoder = get_peft_model(model.visual_encoder, LoraConfig(r=2, lora_alpha=16, target_modules=[".qkv", ".proj", ".fc1", ".fc2"],
+                                                                           lora_dropout=0.0, bias="none", task_type="ViT"))
+    g = torch.Generator().manual_seed(11)
+    k = 0
+    for name, mod in model.named_modules():
+        if hasattr(mod, "lora_A") and hasattr(mod, "mask"):
+            mod.mask = torch.rand(mod.weight.shape, generator=g) > 0.5
+            mod.weight.importance_score = float(k) * 0.25 + 0.125
+            with torch.no_grad():
+                mod.lora_B.weight.copy_(torch.randn(mod.lora_B.weight.shape, generator=g) * 0.01)
+            k += 1
+    return model
+
+
+def test_artefacts_equal_what_the_references_save_block_wrote(tmp_path):
+    import golden_io
+    from vlmc import formats
+    G = golden_io.load("formats")
+    model = _wrapped_toy()
+    sd = {"t5_model.base_model.model.encoder.block.0.layer.0.SelfAttention.q.weight": 0.5, "visual_encoder.blocks.1.mlp.fc2.weight": 0.25}
+    paths = formats.save_pruned_model(model, "job42", "blipt5_wanda_pruner", sparsity_dict=sd, start_time=0.0, root=str(tmp_path))
+    listing = sorted(os.path.relpath(os.path.join(d, f), tmp_path) for d, _, fs in os.walk(tmp_path) for f in fs)
+    assert listing == [str(x) for x in G["files"]]
+    state = torch.load(paths["checkpoint"])
+    assert list(state.keys()) == [str(k) for k in G["ckpt/keys"]]                  # names AND order: the wrappers' module tree
+    assert [str(v.dtype) for v in state.values()] == [str(x) for x in G["ckpt/dtypes"]]
+    assert [",".join(map(str, v.shape)) for v in state.values()] == [str(x) for x in G["ckpt/shapes"]]
+    for k, v in state.items():
+        if "lora_A" in k:                                                          # kaiming draws from the global RNG stream on both sides
+            continue
+        assert torch.equal(v, G["ckpt/tensor/" + k]), k
+    assert open(paths["sparsity_dict"]).read() == str(G["sparsity_yaml"])
+    stats = yaml.safe_load(open(paths["training_statistics"]))
+    assert sorted(stats) == [str(x) for x in G["stats/keys"]]
+    scores = torch.load(paths["importance_scores"])
+    assert list(scores.keys()) == [str(k) for k in G["scores/keys"]]
+    assert [float(v) for v in scores.values()] == [float(v) for v in G["scores/values"]]
+
+
+def test_reload_equals_what_the_references_reload_blocks_loaded(tmp_path):
+    import golden_io
+    from vlmc import formats
+    G = golden_io.load("formats")
+    state = {str(k): G["ckpt/tensor/" + str(k)] for k in G["ckpt/keys"]}           # the checkpoint the reference wrote
+    path = str(tmp_path / "ref.pth")
+    torch.save(state, path)
+    fresh = toy_models.init_toy(toy_models.ToyBlipT5(), seed=99)
+    assert formats.load_pruned_language_model(fresh, path) == "t5_model"
+    assert formats.load_pruned_vit(fresh, path) == "visual_encoder."
+    got = fresh.state_dict()
+    want = {k[len("reloaded/"):]: v for k, v in G.items() if k.startswith("reloaded/")}
+    assert list(got.keys()) == list(want.keys())
+    for k, v in want.items():
+        assert torch.equal(got[k], v), k
+    # and it really took the pruned towers' tensors, stripped of `base_model.model.`
+    assert torch.equal(got["t5_model.encoder.block.0.SelfAttention.q.weight"],
+                       state["t5_model.base_model.model.encoder.block.0.SelfAttention.q.weight"])
+
+
+def test_return_reorder_indice_fixture():
+    """dsnot_pruner.py:1881-1925 stand-alone: the docstring's example and edge rows, the oracle's restatement."""
+    import golden_io
+    from oracle import dsnot as OD
+    G = golden_io.load("formats")
+    names = sorted({k.split("/")[1] for k in G if k.startswith("reorder/")})
+    assert "docstring" in names and len(names) >= 5
+    for n in names:
+        assert torch.equal(OD.reorder_indices(G[f"reorder/{n}/in"]), G[f"reorder/{n}/out"]), n
+    assert G["reorder/docstring/out"].tolist() == [[1, 2, 0], [0, 2, 1], [2, 1, 0], [0, 1, 2]]
