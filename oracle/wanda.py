@@ -126,17 +126,27 @@ def select_matrix(score: np.ndarray, k_index: int) -> np.ndarray:
     return score < thr
 
 
-def select_nm(score: np.ndarray, n: int, m: int) -> np.ndarray:
-    """n smallest of every m consecutive columns (wanda_pruner.py:326-329),
-    ties -> lowest column index.  A trailing group shorter than m (in % m != 0)
-    is handled like torch.topk on the short slice would fail -> we require
-    in % m == 0 (true for every model width)."""
+def select_nm(score: np.ndarray, n: int, m: int, ties: str = "torch_cpu") -> np.ndarray:
+    """n smallest of every m consecutive columns (wanda_pruner.py:326-329: `torch.topk(tmp, n, dim=1, largest=False)`).
+    Groups whose n-th and (n+1)-th smallest scores are EQUAL are decided as the reference's CPU run decides them
+    (`ties="torch_cpu"`: oracle/topk_order.py, the order libstdc++'s nth_element leaves equal keys in) or lowest column
+    first (`ties="lowest"`, the rule of rounds 1-4).  A trailing group shorter than m (in % m != 0) is handled like
+    torch.topk on the short slice would fail -> we require in % m == 0 (true for every model width)."""
+    from . import topk_order
     out_f, in_f = score.shape
     assert in_f % m == 0, "n:m selection needs in_features % m == 0"
     g = score.reshape(out_f, in_f // m, m)
     idx = np.argsort(g, axis=2, kind="stable")[:, :, :n]
     pruned = np.zeros_like(g, dtype=bool)
     np.put_along_axis(pruned, idx, True, axis=2)
+    if ties == "torch_cpu" and 0 < n < m:
+        srt = np.sort(g, axis=2)
+        tied = (srt[:, :, n - 1] == srt[:, :, n]) | (np.isnan(srt[:, :, n - 1]) & np.isnan(srt[:, :, n]))
+        for r, c in zip(*np.nonzero(tied)):
+            pruned[r, c, :] = False
+            pruned[r, c, topk_order.smallest(g[r, c], n)] = True
+    else:
+        assert ties in ("torch_cpu", "lowest")
     return pruned.reshape(out_f, in_f)
 
 

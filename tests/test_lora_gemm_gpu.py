@@ -5,9 +5,9 @@ with neither W_eff nor G = dY^T x in memory.
 What is exact and what has a tolerance:
 * the GENERATED weight tiles: with X = I the forward returns W_eff^T and with dY = I the backward returns W_eff, each
   entry ONE product by 1.0 -- compared bit for bit with `vlmc_lora_effective_weight` (pinned to the reference's goldens
-  by tests/test_sparse_lora_gpu.py) and with the CPU oracle: >= 99.9 % of the entries identical, never more than one ulp of
-  the 16-bit dtype apart (the rank-r sum runs on the 16-bit MFMA here, on an fp32 fma chain there: a value can cross a
-  rounding boundary);
+  by tests/test_sparse_lora_gpu.py) and with the CPU oracle: >= 99.9 % of the entries identical, never more than two ulps of
+  the larger addend apart (the rank-r sum runs on the 16-bit MFMA here, on an fp32 fma chain there: delta can cross a
+  rounding boundary, and wd(W + delta) can then round the other way);
 * outputs and input gradients: fp32 accumulation of 16-bit products in another order than the library GEMM's:
   rtol 2e-2 (bf16) / 4e-3 (fp16) of the row's scale;
 * adapter gradients: rounded to the autocast dtype at the end like the reference's: one ulp + summation order."""
@@ -45,13 +45,14 @@ def _unfused(x, W, A, B, M, b, s, sparse):
 
 
 def _same_bits_or_one_ulp(got, ref, wd, name, W, min_exact=0.999):
-    """one ulp of the LARGER of the two addends: W_eff = W + delta can cancel, and a delta one ulp off stays one ulp of delta off"""
+    """Two ulps of the LARGER of the two addends: W_eff = wd(W + delta) can cancel; a delta one ulp off stays one ulp of delta
+    off, and the sum's own rounding may then fall the other way."""
     got, ref = got.float(), ref.float()
     exact = (got == ref).float().mean().item()
     assert exact >= min_exact, f"{name}: only {exact:.5f} of the entries bit-identical"
-    tol = (ref.abs() + W.float().to(ref.device).abs()).clamp_min(2.0 ** -14) * ULP[wd] * 1.001
+    tol = (ref.abs() + W.float().to(ref.device).abs()).clamp_min(2.0 ** -14) * ULP[wd] * 2.002
     worst = ((got - ref).abs() - tol).max().item()
-    assert worst <= 0, f"{name}: an entry differs by more than one ulp ({worst})"
+    assert worst <= 0, f"{name}: an entry differs by more than two ulps of its addends ({worst})"
     return exact
 
 
@@ -121,8 +122,9 @@ def test_weight_gradients_against_the_oracle_autograd(wd):
         delta.retain_grad()
         weff = (W + delta * 2.0) * Mk if sparse else W * Mk + delta * 2.0
         weff.backward(G)
-        torch.testing.assert_close(Ad.grad.cpu(), A16.grad.to(wd).float(), rtol=4 * ULP[wd], atol=1e-4)
-        torch.testing.assert_close(Bd.grad.cpu(), B16.grad.to(wd).float(), rtol=4 * ULP[wd], atol=1e-4)
+        # (a sum of ~200 signed terms: an entry of G that rounds the other way on the CPU moves a small sum by ulps of its TERMS)
+        for got, ref in ((Ad.grad.cpu(), A16.grad.to(wd).float()), (Bd.grad.cpu(), B16.grad.to(wd).float())):
+            torch.testing.assert_close(got, ref, rtol=4 * ULP[wd], atol=8 * ULP[wd] * ref.abs().max().item())
 
 
 @pytest.mark.parametrize("out_f,in_f", V7B)

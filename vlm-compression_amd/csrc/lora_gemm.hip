@@ -33,6 +33,7 @@
 #include "common.hpp"
 #include "mfma.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace vlmc {
@@ -42,9 +43,9 @@ typedef _Float16 h16x4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x2_t __attribute__((ext_vector_type(2)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int BP = 128, BQ = 256, BK = 64, ROWB = 128;        // rows of 64 elements = 128 B in every LDS image
-constexpr int NTH = 512, TP = 4, TQ = 4;                      // 2 (p) x 4 (q) waves of 64 x 64
-constexpr int P_BYTES = BP * ROWB, Q_BYTES = BQ * ROWB, SLOT = P_BYTES + Q_BYTES, NSL = 3;
+constexpr int BP = 128, BK = 64, ROWB = 128;                  // rows of 64 elements = 128 B in every LDS image
+constexpr int NTH = 512, TP = 4;                              // 2 (p) x 4 (q) waves of 64 x (BQ / 4); BQ = 256 or 192 rows of Q per tile
+constexpr int P_BYTES = BP * ROWB, NSL = 3;
 constexpr int RP = 16;                                        // padded rank
 
 enum { M_FWD = 0, M_DX = 1, M_G = 2 };
@@ -72,7 +73,8 @@ struct LoraArgs {
     const uint16_t *bias;
     // G
     float *part_a, *part_b;       // [nbq][in][16], [nbp][out][16]
-    int nbp, nbq;
+    int nbp, nbq, bq;             // bq: rows of Q per tile, 256 or 192
+    int dbg;                      // VLMC_LORA_DBG (diagnostics): 1 full wait before the generator, 2 full wait at the top of a step
 };
 
 __device__ __forceinline__ int row_off(int row, int ch) { return row * ROWB + ((ch ^ (row & 7)) << 4); }
@@ -184,11 +186,14 @@ __device__ __forceinline__ void gen_piece(const GenSet &s, const u32x2_t (&af)[4
 // barrier after its issuer's wait).  Step d: wait, barrier, issue, first half of the MFMAs, wait for the own piece of step
 // d + 1, generate it in place beside the second half of the MFMAs.
 // G mode: three slots of [P | Q], both by DMA two steps ahead.
-constexpr int QOFF = 0, POFF = 2 * Q_BYTES, MOFF = POFF + 3 * P_BYTES, M_BYTES = BP * BK, SOFF = MOFF + 2 * M_BYTES, S_BYTES = BK * RP * 2;
-constexpr int LDS_GEN = SOFF + 3 * S_BYTES, LDS_G = NSL * SLOT;
+constexpr int M_BYTES = BP * BK, S_BYTES = BK * RP * 2;
 
-template <typename T, int MODE, bool SPARSE, bool FAST>
+template <typename T, int MODE, bool SPARSE, bool FAST, int BQ>
 __global__ __launch_bounds__(NTH, 2) void lora_gemm_kernel(const LoraArgs a) {
+    constexpr int TQ = BQ / 64, Q_BYTES = BQ * ROWB, SLOT = P_BYTES + Q_BYTES;
+    constexpr int QOFF = 0, POFF = 2 * Q_BYTES, MOFF = POFF + 3 * P_BYTES, SOFF = MOFF + 2 * M_BYTES;
+    constexpr int LDS_GEN = SOFF + 3 * S_BYTES, LDS_G = NSL * SLOT;
+    static_assert(BQ == 256 || BQ == 192, "4 waves x 3 or 4 MFMA tiles of 16 rows");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[MODE == M_G ? LDS_G : LDS_GEN];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -209,8 +214,8 @@ __global__ __launch_bounds__(NTH, 2) void lora_gemm_kernel(const LoraArgs a) {
     const int wp = wave >> 2, wq = wave & 3;
     const int nk = a.K / BK;
 
-    // ---- LDS-DMA pieces of 8 rows x 128 B: Q 4 per wave and step; G mode: P 2 per wave and step -----------------------------
-    constexpr int NQP = 4;
+    // ---- LDS-DMA pieces of 8 rows x 128 B: Q 3 or 4 per wave and step; G mode: P 2 per wave and step ------------------------
+    constexpr int NQP = BQ / 64;
     const uint16_t *srcq[NQP];
     uint32_t dstq[NQP];
 #pragma unroll
@@ -272,31 +277,26 @@ __global__ __launch_bounds__(NTH, 2) void lora_gemm_kernel(const LoraArgs a) {
     gm = wave * 1024 + c * 64 + g * 16;
     gs = MODE == M_FWD ? (16 * (c >> 2) + (c & 3)) * 32 + 8 * g : ((wave & 3) * 16 + c) * 32 + 8 * g;      // (+ 4 t rows = 128 t bytes, FWD)
 
-    auto issue_q = [&](int step, uint32_t slot) {
-#pragma unroll
-        for (int v = 0; v < NQP; ++v) glds16(srcq[v] + step * BK, slot + dstq[v]);
-    };
-    auto issue_w = [&](int step, uint32_t slot) {
-#pragma unroll
-        for (int v = 0; v < 2; ++v) glds16(srcw[v] + step * wstep, slot + dstw[v]);
-    };
-    // the wave's piece of `step`: W, mask and fragments out of LDS, W_eff back where W stood
-    auto generate = [&](int step) {
-        unsigned char *pimg = lds + POFF + (step % 3) * P_BYTES;
+    // the wave's piece of a step: W, mask and fragments out of LDS, W_eff back where W stood
+    GenSet gset;
+    auto gen_load = [&](int step) {
+        const unsigned char *pimg = lds + POFF + (step % 3) * P_BYTES;
         const unsigned char *mimg = lds + MOFF + (step & 1) * M_BYTES, *simg = lds + SOFF + (step % 3) * S_BYTES;
-        GenSet s;
-        s.w0 = *reinterpret_cast<const u32x4_t *>(pimg + gw0);
-        s.w1 = *reinterpret_cast<const u32x4_t *>(pimg + gw1);
-        s.m = *reinterpret_cast<const u32x4_t *>(mimg + gm);
-        u32x4_t o0, o1;
+        gset.w0 = *reinterpret_cast<const u32x4_t *>(pimg + gw0);
+        gset.w1 = *reinterpret_cast<const u32x4_t *>(pimg + gw1);
+        gset.m = *reinterpret_cast<const u32x4_t *>(mimg + gm);
         if constexpr (MODE == M_FWD) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) s.f[t] = *reinterpret_cast<const u32x2_t *>(simg + gs + 128 * t);
-            gen_piece<T, SPARSE, FAST>(s, s.f, cfrag[0], a, o0, o1);
+            for (int t = 0; t < 4; ++t) gset.f[t] = *reinterpret_cast<const u32x2_t *>(simg + gs + 128 * t);
         } else {
-            s.f[0] = *reinterpret_cast<const u32x2_t *>(simg + gs);
-            gen_piece<T, SPARSE, FAST>(s, cfrag, s.f[0], a, o0, o1);
+            gset.f[0] = *reinterpret_cast<const u32x2_t *>(simg + gs);
         }
+    };
+    auto gen_finish = [&](int step) {
+        unsigned char *pimg = lds + POFF + (step % 3) * P_BYTES;
+        u32x4_t o0, o1;
+        if constexpr (MODE == M_FWD) gen_piece<T, SPARSE, FAST>(gset, gset.f, cfrag[0], a, o0, o1);
+        else gen_piece<T, SPARSE, FAST>(gset, cfrag, gset.f[0], a, o0, o1);
         *reinterpret_cast<u32x4_t *>(pimg + gw0) = o0;
         *reinterpret_cast<u32x4_t *>(pimg + gw1) = o1;
     };
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(NTH, 2) void lora_gemm_kernel(const LoraArgs a) {
         for (int i = 0; i < TP; ++i)
 #pragma unroll
             for (int j = 0; j < TQ; ++j) {
-                const int o = min(q0 + wq * 64 + 16 * j + c, a.out_f - 1), ib = min(p0 + wp * 64 + 16 * i + 4 * g, a.in_f - 4);
+                const int o = min(q0 + wq * (16 * TQ) + 16 * j + c, a.out_f - 1), ib = min(p0 + wp * 64 + 16 * i + 4 * g, a.in_f - 4);
                 mk[i][j] = *reinterpret_cast<const uint32_t *>(a.mask + int64_t(o) * a.in_f + ib);
             }
     }
@@ -320,10 +320,12 @@ __global__ __launch_bounds__(NTH, 2) void lora_gemm_kernel(const LoraArgs a) {
         for (int j = 0; j < TQ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // fragment offsets inside the images
-    const int fq0 = (wq * 64 + c) * ROWB + ((g ^ (lane & 7)) << 4), fq1 = (wq * 64 + c) * ROWB + (((4 + g) ^ (lane & 7)) << 4);
+    const int fq0 = (wq * (16 * TQ) + c) * ROWB + ((g ^ (lane & 7)) << 4), fq1 = (wq * (16 * TQ) + c) * ROWB + (((4 + g) ^ (lane & 7)) << 4);
     const int fp0 = (wp * 64 + c) * ROWB + ((g ^ (lane & 7)) << 4), fp1 = (wp * 64 + c) * ROWB + (((4 + g) ^ (lane & 7)) << 4);
     const int tq = c >> 2, tp = c & 3;                                    // transposing reads: lane 4 q + p of a 16-lane group
-    auto multiply = [&](const unsigned char *pimg, const unsigned char *qimg, const int kk) {
+    // one K-step of 32: fragments, then TP rows of TQ MFMAs with `between(i)` behind row i (the step's DMA instructions go
+    // there: an LDS-DMA costs its wave 60-180 cycles of issue, which the partner wave's MFMAs cover)
+    auto multiply = [&](const unsigned char *pimg, const unsigned char *qimg, const int kk, auto &&before, auto &&between) {
         u32x4_t fq[TQ], fp[TP];
 #pragma unroll
         for (int j = 0; j < TQ; ++j) fq[j] = *reinterpret_cast<const u32x4_t *>(qimg + (kk ? fq1 : fq0) + j * 16 * ROWB);
@@ -343,74 +345,92 @@ __global__ __launch_bounds__(NTH, 2) void lora_gemm_kernel(const LoraArgs a) {
 #pragma unroll
             for (int i = 0; i < TP; ++i) fp[i] = *reinterpret_cast<const u32x4_t *>(pimg + (kk ? fp1 : fp0) + i * 16 * ROWB);
         }
+        before();
 #pragma unroll
-        for (int i = 0; i < TP; ++i)
+        for (int i = 0; i < TP; ++i) {
 #pragma unroll
             for (int j = 0; j < TQ; ++j) acc[i][j] = mfma16<T>(fp[i], fq[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            between(i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
+    auto nothing = [] {};
 
     // ---- the K loop ------------------------------------------------------------------------------------------------------------
     if constexpr (MODE == M_G) {
-        auto issue = [&](int step) {
+        constexpr int ND = 2 + NQP;
+        auto issue_piece = [&](int step, int v) {                         // v = 0, 1: x^T; 2 ..: dY^T
             const uint32_t slot = lds_base + (step % NSL) * SLOT;
-            issue_w(step, slot);
-            issue_q(step, slot + P_BYTES);
+            if (v < 2) glds16(srcw[v] + step * BK, slot + dstw[v]);
+            else glds16(srcq[v - 2] + step * BK, slot + P_BYTES + dstq[v - 2]);
         };
-        issue(0);
-        if (nk > 1) issue(1);
+        for (int st = 0; st < 2 && st < nk; ++st)
+#pragma unroll
+            for (int v = 0; v < ND; ++v) issue_piece(st, v);
         for (int d = 0; d < nk; ++d) {
-            if (d + 1 < nk) wait_vm_plain<6>();
+            if (d + 1 < nk) wait_vm_plain<ND>();
             else wait_vm_plain<0>();
             barrier();
-            if (d + 2 < nk) issue(d + 2);
+            const bool more = d + 2 < nk;
             const unsigned char *img = lds + (d % NSL) * SLOT;
-            multiply(img, img + P_BYTES, 0);
-            multiply(img, img + P_BYTES, 1);
+            multiply(img, img + P_BYTES, 0, nothing, [&](int i) { if (more && i < 3) issue_piece(d + 2, i); });
+            multiply(img, img + P_BYTES, 1, nothing, [&](int i) { if (more && 3 + i < ND) issue_piece(d + 2, 3 + i); });
         }
     } else {
-        // Per step 8 DMA instructions per wave, in this order: Q(d + 1) x 4, W(d + 2) x 2, mask(d + 2), slab(d + 3).  Steps
-        // past the end are issued all the same with the step index clamped (the last step again, into slots nobody reads
-        // any more), so that the counts of the two waits are constants.
+        // Per step 4 + NQP DMA instructions per wave, in this order: Q(d + 1) x NQP behind the first K-step's MFMA rows, then
+        // W(d + 2) x 2, mask(d + 2), slab(d + 3) behind the second's.  Steps past the end are issued all the same with the step
+        // index clamped (the last step again, into slots nobody reads any more): the counts of the two waits are constants.
         const int last = nk - 1;
-        auto issue_wm = [&](int t) {                                      // piece and mask of step t (clamped) into the slots of t
-            issue_w(min(t, last), lds_base + POFF + (t % 3) * P_BYTES);
-            glds16(srcm + min(t, last) * mstep, lds_base + MOFF + (t & 1) * M_BYTES + wave * 1024);
-        };
+        auto issue_q1 = [&](int t, int v) { glds16(srcq[v] + min(t, last) * BK, lds_base + QOFF + (t & 1) * Q_BYTES + dstq[v]); };
+        auto issue_w1 = [&](int t, int v) { glds16(srcw[v] + min(t, last) * wstep, lds_base + POFF + (t % 3) * P_BYTES + dstw[v]); };
+        auto issue_m1 = [&](int t) { glds16(srcm + min(t, last) * mstep, lds_base + MOFF + (t & 1) * M_BYTES + wave * 1024); };
         auto issue_slab = [&](int t) {
             if (lane < 16) glds16(srcs + int64_t(min(t, last)) * (BK * RP), lds_base + SOFF + (t % 3) * S_BYTES + wave * 256);
         };
         // prologue: what steps -3, -2 and -1 would have issued
         issue_slab(0);
-        issue_wm(0);
+        issue_w1(0, 0); issue_w1(0, 1); issue_m1(0);
         issue_slab(1);
-        issue_q(0, lds_base + QOFF);
-        issue_wm(1);
+#pragma unroll
+        for (int v = 0; v < NQP; ++v) issue_q1(0, v);
+        issue_w1(1, 0); issue_w1(1, 1); issue_m1(1);
         issue_slab(2);
-        wait_vm_plain<9>();                                               // slab 0 and the own piece of step 0 have landed
+        wait_vm_plain<NQP + 5>();                                         // slab 0 and the own piece of step 0 have landed
         barrier();
-        generate(0);
+        gen_load(0);
+        gen_finish(0);
         for (int d = 0; d < nk; ++d) {
-            wait_vm_plain<4>();                                           // own pieces of Q(d) -- and everything older: slab(d + 1)
+            if (a.dbg & 2) wait_vm_plain<0>();
+            else wait_vm_plain<4>();                                      // own pieces of Q(d) -- and everything older: slab(d + 1)
             barrier();                                                    // everybody's have; W_eff(d) stands
-            issue_q(min(d + 1, last), lds_base + QOFF + ((d + 1) & 1) * Q_BYTES);
-            issue_wm(d + 2);
-            issue_slab(d + 3);
             const unsigned char *pimg = lds + POFF + (d % 3) * P_BYTES, *qimg = lds + QOFF + (d & 1) * Q_BYTES;
-            multiply(pimg, qimg, 0);
-            if (d < last) {
-                wait_vm_plain<9>();                                       // the own piece of step d + 1 (issued in step d - 1)
-                generate(d + 1);
-            }
-            multiply(pimg, qimg, 1);
+            multiply(pimg, qimg, 0, nothing, [&](int i) { if (i < NQP) issue_q1(d + 1, i); });
+            const bool gen = d < last;
+            multiply(pimg, qimg, 1,
+                     [&] {
+                         if (gen) {
+                             if (a.dbg & 1) wait_vm_plain<0>();
+                             else wait_vm_plain<NQP + 1>();               // the own piece of step d + 1 (behind it: slab(d + 2), Q(d + 1))
+                             gen_load(d + 1);
+                         }
+                     },
+                     [&](int i) {
+                         if (i == 0) issue_w1(d + 2, 0);
+                         else if (i == 1) issue_w1(d + 2, 1);
+                         else if (i == 2) issue_m1(d + 2);
+                         else issue_slab(d + 3);
+                         if (i == 1 && gen) gen_finish(d + 1);
+                     });
         }
         wait_vm_plain<0>();                                               // (the clamped tail loads)
     }
-    barrier();                                                            // every wave is done with the slots
+    barrier();                                                            // every wave is done with the slots, every DMA has landed
 
     // ---- epilogues -------------------------------------------------------------------------------------------------------------
     if constexpr (MODE != M_G) {
         // Y[q][p]: the wave's 64 x 64 piece through its own 8 KiB of LDS, out as 16 B per lane, 128 B per row
-        unsigned char *wl = lds + wave * 8192;
+        unsigned char *wl = lds + wave * (16 * TQ * ROWB);
         const uint16_t *bias = a.bias;
 #pragma unroll
         for (int i = 0; i < TP; ++i) {
@@ -431,10 +451,10 @@ __global__ __launch_bounds__(NTH, 2) void lora_gemm_kernel(const LoraArgs a) {
             }
         }
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < 2 * TQ; ++s) {
             const int idx = s * 64 + lane, row = idx >> 3, ch = idx & 7;
             const u32x4_t v = *reinterpret_cast<const u32x4_t *>(wl + row * ROWB + ((ch ^ (row & 7)) << 4));
-            const int q = q0 + wq * 64 + row, p = p0 + wp * 64 + ch * 8;
+            const int q = q0 + wq * (16 * TQ) + row, p = p0 + wp * 64 + ch * 8;
             if (q < a.NQ && p + 8 <= a.NP) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t *>(a.Y + int64_t(q) * a.ldy + p));
         }
     } else {
@@ -452,7 +472,7 @@ __global__ __launch_bounds__(NTH, 2) void lora_gemm_kernel(const LoraArgs a) {
         for (int i = 0; i < TP; ++i)
 #pragma unroll
             for (int j = 0; j < TQ; ++j) {
-                const bool valid = q0 + wq * 64 + 16 * j + c < a.out_f && p0 + wp * 64 + 16 * i + 4 * g < a.in_f;
+                const bool valid = q0 + wq * (16 * TQ) + 16 * j + c < a.out_f && p0 + wp * 64 + 16 * i + 4 * g < a.in_f;
                 uint16_t o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -474,7 +494,7 @@ __global__ __launch_bounds__(NTH, 2) void lora_gemm_kernel(const LoraArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < TQ; ++j) {
-            const int ob = q0 + wq * 64 + 16 * j + 4 * g;
+            const int ob = q0 + wq * (16 * TQ) + 16 * j + 4 * g;
             bf[j] = ob < a.out_f ? *reinterpret_cast<const u32x2_t *>(a.Bt16 + int64_t(c) * a.out_f + ob) : u32x2_t{0u, 0u};
         }
 #pragma unroll
@@ -506,7 +526,7 @@ __global__ __launch_bounds__(NTH, 2) void lora_gemm_kernel(const LoraArgs a) {
 #pragma unroll
             for (int j = 0; j < TQ; ++j) {
                 const f32x4_t other = red[((wave + 4) * 8 + j) * 64 + lane];
-                const int o = q0 + wq * 64 + 16 * j + c;
+                const int o = q0 + wq * (16 * TQ) + 16 * j + c;
                 f32x4_t v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = ieee_add(accb[j][r], other[r]);
@@ -659,17 +679,48 @@ void fill_common(LoraArgs &a, const void *W, int64_t ldw, const uint8_t *mask, c
     a.sparse = sparse != 0;
     a.hs = dtype == VLMC_F16 ? half_bits_if_exact(scaling) : 0;
     a.fast = dtype == VLMC_F16 && a.hs != 0;
+    {
+        const char *e = getenv("VLMC_LORA_DBG");
+        a.dbg = e ? atoi(e) : 0;
+    }
 }
 
-template <typename T, int MODE, bool SPARSE> void launch_t(const LoraArgs &a, hipStream_t s) {
+// rows of activations per tile: the choice (256 or 192) that leaves the fewer rounds of workgroups on the chip, then the less padding
+int pick_bq(int64_t M, int nbp) {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    static const int forced = [] {
+        const char *e = getenv("VLMC_LORA_BQ");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 192 || forced == 256) return forced;
+    auto cost = [&](int bq) {
+        const int64_t tiles = int64_t(nbp) * ((M + bq - 1) / bq), rounds = (tiles + cus - 1) / cus;
+        return double(rounds) * bq;                                       // time ~ rounds x rows per tile
+    };
+    return cost(192) < cost(256) ? 192 : 256;
+}
+template <typename T, int MODE, bool SPARSE, int BQ> void launch_q(const LoraArgs &a, hipStream_t s) {
     const unsigned grid = unsigned(a.nbp) * unsigned(a.nbq);
     if constexpr (__is_same(T, f16_t) && MODE != M_G) {
         if (a.fast) {
-            VLMC_LAUNCH_TIMED((lora_gemm_kernel<T, MODE, SPARSE, true>), dim3(grid), dim3(NTH), s, a);
+            VLMC_LAUNCH_TIMED((lora_gemm_kernel<T, MODE, SPARSE, true, BQ>), dim3(grid), dim3(NTH), s, a);
             return;
         }
     }
-    VLMC_LAUNCH_TIMED((lora_gemm_kernel<T, MODE, SPARSE, false>), dim3(grid), dim3(NTH), s, a);
+    VLMC_LAUNCH_TIMED((lora_gemm_kernel<T, MODE, SPARSE, false, BQ>), dim3(grid), dim3(NTH), s, a);
+}
+template <typename T, int MODE, bool SPARSE> void launch_t(const LoraArgs &a, hipStream_t s) {
+    if constexpr (MODE != M_G) {
+        if (a.bq == 192) {
+            launch_q<T, MODE, SPARSE, 192>(a, s);
+            return;
+        }
+    }
+    launch_q<T, MODE, SPARSE, 256>(a, s);
 }
 template <int MODE> void launch(const LoraArgs &a, int dtype, hipStream_t s) {
     if (dtype == VLMC_F16) {
@@ -729,7 +780,8 @@ extern "C" int vlmc_sparse_lora_fwd(const void *X, int64_t M, int64_t ldx, const
     a.ldy = ldy;
     a.bias = static_cast<const uint16_t *>(bias);
     a.nbp = int((out_features + BP - 1) / BP);
-    a.nbq = int((M + BQ - 1) / BQ);
+    a.bq = pick_bq(M, a.nbp);
+    a.nbq = int((M + a.bq - 1) / a.bq);
     launch<M_FWD>(a, dtype, as_stream(stream));
     VLMC_HIP_CHECK_LAUNCH("vlmc_sparse_lora_fwd");
     return VLMC_OK;
@@ -754,7 +806,8 @@ extern "C" int vlmc_sparse_lora_bwd_input(const void *dY, int64_t M, int64_t ldd
     a.ldy = lddx;
     a.bias = nullptr;
     a.nbp = int((in_features + BP - 1) / BP);
-    a.nbq = int((M + BQ - 1) / BQ);
+    a.bq = pick_bq(M, a.nbp);
+    a.nbq = int((M + a.bq - 1) / a.bq);
     launch<M_DX>(a, dtype, as_stream(stream));
     VLMC_HIP_CHECK_LAUNCH("vlmc_sparse_lora_bwd_input");
     return VLMC_OK;
@@ -764,13 +817,14 @@ namespace {
 struct GradWs {
     size_t dyt, xt, part_a, part_b, total;
     int64_t mp;
-    int nbp, nbq;
+    int nbp, nbq, bq;             // bq: rows of Q per tile, 256 or 192
+    int dbg;                      // VLMC_LORA_DBG (diagnostics): 1 full wait before the generator, 2 full wait at the top of a step
 };
 GradWs grad_ws(int64_t M, int64_t out_f, int64_t in_f) {
     GradWs w;
     w.mp = (M + 63) / 64 * 64;
     w.nbp = int((in_f + BP - 1) / BP);
-    w.nbq = int((out_f + BQ - 1) / BQ);
+    w.nbq = int((out_f + 255) / 256);
     w.dyt = 0;
     w.xt = round_up(size_t(out_f) * size_t(w.mp) * 2, 256);
     w.part_a = w.xt + round_up(size_t(in_f) * size_t(w.mp) * 2, 256);
@@ -819,6 +873,7 @@ extern "C" int vlmc_sparse_lora_bwd_weight(const void *dY, int64_t lddy, const v
     a.part_b = reinterpret_cast<float *>(ws + w.part_b);
     a.nbp = w.nbp;
     a.nbq = w.nbq;
+    a.bq = 256;
     launch<M_G>(a, dtype, s);
     const int64_t n = (in_features + out_features) * RP;
     if (dtype == VLMC_F16)
