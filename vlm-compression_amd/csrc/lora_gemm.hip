@@ -51,17 +51,20 @@ constexpr int RP = 16;                                        // padded rank
 enum { M_FWD = 0, M_DX = 1, M_G = 2 };
 
 struct LoraArgs {
-    // Q operand, K-major, by LDS-DMA.  FWD: x [M, in].  DX: dY [M, out].  G: dY^T [out, Mp].
+    // Q operand by LDS-DMA.  FWD: x [M, in], K-major.  DX: dY [M, out], K-major.  G: dY [M, out] as it lies (the reduction runs
+    // down its rows: fragments by ds_read_b64_tr_b16).
     const uint16_t *Q;
     int64_t ldq;
-    int NQ, K;                    // K: in (FWD), out (DX), Mp (G); a multiple of 64
+    int NQ, K;                    // K: in (FWD), out (DX), M rounded up to 64 (G)
     // P operand.  FWD / DX: generated from W [out, in], mask [out, in], At16 [in, 16], B16 [out, 16].  G: x^T [in, Mp] by DMA.
     const uint16_t *W;
     int64_t ldw;
     const uint8_t *mask;
     const uint16_t *At16, *B16, *A16, *Bt16;
-    const uint16_t *Pt;
+    const uint16_t *Pt;           // G: x [M, in]
     int64_t ldp;
+    const uint16_t *zeros;        // G: 128 B of zeros (token rows past M)
+    int M;                        // G: tokens
     int NP;                       // out (FWD), in (DX), in (G)
     int out_f, in_f;
     float scaling;
@@ -74,7 +77,8 @@ struct LoraArgs {
     // G
     float *part_a, *part_b;       // [nbq][in][16], [nbp][out][16]
     int nbp, nbq, bq;             // bq: rows of Q per tile, 256 or 192
-    int dbg;                      // VLMC_LORA_DBG (diagnostics): 1 full wait before the generator, 2 full wait at the top of a step
+    int dbg;                      // VLMC_LORA_DBG (diagnostics; bits >= 4 give wrong results, only the pace is of interest): 1 full wait before
+                                  // the generator, 2 full wait at the top of a step, 4 no generator, 8 no W / mask / slab loads, 16 no Q loads
 };
 
 __device__ __forceinline__ int row_off(int row, int ch) { return row * ROWB + ((ch ^ (row & 7)) << 4); }
@@ -218,11 +222,28 @@ __global__ __launch_bounds__(NTH, 2) void lora_gemm_kernel(const LoraArgs a) {
     constexpr int NQP = BQ / 64;
     const uint16_t *srcq[NQP];
     uint32_t dstq[NQP];
+    int64_t qstep = BK;                                                   // elements per K-step along a source row / down the source rows
+    const uint16_t *srcq_tail[NQP];                                       // G mode: the last step's sources (token rows past M -> a row of zeros)
+    if constexpr (MODE == M_G) {
+        // dY [M, out] as it lies: 4 sub-images [64 tokens][64 out-features] for the transposing reads
+        qstep = int64_t(BK) * a.ldq;
+        const int tail_rows = a.M - (nk - 1) * BK;                        // token rows of the last step
 #pragma unroll
-    for (int v = 0; v < NQP; ++v) {
-        const int grp = wave * NQP + v, r = grp * 8 + (lane >> 3), sc = (lane & 7) ^ (r & 7);
-        srcq[v] = a.Q + int64_t(min(q0 + r, a.NQ - 1)) * a.ldq + sc * 8;
-        dstq[v] = grp * 1024;
+        for (int v = 0; v < NQP; ++v) {
+            const int grp = wave * NQP + v, sub = grp >> 3, r = (grp & 7) * 8 + (lane >> 3), sc = (lane & 7) ^ tr_swz(r);
+            const int col = min(q0 + sub * 64, a.out_f - 64) + sc * 8;
+            srcq[v] = a.Q + int64_t(r) * a.ldq + col;
+            srcq_tail[v] = r < tail_rows ? srcq[v] + int64_t(nk - 1) * qstep : a.zeros + sc * 8;
+            dstq[v] = sub * 8192 + (grp & 7) * 1024;
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < NQP; ++v) {
+            const int grp = wave * NQP + v, r = grp * 8 + (lane >> 3), sc = (lane & 7) ^ (r & 7);
+            srcq[v] = a.Q + int64_t(min(q0 + r, a.NQ - 1)) * a.ldq + sc * 8;
+            srcq_tail[v] = srcq[v];
+            dstq[v] = grp * 1024;
+        }
     }
     // the wave's own piece of W (or, G mode, its two pieces of x^T) and of the mask
     const uint16_t *srcw[2];
@@ -233,12 +254,18 @@ __global__ __launch_bounds__(NTH, 2) void lora_gemm_kernel(const LoraArgs a) {
     const uint16_t *srcs = nullptr;                                       // the step's rank-side fragments: 2 KiB, 256 B per wave
     u32x2_t cfrag[4] = {u32x2_t{0u, 0u}, u32x2_t{0u, 0u}, u32x2_t{0u, 0u}, u32x2_t{0u, 0u}};   // tile-constant rank-side fragments
     int gw0 = 0, gw1 = 0, gm = 0, gs = 0;                                 // where the generator reads / writes inside the slots
+    const uint16_t *srcw_tail[2] = {nullptr, nullptr};
     if constexpr (MODE == M_G) {
+        // x [M, in] as it lies: 2 sub-images [64 tokens][64 in-features]
+        wstep = int64_t(BK) * a.ldp;
+        const int tail_rows = a.M - (nk - 1) * BK;
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
-            const int grp = wave * 2 + v, r = grp * 8 + (lane >> 3), sc = (lane & 7) ^ (r & 7);
-            srcw[v] = a.Pt + int64_t(min(p0 + r, a.NP - 1)) * a.ldp + sc * 8;
-            dstw[v] = grp * 1024;
+            const int grp = wave * 2 + v, sub = grp >> 3, r = (grp & 7) * 8 + (lane >> 3), sc = (lane & 7) ^ tr_swz(r);
+            const int col = min(p0 + sub * 64, a.in_f - 64) + sc * 8;
+            srcw[v] = a.Pt + int64_t(r) * a.ldp + col;
+            srcw_tail[v] = r < tail_rows ? srcw[v] + int64_t(nk - 1) * wstep : a.zeros + sc * 8;
+            dstw[v] = sub * 8192 + (grp & 7) * 1024;
         }
     } else if constexpr (MODE == M_FWD) {
         // piece = rows p0 + 16 wave .. of W (K-major image rows 16 wave ..), the step's 64 columns
@@ -327,20 +354,28 @@ __global__ __launch_bounds__(NTH, 2) void lora_gemm_kernel(const LoraArgs a) {
     // there: an LDS-DMA costs its wave 60-180 cycles of issue, which the partner wave's MFMAs cover)
     auto multiply = [&](const unsigned char *pimg, const unsigned char *qimg, const int kk, auto &&before, auto &&between) {
         u32x4_t fq[TQ], fp[TP];
+        auto tr_frag = [&](const unsigned char *sub_img, int t) {         // 16 columns 16 t .. of a [64 k][64 n] image, k = 32 kk + 8 g ..
+            s16x4_t h[2];
 #pragma unroll
-        for (int j = 0; j < TQ; ++j) fq[j] = *reinterpret_cast<const u32x4_t *>(qimg + (kk ? fq1 : fq0) + j * 16 * ROWB);
-        if constexpr (MODE == M_DX) {
-#pragma unroll
-            for (int i = 0; i < TP; ++i) {
-                s16x4_t h[2];
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int row = 32 * kk + 8 * g + 4 * half + tq;
-                    const unsigned char *p = pimg + wp * 8192 + tr_off(row, 2 * i + (tp >> 1)) + 8 * (tp & 1);
-                    h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t *)(const_cast<unsigned char *>(p)));
-                }
-                __builtin_memcpy(&fp[i], h, 16);
+            for (int half = 0; half < 2; ++half) {
+                const int row = 32 * kk + 8 * g + 4 * half + tq;
+                const unsigned char *p = sub_img + tr_off(row, 2 * t + (tp >> 1)) + 8 * (tp & 1);
+                h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t *)(const_cast<unsigned char *>(p)));
             }
+            u32x4_t f;
+            __builtin_memcpy(&f, h, 16);
+            return f;
+        };
+        if constexpr (MODE == M_G) {
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) fq[j] = tr_frag(qimg + wq * 8192, j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) fq[j] = *reinterpret_cast<const u32x4_t *>(qimg + (kk ? fq1 : fq0) + j * 16 * ROWB);
+        }
+        if constexpr (MODE == M_DX || MODE == M_G) {
+#pragma unroll
+            for (int i = 0; i < TP; ++i) fp[i] = tr_frag(pimg + wp * 8192, i);
         } else {
 #pragma unroll
             for (int i = 0; i < TP; ++i) fp[i] = *reinterpret_cast<const u32x4_t *>(pimg + (kk ? fp1 : fp0) + i * 16 * ROWB);
@@ -360,10 +395,11 @@ __global__ __launch_bounds__(NTH, 2) void lora_gemm_kernel(const LoraArgs a) {
     // ---- the K loop ------------------------------------------------------------------------------------------------------------
     if constexpr (MODE == M_G) {
         constexpr int ND = 2 + NQP;
-        auto issue_piece = [&](int step, int v) {                         // v = 0, 1: x^T; 2 ..: dY^T
+        auto issue_piece = [&](int step, int v) {                         // v = 0, 1: x; 2 ..: dY
             const uint32_t slot = lds_base + (step % NSL) * SLOT;
-            if (v < 2) glds16(srcw[v] + step * BK, slot + dstw[v]);
-            else glds16(srcq[v - 2] + step * BK, slot + P_BYTES + dstq[v - 2]);
+            const bool tail = step == nk - 1;
+            if (v < 2) glds16(tail ? srcw_tail[v] : srcw[v] + step * wstep, slot + dstw[v]);
+            else glds16(tail ? srcq_tail[v - 2] : srcq[v - 2] + step * qstep, slot + P_BYTES + dstq[v - 2]);
         };
         for (int st = 0; st < 2 && st < nk; ++st)
 #pragma unroll
@@ -405,22 +441,24 @@ __global__ __launch_bounds__(NTH, 2) void lora_gemm_kernel(const LoraArgs a) {
             else wait_vm_plain<4>();                                      // own pieces of Q(d) -- and everything older: slab(d + 1)
             barrier();                                                    // everybody's have; W_eff(d) stands
             const unsigned char *pimg = lds + POFF + (d % 3) * P_BYTES, *qimg = lds + QOFF + (d & 1) * Q_BYTES;
-            multiply(pimg, qimg, 0, nothing, [&](int i) { if (i < NQP) issue_q1(d + 1, i); });
-            const bool gen = d < last;
+            multiply(pimg, qimg, 0, nothing, [&](int i) { if (i < NQP && !(a.dbg & 16)) issue_q1(d + 1, i); });
+            const bool gen = d < last && !(a.dbg & 4);
             multiply(pimg, qimg, 1,
                      [&] {
                          if (gen) {
                              if (a.dbg & 1) wait_vm_plain<0>();
-                             else wait_vm_plain<NQP + 1>();               // the own piece of step d + 1 (behind it: slab(d + 2), Q(d + 1))
+                             else if (!(a.dbg & 32)) wait_vm_plain<NQP + 1>();               // the own piece of step d + 1 (behind it: slab(d + 2), Q(d + 1))
                              gen_load(d + 1);
                          }
                      },
                      [&](int i) {
-                         if (i == 0) issue_w1(d + 2, 0);
-                         else if (i == 1) issue_w1(d + 2, 1);
-                         else if (i == 2) issue_m1(d + 2);
-                         else issue_slab(d + 3);
-                         if (i == 1 && gen) gen_finish(d + 1);
+                         if (!(a.dbg & 8)) {
+                             if (i == 0) issue_w1(d + 2, 0);
+                             else if (i == 1) issue_w1(d + 2, 1);
+                             else if (i == 2) issue_m1(d + 2);
+                             else issue_slab(d + 3);
+                         }
+                         if (i == 1 && gen && !(a.dbg & 64)) gen_finish(d + 1);
                      });
         }
         wait_vm_plain<0>();                                               // (the clamped tail loads)
@@ -559,9 +597,10 @@ __global__ __launch_bounds__(NTH, 2) void lora_gemm_kernel(const LoraArgs a) {
 template <typename T>
 __global__ __launch_bounds__(256) void lora_prep_kernel(const float *__restrict__ A, const float *__restrict__ B, int out_f, int in_f, int r,
                                                         uint16_t *__restrict__ At16, uint16_t *__restrict__ A16, uint16_t *__restrict__ B16,
-                                                        uint16_t *__restrict__ Bt16) {
+                                                        uint16_t *__restrict__ Bt16, uint16_t *__restrict__ zeros) {
     const int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x;
     const int64_t na = int64_t(in_f) * RP, nb = int64_t(out_f) * RP;
+    if (idx < 128) zeros[idx] = 0;
     if (idx < na) {
         const int i = int(idx / RP), j = int(idx % RP);
         const uint16_t v = j < r ? from_f32<T>(A[int64_t(j) * in_f + i]) : uint16_t(0);
@@ -576,35 +615,6 @@ __global__ __launch_bounds__(256) void lora_prep_kernel(const float *__restrict_
     }
 }
 
-// x [rows, C] 16-bit -> x^T [C, ldt], tokens past `rows` written as zeros up to Tpad (as gemm_nt.hip's transpose16_kernel)
-__global__ __launch_bounds__(256) void lora_transpose16_kernel(const uint16_t *__restrict__ x, int64_t ldx, int rows, int C,
-                                                               uint16_t *__restrict__ pt, int64_t ldt, int Tpad) {
-    __shared__ uint16_t tile[64][72];
-    const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int piece = tid + h * 256, r = piece >> 3, cc = (piece & 7) * 8;
-        const int t = t0 + r, cidx = c0 + cc;
-        u32x4_t v = {0u, 0u, 0u, 0u};
-        if (t < rows && cidx + 7 < C) v = *reinterpret_cast<const u32x4_t *>(x + int64_t(t) * ldx + cidx);
-        *reinterpret_cast<u32x4_t *>(&tile[r][cc]) = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int piece = tid + h * 256, cr = piece >> 3, tt = (piece & 7) * 8;
-        const int cidx = c0 + cr, t = t0 + tt;
-        if (cidx >= C || t >= Tpad) continue;
-        uint16_t e[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = tile[tt + j][cr];
-        u32x4_t v;
-        __builtin_memcpy(&v, e, 16);
-        *reinterpret_cast<u32x4_t *>(pt + int64_t(cidx) * ldt + t) = v;
-    }
-}
-
 // dA[j][i] = wd(sum_bq part_a[bq][i][j]),  dB[o][j] = wd(sum_bp part_b[bp][o][j]): tiles in order
 template <typename T>
 __global__ __launch_bounds__(256) void lora_partial_reduce_kernel(const float *__restrict__ part_a, int nbq, const float *__restrict__ part_b,
@@ -612,24 +622,29 @@ __global__ __launch_bounds__(256) void lora_partial_reduce_kernel(const float *_
                                                                   float *__restrict__ dB) {
     const int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x;
     const int64_t na = int64_t(in_f) * RP, nb = int64_t(out_f) * RP;
-    if (idx < na) {
-        const int i = int(idx / RP), j = int(idx % RP);
-        if (j >= r || dA == nullptr) return;
-        float v = 0.f;
-        for (int t = 0; t < nbq; ++t) v = ieee_add(v, part_a[int64_t(t) * na + idx]);
-        dA[int64_t(j) * in_f + i] = round16<T>(v);
-    } else if (idx < na + nb) {
-        const int64_t e = idx - na;
-        const int o = int(e / RP), j = int(e % RP);
-        if (j >= r || dB == nullptr) return;
-        float v = 0.f;
-        for (int t = 0; t < nbp; ++t) v = ieee_add(v, part_b[int64_t(t) * nb + e]);
-        dB[int64_t(o) * r + j] = round16<T>(v);
+    const bool is_a = idx < na;
+    if (!is_a && idx >= na + nb) return;
+    const int64_t e = is_a ? idx : idx - na, n = is_a ? na : nb;
+    const int row = int(e / RP), j = int(e % RP), tiles = is_a ? nbq : nbp;
+    float *out = is_a ? dA : dB;
+    if (j >= r || out == nullptr) return;
+    const float *part = (is_a ? part_a : part_b) + e;
+    float v = 0.f;
+    int t = 0;
+    for (; t + 8 <= tiles; t += 8) {                                      // 8 loads in flight, added in tile order
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = part[int64_t(t + u) * n];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v = ieee_add(v, x[u]);
     }
+    for (; t < tiles; ++t) v = ieee_add(v, part[int64_t(t) * n]);
+    if (is_a) dA[int64_t(j) * in_f + row] = round16<T>(v);
+    else dB[int64_t(row) * r + j] = round16<T>(v);
 }
 
 struct PrepLayout {
-    size_t at16, a16, b16, bt16, total;
+    size_t at16, a16, b16, bt16, zeros, total;
 };
 PrepLayout prep_layout(int64_t out_f, int64_t in_f) {
     PrepLayout l;
@@ -638,7 +653,8 @@ PrepLayout prep_layout(int64_t out_f, int64_t in_f) {
     l.a16 = na;
     l.b16 = 2 * na;
     l.bt16 = 2 * na + nb;
-    l.total = 2 * na + 2 * nb;
+    l.zeros = 2 * na + 2 * nb;                    // 256 B of zeros: the token rows past M of the weight-gradient GEMM are read from here
+    l.total = l.zeros + 256;
     return l;
 }
 
@@ -754,9 +770,11 @@ extern "C" int vlmc_sparse_lora_prep(const float *A, const float *B, int64_t out
     uint16_t *at16 = reinterpret_cast<uint16_t *>(p + l.at16), *a16 = reinterpret_cast<uint16_t *>(p + l.a16);
     uint16_t *b16 = reinterpret_cast<uint16_t *>(p + l.b16), *bt16 = reinterpret_cast<uint16_t *>(p + l.bt16);
     if (ab_code == 1)
-        hipLaunchKernelGGL(lora_prep_kernel<f16_t>, grid, dim3(256), 0, as_stream(stream), A, B, int(out_features), int(in_features), r, at16, a16, b16, bt16);
+        hipLaunchKernelGGL(lora_prep_kernel<f16_t>, grid, dim3(256), 0, as_stream(stream), A, B, int(out_features), int(in_features), r, at16, a16, b16, bt16,
+                           reinterpret_cast<uint16_t *>(p + l.zeros));
     else
-        hipLaunchKernelGGL(lora_prep_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), A, B, int(out_features), int(in_features), r, at16, a16, b16, bt16);
+        hipLaunchKernelGGL(lora_prep_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), A, B, int(out_features), int(in_features), r, at16, a16, b16, bt16,
+                           reinterpret_cast<uint16_t *>(p + l.zeros));
     VLMC_HIP_CHECK_LAUNCH("vlmc_sparse_lora_prep");
     return VLMC_OK;
 }
@@ -815,19 +833,14 @@ extern "C" int vlmc_sparse_lora_bwd_input(const void *dY, int64_t M, int64_t ldd
 
 namespace {
 struct GradWs {
-    size_t dyt, xt, part_a, part_b, total;
-    int64_t mp;
-    int nbp, nbq, bq;             // bq: rows of Q per tile, 256 or 192
-    int dbg;                      // VLMC_LORA_DBG (diagnostics): 1 full wait before the generator, 2 full wait at the top of a step
+    size_t part_a, part_b, total;
+    int nbp, nbq;
 };
-GradWs grad_ws(int64_t M, int64_t out_f, int64_t in_f) {
+GradWs grad_ws(int64_t out_f, int64_t in_f) {
     GradWs w;
-    w.mp = (M + 63) / 64 * 64;
     w.nbp = int((in_f + BP - 1) / BP);
     w.nbq = int((out_f + 255) / 256);
-    w.dyt = 0;
-    w.xt = round_up(size_t(out_f) * size_t(w.mp) * 2, 256);
-    w.part_a = w.xt + round_up(size_t(in_f) * size_t(w.mp) * 2, 256);
+    w.part_a = 0;
     w.part_b = w.part_a + round_up(size_t(w.nbq) * size_t(in_f) * RP * 4, 256);
     w.total = w.part_b + round_up(size_t(w.nbp) * size_t(out_f) * RP * 4, 256);
     return w;
@@ -836,7 +849,7 @@ GradWs grad_ws(int64_t M, int64_t out_f, int64_t in_f) {
 
 extern "C" size_t vlmc_sparse_lora_bwd_weight_workspace(int64_t M, int64_t out_features, int64_t in_features) {
     if (M <= 0 || out_features <= 0 || in_features <= 0) return 0;
-    return grad_ws(M, out_features, in_features).total;
+    return grad_ws(out_features, in_features).total;
 }
 
 extern "C" int vlmc_sparse_lora_bwd_weight(const void *dY, int64_t lddy, const void *X, int64_t ldx, int64_t M, int dtype, int64_t out_features,
@@ -847,28 +860,24 @@ extern "C" int vlmc_sparse_lora_bwd_weight(const void *dY, int64_t lddy, const v
                  "vlmc_sparse_lora_bwd_weight: dY and X must be 16-byte aligned with row strides that are multiples of 8");
     VLMC_REQUIRE(M > 0 && M < (int64_t(1) << 24), "vlmc_sparse_lora_bwd_weight: bad M");
     VLMC_REQUIRE(dA || dB, "vlmc_sparse_lora_bwd_weight: nothing to compute");
-    const GradWs w = grad_ws(M, out_features, in_features);
+    const GradWs w = grad_ws(out_features, in_features);
     if (!workspace || workspace_bytes < w.total || (reinterpret_cast<uintptr_t>(workspace) & 255u)) {
         set_error("vlmc_sparse_lora_bwd_weight: a 256-byte aligned workspace of %zu bytes is needed, %zu given", w.total, workspace_bytes);
         return VLMC_EWORKSPACE;
     }
     hipStream_t s = as_stream(stream);
     char *ws = static_cast<char *>(workspace);
-    uint16_t *dyt = reinterpret_cast<uint16_t *>(ws + w.dyt), *xt = reinterpret_cast<uint16_t *>(ws + w.xt);
-    const unsigned tb = unsigned(w.mp / 64);
-    hipLaunchKernelGGL(lora_transpose16_kernel, dim3(tb, unsigned(out_features / 64)), dim3(256), 0, s, static_cast<const uint16_t *>(dY), lddy,
-                       int(M), int(out_features), dyt, w.mp, int(w.mp));
-    hipLaunchKernelGGL(lora_transpose16_kernel, dim3(tb, unsigned(in_features / 64)), dim3(256), 0, s, static_cast<const uint16_t *>(X), ldx,
-                       int(M), int(in_features), xt, w.mp, int(w.mp));
     LoraArgs a{};
     fill_common(a, nullptr, in_features, mask, prep, out_features, in_features, scaling, sparse, dtype);
-    a.Q = dyt;
-    a.ldq = w.mp;
+    a.Q = static_cast<const uint16_t *>(dY);
+    a.ldq = lddy;
     a.NQ = int(out_features);
-    a.K = int(w.mp);
-    a.Pt = xt;
-    a.ldp = w.mp;
+    a.M = int(M);
+    a.K = int((M + BK - 1) / BK * BK);
+    a.Pt = static_cast<const uint16_t *>(X);
+    a.ldp = ldx;
     a.NP = int(in_features);
+    a.zeros = reinterpret_cast<const uint16_t *>(static_cast<const char *>(prep) + prep_layout(out_features, in_features).zeros);
     a.part_a = reinterpret_cast<float *>(ws + w.part_a);
     a.part_b = reinterpret_cast<float *>(ws + w.part_b);
     a.nbp = w.nbp;
