@@ -123,11 +123,12 @@ def prune_unstructured(W, stat, ratio, *, initial_method="wanda", without_DSnoT=
 
 @torch.no_grad()
 def prune_nm(W, stat, n, m_, *, initial_method="wanda", max_cycle_time=100, update_threshold=0.1,
-             pow_of_var_regrowing=1.0, trace=None):
+             pow_of_var_regrowing=1.0, trace=None, ties="torch_cpu"):
     """n:m branch (:407-552).  Group order by stable sort (the reference's torch.sort is unstable on ties).
     `trace` (a dict): receives "tie_rows", the rows whose walk met an m-group whose two smallest metrics were EQUAL when
     `torch.topk(pruning_block, 1, largest=False)` (:517-519) had to pick one -- an exhausted group, both kept entries already
-    at rowmax + 1: implementation-defined in the reference, lowest column here (tests/test_nm_ties.py)."""
+    at rowmax + 1 = +inf.  `ties="torch_cpu"` (default): the entry the reference's CPU run picks (oracle/topk_order.py);
+    `ties="lowest"`: the lowest column (the rule of rounds 1-4)."""
     D, _, init = _metrics(W, stat, initial_method)
     init = init.clone().float()
     out_f, in_f = init.shape
@@ -163,7 +164,12 @@ def prune_nm(W, stat, n, m_, *, initial_method="wanda", max_cycle_time=100, upda
         srt = torch.sort(block, dim=1, stable=True)
         if trace is not None:
             trace.setdefault("tie_rows", set()).update(torch.nonzero(srt[0][:, 0] == srt[0][:, 1]).flatten().tolist())
-        p = start + srt[1][:, 0]                                            # smallest kept metric of r's group
+        pick = srt[1][:, 0].clone()                                         # smallest kept metric of r's group
+        if ties == "torch_cpu":
+            from . import topk_order
+            for rr in torch.nonzero(srt[0][:, 0] == srt[0][:, 1]).flatten().tolist():
+                pick[rr] = topk_order.smallest(block[rr].tolist(), 1)[0]
+        p = start + pick
         Dp = D[rows, p].unsqueeze(1)
         after = err + Dp - Dr
         u = u & (sign0 == torch.sign(after)) & (err.abs() > update_threshold)

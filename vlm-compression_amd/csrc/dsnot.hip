@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "topk_order.hpp"
 
 namespace vlmc {
 
@@ -343,32 +344,34 @@ __global__ __launch_bounds__(64 * NW) void dsnot_simulate_kernel(
         // ---- prune candidate ---------------------------------------------------------------------
         Best pb{0, 0xFFFFFFFFu, 0.f};
         if constexpr (NM) {
-            // smallest metric among the currently kept columns of r's m-group (ties -> lowest column)
+            // `torch.topk(pruning_block, 1, largest=False)` over r's m-group (:517-519): kept columns carry their metric,
+            // pruned and already taken ones +inf; equal minima (an exhausted group is all +inf) are decided as the
+            // reference's CPU run decides them (topk_order.hpp)
             const uint32_t g0 = rcol - rcol % uint32_t(prune_m);
             if (uint32_t(tid) == (rcol / 8) % NT) {          // the m-group lies inside one lane's 8-column chunk
+                uint32_t gkey[8];
+                float gd[8];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) { gkey[a] = 0x7F800000u; gd[a] = 0.f; }
 #pragma unroll
                 for (int i = 0; i < E; ++i) {
                     const uint32_t col = uint32_t((i / 8) * NT * 8 + tid * 8 + (i % 8));
-                    if (((kept_now >> i) & 1u) && col >= g0 && col < g0 + uint32_t(prune_m)) {
-                        const Best c2{wk[i], col, D[i]};
-                        if (better(c2, pb, true)) pb = c2;
+                    if (col >= g0 && col < g0 + uint32_t(prune_m)) {
+#pragma unroll
+                        for (int a = 0; a < 8; ++a)
+                            if (uint32_t(a) == col - g0) {
+                                gkey[a] = ((kept_now >> i) & 1u) ? wk[i] : 0x7F800000u;
+                                gd[a] = D[i];
+                            }
                     }
                 }
+                const int pick = torch_cpu_argmin(gkey, prune_m);
+                float pd = 0.f;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) pd = a == pick ? gd[a] : pd;
+                pb = Best{0u, g0 + uint32_t(pick), pd};
             }
             pb = block_best<NW>(pb, true, sm, phase);
-            if (pb.col == 0xFFFFFFFFu) {
-                // every column of the group already carries the "taken" value: torch.topk over equal
-                // entries -> first column of the group
-                pb.col = g0;
-#pragma unroll
-                for (int i = 0; i < E; ++i) {
-                    const uint32_t col = uint32_t((i / 8) * NT * 8 + tid * 8 + (i % 8));
-                    pb.d = col == g0 ? D[i] : pb.d;
-                }
-                Best tmp{0, (pb.col / 8) % NT == uint32_t(tid) ? 0u : 0xFFFFFFFFu, pb.d};
-                tmp = block_best<NW>(tmp, true, sm, phase);
-                pb.d = tmp.d;
-            }
         } else {
             const bool p_tail = err < 0.f;
             const uint32_t pos = p_tail ? tpos : hpos;       // steps already taken from that end

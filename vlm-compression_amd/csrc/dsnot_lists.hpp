@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "topk_order.hpp"
 
 namespace vlmc {
 
@@ -58,11 +59,12 @@ struct ListEntry {
     uint32_t col;
     float d;
 };
-struct GroupInfo {                   // n:m: the kept columns of an entry's m-group, ascending (metric, column)
+struct GroupInfo {                   // n:m: the kept columns of an entry's m-group in the order successive visits take them
     uint16_t col[kGroupMax];
     float d[kGroupMax];
-    float d0;                        // D of the group's first column (the "all taken" fallback)
-    uint32_t n;
+    float dx;                        // D of the column a visit of the exhausted group picks (all metrics +inf)
+    uint16_t colx;
+    uint16_t n;
 };
 
 constexpr int kFastBinsLog2 = 10;
@@ -644,19 +646,32 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((NW == 
                 key[a] = score_key(use_wanda_init ? ieee_mul(fabsf(w), sqrt_scaler[c]) : fabsf(w));
                 kept[a] = in && krow[c] != 0;
             }
-            gi.d0 = d[0];
+            // visit v takes what `torch.topk(block, 1, largest=False)` returns for the group's current metrics (:517-519) -- kept
+            // columns their metric, pruned and taken ones +inf; equal minima in the reference's CPU order (topk_order.hpp) --
+            // and marks it taken (:531).  Once nothing kept is left every visit picks the same column of the all-+inf group.
+            uint32_t v[kGroupMax];
             gi.n = 0;
 #pragma unroll
             for (int a = 0; a < kGroupMax; ++a) {
-                uint32_t r = 0;
+                v[a] = kept[a] ? key[a] : 0x7F800000u;
+                gi.n += kept[a] ? 1 : 0;
+            }
+#pragma unroll 1
+            for (int visit = 0; visit <= kGroupMax; ++visit) {
+                const int pick = torch_cpu_argmin(v, prune_m);
+                float pd = 0.f;
 #pragma unroll
-                for (int b2 = 0; b2 < kGroupMax; ++b2)
-                    r += (kept[b2] && (key[b2] < key[a] || (key[b2] == key[a] && b2 < a))) ? 1u : 0u;
-                if (kept[a]) {
+                for (int a = 0; a < kGroupMax; ++a) pd = a == pick ? d[a] : pd;
+                if (visit < int(gi.n)) {
 #pragma unroll
-                    for (int slot = 0; slot < kGroupMax; ++slot)       // r is a run-time value: select the slot by compare
-                        if (uint32_t(slot) == r) { gi.col[slot] = uint16_t(g0 + uint32_t(a)); gi.d[slot] = d[a]; }
-                    ++gi.n;
+                    for (int slot = 0; slot < kGroupMax; ++slot)
+                        if (slot == visit) { gi.col[slot] = uint16_t(g0 + uint32_t(pick)); gi.d[slot] = pd; }
+#pragma unroll
+                    for (int a = 0; a < kGroupMax; ++a) v[a] = a == pick ? 0x7F800000u : v[a];
+                } else {
+                    gi.colx = uint16_t(g0 + uint32_t(pick));
+                    gi.dx = pd;
+                    break;
                 }
             }
             sm.grp[li][rank] = gi;
@@ -771,7 +786,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((NW == 
             if (cnt < gi.n) {
                 pcol = gi.col[cnt]; pd = gi.d[cnt];
             } else {
-                pcol = g0; pd = gi.d0;                       // every kept column of the group is taken (dsnot.hip)
+                pcol = gi.colx; pd = gi.dx;                  // every kept column of the group is taken: all metrics equal
             }
             // a visit consumes a kept column only while one is left: the fallback does not
             if (lane == 0) sm.cyc_group[t] = cnt < gi.n ? g0 : 0xFFFFFFFFu;

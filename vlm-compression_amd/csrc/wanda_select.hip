@@ -22,6 +22,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "topk_order.hpp"
 
 namespace vlmc {
 
@@ -1523,6 +1524,7 @@ __global__ __launch_bounds__(256) void nm_kernel(const SelBatch b) {
         uint32_t keepbits = 0;
 #pragma unroll
         for (int g = 0; g < 8 / M; ++g) {
+            uint32_t prunedbits = 0, at_n = 0, at_n1 = 0;                    // keys of stable ranks n - 1 and n
 #pragma unroll
             for (int i = 0; i < M; ++i) {
                 // stable rank of column i inside its group: smaller key first, then lower index
@@ -1532,7 +1534,20 @@ __global__ __launch_bounds__(256) void nm_kernel(const SelBatch b) {
                     const uint32_t kj = key[g * M + j], ki = key[g * M + i];
                     rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0;
                 }
-                const bool pruned = rank < n && (ALIGNED || col0 + g * M + i < in_f);
+                prunedbits |= (rank < n ? 1u : 0u) << i;
+                at_n = rank == n - 1 ? key[g * M + i] : at_n;
+                at_n1 = rank == n ? key[g * M + i] : at_n1;
+            }
+            // a tie across the selection boundary: the columns `torch.topk` returns on the CPU (topk_order.hpp)
+            if (M > 2 && n > 0 && n < M && at_n == at_n1) {
+                uint32_t gk[M];
+#pragma unroll
+                for (int i = 0; i < M; ++i) gk[i] = key[g * M + i];
+                prunedbits = torch_cpu_smallest<M>(gk, n);
+            }
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                const bool pruned = ((prunedbits >> i) & 1u) && (ALIGNED || col0 + g * M + i < in_f);
                 keepbits |= (pruned ? 0u : 1u) << (g * M + i);
                 if (pruned) raw.v[g * M + i] = typename T::raw(0);
             }
