@@ -106,6 +106,40 @@ static int cmp_u32(const void *a, const void *b) {
 
 /* mode 0: per-row k smallest (stable); 1: matrix-wide strict threshold at flat rank k; 2: n of m.
  * mask: 1 = keep.  score_sum (optional) receives sum(score) in double.  Returns 0 / -1. */
+/* libstdc++'s std::nth_element (bits/stl_algo.h: __introselect) on (key, index) pairs ordered by key: median of
+   (first + 1, middle, last - 1) to first, unguarded partition, while more than 3 elements remain; then an insertion sort.
+   (The depth limit 2 lg(len) is not reached for the group sizes of the n:m rules, m <= 8.) */
+static void swap_kv(kv_t *a, kv_t *b) { kv_t t = *a; *a = *b; *b = t; }
+static void nth_element_kv(kv_t *q, int len, int nth) {
+    int first = 0, last = len;
+    while (last - first > 3) {
+        int a = first + 1, b = first + (last - first) / 2, c = last - 1, pick;
+        if (q[a].key < q[b].key) pick = q[b].key < q[c].key ? b : (q[a].key < q[c].key ? c : a);
+        else pick = q[a].key < q[c].key ? a : (q[b].key < q[c].key ? c : b);
+        swap_kv(&q[first], &q[pick]);
+        int f = first + 1, l = last;
+        for (;;) {
+            while (q[f].key < q[first].key) ++f;
+            --l;
+            while (q[first].key < q[l].key) --l;
+            if (!(f < l)) break;
+            swap_kv(&q[f], &q[l]);
+            ++f;
+        }
+        if (f <= nth) first = f; else last = f;
+    }
+    for (int i = first + 1; i < last; ++i) {
+        kv_t v = q[i];
+        int j = i;
+        if (v.key < q[first].key) {
+            for (; j > first; --j) q[j] = q[j - 1];
+        } else {
+            while (v.key < q[j - 1].key) { q[j] = q[j - 1]; --j; }
+        }
+        q[j] = v;
+    }
+}
+
 int wo_select(void *W, int dtype, int64_t out_f, int64_t in_f, const float *scaler_row, int mode, int64_t k, int n, int m,
               int apply_zero, uint8_t *mask, double *score_sum) {
     float *sq = (float *)malloc((size_t)in_f * sizeof(float));
@@ -145,8 +179,11 @@ int wo_select(void *W, int dtype, int64_t out_f, int64_t in_f, const float *scal
                 for (int64_t c = 0; c < in_f; ++c)
                     if (kv[c].key < thr) mask[r * in_f + c] = 0;
         } else {
+            /* torch.topk(group, n, largest=False) on the CPU: std::nth_element(begin, begin + n - 1, end) on (value, index)
+               pairs, the n pairs in front are the answer -- equal keys in the order libstdc++'s introselect leaves them
+               (oracle/topk_order.py has the provenance) */
             for (int64_t g = 0; g < in_f; g += m) {
-                merge_sort(kv + g, kv + in_f, m);
+                if (n > 0) nth_element_kv(kv + g, m, n - 1);
                 for (int i = 0; i < n; ++i) mask[r * in_f + kv[g + i].idx] = 0;
             }
         }

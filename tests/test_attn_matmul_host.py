@@ -88,3 +88,34 @@ def test_switch_turns_the_patches_off(monkeypatch):
     orig = torch.matmul
     with forward.invariant_matmuls():
         assert torch.matmul is orig and "__matmul__" not in torch.Tensor.__dict__
+
+
+def test_other_threads_see_the_original_functions_through_the_patches():
+    """the attribute patches are process-wide, their routing is the installing thread's only -- a product
+    issued by another thread while a replay holds the patches is neither counted nor routed, and a second thread entering the
+    context meanwhile runs unpatched and leaves the first one's patches in place."""
+    import threading
+    x, y = torch.randn(2, 3, 4), torch.randn(2, 4, 5)
+    want = x @ y
+    seen = {}
+
+    def other():
+        before = dict(forward.stats)
+        with torch.no_grad():
+            seen["eq"] = torch.equal(x @ y, want) and torch.equal(torch.matmul(x, y), want) and torch.equal(x.float().mean(-1), x.mean(-1))
+            with forward.invariant_matmuls():                     # a second holder: runs unpatched, must not unpatch the first
+                seen["eq2"] = torch.equal(torch.bmm(x, y), want)
+        seen["counted"] = forward.stats["attn_library"] - before["attn_library"] + forward.stats["attn_kernel"] - before["attn_kernel"]
+
+    with forward.invariant_matmuls():
+        patched = torch.matmul
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        assert torch.matmul is patched and "__matmul__" in torch.Tensor.__dict__      # still installed for this thread
+        before = forward.stats["attn_library"]
+        with torch.no_grad():
+            x @ y
+        assert forward.stats["attn_library"] == before + 1                             # and still routing it
+    assert seen == {"eq": True, "eq2": True, "counted": 0}
+    assert "__matmul__" not in torch.Tensor.__dict__

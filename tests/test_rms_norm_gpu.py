@@ -103,6 +103,29 @@ def test_look_alikes_keep_their_own_forward(cls, monkeypatch):
     assert torch.equal(got, want)
 
 
+def test_a_look_alike_with_an_all_ones_weight_is_not_whitelisted(monkeypatch):
+    """the verdict is cached per class -- a fresh norm (weight all ones) of a class that rounds AFTER the product
+    with the weight compares equal to the fused kernel with its own weight; the self-check uses a random weight instead, so the
+    class is refused and a sibling with a trained weight keeps its own forward."""
+    from vlmc import forward
+    monkeypatch.setenv("VLMC_LINEAR_FWD", "1")
+    forward._NORM_OK.clear()
+    fresh = Block(Fp32ProductNorm, 640, torch.bfloat16).to(DEV).eval()
+    with torch.no_grad():
+        fresh.norm.weight.fill_(1.0)
+    trained = Block(Fp32ProductNorm, 640, torch.bfloat16).to(DEV).eval()
+    x = torch.randn(4, 7, 640, device=DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        s0 = forward.stats["norm_kernel"]
+        with forward.invariant_linears([fresh.lin], roots=(fresh,)):
+            fresh.norm(x)
+        want = trained.norm(x)
+        with forward.invariant_linears([trained.lin], roots=(trained,)):
+            got = trained.norm(x)
+    assert forward.stats["norm_kernel"] == s0 and torch.equal(got, want)
+    assert torch.equal(fresh.norm.weight, torch.ones_like(fresh.norm.weight))      # the module got its own weight back
+
+
 def test_whole_prune_is_bit_identical_with_and_without_the_fused_norm(monkeypatch):
     """The synthetic InstructBLIP's T5 blocks carry T5LayerNorm's op sequence: a small Wanda prune with the norm fused and with
     the seven launches gives the same masks and weights."""

@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import contextlib
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -97,6 +98,29 @@ graph_stats = {"captured": 0, "replayed": 0, "fallbacks": 0, "memo_recorded": 0,
 MEMO_MAX_BYTES = 4 << 30
 
 
+class _PruneContext(threading.local):
+    """What a running prune keeps BETWEEN the functions of this module -- per calling thread, so that two prunes driven from two
+    threads (each on its own device / stream) do not see each other's state (SURVEY.md 8(b): re-entrant per (device, stream);
+    rounds 1-4 kept these in five module globals):
+      later           the capture phase's _LaterEqual, or None: compare remembered tower inputs at once
+      capture_slot    the capture side stream a calibration forward runs on (picks the graph instance and its static buffers)
+      capture_sample  index (within this rank's share) of the calibration forward capture_block_inputs is running
+      stacked         (samples, batch per sample, sample indices) of the grouped block forward under way (stacked_samples())
+      capture_side    device -> the side stream graphs are captured on
+      stream_set      the caller's stream and the capture side streams of the running capture phase"""
+
+    def __init__(self):
+        self.later = None
+        self.capture_slot = None
+        self.capture_sample = None
+        self.stacked = None
+        self.capture_side = {}
+        self.stream_set = ()
+
+
+_CTX = _PruneContext()
+
+
 class _LaterEqual:
     """Bit-for-bit comparisons whose answer is collected at the end of a capture phase instead of one device round trip
     per calibration forward (`torch.equal` waits for the GPU: 2-3 of them per forward were 40 ms of a FlanT5-XL prune).
@@ -132,12 +156,11 @@ class _LaterEqual:
         return False
 
 
-_LATER = None                 # the capture phase's _LaterEqual, or None: compare at once
 
 
 def _bits_equal(r, v):
-    if _LATER is not None and r.is_cuda:
-        return _LATER.same(r, v)
+    if _CTX.later is not None and r.is_cuda:
+        return _CTX.later.same(r, v)
     return r.shape == v.shape and r.dtype == v.dtype and r.device == v.device and bool(torch.equal(r, v))
 
 
@@ -236,8 +259,8 @@ class TowerMemo:
         if index == 0:
             self.expect, self.hit, self.pending = 0, None, None
             # which calibration forward this is: the capture loop says so (it may run a forward twice); else they are counted
-            if _CAPTURE_SAMPLE is not None:
-                self.current = _CAPTURE_SAMPLE
+            if _CTX.capture_sample is not None:
+                self.current = _CTX.capture_sample
             else:
                 self.current, self.cursor = self.cursor, self.cursor + 1
         if index != self.expect:                                   # blocks skipped or repeated inside one forward
@@ -309,7 +332,6 @@ def seed_tower_memo(proxy_cache, module_to_process, layers, final_outs, autocast
     return True
 
 
-_capture_side = {}
 
 
 def capture_graph(fn, device):
@@ -318,9 +340,9 @@ def capture_graph(fn, device):
     the capture itself needs none of it."""
     graph = torch.cuda.CUDAGraph()
     cur = torch.cuda.current_stream(device)
-    side = _capture_side.get(device)
+    side = _CTX.capture_side.get(device)
     if side is None:
-        side = _capture_side[device] = torch.cuda.Stream(device=device)
+        side = _CTX.capture_side[device] = torch.cuda.Stream(device=device)
     side.wait_stream(cur)
     with torch.cuda.stream(side):
         graph.capture_begin(capture_error_mode="thread_local")
@@ -339,7 +361,6 @@ def capture_graph(fn, device):
 
 # Capture phases run the calibration forwards round-robin on a few side streams (capture_streams()); the slot a forward
 # runs in picks the graph instance -- and with it the static buffers -- its proxies replay (None: the caller's stream).
-_CAPTURE_SLOT = None
 
 
 def capture_streams():
@@ -354,8 +375,6 @@ def capture_streams():
         return 1
 
 
-# Index (within this rank's share) of the calibration forward that capture_block_inputs is running; None outside of it.
-_CAPTURE_SAMPLE = None
 
 
 class _Defer(ValueError):
@@ -478,8 +497,8 @@ class TowerGraph:
                 if self.btrace is not None:
                     return self._batched_step(0, args, kwargs)
                 return False, None
-            if _CAPTURE_SAMPLE is not None and tower_batch_enabled():
-                r = self.ready.pop(_CAPTURE_SAMPLE, None)
+            if _CTX.capture_sample is not None and tower_batch_enabled():
+                r = self.ready.pop(_CTX.capture_sample, None)
                 if r is not None:
                     if r.get("key", key) == key and self._same_inputs(r, args, kwargs):
                         given, k, seen = {}, 0, set()
@@ -491,12 +510,12 @@ class TowerGraph:
                         self.live = {"outs": r["outs"], "calls": wiring, "given": given, "clone": False}
                         return True, self._hand_out(0)
                 elif self._batchable(args, kwargs):
-                    self.deferred.append({"j": _CAPTURE_SAMPLE, "key": key, "args": args, "kwargs": kwargs,
+                    self.deferred.append({"j": _CTX.capture_sample, "key": key, "args": args, "kwargs": kwargs,
                                           "ctx": TowerMemo.context()})
                     raise _Defer
-            plan = self.plans.get((_CAPTURE_SLOT, key))
+            plan = self.plans.get((_CTX.capture_slot, key))
             if plan is None:                                              # one graph (and its buffers) per stream slot
-                plan = self.plans[(_CAPTURE_SLOT, key)] = self._build(wiring, args, kwargs)
+                plan = self.plans[(_CTX.capture_slot, key)] = self._build(wiring, args, kwargs)
             if plan is False:
                 return False, None
             return self._replay(plan, args, kwargs)
@@ -516,7 +535,7 @@ class TowerGraph:
     # output nor an outside tensor nor a plain value, a handed-out tensor written to, blocks out of order) ends the batched
     # trace: from that block on the forward runs eagerly, as a plain trace does, and nothing is kept for the others.
     def _begin_batched_trace(self, key, args, kwargs, ext):
-        j = _CAPTURE_SAMPLE
+        j = _CTX.capture_sample
         if self.NEED != 1 or j is None or not (tower_batch_enabled() and tower_predict_enabled()) or self.memo_serves or \
                 os.environ.get("VLMC_TOWER_BATCHED_TRACE", "1") == "0" or j not in self.predicted or not self._batchable(args, kwargs):
             return None
@@ -575,6 +594,14 @@ class TowerGraph:
         flat = self._flat(out)
         if not all(o is None or isinstance(o, torch.Tensor) for o in flat):
             return give_up(True)
+        # The stacked call ran on THIS forward's capture stream; the other samples' slices of its outputs are consumed by
+        # forwards on the other capture streams (and on the caller's).  The stream joins of the sweep order that work; what
+        # they do not cover is the buffers' lifetime -- freed after the consumer's Python returns, a block goes back to the
+        # PRODUCING stream's pool and can be handed out again while the consumer's kernels still read it.
+        for o in flat:
+            if isinstance(o, torch.Tensor) and o.is_cuda:
+                for st in _CTX.stream_set:
+                    o.record_stream(st)
         b0, g, t = bt["b0"], bt["g"], bt["t"]
         parts = [(o.split(b0, dim=0) if isinstance(o, torch.Tensor) and o.dim() >= 1 and o.shape[0] == g * b0 else None) for o in flat]
         mine = [(sp[t] if sp is not None else o) for o, sp in zip(flat, parts)]
@@ -926,7 +953,7 @@ class GraphedModule(nn.Module):
             return mod(*args, **kwargs)
         names = sorted(kwargs)
         # besides its arguments, the autocast state and the train / eval flags decide which kernels a block runs
-        key = (TowerMemo.context(), mod.training, _CAPTURE_SLOT) + \
+        key = (TowerMemo.context(), mod.training, _CTX.capture_slot) + \
             tuple(self._sig(a) for a in args) + tuple((k, self._sig(kwargs[k])) for k in names)
         if any(x is NotImplemented or (isinstance(x, tuple) and len(x) == 2 and x[1] is NotImplemented) for x in key[3:]) or \
                 not any(isinstance(a, torch.Tensor) for a in list(args) + list(kwargs.values())):
@@ -1058,7 +1085,6 @@ def later_check_enabled():
 
 def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forward_to_cache, lora_model, *, vit,
                           model_prefix, count_batches, done_towers, proxy_cache):
-    global _LATER
     total, batches = 0, []
     for batch in dataloader:                       # which batches the reference would consume
         if total >= n_samples:
@@ -1073,14 +1099,14 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
     args = (model, batches, module_to_process, forward_to_cache, lora_model)
     kw = dict(vit=vit, model_prefix=model_prefix, done_towers=done_towers, proxy_cache=proxy_cache)
     p0 = next(model.parameters(), None)
-    if done_towers and proxy_cache is not None and later_check_enabled() and p0 is not None and p0.is_cuda and _LATER is None:
+    if done_towers and proxy_cache is not None and later_check_enabled() and p0 is not None and p0.is_cuda and _CTX.later is None:
         # what finished towers remember of the previous phase is trusted while the forwards run and verified afterwards
-        _LATER = _LaterEqual()
+        _CTX.later = _LaterEqual()
         try:
             res = _capture_once(*args, **kw)
-            bad = _LATER.failed()
+            bad = _CTX.later.failed()
         finally:
-            _LATER = None
+            _CTX.later = None
         if not bad:
             return res
         # a remembered input was not what this phase fed its tower: forget the records, run the phase again, comparing at once
@@ -1115,11 +1141,11 @@ def _capture_once(model, batches, module_to_process, forward_to_cache, lora_mode
             self.module = module
 
         def forward(self, inp, *args, **kwargs):
-            if first is not None and _CAPTURE_SAMPLE is not None and not torch.is_grad_enabled():
+            if first is not None and _CTX.capture_sample is not None and not torch.is_grad_enabled():
                 a_, k_ = (inp,) + tuple(args), dict(kwargs)
-                first[_CAPTURE_SAMPLE] = (a_, k_, TowerMemo.context(), [(t, t._version) for t in TowerGraph._ext(a_, k_)])
+                first[_CTX.capture_sample] = (a_, k_, TowerMemo.context(), [(t, t._version) for t in TowerGraph._ext(a_, k_)])
             if calls is not None:
-                calls.append((_CAPTURE_SAMPLE if _CAPTURE_SAMPLE is not None else len(calls),
+                calls.append((_CTX.capture_sample if _CTX.capture_sample is not None else len(calls),
                               TowerMemo._snapshot((inp,) + tuple(args), kwargs)))
             if vit:
                 rel_pos_bias = args[0] if args else kwargs.get("rel_pos_bias")
@@ -1131,7 +1157,7 @@ def _capture_once(model, batches, module_to_process, forward_to_cache, lora_mode
             inp.requires_grad = False
             if lora_model:
                 cache["dense"] = dense
-            arrived.append((_CAPTURE_SAMPLE if _CAPTURE_SAMPLE is not None else len(arrived), inp, cache))
+            arrived.append((_CTX.capture_sample if _CTX.capture_sample is not None else len(arrived), inp, cache))
             if main_stream is not None:               # produced on a side stream, consumed on the caller's: tell the allocator
                 for t in [inp] + list(cache.values()):
                     if isinstance(t, torch.Tensor) and t.is_cuda:
@@ -1140,7 +1166,6 @@ def _capture_once(model, batches, module_to_process, forward_to_cache, lora_mode
 
     # side streams for the forwards (kept by the pruner from phase to phase): only worth it when finished towers are run
     # through, and only on a GPU model
-    global _CAPTURE_SLOT, _CAPTURE_SAMPLE
     sides, main_stream = [], None
     p0 = next(model.parameters(), None)
     if capture_streams() > 1 and done_towers and p0 is not None and p0.is_cuda and graph_replay_enabled():
@@ -1181,17 +1206,18 @@ def _capture_once(model, batches, module_to_process, forward_to_cache, lora_mode
                 if sides:
                     for st in sides:
                         st.wait_stream(main_stream)
+                    _CTX.stream_set = tuple([main_stream] + list(sides))
                 later = [j for j in pending if j not in scouts] if scouts else []
                 for n_, j in enumerate([j for j in pending if j in scouts] if scouts else pending):
-                    _CAPTURE_SAMPLE = j
+                    _CTX.capture_sample = j
                     if sides:
-                        _CAPTURE_SLOT = n_ % len(sides)
+                        _CTX.capture_slot = n_ % len(sides)
                     try:
-                        with (torch.cuda.stream(sides[_CAPTURE_SLOT]) if sides else contextlib.nullcontext()):
+                        with (torch.cuda.stream(sides[_CTX.capture_slot]) if sides else contextlib.nullcontext()):
                             forward_to_cache(model, mine[j], lora_model)
                     except ValueError:                 # _Stop / _Defer, or the reference's bare ValueError
                         pass
-                _CAPTURE_SAMPLE = _CAPTURE_SLOT = None
+                _CTX.capture_sample = _CTX.capture_slot = None
                 if sides:
                     for st in sides:
                         main_stream.wait_stream(st)
@@ -1208,7 +1234,8 @@ def _capture_once(model, batches, module_to_process, forward_to_cache, lora_mode
                     raise RuntimeError("calibration capture: postponed forwards do not get through the finished towers "
                                        "(set VLMC_TOWER_BATCH=0)")
     finally:
-        _CAPTURE_SLOT = _CAPTURE_SAMPLE = None
+        _CTX.capture_slot = _CTX.capture_sample = None
+        _CTX.stream_set = ()
         if sides:
             for st in sides:
                 main_stream.wait_stream(st)
@@ -1348,11 +1375,10 @@ def plan_groups(cur_in, caches, n_samples, group_max):
 # While a stacked forward runs: (number of stacked calibration samples, their common batch size, their indices in the
 # calibration set).  The statistics hooks read it to keep the reference's per-sample bookkeeping (one `add_batch` per
 # sample, :304-314) in the reference's sample order.
-_STACKED = None
 
 
 def stacked_samples():
-    return _STACKED
+    return _CTX.stacked
 
 
 def _stack_key(x, cache):
@@ -1493,7 +1519,6 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
     per-sample loop (:308-311, :343-346), replayed from HIP graphs.  Either way the activations are the GPU's, not
     the reference host's: both modes track the reference's masks to the same near-tie agreement
     (tests/test_pruner_gpu.py::test_replay_modes_agree_with_the_reference_side_by_side)."""
-    global _STACKED
     layers = get_module_recursive(model, module_to_process)
     n_samples = min(n_samples, len(inps))
     state = {"inps": inps, "outs": outs}
@@ -1509,7 +1534,6 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                     _run_pass(before_sample, so, False)
 
     def _run_pass(before_sample, so, outputs):
-        global _STACKED
         cur_in, cur_out = state["inps"], state["outs"]
         keys = None
         sig = None
@@ -1572,7 +1596,7 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                     cur_out[j] = y[0] if tuple_output else y
                 else:
                     b0 = cur_in[chunk[0]].shape[0]
-                    _STACKED = (len(chunk), b0, tuple(chunk))
+                    _CTX.stacked = (len(chunk), b0, tuple(chunk))
                     key = tuple(chunk)
                     # the group's inputs are usually the slices of ONE tensor -- the previous pass's stacked output -- and the
                     # cached kwargs are the same for every block of the tower: neither needs concatenating again
@@ -1586,7 +1610,7 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                         kw = _stack_caches([caches[j] for j in chunk], b0)
                         kw = stacked_kwargs[key] = kw if kw is not None else False
                     if kw is False:                                 # kwargs that cannot be stacked: sample by sample
-                        _STACKED = None
+                        _CTX.stacked = None
                         for t, j in enumerate(chunk):
                             if t and before_sample is not None:     # (chunk[0] was announced above; the per-sample
                                 before_sample(j)                    # loop announces every sample, like group_max == 1)
@@ -1605,7 +1629,7 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                     except _TailStop:
                         continue
                     finally:
-                        _STACKED = None
+                        _CTX.stacked = None
                     if so is not None:
                         so.end_forward(True)
                     y = y[0] if tuple_output else y

@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import contextlib
 import os
+import threading
 import weakref
 
 import torch
@@ -206,8 +207,14 @@ class _Tracker:
 # `torch.bmm`, `Tensor.__matmul__`, `Tensor.matmul` and `Tensor.bmm` are plain attribute patches (no `TorchFunctionMode`: that
 # would tax every op of a host-bound loop) that send 3-D / 4-D 16-bit products without gradients to `vlmc_attn_matmul`
 # (csrc/attn_matmul.hip) and everything else to the original.  `VLMC_ATTN_MATMUL=0`: off.
+# The attributes are process-wide, the ROUTING is not: every patched function first asks whether the calling thread is the
+# one that installed the patches (`_mm_owner`) and hands any other thread -- a data-loader worker, a DDP hook -- straight to
+# the original.  A second thread that enters `invariant_matmuls` while another one holds the patches
+# runs unpatched (its products go to the library: the replay of ONE prune is what the kernels are promised for).
 _mm_depth = 0
 _mm_saved = {}
+_mm_owner = None
+_ident = threading.get_ident
 
 
 def attn_matmul_enabled():
@@ -218,6 +225,8 @@ def _make_matmul(orig):
     Tensor = torch.Tensor
 
     def matmul(a, b, *args, **kw):
+        if _ident() != _mm_owner:
+            return orig(a, b, *args, **kw)
         if not args and not kw and type(a) is Tensor and type(b) is Tensor and a.dim() >= 3 and not torch.is_grad_enabled():
             if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() != a.dtype:
                 return orig(a, b)                                   # (autocast would cast the operands: the library's call)
@@ -236,6 +245,8 @@ def _make_sdpa(orig):
     Tensor = torch.Tensor
 
     def sdpa(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, scale=None, **kw):
+        if _ident() != _mm_owner:
+            return orig(q, k, v, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal, scale=scale, **kw)
         if attn_mask is None and dropout_p == 0.0 and type(is_causal) is bool and not kw and type(q) is Tensor and \
                 not torch.is_grad_enabled() and not (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() != q.dtype):
             out = ops.sdpa(q, k, v, scale, True, is_causal)
@@ -255,6 +266,8 @@ def _make_mean(orig):
     Tensor, f32 = torch.Tensor, torch.float32
 
     def mean(x, *args, **kw):
+        if _ident() != _mm_owner:
+            return orig(x, *args, **kw)
         if type(x) is Tensor and x.dtype is f32 and x.is_cuda and not torch.is_grad_enabled() and x.dim() >= 2:
             dim = args[0] if args else kw.get("dim")
             if type(dim) in (tuple, list) and len(dim) == 1:
@@ -272,11 +285,12 @@ def _make_mean(orig):
 def invariant_matmuls():
     """Batched 16-bit `matmul`s run on `vlmc_attn_matmul`, fp32 means over the last dimension on `vlmc_row_mean`, for the
     duration (nestable)."""
-    global _mm_depth
-    if not (enabled() and attn_matmul_enabled()):
+    global _mm_depth, _mm_owner
+    if not (enabled() and attn_matmul_enabled()) or (_mm_depth > 0 and _mm_owner != _ident()):
         yield
         return
     if _mm_depth == 0:
+        _mm_owner = _ident()
         base = torch._C.TensorBase
         _mm_saved.update(matmul=torch.matmul, bmm=torch.bmm)
         torch.matmul = _make_matmul(torch.matmul)
@@ -301,6 +315,7 @@ def invariant_matmuls():
     finally:
         _mm_depth -= 1
         if _mm_depth == 0:
+            _mm_owner = None
             torch.matmul, torch.bmm = _mm_saved.pop("matmul"), _mm_saved.pop("bmm")
             if "mean" in _mm_saved:
                 torch.mean = _mm_saved.pop("mean")
@@ -377,11 +392,21 @@ def _norm_mode(m):
         modes = _rsqrt_modes(w.device)
         rows = 37 if modes == (0,) else 1500                                  # (flavours that differ in 1 ulp of r show in ~1 element per 10 rows)
         x = (torch.randn(3, rows, w.shape[0], generator=g, device=w.device) * torch.tensor([0.02, 1.0, 30.0], device=w.device)[:, None, None]).to(w.dtype)
+        # The verdict is cached per (class, dtype, width, eps) and then holds for EVERY module of the class: it must not be
+        # taken with a weight that hides where the class rounds its product -- an all-ones weight (a fresh or synthetic norm)
+        # makes `(w.float() * h32).to(dtype)` and `w * h32.to(dtype)` agree bit for bit.  The module is shown a
+        # random, non-trivial weight for the comparison and gets its own back.
+        own = w.data
+        trial = (torch.randn(w.shape[0], generator=g, device=w.device) * 0.3 + 1.0).to(w.dtype)
         with torch.no_grad():
-            want = m.forward(x)
+            try:
+                w.data = trial
+                want = m.forward(x)
+            finally:
+                w.data = own
             if isinstance(want, torch.Tensor) and want.dtype == w.dtype and want.shape == x.shape:
                 for cand in modes:
-                    if torch.equal(ops.rms_norm(x, w.detach(), eps, cand), want):
+                    if torch.equal(ops.rms_norm(x, trial, eps, cand), want):
                         mode = cand
                         break
     except Exception:

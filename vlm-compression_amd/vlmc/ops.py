@@ -65,6 +65,9 @@ _MODES = {"row": _lib.SEL_ROW, "matrix": _lib.SEL_MATRIX, "nm": _lib.SEL_NM}
 _hessian_ws = Workspace()
 
 
+_FAST_ENTRY_POINTS = ("linear_fwd", "linear_fwd_group", "attn_matmul", "row_mean", "rms_norm", "sdpa")
+
+
 def _load_fast():
     """The compiled host path (csrc/fastpath/fast_bind.cpp -> vlmc/_fast*.so) for linear_fwd / linear_fwd_group / attn_matmul:
     the same C ABI, ~2 us of host time per call instead of 8-22 through ctypes.  None when it has not been built, when
@@ -79,6 +82,11 @@ def _load_fast():
     if _fast.abi_version() != _lib.header_abi_version():
         raise ImportError("vlmc/_fast was built against another ABI version of libvlmc_hip.so; rebuild (make -C vlm-compression_amd/csrc/fastpath)")
     _lib.load()
+    missing = [n for n in _FAST_ENTRY_POINTS if not hasattr(_fast, n)]
+    if missing:                                                          # a stale build at the same ABI: one route for everything, not a mix
+        import warnings
+        warnings.warn(f"vlmc/_fast lacks {missing}: rebuild it (make -C vlm-compression_amd/csrc/fastpath); using the ctypes route")
+        return None
     return _fast
 
 
@@ -295,7 +303,10 @@ def sdpa_plan(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor):
 def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale=None, _try: bool = False, causal: bool = False):
     """`F.scaled_dot_product_attention(q, k, v[, is_causal=True])` (no mask, no dropout) on the fused, batch-invariant MFMA kernel
     (include/vlmc.h: vlmc_sdpa_fwd).  The result is a [B, H, Tq, d] view of a [B, Tq, H, d] buffer: the `transpose(1, 2)
-    .reshape(B, Tq, H * d)` that follows in every model file is then free.  `_try`: None for a call the kernel does not take."""
+    .reshape(B, Tq, H * d)` that follows in every model file is then free.  LAYOUT CONTRACT: unlike torch's math path the
+    result is NOT contiguous in [B, H, Tq, d] order -- code that goes on with `.view(B * H, Tq, d)` needs `.contiguous()` first
+    (`.reshape` and `.transpose(1, 2).reshape(...)` work as they are).  `_try`: None for a call the kernel does not take, also
+    when only the C entry point refuses it."""
     if _fast is not None and q.is_cuda and hasattr(_fast, "sdpa"):
         out = _fast.sdpa(q, k, v, float(q.shape[-1] ** -0.5 if scale is None else scale), bool(causal), _stream())
         if out is None and not _try:
@@ -312,9 +323,13 @@ def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale=None, _try: bo
     B, H, Tq, Tk, d = plan
     out = torch.empty((B, Tq, H, d), dtype=q.dtype, device=q.device)
     sq, sk, sv = q.stride(), k.stride(), v.stride()
-    _lib.check(_lib.load().vlmc_sdpa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _DT[q.dtype], B, H, Tq, Tk, d,
-                                         sq[0], sq[1], sq[2], sk[0], sk[1], sk[2], sv[0], sv[1], sv[2], Tq * H * d, d, H * d,
-                                         float(d ** -0.5 if scale is None else scale), int(bool(causal)), _stream()))
+    rc = _lib.load().vlmc_sdpa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _DT[q.dtype], B, H, Tq, Tk, d,
+                                   sq[0], sq[1], sq[2], sk[0], sk[1], sk[2], sv[0], sv[1], sv[2], Tq * H * d, d, H * d,
+                                   float(d ** -0.5 if scale is None else scale), int(bool(causal)), _stream())
+    if rc:
+        if _try and rc == _lib.VLMC_EINVAL:                               # the entry point refuses the call: the caller's own op runs
+            return None
+        _lib.check(rc)
     return out.transpose(1, 2)
 
 
