@@ -19,6 +19,12 @@ def test_synthetic_model_matches_the_workload_table():
             n += 1
             total += lin.out_features * lin.in_features
     assert n == synthetic.prunable_linears(model) == 588
+    # the Q-Former between the towers (BASELINE.json configs[1]: "ViT-g + QFormer + T5"): 12 BERT-base layers, cross-attention to
+    # the 1408-wide image tokens in every second one, none of its linears among the prunable ones
+    layers = model.Qformer.bert.encoder.layer
+    assert len(layers) == 12 and [l.has_cross_attention for l in layers] == [i % 2 == 0 for i in range(12)]
+    assert tuple(layers[0].crossattention.self.key.weight.shape) == (768, 1408) and tuple(layers[1].intermediate_query.dense.weight.shape) == (3072, 768)
+    assert tuple(model.t5_proj.weight.shape) == (2048, 768)
     assert sum(p.numel() for k, p in model.named_parameters() if p.dim() == 2 and (".blocks." in k or ".block." in k)) == total
 
 
@@ -35,6 +41,46 @@ def test_small_synthetic_model_through_the_wanda_pruner():
     for name, mod in model.named_modules():
         if isinstance(mod, nn.Linear) and ".block." in name:
             assert bool(((mod.weight == 0).sum(dim=1) == mod.weight.shape[1] // 2).all()), name     # per-row rule on the T5 side
+        if isinstance(mod, nn.Linear) and name.startswith("Qformer."):
+            assert float((mod.weight == 0).float().mean()) < 1e-3 and not hasattr(mod, "mask"), name      # the Q-Former is never pruned
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ragged", [False, True])
+def test_q_former_run_as_a_finished_tower_gives_the_per_sample_forwards_result(ragged, monkeypatch):
+    """The Q-Former's layers are run through like a finished tower in the language model's capture phases (stacked over the
+    samples of a group in the encoder's phase, handed out from the memo in the decoder's): masks and weights of a whole prune
+    equal, bit for bit, the route in which every calibration sample goes through them alone (`replay_per_sample`: same
+    batch-invariant kernels, one sample per forward).  Against the route that leaves the Q-Former to torch's eager ops (library
+    GEMMs: other summation orders) the masks agree to near-ties."""
+    from vlmc import synthetic
+    from lavis.compression.pruners import calibration
+    dev = torch.device("cuda:0")
+
+    def run(frozen, per_sample):
+        monkeypatch.setattr(calibration, "FROZEN_TOWERS", frozen)
+        monkeypatch.setenv("VLMC_BATCH_REPLAY", "1" if per_sample else "128")
+        monkeypatch.setenv("VLMC_TOWER_BATCH", "0" if per_sample else "1")
+        torch.manual_seed(0)                                           # (biases and norm weights keep torch's default, RNG-drawn init)
+        model = synthetic.InstructBlipT5(vit_dim=64, vit_hidden=128, vit_heads=4, vit_depth=2, d_model=64, d_ff=128, heads=4, d_kv=16,
+                                         enc_depth=2, dec_depth=2, vocab=100, query_tokens=4, qformer_dim=64, qformer_heads=4, qformer_hidden=128,
+                                         qformer_depth=4, qformer_vocab=50).to(dev).eval()
+        batches = synthetic.calibration_batches(12, dev, vit_tokens=9, vit_dim=64, text_len=5, out_len=3, vocab=100, ragged=ragged)
+        before = dict(calibration.graph_stats)
+        synthetic.time_prune(dev, n_samples=12, model=model, batches=batches)
+        delta = {k: v - before.get(k, 0) for k, v in calibration.graph_stats.items() if isinstance(v, (int, float))}
+        return {n: (m.weight.detach().clone(), m.mask.clone()) for n, m in model.named_modules() if isinstance(m, nn.Linear) and hasattr(m, "mask")}, delta
+
+    frozen = calibration.FROZEN_TOWERS
+    got, stats = run(frozen, False)
+    ref, _ = run(frozen, True)
+    eager, _ = run((), False)
+    assert stats.get("tower_batches", 0) >= 2 and stats.get("memo_recorded", 0) >= 24            # stacked, and remembered for the decoder's phase
+    assert got.keys() == ref.keys() == eager.keys() and len(got) == 2 * 4 + 2 * 7 + 2 * 11
+    for k in got:
+        assert torch.equal(got[k][0], ref[k][0]) and torch.equal(got[k][1], ref[k][1]), k
+    agree = sum(int((got[k][1] == eager[k][1]).sum()) for k in got) / sum(got[k][1].numel() for k in got)
+    assert agree > 0.99, agree
 
 
 def test_synthetic_vicuna_has_the_llama_linears():

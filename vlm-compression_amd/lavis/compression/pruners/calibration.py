@@ -188,6 +188,8 @@ class TowerMemo:
         self.entries, self.mode, self.ok = {}, "record", True        # entries: index of the calibration forward -> record
         self.cursor, self.hit, self.pending, self.expect, self.bytes = 0, None, None, 0, 0
         self.current = 0
+        self.wrap = False            # how the blocks return their hidden states: None = the tensor itself, tuple / list = a sequence
+                                     # of that ONE tensor (BERT-style layers: `layer(...)[0]`); False = not seen yet
 
     @staticmethod
     def fingerprint(blocks):
@@ -287,10 +289,20 @@ class TowerMemo:
             return False, None
         if index == self.n - 1:
             out, self.hit = self.hit.clone(), None
-            return True, out
-        return True, args[0]
+            return True, (self.wrap((out,)) if self.wrap else out)
+        return True, (self.wrap((args[0],)) if self.wrap else args[0])
 
     def leave(self, index, result):
+        if self.ok and self.mode == "record":
+            # every block must hand its hidden states on the same way: the tensor, or a 1-tuple / 1-list of it
+            kind = None if isinstance(result, torch.Tensor) else \
+                (type(result) if type(result) in (tuple, list) and len(result) == 1 and isinstance(result[0], torch.Tensor) else False)
+            if kind is False or (self.wrap is not False and self.wrap is not kind):
+                self._drop()
+                return
+            self.wrap = kind
+            if kind is not None:
+                result = result[0]
         if self.ok and self.mode == "record" and index == self.n - 1:
             if isinstance(result, torch.Tensor) and self.pending is not None and self.expect == self.n:
                 self.entries[self.current] = (self.pending, result.detach().clone())
@@ -326,6 +338,7 @@ def seed_tower_memo(proxy_cache, module_to_process, layers, final_outs, autocast
     if fp is None:
         return False
     memo = TowerMemo(fp, len(layers))
+    memo.wrap = None                                 # (the blocks of such a tower return the tensor itself)
     memo.entries = {j: ((c[0], c[1], ctx), final_outs[j].detach()) for j, c in enumerate(calls[:n])}
     proxy_cache[("memo", module_to_process)] = memo
     graph_stats["memo_recorded"] += n
@@ -483,6 +496,10 @@ class TowerGraph:
             self.live = self.trace = self.btrace = None
             key = self._key0(args, kwargs)
             wiring = self.wirings.get(key) if key is not None else False
+            if os.environ.get("VLMC_DEBUG_TOWERS"):
+                print("TOWER", getattr(self, "path", "?"), "sample", _CTX.capture_sample, "key", key is not None, "wiring",
+                      None if wiring is None else (False if wiring is False else "known"), "ready", len(self.ready), "predicted", len(self.predicted),
+                      "batchable", self._batchable(args, kwargs) if key is not None else None, "memo_serves", self.memo_serves, flush=True)
             if wiring is False or key is None:
                 return False, None
             if wiring is None:                                            # not known yet: trace this forward
@@ -913,7 +930,7 @@ class GraphedModule(nn.Module):
             m, index = memo
             if m.hit is not None and m.ok and 0 < index == m.expect < m.n - 1:
                 m.expect = index + 1
-                return args[0]
+                return m.wrap((args[0],)) if m.wrap else args[0]
         return self.forward(*args, **kwargs)
 
     @staticmethod
@@ -1061,6 +1078,29 @@ def _wrap_towers(model, towers, proxy_cache=None, record=True):
     return undo
 
 
+# Block lists that lie on the model's forward between two pruned towers and are never pruned themselves: the Q-Former of
+# BLIP-2 / InstructBLIP (blip2_t5_instruct.py:146-175: `self.Qformer.bert(...)`, Qformer.py: `bert.encoder.layer`).  Once a tower
+# upstream of them is finished they are run through like a finished tower -- memo from phase to phase, stacked over the samples of a
+# group -- instead of 12 eager batch-1 layers per calibration forward on the host-bound side of every capture phase.
+FROZEN_TOWERS = ("Qformer.bert.encoder.layer",)
+
+
+def with_frozen_towers(model, done_towers, module_to_process):
+    if not done_towers:
+        return done_towers
+    out = list(done_towers)
+    for path in FROZEN_TOWERS:
+        if path in out or path == module_to_process:
+            continue
+        try:
+            blocks = get_module_recursive(model, path)
+        except AttributeError:
+            continue
+        if isinstance(blocks, nn.ModuleList) and len(blocks) >= 2:
+            out.insert(1 if len(out) >= 1 else 0, path)           # (order is informative only: behind the vision tower)
+    return out
+
+
 def capture_block_inputs(model, dataloader, n_samples, module_to_process, forward_to_cache, lora_model, *, vit,
                          model_prefix=None, count_batches=False, done_towers=None, proxy_cache=None):
     """Run the model until block 0 of `module_to_process` is reached, for the first
@@ -1072,6 +1112,7 @@ def capture_block_inputs(model, dataloader, n_samples, module_to_process, forwar
     count_batches=True reproduces the SparseGPT pruners' stop rule (`i >= n_samples` on the
     batch index, sparsegpt_pruner.py:391-393) instead of Wanda's sample count.
     """
+    done_towers = with_frozen_towers(model, done_towers, module_to_process)
     with phases.phase("capture " + module_to_process):
         return _capture_block_inputs(model, dataloader, n_samples, module_to_process, forward_to_cache, lora_model, vit=vit,
                                      model_prefix=model_prefix, count_batches=count_batches, done_towers=done_towers,

@@ -7,8 +7,8 @@ What the pruners need from the reference's model classes is kept: the module nam
 (eva_vit.Block: `blk(x, rel_pos_bias, dense=)`; T5Block: `blk(hidden, attention_mask=..., ..., dense=) -> (hidden,)`),
 `maybe_autocast`, `t5_model.config.use_cache` and `model(samples)["loss"]` (blip2_t5_instruct.py:136-221).
 Shapes: SURVEY.md Appendix A (ViT-g 39 x 1408/6144, 16 heads, 257 tokens, fp16; Flan-T5-XL 24 + 24 x 2048/5120,
-32 heads of 64, bf16).  The Q-Former (never pruned) is replaced by its output shape: 32 query tokens projected to the
-language model's width.
+32 heads of 64, bf16); the Q-Former (never pruned: 12 BERT-base layers over 32 queries + the instruction, cross-attention to
+the image tokens in every second layer, `QFormer` below) between them since round 5 -- BASELINE.json configs[1] names it.
 """
 from __future__ import annotations
 
@@ -232,10 +232,125 @@ class T5Block(nn.Module):
         return (x,) + biases                       # (hidden, position bias[, cross-attention position bias]): use_cache is off
 
 
+# ---- the Q-Former between the vision tower and the language model (never pruned) ----------------------------------------------
+# lavis/models/blip2_models/Qformer.py (BertLayer :378-470, BertSelfAttention :111-260) as blip2_t5_instruct.py:146-175 drives it:
+# 12 BERT-base layers (hidden 768, 12 heads, FFN 3072) over [32 learned queries | instruction text]; every second layer the queries
+# cross-attend to the image tokens (encoder width 1408); queries and text have their own feed-forward halves; the first 32 rows
+# of the last layer go to `t5_proj`.  The reference keeps its weights in fp32 and runs it under the model's fp16 autocast; the
+# stand-in holds them in fp16.  Module names are the reference's (`.attention.self.{query,key,value}`, `.attention.output.dense`,
+# `.crossattention...`, `.intermediate[_query].dense`, `.output[_query].dense`: the targets of `qformer_lora_target_modules`).
+class _QfSelfAttention(nn.Module):
+    def __init__(self, dim, heads, kv_dim, reference_ops):
+        super().__init__()
+        self.heads, self.reference_ops = heads, reference_ops
+        self.query, self.key, self.value = nn.Linear(dim, dim), nn.Linear(kv_dim, dim), nn.Linear(kv_dim, dim)
+
+    def forward(self, x, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None):
+        src, mask = (x, attention_mask) if encoder_hidden_states is None else (encoder_hidden_states, encoder_attention_mask)
+        B, T, D = x.shape
+        h = self.heads
+        q = self.query(x).view(B, T, h, D // h).permute(0, 2, 1, 3)
+        k = self.key(src).view(B, -1, h, D // h).permute(0, 2, 1, 3)
+        v = self.value(src).view(B, -1, h, D // h).permute(0, 2, 1, 3)
+        if self.reference_ops or mask is not None:                        # Qformer.py:205-246: scores, + mask, softmax, probs @ v
+            scores = torch.matmul(q, k.transpose(-1, -2)) / (D // h) ** 0.5
+            if mask is not None:
+                scores = scores + mask
+            y = torch.matmul(torch.softmax(scores, dim=-1), v)
+        else:
+            y = F.scaled_dot_product_attention(q, k, v)
+        return y.permute(0, 2, 1, 3).reshape(B, T, D)
+
+
+class _QfOutput(nn.Module):                         # BertSelfOutput / BertOutput: dense, (dropout,) LayerNorm(dense + residual)
+    def __init__(self, in_dim, dim, eps=1e-12):
+        super().__init__()
+        self.dense = nn.Linear(in_dim, dim)
+        self.LayerNorm = nn.LayerNorm(dim, eps=eps)
+
+    def forward(self, x, residual):
+        return self.LayerNorm(self.dense(x) + residual)
+
+
+class _QfAttention(nn.Module):
+    def __init__(self, dim, heads, kv_dim, reference_ops):
+        super().__init__()
+        self.self = _QfSelfAttention(dim, heads, kv_dim, reference_ops)
+        self.output = _QfOutput(dim, dim)
+
+    def forward(self, x, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None):
+        return self.output(self.self(x, attention_mask, encoder_hidden_states, encoder_attention_mask), x)
+
+
+class _QfIntermediate(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.dense = nn.Linear(dim, hidden)
+
+    def forward(self, x):
+        return F.gelu(self.dense(x))
+
+
+class QFormerLayer(nn.Module):
+    def __init__(self, dim, heads, hidden, encoder_width, cross, reference_ops=False):
+        super().__init__()
+        self.attention = _QfAttention(dim, heads, dim, reference_ops)
+        self.has_cross_attention = cross
+        if cross:
+            self.crossattention = _QfAttention(dim, heads, encoder_width, reference_ops)
+        self.intermediate, self.output = _QfIntermediate(dim, hidden), _QfOutput(hidden, dim)
+        self.intermediate_query, self.output_query = _QfIntermediate(dim, hidden), _QfOutput(hidden, dim)
+
+    def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None, query_length=0):
+        a = self.attention(hidden_states, attention_mask)
+        if query_length > 0:
+            qa = a[:, :query_length]
+            if self.has_cross_attention:
+                qa = self.crossattention(qa, attention_mask, encoder_hidden_states, encoder_attention_mask)
+            out = self.output_query(self.intermediate_query(qa), qa)
+            if a.shape[1] > query_length:
+                ta = a[:, query_length:]
+                out = torch.cat([out, self.output(self.intermediate(ta), ta)], dim=1)
+        else:
+            out = self.output(self.intermediate(a), a)
+        return (out,)
+
+
+class QFormer(nn.Module):
+    """`Qformer.bert(input_ids, attention_mask, query_embeds, encoder_hidden_states, encoder_attention_mask)` of the reference,
+    reduced to what the forward of blip2_t5_instruct.py:146-175 uses: `.bert.embeddings`, `.bert.encoder.layer[i]`."""
+
+    def __init__(self, dim=768, heads=12, hidden=3072, depth=12, encoder_width=1408, vocab=30523, cross_attention_freq=2, reference_ops=False):
+        super().__init__()
+        self.bert = nn.Module()
+        self.bert.embeddings = nn.Module()
+        self.bert.embeddings.word_embeddings = nn.Embedding(vocab, dim)
+        self.bert.embeddings.position_embeddings = nn.Embedding(512, dim)
+        self.bert.embeddings.LayerNorm = nn.LayerNorm(dim, eps=1e-12)
+        self.bert.encoder = nn.Module()
+        self.bert.encoder.layer = nn.ModuleList([QFormerLayer(dim, heads, hidden, encoder_width, i % cross_attention_freq == 0, reference_ops)
+                                                 for i in range(depth)])
+        self.vocab = vocab
+
+    def forward(self, input_ids, query_embeds, encoder_hidden_states):
+        emb = self.bert.embeddings
+        B, Q = query_embeds.shape[:2]
+        if input_ids is not None:
+            pos = torch.arange(input_ids.shape[1], device=input_ids.device)[None]
+            x = torch.cat([query_embeds, emb.word_embeddings(input_ids) + emb.position_embeddings(pos)], dim=1)
+        else:
+            x = query_embeds
+        x = emb.LayerNorm(x)
+        for layer in self.bert.encoder.layer:
+            x = layer(x, None, encoder_hidden_states, None, query_length=Q)[0]
+        return x
+
+
 class InstructBlipT5(nn.Module):
     def __init__(self, vit_dim=1408, vit_hidden=6144, vit_heads=16, vit_depth=39, d_model=2048, d_ff=5120, heads=32, d_kv=64,
                  enc_depth=24, dec_depth=24, vocab=32128, query_tokens=32, vit_dtype=torch.float16, t5_dtype=torch.bfloat16,
-                 reference_ops=False):
+                 reference_ops=False, qformer=True, qformer_dim=768, qformer_heads=12, qformer_hidden=3072, qformer_depth=12,
+                 qformer_vocab=30523):
         """reference_ops=True: the blocks' attention follows the reference's model files op for op -- EVA attention as
         eva_vit.py:129-168 (q / v bias, explicit `q @ k^T`, softmax, `attn @ v`), T5 attention as modeling_t5.py:520-640
         (`torch.matmul` scores, bucketed position bias in block 0 handed on by the stack, fp32 softmax, extended masks) --
@@ -245,7 +360,15 @@ class InstructBlipT5(nn.Module):
         self.visual_encoder = nn.Module()
         self.visual_encoder.blocks = nn.ModuleList([ViTBlock(vit_dim, vit_hidden, vit_heads, reference_ops) for _ in range(vit_depth)])
         self.visual_encoder.to(vit_dtype)
-        self.t5_proj = nn.Linear(vit_dim, d_model).to(t5_dtype)
+        # qformer=False: rounds 1-4's stand-in (the first 32 image tokens projected straight to the language model's width)
+        if qformer:
+            self.ln_vision = nn.LayerNorm(vit_dim).to(vit_dtype)
+            self.Qformer = QFormer(qformer_dim, qformer_heads, qformer_hidden, qformer_depth, vit_dim, qformer_vocab, 2, reference_ops).to(vit_dtype)
+            self.query_embeds = nn.Parameter(torch.zeros(1, query_tokens, qformer_dim, dtype=vit_dtype))
+            self.t5_proj = nn.Linear(qformer_dim, d_model).to(t5_dtype)
+        else:
+            self.Qformer = None
+            self.t5_proj = nn.Linear(vit_dim, d_model).to(t5_dtype)
         t5 = nn.Module()
         t5.config = types.SimpleNamespace(use_cache=True, d_model=d_model)
         t5.shared = nn.Embedding(vocab, d_model)
@@ -270,7 +393,15 @@ class InstructBlipT5(nn.Module):
         for blk in self.visual_encoder.blocks:
             x = blk(x, None, dense=vit_dense)
         t5 = self.t5_model
-        img = self.t5_proj(x[:, :self.query_tokens].to(self.t5_dtype))          # stands in for the Q-Former's 32 queries
+        if self.Qformer is not None:
+            # blip2_t5_instruct.py:144-175: ln_vision, [queries | instruction text] through the Q-Former, its first 32 rows to t5_proj
+            # (the Q-Former has its own tokenizer: the synthetic prompt's ids are folded into its vocabulary)
+            img_embeds = self.ln_vision(x)
+            ids = samples["text_input"] % self.Qformer.vocab
+            qout = self.Qformer(ids, self.query_embeds.expand(x.shape[0], -1, -1), img_embeds)
+            img = self.t5_proj(qout[:, :self.query_tokens].to(self.t5_dtype))
+        else:
+            img = self.t5_proj(x[:, :self.query_tokens].to(self.t5_dtype))      # stands in for the Q-Former's 32 queries
         h = torch.cat([img, t5.shared(samples["text_input"])], dim=1)
         kw = dict(attention_mask=None, position_bias=None, encoder_hidden_states=None, encoder_attention_mask=None,
                   encoder_decoder_position_bias=None, layer_head_mask=None, cross_attn_layer_head_mask=None)
