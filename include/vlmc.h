@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLMC_ABI_VERSION 12
+#define VLMC_ABI_VERSION 13
 
 #define VLMC_OK 0
 #define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
@@ -78,6 +78,9 @@ typedef struct vlmc_stat_job {
     const void *x;
     float *normsq;
     int64_t in_features, tokens, row_stride, call_stride, normsq_stride;
+    const int32_t *call_tokens;   /* device [n_calls] or NULL: only the first call_tokens[c] <= tokens rows of call c count -- a
+                                     group of ragged calibration samples padded to one length (the padding rows are skipped, the
+                                     chain over the real rows is the unpadded call's)                                           */
 } vlmc_stat_job;
 int vlmc_act_sqnorm_batch(const vlmc_stat_job *jobs /* host array */, int n_jobs, int dtype, int64_t n_calls,
                           void *stream);
@@ -278,6 +281,14 @@ int vlmc_sdpa_fwd(const void *Q, const void *K, const void *V, void *O, int dtyp
  *     out[r] = (sum over c of x[r * ldx + c]) / n        one wave per row, a fixed order that depends on n only
  * x [rows, n] fp32 (row stride ldx elements), out [rows] fp32.                                                 */
 int vlmc_row_mean(const float *x, int64_t rows, int64_t n, int64_t ldx, float *out, void *stream);
+
+/* Row-wise softmax over the last dimension of an fp32 matrix, PADDING-invariant: `F.softmax(scores.float(), dim=-1)` of the
+ * blocks' attention (modeling_t5.py:604-606; eva_vit.py:158) during a replay.  One wave per row; lane l takes elements
+ * l + 64 i in ascending i for the maximum and for the sum of expf(x - max), fixed butterflies, one IEEE division per element.
+ * Entries that are masked out (x + finfo.min: expf gives exactly 0) behind a row's real entries add +0 to sums that are
+ * otherwise formed in the same order: a sample's row has the same bits alone and padded to a longer group.
+ * x [rows, n] (row stride ldx), y [rows, n] (row stride ldy), both fp32; y may alias x.                                  */
+int vlmc_softmax_rows(const float *x, int64_t rows, int64_t n, int64_t ldx, float *y, int64_t ldy, void *stream);
 
 /* ---- the RMS norm of a language-model block in one launch ---------------------------------------------
  * Replaces the op sequence of transformers' T5LayerNorm.forward / LlamaRMSNorm.forward inside a replayed block

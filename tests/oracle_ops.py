@@ -68,8 +68,16 @@ def wanda_select(weight, sqrt_scaler_row, mode, *, k=0, n=0, m=0, apply_zero=Tru
     return mask, partials[:nparts]
 
 
-def act_sqnorm_batch(xs, outs=None):
-    rows = [act_sqnorm(x) for x in xs]
+def act_sqnorm_batch(xs, outs=None, call_tokens=None):
+    if call_tokens is not None and any(ct is not None for ct in call_tokens):      # padded groups: each call's own rows only
+        rows = []
+        for x, ct in zip(xs, call_tokens):
+            if ct is None:
+                rows.append(act_sqnorm(x))
+            else:
+                rows.append(torch.cat([act_sqnorm(x[c:c + 1, :int(n)]) for c, n in enumerate(ct.tolist())]))
+    else:
+        rows = [act_sqnorm(x) for x in xs]
     if outs is not None:
         for o, r in zip(outs, rows):
             o.copy_(r)

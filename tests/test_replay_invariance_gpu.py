@@ -163,3 +163,39 @@ def test_a_sibling_group_whose_products_are_wasted_is_forgotten():
         with forward.invariant_linears(mods):
             got = [m(x) for m in mods]                       # the calls show the group again
         assert forward.sibling_groups(mods) == [(q, k, v)] and all(torch.equal(a, b) for a, b in zip(got, want))
+
+
+@pytest.mark.parametrize("lora_model", [False, True])
+def test_ragged_samples_padded_into_one_group_keep_their_bits(lora_model, monkeypatch):
+    """Ragged calibration text on a stand-in whose T5 blocks follow the reference's op sequence (extended masks, explicit matmuls,
+    fp32 softmax): the default route pads all lengths into ONE forward per block pass (zero rows, masks at the dtype's minimum,
+    per-sample token counts for the statistics, the softmax on `vlmc_softmax_rows`); masks, weights and importance scores of a
+    whole Wanda prune equal the groups-of-equal-shapes route (`VLMC_PAD_RAGGED=0`) and the per-sample loop bit for bit."""
+    from vlmc import forward, synthetic
+    from lavis.compression.pruners import calibration
+    dev = torch.device(DEV)
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        torch.manual_seed(0)
+        model = synthetic.InstructBlipT5(vit_dim=64, vit_hidden=128, vit_heads=4, vit_depth=2, d_model=64, d_ff=128, heads=4, d_kv=16,
+                                         enc_depth=3, dec_depth=3, vocab=100, query_tokens=4, reference_ops=True, qformer_dim=64, qformer_heads=4,
+                                         qformer_hidden=128, qformer_depth=2, qformer_vocab=50).to(dev).eval()
+        batches = synthetic.calibration_batches(16, dev, vit_tokens=9, vit_dim=64, vocab=100, ragged=True)
+        before = (calibration.graph_stats.get("padded_forwards", 0), forward.stats["softmax_kernel"])
+        synthetic.time_prune(dev, n_samples=16, model=model, batches=batches, **({"t5_prune_spec": "3-0.5-1.0-1.0"}))
+        out = {n: (m.weight.detach().clone(), m.mask.clone() if hasattr(m, "mask") else None) for n, m in model.named_modules()
+               if isinstance(m, torch.nn.Linear) and (".block." in n or ".blocks." in n)}
+        return out, calibration.graph_stats.get("padded_forwards", 0) - before[0], forward.stats["softmax_kernel"] - before[1]
+
+    base = {"VLMC_BATCH_REPLAY": "128", "VLMC_TOWER_BATCH": "1", "VLMC_PAD_RAGGED": "1"}
+    padded, n_padded, n_softmax = run(base)
+    shaped, n_shaped, _ = run({**base, "VLMC_PAD_RAGGED": "0"})
+    single, _, _ = run({**base, "VLMC_BATCH_REPLAY": "1", "VLMC_TOWER_BATCH": "0"})
+    assert n_padded == 2 * 2 * 3 and n_shaped == 0 and n_softmax > 0          # encoder + decoder tower, two passes, three blocks: ONE forward each
+    assert padded.keys() == shaped.keys() == single.keys() and len(padded) == 2 * 4 + 3 * 7 + 3 * 11
+    for k in padded:
+        for other, name in ((shaped, "groups of equal shapes"), (single, "per-sample loop")):
+            assert torch.equal(padded[k][0], other[k][0]), (k, name)
+            assert (padded[k][1] is None and other[k][1] is None) or torch.equal(padded[k][1], other[k][1]), (k, name)

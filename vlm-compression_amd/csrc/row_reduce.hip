@@ -42,6 +42,55 @@ __global__ __launch_bounds__(256) void row_mean_kernel(const float *__restrict__
     if (lane == 0) out[row] = ieee_div(acc, float(n));
 }
 
+
+// ---- vlmc_softmax_rows: padding-invariant softmax over the last dimension (include/vlmc.h) --------------------------------------
+// One wave per row, lane l owns elements l + 64 i.  Rows of up to 1024 elements stay in registers (one read); longer rows are
+// read three times (L2).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float *__restrict__ x, int64_t rows, int n, int64_t ldx,
+                                                           float *__restrict__ y, int64_t ldy) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *p = x + row * ldx;
+    float *q = y + row * ldy;
+    constexpr int R = 16;
+    if (n <= 64 * R) {
+        float v[R];
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < n ? p[c] : -__builtin_inff();
+            mx = fmaxf(mx, v[i]);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, kWave));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            v[i] = lane + 64 * i < n ? expf(v[i] - mx) : 0.f;
+            sum = ieee_add(sum, v[i]);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sum = ieee_add(sum, __shfl_xor(sum, off, kWave));
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int c = lane + 64 * i;
+            if (c < n) q[c] = ieee_div(v[i], sum);
+        }
+        return;
+    }
+    float mx = -__builtin_inff();
+    for (int c = lane; c < n; c += 64) mx = fmaxf(mx, p[c]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, kWave));
+    float sum = 0.f;
+    for (int c = lane; c < n; c += 64) sum = ieee_add(sum, expf(p[c] - mx));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum = ieee_add(sum, __shfl_xor(sum, off, kWave));
+    for (int c = lane; c < n; c += 64) q[c] = ieee_div(expf(p[c] - mx), sum);
+}
+
 // ---- vlmc_rms_norm: the whole RMS norm of a language-model block in one pass -------------------------------------------------
 //   y = w * wd(x * rsqrt(mean(float(x)^2) + eps))          (transformers' T5LayerNorm.forward / LlamaRMSNorm.forward, op for op)
 // The model files spell it as seven launches -- to(float32), pow(2), mean(-1), + eps, rsqrt, x * r (an fp32 [rows, n] product),
@@ -148,5 +197,14 @@ extern "C" int vlmc_row_mean(const float *x, int64_t rows, int64_t n, int64_t ld
     if (rows == 0) return VLMC_OK;
     hipLaunchKernelGGL(row_mean_kernel, dim3(unsigned((rows + 3) / 4)), dim3(256), 0, as_stream(stream), x, rows, int(n), ldx, out);
     VLMC_HIP_CHECK_LAUNCH("vlmc_row_mean");
+    return VLMC_OK;
+}
+
+extern "C" int vlmc_softmax_rows(const float *x, int64_t rows, int64_t n, int64_t ldx, float *y, int64_t ldy, void *stream) {
+    VLMC_REQUIRE(x && y, "vlmc_softmax_rows: null pointer");
+    VLMC_REQUIRE(rows >= 0 && n > 0 && n < (int64_t(1) << 24) && ldx >= n && ldy >= n && rows < (int64_t(1) << 33), "vlmc_softmax_rows: bad shape");
+    if (rows == 0) return VLMC_OK;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(unsigned((rows + 3) / 4)), dim3(256), 0, as_stream(stream), x, rows, int(n), ldx, y, ldy);
+    VLMC_HIP_CHECK_LAUNCH("vlmc_softmax_rows");
     return VLMC_OK;
 }

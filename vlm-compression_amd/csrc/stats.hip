@@ -34,6 +34,7 @@ template <typename T, int VEC> __device__ __forceinline__ void vec_load(const ty
 struct SqJob {
     const void *x;
     float *out;                 // [n_calls, out_stride] (first in_f columns written)
+    const int32_t *call_tokens; // device [n_calls] or null: token rows of call c that count (a padded group of ragged samples)
     int64_t row_stride, call_stride, out_stride;
     int32_t in_f, tokens, vec, wg_end;   // wg_end: exclusive prefix end of this job's workgroups in grid.x
 };
@@ -95,12 +96,14 @@ __global__ __launch_bounds__(64) void act_sqnorm_kernel(const SqBatch b) {
     if (ch >= jb.in_f) return;
     const typename T::raw *p = static_cast<const typename T::raw *>(jb.x) + call * jb.call_stride + ch;
     float *o = jb.out + call * jb.out_stride + ch;
+    // (a call's own token count: the rows behind it are padding -- same chain over the same rows as the unpadded call)
+    const int tokens = jb.call_tokens ? min(jb.call_tokens[call], jb.tokens) : jb.tokens;
     if constexpr (sizeof(typename T::raw) == 2) {
-        if (vec == 8) { sqnorm_chain<T, 8, 8>(p, jb.tokens, jb.row_stride, o); return; }
+        if (vec == 8) { sqnorm_chain<T, 8, 8>(p, tokens, jb.row_stride, o); return; }
     }
-    if (vec == 4) sqnorm_chain<T, 4, 16>(p, jb.tokens, jb.row_stride, o);
-    else if (vec == 2) sqnorm_chain<T, 2, 32>(p, jb.tokens, jb.row_stride, o);
-    else sqnorm_chain<T, 1, 32>(p, jb.tokens, jb.row_stride, o);
+    if (vec == 4) sqnorm_chain<T, 4, 16>(p, tokens, jb.row_stride, o);
+    else if (vec == 2) sqnorm_chain<T, 2, 32>(p, tokens, jb.row_stride, o);
+    else sqnorm_chain<T, 1, 32>(p, tokens, jb.row_stride, o);
 }
 
 // s *= float(n/(n+b)); n += b; s += normsq[c] / float(n)   (wanda_pruner.py:77-81)
@@ -203,7 +206,7 @@ static int launch_sqnorm(const vlmc_stat_job *jobs, int n_jobs, int64_t n_calls,
         for (int i = 0; i < b.n; ++i) {
             const vlmc_stat_job &j = jobs[base + i];
             SqJob &d = b.job[i];
-            d.x = j.x; d.out = j.normsq;
+            d.x = j.x; d.out = j.normsq; d.call_tokens = j.call_tokens;
             d.row_stride = j.row_stride; d.call_stride = j.call_stride; d.out_stride = j.normsq_stride;
             d.in_f = int32_t(j.in_features); d.tokens = int32_t(j.tokens);
             d.vec = pick_vec(j, sizeof(typename T::raw), n_calls);
@@ -251,7 +254,7 @@ extern "C" int vlmc_act_sqnorm_batch(const vlmc_stat_job *jobs, int n_jobs, int 
 
 extern "C" int vlmc_act_sqnorm(const void *x, int dtype, int64_t n_calls, int64_t tokens, int64_t in_features,
                                int64_t row_stride, int64_t call_stride, float *normsq, void *stream) {
-    const vlmc_stat_job j{x, normsq, in_features, tokens, row_stride, call_stride, in_features};
+    const vlmc_stat_job j{x, normsq, in_features, tokens, row_stride, call_stride, in_features, nullptr};
     return vlmc_act_sqnorm_batch(&j, 1, dtype, n_calls, stream);
 }
 

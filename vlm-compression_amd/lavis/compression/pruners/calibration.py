@@ -106,6 +106,7 @@ class _PruneContext(threading.local):
       capture_slot    the capture side stream a calibration forward runs on (picks the graph instance and its static buffers)
       capture_sample  index (within this rank's share) of the calibration forward capture_block_inputs is running
       stacked         (samples, batch per sample, sample indices) of the grouped block forward under way (stacked_samples())
+      stacked_lengths {padded token count: int32 device tensor [samples]} of a PADDED group of ragged samples, or None
       capture_side    device -> the side stream graphs are captured on
       stream_set      the caller's stream and the capture side streams of the running capture phase"""
 
@@ -114,6 +115,7 @@ class _PruneContext(threading.local):
         self.capture_slot = None
         self.capture_sample = None
         self.stacked = None
+        self.stacked_lengths = None
         self.capture_side = {}
         self.stream_set = ()
 
@@ -1422,6 +1424,126 @@ def stacked_samples():
     return _CTX.stacked
 
 
+def stacked_lengths(padded_tokens):
+    """During the forward of a PADDED group of ragged samples: the int32 device tensor [samples] of the token rows that are each
+    sample's own, for a hook input whose token dimension has `padded_tokens` rows; None otherwise (nothing is padded)."""
+    ln = _CTX.stacked_lengths
+    return None if ln is None else ln.get(int(padded_tokens))
+
+
+# ---- ragged calibration text: ONE padded forward per block instead of one per distinct length ---------------------------------
+# Real calibration prompts and answers are ragged (blip2_t5_instruct.py:49-53: up to 128 / 256 tokens); grouping the samples by
+# shape makes 7 / 18 groups per encoder / decoder block pass on the bench's ragged set, each a walk of the block's Python.  A
+# tower whose blocks are called with additive attention masks (the reference's T5 stack always is: extended masks,
+# modeling_t5.py:1060-1115) can take all lengths at once: inputs padded with zero rows, masks padded with the dtype's minimum,
+# the cross-attention's states padded with zero rows.  A sample's rows keep their bits because every op of the block is
+# row-wise, or a product on the batch-invariant kernels (extra key columns do not touch the real ones; masked probabilities are
+# exactly 0 in `attn @ v`), or the softmax -- which runs on `vlmc_softmax_rows` during a replay for exactly this reason.  The
+# statistics hooks are told each sample's own token count (stacked_lengths).  `VLMC_PAD_RAGGED=0`: groups of equal shapes only.
+PAD_MASK_KEYS = {"attention_mask": "self", "encoder_attention_mask": "cross"}
+PAD_STATE_KEYS = {"encoder_hidden_states": "cross"}
+
+
+def pad_ragged_enabled():
+    from vlmc import forward as fw
+    return os.environ.get("VLMC_PAD_RAGGED", "1") != "0" and fw.enabled() and fw.attn_matmul_enabled() and fw.softmax_enabled()
+
+
+def plan_padded(cur_in, caches, n_samples, group_max):
+    """[(chunk, spec)] covering samples 0 .. n_samples - 1 with PADDED groups, or None when the samples are not ragged or cannot be
+    padded (no mask kwarg to hide the padding behind, tensors this function does not know how to pad, mixed dtypes / widths)."""
+    if n_samples < 2 or not pad_ragged_enabled():
+        return None
+    x0, c0 = cur_in[0], caches[0]
+    if x0.dim() != 3 or x0.shape[0] != 1 or not x0.is_cuda:
+        return None
+    T, S = [], []
+    for j in range(n_samples):
+        x, c = cur_in[j], caches[j]
+        if x.dim() != 3 or x.shape[0] != 1 or x.shape[2] != x0.shape[2] or x.dtype != x0.dtype or sorted(c) != sorted(c0):
+            return None
+        t, s_len = x.shape[1], None
+        for k, v in c.items():
+            v0 = c0[k]
+            if not isinstance(v, torch.Tensor):
+                if isinstance(v0, torch.Tensor) or (v is not v0 and v != v0):
+                    return None
+                continue
+            if not isinstance(v0, torch.Tensor) or v.dtype != v0.dtype or v.dim() != v0.dim():
+                return None
+            if k in PAD_STATE_KEYS:
+                if v.dim() != 3 or v.shape[0] != 1 or v.shape[2] != v0.shape[2]:
+                    return None
+                s_len = v.shape[1]
+            elif k not in PAD_MASK_KEYS:
+                return None                                           # a tensor kwarg nobody told us how to pad
+        for k, kind in PAD_MASK_KEYS.items():
+            v = c.get(k)
+            if v is None:
+                continue
+            keys = t if kind == "self" else s_len
+            if not (isinstance(v, torch.Tensor) and v.is_floating_point() and v.dim() == 4 and v.shape[0] == 1 and v.shape[1] == 1
+                    and keys is not None and v.shape[3] == keys and v.shape[2] in (1, t)):
+                return None
+        T.append(t)
+        S.append(s_len)
+    ragged_t, ragged_s = len(set(T)) > 1, len(set(S)) > 1
+    if not (ragged_t or ragged_s):
+        return None
+    if ragged_t and not isinstance(c0.get("attention_mask"), torch.Tensor):
+        return None                                                   # nothing to hide padded keys behind
+    if ragged_s and (None in S or not isinstance(c0.get("encoder_attention_mask"), torch.Tensor)):
+        return None
+    try:
+        budget = max(1, int(os.environ.get("VLMC_REPLAY_TOKENS", str(REPLAY_TOKEN_BUDGET))))
+    except ValueError:
+        budget = REPLAY_TOKEN_BUDGET
+    g = max(2, min(group_max, budget // max(T)))
+    out = []
+    for c_ in range(0, n_samples, g):
+        chunk = list(range(c_, min(n_samples, c_ + g)))
+        tp = max(T[j] for j in chunk)
+        sp = max(S[j] for j in chunk) if S[chunk[0]] is not None else None
+        if sp is not None and sp == tp:
+            sp += 8                                                   # the hooks tell the two kinds of input apart by their padded length
+        dev = x0.device
+        lengths = {tp: torch.tensor([T[j] for j in chunk], dtype=torch.int32, device=dev)}
+        if sp is not None:
+            lengths[sp] = torch.tensor([S[j] for j in chunk], dtype=torch.int32, device=dev)
+        out.append((chunk, {"T": [T[j] for j in chunk], "S": [S[j] for j in chunk], "tp": tp, "sp": sp, "lengths": lengths}))
+    return out
+
+
+def _pad_inputs(xs, tp):
+    """[1, T_j, d] tensors -> [n, tp, d], zero rows behind each sample's own"""
+    x = torch.nn.utils.rnn.pad_sequence([x_[0] for x_ in xs], batch_first=True)
+    if x.shape[1] < tp:
+        x = torch.nn.functional.pad(x, (0, 0, 0, tp - x.shape[1]))
+    return x
+
+
+def _pad_caches(group, spec):
+    """The cached kwargs of a padded group as one set: masks padded with the dtype's minimum (keys that do not exist; the rows of
+    queries that do not exist are never read), cross-attention states with zero rows, everything else as the first sample has it."""
+    n, tp, sp = len(group), spec["tp"], spec["sp"]
+    out = {}
+    for k, v0 in group[0].items():
+        if not isinstance(v0, torch.Tensor):
+            out[k] = v0
+        elif k in PAD_STATE_KEYS:
+            x = torch.nn.utils.rnn.pad_sequence([c[k][0] for c in group], batch_first=True)
+            out[k] = torch.nn.functional.pad(x, (0, 0, 0, sp - x.shape[1])) if x.shape[1] < sp else x
+        else:
+            keys = tp if PAD_MASK_KEYS[k] == "self" else sp
+            q = tp if v0.shape[2] != 1 else 1
+            m = torch.full((n, 1, q, keys), torch.finfo(v0.dtype).min, dtype=v0.dtype, device=v0.device)
+            for t, c in enumerate(group):
+                v = c[k]
+                m[t, :, :v.shape[2], :v.shape[3]] = v[0]
+            out[k] = m
+    return out
+
+
 def _stack_key(x, cache):
     sig = [tuple(x.shape), x.dtype]
     for k in sorted(cache):
@@ -1546,7 +1668,7 @@ class BlockGraph:
 
 
 def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocast, prune_block, tuple_output,
-                memo_cache=None):
+                memo_cache=None, pad_ragged=False):
     """The block loop of `_prune`: for every block, `prune_block(i, layer, subset, run)`
     is called with `run()` = one pass of the block over all samples (filling `outs`);
     afterwards the block runs again with whatever weights `prune_block` left, and
@@ -1617,7 +1739,13 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
         shapes = [tuple(cur_in[j].shape) for j in range(n_samples)]
         if plan.get("shapes") != shapes:
             plan["shapes"] = shapes
-            plan["chunks"] = plan_groups(cur_in, caches, n_samples, group_max) if group_max > 1 else [[j] for j in range(n_samples)]
+            padded = plan_padded(cur_in, caches, n_samples, group_max) if (pad_ragged and group_max > 1) else None
+            if padded is not None:                                    # ragged samples: padded groups (`pad_ragged`: the caller's hooks take lengths)
+                plan["chunks"] = [c for c, _ in padded]
+                plan["pad"] = {tuple(c): sp for c, sp in padded}
+            else:
+                plan["chunks"] = plan_groups(cur_in, caches, n_samples, group_max) if group_max > 1 else [[j] for j in range(n_samples)]
+                plan["pad"] = {}
         chunks = plan["chunks"]
         kind = "full" if outputs else "stat"
         for chunk in chunks:
@@ -1635,6 +1763,33 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                     if so is not None:
                         so.end_forward(True)
                     cur_out[j] = y[0] if tuple_output else y
+                elif plan["pad"].get(tuple(chunk)) is not None:
+                    # a PADDED group of ragged samples: one forward; the outputs are handed on padded (the next block takes
+                    # the same tensor), every sample sees its own rows of it
+                    key, spec = tuple(chunk), plan["pad"][tuple(chunk)]
+                    prev = getattr(cur_in[chunk[0]], "_vlmc_stack", None)
+                    if prev is not None and prev[1] == key and all(cur_in[j] is prev[2][t] for t, j in enumerate(chunk)):
+                        x = prev[0]
+                    else:
+                        x = _pad_inputs([cur_in[j] for j in chunk], spec["tp"])
+                    kw = stacked_kwargs.get(key)
+                    if kw is None:
+                        kw = stacked_kwargs[key] = _pad_caches([caches[j] for j in chunk], spec)
+                    _CTX.stacked, _CTX.stacked_lengths = (len(chunk), 1, key), spec["lengths"]
+                    graph_stats["padded_forwards"] = graph_stats.get("padded_forwards", 0) + 1
+                    try:
+                        y = layer(x, **kw)
+                    except _TailStop:
+                        continue
+                    finally:
+                        _CTX.stacked = _CTX.stacked_lengths = None
+                    if so is not None:
+                        so.end_forward(True)
+                    y = y[0] if tuple_output else y
+                    slices = [y[t:t + 1, :tj] for t, tj in enumerate(spec["T"])]
+                    slices[0]._vlmc_stack = (y, key, slices)
+                    for t, j in enumerate(chunk):
+                        cur_out[j] = slices[t]
                 else:
                     b0 = cur_in[chunk[0]].shape[0]
                     _CTX.stacked = (len(chunk), b0, tuple(chunk))

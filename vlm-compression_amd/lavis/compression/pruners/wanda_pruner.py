@@ -68,7 +68,9 @@ class WandaStatCollector:
                 # different activation with the same address/shape in the meantime
                 hit = (x, [None])                    # the holder receives the [calls, in] statistic rows of this tensor
                 self._cache[key] = hit
-                self._pending.append((x.reshape(calls, -1, x.shape[-1]), hit[1]))
+                # a padded group of ragged samples: the token rows of sample c that are its own (the rest is padding)
+                lens = cal.stacked_lengths(x.shape[1]) if calls > 1 and x.dim() == 3 else None
+                self._pending.append((x.reshape(calls, -1, x.shape[-1]), hit[1], lens))
             # one record per hook call: the calibration samples it stands for (grouped replay visits samples out of order;
             # `finalize` puts the per-sample rows back into the reference's order)
             self.rows[name].append((idx, hit[1], b0))
@@ -81,15 +83,16 @@ class WandaStatCollector:
 
     def _flush_pending(self):
         by_dtype = {}
-        for x, holder in self._pending:
-            by_dtype.setdefault(x.dtype, []).append((x, holder))
+        for x, holder, lens in self._pending:
+            by_dtype.setdefault(x.dtype, []).append((x, holder, lens))
         for items in by_dtype.values():
             by_calls = {}
-            for x, holder in items:
-                by_calls.setdefault(x.shape[0], []).append((x, holder))
+            for x, holder, lens in items:
+                by_calls.setdefault(x.shape[0], []).append((x, holder, lens))
             for same in by_calls.values():                     # one launch per group of inputs with equally many calls
-                outs = self._ops.act_sqnorm_batch([x for x, _ in same])
-                for (_, holder), rows in zip(same, outs):
+                lens = [l for _, _, l in same]
+                outs = self._ops.act_sqnorm_batch([x for x, _, _ in same], call_tokens=lens if any(l is not None for l in lens) else None)
+                for (_, holder, _l), rows in zip(same, outs):
                     holder[0] = rows                           # row c = the c-th sample of the call, sliced only where needed
         self._pending = []
 
@@ -276,7 +279,8 @@ class T5LayerWandaPruner(LayerWiseBasePruner, _WandaBlockMixin):
                               sparsity_ratio=sparsity_ratio, lora_model=lora_model)
 
         cal.walk_blocks(model, inps, outs, caches, module_to_process, n_samples,
-                        lambda: model.maybe_autocast(dtype=torch.bfloat16), prune_block, tuple_output=True)
+                        lambda: model.maybe_autocast(dtype=torch.bfloat16), prune_block, tuple_output=True,
+                        pad_ragged=True)                       # (the Wanda statistic takes per-sample token counts: WandaStatCollector)
         _importance_readback(self.__dict__.setdefault("_score_backlog", []), self)
         cfg.use_cache = use_cache
         cal.release_tower_memory()

@@ -21,7 +21,7 @@ _p, _i, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
 
 class StatJob(_c.Structure):          # vlmc_stat_job
     _fields_ = [("x", _p), ("normsq", _p), ("in_features", _i64), ("tokens", _i64), ("row_stride", _i64),
-                ("call_stride", _i64), ("normsq_stride", _i64)]
+                ("call_stride", _i64), ("normsq_stride", _i64), ("call_tokens", _p)]
 
 
 class UpdateJob(_c.Structure):        # vlmc_update_job
@@ -72,6 +72,7 @@ SIGNATURES = {
     "vlmc_linear_fwd_group": (_i, [_p, _p, _i, _i, _i64, _i64, _i64, _p]),
     "vlmc_attn_matmul": (_i, [_p, _p, _p, _i] + [_i64] * 15 + [_p]),
     "vlmc_row_mean": (_i, [_p, _i64, _i64, _i64, _p, _p]),
+    "vlmc_softmax_rows": (_i, [_p, _i64, _i64, _i64, _p, _i64, _p]),
     "vlmc_rms_norm": (_i, [_p, _i, _i64, _i64, _i64, _p, _c.c_float, _i, _p, _i64, _p]),
     "vlmc_sdpa_max_keys": (_i, [_i64]),
     "vlmc_sdpa_fwd": (_i, [_p, _p, _p, _p, _i] + [_i64] * 17 + [_c.c_float, _i, _p]),

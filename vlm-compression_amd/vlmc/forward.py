@@ -35,7 +35,7 @@ from . import ops
 
 _active = 0
 stats = {"kernel": 0, "library": 0, "grouped_launches": 0, "served_from_group": 0, "stash_dropped": 0, "attn_kernel": 0,
-         "attn_library": 0, "mean_kernel": 0, "sdpa_kernel": 0, "sdpa_library": 0, "norm_kernel": 0}
+         "attn_library": 0, "mean_kernel": 0, "sdpa_kernel": 0, "sdpa_library": 0, "norm_kernel": 0, "softmax_kernel": 0}
 
 # first member of a learned sibling group -> tuple of weak references to all members, in call order
 _SIBLINGS = weakref.WeakKeyDictionary()
@@ -281,6 +281,27 @@ def _make_mean(orig):
     return mean
 
 
+def _make_softmax(orig, functional):
+    """`F.softmax(x, dim=-1)` / `torch.softmax(x, -1)` / `x.softmax(-1)` of an fp32 CUDA tensor on `vlmc_softmax_rows`: masked-out
+    entries behind a row's real ones leave its bits alone, so a calibration sample can be padded into a group of longer ones
+    (calibration.py: padded groups); every other call -- another dim, a dtype argument, gradients -- goes to the original."""
+    Tensor, f32 = torch.Tensor, torch.float32
+
+    def softmax(x, *args, **kw):
+        if _ident() == _mm_owner and type(x) is Tensor and x.dtype is f32 and x.is_cuda and not torch.is_grad_enabled() and x.dim() >= 1:
+            dim = args[0] if args else kw.get("dim")
+            extra = set(kw) - {"dim", "_stacklevel", "dtype"}
+            if type(dim) is int and (dim == -1 or dim == x.dim() - 1) and len(args) <= 1 and not extra and kw.get("dtype") is None and x.shape[-1] > 0:
+                stats["softmax_kernel"] += 1
+                return ops.softmax_rows(x)
+        return orig(x, *args, **kw)
+    return softmax
+
+
+def softmax_enabled():
+    return os.environ.get("VLMC_SOFTMAX", "1") != "0"
+
+
 @contextlib.contextmanager
 def invariant_matmuls():
     """Batched 16-bit `matmul`s run on `vlmc_attn_matmul`, fp32 means over the last dimension on `vlmc_row_mean`, for the
@@ -303,6 +324,14 @@ def invariant_matmuls():
             import torch.nn.functional as F_
             _mm_saved["sdpa"] = F_.scaled_dot_product_attention
             F_.scaled_dot_product_attention = _make_sdpa(F_.scaled_dot_product_attention)
+        if softmax_enabled():                                     # the attention's fp32 softmax: padding-invariant
+            import torch.nn.functional as F_
+            _mm_saved["softmax"] = (F_.softmax, torch.softmax)
+            F_.softmax = _make_softmax(F_.softmax, True)
+            torch.softmax = _make_softmax(torch.softmax, False)
+            if "softmax" not in torch.Tensor.__dict__:
+                setattr(torch.Tensor, "softmax", _make_softmax(base.softmax, False))
+                _mm_saved.setdefault("tensor", []).append("softmax")
         if os.environ.get("VLMC_ROW_MEAN", "1") != "0":           # the fp32 mean inside the norms (batch-variant in torch)
             _mm_saved["mean"] = torch.mean
             torch.mean = _make_mean(torch.mean)
@@ -319,6 +348,9 @@ def invariant_matmuls():
             torch.matmul, torch.bmm = _mm_saved.pop("matmul"), _mm_saved.pop("bmm")
             if "mean" in _mm_saved:
                 torch.mean = _mm_saved.pop("mean")
+            if "softmax" in _mm_saved:
+                import torch.nn.functional as F_
+                F_.softmax, torch.softmax = _mm_saved.pop("softmax")
             if "sdpa" in _mm_saved:
                 import torch.nn.functional as F_
                 F_.scaled_dot_product_attention = _mm_saved.pop("sdpa")

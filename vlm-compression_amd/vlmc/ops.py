@@ -354,6 +354,21 @@ def row_mean(x: torch.Tensor, keepdim: bool = False) -> torch.Tensor:
     return out
 
 
+def softmax_rows(x: torch.Tensor) -> torch.Tensor:
+    """`torch.softmax(x, -1)` for fp32 CUDA tensors on the padding-invariant kernel (include/vlmc.h: vlmc_softmax_rows)."""
+    _need_gpu(x)
+    if x.dtype != torch.float32 or x.dim() < 1 or x.shape[-1] == 0:
+        raise TypeError("vlmc.softmax_rows: a non-empty fp32 tensor expected")
+    n = x.shape[-1]
+    x2 = x.reshape(-1, n)
+    if x2.stride(1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < n):
+        x2 = x2.contiguous()
+    rows = x2.shape[0]
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().vlmc_softmax_rows(x2.data_ptr(), rows, n, x2.stride(0) if rows > 1 else n, out.data_ptr(), n, _stream()))
+    return out
+
+
 def hessian_accum(H: torch.Tensor, x: torch.Tensor, alpha: float, beta: float) -> torch.Tensor:
     """H = alpha * H + beta * x^T x on the tiles on and below the diagonal (SparseGPT.add_batch, sparsegpt_pruner.py:76-79,
     with alpha = n/(n+b) and beta = 2/(n+b)); x [rows, in] fp16 / bf16 / fp32.  `symmetrize_lower(H)` completes H."""
@@ -471,10 +486,13 @@ def select_partials(mode: str, out_f: int, in_f: int) -> int:
 # ---------------------------------------------------------------------------------------
 # Batched entry points: all hook inputs / statistics / linears of one transformer block per launch
 # ---------------------------------------------------------------------------------------
-def _stat_jobs(xs, outs):
+def _stat_jobs(xs, outs, call_tokens=None):
     jobs = (_lib.StatJob * len(xs))()
     calls = xs[0].shape[0]
     for j, (x, out) in enumerate(zip(xs, outs)):
+        ct = call_tokens[j] if call_tokens is not None else None
+        if ct is not None:
+            assert ct.dtype == torch.int32 and ct.is_cuda and ct.is_contiguous() and ct.numel() == calls
         _need_gpu(x, out)
         assert x.dim() == 3 and x.stride(2) == 1 and x.shape[0] == calls and x.dtype == xs[0].dtype
         assert out.dtype == torch.float32 and out.shape == (calls, x.shape[2]) and out.stride(1) == 1
@@ -483,17 +501,19 @@ def _stat_jobs(xs, outs):
         call_stride = x.stride(0) if calls > 1 else tokens * row_stride
         assert row_stride >= in_f
         jobs[j] = _lib.StatJob(x.data_ptr(), out.data_ptr(), in_f, tokens, row_stride, call_stride,
-                               out.stride(0) if calls > 1 else in_f)
+                               out.stride(0) if calls > 1 else in_f, ct.data_ptr() if ct is not None else None)
     return jobs, calls
 
 
-def act_sqnorm_batch(xs, outs=None):
+def act_sqnorm_batch(xs, outs=None, call_tokens=None):
     """`act_sqnorm` for several hook inputs ([calls, tokens, in_j], same dtype and calls) in one launch.
-    `outs[j]` may be a column slice of a wider fp32 buffer (row stride = the buffer's width)."""
+    `outs[j]` may be a column slice of a wider fp32 buffer (row stride = the buffer's width).  `call_tokens[j]` (int32 device
+    tensor [calls] or None): only the first call_tokens[j][c] token rows of call c of input j count -- a padded group of ragged
+    calibration samples."""
     xs = [x if x.stride(-1) == 1 else x.contiguous() for x in xs]
     if outs is None:
         outs = [torch.empty((x.shape[0], x.shape[2]), dtype=torch.float32, device=x.device) for x in xs]
-    jobs, calls = _stat_jobs(xs, outs)
+    jobs, calls = _stat_jobs(xs, outs, call_tokens)
     _lib.check(_lib.load().vlmc_act_sqnorm_batch(jobs, len(xs), _dtype_code(xs[0]), calls, _stream()))
     return outs
 
