@@ -189,7 +189,10 @@ def install_probes(probe):
     mixed launch per T5 block) are single launches behind one `vlmc.ops` call each."""
     from vlmc import ops
 
-    def sq_bytes(xs, outs=None):
+    def sq_bytes(xs, outs=None, call_tokens=None):
+        if call_tokens is not None and any(ct is not None for ct in call_tokens):     # a padded group of ragged samples: only a sample's own rows are read
+            return sum((int(ct.sum()) if ct is not None else x.shape[0] * x.shape[1]) * x.shape[-1] * x.element_size() + x.shape[0] * x.shape[-1] * 4
+                       for x, ct in zip(xs, call_tokens))
         return sum(x.numel() * x.element_size() + x.shape[0] * x.shape[-1] * 4 for x in xs)
 
     def sel_bytes(ws, sqs, mode, ks=None, n=0, m=0, apply_zero=True, **kw):
@@ -393,11 +396,19 @@ def reference_ops_leg(dev, steps):
     groups = []
     real_plan = cal.plan_groups
 
+    real_padded = cal.plan_padded
+
     def counting(*a, **k):
         chunks = real_plan(*a, **k)
         groups.append(len(chunks))
         return chunks
-    cal.plan_groups = counting
+
+    def counting_padded(*a, **k):                             # ragged samples padded into one forward (round 5): counted the same way
+        padded = real_padded(*a, **k)
+        if padded is not None:
+            groups.append(len(padded))
+        return padded
+    cal.plan_groups, cal.plan_padded = counting, counting_padded
     # the attention products' kernel inside these prunes: every 4th launch carries HIP events in its own dispatch
     from vlmc import ops
     probe = LaunchProbe(4)
@@ -421,7 +432,7 @@ def reference_ops_leg(dev, steps):
         probe.active = False
         plans = list(groups)
     finally:
-        cal.plan_groups = real_plan
+        cal.plan_groups, cal.plan_padded = real_plan, real_padded
         probe.restore()
     a_ms, a_bytes, a_n = probe.summary("attn")
     attn_kernel = None
