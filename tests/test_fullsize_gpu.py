@@ -147,8 +147,8 @@ def test_full_width_blocks_through_the_grouped_walk_match_the_c_oracle(monkeypat
     real_sq, real_prune = ops.act_sqnorm_batch, wanda.prune_block
     seen = {"stat_inputs": 0, "linears": 0, "groups": []}
 
-    def checked_sqnorm(xs, outs=None):
-        rows = real_sq(xs, outs)
+    def checked_sqnorm(xs, outs=None, **kw):
+        rows = real_sq(xs, outs, **kw)
         for x, r in zip(xs, rows):
             seen["groups"].append(x.shape[0])
             for c in (0, x.shape[0] // 2, x.shape[0] - 1):

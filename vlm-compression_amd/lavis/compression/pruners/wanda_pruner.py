@@ -91,7 +91,10 @@ class WandaStatCollector:
                 by_calls.setdefault(x.shape[0], []).append((x, holder, lens))
             for same in by_calls.values():                     # one launch per group of inputs with equally many calls
                 lens = [l for _, _, l in same]
-                outs = self._ops.act_sqnorm_batch([x for x, _, _ in same], call_tokens=lens if any(l is not None for l in lens) else None)
+                if any(l is not None for l in lens):           # a padded group of ragged samples
+                    outs = self._ops.act_sqnorm_batch([x for x, _, _ in same], call_tokens=lens)
+                else:
+                    outs = self._ops.act_sqnorm_batch([x for x, _, _ in same])
                 for (_, holder, _l), rows in zip(same, outs):
                     holder[0] = rows                           # row c = the c-th sample of the call, sliced only where needed
         self._pending = []
