@@ -449,6 +449,7 @@ class TowerGraph:
     def __init__(self, modules):
         self.mods, self.n = list(modules), len(modules)
         self.plans, self.traces, self.wirings = {}, {}, {}
+        self.by_struct = {}                   # argument signature without the tensor extents -> a key whose wiring is known
         self.deferred, self.ready = [], {}    # forwards postponed at block 0; their per-block outputs once the tower ran
         # block-0 calls of this tower as its OWN capture phase saw them, by sample (capture_block_inputs): what the model
         # will hand block 0 again in the next phase, if nothing upstream changed -- run_predicted()
@@ -478,6 +479,27 @@ class TowerGraph:
                 sig.append(first.setdefault(id(v), pos))                 # which arguments are one and the same tensor
         return tuple(sig) + tuple(sorted(kwargs))
 
+    @staticmethod
+    def _struct(key):
+        return tuple(("T", len(e[1])) + e[2:] if isinstance(e, tuple) and len(e) == 4 and e[0] == "T" else e for e in key)
+
+    def _wiring(self, key):
+        """The wiring for a block-0 signature: its own, else the one traced for a signature that differs in tensor EXTENTS only
+        (ragged calibration samples: 7 sequence lengths were 7 eager batch-1 trace forwards per tower and phase, ~9 ms each).
+        A wiring says which argument is which earlier output / outside tensor / plain value, nothing about sizes; a model that
+        does pass a size-dependent plain value to a later block is caught where every served forward is checked (`_serve`
+        compares each plain value with the traced one and leaves the tower path on a difference).  `VLMC_TOWER_SHARE_WIRING=0`:
+        one trace per exact signature, as in rounds 2-4."""
+        if key is None:
+            return False
+        w = self.wirings.get(key)
+        if w is None and os.environ.get("VLMC_TOWER_SHARE_WIRING", "1") != "0":
+            k2 = self.by_struct.get(self._struct(key))
+            if k2 is not None and self.wirings.get(k2):
+                w = self.wirings[key] = self.wirings[k2]
+                graph_stats["shared_wirings"] = graph_stats.get("shared_wirings", 0) + 1
+        return w
+
     def _wire(self, v, known):
         if isinstance(v, torch.Tensor):
             src = known.get(id(v))
@@ -497,7 +519,7 @@ class TowerGraph:
         if index == 0:
             self.live = self.trace = self.btrace = None
             key = self._key0(args, kwargs)
-            wiring = self.wirings.get(key) if key is not None else False
+            wiring = self._wiring(key)
             if os.environ.get("VLMC_DEBUG_TOWERS"):
                 print("TOWER", getattr(self, "path", "?"), "sample", _CTX.capture_sample, "key", key is not None, "wiring",
                       None if wiring is None else (False if wiring is False else "known"), "ready", len(self.ready), "predicted", len(self.predicted),
@@ -688,6 +710,7 @@ class TowerGraph:
         seen.append(calls)
         if len(seen) >= self.NEED:
             self.wirings[key] = calls
+            self.by_struct.setdefault(self._struct(key), key)
 
     def _build(self, calls, args, kwargs):
         try:
@@ -818,7 +841,7 @@ class TowerGraph:
             if rec is None:
                 continue
             key = self._key0(rec[0], rec[1], rec[2])
-            if key is None or self.wirings.get(key) is not None:
+            if key is None or self._wiring(key) is not None:
                 continue
             have = count.get(key, len(self.traces.get(key, [])))
             if have < self.NEED:
@@ -848,7 +871,7 @@ class TowerGraph:
             if any(t._version != v for t, v in versions):               # written to since it was captured
                 continue
             key = self._key0(args, kwargs, ctx)
-            wiring = self.wirings.get(key) if key is not None else None
+            wiring = self._wiring(key) if key is not None else None
             if not wiring or not self._batchable(args, kwargs, ctx):
                 continue
             recs.append({"j": j, "key": key, "args": args, "kwargs": kwargs, "ctx": ctx})
