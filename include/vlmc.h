@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLMC_ABI_VERSION 13
+#define VLMC_ABI_VERSION 14
 
 #define VLMC_OK 0
 #define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
@@ -282,13 +282,37 @@ int vlmc_sdpa_fwd(const void *Q, const void *K, const void *V, void *O, int dtyp
  * x [rows, n] fp32 (row stride ldx elements), out [rows] fp32.                                                 */
 int vlmc_row_mean(const float *x, int64_t rows, int64_t n, int64_t ldx, float *out, void *stream);
 
-/* Row-wise softmax over the last dimension of an fp32 matrix, PADDING-invariant: `F.softmax(scores.float(), dim=-1)` of the
- * blocks' attention (modeling_t5.py:604-606; eva_vit.py:158) during a replay.  One wave per row; lane l takes elements
- * l + 64 i in ascending i for the maximum and for the sum of expf(x - max), fixed butterflies, one IEEE division per element.
+/* Row-wise softmax over the last dimension, PADDING-invariant: `F.softmax(scores.float(), dim=-1)` (modeling_t5.py:604-606),
+ * `attn.softmax(dim=-1)` on 16-bit scores (eva_vit.py:158), `nn.Softmax(dim=-1)(scores)` (Qformer.py:228) during a replay.
+ * fp32 arithmetic in ONE fixed order (csrc/softmax_order.hpp): the maximum; e_j = expf(x_j - max); 16 class sums (class =
+ * j mod 16, ascending j); a butterfly over the classes; one IEEE division per element; rounded once if the output is 16-bit.
  * Entries that are masked out (x + finfo.min: expf gives exactly 0) behind a row's real entries add +0 to sums that are
- * otherwise formed in the same order: a sample's row has the same bits alone and padded to a longer group.
- * x [rows, n] (row stride ldx), y [rows, n] (row stride ldy), both fp32; y may alias x.                                  */
-int vlmc_softmax_rows(const float *x, int64_t rows, int64_t n, int64_t ldx, float *y, int64_t ldy, void *stream);
+ * otherwise formed in the same order: a sample's row has the same bits alone and padded to a longer group.  vlmc_attn_fwd
+ * forms its softmax in the same order.
+ * x [rows, n] (row stride ldx), y [rows, n] (row stride ldy); in_dtype / out_dtype: VLMC_F32 -> VLMC_F32, or VLMC_F16 / VLMC_BF16 ->
+ * the same dtype or VLMC_F32 (`softmax(x, dim=-1, dtype=torch.float32)`); y may alias x when the dtypes are equal.            */
+int vlmc_softmax_rows(const void *x, int in_dtype, int64_t rows, int64_t n, int64_t ldx, void *y, int out_dtype, int64_t ldy,
+                      void *stream);
+
+/* ---- the attention of a replayed block as the reference's model files write it, in one launch (MFMA) --------------------
+ * eva_vit.py:145-164, modeling_t5.py:588-640, Qformer.py:205-246 spell attention out as tensor ops that each round to the
+ * 16-bit dtype:  scores = q @ k^T;  [scores = scores * mul  (`/ sqrt(d)` is torch's multiply by the fp32 reciprocal)];
+ * [scores += add0 [+= add1]  (position bias, extended mask: broadcast over batch / heads / queries through stride 0)];
+ * probs = softmax in fp32, rounded to the dtype;  out = probs @ v.  This entry point computes exactly that chain -- every
+ * intermediate rounded where the tensor op would round it, both products in vlmc_attn_matmul's accumulation order, the
+ * softmax in vlmc_softmax_rows' order -- without the [batch, heads, Tq, Tk] scores ever being in HBM: the result has the
+ * bits of the unfused sequence on this library's kernels (tests/test_attn_fused_gpu.py).
+ * Q [batch, heads, Tq, head_dim], K, V [batch, heads, Tk, head_dim] read in place through ELEMENT strides {batch, head, token}
+ * (head_dim stride 1); add0 / add1: NULL or 16-bit tensors of the same dtype with element strides {batch, head, query, key} (any
+ * of the first three 0 = broadcast; key stride 1 is the fast path, T5's permuted [Tq, Tk, heads] bias table has stride heads); O is written as a contiguous [batch, Tq, heads, head_dim] tensor (the model's
+ * `.transpose(1, 2).reshape(batch, Tq, heads * head_dim)` is then a view).  head_dim: a multiple of 8, at most 128; Tk at most
+ * vlmc_attn_max_keys(head_dim) (512 / 352 / 288 for head_dim <= 64 / 96 / 128: a head's K and V live in LDS).
+ * Batch- and padding-invariant like vlmc_attn_matmul / vlmc_softmax_rows.                                                    */
+int vlmc_attn_max_keys(int64_t head_dim);
+int vlmc_attn_fwd(const void *Q, const void *K, const void *V, void *O, int dtype, int64_t batch, int64_t heads, int64_t Tq,
+                  int64_t Tk, int64_t head_dim, const int64_t *q_strides, const int64_t *k_strides, const int64_t *v_strides,
+                  int has_mul, float mul, const void *add0, const int64_t *add0_strides, const void *add1,
+                  const int64_t *add1_strides, void *stream);
 
 /* ---- the RMS norm of a language-model block in one launch ---------------------------------------------
  * Replaces the op sequence of transformers' T5LayerNorm.forward / LlamaRMSNorm.forward inside a replayed block

@@ -125,7 +125,8 @@ def test_attention_written_as_batched_matmuls_is_identical_for_every_grouping(me
     from vlmc import forward
     before = dict(forward.stats)
     ref = _run_16bit_toy(method, 1, monkeypatch, ragged=ragged, sdpa="matmul16")
-    assert forward.stats["attn_kernel"] > before["attn_kernel"], "the attention products did not run on the invariant kernel"
+    assert forward.stats["attn_kernel"] + forward.stats["attn_fused"] > before["attn_kernel"] + before["attn_fused"], \
+        "the attention products did not run on the invariant kernels"
     assert forward.stats["attn_library"] == before["attn_library"]
     for group in (3, 128):
         got = _run_16bit_toy(method, group, monkeypatch, ragged=ragged, sdpa="matmul16")
@@ -183,11 +184,12 @@ def test_ragged_samples_padded_into_one_group_keep_their_bits(lora_model, monkey
                                          enc_depth=3, dec_depth=3, vocab=100, query_tokens=4, reference_ops=True, qformer_dim=64, qformer_heads=4,
                                          qformer_hidden=128, qformer_depth=2, qformer_vocab=50).to(dev).eval()
         batches = synthetic.calibration_batches(16, dev, vit_tokens=9, vit_dim=64, vocab=100, ragged=True)
-        before = (calibration.graph_stats.get("padded_forwards", 0), forward.stats["softmax_kernel"])
+        before = (calibration.graph_stats.get("padded_forwards", 0), forward.stats["softmax_kernel"] + forward.stats["attn_fused"])
         synthetic.time_prune(dev, n_samples=16, model=model, batches=batches, **({"t5_prune_spec": "3-0.5-1.0-1.0"}))
         out = {n: (m.weight.detach().clone(), m.mask.clone() if hasattr(m, "mask") else None) for n, m in model.named_modules()
                if isinstance(m, torch.nn.Linear) and (".block." in n or ".blocks." in n)}
-        return out, calibration.graph_stats.get("padded_forwards", 0) - before[0], forward.stats["softmax_kernel"] - before[1]
+        return out, calibration.graph_stats.get("padded_forwards", 0) - before[0], \
+            forward.stats["softmax_kernel"] + forward.stats["attn_fused"] - before[1]       # (the softmax kernel, alone or inside the fused attention)
 
     base = {"VLMC_BATCH_REPLAY": "128", "VLMC_TOWER_BATCH": "1", "VLMC_PAD_RAGGED": "1"}
     padded, n_padded, n_softmax = run(base)

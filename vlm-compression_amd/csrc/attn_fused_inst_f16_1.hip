@@ -1,0 +1,6 @@
+// instantiations of csrc/attn_fused_kernel.hpp: f16, 1 addend(s) (a translation unit of their own: `make -j` compiles them side by side)
+#include "attn_fused_kernel.hpp"
+
+namespace vlmc {
+int attn_dispatch_f16_1(const AttnArgs &a, int64_t bh, int ds, hipStream_t s) { return attn_dispatch<f16_t, 1>(a, bh, ds, s); }
+}  // namespace vlmc

@@ -11,6 +11,9 @@
 // IEEE division by n.  A row's mean depends on the row and n only.  HBM-bound (4 B read per element), one launch.
 #include "common.hpp"
 #include "mfma.hpp"
+#include "softmax_order.hpp"
+
+#include <type_traits>
 
 namespace vlmc {
 namespace {
@@ -44,51 +47,28 @@ __global__ __launch_bounds__(256) void row_mean_kernel(const float *__restrict__
 
 
 // ---- vlmc_softmax_rows: padding-invariant softmax over the last dimension (include/vlmc.h) --------------------------------------
-// One wave per row, lane l owns elements l + 64 i.  Rows of up to 1024 elements stay in registers (one read); longer rows are
-// read three times (L2).
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float *__restrict__ x, int64_t rows, int n, int64_t ldx,
-                                                           float *__restrict__ y, int64_t ldy) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float *p = x + row * ldx;
-    float *q = y + row * ldy;
-    constexpr int R = 16;
-    if (n <= 64 * R) {
-        float v[R];
-        float mx = -__builtin_inff();
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const int c = lane + 64 * i;
-            v[i] = c < n ? p[c] : -__builtin_inff();
-            mx = fmaxf(mx, v[i]);
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, kWave));
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            v[i] = lane + 64 * i < n ? expf(v[i] - mx) : 0.f;
-            sum = ieee_add(sum, v[i]);
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sum = ieee_add(sum, __shfl_xor(sum, off, kWave));
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const int c = lane + 64 * i;
-            if (c < n) q[c] = ieee_div(v[i], sum);
-        }
-        return;
-    }
+// The canonical order (softmax_order.hpp; the fused attention kernel forms the same sums from its accumulators): element j
+// belongs to class j mod 16; 16 lanes per row, lane c walks its class in ascending j.  Three passes over the row (L1 / L2).
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const typename TI::raw *__restrict__ x, int64_t rows, int n, int64_t ldx,
+                                                           typename TO::raw *__restrict__ y, int64_t ldy) {
+    const int c = threadIdx.x & 15;
+    const int64_t row = int64_t(blockIdx.x) * 16 + (threadIdx.x >> 4);
+    if (row >= rows) return;                                               // (whole 16-lane groups: the shuffles below stay inside a group)
+    const typename TI::raw *p = x + row * ldx;
+    typename TO::raw *q = y + row * ldy;
     float mx = -__builtin_inff();
-    for (int c = lane; c < n; c += 64) mx = fmaxf(mx, p[c]);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, kWave));
+    for (int j = c; j < n; j += 16) mx = fmaxf(mx, to_f32<TI>(p[j]));
+    mx = softmax_class_max(mx);
     float sum = 0.f;
-    for (int c = lane; c < n; c += 64) sum = ieee_add(sum, expf(p[c] - mx));
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sum = ieee_add(sum, __shfl_xor(sum, off, kWave));
-    for (int c = lane; c < n; c += 64) q[c] = ieee_div(expf(p[c] - mx), sum);
+    for (int j = c; j < n; j += 16) sum = ieee_add(sum, softmax_exp(to_f32<TI>(p[j]), mx));
+    sum = softmax_class_tree(sum);
+    const float inv = softmax_inv(sum);
+    for (int j = c; j < n; j += 16) {
+        const float r = softmax_prob(softmax_exp(to_f32<TI>(p[j]), mx), inv);
+        if constexpr (std::is_same<TO, f32_t>::value) q[j] = r;
+        else q[j] = from_f32<TO>(r);
+    }
 }
 
 // ---- vlmc_rms_norm: the whole RMS norm of a language-model block in one pass -------------------------------------------------
@@ -200,11 +180,25 @@ extern "C" int vlmc_row_mean(const float *x, int64_t rows, int64_t n, int64_t ld
     return VLMC_OK;
 }
 
-extern "C" int vlmc_softmax_rows(const float *x, int64_t rows, int64_t n, int64_t ldx, float *y, int64_t ldy, void *stream) {
+extern "C" int vlmc_softmax_rows(const void *x, int in_dtype, int64_t rows, int64_t n, int64_t ldx, void *y, int out_dtype, int64_t ldy,
+                                 void *stream) {
     VLMC_REQUIRE(x && y, "vlmc_softmax_rows: null pointer");
     VLMC_REQUIRE(rows >= 0 && n > 0 && n < (int64_t(1) << 24) && ldx >= n && ldy >= n && rows < (int64_t(1) << 33), "vlmc_softmax_rows: bad shape");
+    VLMC_REQUIRE((in_dtype == VLMC_F32 && out_dtype == VLMC_F32) || ((in_dtype == VLMC_F16 || in_dtype == VLMC_BF16) &&
+                 (out_dtype == in_dtype || out_dtype == VLMC_F32)),
+                 "vlmc_softmax_rows: fp32 -> fp32, or fp16 / bf16 -> the same dtype or fp32");
     if (rows == 0) return VLMC_OK;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(unsigned((rows + 3) / 4)), dim3(256), 0, as_stream(stream), x, rows, int(n), ldx, y, ldy);
+    const dim3 grid{unsigned((rows + 15) / 16)}, block{256};
+    hipStream_t s = as_stream(stream);
+#define VLMC_SM(TI, TO)                                                                                                          \
+    hipLaunchKernelGGL((softmax_rows_kernel<TI, TO>), grid, block, 0, s, static_cast<const typename TI::raw *>(x), rows, int(n), ldx,   \
+                       static_cast<typename TO::raw *>(y), ldy)
+    if (in_dtype == VLMC_F32) VLMC_SM(f32_t, f32_t);
+    else if (in_dtype == VLMC_F16 && out_dtype == VLMC_F16) VLMC_SM(f16_t, f16_t);
+    else if (in_dtype == VLMC_F16) VLMC_SM(f16_t, f32_t);
+    else if (out_dtype == VLMC_BF16) VLMC_SM(bf16_t, bf16_t);
+    else VLMC_SM(bf16_t, f32_t);
+#undef VLMC_SM
     VLMC_HIP_CHECK_LAUNCH("vlmc_softmax_rows");
     return VLMC_OK;
 }

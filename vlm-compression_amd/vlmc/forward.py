@@ -35,7 +35,8 @@ from . import ops
 
 _active = 0
 stats = {"kernel": 0, "library": 0, "grouped_launches": 0, "served_from_group": 0, "stash_dropped": 0, "attn_kernel": 0,
-         "attn_library": 0, "mean_kernel": 0, "sdpa_kernel": 0, "sdpa_library": 0, "norm_kernel": 0, "softmax_kernel": 0}
+         "attn_library": 0, "mean_kernel": 0, "sdpa_kernel": 0, "sdpa_library": 0, "norm_kernel": 0, "softmax_kernel": 0,
+         "attn_fused": 0, "attn_chain_unfused": 0, "attn_fused_checks": 0}
 
 # first member of a learned sibling group -> tuple of weak references to all members, in call order
 _SIBLINGS = weakref.WeakKeyDictionary()
@@ -221,15 +222,319 @@ def attn_matmul_enabled():
     return os.environ.get("VLMC_ATTN_MATMUL", "1") != "0"
 
 
+# ---- the reference-op attention chain in ONE launch ---------------------------------------------------------------------------
+# The reference's model files write attention as separate tensor ops (eva_vit.py:145-164, modeling_t5.py:588-640,
+# Qformer.py:205-246):  scores = q @ k^T;  [scores / sqrt(d)];  [scores + bias (+ mask)];  softmax (in fp32);  probs @ v -- with
+# the patches above that is 5-7 launches and ~8 passes over the [B, H, Tq, Tk] scores per attention.  `vlmc_attn_fwd`
+# (csrc/attn_fused_kernel.hpp) computes the same chain, rounding where each op rounds, in one launch.  To splice it under model
+# code that nobody here may rewrite, the first product is answered LAZILY: the patched `matmul` hands out a `LazyScores` -- a
+# tensor subclass without storage that only remembers (q, k) -- and every op the model then applies to it arrives in
+# `__torch_function__`:
+#   * the ops of the chain (`+=` / `+` a 16-bit tensor, `/` or `*` a Python number, `.float()`, softmax over the last dim,
+#     `.type_as` / `.to(dtype)`, dropout in eval mode) are RECORDED, twice: literally (function + arguments, for a replay) and as
+#     the fused kernel's arguments;
+#   * the second product `matmul(lazy, v)` runs the fused kernel if the recorded chain is one it computes;
+#   * ANY other op -- or a chain the kernel does not take -- first REALIZES the tensor: the literal record is replayed on the
+#     unfused kernels (`vlmc_attn_matmul`, torch's elementwise ops, `vlmc_softmax_rows`), and the op runs on the result.
+# So the model's code sees exactly the values it would have seen; the only thing that changes is when they are computed.  The
+# first time a chain SIGNATURE (dtype, head_dim, multiplier?, addend broadcast pattern, fp32 detour?) reaches the fused kernel,
+# its output is compared bit for bit with the unfused sequence on the same operands (one extra pass, once per process and
+# signature); a mismatch switches the signature off for good.  `VLMC_ATTN_FUSED=0`: never lazy.
+_SELF = object()
+_FUSED_OK = {}                # chain signature -> True / False
+_LAZY_LIVE = weakref.WeakSet()    # lazy tensors somebody still holds: realized when the patches go (their record replays patched functions)
+
+
+def attn_fused_enabled():
+    return os.environ.get("VLMC_ATTN_FUSED", "1") != "0"
+
+
+_LAZY_META_PROPS = {"shape", "dtype", "device", "ndim", "is_cuda", "requires_grad", "layout", "is_sparse", "is_quantized", "is_meta",
+                    "is_leaf", "grad_fn", "is_cpu", "is_nested", "names"}
+_LAZY_META_FUNCS = set()
+
+
+class LazyScores(torch.Tensor):
+    """`q @ k^T` of an attention, not computed yet (see above).  `_state`: s16 scores in the dtype, s32 after `.float()`,
+    p32 / p16 probabilities in fp32 / the dtype."""
+
+    @staticmethod
+    def __new__(cls, q, kt, shape, dtype, state="s16", ops_=(), mul=None, adds=(), base=None):
+        r = torch.Tensor._make_wrapper_subclass(cls, shape, dtype=dtype, device=q.device)
+        r._q, r._kt, r._state, r._ops, r._mul, r._adds, r._real = q, kt, state, list(ops_), mul, list(adds), None
+        r._dt16 = q.dtype if base is None else base
+        _LAZY_LIVE.add(r)
+        return r
+
+    def _child(self, state, dtype=None):
+        return LazyScores(self._q, self._kt, self.shape, self.dtype if dtype is None else dtype, state, self._ops, self._mul, self._adds,
+                          self._dt16)
+
+    def _realize(self):
+        """The tensor the model's ops would have produced so far, on the unfused kernels."""
+        if self._real is None:
+            t = ops.attn_matmul(self._q, self._kt)
+            for func, args, kwargs in self._ops:
+                t = func(*[t if a_ is _SELF else a_ for a_ in args], **{k_: (t if v_ is _SELF else v_) for k_, v_ in kwargs.items()})
+            self._real = t
+            stats["attn_kernel"] += 1
+            stats["attn_chain_unfused"] += 1
+        return self._real
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        h = _LAZY_HANDLERS.get(func)
+        if h is not None:
+            r = h(func, args, kwargs)
+            if r is not NotImplemented:
+                return r
+        elif func in _LAZY_META_FUNCS or (getattr(func, "__name__", None) == "__get__" and
+                                         getattr(getattr(func, "__self__", None), "__name__", None) in _LAZY_META_PROPS):
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        return func(*_real_args(args), **{k_: _real_arg(v_) for k_, v_ in kwargs.items()})
+
+
+def _lazy_dispatch(cls, func, types, args=(), kwargs=None):
+    """Below `__torch_function__` (an op that reached the dispatcher with a lazy operand all the same): its value."""
+    return func(*_real_args(args), **{k_: _real_arg(v_) for k_, v_ in (kwargs or {}).items()})
+
+
+LazyScores.__torch_dispatch__ = classmethod(_lazy_dispatch)
+
+
+def _real_arg(v):
+    if type(v) is LazyScores:
+        return v._realize()
+    if type(v) in (tuple, list):
+        return type(v)(_real_arg(e) for e in v)
+    return v
+
+
+def _real_args(args):
+    return [_real_arg(v) for v in args]
+
+
+def _is_number(v):
+    return type(v) in (int, float)
+
+
+def _fp32(v):
+    import numpy as np
+    return float(np.float32(v))
+
+
+def _lz_add(func, args, kw, inplace=False):
+    if kw or len(args) != 2:
+        return NotImplemented
+    a, b = args
+    if type(b) is LazyScores:
+        if inplace:
+            return NotImplemented
+        a, b = b, a
+        pos = (b, _SELF)
+    else:
+        pos = (_SELF, b)
+    if type(a) is not LazyScores or a._real is not None or a._state != "s16" or len(a._adds) >= 2 or type(b) is not torch.Tensor or \
+            b.dtype != a._dt16 or b.device != a._q.device or b.requires_grad or b.dim() > 4 or b.dim() == 0:
+        return NotImplemented
+    sh = (1,) * (4 - b.dim()) + tuple(b.shape)
+    if any(n not in (1, m) for n, m in zip(sh[:3], a.shape[:3])) or sh[3] != a.shape[3] or min(b.stride()) < 0 or (b.stride(-1) < 1 and sh[3] != 1):
+        return NotImplemented
+    r = a if inplace else a._child("s16")
+    r._ops.append((func, pos, {}))
+    r._adds.append(b)
+    return r
+
+
+def _lz_iadd(func, args, kw):
+    return _lz_add(func, args, kw, True)
+
+
+def _lz_scale(func, args, kw, divide):
+    if kw or len(args) != 2:
+        return NotImplemented
+    a, c = args
+    if type(a) is not LazyScores or a._real is not None or a._state != "s16" or a._adds or a._mul is not None or not _is_number(c) or \
+            (divide and c == 0):
+        return NotImplemented
+    import numpy as np
+    # torch divides a 16-bit CUDA tensor by a CPU scalar as a multiplication with the fp32 reciprocal (BinaryDivTrueKernel.cu)
+    m = float(np.float32(1.0) / np.float32(c)) if divide else _fp32(c)
+    if not (m == m and abs(m) != float("inf")):
+        return NotImplemented
+    r = a._child("s16")
+    r._ops.append((func, (_SELF, c), {}))
+    r._mul = m
+    return r
+
+
+def _lz_div(func, args, kw):
+    return _lz_scale(func, args, kw, True)
+
+
+def _lz_mul(func, args, kw):
+    if len(args) == 2 and type(args[0]) is not LazyScores:
+        return NotImplemented                                          # (number * lazy arrives as __rmul__(lazy, number))
+    return _lz_scale(func, args, kw, False)
+
+
+def _lz_cast(a, dtype, func, args, kw):
+    if type(a) is not LazyScores or a._real is not None or not isinstance(dtype, torch.dtype):
+        return NotImplemented
+    if dtype == a.dtype:
+        return a
+    if dtype == torch.float32 and a._state == "s16":
+        r = a._child("s32", torch.float32)
+    elif dtype == a._dt16 and a._state == "p32":
+        r = a._child("p16", a._dt16)
+    else:
+        return NotImplemented
+    r._ops.append((func, tuple(_SELF if v is a else v for v in args), dict(kw)))
+    return r
+
+
+def _lz_float(func, args, kw):
+    return _lz_cast(args[0], torch.float32, func, args, kw) if len(args) == 1 and not kw else NotImplemented
+
+
+def _lz_half(func, args, kw):
+    return _lz_cast(args[0], torch.float16, func, args, kw) if len(args) == 1 and not kw else NotImplemented
+
+
+def _lz_bfloat16(func, args, kw):
+    return _lz_cast(args[0], torch.bfloat16, func, args, kw) if len(args) == 1 and not kw else NotImplemented
+
+
+def _lz_to(func, args, kw):
+    if len(args) == 2 and not (set(kw) - {"non_blocking", "copy"}) and not kw.get("copy", False):
+        return _lz_cast(args[0], args[1], func, args, kw)
+    if len(args) == 1 and set(kw) <= {"dtype", "non_blocking", "copy"} and "dtype" in kw and not kw.get("copy", False):
+        return _lz_cast(args[0], kw["dtype"], func, args, kw)
+    return NotImplemented
+
+
+def _lz_type_as(func, args, kw):
+    if len(args) != 2 or kw or not isinstance(args[1], torch.Tensor) or type(args[0]) is not LazyScores:
+        return NotImplemented
+    a, other = args
+    if other.device != a.device:
+        return NotImplemented
+    # (recorded as `.to(dtype)`: the other tensor may be a lazy one itself)
+    return _lz_cast(a, other.dtype, torch.Tensor.to, (a, other.dtype), {})
+
+
+def _lz_softmax(func, args, kw):
+    """softmax(x, dim[, _stacklevel][, dtype]) in any of its spellings"""
+    if not args or type(args[0]) is not LazyScores:
+        return NotImplemented
+    a = args[0]
+    dim = args[1] if len(args) > 1 else kw.get("dim")
+    dtype = kw.get("dtype")
+    if a._real is not None or len(args) > 2 or (set(kw) - {"dim", "_stacklevel", "dtype"}) or type(dim) is not int or dim not in (-1, a.dim() - 1):
+        return NotImplemented
+    if dtype is None and a._state == "s16" and torch.is_autocast_enabled():
+        dtype = torch.float32                                           # (autocast runs softmax in fp32 and returns fp32)
+    if a._state == "s16" and dtype is None:
+        r = a._child("p16")
+    elif a._state in ("s16", "s32") and dtype in (None, torch.float32):
+        r = a._child("p32", torch.float32)
+    else:
+        return NotImplemented
+    r._ops.append((func, tuple(_SELF if v is a else v for v in args), dict(kw)))
+    return r
+
+
+def _lz_dropout(func, args, kw):
+    """F.dropout(x, p, training, inplace) / torch.dropout(x, p, train): the identity in eval mode"""
+    if not args or type(args[0]) is not LazyScores:
+        return NotImplemented
+    names = ("p", "training", "inplace") if func is F.dropout else ("p", "train")
+    vals = dict(zip(names, args[1:]))
+    vals.update(kw)
+    training = vals.get("training", vals.get("train", True))
+    if set(vals) - set(names) or (training and vals.get("p", 0.5) != 0):
+        return NotImplemented
+    return args[0]
+
+
+def _lazy_handlers():
+    T = torch.Tensor
+    h = {T.__iadd__: _lz_iadd, T.add_: _lz_iadd, T.__add__: _lz_add, T.__radd__: _lz_add, T.add: _lz_add, torch.add: _lz_add,
+         T.__truediv__: _lz_div, T.div: _lz_div, T.true_divide: _lz_div, torch.div: _lz_div, torch.true_divide: _lz_div,
+         T.__mul__: _lz_mul, T.__rmul__: _lz_mul, T.mul: _lz_mul, torch.mul: _lz_mul,
+         T.float: _lz_float, T.half: _lz_half, T.bfloat16: _lz_bfloat16, T.to: _lz_to, T.type_as: _lz_type_as,
+         F.dropout: _lz_dropout, torch.dropout: _lz_dropout}
+    for f in (T.size, T.dim, T.numel, T.nelement, T.element_size, T.is_floating_point, T.is_complex, T.get_device, T.ndimension,
+              T.is_contiguous, T.stride):
+        _LAZY_META_FUNCS.add(f)
+    return h
+
+
+_LAZY_HANDLERS = _lazy_handlers()
+
+
+def _chain_signature(a, v):
+    q = a._q
+
+    def pat(t):
+        sh = (1,) * (4 - t.dim()) + tuple(t.shape)
+        return tuple(n != 1 for n in sh[:3])
+    return (q.dtype, q.shape[-1], a._mul is not None, tuple(pat(t) for t in a._adds),
+            tuple(f is _SELF or getattr(f, "__name__", "") for f, _a, _k in a._ops))
+
+
+def _lazy_matmul(a, b, matmul):
+    """`matmul(lazy, v)`: the fused kernel when the recorded chain is one it computes (and has reproduced the unfused bits once),
+    else the realized tensor times v."""
+    fusable = a._real is None and type(b) is torch.Tensor and attn_fused_enabled() and not torch.is_grad_enabled() and \
+        (a._state == "p16" or (a._state == "p32" and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == a._dt16))
+    if fusable:
+        k = a._kt.transpose(-1, -2)
+        plan = ops.attn_fused_plan(a._q, k, b, a._adds)
+        if plan is not None:
+            sig = _chain_signature(a, b)
+            ok = _FUSED_OK.get(sig)
+            if ok is None and not torch.cuda.is_current_stream_capturing():
+                fused = ops.attn_fused(a._q, k, b, a._mul, a._adds, plan)
+                ref = matmul(a._realize(), b)
+                ok = _FUSED_OK[sig] = bool(fused.shape == ref.shape and torch.equal(fused.contiguous().view(torch.int16),
+                                                                                  ref.contiguous().view(torch.int16)))
+                stats["attn_fused_checks"] += 1
+                if not ok:
+                    import warnings
+                    warnings.warn(f"vlmc.forward: the fused attention does not reproduce the unfused op sequence for {sig}; "
+                                  "this chain stays unfused", RuntimeWarning)
+                    return ref
+                stats["attn_fused"] += 1
+                return fused
+            if ok:
+                stats["attn_fused"] += 1
+                return ops.attn_fused(a._q, k, b, a._mul, a._adds, plan)
+    return matmul(a._realize(), b)
+
+
 def _make_matmul(orig):
     Tensor = torch.Tensor
+    lazy = attn_fused_enabled() and softmax_enabled()
 
     def matmul(a, b, *args, **kw):
         if _ident() != _mm_owner:
             return orig(a, b, *args, **kw)
+        if type(a) is LazyScores:
+            if args or kw or type(b) is LazyScores:
+                return orig(a._realize(), _real_arg(b), *args, **kw)
+            return _lazy_matmul(a, b, matmul)
+        if type(b) is LazyScores:
+            return orig(a, b._realize(), *args, **kw)
         if not args and not kw and type(a) is Tensor and type(b) is Tensor and a.dim() >= 3 and not torch.is_grad_enabled():
             if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() != a.dtype:
                 return orig(a, b)                                   # (autocast would cast the operands: the library's call)
+            if lazy and a.dim() == 4 and b.dim() == 4 and b.stride(2) == 1 and a.stride(3) == 1 and b.shape[3] > 1 and \
+                    a.dtype is b.dtype and a.shape[:2] == b.shape[:2] and ops.attn_fused_plan(a, b.transpose(2, 3), b.transpose(2, 3)) is not None:
+                # q @ k^T of an attention (k^T: a transposed view, keys K-contiguous): answered lazily
+                return LazyScores(a, b, (*a.shape[:3], b.shape[3]), a.dtype)
             out = ops.attn_matmul(a, b, None, True)                   # (looked up per call: bench.py's probe wraps it); None: not a
             if out is not None:                                       # product the kernel computes
                 stats["attn_kernel"] += 1
@@ -282,18 +587,28 @@ def _make_mean(orig):
 
 
 def _make_softmax(orig, functional):
-    """`F.softmax(x, dim=-1)` / `torch.softmax(x, -1)` / `x.softmax(-1)` of an fp32 CUDA tensor on `vlmc_softmax_rows`: masked-out
-    entries behind a row's real ones leave its bits alone, so a calibration sample can be padded into a group of longer ones
-    (calibration.py: padded groups); every other call -- another dim, a dtype argument, gradients -- goes to the original."""
+    """`F.softmax(x, dim=-1)` / `torch.softmax(x, -1)` / `x.softmax(-1)` of an fp32 or 16-bit CUDA tensor on `vlmc_softmax_rows`:
+    masked-out entries behind a row's real ones leave its bits alone, so a calibration sample can be padded into a group of longer
+    ones (calibration.py: padded groups), and the fused attention forms its softmax in the same order; 16-bit input: fp32
+    arithmetic, rounded once (under autocast: fp32 out, as autocast's softmax returns it); every other call -- another dim,
+    gradients -- goes to the original.  A lazy attention chain records the call."""
     Tensor, f32 = torch.Tensor, torch.float32
 
     def softmax(x, *args, **kw):
-        if _ident() == _mm_owner and type(x) is Tensor and x.dtype is f32 and x.is_cuda and not torch.is_grad_enabled() and x.dim() >= 1:
-            dim = args[0] if args else kw.get("dim")
-            extra = set(kw) - {"dim", "_stacklevel", "dtype"}
-            if type(dim) is int and (dim == -1 or dim == x.dim() - 1) and len(args) <= 1 and not extra and kw.get("dtype") is None and x.shape[-1] > 0:
-                stats["softmax_kernel"] += 1
-                return ops.softmax_rows(x)
+        if _ident() == _mm_owner:
+            if type(x) is LazyScores:
+                r = _lz_softmax(softmax, (x,) + args, kw)
+                return r if r is not NotImplemented else orig(x._realize(), *args, **kw)
+            if type(x) is Tensor and x.is_cuda and not torch.is_grad_enabled() and x.dim() >= 1 and (x.dtype is f32 or x.dtype in ops._16BIT):
+                dim = args[0] if args else kw.get("dim")
+                extra = set(kw) - {"dim", "_stacklevel", "dtype"}
+                dtype = kw.get("dtype")
+                if type(dim) is int and (dim == -1 or dim == x.dim() - 1) and len(args) <= 1 and not extra and x.shape[-1] > 0 and \
+                        (dtype is None or dtype is f32):
+                    if dtype is None and x.dtype is not f32 and torch.is_autocast_enabled():
+                        dtype = f32
+                    stats["softmax_kernel"] += 1
+                    return ops.softmax_rows(x, dtype)
         return orig(x, *args, **kw)
     return softmax
 
@@ -344,6 +659,8 @@ def invariant_matmuls():
     finally:
         _mm_depth -= 1
         if _mm_depth == 0:
+            for z in list(_LAZY_LIVE):                            # a lazy product that escaped its attention: its value, now
+                z._realize()
             _mm_owner = None
             torch.matmul, torch.bmm = _mm_saved.pop("matmul"), _mm_saved.pop("bmm")
             if "mean" in _mm_saved:

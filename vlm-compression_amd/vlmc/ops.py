@@ -354,19 +354,87 @@ def row_mean(x: torch.Tensor, keepdim: bool = False) -> torch.Tensor:
     return out
 
 
-def softmax_rows(x: torch.Tensor) -> torch.Tensor:
-    """`torch.softmax(x, -1)` for fp32 CUDA tensors on the padding-invariant kernel (include/vlmc.h: vlmc_softmax_rows)."""
+def softmax_rows(x: torch.Tensor, out_dtype=None) -> torch.Tensor:
+    """`torch.softmax(x, -1[, dtype=out_dtype])` on the padding-invariant kernel (include/vlmc.h: vlmc_softmax_rows): fp32 -> fp32,
+    fp16 / bf16 -> the same dtype (fp32 arithmetic, one rounding) or fp32."""
     _need_gpu(x)
-    if x.dtype != torch.float32 or x.dim() < 1 or x.shape[-1] == 0:
-        raise TypeError("vlmc.softmax_rows: a non-empty fp32 tensor expected")
+    out_dtype = x.dtype if out_dtype is None else out_dtype
+    if x.dim() < 1 or x.shape[-1] == 0 or not ((x.dtype == torch.float32 and out_dtype == torch.float32) or
+                                               (x.dtype in _16BIT and out_dtype in (x.dtype, torch.float32))):
+        raise TypeError("vlmc.softmax_rows: a non-empty fp32 tensor, or fp16 / bf16 with the same or fp32 output dtype, expected")
     n = x.shape[-1]
     x2 = x.reshape(-1, n)
     if x2.stride(1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < n):
         x2 = x2.contiguous()
     rows = x2.shape[0]
-    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().vlmc_softmax_rows(x2.data_ptr(), rows, n, x2.stride(0) if rows > 1 else n, out.data_ptr(), n, _stream()))
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _lib.check(_lib.load().vlmc_softmax_rows(x2.data_ptr(), _DT[x.dtype], rows, n, x2.stride(0) if rows > 1 else n, out.data_ptr(),
+                                             _DT[out_dtype], n, _stream()))
     return out
+
+
+_attn_max_keys = {}
+_I64x3 = ctypes.c_int64 * 3
+_I64x4 = ctypes.c_int64 * 4
+
+
+def attn_fused_plan(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, adds=(), _cuda_only: bool = True):
+    """(B, H, Tq, Tk, d) if `vlmc_attn_fwd` computes the reference-op attention chain for these operands, else None: q [B, H, Tq, d],
+    k, v [B, H, Tk, d] CUDA tensors of one 16-bit dtype with unit stride along d (k is the operand BEFORE its transpose), d a multiple
+    of 8 up to 128, Tk within what a head's K and V may take of LDS; at most two addends of the same dtype, broadcastable to
+    [B, H, Tq, Tk] (any strides: T5's position bias is a permuted table lookup)."""
+    if q.dim() != 4 or k.dim() != 4 or v.dim() != 4 or q.dtype not in _16BIT or k.dtype != q.dtype or v.dtype != q.dtype or \
+            (_cuda_only and not (q.is_cuda and k.is_cuda and v.is_cuda)):
+        return None
+    B, H, Tq, d = q.shape
+    Tk = k.shape[2]
+    if k.shape != (B, H, Tk, d) or v.shape != (B, H, Tk, d) or d % 8 or d > 128 or min(B, H, Tq, Tk, d) <= 0:
+        return None
+    for t in (q, k, v):
+        st = t.stride()
+        if (st[3] != 1 and d != 1) or min(st[0], st[1], st[2]) < 0:
+            return None
+    mk = _attn_max_keys.get(d)
+    if mk is None:
+        mk = _attn_max_keys[d] = int(_lib.load().vlmc_attn_max_keys(d))
+    if Tk > mk or len(adds) > 2:
+        return None
+    for t in adds:
+        if t.dtype != q.dtype or t.device != q.device or t.dim() > 4 or t.dim() == 0 or t.requires_grad:
+            return None
+        sh = (1,) * (4 - t.dim()) + tuple(t.shape)
+        if sh[3] != Tk or sh[0] not in (1, B) or sh[1] not in (1, H) or sh[2] not in (1, Tq) or (t.stride(-1) < 1 and Tk != 1) or min(t.stride()) < 0:
+            return None
+    return B, H, Tq, Tk, d
+
+
+def _add_strides(t, B, H, Tq):
+    sh = (1,) * (4 - t.dim()) + tuple(t.shape)
+    st = (0,) * (4 - t.dim()) + tuple(t.stride())
+    return _I64x4(*(0 if n == 1 else s for n, s in zip(sh[:3], st[:3])), max(1, st[3]))
+
+
+def attn_fused(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mul=None, adds=(), _plan=None) -> torch.Tensor:
+    """The reference-op attention chain in one launch (include/vlmc.h: vlmc_attn_fwd):
+        s = q @ k^T;  [s = s * mul];  [s = s + adds[0] [+ adds[1]]];  p = softmax in fp32, rounded;  out = p @ v
+    every intermediate rounded to the dtype where the tensor op would round it -- the bits of the unfused sequence on
+    `attn_matmul`, torch's elementwise ops and `softmax_rows`.  Returns [B, H, Tq, d] as a VIEW of a contiguous [B, Tq, H, d]
+    tensor (the model's `.transpose(1, 2).reshape(B, Tq, H * d)` is free).  `mul`: a Python float already rounded to fp32."""
+    _need_gpu(q, k, v)
+    plan = _plan if _plan is not None else attn_fused_plan(q, k, v, adds)
+    if plan is None:
+        raise TypeError("vlmc.attn_fused: q [B, H, Tq, d], k, v [B, H, Tk, d] of one 16-bit dtype with unit stride along d, at most "
+                        "vlmc_attn_max_keys(d) keys, at most two broadcastable 16-bit addends expected")
+    B, H, Tq, Tk, d = plan
+    out = torch.empty((B, Tq, H, d), dtype=q.dtype, device=q.device)
+    a0 = adds[0] if len(adds) > 0 else None
+    a1 = adds[1] if len(adds) > 1 else None
+    _lib.check(_lib.load().vlmc_attn_fwd(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _DT[q.dtype], B, H, Tq, Tk, d, _I64x3(*q.stride()[:3]),
+        _I64x3(*k.stride()[:3]), _I64x3(*v.stride()[:3]), 0 if mul is None else 1, 0.0 if mul is None else float(mul),
+        None if a0 is None else a0.data_ptr(), None if a0 is None else _add_strides(a0, B, H, Tq),
+        None if a1 is None else a1.data_ptr(), None if a1 is None else _add_strides(a1, B, H, Tq), _stream()))
+    return out.permute(0, 2, 1, 3)
 
 
 def hessian_accum(H: torch.Tensor, x: torch.Tensor, alpha: float, beta: float) -> torch.Tensor:
