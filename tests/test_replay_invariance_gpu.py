@@ -184,20 +184,28 @@ def test_ragged_samples_padded_into_one_group_keep_their_bits(lora_model, monkey
                                          enc_depth=3, dec_depth=3, vocab=100, query_tokens=4, reference_ops=True, qformer_dim=64, qformer_heads=4,
                                          qformer_hidden=128, qformer_depth=2, qformer_vocab=50).to(dev).eval()
         batches = synthetic.calibration_batches(16, dev, vit_tokens=9, vit_dim=64, vocab=100, ragged=True)
-        before = (calibration.graph_stats.get("padded_forwards", 0), forward.stats["softmax_kernel"] + forward.stats["attn_fused"])
+        before = (calibration.graph_stats.get("padded_forwards", 0), forward.stats["softmax_kernel"] + forward.stats["attn_fused"],
+                  calibration.graph_stats.get("tower_padded_passes", 0))
         synthetic.time_prune(dev, n_samples=16, model=model, batches=batches, **({"t5_prune_spec": "3-0.5-1.0-1.0"}))
         out = {n: (m.weight.detach().clone(), m.mask.clone() if hasattr(m, "mask") else None) for n, m in model.named_modules()
                if isinstance(m, torch.nn.Linear) and (".block." in n or ".blocks." in n)}
+        seen["tower_padded"] = calibration.graph_stats.get("tower_padded_passes", 0) - before[2]
         return out, calibration.graph_stats.get("padded_forwards", 0) - before[0], \
             forward.stats["softmax_kernel"] + forward.stats["attn_fused"] - before[1]       # (the softmax kernel, alone or inside the fused attention)
 
-    base = {"VLMC_BATCH_REPLAY": "128", "VLMC_TOWER_BATCH": "1", "VLMC_PAD_RAGGED": "1"}
+    base = {"VLMC_BATCH_REPLAY": "128", "VLMC_TOWER_BATCH": "1", "VLMC_PAD_RAGGED": "1", "VLMC_TOWER_PAD": "1"}
+    seen = {}
     padded, n_padded, n_softmax = run(base)
+    # .. and the finished encoder tower ran ONE padded stacked pass for the samples behind the scout's group while the decoder's
+    # inputs were captured (TowerGraph._run_padded)
+    assert seen["tower_padded"] >= 1, seen
+    towers_per_length, n_tp, _ = run({**base, "VLMC_TOWER_PAD": "0"})
+    assert seen["tower_padded"] == 0 and n_tp == n_padded
     shaped, n_shaped, _ = run({**base, "VLMC_PAD_RAGGED": "0"})
     single, _, _ = run({**base, "VLMC_BATCH_REPLAY": "1", "VLMC_TOWER_BATCH": "0"})
     assert n_padded == 2 * 2 * 3 and n_shaped == 0 and n_softmax > 0          # encoder + decoder tower, two passes, three blocks: ONE forward each
     assert padded.keys() == shaped.keys() == single.keys() and len(padded) == 2 * 4 + 3 * 7 + 3 * 11
     for k in padded:
-        for other, name in ((shaped, "groups of equal shapes"), (single, "per-sample loop")):
+        for other, name in ((shaped, "groups of equal shapes"), (single, "per-sample loop"), (towers_per_length, "towers per token count")):
             assert torch.equal(padded[k][0], other[k][0]), (k, name)
             assert (padded[k][1] is None and other[k][1] is None) or torch.equal(padded[k][1], other[k][1]), (k, name)

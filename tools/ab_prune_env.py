@@ -13,8 +13,9 @@ from vlmc import synthetic  # noqa: E402
 configs = [dict(kv.split("=") for kv in c.split(",") if kv) for c in sys.argv[1:]] or [{}]
 world = os.environ.get("AB_SIMULATE_WORLD")
 dev = torch.device("cuda:0")
-model = synthetic.InstructBlipT5().to(dev).eval()
-batches = synthetic.calibration_batches(128, dev, vocab=model.t5_model.shared.num_embeddings)
+refops = os.environ.get("AB_REFERENCE_OPS") == "1"            # the reference's attention op sequence + ragged calibration text
+model = synthetic.InstructBlipT5(reference_ops=refops).to(dev).eval()
+batches = synthetic.calibration_batches(128, dev, vocab=model.t5_model.shared.num_embeddings, ragged=refops)
 keys = sorted({k for c in configs for k in c})
 times = [[] for _ in configs]
 for rnd in range(int(os.environ.get("AB_ROUNDS", "6")) + 1):

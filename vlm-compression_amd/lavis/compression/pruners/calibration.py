@@ -409,6 +409,12 @@ def tower_predict_enabled():
     return os.environ.get("VLMC_TOWER_PREDICT", "1") != "0"
 
 
+def tower_pad_enabled():
+    """Ragged samples of one argument structure run a finished tower as ONE padded stacked pass (TowerGraph._run_padded;
+    `VLMC_TOWER_PAD=0`: one pass per token count, as before)."""
+    return os.environ.get("VLMC_TOWER_PAD", "1") != "0" and pad_ragged_enabled()
+
+
 def tower_graph_enabled():
     """One HIP graph per finished TOWER and calibration forward (`VLMC_TOWER_GRAPH=0`: one per block)."""
     return os.environ.get("VLMC_TOWER_GRAPH", "1") != "0"
@@ -450,6 +456,7 @@ class TowerGraph:
         self.mods, self.n = list(modules), len(modules)
         self.plans, self.traces, self.wirings = {}, {}, {}
         self.by_struct = {}                   # argument signature without the tensor extents -> a key whose wiring is known
+        self.shapes = {}                      # key -> (token count of the traced sample, per block the shapes of its outputs): what a padded pass is trimmed by
         self.deferred, self.ready = [], {}    # forwards postponed at block 0; their per-block outputs once the tower ran
         # block-0 calls of this tower as its OWN capture phase saw them, by sample (capture_block_inputs): what the model
         # will hand block 0 again in the next phase, if nothing upstream changed -- run_predicted()
@@ -533,7 +540,8 @@ class TowerGraph:
                     if isinstance(v, torch.Tensor) and id(v) not in known:
                         known[id(v)] = (v, ("ext", len(ext)))
                         ext.append(v)
-                self.trace = {"key": key, "known": known, "calls": [], "next": 0}
+                self.trace = {"key": key, "known": known, "calls": [], "next": 0, "shapes": [],
+                              "len": args[0].shape[1] if args and isinstance(args[0], torch.Tensor) and args[0].dim() >= 2 else None}
                 self.btrace = self._begin_batched_trace(key, args, kwargs, ext)
                 if self.btrace is not None:
                     return self._batched_step(0, args, kwargs)
@@ -652,6 +660,7 @@ class TowerGraph:
                 bt["ver"][id(o)] = o._version
         tr["calls"].append((tuple(wires), tuple(sorted(kwires.items())), isinstance(out, tuple), isinstance(out, list),
                             tuple(o is None for o in flat)))
+        tr["shapes"].append(tuple(tuple(o.shape) if isinstance(o, torch.Tensor) else None for o in mine))
         tr["next"] = index + 1
         bt["outs"].append(out)
         bt.setdefault("parts", []).append(parts)
@@ -693,6 +702,7 @@ class TowerGraph:
                 tr["known"][id(o)] = (o, ("out", index, pos))
         tr["calls"].append((tuple(wires), tuple(sorted(kwires.items())), isinstance(out, tuple), isinstance(out, list),
                             tuple(o is None for o in flat)))
+        tr["shapes"].append(tuple(tuple(o.shape) if isinstance(o, torch.Tensor) else None for o in flat))
         if index == self.n - 1:
             self._finish_trace(tr)
             self.trace = None
@@ -710,6 +720,7 @@ class TowerGraph:
         seen.append(calls)
         if len(seen) >= self.NEED:
             self.wirings[key] = calls
+            self.shapes[key] = (tr.get("len"), tuple(tr.get("shapes", ())))
             self.by_struct.setdefault(self._struct(key), key)
 
     def _build(self, calls, args, kwargs):
@@ -836,6 +847,7 @@ class TowerGraph:
         if not self.predicted or self.memo_serves or self.off or not (tower_batch_enabled() and tower_predict_enabled()):
             return set()
         out, count = set(), {}
+        shared = os.environ.get("VLMC_TOWER_SHARE_WIRING", "1") != "0" and tower_pad_enabled()
         for j in samples:
             rec = self.predicted.get(j)
             if rec is None:
@@ -843,10 +855,13 @@ class TowerGraph:
             key = self._key0(rec[0], rec[1], rec[2])
             if key is None or self._wiring(key) is not None:
                 continue
-            have = count.get(key, len(self.traces.get(key, [])))
+            # signatures that differ in extents only share a wiring, and their samples can share a PADDED stacked pass
+            # (run_deferred): one scout for all of them
+            ckey = self._struct(key) if shared else key
+            have = count.get(ckey, len(self.traces.get(key, [])))
             if have < self.NEED:
                 out.add(j)
-                count[key] = have + 1
+                count[ckey] = have + 1
         return out
 
     def run_predicted(self, samples):
@@ -885,6 +900,109 @@ class TowerGraph:
         return len(recs)
 
     @torch.no_grad()
+    def _run_padded(self, groups, fw):
+        """Ragged samples of ONE argument structure (signatures that differ in their token count only) through the tower as ONE
+        padded stacked pass instead of one pass per length: hidden rows behind a sample's own are zero, its mask columns the
+        dtype's minimum (`plan_padded`: what the model's own extended mask holds for padding), and every block output is cut back
+        to the sample's length before it is handed out -- along exactly the dimensions in which the padded pass's shapes differ
+        from the shapes the TRACED sample produced (its length is never the padded length: the pad is one longer if need be, so a
+        dimension that depends on the token count always differs and a constant one never does).  The live rows carry the bits of
+        the sample's own pass (linears, norms: row-wise, batch-invariant; attention: vlmc_attn_fwd / vlmc_attn_matmul +
+        vlmc_softmax_rows, padding-invariant) -- the argument of walk_blocks' padded groups, tested there and in
+        tests/test_replay_invariance_gpu.py.  Returns the groups that are left for the per-signature passes."""
+        by_struct = {}
+        for key in groups:
+            by_struct.setdefault(self._struct(key), []).append(key)
+        left = dict(groups)
+        for st, keys in by_struct.items():
+            base = self.by_struct.get(st)
+            calls = self.wirings.get(base) if base is not None else None
+            t_s, shapes = self.shapes.get(base, (None, None))
+            if len(keys) < 2 or not calls or t_s is None or len(shapes) != len(calls):
+                continue
+            recs = sorted((r for k in keys for r in groups[k]), key=lambda r: r["j"])
+            ctx = recs[0]["ctx"]
+            if any(len(r["args"]) != 1 or r["ctx"] != ctx for r in recs):
+                continue
+            plan = plan_padded([r["args"][0] for r in recs], [r["kwargs"] for r in recs], len(recs), replay_group_size())
+            n_ext = len(self._ext(recs[0]["args"], recs[0]["kwargs"]))
+            if plan is None or any(spec["sp"] is not None for _c, spec in plan):
+                continue                                                 # (a second ragged length -- cross-attention states -- is not handled here)
+            done, ok = {}, True
+            for chunk, spec in plan:
+                crecs = [recs[i] for i in chunk]
+                tp = spec["tp"] + 1 if spec["tp"] == t_s else spec["tp"]
+                x = _pad_inputs([r["args"][0] for r in crecs], tp)
+                kw = _pad_caches([r["kwargs"] for r in crecs], dict(spec, tp=tp))
+                ext = self._ext((x,), kw)
+                if len(ext) != n_ext:
+                    ok = False
+                    break
+                outs = []
+
+                def resolve(w):
+                    if w[0] == "ext":
+                        return ext[w[1]]
+                    if w[0] == "out":
+                        return self._flat(outs[w[1]])[w[2]]
+                    return w[1]
+                with torch.autocast(device_type="cuda", dtype=ctx[1], enabled=ctx[0]) if ctx[0] else contextlib.nullcontext(), \
+                        fw.invariant_linears(self.linears, roots=self.mods):
+                    for i, (wires, kwires, _t, _l, _n) in enumerate(calls):
+                        outs.append(self.mods[i](*[resolve(w) for w in wires], **{k: resolve(w) for k, w in kwires}))
+                g, lens = len(crecs), spec["T"]
+                # per block output: which dimensions carry the token count, and the per-sample pieces
+                cut = []
+                for out, sh in zip(outs, shapes):
+                    flat = self._flat(out)
+                    if len(flat) != len(sh):
+                        ok = False
+                        break
+                    row = []
+                    for o, s0 in zip(flat, sh):
+                        if o is None or s0 is None:
+                            if (o is None) != (s0 is None):
+                                ok = False
+                            row.append(None)
+                            continue
+                        if o.dim() != len(s0) or o.dim() < 1 or o.shape[0] not in (g * s0[0], s0[0]):
+                            ok = False
+                            break
+                        dims = [d for d in range(1, o.dim()) if o.shape[d] != s0[d]]
+                        if any(s0[d] != t_s or o.shape[d] != tp for d in dims):
+                            ok = False
+                            break
+                        row.append((o.split(s0[0], dim=0) if o.shape[0] == g * s0[0] and g > 1 else None, dims))
+                    if not ok:
+                        break
+                    cut.append(row)
+                if not ok:
+                    break
+                for t, rec in enumerate(crecs):
+                    n_t, mine = lens[t], []
+                    for out, row in zip(outs, cut):
+                        flat = []
+                        for o, c_ in zip(self._flat(out), row):
+                            if c_ is None:
+                                flat.append(o)
+                                continue
+                            v = c_[0][t] if c_[0] is not None else o
+                            for d in c_[1]:
+                                v = v.narrow(d, 0, n_t)
+                            flat.append(v)
+                        mine.append(tuple(flat) if isinstance(out, tuple) else flat if isinstance(out, list) else flat[0])
+                    done[rec["j"]] = {"outs": mine, "args": rec["args"], "kwargs": rec["kwargs"], "key": rec["key"]}
+                graph_stats["tower_batches"] = graph_stats.get("tower_batches", 0) + 1
+                graph_stats["tower_padded_passes"] = graph_stats.get("tower_padded_passes", 0) + 1
+            if not ok:
+                continue                                                 # (nothing of this structure was handed out: the per-signature passes run)
+            for k in keys:
+                self.wirings.setdefault(k, calls)
+                left.pop(k)
+            self.ready.update(done)
+        return left
+
+    @torch.no_grad()
     def run_deferred(self):
         """The tower for every postponed forward, stacked per group of equal signature; returns their indices."""
         from vlmc import forward as fw
@@ -892,6 +1010,8 @@ class TowerGraph:
         groups = {}
         for rec in todo:
             groups.setdefault(rec["key"], []).append(rec)
+        if len(groups) > 1 and tower_pad_enabled():
+            groups = self._run_padded(groups, fw)
         for key, recs in groups.items():
             calls = self.wirings[key]
             x0 = recs[0]["args"][0]
