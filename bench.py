@@ -419,6 +419,15 @@ def reference_ops_leg(dev, steps):
             lead *= max(x, y)
         return 2.0 * lead * (a.shape[-2] * a.shape[-1] + b.shape[-2] * b.shape[-1] + a.shape[-2] * b.shape[-1])
     probe.wrap(ops, "attn_matmul", "attn", attn_bytes, lambda a, b, *r, **k: a.is_cuda and a.dim() >= 3 and a.dtype in (torch.float16, torch.bfloat16))
+
+    def fused_flops(q, k, v, *rest, **kw):                    # both products of the chain: 4 B H Tq Tk d
+        return 4.0 * q.shape[0] * q.shape[1] * q.shape[2] * k.shape[2] * q.shape[3]
+    score_bytes = []
+
+    def fused_units(q, k, v, *rest, **kw):
+        score_bytes.append(2.0 * q.shape[0] * q.shape[1] * q.shape[2] * k.shape[2])
+        return fused_flops(q, k, v)
+    probe.wrap(ops, "attn_fused", "attnf", fused_units)       # round 5: the whole chain of a replayed block's attention in one launch
     try:
         job.step()                                            # warm-up (code objects of the batched matmuls, allocator)
         torch.cuda.synchronize()
@@ -443,6 +452,18 @@ def reference_ops_leg(dev, steps):
                        "bound": "hbm", "timed_launches": a_n, "launches_per_step": round(probe.calls.get("attn", 0) / steps, 1),
                        "avg_launch_us": round(a_ms * 1e3 / a_n, 2), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_launch": round(a_bytes / a_n)}
+    f_ms, f_flops, f_n = probe.summary("attnf")
+    if f_n:
+        tfs = f_flops / (f_ms * 1e-3) / 1e12
+        fused = {"kernel": "vlmc::attn_fused_kernel (vlmc_attn_fwd: scores, scaling, position bias / mask addends, fp32 softmax and probs @ v of a "
+                           "replayed block's attention in one launch, every intermediate rounded like the tensor op it replaces; algorithmic "
+                           "flops = 4 B H Tq Tk d; what paces it is the softmax's VALU work and LDS fragment reads, not the matrix cores)",
+                 "bound": "mfma", "timed_launches": f_n, "launches_per_step": round(probe.calls.get("attnf", 0) / steps, 1),
+                 "avg_launch_us": round(f_ms * 1e3 / f_n, 2), "achieved": round(tfs, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(tfs / MFMA_PEAK_TFLOPS, 4), "flops_per_launch": round(f_flops / f_n),
+                 "score_bytes_not_written_per_launch": round(sum(score_bytes) / max(1, len(score_bytes))),
+                 "unfused_products": attn_kernel}
+        attn_kernel = fused
     grouped = job.masks()
     frac = job.pruned_fraction()
     keep = {k: os.environ.get(k) for k in ("VLMC_BATCH_REPLAY", "VLMC_TOWER_BATCH")}
