@@ -194,7 +194,8 @@ int vlmc_lora_grad(const void *G, int dtype, int64_t out_features, int64_t in_fe
  * vlmc_sparse_lora_bwd_input:  dX [M,in]  = wd(dY [M,out] W_eff)
  * vlmc_sparse_lora_bwd_weight: G = wd(dY^T X); Gm = wd((sparse ? G . M : G) * s); dB [out,r] = wd(Gm A16^T),
  *   dA [r,in] = wd(B16^T Gm), fp32 (dA or dB may be NULL); workspace of vlmc_sparse_lora_bwd_weight_workspace() bytes,
- *   256-byte aligned (transposed operands + per-tile partial sums, combined in a fixed order: deterministic).        */
+ *   256-byte aligned (per-tile partial sums of dA and dB, combined in tile order: deterministic; dY and X are read as
+ *   they lie -- the transposed operand comes out of ds_read_b64_tr_b16, nothing is transposed in memory).                 */
 size_t vlmc_sparse_lora_prep_bytes(int64_t out_features, int64_t in_features);
 int vlmc_sparse_lora_prep(const float *A, const float *B, int64_t out_features, int64_t in_features, int r, int autocast,
                           void *prep, void *stream);
