@@ -3,6 +3,12 @@
 Every function takes CUDA(HIP) tensors, passes raw device pointers + the current
 torch stream, and never synchronises.  Mirrors, op for op, what the reference's
 pruner loop does with PyTorch ops (file:line under /root/reference cited per op).
+
+There is ONE backend: these kernels.  The `VLMC_*` switches that send an op back to a torch / library call
+(`VLMC_LINEAR_FWD=0`, `VLMC_SDPA=0`, `VLMC_ATTN_MATMUL=0`, `VLMC_SGPT_PERSISTENT=0`, ... -- `vlmc/crosscheck.py` lists them by
+name) exist so that the tests can hold every kernel against the route it replaced, on the GPU, inside whole prunes; they are
+test and measurement aids, not a supported second path: nothing in the product selects them, a missing library raises
+(`_lib.load`), CPU tensors raise (`_need_gpu`).
 """
 from __future__ import annotations
 
