@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLMC_ABI_VERSION 14
+#define VLMC_ABI_VERSION 15
 
 #define VLMC_OK 0
 #define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
@@ -210,6 +210,19 @@ int vlmc_sparse_lora_bwd_weight(const void *dY, int64_t lddy, const void *X, int
                                 int64_t out_features, int64_t in_features, const uint8_t *mask, const void *prep, int r,
                                 float scaling, int sparse, int autocast, float *dA, float *dB, void *workspace,
                                 size_t workspace_bytes, void *stream);
+
+/* ---- packed 2:4 weights (the optional inference format) -----------------------------------------------------
+ * A linear pruned 2:4 by the n:m rule (wanda_pruner.py:326-329; the masks `prune()` leaves on the modules) as
+ *     values [out, in / 2]  16-bit, the two kept weights of every group of four input columns, in column order
+ *     meta   [out, in / 8]  one byte per two groups: per group the 4-bit code i0 | i1 << 2, i0 < i1 the kept positions
+ * (two 2-bit selectors per group, the index form of the structured-sparse MFMA instructions): 9 / 16 of the dense bytes.  The
+ * positions are the MASK's (1 = keep), not "the non-zero values": vlmc_unpack_24(vlmc_pack_24(W, mask)) == W . mask bit for
+ * bit, and the mask is recovered.  *bad_groups (device, zeroed by the caller) counts the groups that do not keep exactly two
+ * (pack) or whose code is not i0 < i1 (unpack); their output is unspecified.  in_features: a multiple of 8.            */
+int vlmc_pack_24(const void *W, int dtype, int64_t out_features, int64_t in_features, int64_t ldw, const uint8_t *mask, int64_t ldm,
+                 void *values, uint8_t *meta, unsigned int *bad_groups, void *stream);
+int vlmc_unpack_24(const void *values, const uint8_t *meta, int dtype, int64_t out_features, int64_t in_features, void *W, int64_t ldw,
+                   uint8_t *mask /* NULL or [out, in] */, int64_t ldm, unsigned int *bad_groups, void *stream);
 
 /* ---- dense calibration forward of one linear (MFMA) ---------------------------------------------
  * Replaces `F.linear(x, weight, bias)` inside the block forwards of the calibration replay,

@@ -15,6 +15,8 @@ import math
 
 import torch
 
+from . import topk_order
+
 
 def hessian_update(H: torch.Tensor, nsamples: int, x: torch.Tensor):
     """One `SparseGPT.add_batch` call; x is [b, T, in] or [T, in].  Returns new nsamples (H in place)."""
@@ -83,7 +85,14 @@ def sweep_block(W1, U1, mask1, prune_n, prune_m):
         d = U1[i, i]
         if prune_n != 0 and i % prune_m == 0:
             tmp = W1[:, i:i + prune_m] ** 2 / d_all[i:i + prune_m].reshape(1, -1) ** 2
-            idx = torch.sort(tmp, dim=1, stable=True)[1][:, :prune_n]
+            srt, order = torch.sort(tmp, dim=1, stable=True)
+            idx = order[:, :prune_n]
+            # :191 is `torch.topk(tmp, prune_n, dim=1, largest=False)`: WHICH of several equal scores it returns on the CPU is
+            # libstdc++'s nth_element order (oracle/topk_order.py); only rows whose n-th and (n+1)-th smallest are equal can differ
+            # from the stable order (exact zeros of an already pruned weight)
+            if 0 < prune_n < tmp.shape[1]:
+                for r in torch.nonzero(srt[:, prune_n - 1] == srt[:, prune_n]).flatten().tolist():
+                    idx[r] = torch.tensor(topk_order.smallest(tmp[r].tolist(), prune_n), dtype=idx.dtype)
             mask1.scatter_(1, i + idx, True)
         q = w.clone()
         q[mask1[:, i]] = 0

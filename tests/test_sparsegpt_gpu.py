@@ -46,6 +46,36 @@ def test_sweep_kernel_bit_exact_vs_oracle(count, rows, nm):
     assert torch.equal(mout[:, 3:3 + count].cpu(), mask_ref)
 
 
+@pytest.mark.parametrize("nm", [(2, 4), (4, 8), (1, 4), (3, 4)])
+def test_sweep_kernel_decides_tied_groups_like_torch_topk_on_the_cpu(nm):
+    """sparsegpt_pruner.py:190-192 picks the n columns of a group with `torch.topk(tmp, prune_n, dim=1, largest=False)`; equal scores
+    (exact zeros of an already sparse weight, before the first compensation touches them: the first group of a block) are decided
+    by the CPU kernel's nth_element order, restated in oracle/topk_order.py and csrc/topk_order.hpp.  60 % zeros: about half of the
+    rows tie in their first group."""
+    from vlmc import sparsegpt as SG
+    n, m = nm
+    rows, count = 2000, 128
+    g = torch.Generator().manual_seed(7 + n + m)
+    W1 = torch.randn(rows, count, generator=g) * 0.05
+    W1[torch.rand(rows, count, generator=g) < 0.6] = 0
+    A = torch.randn(count, count * 2, generator=g)
+    U = torch.linalg.cholesky(A @ A.t() / count + 0.1 * torch.eye(count), upper=True)
+    tmp = W1[:, :m] ** 2 / torch.diag(U)[:m].reshape(1, -1) ** 2
+    srt = torch.sort(tmp, dim=1)[0]
+    tied = srt[:, n - 1] == srt[:, n]
+    assert int(tied.sum()) > 200
+    want = torch.zeros(rows, m, dtype=torch.bool).scatter_(1, torch.topk(tmp, n, dim=1, largest=False)[1], True)    # the reference's op
+    Q, Err, mask_ref = OS.sweep_block(W1.clone(), U, torch.zeros_like(W1) == 1, n, m)
+    assert torch.equal(mask_ref[:, :m], want), "the oracle's tie order is not this container's torch.topk"
+    stable = torch.zeros(rows, m, dtype=torch.bool).scatter_(1, torch.sort(tmp, dim=1, stable=True)[1][:, :n], True)
+    assert (stable != want).any(dim=1).sum() > 50                          # (the old rule decided these rows differently)
+    Wd = W1.to(DEV).contiguous()
+    err = torch.empty(rows, count, device=DEV)
+    mout = torch.zeros(rows, count, dtype=torch.bool, device=DEV)
+    SG.sweep_block(Wd, 0, count, U.contiguous().to(DEV), None, n, m, err, mout)
+    assert torch.equal(mout.cpu(), mask_ref) and torch.equal(Wd.cpu(), Q) and torch.equal(err.cpu(), Err)
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_fasterprune_matches_reference_golden(name):
     from vlmc import sparsegpt as SG

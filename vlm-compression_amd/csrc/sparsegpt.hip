@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "topk_order.hpp"
 
 namespace vlmc {
 
@@ -70,6 +71,7 @@ __device__ __forceinline__ void nm_decide(int i, int count, int lane, int prune_
                 t[a] = 0xFFFFFFFFu;
             }
         }
+        uint32_t pruned = 0, at_n = 0, at_n1 = 1;
 #pragma unroll
         for (int a = 0; a < kMax; ++a) {
             if (a < prune_m && i + a < count) {
@@ -77,10 +79,24 @@ __device__ __forceinline__ void nm_decide(int i, int count, int lane, int prune_
 #pragma unroll
                 for (int b = 0; b < kMax; ++b)
                     if (b < prune_m) rank += (t[b] < t[a] || (t[b] == t[a] && b < a)) ? 1 : 0;
-                const int col = i + a;
-                if (rank < prune_n && lane == (col & 63)) {
-                    if (col >= 64) m1[r] = 1; else m0[r] = 1;
-                }
+                pruned |= (rank < prune_n ? 1u : 0u) << a;
+                at_n = rank == prune_n - 1 ? t[a] : at_n;
+                at_n1 = rank == prune_n ? t[a] : at_n1;
+            }
+        }
+        // a tie across the selection boundary (:191 `torch.topk`): the columns it returns on the CPU (topk_order.hpp).  Whole groups
+        // of a compile-time m only; a run-time m keeps the stable order (documented in DESIGN.md §2).
+        if (M > 2 && prune_n > 0 && prune_n < M && i + M <= count && at_n == at_n1) {
+            uint32_t gk[kMax];
+#pragma unroll
+            for (int a = 0; a < kMax; ++a) gk[a] = t[a];
+            pruned = torch_cpu_smallest<kMax>(gk, prune_n);
+        }
+#pragma unroll
+        for (int a = 0; a < kMax; ++a) {
+            const int col = i + a;
+            if (a < prune_m && col < count && ((pruned >> a) & 1u) && lane == (col & 63)) {
+                if (col >= 64) m1[r] = 1; else m0[r] = 1;
             }
         }
     }
@@ -103,13 +119,22 @@ __device__ __forceinline__ void nm_decide_lanes(int i, int count, int lane, int 
     for (int r = 0; r < kSgRows; ++r) {
         const float wv = hi ? w1[r] : w0[r];
         const uint32_t key = incount ? score_key(ieee_div(ieee_mul(wv, wv), hi ? dsq1 : dsq0)) : 0xFFFFFFFFu;
-        int rank = 0;
+        int rank = 0, less = 0, equal = 0;
+        uint32_t gk[M];
 #pragma unroll
         for (int b = 0; b < M; ++b) {
-            const uint32_t tb = uint32_t(__builtin_amdgcn_readlane(int(key), l0 + b));
+            const uint32_t tb = gk[b] = uint32_t(__builtin_amdgcn_readlane(int(key), l0 + b));
             rank += (tb < key || (tb == key && l0 + b < lane)) ? 1 : 0;
+            less += tb < key ? 1 : 0;
+            equal += tb == key ? 1 : 0;
         }
-        if (mine && incount && rank < prune_n) {
+        bool pruned = rank < prune_n;
+        // a run of equal scores that straddles the selection boundary (:191 `torch.topk`): the columns it returns on the CPU
+        // (topk_order.hpp); whole groups only.  (wave-uniform: the group's lanes vote)
+        const bool straddles = mine && less < prune_n && less + equal > prune_n;
+        if (M > 2 && prune_n > 0 && prune_n < M && (hi ? 64 : 0) + l0 + M <= count && __ballot(straddles) != 0)
+            pruned = (torch_cpu_smallest<M>(gk, prune_n) >> ((lane - l0) & (M - 1))) & 1u;
+        if (mine && incount && pruned) {
             if (hi) m1[r] = 1; else m0[r] = 1;
         }
     }

@@ -8,7 +8,12 @@ Writing (train.py:677-714, after `pruner.prune()` / the RESSA loop):
 Reading (evaluate_new.py:226-276, evaluate_old.py:246-290): one tower at a time, dropping LoRA and mask entries and
 the PEFT wrapper prefixes, then `load_state_dict` into the tower.
 
-Host-side file formats only: the tensors are whatever the pruners left on the GPU; nothing here touches the kernels.
+Host-side file formats only: the tensors are whatever the pruners left on the GPU; nothing above touches the kernels.
+
+Packed 2:4 (SURVEY.md §8(f)3 "an optional packed 2:4 format for inference"; the reference has none): `pack_state_dict_24` /
+`unpack_state_dict_24` turn the `weight` + `mask` pair of every linear that a 2:4 prune left behind into
+`weight_packed24` [out, in / 2] + `weight_meta24` [out, in / 8] (include/vlmc.h: vlmc_pack_24) and back, bit for bit --
+9 / 16 of the bytes of the 16-bit weight, 3 / 8 of weight + mask.
 """
 from __future__ import annotations
 
@@ -102,3 +107,47 @@ def remaining_proportion(model, orig_total_size) -> float:
     """evaluate_new.py:279-283: non-zero parameters over the original parameter count, in percent."""
     kept = sum((p != 0).float().sum() for p in model.parameters())
     return float(kept / orig_total_size * 100)
+
+
+PACKED_VALUES, PACKED_META = "weight_packed24", "weight_meta24"
+
+
+def pack_state_dict_24(state: dict, keep_masks: bool = False) -> dict:
+    """`model.state_dict()` of a 2:4-pruned model with every (`<name>.weight`, `<name>.mask`) pair whose mask keeps exactly two of
+    every four input columns replaced by `<name>.weight_packed24` / `<name>.weight_meta24` (CUDA tensors; the kernels pack).
+    Pairs that are not 2:4 (unstructured masks, fp32 weights, widths that are not multiples of 8) stay as they are.
+    `keep_masks`: keep the `mask` entries of packed linears too (they are recoverable from the metadata)."""
+    from . import ops
+    out = {}
+    for k, v in state.items():
+        if k.endswith(".weight") and k[:-6] + "mask" in state and isinstance(v, torch.Tensor) and v.is_cuda and v.dim() == 2 and \
+                v.dtype in (torch.float16, torch.bfloat16) and v.shape[1] % 8 == 0:
+            m = state[k[:-6] + "mask"]
+            if m.shape == v.shape and m.dtype == torch.bool and bool((m.view(v.shape[0], -1, 4).sum(-1) == 2).all()):
+                w = v if v.stride(1) == 1 else v.contiguous()
+                # (what is stored is W . mask: under SparseLoRA the pruned positions of `weight` are zero already, lora.py:362)
+                values, meta = ops.pack_24(w, m if m.stride(1) == 1 else m.contiguous())
+                out[k[:-6] + PACKED_VALUES], out[k[:-6] + PACKED_META] = values, meta
+                continue
+        out[k] = v
+    if not keep_masks:
+        for k in [k for k in out if k.endswith(".mask") and k[:-4] + PACKED_VALUES in out]:
+            del out[k]
+    return out
+
+
+def unpack_state_dict_24(state: dict, device=None) -> dict:
+    """The dense state dict back: `<name>.weight` (zeros where nothing was kept) and `<name>.mask` for every packed pair."""
+    from . import ops
+    out = {}
+    for k, v in state.items():
+        if k.endswith("." + PACKED_VALUES):
+            base = k[:-len(PACKED_VALUES)]
+            values, meta = v, state[base + PACKED_META]
+            if device is not None:
+                values, meta = values.to(device), meta.to(device)
+            w, m = ops.unpack_24(values.contiguous(), meta.contiguous())
+            out[base + "weight"], out[base + "mask"] = w, m
+        elif not k.endswith("." + PACKED_META):
+            out.setdefault(k, v)
+    return out

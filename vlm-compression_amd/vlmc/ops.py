@@ -443,6 +443,43 @@ def attn_fused(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mul=None, adds
     return out.permute(0, 2, 1, 3)
 
 
+def pack_24(weight: torch.Tensor, mask: torch.Tensor):
+    """(values [out, in / 2], meta [out, in / 8] uint8) of a 16-bit weight whose `mask` (bool, 1 = keep) keeps exactly two of every
+    four consecutive input columns (include/vlmc.h: vlmc_pack_24).  Raises if a group keeps another number."""
+    _need_gpu(weight, mask)
+    out_f, in_f = weight.shape
+    if weight.dtype not in _16BIT or mask.shape != weight.shape or mask.dtype not in (torch.bool, torch.uint8) or in_f % 8 or \
+            weight.stride(1) != 1 or mask.stride(1) != 1:
+        raise TypeError("vlmc.pack_24: a 16-bit weight [out, in] (in % 8 == 0) and a bool mask of the same shape, rows contiguous, expected")
+    values = torch.empty((out_f, in_f // 2), dtype=weight.dtype, device=weight.device)
+    meta = torch.empty((out_f, in_f // 8), dtype=torch.uint8, device=weight.device)
+    bad = torch.zeros(1, dtype=torch.int32, device=weight.device)
+    _lib.check(_lib.load().vlmc_pack_24(weight.data_ptr(), _DT[weight.dtype], out_f, in_f, weight.stride(0), mask.data_ptr(), mask.stride(0),
+                                        values.data_ptr(), meta.data_ptr(), bad.data_ptr(), _stream()))
+    n_bad = int(bad.item())
+    if n_bad:
+        raise ValueError(f"vlmc.pack_24: {n_bad} groups of four columns do not keep exactly two weights: not a 2:4 mask")
+    return values, meta
+
+
+def unpack_24(values: torch.Tensor, meta: torch.Tensor, want_mask: bool = True):
+    """The dense [out, in] weight (zeros where nothing was kept) and the bool mask of `pack_24`'s output (vlmc_unpack_24)."""
+    _need_gpu(values, meta)
+    out_f, half = values.shape
+    in_f = 2 * half
+    if values.dtype not in _16BIT or meta.dtype != torch.uint8 or in_f % 8 or meta.shape != (out_f, in_f // 8) or \
+            not values.is_contiguous() or not meta.is_contiguous():
+        raise TypeError("vlmc.unpack_24: contiguous values [out, in / 2] (16-bit) and meta [out, in / 8] (uint8) expected")
+    w = torch.empty((out_f, in_f), dtype=values.dtype, device=values.device)
+    mask = torch.empty((out_f, in_f), dtype=torch.bool, device=values.device) if want_mask else None
+    bad = torch.zeros(1, dtype=torch.int32, device=values.device)
+    _lib.check(_lib.load().vlmc_unpack_24(values.data_ptr(), meta.data_ptr(), _DT[values.dtype], out_f, in_f, w.data_ptr(), in_f,
+                                          None if mask is None else mask.data_ptr(), in_f, bad.data_ptr(), _stream()))
+    if int(bad.item()):
+        raise ValueError("vlmc.unpack_24: the metadata holds codes that pack_24 never writes")
+    return w, mask
+
+
 def hessian_accum(H: torch.Tensor, x: torch.Tensor, alpha: float, beta: float) -> torch.Tensor:
     """H = alpha * H + beta * x^T x on the tiles on and below the diagonal (SparseGPT.add_batch, sparsegpt_pruner.py:76-79,
     with alpha = n/(n+b) and beta = 2/(n+b)); x [rows, in] fp16 / bf16 / fp32.  `symmetrize_lower(H)` completes H."""
