@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLMC_ABI_VERSION 15
+#define VLMC_ABI_VERSION 16
 
 #define VLMC_OK 0
 #define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
@@ -251,6 +251,19 @@ typedef struct vlmc_linear_job {
 } vlmc_linear_job;
 int vlmc_linear_fwd_group(const void *X, const vlmc_linear_job *jobs /* host array */, int n_jobs /* 1..4 */, int dtype,
                           int64_t M, int64_t K, int64_t ldx, void *stream);
+
+/* vlmc_linear_fwd with the elementwise op(s) the model applies to a linear's output folded into the epilogue -- each still rounding
+ * to the dtype where the tensor op rounds, so the result has the BITS of `vlmc_linear_fwd` followed by the torch op(s):
+ *     y = wd(X W^T + bias)                                   the module's own output (nn.Linear.forward)
+ *     [y = wd(y + post_bias[n])]                             `self.qkv(x) + qkv_bias`            eva_vit.py:137-142
+ *     [y = wd(gelu(y))]  act = 1: erf form, nn.GELU()        `self.act(self.fc1(x))`             eva_vit.py:62-64
+ *     [y = wd(residual[m][n] + y)]                           `x + self.drop_path(self.mlp(..))`  eva_vit.py:216-221,
+ *                                                            `hidden_states + self.dropout(..)`  modeling_t5.py:675, :710, :346
+ * in this order.  Saves one HBM pass over [M, N] per op (GELU on the ViT-g fc1 output: 808 MB per block and pass).  post_bias [N],
+ * residual [M, N] (row stride ldr): the operand dtype, or NULL.  Batch-invariant like vlmc_linear_fwd.                        */
+int vlmc_linear_fwd_post(const void *X, const void *W, const void *bias, int dtype, int64_t M, int64_t N, int64_t K, int64_t ldx,
+                         int64_t ldw, void *Y, int64_t ldy, const void *post_bias, int act, const void *residual, int64_t ldr,
+                         void *stream);
 
 /* ---- batched attention products of the calibration forward (MFMA) ---------------------------------
  * Replaces the batched matmuls inside the attention of a replayed block -- `attn = q @ k.transpose(-2, -1)` and `attn @ v`

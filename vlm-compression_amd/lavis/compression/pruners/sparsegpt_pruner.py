@@ -50,13 +50,13 @@ class _SparseGPTBlockMixin:
                     acc = fed.get(key)
                     if acc is None:
                         acc = sparsegpt.SparseGPT(subset[name])
-                        acc.add_batch(x, None if out is None else out.data)     # (`out` is None where the statistics pass cut the dead tail; add_batch never reads it, sparsegpt_pruner.py:68-79)
+                        acc.add_batch(x, None)     # (`out` is None where the statistics pass cut the dead tail; add_batch never reads it, sparsegpt_pruner.py:68-79)
                         fed[key] = acc
                     wrapped[name] = acc
                 elif fed.get(key) is not acc:
                     if key in fed:
                         raise RuntimeError(f"{name}: the linears sharing an input changed between calibration samples")
-                    acc.add_batch(x, None if out is None else out.data)     # (`out` is None where the statistics pass cut the dead tail; add_batch never reads it, sparsegpt_pruner.py:68-79)
+                    acc.add_batch(x, None)     # (`out` is None where the statistics pass cut the dead tail; add_batch never reads it, sparsegpt_pruner.py:68-79)
                     fed[key] = acc
                 acc._keep_alive = x                                   # the signature holds only while `x` lives
             return hook
