@@ -531,3 +531,42 @@ def test_simulated_world_is_rank_0_of_w_with_its_own_rows_in_place_of_the_exchan
     assert want.keys() == got.keys()
     for k in want:
         assert torch.equal(want[k], got[k]), k
+
+
+def test_prune_freezes_the_collector_for_its_duration_only(monkeypatch):
+    """calibration.quiet_gc: the objects alive at entry sit in the permanent generation while a prune runs (no full collection over
+    the model's 10^5 objects in the middle of it), and are back afterwards -- also when the prune raises, not when somebody else froze."""
+    import gc
+    from lavis.compression.pruners import calibration as cal
+    seen = []
+
+    @cal.quiet_gc
+    def outer(fail=False):
+        seen.append(gc.get_freeze_count())
+        inner()
+        if fail:
+            raise ValueError("x")
+        return 7
+
+    @cal.quiet_gc
+    def inner():
+        seen.append(gc.get_freeze_count())                     # nested: the outermost call owns the freeze
+
+    assert gc.get_freeze_count() == 0
+    assert outer() == 7 and seen[0] > 1000 and seen[1] >= seen[0] and gc.get_freeze_count() == 0
+    with pytest.raises(ValueError):
+        outer(fail=True)
+    assert gc.get_freeze_count() == 0
+    monkeypatch.setenv("VLMC_GC_FREEZE", "0")
+    seen.clear()
+    outer()
+    assert seen == [0, 0]
+    monkeypatch.delenv("VLMC_GC_FREEZE")
+    gc.freeze()                                                # somebody else's freeze is left alone
+    try:
+        n = gc.get_freeze_count()
+        seen.clear()
+        outer()
+        assert seen[0] == n and gc.get_freeze_count() == n
+    finally:
+        gc.unfreeze()

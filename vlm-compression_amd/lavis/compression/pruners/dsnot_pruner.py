@@ -217,6 +217,7 @@ class T5LayerDSnoTPruner(LayerWiseBasePruner, _DsnotBlockMixin):
         cal.release_tower_memory()
         return model
 
+    @cal.quiet_gc
     @print_time
     def prune(self, importance_scores=None, keep_indices_or_masks=None, lora_model=False):
         dtype_record, requires_grad_record, device = self.model_setup_and_record_attributes(self.model)
@@ -279,6 +280,7 @@ class VITLayerDSnoTPruner(LayerWiseBasePruner, _DsnotBlockMixin):
         cal.release_tower_memory()
         return model
 
+    @cal.quiet_gc
     @print_time
     def prune(self, importance_scores=None, keep_indices_or_masks=None, lora_model=False):
         dtype_record, requires_grad_record, device = self.model_setup_and_record_attributes(self.model)
@@ -349,6 +351,7 @@ class BLIPT5LayerDSnoTPruner(LayerWiseBasePruner, _DsnotBlockMixin):
         self._done_towers = getattr(self, "_done_towers", []) + [kw["module_to_process"]]
         return out
 
+    @cal.quiet_gc
     @print_time
     def prune(self, importance_scores=None, keep_indices_or_masks=None, lora_model=False):
         dtype_record, requires_grad_record, device = self.model_setup_and_record_attributes(self.model)

@@ -289,6 +289,7 @@ class BLIPT5LayerSparseGPTPruner(LayerWiseBasePruner, _SparseGPTBlockMixin):
     def forward_to_cache(self, model, batch):
         return model(batch)
 
+    @cal.quiet_gc
     @print_time
     def prune(self, importance_scores=None, keep_indices_or_masks=None):
         print("In: ", self.pruner_name)

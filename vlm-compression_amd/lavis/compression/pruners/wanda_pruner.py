@@ -432,6 +432,7 @@ class BLIPT5LayerWandaPruner(LayerWiseBasePruner):
         self._done_towers = getattr(self, "_done_towers", []) + [kw["module_to_process"]]
         return out
 
+    @cal.quiet_gc
     @print_time
     def prune(self, importance_scores=None, keep_indices_or_masks=None, lora_model=False):
         dtype_record, requires_grad_record, device = self.model_setup_and_record_attributes(self.model)
