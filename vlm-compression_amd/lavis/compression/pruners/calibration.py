@@ -589,6 +589,8 @@ class TowerGraph:
                         self.live = {"outs": r["outs"], "calls": wiring, "given": given, "clone": False}
                         return True, self._hand_out(0)
                 elif self._batchable(args, kwargs):
+                    # (measured, round 5: answering a tower nothing was predicted for -- the frozen Q-Former in the encoder's capture
+                    # phase -- per sample from its HIP graph instead of abort + stacked pass + repeat: 334 against 289 ms per prune)
                     self.deferred.append({"j": _CTX.capture_sample, "key": key, "args": args, "kwargs": kwargs,
                                           "ctx": TowerMemo.context()})
                     raise _Defer
