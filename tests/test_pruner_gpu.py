@@ -527,6 +527,7 @@ def test_tower_batching_gives_the_per_sample_forward_bit_for_bit(ragged, monkeyp
     """Finished 16-bit towers (their linears on the batch-invariant kernel) run ONCE for all postponed calibration forwards
     of a shape (`TowerGraph.run_deferred`); the forwards are repeated and served slices.  The captured decoder inputs equal
     those of the sample-by-sample route bit for bit, in sample order, also with ragged text (three shapes, interleaved)."""
+    monkeypatch.setenv("VLMC_CAPTURE_MERGED", "0")          # (this is about the per-sample route: one model forward per calibration batch)
     import toy_models
     from lavis.compression.pruners import calibration as cal
     monkeypatch.setattr(toy_models.ToyAttention, "use_sdpa", True)        # attention per sample and head by construction
@@ -557,6 +558,7 @@ def test_finished_tower_that_hands_a_block_output_on_as_a_keyword(monkeypatch):
     """transformers' T5Stack: block 0 computes the relative position bias and RETURNS it, the stack hands it to every later
     block as `position_bias=`.  The capture machinery must wire that (an output of block 0 is a keyword argument of blocks
     1..n) in all three ways a finished tower is traversed: eagerly, as one graph per sample, stacked for all samples."""
+    monkeypatch.setenv("VLMC_CAPTURE_MERGED", "0")          # (this is about the per-sample route: one model forward per calibration batch)
     import torch.nn.functional as F
     from lavis.compression.pruners import calibration as cal
 
@@ -624,6 +626,7 @@ def test_predicted_tower_pass_gives_the_aborted_and_repeated_forwards_result(rag
     """Decoder capture of the 16-bit toy InstructBLIP: the T5 encoder (just pruned) runs stacked for all samples from the
     block-0 arguments its own capture phase saw (`TowerGraph.run_predicted`), every sample then needs ONE forward instead of
     an aborted one plus a repeated one.  Same pruned model, masks and importance scores, bit for bit."""
+    monkeypatch.setenv("VLMC_CAPTURE_MERGED", "0")          # (this is about the per-sample route: one model forward per calibration batch)
     import toy_models
     from lavis.compression.pruners import calibration as cal
     monkeypatch.setattr(toy_models.ToyAttention, "use_sdpa", True)
@@ -657,6 +660,7 @@ def test_a_wrong_prediction_is_noticed_and_the_phase_runs_again(batched_trace, m
     input, the end-of-phase comparison says so (`later_failed`), the phase is repeated without memos or predictions, and the
     pruned model is the one the plain route gives.  Both ways the stacked pass can start: from the forward that traces the wiring
     (`_begin_batched_trace`) and, with an eager trace, from `run_predicted`."""
+    monkeypatch.setenv("VLMC_CAPTURE_MERGED", "0")          # (this is about the per-sample route: one model forward per calibration batch)
     import toy_models
     from lavis.compression.pruners import calibration as cal
     monkeypatch.setattr(toy_models.ToyAttention, "use_sdpa", True)

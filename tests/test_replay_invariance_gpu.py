@@ -193,8 +193,11 @@ def test_ragged_samples_padded_into_one_group_keep_their_bits(lora_model, monkey
         return out, calibration.graph_stats.get("padded_forwards", 0) - before[0], \
             forward.stats["softmax_kernel"] + forward.stats["attn_fused"] - before[1]       # (the softmax kernel, alone or inside the fused attention)
 
-    base = {"VLMC_BATCH_REPLAY": "128", "VLMC_TOWER_BATCH": "1", "VLMC_PAD_RAGGED": "1", "VLMC_TOWER_PAD": "1"}
+    base = {"VLMC_BATCH_REPLAY": "128", "VLMC_TOWER_BATCH": "1", "VLMC_PAD_RAGGED": "1", "VLMC_TOWER_PAD": "1", "VLMC_CAPTURE_MERGED": "0"}
     seen = {}
+    before_m = calibration.graph_stats.get("merged_forwards", 0)
+    merged, n_m, _ = run({**base, "VLMC_CAPTURE_MERGED": "1"})              # the default: calibration batches of one shape in ONE model forward
+    assert n_m == 2 * 2 * 3          # (ragged batches: more than two shapes, the merged route declines and the per-sample route pads)
     padded, n_padded, n_softmax = run(base)
     # .. and the finished encoder tower ran ONE padded stacked pass for the samples behind the scout's group while the decoder's
     # inputs were captured (TowerGraph._run_padded)
@@ -206,6 +209,46 @@ def test_ragged_samples_padded_into_one_group_keep_their_bits(lora_model, monkey
     assert n_padded == 2 * 2 * 3 and n_shaped == 0 and n_softmax > 0          # encoder + decoder tower, two passes, three blocks: ONE forward each
     assert padded.keys() == shaped.keys() == single.keys() and len(padded) == 2 * 4 + 3 * 7 + 3 * 11
     for k in padded:
-        for other, name in ((shaped, "groups of equal shapes"), (single, "per-sample loop"), (towers_per_length, "towers per token count")):
+        for other, name in ((shaped, "groups of equal shapes"), (single, "per-sample loop"), (towers_per_length, "towers per token count"),
+                            (merged, "merged capture forwards")):
             assert torch.equal(padded[k][0], other[k][0]), (k, name)
             assert (padded[k][1] is None and other[k][1] is None) or torch.equal(padded[k][1], other[k][1]), (k, name)
+
+
+@pytest.mark.parametrize("n_shapes", [1, 2])
+def test_merged_capture_forwards_give_the_per_sample_routes_bits(n_shapes, monkeypatch):
+    """calibration._capture_merged: the calibration batches of one shape go through the model's own forward as ONE stacked batch per
+    capture phase (the Q-Former in the way is simply run, nothing is aborted and repeated); a whole prune -- masks, weights,
+    importance scores of all three towers -- equals the per-sample route's (one model forward per calibration batch) and the
+    reference's one-sample-per-forward loop, bit for bit; with two text lengths the batches merge per length."""
+    from vlmc import forward, synthetic
+    from lavis.compression.pruners import calibration
+    dev = torch.device(DEV)
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        torch.manual_seed(0)
+        model = synthetic.InstructBlipT5(vit_dim=64, vit_hidden=128, vit_heads=4, vit_depth=2, d_model=64, d_ff=128, heads=4, d_kv=16,
+                                         enc_depth=3, dec_depth=3, vocab=100, query_tokens=4, reference_ops=True, qformer_dim=64, qformer_heads=4,
+                                         qformer_hidden=128, qformer_depth=2, qformer_vocab=50).to(dev).eval()
+        batches = synthetic.calibration_batches(16, dev, vit_tokens=9, vit_dim=64, vocab=100, ragged=False)
+        if n_shapes == 2:                                                  # every third sample with a shorter prompt
+            for b in batches[::3]:
+                b["text_input"] = b["text_input"][:, :5].contiguous()
+        m0, d0 = calibration.graph_stats.get("merged_forwards", 0), calibration.graph_stats.get("merged_capture_declined", 0)
+        synthetic.time_prune(dev, n_samples=16, model=model, batches=batches, **({"t5_prune_spec": "3-0.5-1.0-1.0"}))
+        out = {n: (m.weight.detach().clone(), m.mask.clone() if hasattr(m, "mask") else None, getattr(m.weight, "importance_score", None))
+               for n, m in model.named_modules() if isinstance(m, torch.nn.Linear) and (".block." in n or ".blocks." in n)}
+        return out, calibration.graph_stats.get("merged_forwards", 0) - m0, calibration.graph_stats.get("merged_capture_declined", 0) - d0
+
+    merged, n_merged, declined = run({"VLMC_CAPTURE_MERGED": "1", "VLMC_BATCH_REPLAY": "128", "VLMC_TOWER_BATCH": "1"})
+    assert n_merged == 3 * n_shapes and declined == 0                      # one stacked model forward per tower, capture phase and shape
+    per_sample, n0, _ = run({"VLMC_CAPTURE_MERGED": "0"})
+    loop, _, _ = run({"VLMC_CAPTURE_MERGED": "0", "VLMC_BATCH_REPLAY": "1", "VLMC_TOWER_BATCH": "0"})
+    assert n0 == 0 and merged.keys() == per_sample.keys() == loop.keys() and len(merged) == 2 * 4 + 3 * 7 + 3 * 11
+    for k in merged:
+        for other, name in ((per_sample, "per-sample capture"), (loop, "the reference's loop")):
+            assert torch.equal(merged[k][0], other[k][0]), (k, name)
+            assert (merged[k][1] is None and other[k][1] is None) or torch.equal(merged[k][1], other[k][1]), (k, name)
+            assert merged[k][2] == other[k][2], (k, name)

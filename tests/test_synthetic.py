@@ -53,6 +53,7 @@ def test_q_former_run_as_a_finished_tower_gives_the_per_sample_forwards_result(r
     equal, bit for bit, the route in which every calibration sample goes through them alone (`replay_per_sample`: same
     batch-invariant kernels, one sample per forward).  Against the route that leaves the Q-Former to torch's eager ops (library
     GEMMs: other summation orders) the masks agree to near-ties."""
+    monkeypatch.setenv("VLMC_CAPTURE_MERGED", "0")          # (this is about the per-sample route: one model forward per calibration batch)
     from vlmc import synthetic
     from lavis.compression.pruners import calibration
     dev = torch.device("cuda:0")

@@ -116,6 +116,7 @@ class _PruneContext(threading.local):
         self.capture_sample = None
         self.stacked = None
         self.stacked_lengths = None
+        self.capture_group = None          # merged capture: the samples (indices) of the calibration forward that is running
         self.capture_side = {}
         self.stream_set = ()
 
@@ -256,14 +257,39 @@ class TowerMemo:
     def _drop(self):
         self.ok, self.entries, self.hit, self.pending = False, {}, None, None
 
+    def _group_hit(self, group, args, kwargs):
+        """A merged calibration forward (samples `group` stacked along the batch): the remembered outputs of those samples, stacked,
+        if the stacked input is their remembered inputs (bits compared like every remembered tensor: `_bits_equal`)."""
+        ents = [self.entries.get(j) for j in group]
+        if not ents or any(e is None for e in ents) or not args or not isinstance(args[0], torch.Tensor):
+            return None
+        (rargs0, rkw0, ctx0), x = ents[0][0], args[0]
+        b = rargs0[0].shape[0]
+        if ctx0 != self.context() or len(rargs0) != len(args) or sorted(rkw0) != sorted(kwargs) or x.shape[0] != b * len(group) or \
+                x.shape[1:] != rargs0[0].shape[1:]:
+            return None
+        for r, v in list(zip(rargs0[1:], args[1:])) + [(rkw0[k], kwargs[k]) for k in rkw0]:
+            if isinstance(r, torch.Tensor) or isinstance(v, torch.Tensor) or (r is not v and r != v):
+                return None                                         # (only towers whose blocks get nothing but the hidden states and plain values)
+        parts = x.split(b, dim=0)
+        for (rec, _out), part in zip(ents, parts):
+            rargs, rkw, ctx = rec
+            if ctx != ctx0 or len(rargs) != len(args) or not _bits_equal(rargs[0], part):
+                return None
+        return torch.cat([e[1] for e in ents], dim=0)
+
     def enter(self, index, args, kwargs):
         """-> (handled, value).  Called by block `index` of the tower before it would run."""
         if not self.ok:
             return False, None
+        group = _CTX.capture_group
         if index == 0:
             self.expect, self.hit, self.pending = 0, None, None
+            self.hit_fresh = False
             # which calibration forward this is: the capture loop says so (it may run a forward twice); else they are counted
-            if _CTX.capture_sample is not None:
+            if group is not None:
+                self.current = None
+            elif _CTX.capture_sample is not None:
                 self.current = _CTX.capture_sample
             else:
                 self.current, self.cursor = self.cursor, self.cursor + 1
@@ -274,13 +300,19 @@ class TowerMemo:
             self._drop()
             return False, None
         self.expect = index + 1
+        if group is not None and self.mode == "record":
+            return False, None                                     # (a merged forward: nothing is remembered per sample)
         if self.mode == "record":
             if index == 0:
                 self.pending = self._snapshot(args, kwargs) if args and isinstance(args[0], torch.Tensor) else None
                 if self.pending is None:
                     self._drop()
             return False, None
-        if index == 0:
+        if index == 0 and group is not None:
+            self.hit = self._group_hit(group, args, kwargs)
+            self.hit_fresh = self.hit is not None
+            graph_stats["memo_hits" if self.hit is not None else "memo_misses"] += 1
+        elif index == 0:
             ent = self.entries.get(self.current)
             if ent is not None and self._same(ent[0], args, kwargs):
                 self.hit = ent[1]
@@ -290,11 +322,13 @@ class TowerMemo:
         if self.hit is None:
             return False, None
         if index == self.n - 1:
-            out, self.hit = self.hit.clone(), None
+            out, self.hit = (self.hit if self.hit_fresh else self.hit.clone()), None
             return True, (self.wrap((out,)) if self.wrap else out)
         return True, (self.wrap((args[0],)) if self.wrap else args[0])
 
     def leave(self, index, result):
+        if _CTX.capture_group is not None:
+            return
         if self.ok and self.mode == "record":
             # every block must hand its hidden states on the same way: the tensor, or a 1-tuple / 1-list of it
             kind = None if isinstance(result, torch.Tensor) else \
@@ -1130,6 +1164,8 @@ class GraphedModule(nn.Module):
         return out
 
     def _tower_forward(self, *args, **kwargs):
+        if _CTX.capture_group is not None:                      # a merged calibration forward runs the tower as the model calls it
+            return self.__dict__["_wrapped"](*args, **kwargs)
         tg = self.__dict__.get("_tower")                        # (TowerGraph, index) or None
         if tg is None:
             return self._forward(*args, **kwargs)
@@ -1317,6 +1353,20 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
     args = (model, batches, module_to_process, forward_to_cache, lora_model)
     kw = dict(vit=vit, model_prefix=model_prefix, done_towers=done_towers, proxy_cache=proxy_cache)
     p0 = next(model.parameters(), None)
+    if merged_capture_enabled() and p0 is not None and p0.is_cuda and _CTX.later is None:
+        _CTX.later = _LaterEqual()                              # (remembered tower inputs against what the merged forward feeds them)
+        try:
+            res = _capture_merged(*args, **kw)
+            bad = res is not None and _CTX.later.failed()
+        finally:
+            _CTX.later = None
+        if res is not None and not bad:
+            return res
+        graph_stats["merged_capture_declined"] = graph_stats.get("merged_capture_declined", 0) + 1
+        if bad:
+            for key, val in list(proxy_cache.items() if proxy_cache is not None else []):
+                if isinstance(val, TowerMemo):
+                    val._drop()
     if done_towers and proxy_cache is not None and later_check_enabled() and p0 is not None and p0.is_cuda and _CTX.later is None:
         # what finished towers remember of the previous phase is trusted while the forwards run and verified afterwards
         _CTX.later = _LaterEqual()
@@ -1335,6 +1385,249 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
             elif isinstance(key, tuple) and key and key[0] == "block0":
                 del proxy_cache[key]                       # ... nor the block-0 arguments remembered for run_predicted
     return _capture_once(*args, **kw)
+
+
+def merged_capture_enabled():
+    """Calibration batches of one structure run the model's forward to the next tower as ONE stacked batch
+    (`_capture_merged`; `VLMC_CAPTURE_MERGED=0`: one forward per calibration batch, as the reference's loop)."""
+    return os.environ.get("VLMC_CAPTURE_MERGED", "1") != "0" and tower_batch_enabled() and replay_group_size() > 1 and \
+        graph_replay_enabled() and torch.cuda.is_available()
+
+
+def _batch_signature(batch):
+    if not isinstance(batch, dict):
+        return None
+    sig = []
+    for k in sorted(batch):
+        v = batch[k]
+        if isinstance(v, torch.Tensor):
+            if v.dim() < 1 or v.requires_grad:
+                return None
+            sig.append((k, "T", tuple(v.shape), v.dtype, v.device))
+        elif isinstance(v, (list, tuple)):
+            sig.append((k, "L", type(v), len(v), tuple(type(e) for e in v)))
+        elif v is None or isinstance(v, (bool, int, float, str)):
+            sig.append((k, "V", v))
+        else:
+            return None
+    return tuple(sig)
+
+
+def _merge_batches(batches):
+    out = {}
+    for k, v0 in batches[0].items():
+        if isinstance(v0, torch.Tensor):
+            out[k] = torch.cat([b[k] for b in batches], dim=0)
+        elif isinstance(v0, (list, tuple)):
+            out[k] = type(v0)(e for b in batches for e in b[k])
+        else:
+            out[k] = v0
+    return out
+
+
+def all_linears(model, proxy_cache):
+    """Every exact-type nn.Linear of the model (one walk per prune): during a capture phase they all run on the batch-invariant
+    kernel -- the towers' and the glue between them (`t5_proj`, ..) -- so that what a sample's forward hands the next tower does
+    not depend on how many samples share the forward."""
+    key = ("all_linears", id(model))
+    lin = proxy_cache.get(key) if proxy_cache is not None else None
+    if lin is None:
+        lin = [m for m in model.modules() if type(m) is nn.Linear]
+        if proxy_cache is not None:
+            proxy_cache[key] = lin
+    return lin
+
+
+def _capture_merged(model, batches, module_to_process, forward_to_cache, lora_model, *, vit, model_prefix, done_towers, proxy_cache):
+    """The capture phase with the calibration batches of one structure STACKED into one forward of the model.
+
+    The reference forwards every calibration batch on its own up to the tower that is to be pruned
+    (wanda_pruner.py:213-273: Catcher); 128 batch-1 forwards of the model's Python per phase were half of a prune's wall-clock
+    once the towers themselves ran stacked (the host paced them, the GPU idled), and a never-pruned tower in the way -- the
+    Q-Former -- cost every sample an aborted forward and a repeated one.  The model's own forward takes batches: the samples
+    whose batch dicts have one structure (same tensor shapes, same list lengths) are concatenated and forwarded ONCE; the
+    Catcher's one call is cut back into per-sample inputs and kwargs.  What makes a sample's slice carry the bits of its own
+    forward: every nn.Linear on the way runs on the batch-invariant kernel (`all_linears`), attention and norms of the finished
+    towers on the invariant kernels of vlmc/forward.py, everything else on the way is row-wise.  It is CHECKED, not assumed:
+    sample 0 is also forwarded alone (the same route, batch 1); its captured tensors say which kwargs carry the batch
+    dimension, and they must equal slice 0 of the merged capture bit for bit -- otherwise, or when a batch does not merge, or
+    when the model turns out to pad inside the merged forward (mask kwargs that differ between samples), this returns None
+    and the phase runs the reference's way (`_capture_once`).  Finished towers are entered through their proxies: a tower
+    whose outputs are remembered from its own walk (the ViT) hands them over stacked, the others run as the model calls them.
+    """
+    rank, world = calibration_shard()
+    if world > 1:
+        if len(batches) % world != 0:
+            return None
+        per = len(batches) // world
+        mine = batches[rank * per:(rank + 1) * per]
+    else:
+        mine = batches
+    if len(mine) < 2:
+        return None
+    sigs = [_batch_signature(b) for b in mine]
+    if any(s_ is None for s_ in sigs):
+        return None
+    order, groups = [], {}
+    for j, s_ in enumerate(sigs):
+        if s_ not in groups:
+            groups[s_] = []
+            order.append(s_)
+        groups[s_].append(j)
+    layers = get_module_recursive(model, module_to_process)
+    keys = None if vit else _keys_for(model_prefix)
+    final = proxy_cache is not None and proxy_cache.get(("last_tower",)) == module_to_process
+    want_calls = vit and proxy_cache is not None and tower_memo_enabled() and graph_replay_enabled()
+    got = []
+
+    class MergedCatcher(nn.Module):
+        def __init__(self, module):
+            super().__init__()
+            self.module = module
+
+        def forward(self, inp, *args, **kwargs):
+            got.append((inp, args, dict(kwargs)))
+            raise _Stop
+
+    def run(idxs):
+        got.clear()
+        batch = mine[idxs[0]] if len(idxs) == 1 else _merge_batches([mine[j] for j in idxs])
+        _CTX.capture_group = list(idxs)
+        try:
+            forward_to_cache(model, batch, lora_model)
+        except ValueError:                                     # _Stop, or the reference's bare ValueError
+            pass
+        finally:
+            _CTX.capture_group = None
+        return got[0] if len(got) == 1 else None
+
+    def tensors_of(call):
+        inp, args, kw = call
+        return [("#inp", inp)] + [(f"#{i}", a) for i, a in enumerate(args)] + sorted(kw.items())
+
+    layers[0] = MergedCatcher(layers[0])
+    undo = _wrap_towers(model, [t for t in (done_towers or []) if t != module_to_process], proxy_cache, record=False)
+    arrived, calls = [], []
+    try:
+        towers = []
+        for blocks_, i_, _orig in undo:
+            tg_ = blocks_[i_].__dict__.get("_tower")
+            if tg_ is not None and not any(tg_[0] is t for t in towers):
+                towers.append(tg_[0])
+        order.sort(key=lambda s_: -len(groups[s_]))             # the largest group first: its first sample is the one forwarded alone
+        scout = groups[order[0]][0]
+        if len(groups[order[0]]) < 2 or len(order) > 2:
+            # nothing to merge -- or ragged batches: a merged forward per token count would run the finished towers once per count,
+            # where the per-sample route pads them into one stacked pass (TowerGraph._run_padded; measured: 532 against 500 ms)
+            return None
+        flags = []                                               # device-side verdicts, read once at the end (no wait per forward)
+        with torch.no_grad(), forward.invariant_linears(all_linears(model, proxy_cache), roots=[b for t in towers for b in t.mods]):
+            one = run([scout])                                  # one sample alone: the shapes of a batch-1 call, and the bits to hold the merge to
+            if one is None or not isinstance(one[0], torch.Tensor) or one[0].dim() < 2:
+                return None
+            names1 = tensors_of(one)
+            batched = None                                       # name -> does the tensor carry the batch dimension (learned on the first merged call)
+            for s_ in order:
+                idxs = groups[s_]
+                first_rows = None
+                c0 = 0
+                while c0 < len(idxs):
+                    if first_rows is None:
+                        per = min(replay_group_size(), len(idxs))
+                    chunk = idxs[c0:c0 + per]
+                    call = run(chunk)
+                    if call is None or not isinstance(call[0], torch.Tensor):
+                        return None
+                    g = len(chunk)
+                    if first_rows is None:                      # the token budget of a stacked forward (the same as the replay's)
+                        first_rows = max(1, call[0].numel() // max(1, call[0].shape[-1])) // g
+                        fit = max(1, REPLAY_TOKEN_BUDGET // max(1, first_rows))
+                        if g > fit and g > 1:
+                            per = fit
+                            continue                              # (rerun this chunk smaller; rare: only very long samples)
+                    c0 += g
+                    names = tensors_of(call)
+                    if len(names) != len(names1) or [n for n, _ in names] != [n for n, _ in names1]:
+                        return None
+                    learn = batched is None
+                    if learn:
+                        if g < 2 or chunk[0] != scout:
+                            return None
+                        batched = {}
+                    pieces = {}
+                    for (name, v), (_n1, v1) in zip(names, names1):
+                        if isinstance(v, torch.Tensor) != isinstance(v1, torch.Tensor):
+                            return None
+                        if not isinstance(v, torch.Tensor):
+                            if v is not v1 and v != v1:
+                                return None                     # a plain argument that depends on the batch
+                            continue
+                        if v.dtype != v1.dtype or v.dim() != v1.dim():
+                            return None
+                        if learn:
+                            # carries the batch dimension: g times the batch-1 extent in front, the rest as in the batch-1 call
+                            if v.dim() >= 1 and v.shape[0] == g * v1.shape[0] and v.shape[1:] == v1.shape[1:]:
+                                batched[name] = v1.shape[0]
+                            elif v.shape == v1.shape:
+                                batched[name] = 0
+                            else:
+                                return None                     # (e.g. the model padded: another token count than the sample alone)
+                        b_ = batched[name]
+                        if b_:
+                            if v.dim() < 1 or v.shape[0] != g * b_:
+                                return None
+                            pieces[name] = v.split(b_, dim=0)
+                        if learn:                                # the merge against the sample's own forward, bit for bit
+                            mine0 = pieces[name][0] if name in pieces else v
+                            flags.append((mine0 == v1).all() if mine0.shape == v1.shape else torch.zeros((), dtype=torch.bool, device=v.device))
+                        # a mask the model built for padding inside the merged forward: the samples would differ in it
+                        if name in PAD_MASK_KEYS and name in pieces and g > 1:
+                            flags.append((v == v[:b_].repeat(g, *([1] * (v.dim() - 1)))).all())
+                    if not batched.get("#inp"):
+                        return None
+                    inp, args, kw = call
+                    for t, j in enumerate(chunk):
+                        pick = lambda name, v: (pieces[name][t] if name in pieces else v)
+                        inp_j = pick("#inp", inp)
+                        args_j = tuple(pick(f"#{i}", a_) for i, a_ in enumerate(args))
+                        kw_j = {k: pick(k, v) for k, v in kw.items()}
+                        if want_calls:
+                            calls.append((j, TowerMemo._snapshot((inp_j,) + args_j, kw_j)))
+                        if vit:
+                            rel_pos_bias = args_j[0] if args_j else kw_j.get("rel_pos_bias")
+                            dense = args_j[1] if len(args_j) > 1 else kw_j.get("dense", True)
+                            cache = {"rel_pos_bias": rel_pos_bias}
+                        else:
+                            dense = kw_j.pop("dense", True)
+                            cache = {k: kw_j[k] for k in keys}
+                        if lora_model:
+                            cache["dense"] = dense
+                        arrived.append((j, inp_j, cache))
+                    graph_stats["merged_forwards"] = graph_stats.get("merged_forwards", 0) + 1
+        if flags and not bool(torch.stack(flags).all()):
+            graph_stats["merged_capture_mismatch"] = graph_stats.get("merged_capture_mismatch", 0) + 1
+            return None
+    except KeyError:
+        return None                                             # (a kwarg the reference's key list names is missing: its path)
+    finally:
+        _CTX.capture_group = None
+        layers[0] = layers[0].module
+        for blocks, i, orig in undo:
+            blocks[i].__dict__["_memo"] = None
+            blocks[i].__dict__["_tower"] = None
+            blocks[i] = orig
+    if len(arrived) != len(mine):
+        return None
+    arrived.sort(key=lambda a: a[0])
+    if want_calls:
+        calls.sort(key=lambda c: c[0])
+        proxy_cache[("calls", module_to_process)] = [c[1] for c in calls]
+    if proxy_cache is not None:
+        proxy_cache.pop(("block0", module_to_process), None)       # (nothing was remembered for the per-sample route's predicted passes)
+    for a in arrived:
+        if isinstance(a[1], torch.Tensor):
+            a[1].requires_grad = False
+    return [a[1] for a in arrived], [None] * len(arrived), [a[2] for a in arrived]
 
 
 def _capture_once(model, batches, module_to_process, forward_to_cache, lora_model, *, vit, model_prefix, done_towers,
@@ -1408,7 +1701,9 @@ def _capture_once(model, batches, module_to_process, forward_to_cache, lora_mode
                 towers.append(tg_[0])
         # the finished towers' linears run on the batch-invariant kernel whichever way a sample gets through them (alone,
         # from a graph, or stacked with others): the captured inputs do not depend on the route
-        with forward.invariant_linears([m for t in towers for m in t.linears], roots=[b for t in towers for b in t.mods]):
+        # (.. and so do the linears between the towers: the per-sample route and the merged one hand the next tower the same bits)
+        with forward.invariant_linears(all_linears(model, proxy_cache) if proxy_cache is not None else [m for t in towers for m in t.linears],
+                                       roots=[b for t in towers for b in t.mods]):
             pending, sweeps = list(range(len(mine))), 0
             while pending:
                 sweeps += 1
