@@ -242,6 +242,7 @@ def test_merged_capture_forwards_give_the_per_sample_routes_bits(n_shapes, monke
                for n, m in model.named_modules() if isinstance(m, torch.nn.Linear) and (".block." in n or ".blocks." in n)}
         return out, calibration.graph_stats.get("merged_forwards", 0) - m0, calibration.graph_stats.get("merged_capture_declined", 0) - d0
 
+    monkeypatch.setattr(calibration, "MERGED_CAPTURE_MIN", 2)             # (16 samples here; the default asks for 24)
     merged, n_merged, declined = run({"VLMC_CAPTURE_MERGED": "1", "VLMC_BATCH_REPLAY": "128", "VLMC_TOWER_BATCH": "1"})
     assert n_merged == 3 * n_shapes and declined == 0                      # one stacked model forward per tower, capture phase and shape
     per_sample, n0, _ = run({"VLMC_CAPTURE_MERGED": "0"})

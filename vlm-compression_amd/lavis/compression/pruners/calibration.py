@@ -1387,6 +1387,12 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
     return _capture_once(*args, **kw)
 
 
+try:
+    MERGED_CAPTURE_MIN = max(2, int(os.environ.get("VLMC_CAPTURE_MERGED_MIN", "24")))
+except ValueError:
+    MERGED_CAPTURE_MIN = 24
+
+
 def merged_capture_enabled():
     """Calibration batches of one structure run the model's forward to the next tower as ONE stacked batch
     (`_capture_merged`; `VLMC_CAPTURE_MERGED=0`: one forward per calibration batch, as the reference's loop)."""
@@ -1463,8 +1469,8 @@ def _capture_merged(model, batches, module_to_process, forward_to_cache, lora_mo
         mine = batches[rank * per:(rank + 1) * per]
     else:
         mine = batches
-    if len(mine) < 2:
-        return None
+    if len(mine) < MERGED_CAPTURE_MIN:
+        return None                                              # (few samples: the forward of one sample alone that the merge is checked against costs what it saves)
     sigs = [_batch_signature(b) for b in mine]
     if any(s_ is None for s_ in sigs):
         return None
