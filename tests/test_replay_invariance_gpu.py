@@ -196,8 +196,11 @@ def test_ragged_samples_padded_into_one_group_keep_their_bits(lora_model, monkey
     base = {"VLMC_BATCH_REPLAY": "128", "VLMC_TOWER_BATCH": "1", "VLMC_PAD_RAGGED": "1", "VLMC_TOWER_PAD": "1", "VLMC_CAPTURE_MERGED": "0"}
     seen = {}
     before_m = calibration.graph_stats.get("merged_forwards", 0)
-    merged, n_m, _ = run({**base, "VLMC_CAPTURE_MERGED": "1"})              # the default: calibration batches of one shape in ONE model forward
-    assert n_m == 2 * 2 * 3          # (ragged batches: more than two shapes, the merged route declines and the per-sample route pads)
+    monkeypatch.setattr(calibration, "MERGED_CAPTURE_MIN", 2)
+    merged, n_m, _ = run({**base, "VLMC_CAPTURE_MERGED": "1", "VLMC_CAPTURE_MERGED_RAGGED": "1"})      # merged forwards per shape, towers deferred (opt-in)
+    monkeypatch.delenv("VLMC_CAPTURE_MERGED_RAGGED")
+    # (ragged batches: the groups' merged forwards are postponed at the finished towers, which run once, padded, for all samples)
+    assert calibration.graph_stats.get("merged_forwards", 0) > before_m and n_m == 2 * 2 * 3, calibration.graph_stats
     padded, n_padded, n_softmax = run(base)
     # .. and the finished encoder tower ran ONE padded stacked pass for the samples behind the scout's group while the decoder's
     # inputs were captured (TowerGraph._run_padded)

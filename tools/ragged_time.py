@@ -18,4 +18,4 @@ for rep in range(n + 2):
 env = {k: v for k, v in os.environ.items() if k.startswith("VLMC_")}
 print(f"{env}: median {statistics.median(ts) * 1e3:.1f} ms  min {min(ts) * 1e3:.1f}  ({' '.join(f'{x * 1e3:.0f}' for x in ts)})")
 print("   ", {k: v for k, v in forward.stats.items() if k.startswith("attn") or k.startswith("softmax")},
-      {k: v for k, v in cal.graph_stats.items() if "tower" in k or "padded" in k or "shared" in k})
+      {k: v for k, v in cal.graph_stats.items() if "tower" in k or "padded" in k or "shared" in k or "merged" in k or "memo" in k})

@@ -117,6 +117,7 @@ class _PruneContext(threading.local):
         self.stacked = None
         self.stacked_lengths = None
         self.capture_group = None          # merged capture: the samples (indices) of the calibration forward that is running
+        self.group_defer = False           # .. and finished towers are left for ONE (padded) stacked pass over all groups (ragged batches)
         self.capture_side = {}
         self.stream_set = ()
 
@@ -301,7 +302,19 @@ class TowerMemo:
             return False, None
         self.expect = index + 1
         if group is not None and self.mode == "record":
-            return False, None                                     # (a merged forward: nothing is remembered per sample)
+            # a merged forward: the per-sample calls are cut out of the stacked one, the last block's output likewise (leave)
+            if index == 0:
+                self.pending = None
+                x = args[0] if args and isinstance(args[0], torch.Tensor) else None
+                g = len(group)
+                if x is not None and x.dim() >= 2 and x.shape[0] % g == 0:
+                    b = x.shape[0] // g
+                    cut = lambda v: (v.split(b, dim=0) if isinstance(v, torch.Tensor) and v.dim() >= 2 and v.shape[0] == g * b else None)
+                    ca, ck = [cut(v) for v in args], {k: cut(v) for k, v in kwargs.items()}
+                    self.pending = ("group", list(group), b,
+                                    [self._snapshot([c[t] if c is not None else v for c, v in zip(ca, args)],
+                                                    {k: (ck[k][t] if ck[k] is not None else v) for k, v in kwargs.items()}) for t in range(g)])
+            return False, None
         if self.mode == "record":
             if index == 0:
                 self.pending = self._snapshot(args, kwargs) if args and isinstance(args[0], torch.Tensor) else None
@@ -328,6 +341,21 @@ class TowerMemo:
 
     def leave(self, index, result):
         if _CTX.capture_group is not None:
+            if self.ok and self.mode == "record" and index == self.n - 1 and isinstance(self.pending, tuple) and self.pending[0] == "group" \
+                    and self.expect == self.n:
+                _tag, group, b, snaps = self.pending
+                self.pending = None
+                kind = None if isinstance(result, torch.Tensor) else \
+                    (type(result) if type(result) in (tuple, list) and len(result) == 1 and isinstance(result[0], torch.Tensor) else False)
+                if kind is False or (self.wrap is not False and self.wrap is not kind):
+                    return
+                self.wrap = kind
+                out = result if kind is None else result[0]
+                if out.shape[0] != b * len(group):
+                    return
+                for j, snap, o in zip(group, snaps, out.split(b, dim=0)):
+                    self.entries[j] = (snap, o.detach().clone())
+                    graph_stats["memo_recorded"] += 1
             return
         if self.ok and self.mode == "record":
             # every block must hand its hidden states on the same way: the tensor, or a 1-tuple / 1-list of it
@@ -639,6 +667,62 @@ class TowerGraph:
         if self.btrace is not None and self.trace is not None:
             return self._batched_step(index, args, kwargs)
         return False, None
+
+    # -- merged calibration forwards of ragged batches (calibration._capture_merged) ------------------------------------------------
+    def enter_group(self, index, args, kwargs):
+        """-> (handled, value) for block `index` called with the STACKED samples `_CTX.capture_group`."""
+        grp = _CTX.capture_group
+        if self.off or torch.is_grad_enabled():
+            self.live = None
+            return False, None
+        if index > 0:
+            return self._serve(index, args, kwargs) if self.live is not None else (False, None)
+        self.live = self.trace = self.btrace = None
+        g = len(grp)
+        if not (args and isinstance(args[0], torch.Tensor) and args[0].dim() >= 2 and args[0].shape[0] % g == 0):
+            return False, None
+        # the group's arguments as per-sample calls: tensors with g times the per-sample batch extent in front are cut, the rest is shared
+        b = args[0].shape[0] // g
+
+        def cut(v):
+            if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == g * b and v.dim() >= 2:
+                return v.split(b, dim=0)
+            return None
+        cuts_a = [cut(v) for v in args]
+        cuts_k = {k: cut(v) for k, v in kwargs.items()}
+        per = [(tuple(c[t] if c is not None else v for c, v in zip(cuts_a, args)),
+                {k: (cuts_k[k][t] if cuts_k[k] is not None else v) for k, v in kwargs.items()}) for t in range(g)]
+        keys = [self._key0(a_, k_) for a_, k_ in per]
+        wiring = self._wiring(keys[0])
+        if not wiring or not self._batchable(per[0][0], per[0][1]) or any(self._wiring(k_) is not wiring for k_ in keys[1:]):
+            return False, None
+        if all(j in self.ready for j in grp):
+            recs = [self.ready.pop(j) for j in grp]
+            if all(self._same_inputs(r, a_, k_) for r, (a_, k_) in zip(recs, per)):
+                outs = []
+                for i in range(self.n):
+                    firsts = recs[0]["outs"][i]
+                    flat0 = self._flat(firsts)
+                    flat = []
+                    for pos, o0 in enumerate(flat0):
+                        if isinstance(o0, torch.Tensor):
+                            flat.append(torch.cat([self._flat(r["outs"][i])[pos] for r in recs], dim=0) if g > 1 else o0)
+                        else:
+                            flat.append(o0)
+                    outs.append(tuple(flat) if isinstance(firsts, tuple) else flat if isinstance(firsts, list) else flat[0])
+                given, k, seen = {}, 0, set()
+                for v in list(args) + [kwargs[kk] for kk in sorted(kwargs)]:
+                    if isinstance(v, torch.Tensor) and id(v) not in seen:
+                        seen.add(id(v))
+                        given[("ext", k)] = (v, v._version)
+                        k += 1
+                self.live = {"outs": outs, "calls": wiring, "given": given, "clone": False}
+                return True, self._hand_out(0)
+            return False, None
+        ctx = TowerMemo.context()
+        for j, key_j, (a_, k_) in zip(grp, keys, per):
+            self.deferred.append({"j": j, "key": key_j, "args": a_, "kwargs": k_, "ctx": ctx})
+        raise _Defer
 
     # -- tracing the wiring WHILE the tower runs stacked ---------------------------------------------------------------------
     # The forward that traces a tower's wiring used to run the tower eagerly for its one sample (24 T5 blocks: 7-9 ms of host
@@ -1164,7 +1248,15 @@ class GraphedModule(nn.Module):
         return out
 
     def _tower_forward(self, *args, **kwargs):
-        if _CTX.capture_group is not None:                      # a merged calibration forward runs the tower as the model calls it
+        if _CTX.capture_group is not None:
+            # a merged calibration forward runs the tower as the model calls it -- unless the batches are ragged: then every group's
+            # forward is postponed at the tower's first block, the tower runs ONCE, padded, for the samples of all groups, and the
+            # repeated forwards are handed their groups' outputs (TowerGraph.enter_group)
+            tg = self.__dict__.get("_tower")
+            if tg is not None and _CTX.group_defer:
+                handled, value = tg[0].enter_group(tg[1], args, kwargs)
+                if handled:
+                    return value
             return self.__dict__["_wrapped"](*args, **kwargs)
         tg = self.__dict__.get("_tower")                        # (TowerGraph, index) or None
         if tg is None:
@@ -1495,25 +1587,35 @@ def _capture_merged(model, batches, module_to_process, forward_to_cache, lora_mo
             got.append((inp, args, dict(kwargs)))
             raise _Stop
 
-    def run(idxs):
+    def run(idxs, alone=False):
+        """-> the Catcher's call, None (the forward did not reach it), or "later" (postponed at a finished tower)"""
         got.clear()
         batch = mine[idxs[0]] if len(idxs) == 1 else _merge_batches([mine[j] for j in idxs])
-        _CTX.capture_group = list(idxs)
+        n_def = sum(len(t.deferred) for t in towers)
+        if alone:
+            _CTX.capture_sample = idxs[0]                       # the per-sample route: finished towers are traced (their wiring, their shapes)
+        else:
+            _CTX.capture_group = list(idxs)
         try:
             forward_to_cache(model, batch, lora_model)
-        except ValueError:                                     # _Stop, or the reference's bare ValueError
+        except ValueError:                                     # _Stop / _Defer, or the reference's bare ValueError
             pass
         finally:
-            _CTX.capture_group = None
-        return got[0] if len(got) == 1 else None
+            _CTX.capture_group = _CTX.capture_sample = None
+        if len(got) == 1:
+            return got[0]
+        return "later" if sum(len(t.deferred) for t in towers) > n_def else None
 
     def tensors_of(call):
         inp, args, kw = call
         return [("#inp", inp)] + [(f"#{i}", a) for i, a in enumerate(args)] + sorted(kw.items())
 
     layers[0] = MergedCatcher(layers[0])
-    undo = _wrap_towers(model, [t for t in (done_towers or []) if t != module_to_process], proxy_cache, record=False)
+    undo = _wrap_towers(model, [t for t in (done_towers or []) if t != module_to_process], proxy_cache, record=not final)
     arrived, calls = [], []
+    # how the model calls block 0 of THIS tower, by sample: should the next phase take the per-sample route, its stacked pass
+    # through this tower starts from these (TowerGraph.run_predicted)
+    first = {} if (proxy_cache is not None and not final and tower_graph_enabled() and tower_predict_enabled()) else None
     try:
         towers = []
         for blocks_, i_, _orig in undo:
@@ -1522,36 +1624,56 @@ def _capture_merged(model, batches, module_to_process, forward_to_cache, lora_mo
                 towers.append(tg_[0])
         order.sort(key=lambda s_: -len(groups[s_]))             # the largest group first: its first sample is the one forwarded alone
         scout = groups[order[0]][0]
-        if len(groups[order[0]]) < 2 or len(order) > 2:
-            # nothing to merge -- or ragged batches: a merged forward per token count would run the finished towers once per count,
-            # where the per-sample route pads them into one stacked pass (TowerGraph._run_padded; measured: 532 against 500 ms)
+        if len(groups[order[0]]) < 2:
+            return None                                          # nothing to merge
+        # ragged batches (more than two shapes): a merged forward per token count would run every finished tower once per count
+        # (measured: 532 against 500 ms for the per-sample route, which pads them into one stacked pass).  Instead every group's
+        # forward is postponed at a finished tower's first block, the tower runs ONCE, padded, for the samples of all groups
+        # (TowerGraph.enter_group -> run_deferred -> _run_padded) and the groups' forwards are repeated.
+        defer = len(order) > 2
+        if defer and not (os.environ.get("VLMC_CAPTURE_MERGED_RAGGED", "0") == "1" and tower_pad_enabled() and tower_graph_enabled()):
+            # (off by default: with it the encoder's phase of the ragged reference-op prune is 55-59 ms instead of 100 in the
+            # synchronising phase timers, but the whole prune is level -- 486 / 494 against 477 ms, tools/ragged_time.py -- because
+            # the per-sample Python it removes ran behind the GPU tail of the preceding walk anyway)
+            return None
+        if defer and any(not t.memo_serves and t.path not in FROZEN_TOWERS for t in towers):
+            # ragged batches and a PRUNED tower on the way whose outputs are not remembered (the decoder's phase: 24 encoder blocks):
+            # handing the groups their blocks' outputs means cutting the padded pass per sample and stacking per group again, per
+            # block and output -- measured 145-173 ms for that phase against 87 on the per-sample route.  A frozen tower alone (the
+            # encoder's phase: the Q-Former's 12 single-output layers) is the case that pays: 55-59 against 100 ms.
             return None
         flags = []                                               # device-side verdicts, read once at the end (no wait per forward)
         with torch.no_grad(), forward.invariant_linears(all_linears(model, proxy_cache), roots=[b for t in towers for b in t.mods]):
-            one = run([scout])                                  # one sample alone: the shapes of a batch-1 call, and the bits to hold the merge to
-            if one is None or not isinstance(one[0], torch.Tensor) or one[0].dim() < 2:
+            one = run([scout], alone=defer)                     # one sample alone: the shapes of a batch-1 call, and the bits to hold the merge to
+            for _ in range(len(towers) + 1):                     # (a tower whose wiring an earlier phase traced postpones this forward too)
+                if one != "later":
+                    break
+                for t in towers:
+                    if t.deferred:
+                        t.run_deferred()
+                one = run([scout], alone=True)
+            if one is None or one == "later" or not isinstance(one[0], torch.Tensor) or one[0].dim() < 2:
                 return None
             names1 = tensors_of(one)
-            batched = None                                       # name -> does the tensor carry the batch dimension (learned on the first merged call)
-            for s_ in order:
-                idxs = groups[s_]
-                first_rows = None
-                c0 = 0
-                while c0 < len(idxs):
-                    if first_rows is None:
-                        per = min(replay_group_size(), len(idxs))
-                    chunk = idxs[c0:c0 + per]
+            batched = None                                       # name -> the per-sample batch extent of a tensor that carries the batch dimension, else 0
+            rows = max(1, one[0].numel() // max(1, one[0].shape[-1]))
+            per = max(2, min(replay_group_size(), REPLAY_TOKEN_BUDGET // rows))
+            pending = [groups[s_][c0:c0 + per] for s_ in order for c0 in range(0, len(groups[s_]), per)]
+            _CTX.group_defer = defer
+            sweeps = 0
+            while pending:
+                sweeps += 1
+                if sweeps > len(towers) + 2:
+                    return None
+                again = []
+                for chunk in pending:
                     call = run(chunk)
+                    if call == "later":
+                        again.append(chunk)
+                        continue
                     if call is None or not isinstance(call[0], torch.Tensor):
                         return None
                     g = len(chunk)
-                    if first_rows is None:                      # the token budget of a stacked forward (the same as the replay's)
-                        first_rows = max(1, call[0].numel() // max(1, call[0].shape[-1])) // g
-                        fit = max(1, REPLAY_TOKEN_BUDGET // max(1, first_rows))
-                        if g > fit and g > 1:
-                            per = fit
-                            continue                              # (rerun this chunk smaller; rare: only very long samples)
-                    c0 += g
                     names = tensors_of(call)
                     if len(names) != len(names1) or [n for n, _ in names] != [n for n, _ in names1]:
                         return None
@@ -1599,6 +1721,9 @@ def _capture_merged(model, batches, module_to_process, forward_to_cache, lora_mo
                         kw_j = {k: pick(k, v) for k, v in kw.items()}
                         if want_calls:
                             calls.append((j, TowerMemo._snapshot((inp_j,) + args_j, kw_j)))
+                        if first is not None:
+                            a_, k_ = (inp_j,) + args_j, dict(kw_j)
+                            first[j] = (a_, k_, TowerMemo.context(), [(t_, t_._version) for t_ in TowerGraph._ext(a_, k_)])
                         if vit:
                             rel_pos_bias = args_j[0] if args_j else kw_j.get("rel_pos_bias")
                             dense = args_j[1] if len(args_j) > 1 else kw_j.get("dense", True)
@@ -1610,15 +1735,23 @@ def _capture_merged(model, batches, module_to_process, forward_to_cache, lora_mo
                             cache["dense"] = dense
                         arrived.append((j, inp_j, cache))
                     graph_stats["merged_forwards"] = graph_stats.get("merged_forwards", 0) + 1
+                for t in towers:
+                    if t.deferred:
+                        t.run_deferred()
+                pending = again
         if flags and not bool(torch.stack(flags).all()):
             graph_stats["merged_capture_mismatch"] = graph_stats.get("merged_capture_mismatch", 0) + 1
             return None
     except KeyError:
         return None                                             # (a kwarg the reference's key list names is missing: its path)
     finally:
-        _CTX.capture_group = None
+        _CTX.capture_group = _CTX.capture_sample = None
+        _CTX.group_defer = False
         layers[0] = layers[0].module
         for blocks, i, orig in undo:
+            tg = blocks[i].__dict__.get("_tower")
+            if tg is not None:
+                tg[0].deferred, tg[0].ready, tg[0].live, tg[0].trace, tg[0].btrace = [], {}, None, None, None
             blocks[i].__dict__["_memo"] = None
             blocks[i].__dict__["_tower"] = None
             blocks[i] = orig
@@ -1628,8 +1761,8 @@ def _capture_merged(model, batches, module_to_process, forward_to_cache, lora_mo
     if want_calls:
         calls.sort(key=lambda c: c[0])
         proxy_cache[("calls", module_to_process)] = [c[1] for c in calls]
-    if proxy_cache is not None:
-        proxy_cache.pop(("block0", module_to_process), None)       # (nothing was remembered for the per-sample route's predicted passes)
+    if first is not None:
+        proxy_cache[("block0", module_to_process)] = first
     for a in arrived:
         if isinstance(a[1], torch.Tensor):
             a[1].requires_grad = False
