@@ -42,6 +42,10 @@ class _Fused:
 
 @pytest.fixture
 def fake_kernels(monkeypatch):
+    # (one thread: the stand-ins are compared bit for bit with a second evaluation of the same CPU products, and a threaded fp32 matmul
+    # on a loaded host has been seen to split its reduction differently from one call to the next)
+    n_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
     fused = _Fused()
     monkeypatch.setattr(ops, "attn_matmul", lambda a, b, _plan=None, _try=False: _mm(a, b))
     monkeypatch.setattr(ops, "attn_fused_plan", functools.partial(ops.attn_fused_plan, _cuda_only=False))
@@ -51,7 +55,8 @@ def fake_kernels(monkeypatch):
     monkeypatch.setattr(ops, "_attn_max_keys", {8: 512, 16: 512})
     monkeypatch.setattr(forward, "_FUSED_OK", {})
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
-    return fused
+    yield fused
+    torch.set_num_threads(n_threads)
 
 
 def _qkv(B=2, H=3, Tq=5, Tk=7, d=8, dtype=torch.bfloat16, seed=0):
