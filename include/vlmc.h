@@ -289,7 +289,7 @@ int vlmc_attn_matmul(const void *A, const void *B, void *C, int dtype, int64_t b
  * product (as the unfused form does), fp32 accumulation, one rounding of O.  Q, K, V, O are read / written in place through
  * their ELEMENT strides (batch, head, token; the head_dim stride is 1): `qkv.reshape(B, T, 3, H, d).unbind(2)` views and
  * `[B, T, H, d]` outputs need no copy.  head_dim: a multiple of 8, at most 128; keys per head: at most
- * vlmc_sdpa_max_keys(head_dim) (256; 288 for 65 <= head_dim <= 96) -- a head's K and V live in LDS for the whole head;
+ * vlmc_sdpa_max_keys(head_dim) (288; 256 for head_dim > 96) -- a head's K and V live in LDS for the whole head;
  * scale: finite and positive; causal = 1: key j counts for query i iff j <= i (torch's is_causal: aligned to the top left), the
  * self-attention of decoder-only towers (modeling_llama.py).
  * Batch-invariant like vlmc_linear_fwd: an output row depends on its own query row and its head's K and V only, through a

@@ -30,7 +30,9 @@ SHAPES = [(3, 16, 257, 257, 88, torch.float16), (2, 32, 64, 64, 64, torch.bfloat
           (1, 5, 16, 16, 64, torch.bfloat16),            # 5 heads, 4 per workgroup: the last workgroup has empty slots
           (1, 3, 40, 64, 64, torch.float16),             # 3 heads, 2 per workgroup
           (1, 2, 900, 100, 64, torch.bfloat16),          # many queries: a head's blocks on three workgroups
-          (2, 2, 33, 129, 32, torch.float16)]            # head_dim 32 in the 64-wide instantiation, 129 keys
+          (2, 2, 33, 129, 32, torch.float16),            # head_dim 32 in the 64-wide instantiation, 129 keys
+          (2, 12, 48, 257, 64, torch.float16),           # the Q-Former's cross-attention to the ViT's 257 tokens (head_dim 64: 288 keys fit since round 5)
+          (1, 2, 20, 288, 64, torch.bfloat16)]
 
 
 @pytest.mark.parametrize("B,H,Tq,Tk,d,dtype", SHAPES)

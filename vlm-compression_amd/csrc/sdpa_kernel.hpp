@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void sdpa_fwd_kernel(const SdpaArgs a) {
 // keys a head may have for a given head_dim (the accumulators of S^T live in registers, K and V in LDS)
 static int sdpa_max_keys(int d) {
     const int ds = (d + 31) / 32;
-    return ds == 3 ? 288 : 256;
+    return ds == 4 ? 256 : 288;          // (head_dim <= 96: 288 keys -- the ViT's 257 tokens, and the Q-Former's cross-attention to them at head_dim 64)
 }
 
 template <typename T, int DS, int MAXKT, bool FULL, bool CAUSAL> static int sdpa_launch2(const SdpaArgs &a, int64_t bh, size_t lds, hipStream_t s) {
@@ -332,7 +332,7 @@ template <typename T, int DS, int MAXKT> static int sdpa_launch1(const SdpaArgs 
 }
 
 template <typename T, int DS> static int sdpa_launch(const SdpaArgs &a, int64_t bh, hipStream_t s) {
-    constexpr int RS = 32 * DS * 2 + 16, BIG = DS == 3 ? 18 : 16;
+    constexpr int RS = 32 * DS * 2 + 16, BIG = DS == 4 ? 16 : 18;
     const int KT = ((a.Tk + 31) >> 5) << 1;
     const size_t lds = size_t(a.hpw) * 2 * ((size_t(KT) * 16 * RS + 1023) & ~size_t(1023));
     if (KT <= 4) return sdpa_launch1<T, DS, 4>(a, bh, lds, KT, s);
