@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLMC_ABI_VERSION 16
+#define VLMC_ABI_VERSION 17
 
 #define VLMC_OK 0
 #define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
@@ -308,6 +308,14 @@ int vlmc_sdpa_fwd(const void *Q, const void *K, const void *V, void *O, int dtyp
  *     out[r] = (sum over c of x[r * ldx + c]) / n        one wave per row, a fixed order that depends on n only
  * x [rows, n] fp32 (row stride ldx elements), out [rows] fp32.                                                 */
 int vlmc_row_mean(const float *x, int64_t rows, int64_t n, int64_t ldx, float *out, void *stream);
+
+/* GELU of a replayed block's feed-forward (`self.act(self.fc1(x))`, eva_vit.py:62-64; T5 v1.1's gated GELU, modeling_t5.py:337-346)
+ * with one instruction sequence for EVERY element.  torch's elementwise kernels compute a tensor's last partial block with other
+ * code than its body (hipcc contracts x/2 * (1 + erf) into an fma there: ~20 % of all 16-bit inputs differ in the last bit), so which
+ * rows of a batch get which bits depends on how many samples share the forward.  This kernel uses the body's arithmetic everywhere:
+ * equal to torch's body for all 65 536 fp16 / bf16 inputs, batch-invariant.  tanh_approx: 0 = erf form, 1 = `approximate="tanh"`.
+ * x, y: n contiguous 16-bit elements (y may be x).                                                                            */
+int vlmc_gelu(const void *x, void *y, int64_t n, int dtype, int tanh_approx, void *stream);
 
 /* Row-wise softmax over the last dimension, PADDING-invariant: `F.softmax(scores.float(), dim=-1)` (modeling_t5.py:604-606),
  * `attn.softmax(dim=-1)` on 16-bit scores (eva_vit.py:158), `nn.Softmax(dim=-1)(scores)` (Qformer.py:228) during a replay.

@@ -37,7 +37,7 @@ _active = 0
 stats = {"kernel": 0, "library": 0, "grouped_launches": 0, "served_from_group": 0, "stash_dropped": 0, "attn_kernel": 0,
          "attn_library": 0, "mean_kernel": 0, "sdpa_kernel": 0, "sdpa_library": 0, "norm_kernel": 0, "softmax_kernel": 0,
          "attn_fused": 0, "attn_chain_unfused": 0, "attn_fused_checks": 0, "linear_post": 0, "linear_lazy_unfused": 0,
-         "linear_post_checks": 0}
+         "linear_post_checks": 0, "gelu_kernel": 0}
 
 # first member of a learned sibling group -> tuple of weak references to all members, in call order
 _SIBLINGS = weakref.WeakKeyDictionary()
@@ -789,6 +789,26 @@ def softmax_enabled():
     return os.environ.get("VLMC_SOFTMAX", "1") != "0"
 
 
+def _make_gelu(orig):
+    """`F.gelu(x[, approximate=...])` of a 16-bit CUDA tensor on `vlmc_gelu`: torch's elementwise kernel computes a tensor's last
+    partial block with other instructions than its body (an fma contraction: ~20 % of all 16-bit inputs differ in the last bit), so
+    which bits a sample's last rows get depends on how many samples share the forward -- the one elementwise op of the blocks that is
+    not batch-invariant in torch.  The kernel uses the body's arithmetic for every element (`VLMC_GELU=0`: torch's)."""
+    Tensor = torch.Tensor
+
+    def gelu(x, *args, **kw):
+        if _ident() == _mm_owner:
+            if type(x) is LazyLinear:
+                r = _ll_gelu(orig, (x,) + args, kw)
+                return r if r is not NotImplemented else gelu(x._realize(), *args, **kw)
+            if type(x) is Tensor and x.is_cuda and x.dtype in ops._16BIT and not torch.is_grad_enabled() and not args and \
+                    not (set(kw) - {"approximate"}) and kw.get("approximate", "none") in ("none", "tanh") and x.numel() > 0:
+                stats["gelu_kernel"] += 1
+                return ops.gelu(x, kw.get("approximate", "none"))
+        return orig(x, *args, **kw)
+    return gelu
+
+
 @contextlib.contextmanager
 def invariant_matmuls():
     """Batched 16-bit `matmul`s run on `vlmc_attn_matmul`, fp32 means over the last dimension on `vlmc_row_mean`, for the
@@ -819,6 +839,10 @@ def invariant_matmuls():
             if "softmax" not in torch.Tensor.__dict__:
                 setattr(torch.Tensor, "softmax", _make_softmax(base.softmax, False))
                 _mm_saved.setdefault("tensor", []).append("softmax")
+        if os.environ.get("VLMC_GELU", "1") != "0":               # torch's GELU: another instruction sequence in a tensor's last block
+            import torch.nn.functional as F_
+            _mm_saved["gelu"] = F_.gelu
+            F_.gelu = _make_gelu(F_.gelu)
         if os.environ.get("VLMC_ROW_MEAN", "1") != "0":           # the fp32 mean inside the norms (batch-variant in torch)
             _mm_saved["mean"] = torch.mean
             torch.mean = _make_mean(torch.mean)
@@ -836,6 +860,9 @@ def invariant_matmuls():
             torch.matmul, torch.bmm = _mm_saved.pop("matmul"), _mm_saved.pop("bmm")
             if "mean" in _mm_saved:
                 torch.mean = _mm_saved.pop("mean")
+            if "gelu" in _mm_saved:
+                import torch.nn.functional as F_
+                F_.gelu = _mm_saved.pop("gelu")
             if "softmax" in _mm_saved:
                 import torch.nn.functional as F_
                 F_.softmax, torch.softmax = _mm_saved.pop("softmax")

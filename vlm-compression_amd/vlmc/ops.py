@@ -389,6 +389,18 @@ def row_mean(x: torch.Tensor, keepdim: bool = False) -> torch.Tensor:
     return out
 
 
+def gelu(x: torch.Tensor, approximate: str = "none") -> torch.Tensor:
+    """`F.gelu(x, approximate=...)` for 16-bit CUDA tensors with one instruction sequence for every element (include/vlmc.h:
+    vlmc_gelu): torch's body arithmetic also where torch itself switches to another (its kernels' last partial block)."""
+    _need_gpu(x)
+    if x.dtype not in _16BIT or approximate not in ("none", "tanh"):
+        raise TypeError("vlmc.gelu: an fp16 / bf16 tensor and approximate 'none' or 'tanh' expected")
+    xc = x if x.is_contiguous() else x.contiguous()
+    y = torch.empty_like(xc)
+    _lib.check(_lib.load().vlmc_gelu(xc.data_ptr(), y.data_ptr(), xc.numel(), _DT[x.dtype], 1 if approximate == "tanh" else 0, _stream()))
+    return y
+
+
 def softmax_rows(x: torch.Tensor, out_dtype=None) -> torch.Tensor:
     """`torch.softmax(x, -1[, dtype=out_dtype])` on the padding-invariant kernel (include/vlmc.h: vlmc_softmax_rows): fp32 -> fp32,
     fp16 / bf16 -> the same dtype (fp32 arithmetic, one rounding) or fp32."""
