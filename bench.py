@@ -508,6 +508,16 @@ def reference_ops_leg(dev, steps):
     return out
 
 
+def capture_info():
+    """How the capture phases of the prunes so far forwarded the calibration batches (calibration.graph_stats, whole process)."""
+    from lavis.compression.pruners import calibration as cal
+    g = cal.graph_stats
+    return {"what": "model forwards that carried ALL calibration batches of one shape stacked (merged_forwards; each checked against one "
+                    "sample's own forward bit for bit) / capture phases that took the per-sample route instead (declined)",
+            "merged_forwards": g.get("merged_forwards", 0), "declined": g.get("merged_capture_declined", 0),
+            "mismatches": g.get("merged_capture_mismatch", 0)}
+
+
 def load_traffic():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
@@ -740,12 +750,14 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f16/bf16", "data": "synthetic",
             "config": {"workload": "configs[1]: one whole load_pruner('blipt5_wanda_pruner').prune() -- Wanda 50% unstructured, "
                                    "InstructBLIP-FlanT5-XL architecture and shapes (39 ViT-g blocks fp16 matrix-wide rule + 24/24 "
-                                   "Flan-T5-XL blocks bf16 per-row rule; Q-Former, never pruned, replaced by its 32 query tokens), "
+                                   "Flan-T5-XL blocks bf16 per-row rule; between them the 12-layer Q-Former, never pruned: 32 queries + the instruction "
+                                   "tokens, cross-attention to the image every second layer, blip2_t5_instruct.py:136-221), "
                                    "random init, 128 batch-1 calibration samples (257 image tokens, 32+32 text, 16 output tokens)",
                        "linears": n_lin, "blocks": 87, "calib_samples": N_CALIB, "ratio": RATIO,
                        "total_prune_wall_clock_s": round(sec, 4), "blocks_per_s": round(87 / sec, 1),
                        "pruned_fraction": round(pruned_fraction, 6), "subtotals_s": sub,
                        "replay": f"grouped: up to {os.environ.get('VLMC_BATCH_REPLAY', '128')} equal-shape samples per block forward",
+                       "capture": capture_info(),
                        "parallelism": f"calib-dp{world}", "backend": backend, "per_rank_floor": floor,
                        "reference_ops": ref_ops,
                        "world_size": dist.get_world_size() if world > 1 else 1},
