@@ -515,7 +515,7 @@ def capture_info():
     return {"what": "model forwards that carried ALL calibration batches of one shape stacked (merged_forwards; each checked against one "
                     "sample's own forward bit for bit) / capture phases that took the per-sample route instead (declined)",
             "merged_forwards": g.get("merged_forwards", 0), "declined": g.get("merged_capture_declined", 0),
-            "mismatches": g.get("merged_capture_mismatch", 0)}
+            "mismatches": g.get("merged_capture_mismatch", 0), "errors": g.get("merged_capture_errors", 0)}
 
 
 def load_traffic():

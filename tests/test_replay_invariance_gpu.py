@@ -256,3 +256,36 @@ def test_merged_capture_forwards_give_the_per_sample_routes_bits(n_shapes, monke
             assert torch.equal(merged[k][0], other[k][0]), (k, name)
             assert (merged[k][1] is None and other[k][1] is None) or torch.equal(merged[k][1], other[k][1]), (k, name)
             assert merged[k][2] == other[k][2], (k, name)
+
+
+def test_a_model_that_cannot_take_the_merged_batch_is_forwarded_per_sample(monkeypatch):
+    """A forward that assumes batch 1 somewhere (here: it raises on the stacked batch) sends the capture phase down the per-sample
+    route -- the prune's result is the per-sample route's, the refusal is counted."""
+    from vlmc import synthetic
+    from lavis.compression.pruners import calibration
+    dev = torch.device(DEV)
+    monkeypatch.setattr(calibration, "MERGED_CAPTURE_MIN", 2)
+
+    def run(picky):
+        torch.manual_seed(0)
+        model = synthetic.InstructBlipT5(vit_dim=64, vit_hidden=128, vit_heads=4, vit_depth=2, d_model=64, d_ff=128, heads=4, d_kv=16,
+                                         enc_depth=2, dec_depth=2, vocab=100, query_tokens=4, qformer_dim=64, qformer_heads=4,
+                                         qformer_hidden=128, qformer_depth=2, qformer_vocab=50).to(dev).eval()
+        if picky:
+            plain = model.forward
+
+            def forward(samples, *a, **k):
+                if samples["image"].shape[0] != 1:
+                    raise RuntimeError("this model forwards one sample at a time")
+                return plain(samples, *a, **k)
+            model.forward = forward
+        batches = synthetic.calibration_batches(8, dev, vit_tokens=9, vit_dim=64, vocab=100)
+        e0 = calibration.graph_stats.get("merged_capture_errors", 0)
+        synthetic.time_prune(dev, n_samples=8, model=model, batches=batches)
+        return {n: m.weight.detach().clone() for n, m in model.named_modules() if isinstance(m, torch.nn.Linear)}, \
+            calibration.graph_stats.get("merged_capture_errors", 0) - e0
+    a, errs = run(True)
+    b, errs0 = run(False)
+    assert errs == 3 and errs0 == 0 and a.keys() == b.keys()          # one refusal per capture phase
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

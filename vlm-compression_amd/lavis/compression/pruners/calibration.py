@@ -1448,7 +1448,15 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
     if merged_capture_enabled() and p0 is not None and p0.is_cuda and _CTX.later is None:
         _CTX.later = _LaterEqual()                              # (remembered tower inputs against what the merged forward feeds them)
         try:
-            res = _capture_merged(*args, **kw)
+            try:
+                res = _capture_merged(*args, **kw)
+            except (RuntimeError, TypeError, IndexError, AssertionError, AttributeError) as e:
+                # a model whose forward does not take the stacked batch (it assumes batch 1 somewhere): its own way, per sample --
+                # if the trouble is not the merge (out of memory, a broken model) the per-sample route meets it again and raises
+                res = None
+                graph_stats["merged_capture_errors"] = graph_stats.get("merged_capture_errors", 0) + 1
+                if os.environ.get("VLMC_VERBOSE") == "1":
+                    print(f"merged capture declined ({type(e).__name__}: {e})")
             bad = res is not None and _CTX.later.failed()
         finally:
             _CTX.later = None
