@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLMC_ABI_VERSION 17
+#define VLMC_ABI_VERSION 18
 
 #define VLMC_OK 0
 #define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
@@ -461,6 +461,14 @@ int vlmc_dsnot_refine(const void *W, int dtype, int64_t out_features, int64_t in
                       int without_same_sign, uint32_t *events, int32_t *stop_cycle, void *stream);
 int vlmc_dsnot_apply(void *W, int dtype, int64_t out_features, int64_t in_features, int64_t ldw, uint8_t *keep_mask,
                      const uint32_t *events, const int32_t *ncycles, int max_cycle, int nm_mode, int apply_zero, void *stream);
+
+/* vlmc_reorder_indices: `return_reorder_indice(input_tensor)` (dsnot_pruner.py:1881-1925), the module-level helper the
+ *   unstructured branch orders its prune list with (:623-631).  Per row of x [rows, cols] (row stride ldx; VLMC_F32 / F16 / BF16):
+ *   out[row, :] (int64, row stride ldo) = the column indices of the negative entries in ascending order at the head, the indices
+ *   of the positive entries in DESCENDING order at the tail, and 0 in every position between them (one per entry that is
+ *   neither: zeros, NaN) -- what the reference's two sorts of +inf-padded index matrices, the flip and the sum produce. */
+int vlmc_reorder_indices(const void *x, int dtype, int64_t rows, int64_t cols, int64_t ldx, int64_t *out, int64_t ldo,
+                         void *stream);
 
 /* ---- K17: one threshold over many score tensors (the global pruners) -----------------------
  * Replaces `get_mask` / `get_layerwise_mask` and the weight update of global_pruner.py:107-148,

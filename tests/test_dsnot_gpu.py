@@ -217,3 +217,45 @@ def test_moments_of_stacked_calls_equal_the_per_call_launches(dtype):
     for k in ("scaler_row", "sum_row", "var_row", "sqrt_row"):
         assert torch.equal(getattr(a, k), getattr(b, k)), k
     assert a.nsamples == b.nsamples == 12 and a.ntokens == b.ntokens
+
+
+# ---- return_reorder_indice as a callable of the drop-in module (dsnot_pruner.py:1881-1925) ------------------------------------------
+_FG = golden_io.load("formats")
+_REORDER = sorted({k.split("/")[1] for k in _FG if k.startswith("reorder/")})
+
+
+@pytest.mark.parametrize("name", _REORDER)
+def test_return_reorder_indice_on_gpu_matches_reference_fixture(name):
+    """The HIP ordering (vlmc_reorder_indices) through the drop-in module's own symbol, against the reference's recorded answers."""
+    from lavis.compression.pruners.dsnot_pruner import return_reorder_indice
+    x, want = _FG[f"reorder/{name}/in"], _FG[f"reorder/{name}/out"]
+    got = return_reorder_indice(x.to(DEV))
+    assert got.dtype == torch.int64 and got.device.type == "cuda"
+    assert torch.equal(got.cpu(), want), name
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(1, 1), (3, 255), (5, 256), (7, 257), (4, 5120), (2, 11008), (300, 70)])
+def test_return_reorder_indice_on_gpu_matches_oracle(shape, dtype):
+    """Widths around the 256-column chunk, model widths, zeros / NaN / -0.0 among the entries; strided input."""
+    from lavis.compression.pruners.dsnot_pruner import return_reorder_indice
+    g = torch.Generator().manual_seed(shape[0] * 131 + shape[1])
+    x = torch.randn(shape, generator=g)
+    x[torch.rand(shape, generator=g) < 0.2] = 0.0
+    x[torch.rand(shape, generator=g) < 0.02] = float("nan")
+    x[torch.rand(shape, generator=g) < 0.02] = -0.0
+    x = x.to(dtype)
+    assert torch.equal(return_reorder_indice(x.to(DEV)).cpu(), OD.reorder_indices(x.float()))
+    wide = torch.cat([x, x], dim=1).to(DEV)                                  # a row-strided view of a wider tensor
+    assert torch.equal(return_reorder_indice(wide[:, :shape[1]]).cpu(), OD.reorder_indices(x.float()))
+    if shape[1] > 1:                                                          # all negative / all positive rows
+        assert torch.equal(return_reorder_indice(-x.abs().nan_to_num(1.0).clamp_min(1e-3).to(DEV)).cpu(),
+                           torch.arange(shape[1]).repeat(shape[0], 1))
+        assert torch.equal(return_reorder_indice(x.abs().nan_to_num(1.0).clamp_min(1e-3).to(DEV)).cpu(),
+                           torch.arange(shape[1] - 1, -1, -1).repeat(shape[0], 1))
+
+
+def test_return_reorder_indice_refuses_cpu_tensors():
+    from lavis.compression.pruners.dsnot_pruner import return_reorder_indice
+    with pytest.raises(RuntimeError, match="GPU only"):
+        return_reorder_indice(torch.randn(2, 3))

@@ -2,6 +2,7 @@
 rewrites (evaluate_new.py:226-276), on the toy InstructBLIP pruned through the drop-in Wanda pruner."""
 import os
 
+import pytest
 import torch
 import yaml
 
@@ -156,3 +157,80 @@ def test_return_reorder_indice_fixture():
     for n in names:
         assert torch.equal(OD.reorder_indices(G[f"reorder/{n}/in"]), G[f"reorder/{n}/out"]), n
     assert G["reorder/docstring/out"].tolist() == [[1, 2, 0], [0, 2, 1], [2, 1, 0], [0, 1, 2]]
+
+
+# ---- PEFT surface: LoraModel.enable / disable_adapter_layers, get_peft_config_as_dict (lora.py:221-236), default targets ----------------
+def test_lora_model_adapter_switches_and_config_dict():
+    """`PeftModel.disable_adapter()` (peft_model.py:312-316) goes through LoraModel.disable_adapter_layers / enable_adapter_layers;
+    with the adapters disabled a SparseLoRA layer is the plain linear on W (lora.py:361-362), on CPU as well."""
+    from lavis.peft.src.peft.tuners.lora import LoraLayer
+    model = _wrapped_toy()
+    t5 = model.t5_model
+    layers = [m for m in t5.modules() if isinstance(m, LoraLayer)]
+    assert layers and all(not m.disable_adapters for m in layers)
+    x = torch.randn(2, 3, layers[0].in_features)
+    with t5.disable_adapter():
+        assert all(m.disable_adapters for m in layers)
+        assert torch.equal(layers[0](x), torch.nn.functional.linear(x, layers[0].weight, layers[0].bias))
+    assert all(not m.disable_adapters for m in layers)
+    t5.base_model.disable_adapter_layers()
+    assert all(m.disable_adapters for m in layers)
+    t5.base_model.enable_adapter_layers()
+    cfg = t5.base_model.get_peft_config_as_dict()
+    assert cfg["peft_type"] == "LORA" and cfg["task_type"] == "CAUSAL_LM" and cfg["r"] == 4 and cfg["lora_alpha"] == 16
+    assert cfg["inference_mode"] is False and t5.base_model.get_peft_config_as_dict(inference=True)["inference_mode"] is True
+    assert t5.base_model.modules_to_save is None
+
+
+def test_get_peft_model_default_targets_follow_the_model_type():
+    """mapping.py:152-158: `target_modules=None` takes the model type's default linears; an unknown type raises as the reference does."""
+    import types
+
+    from lavis.peft.src.peft import LoraConfig, get_peft_model
+    from lavis.peft.src.peft.tuners.lora import Linear
+
+    class Attn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj, self.k_proj, self.v_proj = torch.nn.Linear(8, 8), torch.nn.Linear(8, 8), torch.nn.Linear(8, 8)
+
+    class Net(torch.nn.Module):
+        def __init__(self, model_type):
+            super().__init__()
+            self.config = types.SimpleNamespace(model_type=model_type)
+            self.attn = Attn()
+
+    wrapped = get_peft_model(Net("llama"), LoraConfig(r=2, lora_alpha=4, target_modules=None, task_type="CAUSAL_LM"))
+    attn = wrapped.base_model.model.attn
+    assert type(attn.q_proj) is Linear and type(attn.v_proj) is Linear and type(attn.k_proj) is torch.nn.Linear
+    with pytest.raises(ValueError, match="target_modules"):
+        get_peft_model(Net("no-such-model"), LoraConfig(r=2, lora_alpha=4, target_modules=None, task_type="CAUSAL_LM"))
+
+
+def test_qformer_wrapper_takes_positional_input_ids_and_hands_on_the_reference_defaults():
+    from lavis.peft.src.peft import LoraConfig, get_peft_model
+    seen = {}
+
+    class QF(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.query = torch.nn.Linear(4, 4)
+
+        def forward(self, **kw):
+            seen.update(kw)
+            return 7
+
+    w = get_peft_model(QF(), LoraConfig(r=2, lora_alpha=4, target_modules=[".query", "query"], task_type="Qformer"))
+    assert w(torch.zeros(1, 2, dtype=torch.long), query_embeds="q") == 7
+    assert seen["input_ids"].shape == (1, 2) and seen["query_embeds"] == "q"
+    assert seen["use_cache"] is True and seen["is_decoder"] is True and seen["reduction"] == "mean" and seen["return_logits"] is False
+
+
+def test_pack_state_dict_24_takes_a_non_contiguous_mask():
+    """ `m.view` raised on a transposed mask before the `.contiguous()` fallback; CPU: such a pair simply stays unpacked."""
+    from vlmc import formats
+    w = torch.randn(8, 16).half()
+    m = (torch.arange(16 * 8).reshape(16, 8) % 4 < 2).t()                 # [8, 16], stride (1, 8)
+    assert not m.is_contiguous()
+    out = formats.pack_state_dict_24({"l.weight": w, "l.mask": m})
+    assert set(out) == {"l.weight", "l.mask"}

@@ -644,3 +644,60 @@ extern "C" int vlmc_dsnot_apply(void *W, int dtype, int64_t out_features, int64_
     VLMC_HIP_CHECK_LAUNCH("vlmc_dsnot_apply");
     return VLMC_OK;
 }
+
+// ---- vlmc_reorder_indices: dsnot_pruner.py:1881-1925 `return_reorder_indice` as a callable of its own ---------------------------
+// Per row of `x`: the column indices of the NEGATIVE entries, ascending, at the head; the indices of the POSITIVE entries,
+// descending, at the tail; every position in between -- one per entry that is neither (zeros, NaN) -- holds 0.  (The reference
+// forms it from two fp64 index matrices with +inf sentinels, two full sorts, a flip and a sum; the list kernel above applies the
+// same rule to its kept list in LDS.)  One workgroup per row, one pass over the row: per 256-column chunk a wave ballot ranks the
+// negatives and the positives, running counts carry over the chunks; the middle is zero-filled at the end.
+namespace vlmc {
+template <typename T>
+__global__ __launch_bounds__(256) void reorder_indices_kernel(const typename T::raw *__restrict__ x, int64_t cols, int64_t ldx,
+                                                              int64_t *__restrict__ out, int64_t ldo) {
+    __shared__ uint32_t wneg[4], wpos[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const typename T::raw *p = x + int64_t(blockIdx.x) * ldx;
+    int64_t *q = out + int64_t(blockIdx.x) * ldo;
+    int64_t nneg = 0, npos = 0;                                              // entries of either sign in the chunks before this one
+    for (int64_t c0 = 0; c0 < cols; c0 += 256) {
+        const int64_t c = c0 + threadIdx.x;
+        const float v = c < cols ? to_f32<T>(p[c]) : 0.f;
+        const bool neg = v < 0.f, pos = v > 0.f;
+        const uint64_t bn = __ballot(neg), bp = __ballot(pos);
+        if (lane == 0) wneg[wave] = uint32_t(__popcll(bn)), wpos[wave] = uint32_t(__popcll(bp));
+        __syncthreads();
+        uint32_t on = 0, op = 0, tn = 0, tp = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) on += wneg[w], op += wpos[w];
+            tn += wneg[w], tp += wpos[w];
+        }
+        const uint64_t below = lane == 0 ? 0 : (~uint64_t(0) >> (64 - lane));
+        if (neg) q[nneg + on + __popcll(bn & below)] = c;
+        if (pos) q[cols - 1 - (npos + op + __popcll(bp & below))] = c;
+        nneg += tn, npos += tp;
+        __syncthreads();
+    }
+    for (int64_t c = nneg + threadIdx.x; c < cols - npos; c += 256) q[c] = 0;
+}
+}  // namespace vlmc
+
+extern "C" int vlmc_reorder_indices(const void *x, int dtype, int64_t rows, int64_t cols, int64_t ldx, int64_t *out, int64_t ldo,
+                                    void *stream) {
+    VLMC_REQUIRE(x && out, "vlmc_reorder_indices: null pointer");
+    VLMC_REQUIRE(rows >= 0 && cols > 0 && ldx >= cols && ldo >= cols && rows < (int64_t(1) << 31), "vlmc_reorder_indices: bad shape");
+    if (rows == 0) return VLMC_OK;
+    hipStream_t st = as_stream(stream);
+#define VLMC_RO(T) hipLaunchKernelGGL((reorder_indices_kernel<T>), dim3(unsigned(rows)), dim3(256), 0, st,                       \
+                                      static_cast<const T::raw *>(x), cols, ldx, out, ldo)
+    switch (dtype) {
+        case VLMC_F32: VLMC_RO(f32_t); break;
+        case VLMC_F16: VLMC_RO(f16_t); break;
+        case VLMC_BF16: VLMC_RO(bf16_t); break;
+        default: set_error("vlmc_reorder_indices: unknown dtype %d", dtype); return VLMC_EINVAL;
+    }
+#undef VLMC_RO
+    VLMC_HIP_CHECK_LAUNCH("vlmc_reorder_indices");
+    return VLMC_OK;
+}

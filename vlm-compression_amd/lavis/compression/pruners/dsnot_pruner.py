@@ -396,3 +396,13 @@ class BLIPT5LayerDSnoTPruner(LayerWiseBasePruner, _DsnotBlockMixin):
         vit_keep = (vit_params + t5_params) * vit_keep_ratio / 2
         t5_keep = (vit_params + t5_params) * t5_keep_ratio / 2
         return min(vit_keep / vit_params, 1.0), min(t5_keep / t5_params, 1.0)
+
+
+def return_reorder_indice(input_tensor):
+    """The reference's module-level helper (dsnot_pruner.py:1881-1925), same name and contract: for
+    [[1., -2., 3.], [-2, 2., -4], [5., 6., -7], [-6, -7, -4]] the int64 indices [[1, 2, 0], [0, 2, 1], [2, 1, 0], [0, 1, 2]] --
+    negative entries keep their relative order at the head, positive entries are flipped at the tail, an entry that is
+    neither contributes a 0 between them.  One launch of `vlmc_reorder_indices` instead of two fp64 [rows, cols] index
+    matrices, two sorts, a flip and a sum; GPU tensors only (no CPU fallback, like every op of this build)."""
+    from vlmc import dsnot
+    return dsnot.reorder_indices(input_tensor)

@@ -68,5 +68,15 @@ class PeftModelForViT(PeftModel):
 
 
 class PeftModelForQformer(PeftModel):
-    def forward(self, **kwargs):
-        return self.base_model(**kwargs)
+    """(peft_model.py:663-705) the Q-Former's `BertLMHeadModel.forward` signature, positional `input_ids` included, with the
+    defaults the reference hands on explicitly (`use_cache=True`, `is_decoder=True`, `reduction="mean"`, `return_logits=False`)."""
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, head_mask=None, query_embeds=None,
+                encoder_hidden_states=None, encoder_attention_mask=None, labels=None, past_key_values=None, use_cache=True,
+                output_attentions=None, output_hidden_states=None, return_dict=None, return_logits=False, is_decoder=True,
+                reduction="mean"):
+        return self.base_model(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids, head_mask=head_mask,
+                               query_embeds=query_embeds, encoder_hidden_states=encoder_hidden_states,
+                               encoder_attention_mask=encoder_attention_mask, labels=labels, past_key_values=past_key_values,
+                               use_cache=use_cache, output_attentions=output_attentions, output_hidden_states=output_hidden_states,
+                               return_dict=return_dict, return_logits=return_logits, is_decoder=is_decoder, reduction=reduction)

@@ -241,3 +241,29 @@ class LoraModel(torch.nn.Module):
             if "model" not in modules:
                 raise
             return getattr(modules["model"], name)
+
+    @property
+    def modules_to_save(self):
+        return None
+
+    def get_peft_config_as_dict(self, inference: bool = False):
+        """The adapter configuration as plain values (lora.py:221-225): enum members by value, `inference_mode` forced on request."""
+        from dataclasses import asdict
+        from enum import Enum
+        config = {k: v.value if isinstance(v, Enum) else v for k, v in asdict(self.peft_config).items()}
+        if inference:
+            config["inference_mode"] = True
+        return config
+
+    def _set_adapter_layers(self, enabled=True):
+        for module in self.model.modules():
+            if isinstance(module, LoraLayer):
+                module.disable_adapters = not enabled
+
+    def enable_adapter_layers(self):
+        """(lora.py:232-233) every SparseLoRA layer adds its adapter again."""
+        self._set_adapter_layers(enabled=True)
+
+    def disable_adapter_layers(self):
+        """(lora.py:235-236) every SparseLoRA layer computes the plain `F.linear(x, W, b)` -- `PeftModel.disable_adapter()`."""
+        self._set_adapter_layers(enabled=False)

@@ -68,6 +68,7 @@ SIGNATURES = {
     "vlmc_dsnot_stats_update": (_i, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p]),
     "vlmc_dsnot_refine": (_i, [_p, _i, _i64, _i64, _i64, _p, _p, _p, _p, _i, _i, _i, _i, _c.c_float, _c.c_float, _i, _p, _p, _p]),
     "vlmc_dsnot_apply": (_i, [_p, _i, _i64, _i64, _i64, _p, _p, _p, _i, _i, _i, _p]),
+    "vlmc_reorder_indices": (_i, [_p, _i, _i64, _i64, _i64, _p, _i64, _p]),
     "vlmc_pack_24": (_i, [_p, _i, _i64, _i64, _i64, _p, _i64, _p, _p, _p, _p]),
     "vlmc_unpack_24": (_i, [_p, _p, _i, _i64, _i64, _p, _i64, _p, _i64, _p, _p]),
     "vlmc_linear_fwd": (_i, [_p, _p, _p, _i, _i64, _i64, _i64, _i64, _i64, _p, _i64, _p]),

@@ -136,6 +136,26 @@ def gather_stats(stats):
 
 
 @torch.no_grad()
+def reorder_indices(input_tensor: torch.Tensor) -> torch.Tensor:
+    """`return_reorder_indice(input_tensor)` (dsnot_pruner.py:1881-1925) on the GPU: int64 [rows, cols]; per row the indices of the
+    negative entries in order, then one 0 per entry that is neither negative nor positive, then the indices of the positive
+    entries reversed (include/vlmc.h: vlmc_reorder_indices)."""
+    _need_gpu(input_tensor)
+    if input_tensor.dim() != 2:
+        raise ValueError("return_reorder_indice expects a 2-D tensor (the reference indexes input_tensor.shape[1], :1906)")
+    x = input_tensor.detach()
+    if x.dtype not in ops._DT:
+        x = x.to(torch.float32)                                   # (integer inputs: exact in fp32 up to 2^24; only the sign is read)
+    if x.shape[1] and x.stride(1) != 1:
+        x = x.contiguous()
+    rows, cols = x.shape
+    out = torch.empty((rows, cols), dtype=torch.int64, device=x.device)
+    if rows and cols:
+        _lib.check(_lib.load().vlmc_reorder_indices(x.data_ptr(), _dtype_code(x), rows, cols, x.stride(0) if rows > 1 else cols,
+                                                    out.data_ptr(), cols, _stream()))
+    return out
+
+
 def prune_linear(weight: torch.Tensor, stat: DsnotInputStat, ratio, *, prune_n=0, prune_m=0, initial_method="wanda",
                  without_DSnoT=False, max_cycle_time=100, update_threshold=0.1, pow_of_var_regrowing=1.0,
                  without_same_sign=True, apply_zero=True):

@@ -123,7 +123,7 @@ def pack_state_dict_24(state: dict, keep_masks: bool = False) -> dict:
         if k.endswith(".weight") and k[:-6] + "mask" in state and isinstance(v, torch.Tensor) and v.is_cuda and v.dim() == 2 and \
                 v.dtype in (torch.float16, torch.bfloat16) and v.shape[1] % 8 == 0:
             m = state[k[:-6] + "mask"]
-            if m.shape == v.shape and m.dtype == torch.bool and bool((m.view(v.shape[0], -1, 4).sum(-1) == 2).all()):
+            if m.shape == v.shape and m.dtype == torch.bool and bool((m.reshape(v.shape[0], -1, 4).sum(-1) == 2).all()):
                 w = v if v.stride(1) == 1 else v.contiguous()
                 # (what is stored is W . mask: under SparseLoRA the pruned positions of `weight` are zero already, lora.py:362)
                 values, meta = ops.pack_24(w, m if m.stride(1) == 1 else m.contiguous())
