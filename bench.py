@@ -7,14 +7,21 @@ wanda_pruner.py:947) on configs[1]: all 588 prunable linears (39 ViT-g blocks fp
 Flan-T5-XL blocks bf16 with the per-row rule), 128 batch-1 calibration samples, random-init weights of the true
 architecture and synthetic calibration data (`vlmc/synthetic.py`), everything resident in HBM before the timed region.
 
+THE WORKLOAD (since round 6): the stand-in whose blocks follow the reference's model files op for op -- EVA attention as
+eva_vit.py:129-168 (q / v bias, explicit `q @ k^T`, softmax, `attn @ v`), T5 attention as modeling_t5.py:520-640
+(`torch.matmul` scores, bucketed position bias of block 0, extended masks, fp32 softmax), the Q-Former as Qformer.py:205-246 --
+with RAGGED calibration text (prompts of 8..128 tokens, answers of 4..16: blip2_t5_instruct.py:49-53 allows 128 / 256).  Rounds
+2-5 quoted a friendlier stand-in (attention as one `F.scaled_dot_product_attention` call, all text of one length); that prune is
+kept as the sub-object `config.sdpa_equal_lengths`.
+
 One "step" = ONE whole prune through the drop-in pruner API: capture of each tower's inputs by the model's own
 forward, block replay over the calibration samples, activation statistics, score / select / apply of every linear.
 Before each step the dense weights are copied back (7.4 GB device-to-device, ~3 ms, inside the timed region).
 `value` = 588 x steps / seconds.  `config.subtotals_s` (capture / replay / stat / select) come from ONE extra, untimed
 prune with synchronising phase timers.  `roofline` is measured inside the timed steps with HIP events carried by the
 kernel launches themselves (vlmc_set_launch_events -> hipExtLaunchKernel) on a rotating subset of the launches.
-`kernel_pass` is last round's headline kept as a sub-object: statistics + select kernels alone on resident
-activations (no block forward).
+`config.invariance`: the same prune once more as the reference's one-sample-per-forward loop on this GPU, and how many mask bits
+differ from the grouped replay's (0 expected).  `kernel_pass`: statistics + select kernels alone on resident activations.
 
 N GPUs: `python bench.py --gpus N` starts N ranks by itself (torch.distributed.run as a child process, before this
 process touches a GPU); under a launcher (WORLD_SIZE set) it is one of the ranks.  The 128 calibration samples are
@@ -60,13 +67,17 @@ def parse():
                     help="HIP events on every N-th launch of a timed kernel (1 = every launch; a timed launch idles the "
                          "GPU for ~10 us)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds before self-launched ranks are killed")
-    ap.add_argument("--reference-ops", default="auto", choices=["auto", "0", "1"],
-                    help="second line: the same prune on a stand-in whose attention follows the reference's model files op for op "
-                         "(explicit q @ k^T, position bias, fp32 softmax, masks) with ragged calibration text (auto: only at N=1)")
-    ap.add_argument("--calib-local", type=int, default=0, choices=[0, 16, 32, 64],
+    ap.add_argument("--invariance", default="auto", choices=["auto", "0", "1"],
+                    help="also run the headline's prune once as the reference's one-sample-per-forward loop and count the mask bits "
+                         "that differ from the grouped replay's (auto: only at N=1)")
+    ap.add_argument("--sdpa-leg", default="auto", choices=["auto", "0", "1"],
+                    help="sub-object: the rounds 2-5 headline -- the same prune on the stand-in that writes attention as "
+                         "F.scaled_dot_product_attention, all calibration text of one length (auto: only at N=1)")
+    ap.add_argument("--calib-local", default="auto", choices=["auto", "0", "16", "32", "64"],
                     help="rehearse ONE rank's share of an N-GPU run on this GPU (16 / 32 / 64 samples = one rank of 8 / 4 / 2): "
                          "every kernel a rank runs, the statistics exchange filled in with the rank's own rows "
-                         "(VLMC_SIMULATE_WORLD, vlmc/shard.py); reported as config.per_rank_floor, never as the headline")
+                         "(VLMC_SIMULATE_WORLD, vlmc/shard.py); reported as config.per_rank_floor, never as the headline "
+                         "(auto: all three at N=1, two prunes each)")
     return ap.parse_args()
 
 
@@ -212,10 +223,18 @@ def install_probes(probe):
     def group_flops(x, weights, biases=None, **kw):
         return 2.0 * (x.numel() // x.shape[-1]) * sum(w.shape[0] for w in weights) * weights[0].shape[1]
 
+    def rows_flops(x, weights, biases, rowmap, n_real, **kw):           # a padded group of ragged samples: the REAL rows only
+        return 2.0 * int(n_real) * sum(w.shape[0] for w in weights) * weights[0].shape[1]
+
     probe.wrap(ops, "act_sqnorm_batch", "stat", sq_bytes)
     probe.wrap(ops, "wanda_select_batch", "rows", sel_bytes, sel_single)
     probe.wrap(ops, "linear_fwd", "gemm", gemm_flops)
     probe.wrap(ops, "linear_fwd_group", "gemm", group_flops)          # q / k / v, wi_0 / wi_1: one launch (vlmc/forward.py)
+    probe.wrap(ops, "linear_fwd_rows", "gemm", rows_flops)            # the same products over a row map (padding rows skipped)
+
+    def fused_flops(q, k, v, *rest, **kw):                              # both products of the chain: 4 B H Tq Tk d
+        return 4.0 * q.shape[0] * q.shape[1] * q.shape[2] * k.shape[2] * q.shape[3]
+    probe.wrap(ops, "attn_fused", "attnf", fused_flops)               # the whole attention chain of a replayed block in one launch
 
     def sdpa_flops(q, k, v, *a, **kw):                                  # both products: 4 B H Tq Tk d
         return 4.0 * q.shape[0] * q.shape[1] * q.shape[2] * k.shape[2] * q.shape[3]
@@ -380,94 +399,16 @@ def kernel_pass(dev, steps, warmup, stride):
 
 
 # ----------------------------------------------------------------------------------------------------------------
-# second line: the reference's own op sequence in the blocks' attention, ragged calibration text
+# the grouped replay against the reference's own loop, on this GPU
 # ----------------------------------------------------------------------------------------------------------------
-def reference_ops_leg(dev, steps):
-    """The headline's stand-in writes attention as F.scaled_dot_product_attention on text of one length: one group of 128
-    samples per block, attention per (sample, head).  The reference's model files (eva_vit.py:129-168,
-    modeling_t5.py:520-640) write it as batched `torch.matmul`s with a position bias, masks and an fp32 softmax, and real
-    calibration text is ragged.  Same prune on such a stand-in (vlmc/synthetic.py reference_ops=True, prompt lengths
-    8..128): seconds, groups per block forward, and how far the grouped replay's masks are from the reference's
-    one-sample-per-forward loop run on the same GPU.  Since round 4 the blocks' batched matmuls run on vlmc_attn_matmul and
-    the norms' fp32 mean on vlmc_row_mean during the replay (vlmc/forward.py: invariant_matmuls), batch-invariant like the
-    linears: the agreement is expected to be exactly 1.0 (round 3, library matmuls: 0.9971-0.99997, run to run)."""
-    from lavis.compression.pruners import calibration as cal
-    job = PruneJob(dev, reference_ops=True, ragged=True)
-    groups = []
-    real_plan = cal.plan_groups
-
-    real_padded = cal.plan_padded
-
-    def counting(*a, **k):
-        chunks = real_plan(*a, **k)
-        groups.append(len(chunks))
-        return chunks
-
-    def counting_padded(*a, **k):                             # ragged samples padded into one forward (round 5): counted the same way
-        padded = real_padded(*a, **k)
-        if padded is not None:
-            groups.append(len(padded))
-        return padded
-    cal.plan_groups, cal.plan_padded = counting, counting_padded
-    # the attention products' kernel inside these prunes: every 4th launch carries HIP events in its own dispatch
-    from vlmc import ops
-    probe = LaunchProbe(4)
-
-    def attn_bytes(a, b, *rest, **kw):                        # operands once + the output once, 2 bytes per element
-        lead = 1
-        for x, y in zip(a.shape[:-2], b.shape[:-2]):
-            lead *= max(x, y)
-        return 2.0 * lead * (a.shape[-2] * a.shape[-1] + b.shape[-2] * b.shape[-1] + a.shape[-2] * b.shape[-1])
-    probe.wrap(ops, "attn_matmul", "attn", attn_bytes, lambda a, b, *r, **k: a.is_cuda and a.dim() >= 3 and a.dtype in (torch.float16, torch.bfloat16))
-
-    def fused_flops(q, k, v, *rest, **kw):                    # both products of the chain: 4 B H Tq Tk d
-        return 4.0 * q.shape[0] * q.shape[1] * q.shape[2] * k.shape[2] * q.shape[3]
-    score_bytes = []
-
-    def fused_units(q, k, v, *rest, **kw):
-        score_bytes.append(2.0 * q.shape[0] * q.shape[1] * q.shape[2] * k.shape[2])
-        return fused_flops(q, k, v)
-    probe.wrap(ops, "attn_fused", "attnf", fused_units)       # round 5: the whole chain of a replayed block's attention in one launch
-    try:
-        job.step()                                            # warm-up (code objects of the batched matmuls, allocator)
-        torch.cuda.synchronize()
-        groups.clear()
-        probe.active = True
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            job.step()
-        torch.cuda.synchronize()
-        sec = (time.perf_counter() - t0) / steps
-        probe.active = False
-        plans = list(groups)
-    finally:
-        cal.plan_groups, cal.plan_padded = real_plan, real_padded
-        probe.restore()
-    a_ms, a_bytes, a_n = probe.summary("attn")
-    attn_kernel = None
-    if a_n:
-        gbs = a_bytes / (a_ms * 1e-3) / 1e9
-        attn_kernel = {"kernel": "vlmc::attn_matmul_kernel (vlmc_attn_matmul: q @ k^T and attn @ v of the replayed blocks, batch-invariant; "
-                                 "algorithmic bytes = both operands once + the output once)",
-                       "bound": "hbm", "timed_launches": a_n, "launches_per_step": round(probe.calls.get("attn", 0) / steps, 1),
-                       "avg_launch_us": round(a_ms * 1e3 / a_n, 2), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_launch": round(a_bytes / a_n)}
-    f_ms, f_flops, f_n = probe.summary("attnf")
-    if f_n:
-        tfs = f_flops / (f_ms * 1e-3) / 1e12
-        fused = {"kernel": "vlmc::attn_fused_kernel (vlmc_attn_fwd: scores, scaling, position bias / mask addends, fp32 softmax and probs @ v of a "
-                           "replayed block's attention in one launch, every intermediate rounded like the tensor op it replaces; algorithmic "
-                           "flops = 4 B H Tq Tk d; what paces it is the softmax's VALU work and LDS fragment reads, not the matrix cores)",
-                 "bound": "mfma", "timed_launches": f_n, "launches_per_step": round(probe.calls.get("attnf", 0) / steps, 1),
-                 "avg_launch_us": round(f_ms * 1e3 / f_n, 2), "achieved": round(tfs, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                 "frac": round(tfs / MFMA_PEAK_TFLOPS, 4), "flops_per_launch": round(f_flops / f_n),
-                 "score_bytes_not_written_per_launch": round(sum(score_bytes) / max(1, len(score_bytes))),
-                 "unfused_products": attn_kernel}
-        attn_kernel = fused
+def invariance_leg(job):
+    """The headline's masks (grouped, padded replay) against ONE more prune run as the reference's loop -- one calibration sample
+    per block forward (wanda_pruner.py:308-311, :343-346; VLMC_BATCH_REPLAY=1, VLMC_TOWER_BATCH=0) -- on the same GPU: the
+    blocks' linears, attention products, softmax, norms and GELU run on batch- and padding-invariant kernels during a replay
+    (vlmc/forward.py), so the agreement is expected to be exactly 1.0."""
     grouped = job.masks()
-    frac = job.pruned_fraction()
     keep = {k: os.environ.get(k) for k in ("VLMC_BATCH_REPLAY", "VLMC_TOWER_BATCH")}
-    os.environ.update(VLMC_BATCH_REPLAY="1", VLMC_TOWER_BATCH="0")          # the reference's loop: one sample per forward
+    os.environ.update(VLMC_BATCH_REPLAY="1", VLMC_TOWER_BATCH="0")
     try:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -489,21 +430,57 @@ def reference_ops_leg(dev, steps):
         diff += d
         if d / m.numel() > worst[0]:
             worst = (d / m.numel(), n)
-    per_tower = {}
-    if plans:                                                   # one plan per tower and prune (the plan of the first pass holds)
-        per = len(plans) // steps
-        for t, name in enumerate(("visual_encoder.blocks", "t5_model.encoder.block", "t5_model.decoder.block")[:per]):
-            per_tower[name] = plans[t]
-    out = {"what": "the same whole prune on a stand-in whose attention follows the reference's op sequence (eva_vit.py:129-168: "
-                   "q / v bias, explicit q @ k^T, softmax, attn @ v; modeling_t5.py:520-640: torch.matmul scores, bucketed position "
-                   "bias of block 0, extended masks, fp32 softmax) with ragged calibration text (prompts of 8..128 tokens, outputs "
-                   "of 4..16)",
+    return {"what": "mask bits of the timed (grouped, padded) prune against one more prune run as the reference's one-sample-per-forward "
+                    "loop on this GPU", "per_sample_loop_seconds": round(per_sample_sec, 3),
+            "mask_agreement_grouped_vs_per_sample": round(1.0 - diff / max(1, total), 9), "mask_elements": total,
+            "mask_elements_differing": diff, "worst_linear": {"name": worst[1], "fraction_differing": round(worst[0], 9)}}
+
+
+def sdpa_leg(dev, steps, stride):
+    """Rounds 2-5's headline, kept as a sub-object: the same whole prune on the stand-in whose blocks write attention as ONE
+    `F.scaled_dot_product_attention` call (no position bias, no masks) and whose calibration text is all of one length (32 + 32
+    prompt tokens, 16 answer tokens): one group of 128 equal samples per block forward, nothing to pad."""
+    from vlmc import ops
+    job = PruneJob(dev)
+    probe = LaunchProbe(stride)
+
+    def sdpa_flops(q, k, v, *a, **kw):                                  # both products: 4 B H Tq Tk d
+        return 4.0 * q.shape[0] * q.shape[1] * q.shape[2] * k.shape[2] * q.shape[3]
+
+    def gemm_flops(x, weight, bias=None, **kw):
+        return 2.0 * (x.numel() // x.shape[-1]) * weight.shape[0] * weight.shape[1]
+
+    def group_flops(x, weights, biases=None, **kw):
+        return 2.0 * (x.numel() // x.shape[-1]) * sum(w.shape[0] for w in weights) * weights[0].shape[1]
+    probe.wrap(ops, "sdpa", "attn", sdpa_flops, lambda q, k, v, *a, **kw: ops.sdpa_plan(q, k, v) is not None)
+    probe.wrap(ops, "linear_fwd", "gemm", gemm_flops)
+    probe.wrap(ops, "linear_fwd_group", "gemm", group_flops)
+    try:
+        job.step()
+        job.step()
+        torch.cuda.synchronize()
+        probe.active = True
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            job.step()
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / steps
+        probe.active = False
+    finally:
+        probe.restore()
+    out = {"what": "the same whole prune on the friendlier stand-in rounds 2-5 quoted: attention written as F.scaled_dot_product_attention, "
+                   "128 calibration samples of equal length (257 image tokens, 32 + 32 text, 16 output tokens)",
            "seconds_per_prune": round(sec, 4), "layers_per_s": round(588 / sec, 1), "steps": steps,
-           "groups_per_block_forward": per_tower, "pruned_fraction": round(frac, 6), "attention_kernel": attn_kernel,
-           "per_sample_loop_seconds": round(per_sample_sec, 3),
-           "mask_agreement_grouped_vs_per_sample": round(1.0 - diff / max(1, total), 9), "mask_elements": total,
-           "mask_elements_differing": diff, "worst_linear": {"name": worst[1], "fraction_differing": round(worst[0], 9)}}
-    del job, grouped, single
+           "pruned_fraction": round(job.pruned_fraction(), 6)}
+    for kind, name in (("gemm", "vlmc::gemm_nt_kernel"), ("attn", "vlmc::sdpa_fwd_kernel")):
+        ms, flops, n = probe.summary(kind)
+        if n:
+            tfs = flops / (ms * 1e-3) / 1e12
+            calls = probe.calls.get(kind, 0)
+            out[kind] = {"kernel": name, "bound": "mfma", "achieved": round(tfs, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tfs / MFMA_PEAK_TFLOPS, 4), "avg_launch_us": round(ms * 1e3 / n, 2),
+                         "launches_per_step": round(calls / steps, 1), "gpu_ms_per_step": round(ms / n * calls / steps, 2)}
+    del job
     torch.cuda.empty_cache()
     return out
 
@@ -626,12 +603,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    job = PruneJob(dev)
+    # ---- groups per block forward: counted through the planner the walk itself calls (one plan per tower and prune) ----------
+    from lavis.compression.pruners import calibration as cal
+    groups = []
+    real_plan, real_padded = cal.plan_groups, cal.plan_padded
+
+    def counting(*a, **k):
+        chunks = real_plan(*a, **k)
+        groups.append(len(chunks))
+        return chunks
+
+    def counting_padded(*a, **k):
+        padded = real_padded(*a, **k)
+        if padded is not None:
+            groups.append(len(padded))
+        return padded
+    cal.plan_groups, cal.plan_padded = counting, counting_padded
+
+    job = PruneJob(dev, reference_ops=True, ragged=True)
     probe = LaunchProbe(args.event_stride)
     install_probes(probe)
     for _ in range(args.warmup):
         job.step()
     sync()
+    groups.clear()
     probe.active = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -640,11 +635,21 @@ def main():
     elapsed = time.perf_counter() - t0
     probe.active = False
     probe.restore()
+    cal.plan_groups, cal.plan_padded = real_plan, real_padded
+    rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        rank_ms = [round(float(e.item()) / args.steps * 1e3, 3) for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     pruned_fraction = job.pruned_fraction()
+    per_tower = {}
+    if groups and args.steps:
+        per = len(groups) // args.steps
+        for t_, name in enumerate(("visual_encoder.blocks", "t5_model.encoder.block", "t5_model.decoder.block")[:per]):
+            per_tower[name] = groups[t_]
 
     # ---- sub-totals: one extra, untimed prune with synchronising phase timers ------------------------------------
     from vlmc import phases
@@ -673,7 +678,9 @@ def main():
                  f"the timed prunes")
         avg_us = ms * 1e3 / max(1, n)
         common = {"kernel": kernel, "launches": n, "avg_launch_us": round(avg_us, 2), "launches_per_step": round(calls / args.steps, 1),
-                  "gpu_ms_per_step": round(avg_us * calls / args.steps * 1e-3, 2), "traffic": traffic.get(tkey), "timed": timed}
+                  "gpu_ms_per_step": round(avg_us * calls / args.steps * 1e-3, 2), "traffic": traffic.get(tkey),
+                  "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload taken when "
+                                    "the profiles were collected (static; NOT measured in this run)", "timed": timed}
         if bound == "mfma":
             ach = units / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             return dict(common, bound="mfma", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
@@ -682,45 +689,61 @@ def main():
         return dict(common, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
                     bytes_per_launch=round(units / max(1, n)))
 
-    rows = [roof("gemm", "vlmc::gemm_nt_kernel (vlmc_linear_fwd: the dense calibration forward of the blocks' linears on "
-                         "v_mfma_f32_16x16x32, batch-invariant; algorithmic flops = 2 M N K)", "gemm_nt_bytes_per_launch", "mfma"),
+    rows = [roof("gemm", "vlmc::gemm_nt_kernel (vlmc_linear_fwd / _group / _rows: the dense calibration forward of the blocks' linears on "
+                         "v_mfma_f32_16x16x32, batch-invariant; algorithmic flops = 2 M N K over the REAL rows of a padded group)",
+                 "gemm_nt_bytes_per_launch", "mfma"),
             roof("stat", "vlmc::act_sqnorm_kernel (per-sample squared column norms of every distinct linear input of a block; one "
                          "launch per group of calibration samples)", "act_sqnorm_kernel_bytes_per_launch"),
             roof("rows", "vlmc::select_rows_mixed_kernel (score+select+apply, per-row rule; all linears of a T5 block in one "
                          "launch)", "select_rows_mixed_kernel_bytes_per_launch"),
-            roof("attn", "vlmc::sdpa_fwd_kernel (vlmc_sdpa_fwd: the fused attention of a replayed block, K and V of a head in LDS; "
-                         "algorithmic flops = 4 B H Tq Tk d; what paces it is LDS bandwidth and the softmax's VALU work, "
-                         "not the matrix cores)", "sdpa_fwd_kernel_bytes_per_launch", "mfma")]
+            roof("attnf", "vlmc::attn_fused_kernel (vlmc_attn_fwd: scores, scaling, position bias / mask addends, fp32 softmax and probs @ v "
+                          "of a replayed block's attention in one launch, every intermediate rounded like the tensor op it replaces; "
+                          "algorithmic flops = 4 B H Tq Tk d; what paces it is the softmax's VALU work and LDS fragment reads, not the "
+                          "matrix cores)", "attn_fused_kernel_bytes_per_launch", "mfma")]
     # the dominant kernel = the product kernel with the most GPU time per step (measured, not assumed)
     rows.sort(key=lambda r: -r["gpu_ms_per_step"])
     roofline = rows[0]
     roofline["other"] = rows[1:]
 
+    invariance = None
+    if args.invariance == "1" or (args.invariance == "auto" and world == 1):
+        try:
+            invariance = invariance_leg(job)
+        except Exception as e:                    # never lose the bench line to a side measurement
+            invariance = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- one rank's floor of an N-GPU run, rehearsed on this GPU (--calib-local) -----------------------------------
     floor = None
-    if args.calib_local and world == 1:
-        os.environ["VLMC_SIMULATE_WORLD"] = str(N_CALIB // args.calib_local)
-        try:
-            job.step()                                            # warm-up at the rank's shapes (code objects, allocator)
-            torch.cuda.synchronize()
-            busy0 = time.perf_counter()
-            for _ in range(args.steps):
-                job.step()
-            torch.cuda.synchronize()
-            fsec = (time.perf_counter() - busy0) / args.steps
-            floor = {"calib_samples_on_this_rank": args.calib_local, "stands_for_world_size": N_CALIB // args.calib_local,
-                     "seconds_per_prune": round(fsec, 4), "layers_per_s_if_every_rank_kept_this_pace": round(588 / fsec, 1),
-                     "pruned_fraction": round(job.pruned_fraction(), 6),
-                     "what": "rank 0 of W: capture + replay + statistics of its 128 / W samples, selects of all 588 linears, the "
-                             "running-mean recurrence over all 128 rows; the per-block all-gather is filled in with the rank's own "
-                             "rows (VLMC_SIMULATE_WORLD) -- no RCCL, no arrival skew"}
-        finally:
-            os.environ.pop("VLMC_SIMULATE_WORLD", None)
+    locals_ = [] if world > 1 or args.calib_local == "0" else ([16, 32, 64] if args.calib_local == "auto" else [int(args.calib_local)])
+    if locals_:
+        floor = {"what": "rank 0 of W rehearsed on this GPU: capture + replay + statistics of its 128 / W samples, selects of all 588 "
+                         "linears, the running-mean recurrence over all 128 rows; the per-block all-gather is filled in with the rank's "
+                         "own rows (VLMC_SIMULATE_WORLD) -- no RCCL, no arrival skew.  projected_speedup = this run's N = 1 seconds / "
+                         "the rank's seconds: an upper bound for N = W",
+                 "ranks": {}}
+        fsteps = args.steps if args.calib_local != "auto" else 2
+        for loc in locals_:
+            os.environ["VLMC_SIMULATE_WORLD"] = str(N_CALIB // loc)
+            try:
+                job.step()                                            # warm-up at the rank's shapes (code objects, allocator)
+                torch.cuda.synchronize()
+                busy0 = time.perf_counter()
+                for _ in range(fsteps):
+                    job.step()
+                torch.cuda.synchronize()
+                fsec = (time.perf_counter() - busy0) / fsteps
+                floor["ranks"][f"world_{N_CALIB // loc}"] = {
+                    "calib_samples_on_this_rank": loc, "seconds_per_prune": round(fsec, 4),
+                    "projected_speedup": round(elapsed / args.steps / fsec, 2), "pruned_fraction": round(job.pruned_fraction(), 6)}
+            except Exception as e:
+                floor["ranks"][f"world_{N_CALIB // loc}"] = {"error": f"{type(e).__name__}: {e}"}
+            finally:
+                os.environ.pop("VLMC_SIMULATE_WORLD", None)
 
+    job = None
+    torch.cuda.empty_cache()
     kp = None
     if args.kernel_pass == "1" or (args.kernel_pass == "auto" and world == 1):
-        job = None
-        torch.cuda.empty_cache()
         try:
             kp = kernel_pass(dev, args.kernel_steps, 2, max(1, args.event_stride))
             for k in kp["kernels"]:
@@ -730,14 +753,13 @@ def main():
         except Exception as e:                    # never lose the bench line to the side measurement
             kp = {"error": f"{type(e).__name__}: {e}"}
 
-    ref_ops = None
-    if args.reference_ops == "1" or (args.reference_ops == "auto" and world == 1):
-        job = None
+    sdpa = None
+    if args.sdpa_leg == "1" or (args.sdpa_leg == "auto" and world == 1):
         torch.cuda.empty_cache()
         try:
-            ref_ops = reference_ops_leg(dev, max(1, min(args.steps, 3)))
-        except Exception as e:                    # never lose the bench line to the second measurement
-            ref_ops = {"error": f"{type(e).__name__}: {e}"}
+            sdpa = sdpa_leg(dev, max(1, min(args.steps, 3)), args.event_stride)
+        except Exception as e:
+            sdpa = {"error": f"{type(e).__name__}: {e}"}
 
     out = None
     if rank == 0:
@@ -750,17 +772,24 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f16/bf16", "data": "synthetic",
             "config": {"workload": "configs[1]: one whole load_pruner('blipt5_wanda_pruner').prune() -- Wanda 50% unstructured, "
                                    "InstructBLIP-FlanT5-XL architecture and shapes (39 ViT-g blocks fp16 matrix-wide rule + 24/24 "
-                                   "Flan-T5-XL blocks bf16 per-row rule; between them the 12-layer Q-Former, never pruned: 32 queries + the instruction "
-                                   "tokens, cross-attention to the image every second layer, blip2_t5_instruct.py:136-221), "
-                                   "random init, 128 batch-1 calibration samples (257 image tokens, 32+32 text, 16 output tokens)",
+                                   "Flan-T5-XL blocks bf16 per-row rule; between them the 12-layer Q-Former, never pruned), the blocks written "
+                                   "with the REFERENCE'S OP SEQUENCE (eva_vit.py:129-168: q / v bias, explicit q @ k^T, softmax, attn @ v; "
+                                   "modeling_t5.py:520-640: torch.matmul scores, bucketed position bias of block 0, extended masks, fp32 "
+                                   "softmax; Qformer.py:205-246), random init, 128 batch-1 calibration samples with RAGGED text (257 image "
+                                   "tokens, 32 queries + prompts of 8..128 tokens, answers of 4..16 tokens)",
                        "linears": n_lin, "blocks": 87, "calib_samples": N_CALIB, "ratio": RATIO,
                        "total_prune_wall_clock_s": round(sec, 4), "blocks_per_s": round(87 / sec, 1),
                        "pruned_fraction": round(pruned_fraction, 6), "subtotals_s": sub,
-                       "replay": f"grouped: up to {os.environ.get('VLMC_BATCH_REPLAY', '128')} equal-shape samples per block forward",
-                       "capture": capture_info(),
+                       "replay": f"grouped: up to {os.environ.get('VLMC_BATCH_REPLAY', '128')} samples per block forward; ragged samples "
+                                 "padded into one group, the linears skip the padding rows (vlmc_linear_fwd_rows)",
+                       "groups_per_block_forward": per_tower,
+                       "capture": capture_info(), "invariance": invariance,
                        "parallelism": f"calib-dp{world}", "backend": backend, "per_rank_floor": floor,
-                       "reference_ops": ref_ops,
-                       "world_size": dist.get_world_size() if world > 1 else 1},
+                       "sdpa_equal_lengths": sdpa,
+                       "world_size": dist.get_world_size() if world > 1 else 1,
+                       "per_rank_ms_per_step": rank_ms,
+                       "exchange": ("one all-gather of the per-sample statistics rows per block (87 per prune); seconds inside them in the "
+                                    "phase-timed prune: subtotals_s.exchange (includes the ranks' arrival skew)") if world > 1 else None},
             "roofline": roofline,
             "kernel_pass": kp,
         }

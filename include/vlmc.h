@@ -252,6 +252,17 @@ typedef struct vlmc_linear_job {
 int vlmc_linear_fwd_group(const void *X, const vlmc_linear_job *jobs /* host array */, int n_jobs /* 1..4 */, int dtype,
                           int64_t M, int64_t K, int64_t ldx, void *stream);
 
+/* The same product over the rows a ROW MAP names -- the dense calibration forward of a PADDED group of ragged calibration samples
+ * (the reference forwards every sample alone, `layer(inps[j], **caches[j])`, wanda_pruner.py:308-311: a sample's rows are all real;
+ * stacked as [samples, longest, K] for one forward of the block, the rows behind a sample's own are padding).  X and every Y_g hold
+ * M physical rows; `rowmap` (device, int32 [M], a permutation of 0 .. M - 1) lists the n_real rows to compute first and the
+ * M - n_real padding rows after them:
+ *     Y_g[rowmap[i], :] = wd(X[rowmap[i], :] W_g^T + bias_g)   for i < n_real      (accumulated exactly as by vlmc_linear_fwd: same bits)
+ *     Y_g[rowmap[i], :] = 0                                     for i >= n_real     (finite values behind the attention's masks)
+ * Padding rows of X are neither loaded nor multiplied; the tiles are cut from the n_real compacted rows.  1 <= n_real <= M. */
+int vlmc_linear_fwd_rows(const void *X, const vlmc_linear_job *jobs /* host array */, int n_jobs /* 1..4 */, int dtype, int64_t M,
+                         int64_t K, int64_t ldx, const int32_t *rowmap, int64_t n_real, void *stream);
+
 /* vlmc_linear_fwd with the elementwise op(s) the model applies to a linear's output folded into the epilogue -- each still rounding
  * to the dtype where the tensor op rounds, so the result has the BITS of `vlmc_linear_fwd` followed by the torch op(s):
  *     y = wd(X W^T + bias)                                   the module's own output (nn.Linear.forward)

@@ -324,3 +324,99 @@ torch.save(outs, sys.argv[1])
     for extra, other in zip(envs[1:], results[1:]):
         for a, b in zip(results[0], other):
             assert torch.equal(a, b), extra
+
+
+# ---- vlmc_linear_fwd_rows: the dense calibration forward of a PADDED group of ragged samples (round 6) ------------------------------
+def _ragged_case(dtype, lengths, tpad, K, seed, garbage=True):
+    """x [samples, tpad, K]: a sample's own rows are data, the rows behind them hold NaN / Inf garbage (nothing may read them);
+    rowmap = real rows first (sample order, token order), padding rows after."""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    B = len(lengths)
+    x = (torch.randn(B, tpad, K, generator=g, device=DEV) * 0.5 + 0.1).to(dtype)
+    real, pad = [], []
+    for b, t in enumerate(lengths):
+        real += [b * tpad + i for i in range(t)]
+        pad += [b * tpad + i for i in range(t, tpad)]
+        if garbage and t < tpad:
+            x[b, t:] = float("nan")
+            x[b, t::2] = float("inf")
+    rowmap = torch.tensor(real + pad, dtype=torch.int32, device=DEV)
+    return x, rowmap, len(real)
+
+
+RAGGED_SHAPES = [  # (lengths, tpad, K, [N..]): the tile families -- persistent 256 x 256, 128 x 128, 64 / 32 -- and edge rows
+    ([40, 48, 56, 64, 64, 80, 96, 160] * 16, 160, 2048, [2048, 2048, 2048]),       # a T5 encoder block's q / k / v at 128 ragged samples
+    ([40, 48, 56, 64, 64, 80, 96, 160] * 16, 160, 2048, [5120, 5120]),             # wi_0 / wi_1
+    ([4, 8, 16, 16] * 32, 16, 2048, [2048]),                                          # the decoder's self-attention projections
+    ([3, 1, 7], 9, 72, [40]),
+    ([1], 5, 64, [24, 8]),
+    ([17, 257, 100, 31], 257, 1408, [4224]),
+    ([5, 5, 5], 5, 128, [136]),                                                       # nothing is padding
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", range(len(RAGGED_SHAPES)))
+def test_linear_fwd_rows_has_the_bits_of_each_samples_own_forward(dtype, case):
+    """Row-mapped launch == `linear_fwd` of every sample ALONE on its own rows (what the reference's one-sample-per-forward loop
+    computes, wanda_pruner.py:308-311), bit for bit; padding rows of the outputs are +0; NaN / Inf in the padding rows of x reach nothing."""
+    from vlmc import ops
+    lengths, tpad, K, Ns = RAGGED_SHAPES[case]
+    x, rowmap, n_real = _ragged_case(dtype, lengths, tpad, K, seed=case * 13 + 1)
+    g = torch.Generator(device=DEV).manual_seed(case + 100)
+    ws = [(torch.randn(N, K, generator=g, device=DEV) * 0.05).to(dtype) for N in Ns]
+    bs = [(torch.randn(N, generator=g, device=DEV) * 0.1).to(dtype) if i % 2 == 0 else None for i, N in enumerate(Ns)]
+    outs = ops.linear_fwd_rows(x, ws, bs, rowmap, n_real)
+    assert len(outs) == len(ws)
+    for y, w, b in zip(outs, ws, bs):
+        assert y.shape == (len(lengths), tpad, w.shape[0]) and y.dtype == dtype
+        for s_ in sorted(set(range(0, len(lengths), max(1, len(lengths) // 9))) | {len(lengths) - 1}):
+            t = lengths[s_]
+            alone = ops.linear_fwd(x[s_:s_ + 1, :t].contiguous(), w, b)
+            assert torch.equal(y[s_, :t].view(torch.int16), alone[0].view(torch.int16)), (case, s_)
+            assert bool((y[s_, t:].view(torch.int16) == 0).all()), "a padding row of Y is not +0"
+        assert bool(torch.isfinite(y.float()).all())
+    # against fp64 on the real rows (the same bound as vlmc_linear_fwd's)
+    y, w, b = outs[0], ws[0], bs[0]
+    rows = rowmap[:n_real].long()
+    xr = x.reshape(-1, K)[rows]
+    ref = _ref64(xr, w, b)
+    scale = xr.double().abs() @ w.double().abs().t() + (b.double().abs() if b is not None else 0)
+    err = (y.reshape(-1, w.shape[0])[rows].double() - ref).abs()
+    assert bool((err <= ULP[dtype] * ref.abs() + 4e-7 * math.sqrt(K) * scale + 1e-30).all())
+
+
+def test_linear_fwd_rows_any_row_order_and_strided_input():
+    """The map is a permutation: real rows listed in another order give the same Y; x may be a row-strided view."""
+    from vlmc import ops
+    dtype, lengths, tpad, K, N = torch.bfloat16, [9, 3, 12, 1, 7], 12, 256, 320
+    x, rowmap, n_real = _ragged_case(dtype, lengths, tpad, K, seed=3)
+    w = (torch.randn(N, K, device=DEV) * 0.05).to(dtype)
+    y0 = ops.linear_fwd_rows(x, [w], None, rowmap, n_real)[0]
+    perm = torch.randperm(n_real, device=DEV)
+    shuffled = torch.cat([rowmap[:n_real][perm], rowmap[n_real:].flip(0)]).contiguous()
+    y1 = ops.linear_fwd_rows(x, [w], None, shuffled, n_real)[0]
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    wide = torch.full((len(lengths), tpad, K + 64), float("nan"), dtype=dtype, device=DEV)
+    wide[..., :K] = x
+    y2 = ops.linear_fwd_rows(wide[..., :K], [w], None, rowmap, n_real)[0]
+    assert torch.equal(y0.view(torch.int16), y2.view(torch.int16))
+
+
+def test_linear_fwd_rows_refuses_bad_maps():
+    from vlmc import _lib, ops
+    x = torch.zeros(2, 4, 64, dtype=torch.float16, device=DEV)
+    w = torch.zeros(8, 64, dtype=torch.float16, device=DEV)
+    rm = torch.arange(8, dtype=torch.int32, device=DEV)
+    with pytest.raises(ValueError):
+        ops.linear_fwd_rows(x, [w], None, rm[:7].contiguous(), 4)
+    with pytest.raises(ValueError):
+        ops.linear_fwd_rows(x, [w], None, rm, 0)
+    with pytest.raises(ValueError):
+        ops.linear_fwd_rows(x, [w], None, rm.long(), 4)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.linear_fwd_rows(x.cpu(), [w.cpu()], None, rm.cpu(), 4)
+    lib = _lib.load()
+    job = (_lib.LinearJob * 1)(_lib.LinearJob(w.data_ptr(), None, x.data_ptr(), 8, 64, 8))
+    assert lib.vlmc_linear_fwd_rows(x.data_ptr(), job, 1, _lib.F16, 8, 64, 64, None, 4, None) == _lib.VLMC_EINVAL
+    assert lib.vlmc_linear_fwd_rows(x.data_ptr(), job, 1, _lib.F16, 8, 64, 64, rm.data_ptr(), 9, None) == _lib.VLMC_EINVAL

@@ -127,11 +127,26 @@ def test_weight_gradients_against_the_oracle_autograd(wd):
             torch.testing.assert_close(got, ref, rtol=4 * ULP[wd], atol=8 * ULP[wd] * ref.abs().max().item())
 
 
+def _oracle_autograd(x, gy, W, A, B, Mk, s, sparse, wd):
+    """Forward and gradients of lora.py:359-380 under 16-bit autocast by autograd on the ORACLE's expression (oracle/sparse_lora.py:
+    effective_weight), CPU: the fp32 adapters enter as autocast casts them (rounded to `wd`; their gradients come back rounded to
+    it), `B @ A` leaves the autocast matmul in `wd`, the main product accumulates in fp32 and is rounded once.
+    Returns (y, dX, dA, dB) as fp32 tensors."""
+    xl = x.clone().requires_grad_(True)
+    A16, B16 = A.to(wd).float().requires_grad_(True), B.to(wd).float().requires_grad_(True)
+    weff = OL.effective_weight(W, A16, B16, Mk, s, sparse)
+    assert weff.dtype == wd
+    y = (xl.float() @ weff.float().t()).to(wd)
+    y.backward(gy)
+    return y.detach().float(), xl.grad.float(), A16.grad.to(wd).float(), B16.grad.to(wd).float()
+
+
 @pytest.mark.parametrize("out_f,in_f", V7B)
 @pytest.mark.parametrize("sparse", [True, False])
 def test_vicuna_7b_shapes(out_f, in_f, sparse):
     """All seven SparseLoRA linears of a Vicuna-7B layer (three distinct shapes), r = 16, fp16 autocast, one RESSA
-    micro-batch of 16 x (32 + 64) tokens: generated tiles exact, outputs and gradients against the unfused kernels."""
+    micro-batch of 16 x (32 + 64) tokens: generated tiles exact; outputs, dX, dA, dB against the unfused kernels (every entry) and
+    against the oracle's autograd (64 rows and 64 columns of the layer, each a complete sub-problem)."""
     from vlmc import sparse_lora as SL
     wd, r, M, s = torch.float16, 16, 16 * 96, 1.0
     W, A, B, Mk, _ = _layer(out_f, in_f, r, wd)
@@ -157,6 +172,19 @@ def test_vicuna_7b_shapes(out_f, in_f, sparse):
     for name, got, ref in zip(("y", "gx", "gA", "gB"), *res):
         scale = ref.abs().max().item()
         torch.testing.assert_close(got, ref, rtol=4e-3, atol=2e-3 * scale, msg=lambda m, n=name: f"{n}: {m}")
+    # ---- and DIRECTLY against the oracle's autograd, on slices that are complete sub-problems -----------------
+    # rows J of W: y[:, J] and dB[J] depend on nothing else; columns I of W: x[:, I] @ W_eff[:, I]^T is one addend of y whose
+    # gradients with respect to x[:, I] and A[:, I] are dX[:, I] and dA[:, I] of the whole layer.
+    y, gx, gA, gB = res[0]
+    gi = torch.Generator().manual_seed(out_f + in_f)
+    J = torch.randperm(out_f, generator=gi)[:64].sort().values
+    yo, _, _, gBo = _oracle_autograd(x, gy[:, J], W[J], A, B[J], Mk[J], s, sparse, wd)
+    torch.testing.assert_close(y[:, J], yo, rtol=4e-3, atol=2e-3 * yo.abs().max().item(), msg=lambda m: f"y[:, J] vs oracle: {m}")
+    torch.testing.assert_close(gB[J], gBo, rtol=4 * ULP[wd], atol=8 * ULP[wd] * gBo.abs().max().item(), msg=lambda m: f"dB[J] vs oracle: {m}")
+    I = torch.randperm(in_f, generator=gi)[:64].sort().values
+    _, gxo, gAo, _ = _oracle_autograd(x[:, I], gy, W[:, I], A[:, I], B, Mk[:, I], s, sparse, wd)
+    torch.testing.assert_close(gx[:, I], gxo, rtol=4e-3, atol=2e-3 * gxo.abs().max().item(), msg=lambda m: f"dX[:, I] vs oracle: {m}")
+    torch.testing.assert_close(gA[:, I], gAo, rtol=4 * ULP[wd], atol=8 * ULP[wd] * gAo.abs().max().item(), msg=lambda m: f"dA[:, I] vs oracle: {m}")
 
 
 def test_drop_in_module_takes_the_fused_route_under_autocast_and_nothing_weight_sized_is_saved():

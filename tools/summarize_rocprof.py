@@ -33,6 +33,22 @@ def stats(d, out):
     print(open(out).read())
 
 
+def stats_all(d, out):
+    """Every kernel by name (torch's own elementwise / copy kernels too): where a prune's GPU time goes."""
+    f = find(d, "*kernel_stats.csv")
+    rows = list(csv.DictReader(open(f)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    with open(out, "w") as o:
+        o.write(f"total kernel time {tot/1e6:.1f} ms, {sum(int(r['Calls']) for r in rows)} launches\n\n")
+        o.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+        for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:70]:
+            o.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.2f} | "
+                    f"{100*float(r['TotalDurationNs'])/tot:.1f} |\n")
+        ours = sum(float(r["TotalDurationNs"]) for r in rows if "vlmc::" in r["Name"])
+        o.write(f"\nvlmc:: kernels {ours/1e6:.1f} ms ({100*ours/tot:.1f} %), everything else {(tot-ours)/1e6:.1f} ms\n")
+    print(open(out).read())
+
+
 def pmc(d, out):
     f = find(d, "*counter_collection.csv")
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -48,4 +64,4 @@ def pmc(d, out):
 
 
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    {"stats": stats, "stats_all": stats_all, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])

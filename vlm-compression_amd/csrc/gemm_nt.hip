@@ -82,6 +82,11 @@ struct GemmArgs {
     int fstart[MAXG + 1];
     int hgroup[MAXG];
     int npf, nph, nqf, q_half;
+    // EPI_LINEAR with a ROW MAP (vlmc_linear_fwd_rows): X and Y hold more rows than are computed -- a padded group of ragged
+    // calibration samples.  Row q of the product (q < NQ) is row qmap[q] of X and of Y; rows qmap[NQ .. NQ + nq_zero) of Y are
+    // written as zeros (every tile clears its own columns of an equal share of them).  NULL: row q is row q.
+    const int32_t *qmap;
+    int nq_zero;
     // EPI_SYRK
     float *H;                     // [N, N], lower-triangle tiles are updated
     int64_t ldh;
@@ -127,6 +132,34 @@ __device__ __forceinline__ Panel locate_panel(const GemmArgs &a, int bp, int BP)
 
 // byte offset of 16-B chunk `ch` (0..7) of tile row `row` in an LDS operand tile
 __device__ __forceinline__ int lds_off(int row, int ch) { return row * ROW_BYTES + ((ch ^ (row & 7)) << 4); }
+
+// physical row of X / Y behind row q of the product (GemmArgs::qmap)
+__device__ __forceinline__ int q_phys(const GemmArgs &a, int q) { return a.qmap != nullptr ? a.qmap[q] : q; }
+
+// Row-mapped linear: this tile's share of the rows of Y that are only cleared (qmap[NQ ..]): columns [p0, p0 + BP) of
+// ceil(nq_zero / q-blocks) rows, 16 B per lane.  Issued before the tile's epilogue; nobody waits for the stores.
+template <typename T, int NT_, int BP_, int BQ_>
+__device__ __forceinline__ void zero_pad_rows(const GemmArgs &a, const Panel &pn, int q0, int tid) {
+    if (a.nq_zero == 0) return;
+    const int nqb = a.nqf + a.q_half, bq = q0 / BQ_;
+    const int per = (a.nq_zero + nqb - 1) / nqb;
+    const int r0 = bq * per, r1 = min(a.nq_zero, r0 + per);
+    const int ncol = min(BP_, pn.NP - pn.p0);
+    if (r1 <= r0 || ncol <= 0) return;
+    const int cpr = (ncol + 7) >> 3;
+    const bool vec_ok = (pn.ldy & 7) == 0 && (reinterpret_cast<uintptr_t>(pn.Y) & 15u) == 0;
+    const u32x4_t zero = {0u, 0u, 0u, 0u};
+    for (int c = tid; c < (r1 - r0) * cpr; c += NT_) {
+        const int r = c / cpr, ch = c - r * cpr;
+        const int p = pn.p0 + ch * 8;
+        uint16_t *dst = pn.Y + int64_t(a.qmap[a.NQ + r0 + r]) * pn.ldy + p;
+        if (vec_ok && p + 7 < pn.NP) {
+            __builtin_nontemporal_store(zero, reinterpret_cast<u32x4_t *>(dst));
+        } else {
+            for (int e = 0; e < 8 && p + e < pn.NP; ++e) dst[e] = 0;
+        }
+    }
+}
 
 // ---- epilogue: lane holds p = pbase + 16 i + 4 (lane >> 4) + r (r = 0..3), q = qbase + 16 j + (lane & 15) ---------------
 // Linear: Y[q][p], p contiguous.  Straight from the accumulators a store instruction would put 8 B into each of 16 rows
@@ -223,8 +256,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, const Panel &pn
                 u32x4_t v = *reinterpret_cast<const u32x4_t *>(wl + row * PITCH + ((ch ^ (row & (CPR - 1))) << 4));
                 const int q = q0 + wq * (TQ * 16) + pass * ROWS + row, p = p0 + wp * PW + ch * 8;
                 if (q >= a.NQ || p >= pn.NP) continue;
-                if (pn.post_bias != nullptr || pn.act != 0 || pn.res != nullptr) v = linear_post<T>(pn, v, q, p);     // (uniform: rare)
-                uint16_t *dst = pn.Y + int64_t(q) * pn.ldy + p;
+                const int qp = q_phys(a, q);                                // (row-mapped launch: where row q of the product lives)
+                if (pn.post_bias != nullptr || pn.act != 0 || pn.res != nullptr) v = linear_post<T>(pn, v, qp, p);    // (uniform: rare)
+                uint16_t *dst = pn.Y + int64_t(qp) * pn.ldy + p;
                 if (vec_ok && p + 7 < pn.NP) {
 #ifndef VLMC_GEMM_PLAIN_STORES
                     // streaming stores: Y is written once and read by another kernel; plain stores cost the operand panels
@@ -315,6 +349,12 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(const GemmArgs a) {
 
     // ---- staging: thread t moves chunks t, t + NT, ... of each operand tile (8 consecutive threads = one 128-B row)
     u32x4_t stage_p[S::CP], stage_q[S::CQ];
+    int qrow[S::CQ];                                                      // physical row of X behind each of this thread's Q chunks (-1: none)
+#pragma unroll
+    for (int i = 0; i < S::CQ; ++i) {
+        const int row = q0 + ((tid + i * NT) >> 3);
+        qrow[i] = row < a.NQ ? (EPI == EPI_LINEAR ? q_phys(a, row) : row) : -1;
+    }
     auto load_tiles = [&](int k0) {
         const u32x4_t zero = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -324,8 +364,8 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(const GemmArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < S::CQ; ++i) {
-            const int c = tid + i * NT, row = q0 + (c >> 3), k = k0 + (c & 7) * 8;
-            stage_q[i] = (row < a.NQ && k < a.K) ? *reinterpret_cast<const u32x4_t *>(a.Q + int64_t(row) * a.ldq + koff + k) : zero;
+            const int c = tid + i * NT, k = k0 + (c & 7) * 8;
+            stage_q[i] = (qrow[i] >= 0 && k < a.K) ? *reinterpret_cast<const u32x4_t *>(a.Q + int64_t(qrow[i]) * a.ldq + koff + k) : zero;
         }
     };
     auto store_tiles = [&](int buf) {
@@ -378,6 +418,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_kernel(const GemmArgs a) {
         __syncthreads();
     }
 
+    if constexpr (EPI == EPI_LINEAR) zero_pad_rows<T, NT, BP, BQ>(a, pn, q0, tid);
     gemm_epilogue<T, EPI, S>(a, pn, acc, q0, wp, wq, lane, lds, wave);
 }
 
@@ -425,7 +466,8 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_kernel(const GemmArgs a
         const int g = is_q ? gidx - BP / 16 : gidx;
         const int r = g * 16 + (lane >> 2);                               // tile row
         const int sc = (lane & 3) ^ ring_perm(r);                         // source chunk that belongs at LDS chunk (lane & 3)
-        const int grow = is_q ? min(q0 + r, a.NQ - 1) : min(p0 + r, pn.NP - 1);
+        int grow = is_q ? min(q0 + r, a.NQ - 1) : min(p0 + r, pn.NP - 1);
+        if (EPI == EPI_LINEAR && is_q) grow = q_phys(a, grow);
         src[u] = (is_q ? a.Q + int64_t(grow) * a.ldq : pn.P + int64_t(grow) * pn.ldp) + koff + sc * 8;
         dst[u] = (is_q ? P_BYTES : 0) + g * 1024;
     }
@@ -479,6 +521,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_kernel(const GemmArgs a
         for (; t < nk; ++t) kstep(std::false_type{}, t);
     }
 
+    if constexpr (EPI == EPI_LINEAR) zero_pad_rows<T, S::NT, BP, BQ>(a, pn, q0, tid);
     gemm_epilogue<T, EPI, S>(a, pn, acc, q0, wp, wq, lane, lds, wave);
 }
 
@@ -521,7 +564,8 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_wide_kernel(const GemmA
         const int g = is_q ? gidx - BP / 8 : gidx;
         const int r = g * 8 + (lane >> 3);                                // tile row
         const int sc = (lane & 7) ^ (r & 7);                              // source chunk that belongs at LDS chunk (lane & 7)
-        const int grow = is_q ? min(q0 + r, a.NQ - 1) : min(p0 + r, pn.NP - 1);
+        int grow = is_q ? min(q0 + r, a.NQ - 1) : min(p0 + r, pn.NP - 1);
+        if (EPI == EPI_LINEAR && is_q) grow = q_phys(a, grow);
         src[u] = (is_q ? a.Q + int64_t(grow) * a.ldq : pn.P + int64_t(grow) * pn.ldp) + koff + sc * 8;
         dst[u] = (is_q ? P_BYTES : 0) + g * 1024;
     }
@@ -576,6 +620,7 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_ring_wide_kernel(const GemmA
         // (the reads above are complete before this wave reaches the next barrier: the MFMAs wait for them)
     }
     __builtin_amdgcn_s_barrier();                                         // every wave is done with the slots: the epilogue's scratch
+    if constexpr (EPI == EPI_LINEAR) zero_pad_rows<T, S::NT, BP, BQ>(a, pn, q0, tid);
     gemm_epilogue<T, EPI, S, (TQ >= 2 ? 32 : 16), false>(a, pn, acc, q0, wp, wq, lane, lds, wave);
 }
 
@@ -685,7 +730,8 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
     auto tile_sources = [&](const Panel &pn, int q0, const uint16_t *(&out)[PER_WAVE]) {
 #pragma unroll
         for (int v = 0; v < PER_WAVE; ++v) {
-            const int grow = piece_q[v] ? min(q0 + piece_row[v], a.NQ - 1) : min(pn.p0 + piece_row[v], pn.NP - 1);
+            int grow = piece_q[v] ? min(q0 + piece_row[v], a.NQ - 1) : min(pn.p0 + piece_row[v], pn.NP - 1);
+            if (EPI == EPI_LINEAR && piece_q[v]) grow = q_phys(a, grow);
             out[v] = (piece_q[v] ? a.Q + int64_t(grow) * a.ldq : pn.P + int64_t(grow) * pn.ldp) + koff + piece_sc[v] * 8;
         }
     };
@@ -853,8 +899,9 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_pingpong_kernel(const GemmAr
             for (int i = 0; i < TP; ++i)
 #pragma unroll
                 for (int j = 0; j < TQ; ++j) asm volatile("" ::"v"(acc[i][j]));
-        } else if (cactive) {
-            gemm_epilogue<T, EPI, S, EPI_ROWS, false>(a, cpn, acc, cq0, wp, wq, lane, lds + (NSLOT - 1) * SLOT, wave);
+        } else {
+            if constexpr (EPI == EPI_LINEAR) zero_pad_rows<T, S::NT, BP, BQ>(a, cpn, cq0, tid);
+            if (cactive) gemm_epilogue<T, EPI, S, EPI_ROWS, false>(a, cpn, acc, cq0, wp, wq, lane, lds + (NSLOT - 1) * SLOT, wave);
         }
         if (!has_next) break;
     }
@@ -957,7 +1004,8 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_wide_kernel(const GemmArgs a
     auto tile_sources = [&](const Panel &pn, int q0, const uint16_t *(&out)[PER_WAVE]) {
 #pragma unroll
         for (int v = 0; v < PER_WAVE; ++v) {
-            const int grow = piece_q ? min(q0 + piece_row[v], a.NQ - 1) : min(pn.p0 + piece_row[v], pn.NP - 1);
+            int grow = piece_q ? min(q0 + piece_row[v], a.NQ - 1) : min(pn.p0 + piece_row[v], pn.NP - 1);
+            if (EPI == EPI_LINEAR && piece_q) grow = q_phys(a, grow);
             out[v] = (piece_q ? a.Q + int64_t(grow) * a.ldq : pn.P + int64_t(grow) * pn.ldp) + koff + piece_sc[v] * 8;
         }
     };
@@ -1107,8 +1155,9 @@ __global__ __launch_bounds__(S::NT, 2) void gemm_nt_wide_kernel(const GemmArgs a
             for (int i = 0; i < TP; ++i)
 #pragma unroll
                 for (int j = 0; j < TQ; ++j) asm volatile("" ::"v"(acc[i][j]));
-        } else if (cactive) {
-            gemm_epilogue<T, EPI, S, EPI_ROWS, false>(a, cpn, acc, cq0, wp, wq, lane, lds + SLOT + (EPI_ROWS == 16 ? P_BYTES : 0), wave);
+        } else {
+            if constexpr (EPI == EPI_LINEAR) zero_pad_rows<T, S::NT, BP, BQ>(a, cpn, cq0, tid);
+            if (cactive) gemm_epilogue<T, EPI, S, EPI_ROWS, false>(a, cpn, acc, cq0, wp, wq, lane, lds + SLOT + (EPI_ROWS == 16 ? P_BYTES : 0), wave);
         }
         if (!has_next) break;
     }
@@ -1380,7 +1429,8 @@ struct LinearPost {
 };
 
 static int linear_group_launch(const char *what, const void *X, const vlmc_linear_job *jobs, int n_jobs, int dtype, int64_t M,
-                               int64_t K, int64_t ldx, void *stream, const LinearPost *post = nullptr) {
+                               int64_t K, int64_t ldx, void *stream, const LinearPost *post = nullptr, const int32_t *rowmap = nullptr,
+                               int64_t n_real = 0) {
     VLMC_REQUIRE(dtype_ok16(dtype), "%s: dtype must be VLMC_F16 or VLMC_BF16", what);
     VLMC_REQUIRE(X && jobs && n_jobs >= 1 && n_jobs <= MAXG, "%s: null pointer or bad job count (1..%d)", what, MAXG);
     VLMC_REQUIRE(M >= 0 && K > 0 && M < (int64_t(1) << 31) && K < (int64_t(1) << 31), "%s: bad shape", what);
@@ -1415,6 +1465,12 @@ static int linear_group_launch(const char *what, const void *X, const vlmc_linea
     }
     VLMC_REQUIRE(total < (int64_t(1) << 31), "%s: too many output features", what);
     if (M == 0) return VLMC_OK;
+    if (rowmap != nullptr) {                                   // the first n_real entries are computed, the other M - n_real rows of Y cleared
+        VLMC_REQUIRE(n_real >= 1 && n_real <= M, "%s: n_real must be in 1..M", what);
+        a.qmap = rowmap;
+        a.NQ = int(n_real);
+        a.nq_zero = int(M - n_real);
+    }
     if (dtype == VLMC_BF16) launch_gemm<bf16_t, EPI_LINEAR>(a, as_stream(stream));
     else launch_gemm<f16_t, EPI_LINEAR>(a, as_stream(stream));
     VLMC_HIP_CHECK_LAUNCH(what);
@@ -1439,6 +1495,12 @@ extern "C" int vlmc_linear_fwd_post(const void *X, const void *W, const void *bi
 extern "C" int vlmc_linear_fwd_group(const void *X, const vlmc_linear_job *jobs, int n_jobs, int dtype, int64_t M, int64_t K,
                                      int64_t ldx, void *stream) {
     return linear_group_launch("vlmc_linear_fwd_group", X, jobs, n_jobs, dtype, M, K, ldx, stream);
+}
+
+extern "C" int vlmc_linear_fwd_rows(const void *X, const vlmc_linear_job *jobs, int n_jobs, int dtype, int64_t M, int64_t K, int64_t ldx,
+                                    const int32_t *rowmap, int64_t n_real, void *stream) {
+    VLMC_REQUIRE(rowmap != nullptr, "vlmc_linear_fwd_rows: null row map");
+    return linear_group_launch("vlmc_linear_fwd_rows", X, jobs, n_jobs, dtype, M, K, ldx, stream, nullptr, rowmap, n_real);
 }
 
 // Split of the SYRK along the rows of X.  A Hessian of 1408 columns is 66 tiles of 128 x 128 (21 of 256 x 256) on a 256-CU

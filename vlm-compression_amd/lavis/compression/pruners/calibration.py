@@ -355,7 +355,11 @@ class TowerMemo:
                     return
                 for j, snap, o in zip(group, snaps, out.split(b, dim=0)):
                     self.entries[j] = (snap, o.detach().clone())
+                    self.bytes += o.numel() * o.element_size() + sum(v.numel() * v.element_size() for v in list(snap[0]) + list(snap[1].values())
+                                                                     if isinstance(v, torch.Tensor))
                     graph_stats["memo_recorded"] += 1
+                if self.bytes > MEMO_MAX_BYTES:
+                    self._drop()
             return
         if self.ok and self.mode == "record":
             # every block must hand its hidden states on the same way: the tensor, or a 1-tuple / 1-list of it
@@ -1097,7 +1101,8 @@ class TowerGraph:
                         return self._flat(outs[w[1]])[w[2]]
                     return w[1]
                 with torch.autocast(device_type="cuda", dtype=ctx[1], enabled=ctx[0]) if ctx[0] else contextlib.nullcontext(), \
-                        fw.invariant_linears(self.linears, roots=self.mods):
+                        fw.invariant_linears(self.linears, roots=self.mods), \
+                        fw.padded_rows({(len(crecs), tp): row_map(spec["T"], tp, x.device)}):    # the blocks' linears skip the padding rows
                     for i, (wires, kwires, _t, _l, _n) in enumerate(calls):
                         outs.append(self.mods[i](*[resolve(w) for w in wires], **{k: resolve(w) for k, w in kwires}))
                 g, lens = len(crecs), spec["T"]
@@ -1447,26 +1452,41 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
     p0 = next(model.parameters(), None)
     if merged_capture_enabled() and p0 is not None and p0.is_cuda and _CTX.later is None:
         _CTX.later = _LaterEqual()                              # (remembered tower inputs against what the merged forward feeds them)
+        keys_before = set(proxy_cache) if proxy_cache is not None else set()
         try:
             try:
                 res = _capture_merged(*args, **kw)
             except (RuntimeError, TypeError, IndexError, AssertionError, AttributeError) as e:
                 # a model whose forward does not take the stacked batch (it assumes batch 1 somewhere): its own way, per sample --
                 # if the trouble is not the merge (out of memory, a broken model) the per-sample route meets it again and raises
+                # Out of memory is not a refusal of the stacked batch, and `VLMC_STRICT=1` (CI of the engine itself) wants every such
+                # exception raised: a regression inside the merged path must not hide behind its fallback.
+                if isinstance(e, torch.cuda.OutOfMemoryError) or os.environ.get("VLMC_STRICT") == "1":
+                    raise
                 res = None
                 graph_stats["merged_capture_errors"] = graph_stats.get("merged_capture_errors", 0) + 1
-                if os.environ.get("VLMC_VERBOSE") == "1":
-                    print(f"merged capture declined ({type(e).__name__}: {e})")
+                import warnings
+                warnings.warn(f"vlmc: the stacked calibration forward was declined ({type(e).__name__}: {e}); this capture phase forwards "
+                              "one calibration batch at a time, as the reference does", RuntimeWarning)
             bad = res is not None and _CTX.later.failed()
         finally:
             _CTX.later = None
         if res is not None and not bad:
             return res
         graph_stats["merged_capture_declined"] = graph_stats.get("merged_capture_declined", 0) + 1
-        if bad:
-            for key, val in list(proxy_cache.items() if proxy_cache is not None else []):
-                if isinstance(val, TowerMemo):
+        # Whatever the declined attempt left behind must not serve the per-sample route that follows: a TowerMemo it
+        # created -- or re-recorded: `_wrap_towers` begins a stale memo anew in "record" mode -- holds outputs cut out of the merged
+        # forward, the very values the comparison has just refused (or never checked); likewise the block-0 arguments / catcher
+        # calls it noted for the next phase.  Memos that only REPLAYED during the attempt hold the previous phase's per-sample
+        # records and stay, unless a remembered input was refuted (`bad`): then every record goes, as on the per-sample route.
+        for key, val in list(proxy_cache.items() if proxy_cache is not None else []):
+            if isinstance(val, TowerMemo):
+                if bad or key not in keys_before or val.mode == "record":
                     val._drop()
+                    if key not in keys_before or val.mode == "record":
+                        del proxy_cache[key]
+            elif isinstance(key, tuple) and key and key[0] in ("calls", "block0") and (bad or key not in keys_before):
+                del proxy_cache[key]
     if done_towers and proxy_cache is not None and later_check_enabled() and p0 is not None and p0.is_cuda and _CTX.later is None:
         # what finished towers remember of the previous phase is trusted while the forwards run and verified afterwards
         _CTX.later = _LaterEqual()
@@ -2167,10 +2187,26 @@ def plan_padded(cur_in, caches, n_samples, group_max):
             sp += 8                                                   # the hooks tell the two kinds of input apart by their padded length
         dev = x0.device
         lengths = {tp: torch.tensor([T[j] for j in chunk], dtype=torch.int32, device=dev)}
+        rows = {(len(chunk), tp): row_map([T[j] for j in chunk], tp, dev)}
         if sp is not None:
             lengths[sp] = torch.tensor([S[j] for j in chunk], dtype=torch.int32, device=dev)
-        out.append((chunk, {"T": [T[j] for j in chunk], "S": [S[j] for j in chunk], "tp": tp, "sp": sp, "lengths": lengths}))
+            rows[(len(chunk), sp)] = row_map([S[j] for j in chunk], sp, dev)
+        out.append((chunk, {"T": [T[j] for j in chunk], "S": [S[j] for j in chunk], "tp": tp, "sp": sp, "lengths": lengths,
+                            "rows": rows}))
     return out
+
+
+def row_map(lengths, padded, device):
+    """(int32 device tensor [len(lengths) * padded], number of real rows) for a [samples, padded, d] stack whose sample t owns
+    its first lengths[t] token rows: the flattened indices of the real rows in order, then those of the padding rows
+    (vlmc_linear_fwd_rows computes the former and clears the latter; vlmc/forward.py: padded_rows)."""
+    import numpy as np
+    ln = np.asarray(lengths, dtype=np.int64)
+    tok = np.arange(padded, dtype=np.int64)[None, :]
+    real = tok < ln[:, None]
+    flat = (np.arange(len(ln), dtype=np.int64)[:, None] * padded + tok)
+    order = np.concatenate([flat[real], flat[~real]]).astype(np.int32)
+    return torch.from_numpy(order).to(device), int(real.sum())
 
 
 def _pad_inputs(xs, tp):
@@ -2437,7 +2473,8 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                     _CTX.stacked, _CTX.stacked_lengths = (len(chunk), 1, key), spec["lengths"]
                     graph_stats["padded_forwards"] = graph_stats.get("padded_forwards", 0) + 1
                     try:
-                        y = layer(x, **kw)
+                        with forward.padded_rows(spec.get("rows")):       # the block's linears skip the padding rows
+                            y = layer(x, **kw)
                     except _TailStop:
                         continue
                     finally:

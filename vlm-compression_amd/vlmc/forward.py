@@ -37,7 +37,7 @@ _active = 0
 stats = {"kernel": 0, "library": 0, "grouped_launches": 0, "served_from_group": 0, "stash_dropped": 0, "attn_kernel": 0,
          "attn_library": 0, "mean_kernel": 0, "sdpa_kernel": 0, "sdpa_library": 0, "norm_kernel": 0, "softmax_kernel": 0,
          "attn_fused": 0, "attn_chain_unfused": 0, "attn_fused_checks": 0, "linear_post": 0, "linear_lazy_unfused": 0,
-         "linear_post_checks": 0, "gelu_kernel": 0}
+         "linear_post_checks": 0, "gelu_kernel": 0, "kernel_rows": 0}
 
 # first member of a learned sibling group -> tuple of weak references to all members, in call order
 _SIBLINGS = weakref.WeakKeyDictionary()
@@ -67,9 +67,48 @@ def _prepare(x, weight, bias):
     return None
 
 
+# ---- a PADDED group of ragged calibration samples: the linears skip the padding rows ------------------------------------------
+# `calibration.walk_blocks` forwards ragged samples of a block as ONE [samples, longest, d] batch (zero rows behind a sample's own,
+# masks at the dtype's minimum).  On the bench's ragged set (prompts of 8..128 tokens) more than half of those rows are padding, and
+# the linears are where a block's time goes.  While such a forward runs, `_ROW_MAPS` maps (samples, padded tokens) to the row map of
+# that layout (real rows first; built by calibration.plan_padded): a linear whose input has that leading shape runs on
+# `vlmc_linear_fwd_rows` -- padding rows are neither loaded nor multiplied, and come out as zeros, so they stay zero through the
+# whole block (every op of a block is row-wise but attention, which masks the padded keys).  A sample's own rows keep the bits of
+# its own forward (tests/test_gemm_gpu.py).  `VLMC_ROW_MAP=0`: every row is computed, as before round 6.
+_ROW_MAPS = None
+
+
+def row_map_enabled():
+    return os.environ.get("VLMC_ROW_MAP", "1") != "0"
+
+
+@contextlib.contextmanager
+def padded_rows(maps):
+    """`maps`: {(samples, padded tokens): (int32 device tensor [samples * padded tokens], number of real rows)} or None."""
+    global _ROW_MAPS
+    prev = _ROW_MAPS
+    _ROW_MAPS = maps if (maps and row_map_enabled()) else None
+    try:
+        yield
+    finally:
+        _ROW_MAPS = prev
+
+
+def _rows_for(x):
+    return _ROW_MAPS.get((x.shape[0], x.shape[1])) if x.dim() == 3 else None
+
+
 def linear(x, weight, bias=None):
     """`F.linear` for a calibration forward: the invariant kernel when the replay engine asked for it and the call fits."""
     if _active and not torch.is_grad_enabled() and weight.is_cuda:
+        if _ROW_MAPS is not None:
+            rm = _rows_for(x)
+            if rm is not None:
+                p = _prepare(x, weight, bias)
+                if p is not None:
+                    stats["kernel"] += 1
+                    stats["kernel_rows"] += 1
+                    return ops.linear_fwd_rows(p[0], [weight], [p[1]], rm[0], rm[1])[0]
         if not torch.is_autocast_enabled():
             y = ops.linear_fwd(x, weight, bias, _try=True)           # (the entry point checks; None: not one it takes)
             if y is not None:
@@ -191,7 +230,12 @@ class _Tracker:
                             break
                         biases.append(b)
                     if ok:
-                        outs = ops.linear_fwd_group(xin, [g.weight for g in group], biases, _checked=True)
+                        rm = _rows_for(xin) if _ROW_MAPS is not None else None
+                        if rm is not None:                       # a padded group of ragged samples: the padding rows are skipped
+                            outs = ops.linear_fwd_rows(xin, [g.weight for g in group], biases, rm[0], rm[1])
+                            stats["kernel_rows"] += len(group)
+                        else:
+                            outs = ops.linear_fwd_group(xin, [g.weight for g in group], biases, _checked=True)
                         stats["kernel"] += len(group)
                         stats["grouped_launches"] += 1
                         for g, y in zip(group[1:], outs[1:]):
@@ -202,7 +246,8 @@ class _Tracker:
 
     def single(self, mod, x):
         """A linear on its own: answered lazily when the op that follows may fold into its epilogue (LazyLinear)."""
-        if self.post and _POST.get(mod) is not False and not torch.is_grad_enabled() and mod.weight.is_cuda:
+        if self.post and _POST.get(mod) is not False and not torch.is_grad_enabled() and mod.weight.is_cuda and \
+                (_ROW_MAPS is None or _rows_for(x) is None):
             if torch.is_autocast_enabled():
                 p = _prepare(x, mod.weight, mod.bias)
             else:

@@ -219,6 +219,39 @@ def linear_fwd_group(x: torch.Tensor, weights, biases=None, _checked: bool = Fal
     return [y.reshape(*lead, y.shape[1]) for y in outs]
 
 
+def linear_fwd_rows(x: torch.Tensor, weights, biases, rowmap: torch.Tensor, n_real: int) -> list:
+    """[x @ w.T + b for w, b in zip(weights, biases)] over the rows `rowmap[:n_real]` of the flattened x only; rows
+    `rowmap[n_real:]` of every output are zeros (include/vlmc.h: vlmc_linear_fwd_rows).  x [.., K] flattens to M rows; `rowmap`:
+    int32 device tensor [M], a permutation of 0 .. M - 1 with the rows that are real first (a padded group of ragged calibration
+    samples: calibration.plan_padded builds it).  A computed row has the bits `linear_fwd` gives it."""
+    n = len(weights)
+    if biases is None:
+        biases = [None] * n
+    if not 1 <= n <= LINEAR_GROUP_MAX or len(biases) != n:
+        raise ValueError(f"linear_fwd_rows takes 1..{LINEAR_GROUP_MAX} weights and as many biases")
+    _need_gpu(x, rowmap, *weights, *[b for b in biases if b is not None])
+    for w, b in zip(weights, biases):
+        if not linear_fwd_supported(x, w, b):
+            raise TypeError("vlmc.linear_fwd_rows: fp16/bf16 tensors of one dtype with in_features % 8 == 0 expected")
+    K = weights[0].shape[1]
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1 or x2.stride(0) % 8 != 0 or x2.stride(0) < K or x2.data_ptr() % 16 != 0:
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    if rowmap.dtype != torch.int32 or rowmap.dim() != 1 or rowmap.shape[0] != M or not rowmap.is_contiguous() or not 1 <= n_real <= M:
+        raise ValueError("vlmc.linear_fwd_rows: rowmap must be a contiguous int32 [rows of x] tensor and 1 <= n_real <= rows")
+    jobs = (_lib.LinearJob * n)()
+    outs = []
+    for g, (w, b) in enumerate(zip(weights, biases)):
+        y = torch.empty((M, w.shape[0]), dtype=x.dtype, device=x.device)
+        jobs[g] = _lib.LinearJob(w.data_ptr(), b.data_ptr() if b is not None else None, y.data_ptr(), w.shape[0], w.stride(0), w.shape[0])
+        outs.append(y)
+    _lib.check(_lib.load().vlmc_linear_fwd_rows(x2.data_ptr(), jobs, n, _DT[x.dtype], M, K, x2.stride(0), rowmap.data_ptr(), int(n_real),
+                                                _stream()))
+    lead = x.shape[:-1]
+    return [y.reshape(*lead, y.shape[1]) for y in outs]
+
+
 _16BIT = (torch.float16, torch.bfloat16)
 
 

@@ -125,7 +125,9 @@ def gather_stats(stats, group=None):
         gathered = flat.repeat(world, 1)                               # one rank rehearsing W: its own rows W times
     else:
         gathered = torch.empty((world * n_local, flat.shape[1]), dtype=flat.dtype, device=flat.device)
-        dist.all_gather_into_tensor(gathered, flat, group=group)       # rank-major == sample order
+        from . import phases
+        with phases.phase("exchange"):                                 # (a timer only under VLMC_PHASE_TIMERS=1: bench.py's sub-totals)
+            dist.all_gather_into_tensor(gathered, flat, group=group)   # rank-major == sample order
     parts, off = [], 0
     for st in stats:
         parts.append(gathered[:, off:off + st.in_features])            # column slices: the kernel takes a row stride
