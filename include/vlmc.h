@@ -360,6 +360,16 @@ int vlmc_attn_fwd(const void *Q, const void *K, const void *V, void *O, int dtyp
                   int has_mul, float mul, const void *add0, const int64_t *add0_strides, const void *add1,
                   const int64_t *add1_strides, void *stream);
 
+/* vlmc_attn_fwd for a PADDED group of ragged calibration samples (the reference forwards every sample alone,
+ * wanda_pruner.py:308-311: all its tokens are real).  q_len / k_len: device int32 [batch] or NULL.  k_len[b] = the keys of batch entry b
+ * that are real; the caller vouches that an addend masks every key behind them (the dtype's minimum: probability exactly 0), so their
+ * tiles are neither staged nor multiplied -- the live rows keep the bits vlmc_attn_fwd gives them (a masked key adds +0 to a sum and 0 . v
+ * to a product).  q_len[b] = its real queries; output rows behind them are written as ZEROS.  k_len needs add0.                       */
+int vlmc_attn_fwd_lens(const void *Q, const void *K, const void *V, void *O, int dtype, int64_t batch, int64_t heads, int64_t Tq,
+                       int64_t Tk, int64_t head_dim, const int64_t *q_strides, const int64_t *k_strides, const int64_t *v_strides,
+                       int has_mul, float mul, const void *add0, const int64_t *add0_strides, const void *add1,
+                       const int64_t *add1_strides, const int32_t *q_len, const int32_t *k_len, void *stream);
+
 /* ---- the RMS norm of a language-model block in one launch ---------------------------------------------
  * Replaces the op sequence of transformers' T5LayerNorm.forward / LlamaRMSNorm.forward inside a replayed block
  *     variance = x.to(torch.float32).pow(2).mean(-1, keepdim=True);  h = (x * torch.rsqrt(variance + eps)).to(dtype);  y = weight * h

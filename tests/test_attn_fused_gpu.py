@@ -154,6 +154,49 @@ def test_a_sample_has_the_same_bits_alone_in_a_group_and_padded():
     assert torch.equal(_bits(grouped), _bits(_unfused(pad(qs), pad(ks), pad(vs), adds=[full], f32_softmax=True)))
 
 
+@pytest.mark.parametrize("dtype,H,d,lens_q,lens_k,nadd", [
+    (torch.bfloat16, 32, 64, [40, 160, 48, 96, 33], None, 1),                 # T5 encoder self-attention, ragged (keys = queries)
+    (torch.bfloat16, 32, 64, [4, 16, 8, 16, 1], [40, 160, 48, 96, 33], 2),    # T5 cross-attention: ragged answers over ragged prompts
+    (torch.float16, 12, 64, [40, 64, 33], None, 1),                           # Q-Former self-attention with text
+    (torch.float16, 16, 88, [257, 100, 17], None, 1),                         # head_dim 88, three K-steps along d, the 8-wave kernel
+])
+def test_lengths_skip_the_padding_and_keep_the_live_bits(dtype, H, d, lens_q, lens_k, nadd):
+    """vlmc_attn_fwd_lens: with per-sample key / query counts the masked keys are neither staged nor multiplied and the padding
+    queries come out as zeros; every live row has the bits of the launch without lengths (and therefore of the sample alone)."""
+    ops = _ops()
+    g = _gen(17 + d)
+    lens_k = lens_q if lens_k is None else lens_k
+    B, Tq, Tk = len(lens_q), max(lens_q), max(lens_k)
+    q = _heads(B, Tq, H, d, dtype, g, 0.6)
+    k = _heads(B, Tk, H, d, dtype, g, 0.6)
+    v = _heads(B, Tk, H, d, dtype, g)
+    for i in range(B):                                                       # padding rows hold zeros, as the row-mapped linears leave them
+        q[i, :, lens_q[i]:] = 0
+        k[i, :, lens_k[i]:] = 0
+        v[i, :, lens_k[i]:] = 0
+    mask = torch.zeros(B, 1, 1, Tk, dtype=dtype, device=DEV)
+    for i, n in enumerate(lens_k):
+        mask[i, ..., n:] = torch.finfo(dtype).min
+    bias = torch.randn(1, H, Tq, Tk, generator=g, device=DEV).to(dtype)
+    adds = [bias + mask] if nadd == 1 else [bias, mask]
+    ql = torch.tensor(lens_q, dtype=torch.int32, device=DEV)
+    kl = torch.tensor(lens_k, dtype=torch.int32, device=DEV)
+    full = ops.attn_fused(q, k, v, None, adds)
+    for kw in (dict(q_len=ql, k_len=kl), dict(k_len=kl), dict(q_len=ql)):
+        cut = ops.attn_fused(q, k, v, None, adds, **kw)
+        for i in range(B):
+            nq = lens_q[i]
+            assert torch.equal(_bits(cut[i, :, :nq]), _bits(full[i, :, :nq])), (kw.keys(), i)
+            if "q_len" in kw:
+                assert bool((_bits(cut[i, :, nq:]) == 0).all()), "a padding query is not +0"
+            else:
+                assert torch.equal(_bits(cut[i, :, nq:]), _bits(full[i, :, nq:]))
+    with pytest.raises(ValueError):
+        ops.attn_fused(q, k, v, None, [], k_len=kl)                          # nothing masks the skipped keys
+    with pytest.raises(TypeError):
+        ops.attn_fused(q, k, v, None, adds, k_len=kl.long())
+
+
 def test_operands_are_read_in_place_through_their_strides():
     ops = _ops()
     g = _gen(3)

@@ -201,7 +201,14 @@ def test_ragged_samples_padded_into_one_group_keep_their_bits(lora_model, monkey
     monkeypatch.delenv("VLMC_CAPTURE_MERGED_RAGGED")
     # (ragged batches: the groups' merged forwards are postponed at the finished towers, which run once, padded, for all samples)
     assert calibration.graph_stats.get("merged_forwards", 0) > before_m and n_m == 2 * 2 * 3, calibration.graph_stats
+    rows0, lens0 = forward.stats["kernel_rows"], forward.stats["attn_fused_lens"]
     padded, n_padded, n_softmax = run(base)
+    # (round 6) inside the padded groups the linears ran over the row map and the fused attention took the samples' lengths ...
+    assert forward.stats["kernel_rows"] > rows0 and forward.stats["attn_fused_lens"] > lens0, forward.stats
+    rows1 = forward.stats["kernel_rows"]
+    every_row, n_er, _ = run({**base, "VLMC_ROW_MAP": "0"})                  # ... and with every padding row computed, as in round 5: same bits
+    assert forward.stats["kernel_rows"] == rows1 and n_er == n_padded
+    monkeypatch.delenv("VLMC_ROW_MAP")
     # .. and the finished encoder tower ran ONE padded stacked pass for the samples behind the scout's group while the decoder's
     # inputs were captured (TowerGraph._run_padded)
     assert seen["tower_padded"] >= 1, seen
@@ -213,7 +220,7 @@ def test_ragged_samples_padded_into_one_group_keep_their_bits(lora_model, monkey
     assert padded.keys() == shaped.keys() == single.keys() and len(padded) == 2 * 4 + 3 * 7 + 3 * 11
     for k in padded:
         for other, name in ((shaped, "groups of equal shapes"), (single, "per-sample loop"), (towers_per_length, "towers per token count"),
-                            (merged, "merged capture forwards")):
+                            (merged, "merged capture forwards"), (every_row, "padding rows computed")):
             assert torch.equal(padded[k][0], other[k][0]), (k, name)
             assert (padded[k][1] is None and other[k][1] is None) or torch.equal(padded[k][1], other[k][1]), (k, name)
 

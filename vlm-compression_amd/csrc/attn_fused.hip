@@ -17,6 +17,14 @@ extern "C" int vlmc_attn_fwd(const void *Q, const void *K, const void *V, void *
                              int64_t Tk, int64_t head_dim, const int64_t *q_strides, const int64_t *k_strides, const int64_t *v_strides,
                              int has_mul, float mul, const void *add0, const int64_t *add0_strides, const void *add1,
                              const int64_t *add1_strides, void *stream) {
+    return vlmc_attn_fwd_lens(Q, K, V, O, dtype, batch, heads, Tq, Tk, head_dim, q_strides, k_strides, v_strides, has_mul, mul, add0,
+                              add0_strides, add1, add1_strides, nullptr, nullptr, stream);
+}
+
+extern "C" int vlmc_attn_fwd_lens(const void *Q, const void *K, const void *V, void *O, int dtype, int64_t batch, int64_t heads, int64_t Tq,
+                                  int64_t Tk, int64_t head_dim, const int64_t *q_strides, const int64_t *k_strides,
+                                  const int64_t *v_strides, int has_mul, float mul, const void *add0, const int64_t *add0_strides,
+                                  const void *add1, const int64_t *add1_strides, const int32_t *q_len, const int32_t *k_len, void *stream) {
     VLMC_REQUIRE(dtype == VLMC_F16 || dtype == VLMC_BF16, "vlmc_attn_fwd: dtype must be VLMC_F16 or VLMC_BF16");
     VLMC_REQUIRE(Q && K && V && O && q_strides && k_strides && v_strides, "vlmc_attn_fwd: null pointer");
     VLMC_REQUIRE(batch > 0 && heads > 0 && Tq > 0 && Tk > 0, "vlmc_attn_fwd: empty problem");
@@ -54,6 +62,8 @@ extern "C" int vlmc_attn_fwd(const void *Q, const void *K, const void *V, void *
     }
     a.H = int(heads), a.Tq = int(Tq), a.Tk = int(Tk), a.d = int(head_dim);
     a.has_mul = has_mul, a.mul = mul;
+    VLMC_REQUIRE(k_len == nullptr || add0 != nullptr, "vlmc_attn_fwd_lens: k_len needs an addend that masks the keys behind it");
+    a.qlen = q_len, a.klen = k_len;
     // a head's queries on several workgroups once there are many (each stages K and V again): blocks of 16 queries, ~6 per wave
     a.nblk = int((Tq + 15) / 16);
     a.bpw = 6;

@@ -43,6 +43,10 @@ struct AttnArgs {
     int dma;                    // K and V rows are 16-byte aligned: staged by LDS-DMA
     int has_mul;
     float mul;
+    // a PADDED group of ragged samples (vlmc_attn_fwd_lens), either may be NULL: klen[b] = the keys of batch entry b that are real -- the
+    // caller vouches that every key behind them is masked out by an addend (probability exactly 0): their tiles are neither staged nor
+    // multiplied; qlen[b] = its real queries: the rows behind them are written as zeros, not computed
+    const int32_t *qlen, *klen;
 };
 
 typedef short af_s16x4_t __attribute__((ext_vector_type(4)));
@@ -87,21 +91,23 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_fused_kernel(const AttnArg
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, c = lane >> 4;
     const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
-    const int KT = ((a.Tk + 31) >> 5) << 1;                                   // key tiles, even (K-steps of 32 keys)
+    const int image = ((((a.Tk + 31) >> 5) << 5) * RS + 1023) & ~1023;         // (the layout is the launch's: lengths only shorten the loops)
+    const int Tk = a.klen != nullptr ? max(1, min(a.Tk, a.klen[b])) : a.Tk;  // this batch entry's live keys
+    const int Tql = a.qlen != nullptr ? max(0, min(a.Tq, a.qlen[b])) : a.Tq; // .. and live queries
+    const int KT = ((Tk + 31) >> 5) << 1;                                     // key tiles, even (K-steps of 32 keys)
     const int rows = KT * 16;
-    const int image = (rows * RS + 1023) & ~1023;
     unsigned char *lk = lds, *lv = lds + image, *lp = lds + 2 * image + wave * kAttnScratch;
     const uint16_t *Kp = a.K + int64_t(b) * a.sk_b + int64_t(h) * a.sk_h;
     const uint16_t *Vp = a.V + int64_t(b) * a.sv_b + int64_t(h) * a.sv_h;
     // ---- the head's K and V into LDS, zero where there is no key / no d -------------------------------------------------
     if (a.dma) {
         constexpr int SPR = RS / 16;
-        const int total = image / 16;
+        const int total = (rows * RS + 1023) / 1024 * 64;                      // 16-byte pieces, whole wave-instructions
         const uint32_t lds_k = uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)lk));
         const uint32_t lds_v = uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)lv));
         for (int base = wave * 64; base < total; base += NT) {
             const int j = base + lane, r = j / SPR, ch = j - r * SPR;
-            const bool in = r < a.Tk && ch * 8 < a.d;
+            const bool in = r < Tk && ch * 8 < a.d;
             const void *srck = in ? static_cast<const void *>(Kp + int64_t(r) * a.sk_t + ch * 8) : static_cast<const void *>(attn_zero_chunk);
             const void *srcv = in ? static_cast<const void *>(Vp + int64_t(r) * a.sv_t + ch * 8) : static_cast<const void *>(attn_zero_chunk);
             attn_glds16(srck, __builtin_amdgcn_readfirstlane(lds_k + base * 16));
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_fused_kernel(const AttnArg
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int i = base + j * NT, r = i / CPR, ch = i - r * CPR;
-                const bool in = i < total && r < a.Tk && ch * 8 < a.d;
+                const bool in = i < total && r < Tk && ch * 8 < a.d;
                 kv[j] = in ? attn_load16(Kp + int64_t(r) * a.sk_t + ch * 8) : zero;
                 vv[j] = in ? attn_load16(Vp + int64_t(r) * a.sv_t + ch * 8) : zero;
             }
@@ -146,6 +152,17 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_fused_kernel(const AttnArg
         const int q0 = blk * 16;
         const int q = q0 + l15;
         const bool qlive = q < a.Tq;
+        if (q0 >= Tql) {                                                      // a block of padding queries: zeros, nothing computed
+            if (qlive) {
+                uint16_t *orow = Op + int64_t(q) * a.so_t;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const int e0 = 16 * dt + 4 * c;
+                    if (e0 < a.d) *reinterpret_cast<AU16x4 *>(orow + e0) = AU16x4{0u, 0u};
+                }
+            }
+            continue;
+        }
         const int qc = qlive ? q : a.Tq - 1;                                  // (rows past the end repeat the last: never stored)
         // ---- Q: B operand of S^T, lane (query l15, d chunk c) ------------------------------------------------------------
         u32x4_t fq[DS];
@@ -212,7 +229,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_fused_kernel(const AttnArg
                     asm volatile("" : "+v"(t));
                     s = attn_round<T>(t);
                 }
-                s = 16 * kt + 4 * c + g < a.Tk ? s : ninf;                    // keys of the padding
+                s = 16 * kt + 4 * c + g < Tk ? s : ninf;                      // keys of the padding
                 acc[kt][g] = s;
                 m = fmaxf(m, s);
             }
@@ -286,7 +303,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_fused_kernel(const AttnArg
                 if (e0 >= a.d) continue;
                 uint16_t e[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) e[g] = from_f32<T>(oacc[dt][g]);
+                for (int g = 0; g < 4; ++g) e[g] = q < Tql ? from_f32<T>(oacc[dt][g]) : uint16_t(0);     // (padding queries of a live block: zeros)
                 AU16x4 v;
                 __builtin_memcpy(&v, e, 8);
                 *reinterpret_cast<AU16x4 *>(orow + e0) = v;

@@ -1102,7 +1102,8 @@ class TowerGraph:
                     return w[1]
                 with torch.autocast(device_type="cuda", dtype=ctx[1], enabled=ctx[0]) if ctx[0] else contextlib.nullcontext(), \
                         fw.invariant_linears(self.linears, roots=self.mods), \
-                        fw.padded_rows({(len(crecs), tp): row_map(spec["T"], tp, x.device)}):    # the blocks' linears skip the padding rows
+                        fw.padded_rows({(len(crecs), tp): row_map(spec["T"], tp, x.device)},
+                                       {tp: torch.tensor(spec["T"], dtype=torch.int32, device=x.device)}):   # linears and attention skip the padding rows
                     for i, (wires, kwires, _t, _l, _n) in enumerate(calls):
                         outs.append(self.mods[i](*[resolve(w) for w in wires], **{k: resolve(w) for k, w in kwires}))
                 g, lens = len(crecs), spec["T"]
@@ -1659,10 +1660,11 @@ def _capture_merged(model, batches, module_to_process, forward_to_cache, lora_mo
         # forward is postponed at a finished tower's first block, the tower runs ONCE, padded, for the samples of all groups
         # (TowerGraph.enter_group -> run_deferred -> _run_padded) and the groups' forwards are repeated.
         defer = len(order) > 2
-        if defer and not (os.environ.get("VLMC_CAPTURE_MERGED_RAGGED", "0") == "1" and tower_pad_enabled() and tower_graph_enabled()):
-            # (off by default: with it the encoder's phase of the ragged reference-op prune is 55-59 ms instead of 100 in the
-            # synchronising phase timers, but the whole prune is level -- 486 / 494 against 477 ms, tools/ragged_time.py -- because
-            # the per-sample Python it removes ran behind the GPU tail of the preceding walk anyway)
+        if defer and not (os.environ.get("VLMC_CAPTURE_MERGED_RAGGED", "1") == "1" and tower_pad_enabled() and tower_graph_enabled()):
+            # (on since round 6: the encoder's phase of the ragged reference-op prune is 55-59 ms instead of 100 in the synchronising
+            # phase timers.  In round 5 the whole prune was level with it -- the per-sample Python it removes ran behind the GPU tail of
+            # the preceding walk -- but with the linears skipping the padding rows that tail is shorter and the host shows: 479 -> 463 ms,
+            # same box, tools/ragged_prof.py)
             return None
         if defer and any(not t.memo_serves and t.path not in FROZEN_TOWERS for t in towers):
             # ragged batches and a PRUNED tower on the way whose outputs are not remembered (the decoder's phase: 24 encoder blocks):
@@ -2473,7 +2475,7 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                     _CTX.stacked, _CTX.stacked_lengths = (len(chunk), 1, key), spec["lengths"]
                     graph_stats["padded_forwards"] = graph_stats.get("padded_forwards", 0) + 1
                     try:
-                        with forward.padded_rows(spec.get("rows")):       # the block's linears skip the padding rows
+                        with forward.padded_rows(spec.get("rows"), spec["lengths"]):     # linears and attention skip the padding rows
                             y = layer(x, **kw)
                     except _TailStop:
                         continue

@@ -81,6 +81,7 @@ SIGNATURES = {
     "vlmc_softmax_rows": (_i, [_p, _i, _i64, _i64, _i64, _p, _i, _i64, _p]),
     "vlmc_attn_max_keys": (_i, [_i64]),
     "vlmc_attn_fwd": (_i, [_p, _p, _p, _p, _i] + [_i64] * 5 + [_p, _p, _p, _i, _c.c_float, _p, _p, _p, _p, _p]),
+    "vlmc_attn_fwd_lens": (_i, [_p, _p, _p, _p, _i] + [_i64] * 5 + [_p, _p, _p, _i, _c.c_float, _p, _p, _p, _p, _p, _p, _p]),
     "vlmc_rms_norm": (_i, [_p, _i, _i64, _i64, _i64, _p, _c.c_float, _i, _p, _i64, _p]),
     "vlmc_sdpa_max_keys": (_i, [_i64]),
     "vlmc_sdpa_fwd": (_i, [_p, _p, _p, _p, _i] + [_i64] * 17 + [_c.c_float, _i, _p]),

@@ -37,7 +37,7 @@ _active = 0
 stats = {"kernel": 0, "library": 0, "grouped_launches": 0, "served_from_group": 0, "stash_dropped": 0, "attn_kernel": 0,
          "attn_library": 0, "mean_kernel": 0, "sdpa_kernel": 0, "sdpa_library": 0, "norm_kernel": 0, "softmax_kernel": 0,
          "attn_fused": 0, "attn_chain_unfused": 0, "attn_fused_checks": 0, "linear_post": 0, "linear_lazy_unfused": 0,
-         "linear_post_checks": 0, "gelu_kernel": 0, "kernel_rows": 0}
+         "linear_post_checks": 0, "gelu_kernel": 0, "kernel_rows": 0, "attn_fused_lens": 0}
 
 # first member of a learned sibling group -> tuple of weak references to all members, in call order
 _SIBLINGS = weakref.WeakKeyDictionary()
@@ -82,16 +82,34 @@ def row_map_enabled():
     return os.environ.get("VLMC_ROW_MAP", "1") != "0"
 
 
+_PAD_LENGTHS = None           # {padded tokens: int32 device tensor [samples]}: each sample's own token rows (the fused attention skips the rest)
+
+
 @contextlib.contextmanager
-def padded_rows(maps):
-    """`maps`: {(samples, padded tokens): (int32 device tensor [samples * padded tokens], number of real rows)} or None."""
-    global _ROW_MAPS
-    prev = _ROW_MAPS
-    _ROW_MAPS = maps if (maps and row_map_enabled()) else None
+def padded_rows(maps, lengths=None):
+    """`maps`: {(samples, padded tokens): (int32 device tensor [samples * padded tokens], number of real rows)} or None;
+    `lengths`: {padded tokens: int32 device tensor [samples]} or None -- what the fused attention takes as q_len / k_len."""
+    global _ROW_MAPS, _PAD_LENGTHS
+    prev = _ROW_MAPS, _PAD_LENGTHS
+    on = row_map_enabled()
+    _ROW_MAPS = maps if (maps and on) else None
+    _PAD_LENGTHS = lengths if (lengths and on) else None
     try:
         yield
     finally:
-        _ROW_MAPS = prev
+        _ROW_MAPS, _PAD_LENGTHS = prev
+
+
+def _pad_lengths(q, k, adds):
+    """(q_len, k_len) for `ops.attn_fused` inside a padded group: the samples' own query / key counts where the operands' token
+    counts are a padded length of the group (k_len only with an addend: the mask that hides the padding keys)."""
+    ql = _PAD_LENGTHS.get(q.shape[2])
+    kl = _PAD_LENGTHS.get(k.shape[2]) if adds else None
+    if ql is not None and ql.shape[0] != q.shape[0]:
+        ql = None
+    if kl is not None and kl.shape[0] != k.shape[0]:
+        kl = None
+    return ql, kl
 
 
 def _rows_for(x):
@@ -711,6 +729,7 @@ def _lazy_matmul(a, b, matmul):
         if plan is not None:
             sig = _chain_signature(a, b)
             ok = _FUSED_OK.get(sig)
+            ql, kl = _pad_lengths(a._q, k, a._adds) if _PAD_LENGTHS is not None else (None, None)
             if ok is None and not torch.cuda.is_current_stream_capturing():
                 fused = ops.attn_fused(a._q, k, b, a._mul, a._adds, plan)
                 ref = matmul(a._realize(), b)
@@ -728,6 +747,9 @@ def _lazy_matmul(a, b, matmul):
             if ok:
                 stats["attn_fused"] += 1
                 a._consumed = True
+                if ql is not None or kl is not None:
+                    stats["attn_fused_lens"] += 1
+                    return ops.attn_fused(a._q, k, b, a._mul, a._adds, plan, ql, kl)
                 return ops.attn_fused(a._q, k, b, a._mul, a._adds, plan)
     return matmul(a._realize(), b)
 

@@ -494,13 +494,15 @@ def _add_strides(t, B, H, Tq):
     return _I64x4(*(0 if n == 1 else s for n, s in zip(sh[:3], st[:3])), max(1, st[3]))
 
 
-def attn_fused(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mul=None, adds=(), _plan=None) -> torch.Tensor:
+def attn_fused(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mul=None, adds=(), _plan=None, q_len=None, k_len=None) -> torch.Tensor:
     """The reference-op attention chain in one launch (include/vlmc.h: vlmc_attn_fwd):
         s = q @ k^T;  [s = s * mul];  [s = s + adds[0] [+ adds[1]]];  p = softmax in fp32, rounded;  out = p @ v
     every intermediate rounded to the dtype where the tensor op would round it -- the bits of the unfused sequence on
     `attn_matmul`, torch's elementwise ops and `softmax_rows`.  Returns [B, H, Tq, d] as a VIEW of a contiguous [B, Tq, H, d]
-    tensor (the model's `.transpose(1, 2).reshape(B, Tq, H * d)` is free).  `mul`: a Python float already rounded to fp32."""
-    _need_gpu(q, k, v)
+    tensor (the model's `.transpose(1, 2).reshape(B, Tq, H * d)` is free).  `mul`: a Python float already rounded to fp32.
+    `q_len` / `k_len` (int32 device tensors [B], a padded group of ragged samples): output rows behind q_len[b] are zeros; keys
+    behind k_len[b] -- which an addend must mask -- are skipped (include/vlmc.h: vlmc_attn_fwd_lens)."""
+    _need_gpu(q, k, v, q_len, k_len)
     plan = _plan if _plan is not None else attn_fused_plan(q, k, v, adds)
     if plan is None:
         raise TypeError("vlmc.attn_fused: q [B, H, Tq, d], k, v [B, H, Tk, d] of one 16-bit dtype with unit stride along d, at most "
@@ -509,11 +511,17 @@ def attn_fused(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mul=None, adds
     out = torch.empty((B, Tq, H, d), dtype=q.dtype, device=q.device)
     a0 = adds[0] if len(adds) > 0 else None
     a1 = adds[1] if len(adds) > 1 else None
-    _lib.check(_lib.load().vlmc_attn_fwd(
+    for ln in (q_len, k_len):
+        if ln is not None and (ln.dtype != torch.int32 or ln.shape != (B,) or not ln.is_contiguous()):
+            raise TypeError("vlmc.attn_fused: q_len / k_len must be contiguous int32 [batch] tensors")
+    if k_len is not None and a0 is None:
+        raise ValueError("vlmc.attn_fused: k_len needs an addend that masks the keys behind it")
+    _lib.check(_lib.load().vlmc_attn_fwd_lens(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _DT[q.dtype], B, H, Tq, Tk, d, _I64x3(*q.stride()[:3]),
         _I64x3(*k.stride()[:3]), _I64x3(*v.stride()[:3]), 0 if mul is None else 1, 0.0 if mul is None else float(mul),
         None if a0 is None else a0.data_ptr(), None if a0 is None else _add_strides(a0, B, H, Tq),
-        None if a1 is None else a1.data_ptr(), None if a1 is None else _add_strides(a1, B, H, Tq), _stream()))
+        None if a1 is None else a1.data_ptr(), None if a1 is None else _add_strides(a1, B, H, Tq),
+        None if q_len is None else q_len.data_ptr(), None if k_len is None else k_len.data_ptr(), _stream()))
     return out.permute(0, 2, 1, 3)
 
 
