@@ -436,10 +436,20 @@ int vlmc_chol_inverse(const float *A, int64_t n, int64_t lda, float *M, int64_t 
  * unstructured mask (1 = prune; sparsegpt_pruner.py:180-185; ignored for n:m), mask_out
  * (optional) receives the final pruned mask of the block.  Elementwise IEEE fp32 in the
  * reference's operation order: bit-exact given the same factor.  The caller applies the
- * trailing update W[:, i2:] -= Err1 @ U[i1:i2, i2:] (:210) with a library GEMM.            */
+ * trailing update W[:, i2:] -= Err1 @ U[i1:i2, i2:] (:210) with vlmc_sparsegpt_trailing_update.   */
 int vlmc_sparsegpt_sweep(float *W, int64_t out_features, int64_t count, int64_t ldw, const float *U1, int64_t ldu,
                          const uint8_t *mask1, int64_t ldm, int prune_n, int prune_m, float *Err1, int64_t lde,
                          uint8_t *mask_out, int64_t ldmo, void *stream);
+
+/* K10: the trailing update that follows a block's sweep, `W[:, i2:] -= Err1.matmul(Hinv[i1:i2, i2:])` (sparsegpt_pruner.py:210), on
+ * fp32 matrix cores (v_mfma_f32_32x32x2_f32) instead of a GEMM library call:
+ *     W[r, c] -= sum_{k < count} Err1[r, k] * U[k, c]        r < out_features, c < ncols
+ * W: pointer at the first column to update (row stride ldw); Err1 [out_features, count] as vlmc_sparsegpt_sweep wrote it (row stride
+ * lde); U: pointer at U[i1, first column] (row stride ldu); count <= 128 (the block).  One accumulator per element over the block's k in
+ * ascending pairs, then one subtraction: an element's result does not depend on which columns share the launch, so a caller may update
+ * the next block's columns first and the rest beside the next sweep (vlmc/sparsegpt.py) and get the same bits as one launch.       */
+int vlmc_sparsegpt_trailing_update(float *W, int64_t out_features, int64_t ncols, int64_t ldw, const float *Err1, int64_t lde,
+                                   const float *U, int64_t ldu, int64_t count, void *stream);
 
 /* vlmc_sparsegpt_select_sweep: unstructured mode, the block's threshold AND its sweep in one launch
  * (sparsegpt_pruner.py:183-205):

@@ -490,3 +490,62 @@ def test_persistent_factorization_equals_the_chain_and_any_workgroup_count(n):
     finally:
         SG._PERSISTENT = True
     assert int(info) == int(info_c)
+
+
+# ---- K10 on fp32 matrix cores (round 6): vlmc_sparsegpt_trailing_update and the look-ahead around it -------------------------------
+@pytest.mark.parametrize("rows,ncols,count", [(1, 1, 1), (37, 5, 128), (128, 128, 128), (300, 1000, 96), (2048, 4992, 128), (10240, 1920, 128),
+                                              (130, 257, 127)])
+def test_trailing_update_matches_fp64(rows, ncols, count):
+    """`W[:, i2:] -= Err1.matmul(Hinv[i1:i2, i2:])` (sparsegpt_pruner.py:210): every element one fp32 accumulator over the block's k and one
+    subtraction -- against the fp64 product within fp32 accumulation error (north_star: 1e-3 relative on updated fp32 weights; here ~1e-6)."""
+    from vlmc import sparsegpt as SG
+    g = torch.Generator(device=DEV).manual_seed(rows + ncols + count)
+    i1, extra = 64, 40                                                         # the block sits inside a larger factor; W has columns to the left
+    U = torch.randn(i1 + count + 8, extra + ncols, generator=g, device=DEV) * 0.3
+    W = torch.randn(rows, extra + ncols, generator=g, device=DEV) * 0.05
+    err = torch.randn(rows, 128, generator=g, device=DEV) * 0.02
+    want = W.double().clone()
+    want[:, extra:] -= err[:, :count].double() @ U[i1:i1 + count, extra:].double()
+    W0 = W.clone()
+    SG.trailing_update(W, extra, extra + ncols, err, U, i1, i1 + count)
+    assert torch.equal(W[:, :extra], W0[:, :extra]), "columns left of the update were touched"
+    scale = (err[:, :count].double().abs() @ U[i1:i1 + count, extra:].double().abs()) + W0[:, extra:].double().abs()
+    assert bool(((W[:, extra:].double() - want[:, extra:]).abs() <= 2e-6 * scale + 1e-30).all())
+    # splitting the columns over launches changes nothing: the same bits as one launch (what the look-ahead relies on)
+    W2 = W0.clone()
+    cut = extra + min(ncols, 128)
+    SG.trailing_update(W2, extra, cut, err, U, i1, i1 + count)
+    SG.trailing_update(W2, cut, extra + ncols, err, U, i1, i1 + count)
+    assert torch.equal(W2, W)
+
+
+@pytest.mark.parametrize("grouped,nm", [(False, (0, 0)), (True, (0, 0)), (True, (2, 4))])
+def test_lookahead_gives_the_bits_of_one_trailing_launch_per_block(grouped, nm, monkeypatch):
+    """The next block's columns first, the rest on a side stream beside the next sweep (vlmc/sparsegpt.py: BlockedSweep) against
+    `VLMC_SGPT_LOOKAHEAD=0`: identical weights, bit for bit, at a T5 width."""
+    from vlmc import sparsegpt as SG
+    g = torch.Generator().manual_seed(4)
+    in_f = 2048
+    layers0 = [nn.Linear(in_f, n, bias=False) for n in ((512, 384) if grouped else (640,))]
+    for l in layers0:
+        l.weight.data = (torch.randn(l.weight.shape, generator=g) * 0.05)
+    X = torch.randn(4096, in_f, generator=g) * (torch.rand(in_f, generator=g) + 0.2)
+    res = []
+    for look in (True, False):
+        monkeypatch.setattr(SG, "_LOOKAHEAD", look)
+        layers = [nn.Linear(in_f, l.weight.shape[0], bias=False).to(DEV) for l in layers0]
+        for l, l0 in zip(layers, layers0):
+            l.weight.data = l0.weight.data.clone().to(DEV)
+        H = (X.to(DEV).t() @ X.to(DEV)) * (2.0 / X.shape[0])
+        cache = {}
+        U, dead = SG.factorize(H, 0.01)
+        cache["U"], cache["dead"] = U, dead
+        if grouped:
+            SG.fasterprune_group(layers, [0.5] * len(layers), cache, prune_n=nm[0], prune_m=nm[1])
+        else:
+            SG.fasterprune(layers[0], None, 0.5, prune_n=nm[0], prune_m=nm[1], factor_cache=cache)
+        torch.cuda.synchronize()
+        res.append([l.weight.data.clone() for l in layers])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+        assert abs(float((a == 0).float().mean()) - 0.5) < 0.02

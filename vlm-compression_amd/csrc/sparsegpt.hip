@@ -677,3 +677,118 @@ extern "C" int vlmc_sparsegpt_select_sweep(float *W, int64_t count, int64_t ldw,
     VLMC_HIP_CHECK_LAUNCH("vlmc_sparsegpt_select_sweep");
     return VLMC_OK;
 }
+
+// ---- K10: the trailing update of a 128-column block, `W[:, i2:] -= Err1.matmul(Hinv[i1:i2, i2:])` (sparsegpt_pruner.py:210) -------
+//   W[r, c] -= sum_{k < count} Err[r, k] * U[k, c]          fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32
+// (rounds 2-5 handed this to the GEMM library through `torch.addmm_`).  K is the block's 128 columns -- one pass, no K loop over
+// memory: a workgroup stages its 128 x 128 tile of Err and its 128 x 128 tile of U in LDS, each of its four waves owns 64 x 64 of the
+// product (2 x 2 MFMA tiles, k ascending in pairs), and subtracts its accumulators from W in place (a lane's 32 columns of a row are
+// contiguous: 128-byte segments).  An element's arithmetic -- one accumulator over the block's k, one subtraction -- does not depend
+// on which columns share the launch: the host splits the update into the NEXT block's 128 columns (on the sweeps' critical path)
+// and the rest (on a side stream, beside the next sweep) without changing a bit (vlmc/sparsegpt.py: look-ahead).
+// MFMA-bound by design (157 TFLOP/s fp32 matrix peak): a tile is 4.2 MFLOP = ~6.8 us of one CU's matrix pipes against ~2 us of loads.
+namespace vlmc {
+typedef float tu_f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kTuTile = 128, kTuLdE = 129, kTuLdU = 132;          // Err rows are read down a column of k (odd pitch: conflict-free), U rows along c
+
+__global__ __launch_bounds__(256) void sgpt_trailing_kernel(float *__restrict__ W, int rows, int ncols, int64_t ldw,
+                                                            const float *__restrict__ Err, int64_t lde, const float *__restrict__ U,
+                                                            int64_t ldu, int count) {
+    extern __shared__ float tu_sh[];
+    float *ea = tu_sh, *ub = tu_sh + kTuTile * kTuLdE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.y * kTuTile, c0 = blockIdx.x * kTuTile;
+    const int kpad = (count + 1) & ~1;
+    // ---- stage: Err[r0 .. +128, 0 .. count) and U[0 .. count, c0 .. +128), zeros outside ------------------------------------------
+    const bool evec = (lde & 3) == 0 && (reinterpret_cast<uintptr_t>(Err) & 15u) == 0;
+    const bool uvec = (ldu & 3) == 0 && (reinterpret_cast<uintptr_t>(U) & 15u) == 0;
+    for (int e = tid; e < kTuTile * (kTuTile / 4); e += 256) {
+        const int row = e >> 5, k4 = (e & 31) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + row < rows && k4 < count) {
+            const float *src = Err + int64_t(r0 + row) * lde + k4;
+            if (evec && k4 + 3 < count) {
+                const f32x4_t q = *reinterpret_cast<const f32x4_t *>(src);
+                v[0] = q[0], v[1] = q[1], v[2] = q[2], v[3] = q[3];
+            } else {
+                for (int t = 0; t < 4 && k4 + t < count; ++t) v[t] = src[t];
+            }
+        }
+        float *d = ea + row * kTuLdE + k4;
+        d[0] = v[0], d[1] = v[1], d[2] = v[2], d[3] = v[3];
+    }
+    for (int e = tid; e < kTuTile * (kTuTile / 4); e += 256) {
+        const int k = e >> 5, c4 = (e & 31) * 4;
+        f32x4_t q = {0.f, 0.f, 0.f, 0.f};
+        if (k < count && c0 + c4 < ncols) {
+            const float *src = U + int64_t(k) * ldu + c0 + c4;
+            if (uvec && c0 + c4 + 3 < ncols) q = *reinterpret_cast<const f32x4_t *>(src);
+            else
+                for (int t = 0; t < 4 && c0 + c4 + t < ncols; ++t) q[t] = src[t];
+        }
+        *reinterpret_cast<f32x4_t *>(ub + k * kTuLdU + c4) = q;
+    }
+    __syncthreads();
+    // ---- 64 x 64 per wave: acc[i][j] = rows 64 rb + 32 i .., columns 64 cb + 32 j .. -----------------------------------------------
+    const int rb = wave >> 1, cb = wave & 1;
+    tu_f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const float *ap0 = ea + (rb * 64 + (lane & 31)) * kTuLdE + (lane >> 5), *ap1 = ap0 + 32 * kTuLdE;
+    const float *bp0 = ub + (lane >> 5) * kTuLdU + cb * 64 + (lane & 31), *bp1 = bp0 + 32;
+#pragma unroll 4
+    for (int k = 0; k < kpad; k += 2) {
+        const float a0 = ap0[k], a1 = ap1[k], b0 = bp0[k * kTuLdU], b1 = bp1[k * kTuLdU];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    // ---- W -= acc: register r of a tile is row 8 (r / 4) + 4 (lane / 32) + r % 4, column lane % 32 --------------------------------
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = c0 + cb * 64 + j * 32 + (lane & 31);
+            if (col >= ncols) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = r0 + rb * 64 + i * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                if (row < rows) {
+                    float *w = W + int64_t(row) * ldw + col;
+                    *w = ieee_add(*w, -acc[i][j][r]);
+                }
+            }
+        }
+}
+}  // namespace vlmc
+
+extern "C" int vlmc_sparsegpt_trailing_update(float *W, int64_t out_features, int64_t ncols, int64_t ldw, const float *Err1, int64_t lde,
+                                              const float *U, int64_t ldu, int64_t count, void *stream) {
+    VLMC_REQUIRE(W && Err1 && U, "vlmc_sparsegpt_trailing_update: null pointer");
+    VLMC_REQUIRE(out_features > 0 && ncols >= 0 && count > 0 && count <= kTuTile && out_features < (int64_t(1) << 24) && ncols < (int64_t(1) << 24),
+                 "vlmc_sparsegpt_trailing_update: bad shape (1 <= count <= 128)");
+    VLMC_REQUIRE(ldw >= ncols && lde >= count && ldu >= ncols, "vlmc_sparsegpt_trailing_update: a row stride is shorter than its row");
+    if (ncols == 0) return VLMC_OK;
+    const size_t lds = size_t(kTuTile) * (kTuLdE + kTuLdU) * sizeof(float);
+    static PerDeviceOnce once;
+    int dev;
+    if (once.needed(&dev)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(sgpt_trailing_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) !=
+            hipSuccess) {
+            set_error("vlmc_sparsegpt_trailing_update: cannot reserve %zu bytes of LDS", lds);
+            return VLMC_EHIP;
+        }
+        once.mark(dev);
+    }
+    const dim3 grid{unsigned((ncols + kTuTile - 1) / kTuTile), unsigned((out_features + kTuTile - 1) / kTuTile)};
+    hipLaunchKernelGGL(sgpt_trailing_kernel, grid, dim3(256), lds, as_stream(stream), W, int(out_features), int(ncols), ldw, Err1, lde, U,
+                       ldu, int(count));
+    VLMC_HIP_CHECK_LAUNCH("vlmc_sparsegpt_trailing_update");
+    return VLMC_OK;
+}

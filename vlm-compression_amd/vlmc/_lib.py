@@ -92,6 +92,7 @@ SIGNATURES = {
     "vlmc_chol_inverse_workspace": (_sz, [_i64]),
     "vlmc_chol_inverse": (_i, [_p, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _sz, _i, _p]),
     "vlmc_sparsegpt_sweep": (_i, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i, _i, _p, _i64, _p, _i64, _p]),
+    "vlmc_sparsegpt_trailing_update": (_i, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i64, _p]),
     "vlmc_sparsegpt_select_workspace_bytes": (_i64, []),
     "vlmc_sparsegpt_select_sweep": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _p, _p, _i64, _p, _i64, _p, _p]),
     "vlmc_score_select_workspace": (_sz, [_i, _i]),

@@ -568,6 +568,85 @@ def sweep_block(W: torch.Tensor, i1: int, i2: int, U: torch.Tensor, mask1, prune
         mask_out.stride(0) if mask_out is not None else 0, _stream()))
 
 
+def trailing_update(W: torch.Tensor, c0: int, c1: int, err: torch.Tensor, U: torch.Tensor, i1: int, i2: int):
+    """`W[:, c0:c1] -= err[:, :i2 - i1] @ U[i1:i2, c0:c1]` in place on fp32 matrix cores (include/vlmc.h: vlmc_sparsegpt_trailing_update):
+    the reference's `W[:, i2:] -= Err1.matmul(Hinv[i1:i2, i2:])` (:210) for the columns c0..c1 of it."""
+    _need_gpu(W, err, U)
+    assert W.dtype == torch.float32 and U.dtype == torch.float32 and err.dtype == torch.float32
+    assert W.stride(1) == 1 and U.stride(1) == 1 and err.stride(1) == 1 and 0 < i2 - i1 <= err.shape[1] and err.shape[0] == W.shape[0]
+    if c1 <= c0:
+        return
+    el = W.element_size()
+    _lib.check(_lib.load().vlmc_sparsegpt_trailing_update(
+        W.data_ptr() + c0 * el, W.shape[0], c1 - c0, W.stride(0), err.data_ptr(), err.stride(0),
+        U.data_ptr() + (i1 * U.stride(0) + c0) * el, U.stride(0), i2 - i1, _stream()))
+
+
+_LOOKAHEAD = __import__("os").environ.get("VLMC_SGPT_LOOKAHEAD", "1") != "0"
+_LOOKAHEAD_STREAMS = {}       # (device index, the stream the sweeps run on) -> the side stream of their trailing updates
+
+
+class BlockedSweep:
+    """The 128-column block loop of `fasterprune` (:167-212) with the trailing update LOOKING AHEAD.
+
+    The reference sweeps a block and then updates every column to its right before it sweeps the next block.  The next sweep only
+    needs ITS OWN 128 columns updated: those are updated first, on the sweeps' stream; the rest of the trailing update runs on a side
+    stream beside the next sweep (a sweep is a latency chain of 128 dependent column steps that leaves the matrix cores idle).
+    Orders that must hold, and how: the wide update of block b and the narrow update of block b + 1 write the same columns --
+    the narrow one waits for the wide one's event; wide updates follow each other on the one side stream; a block's error matrix is
+    read by its wide update while the next sweep writes its own -- two error buffers, and buffer b % 2 is rewritten by sweep b + 2, which
+    the narrow update of block b + 1 (behind the wide update of block b) precedes.  Every element sees the same operations in the same
+    order as with one trailing launch per block: the same bits (tests/test_sparsegpt_gpu.py).  `VLMC_SGPT_LOOKAHEAD=0`: one launch per
+    block on the sweeps' stream."""
+
+    def __init__(self, W, U, blocksize):
+        self.W, self.U, self.bs = W, U, blocksize
+        rows, cols = W.shape
+        self.cols = cols
+        n = min(blocksize, cols)
+        self.errs = [torch.empty((rows, n), dtype=torch.float32, device=W.device) for _ in range(2 if _LOOKAHEAD and cols > 2 * blocksize else 1)]
+        self.main = torch.cuda.current_stream(W.device)
+        self.side = None
+        if len(self.errs) == 2:
+            key = (W.device.index, self.main.cuda_stream)
+            self.side = _LOOKAHEAD_STREAMS.get(key)
+            if self.side is None:
+                self.side = _LOOKAHEAD_STREAMS[key] = torch.cuda.Stream(device=W.device)
+        self.wide_done = None
+        self.b = 0
+
+    def err(self):
+        """the error buffer the sweep of the current block writes"""
+        return self.errs[self.b % len(self.errs)]
+
+    def after_sweep(self, i1, i2):
+        """the trailing update of block [i1, i2) -- call once its sweep has been issued"""
+        W, U, cols = self.W, self.U, self.cols
+        err = self.err()
+        self.b += 1
+        if i2 >= cols:
+            return
+        if self.side is None:
+            trailing_update(W, i2, cols, err, U, i1, i2)
+            return
+        n2 = min(i2 + self.bs, cols)
+        swept = torch.cuda.Event()
+        swept.record(self.main)                                   # err is complete
+        if self.wide_done is not None:
+            self.main.wait_event(self.wide_done)                   # the previous block's wide update wrote columns i2 .. too
+        trailing_update(W, i2, n2, err, U, i1, i2)                 # the next block's own columns: on the critical path
+        if n2 < cols:
+            self.side.wait_event(swept)
+            with torch.cuda.stream(self.side):
+                trailing_update(W, n2, cols, err, U, i1, i2)       # everything further right: beside the next sweep
+                self.wide_done = torch.cuda.Event()
+                self.wide_done.record(self.side)
+
+    def finish(self):
+        if self.side is not None:
+            self.main.wait_stream(self.side)                       # (every tensor used on the side stream outlives it)
+
+
 _SELECT_SWEEP = __import__("os").environ.get("VLMC_SGPT_SELECT_SWEEP", "1") != "0"
 _select_ws = {}            # device index -> the zero-filled workspace of vlmc_sparsegpt_select_sweep (returned zero by every call)
 _sweep_rows = {}          # device index -> rows the one-launch threshold + sweep takes on that part
@@ -631,17 +710,17 @@ def fasterprune(layer, H: torch.Tensor, sparsity, prune_n=0, prune_m=0, blocksiz
     diag = torch.diag(U)
     score_mean = (W ** 2 / diag.reshape(1, -1) ** 2).abs().mean()
     rows, cols = W.shape
-    err = torch.empty((rows, min(blocksize, cols)), dtype=torch.float32, device=W.device)
+    blocks = BlockedSweep(W, U, blocksize)
     pruned = torch.zeros((rows, cols), dtype=torch.bool, device=W.device) if return_mask else None
     fused = prune_n == 0 and _SELECT_THRESHOLD and select_sweep_usable([rows], W.device)
     for i1 in range(0, cols, blocksize):
         i2 = min(i1 + blocksize, cols)
         mask1 = None
+        err = blocks.err()
         if fused:                                                                          # :183-205 in one launch
             rank = min(int(rows * (i2 - i1) * sparsity), rows * (i2 - i1) - 1)
             select_sweep_block(W, i1, i2, U, [rows], [rank], err, pruned)
-            if i2 < cols:
-                W[:, i2:].addmm_(err[:, :i2 - i1], U[i1:i2, i2:], beta=1.0, alpha=-1.0)    # :210
+            blocks.after_sweep(i1, i2)                                                     # :210
             continue
         if prune_n == 0:
             tmp = W[:, i1:i2] ** 2 / diag[i1:i2].reshape(1, -1) ** 2                       # :183
@@ -655,8 +734,8 @@ def fasterprune(layer, H: torch.Tensor, sparsity, prune_n=0, prune_m=0, blocksiz
                 thresh = torch.sort(tmp.flatten())[0][int(tmp.numel() * sparsity)]         # :184
                 mask1 = (tmp <= thresh).contiguous()                                        # :185
         sweep_block(W, i1, i2, U, mask1, prune_n, prune_m, err, pruned)
-        if i2 < cols:
-            W[:, i2:].addmm_(err[:, :i2 - i1], U[i1:i2, i2:], beta=1.0, alpha=-1.0)        # :210
+        blocks.after_sweep(i1, i2)                                                         # :210
+    blocks.finish()
     if score_sink is None:
         setattr(layer.weight, "importance_score", score_mean.item())                       # :165
     else:
@@ -690,17 +769,17 @@ def fasterprune_group(layers, sparsities, factor_cache, prune_n=0, prune_m=0, bl
     for r in rows:
         bounds.append(bounds[-1] + r)
     means = [(W[bounds[i]:bounds[i + 1]] ** 2 / dsq).abs().mean() for i in range(len(layers))]
-    err = torch.empty((W.shape[0], min(blocksize, cols)), dtype=torch.float32, device=W.device)
+    blocks = BlockedSweep(W, U, blocksize)
     keep = torch.empty((W.shape[0], min(blocksize, cols)), dtype=torch.bool, device=W.device) if prune_n == 0 else None
     fused = prune_n == 0 and _SELECT_THRESHOLD and select_sweep_usable(rows, W.device)
     for i1 in range(0, cols, blocksize):
         i2 = min(i1 + blocksize, cols)
         mask1 = None
+        err = blocks.err()
         if fused:                                                                          # :183-205 in one launch, a scope per linear
             ranks = [min(int(r * (i2 - i1) * sp), r * (i2 - i1) - 1) for r, sp in zip(rows, sparsities)]
             select_sweep_block(W, i1, i2, U, rows, ranks, err, None)
-            if i2 < cols:
-                W[:, i2:].addmm_(err[:, :i2 - i1], U[i1:i2, i2:], beta=1.0, alpha=-1.0)    # :210
+            blocks.after_sweep(i1, i2)                                                     # :210
             continue
         if prune_n == 0:
             tmp = W[:, i1:i2] ** 2 / dsq[:, i1:i2]                                          # :183
@@ -711,8 +790,8 @@ def fasterprune_group(layers, sparsities, factor_cache, prune_n=0, prune_m=0, bl
                              apply_weights=False, keeps=[kb[bounds[i]:bounds[i + 1]] for i in range(len(layers))])
             mask1 = torch.logical_not(kb)
         sweep_block(W, i1, i2, U, mask1, prune_n, prune_m, err, None)
-        if i2 < cols:
-            W[:, i2:].addmm_(err[:, :i2 - i1], U[i1:i2, i2:], beta=1.0, alpha=-1.0)        # :210
+        blocks.after_sweep(i1, i2)                                                         # :210
+    blocks.finish()
     for i, layer in enumerate(layers):
         if score_sink is None:
             setattr(layer.weight, "importance_score", means[i].item())                     # :165
