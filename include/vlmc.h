@@ -446,8 +446,7 @@ int vlmc_sparsegpt_sweep(float *W, int64_t out_features, int64_t count, int64_t 
  *     W[r, c] -= sum_{k < count} Err1[r, k] * U[k, c]        r < out_features, c < ncols
  * W: pointer at the first column to update (row stride ldw); Err1 [out_features, count] as vlmc_sparsegpt_sweep wrote it (row stride
  * lde); U: pointer at U[i1, first column] (row stride ldu); count <= 128 (the block).  One accumulator per element over the block's k in
- * ascending pairs, then one subtraction: an element's result does not depend on which columns share the launch, so a caller may update
- * the next block's columns first and the rest beside the next sweep (vlmc/sparsegpt.py) and get the same bits as one launch.       */
+ * ascending pairs, then one subtraction: an element's result does not depend on which columns share the launch.                   */
 int vlmc_sparsegpt_trailing_update(float *W, int64_t out_features, int64_t ncols, int64_t ldw, const float *Err1, int64_t lde,
                                    const float *U, int64_t ldu, int64_t count, void *stream);
 
@@ -465,6 +464,17 @@ int64_t vlmc_sparsegpt_select_workspace_bytes(void);
 int vlmc_sparsegpt_select_sweep(float *W, int64_t count, int64_t ldw, const float *U1, int64_t ldu, int n_scopes,
                                 const int64_t *scope_rows, const int64_t *scope_ranks, float *Err1, int64_t lde,
                                 uint8_t *mask_out, int64_t ldmo, void *workspace, void *stream);
+
+/* The whole block loop of `SparseGPT.fasterprune` (sparsegpt_pruner.py:167-212) from one call: for every block of `blocksize` (<= 128)
+ * columns the sweep -- vlmc_sparsegpt_sweep when prune_n != 0, else vlmc_sparsegpt_select_sweep with rank_q = int(rows_q * count *
+ * scope_sparsity[q]) (:184; `select_workspace` as that entry point wants it, every scope's rows stacked in W) -- and the trailing update
+ * `W[:, i2:] -= Err1 @ U[i1:i2, i2:]` (:210, vlmc_sparsegpt_trailing_update), in order on `stream`.  W [out_features, in_features] fp32
+ * working copy (row stride ldw), U the upper factor of H^-1 (row stride ldu), err: scratch of [out_features, blocksize] floats (row
+ * stride lde), mask_out optional ([out_features, in_features] bytes, row stride ldmo).  The bits of the entry points called one by one. */
+int vlmc_sparsegpt_prune_blocks(float *W, int64_t out_features, int64_t in_features, int64_t ldw, const float *U, int64_t ldu,
+                                int64_t blocksize, int prune_n, int prune_m, int n_scopes, const int64_t *scope_rows,
+                                const double *scope_sparsity, float *err, int64_t lde, uint8_t *mask_out, int64_t ldmo,
+                                void *select_workspace, void *stream);
 
 /* ---- K11-K13: DSnoT --------------------------------------------------------------------
  * vlmc_act_moments: per hook call and channel (layout as vlmc_act_sqnorm) the squared norm, the

@@ -511,7 +511,7 @@ def test_trailing_update_matches_fp64(rows, ncols, count):
     assert torch.equal(W[:, :extra], W0[:, :extra]), "columns left of the update were touched"
     scale = (err[:, :count].double().abs() @ U[i1:i1 + count, extra:].double().abs()) + W0[:, extra:].double().abs()
     assert bool(((W[:, extra:].double() - want[:, extra:]).abs() <= 2e-6 * scale + 1e-30).all())
-    # splitting the columns over launches changes nothing: the same bits as one launch (what the look-ahead relies on)
+    # splitting the columns over launches changes nothing: an element's arithmetic does not depend on what shares its launch
     W2 = W0.clone()
     cut = extra + min(ncols, 128)
     SG.trailing_update(W2, extra, cut, err, U, i1, i1 + count)
@@ -519,10 +519,10 @@ def test_trailing_update_matches_fp64(rows, ncols, count):
     assert torch.equal(W2, W)
 
 
-@pytest.mark.parametrize("grouped,nm", [(False, (0, 0)), (True, (0, 0)), (True, (2, 4))])
-def test_lookahead_gives_the_bits_of_one_trailing_launch_per_block(grouped, nm, monkeypatch):
-    """The next block's columns first, the rest on a side stream beside the next sweep (vlmc/sparsegpt.py: BlockedSweep) against
-    `VLMC_SGPT_LOOKAHEAD=0`: identical weights, bit for bit, at a T5 width."""
+@pytest.mark.parametrize("grouped,nm", [(False, (0, 0)), (True, (0, 0)), (True, (2, 4)), (False, (2, 4))])
+def test_block_loop_from_one_call_equals_the_loop_issued_from_python(grouped, nm, monkeypatch):
+    """`vlmc_sparsegpt_prune_blocks` (every block's sweep + trailing update from one call) against the same entry points called block
+    by block from Python (`VLMC_SGPT_BLOCK_LOOP=0`): identical weights and masks, bit for bit, at a T5 width."""
     from vlmc import sparsegpt as SG
     g = torch.Generator().manual_seed(4)
     in_f = 2048
@@ -531,8 +531,8 @@ def test_lookahead_gives_the_bits_of_one_trailing_launch_per_block(grouped, nm, 
         l.weight.data = (torch.randn(l.weight.shape, generator=g) * 0.05)
     X = torch.randn(4096, in_f, generator=g) * (torch.rand(in_f, generator=g) + 0.2)
     res = []
-    for look in (True, False):
-        monkeypatch.setattr(SG, "_LOOKAHEAD", look)
+    for loop in (True, False):
+        monkeypatch.setattr(SG, "_BLOCK_LOOP", loop)
         layers = [nn.Linear(in_f, l.weight.shape[0], bias=False).to(DEV) for l in layers0]
         for l, l0 in zip(layers, layers0):
             l.weight.data = l0.weight.data.clone().to(DEV)
@@ -540,12 +540,15 @@ def test_lookahead_gives_the_bits_of_one_trailing_launch_per_block(grouped, nm, 
         cache = {}
         U, dead = SG.factorize(H, 0.01)
         cache["U"], cache["dead"] = U, dead
+        masks = None
         if grouped:
             SG.fasterprune_group(layers, [0.5] * len(layers), cache, prune_n=nm[0], prune_m=nm[1])
         else:
-            SG.fasterprune(layers[0], None, 0.5, prune_n=nm[0], prune_m=nm[1], factor_cache=cache)
+            masks = SG.fasterprune(layers[0], None, 0.5, prune_n=nm[0], prune_m=nm[1], factor_cache=cache, return_mask=True)
         torch.cuda.synchronize()
-        res.append([l.weight.data.clone() for l in layers])
-    for a, b in zip(*res):
+        res.append(([l.weight.data.clone() for l in layers], masks))
+    for a, b in zip(res[0][0], res[1][0]):
         assert torch.equal(a, b)
         assert abs(float((a == 0).float().mean()) - 0.5) < 0.02
+    if res[0][1] is not None:
+        assert torch.equal(res[0][1], res[1][1])

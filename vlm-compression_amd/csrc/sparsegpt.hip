@@ -680,57 +680,64 @@ extern "C" int vlmc_sparsegpt_select_sweep(float *W, int64_t count, int64_t ldw,
 
 // ---- K10: the trailing update of a 128-column block, `W[:, i2:] -= Err1.matmul(Hinv[i1:i2, i2:])` (sparsegpt_pruner.py:210) -------
 //   W[r, c] -= sum_{k < count} Err[r, k] * U[k, c]          fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32
-// (rounds 2-5 handed this to the GEMM library through `torch.addmm_`).  K is the block's 128 columns -- one pass, no K loop over
-// memory: a workgroup stages its 128 x 128 tile of Err and its 128 x 128 tile of U in LDS, each of its four waves owns 64 x 64 of the
-// product (2 x 2 MFMA tiles, k ascending in pairs), and subtracts its accumulators from W in place (a lane's 32 columns of a row are
-// contiguous: 128-byte segments).  An element's arithmetic -- one accumulator over the block's k, one subtraction -- does not depend
-// on which columns share the launch: the host splits the update into the NEXT block's 128 columns (on the sweeps' critical path)
-// and the rest (on a side stream, beside the next sweep) without changing a bit (vlmc/sparsegpt.py: look-ahead).
-// MFMA-bound by design (157 TFLOP/s fp32 matrix peak): a tile is 4.2 MFLOP = ~6.8 us of one CU's matrix pipes against ~2 us of loads.
+// (rounds 2-5 handed this to the GEMM library through `torch.addmm_`).  K is the block's 128 columns.  A workgroup owns a 128 x 128
+// tile of W; each of its four waves 64 x 64 of it (2 x 2 MFMA tiles, k ascending in pairs).  K goes through LDS in four chunks of 32,
+// double buffered: the next chunk's 16-byte global loads are in flight during this chunk's 64 MFMAs per wave, and 68 KB of LDS let a
+// second workgroup share the CU (its loads and stores run beside this one's products).  The tile of W is requested before the
+// products and subtracted after them: a lane's 32 columns of a row are one 128-byte segment per half wave.  An element's arithmetic
+// -- one accumulator over the block's k, one subtraction -- does not depend on which columns share the launch.  MFMA-bound by design (157 TFLOP/s fp32 matrix peak): a tile is 4.2 MFLOP = 6.8 us of a CU's matrix pipes.
 namespace vlmc {
 typedef float tu_f32x16_t __attribute__((ext_vector_type(16)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-constexpr int kTuTile = 128, kTuLdE = 129, kTuLdU = 132;          // Err rows are read down a column of k (odd pitch: conflict-free), U rows along c
+constexpr int kTuTile = 128, kTuK = 32, kTuLdE = kTuK + 1, kTuLdU = kTuTile + 4;     // Err rows are read down a column of k (odd pitch), U rows along c
+constexpr int kTuBuf = kTuTile * kTuLdE + kTuK * kTuLdU;                             // floats per LDS buffer (Err chunk | U chunk)
 
-__global__ __launch_bounds__(256) void sgpt_trailing_kernel(float *__restrict__ W, int rows, int ncols, int64_t ldw,
-                                                            const float *__restrict__ Err, int64_t lde, const float *__restrict__ U,
-                                                            int64_t ldu, int count) {
+__global__ __launch_bounds__(256, 2) void sgpt_trailing_kernel(float *__restrict__ W, int rows, int ncols, int64_t ldw,
+                                                               const float *__restrict__ Err, int64_t lde, const float *__restrict__ U,
+                                                               int64_t ldu, int count) {
     extern __shared__ float tu_sh[];
-    float *ea = tu_sh, *ub = tu_sh + kTuTile * kTuLdE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.y * kTuTile, c0 = blockIdx.x * kTuTile;
-    const int kpad = (count + 1) & ~1;
-    // ---- stage: Err[r0 .. +128, 0 .. count) and U[0 .. count, c0 .. +128), zeros outside ------------------------------------------
     const bool evec = (lde & 3) == 0 && (reinterpret_cast<uintptr_t>(Err) & 15u) == 0;
     const bool uvec = (ldu & 3) == 0 && (reinterpret_cast<uintptr_t>(U) & 15u) == 0;
-    for (int e = tid; e < kTuTile * (kTuTile / 4); e += 256) {
-        const int row = e >> 5, k4 = (e & 31) * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (r0 + row < rows && k4 < count) {
-            const float *src = Err + int64_t(r0 + row) * lde + k4;
-            if (evec && k4 + 3 < count) {
-                const f32x4_t q = *reinterpret_cast<const f32x4_t *>(src);
-                v[0] = q[0], v[1] = q[1], v[2] = q[2], v[3] = q[3];
-            } else {
-                for (int t = 0; t < 4 && k4 + t < count; ++t) v[t] = src[t];
+    // chunk q of K: thread t stages Err rows (t >> 3) + 32 i, k = 4 (t & 7) ..; U rows k = (t >> 5) + 8 i, columns 4 (t & 31) ..
+    f32x4_t se[4], su[4];
+    auto fetch = [&](int q) {
+        const int k0 = q * kTuK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + (tid >> 3) + 32 * i, k = k0 + 4 * (tid & 7);
+            f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+            if (row < rows && k < count) {
+                const float *src = Err + int64_t(row) * lde + k;
+                if (evec && k + 3 < count) v = *reinterpret_cast<const f32x4_t *>(src);
+                else
+                    for (int t = 0; t < 4 && k + t < count; ++t) v[t] = src[t];
             }
+            se[i] = v;
         }
-        float *d = ea + row * kTuLdE + k4;
-        d[0] = v[0], d[1] = v[1], d[2] = v[2], d[3] = v[3];
-    }
-    for (int e = tid; e < kTuTile * (kTuTile / 4); e += 256) {
-        const int k = e >> 5, c4 = (e & 31) * 4;
-        f32x4_t q = {0.f, 0.f, 0.f, 0.f};
-        if (k < count && c0 + c4 < ncols) {
-            const float *src = U + int64_t(k) * ldu + c0 + c4;
-            if (uvec && c0 + c4 + 3 < ncols) q = *reinterpret_cast<const f32x4_t *>(src);
-            else
-                for (int t = 0; t < 4 && c0 + c4 + t < ncols; ++t) q[t] = src[t];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + (tid >> 5) + 8 * i, c = c0 + 4 * (tid & 31);
+            f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+            if (k < count && c < ncols) {
+                const float *src = U + int64_t(k) * ldu + c;
+                if (uvec && c + 3 < ncols) v = *reinterpret_cast<const f32x4_t *>(src);
+                else
+                    for (int t = 0; t < 4 && c + t < ncols; ++t) v[t] = src[t];
+            }
+            su[i] = v;
         }
-        *reinterpret_cast<f32x4_t *>(ub + k * kTuLdU + c4) = q;
-    }
-    __syncthreads();
-    // ---- 64 x 64 per wave: acc[i][j] = rows 64 rb + 32 i .., columns 64 cb + 32 j .. -----------------------------------------------
+    };
+    auto stash = [&](int buf) {
+        float *ea = tu_sh + buf * kTuBuf, *ub = ea + kTuTile * kTuLdE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float *d = ea + ((tid >> 3) + 32 * i) * kTuLdE + 4 * (tid & 7);
+            d[0] = se[i][0], d[1] = se[i][1], d[2] = se[i][2], d[3] = se[i][3];
+            *reinterpret_cast<f32x4_t *>(ub + ((tid >> 5) + 8 * i) * kTuLdU + 4 * (tid & 31)) = su[i];
+        }
+    };
     const int rb = wave >> 1, cb = wave & 1;
     tu_f32x16_t acc[2][2];
 #pragma unroll
@@ -739,30 +746,46 @@ __global__ __launch_bounds__(256) void sgpt_trailing_kernel(float *__restrict__ 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const float *ap0 = ea + (rb * 64 + (lane & 31)) * kTuLdE + (lane >> 5), *ap1 = ap0 + 32 * kTuLdE;
-    const float *bp0 = ub + (lane >> 5) * kTuLdU + cb * 64 + (lane & 31), *bp1 = bp0 + 32;
-#pragma unroll 4
-    for (int k = 0; k < kpad; k += 2) {
-        const float a0 = ap0[k], a1 = ap1[k], b0 = bp0[k * kTuLdU], b1 = bp1[k * kTuLdU];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    const int nq = (count + kTuK - 1) / kTuK;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int q = 0; q < nq; ++q) {
+        if (q + 1 < nq) fetch(q + 1);                                         // in flight during this chunk's products
+        const float *ea = tu_sh + (q & 1) * kTuBuf, *ub = ea + kTuTile * kTuLdE;
+        const float *ap0 = ea + (rb * 64 + (lane & 31)) * kTuLdE + (lane >> 5), *ap1 = ap0 + 32 * kTuLdE;
+        const float *bp0 = ub + (lane >> 5) * kTuLdU + cb * 64 + (lane & 31), *bp1 = bp0 + 32;
+#pragma unroll
+        for (int k = 0; k < kTuK; k += 2) {
+            const float a0 = ap0[k], a1 = ap1[k], b0 = bp0[k * kTuLdU], b1 = bp1[k * kTuLdU];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (q + 1 < nq) {
+            stash((q + 1) & 1);                                               // (the buffer chunk q - 1 was read from: every wave left it before the last barrier)
+            __syncthreads();
+        }
     }
-    // ---- W -= acc: register r of a tile is row 8 (r / 4) + 4 (lane / 32) + r % 4, column lane % 32 --------------------------------
+    // ---- W -= acc: register r of a tile is row 8 (r / 4) + 4 (lane / 32) + r % 4, column lane % 32; 16 loads in flight, then 16 stores ----
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = c0 + cb * 64 + j * 32 + (lane & 31);
             if (col >= ncols) continue;
+            const int rbase = r0 + rb * 64 + i * 32 + 4 * (lane >> 5);
+            float w[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = r0 + rb * 64 + i * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-                if (row < rows) {
-                    float *w = W + int64_t(row) * ldw + col;
-                    *w = ieee_add(*w, -acc[i][j][r]);
-                }
+                const int row = rbase + 8 * (r >> 2) + (r & 3);
+                w[r] = row < rows ? W[int64_t(row) * ldw + col] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + 8 * (r >> 2) + (r & 3);
+                if (row < rows) W[int64_t(row) * ldw + col] = ieee_add(w[r], -acc[i][j][r]);
             }
         }
 }
@@ -775,7 +798,7 @@ extern "C" int vlmc_sparsegpt_trailing_update(float *W, int64_t out_features, in
                  "vlmc_sparsegpt_trailing_update: bad shape (1 <= count <= 128)");
     VLMC_REQUIRE(ldw >= ncols && lde >= count && ldu >= ncols, "vlmc_sparsegpt_trailing_update: a row stride is shorter than its row");
     if (ncols == 0) return VLMC_OK;
-    const size_t lds = size_t(kTuTile) * (kTuLdE + kTuLdU) * sizeof(float);
+    const size_t lds = size_t(2) * kTuBuf * sizeof(float);
     static PerDeviceOnce once;
     int dev;
     if (once.needed(&dev)) {
@@ -790,5 +813,49 @@ extern "C" int vlmc_sparsegpt_trailing_update(float *W, int64_t out_features, in
     hipLaunchKernelGGL(sgpt_trailing_kernel, grid, dim3(256), lds, as_stream(stream), W, int(out_features), int(ncols), ldw, Err1, lde, U,
                        ldu, int(count));
     VLMC_HIP_CHECK_LAUNCH("vlmc_sparsegpt_trailing_update");
+    return VLMC_OK;
+}
+
+// ---- the whole 128-column block loop of `fasterprune` (sparsegpt_pruner.py:167-212) issued from ONE call -------------------------------
+// Per block the reference runs the threshold, a Python loop over the block's columns and the trailing product; here a block is one sweep
+// launch (vlmc_sparsegpt_sweep in n:m mode, vlmc_sparsegpt_select_sweep otherwise) and one trailing-update launch, all blocks issued from
+// this one call: from Python a block was ~30 us of host time (ctypes) against ~41 us of sweep on the GPU, on a rank that holds 1 / 8 of
+// the samples the host paced the loop.
+// Measured and NOT kept (profiles/r06_sparsegpt.md): a LOOK-AHEAD form -- the next block's 128 columns updated first, the rest of the
+// trailing update on a side stream beside the next sweep (same bits: an element's arithmetic does not depend on the split).  It is 5 %
+// SLOWER on configs[2] (2.02 against 1.92 s): the sweeps of a block's independent linears already run side by side on streams of their own,
+// and MFMA waves sharing a SIMD with a sweep delay its chain of 128 dependent column steps by more than the overlap returns.
+extern "C" int vlmc_sparsegpt_prune_blocks(float *W, int64_t out_features, int64_t in_features, int64_t ldw, const float *U, int64_t ldu,
+                                           int64_t blocksize, int prune_n, int prune_m, int n_scopes, const int64_t *scope_rows,
+                                           const double *scope_sparsity, float *err, int64_t lde, uint8_t *mask_out, int64_t ldmo,
+                                           void *select_workspace, void *stream) {
+    VLMC_REQUIRE(W && U && err, "vlmc_sparsegpt_prune_blocks: null pointer");
+    VLMC_REQUIRE(out_features > 0 && in_features > 0 && blocksize > 0 && blocksize <= kSgBlock && ldw >= in_features && ldu >= in_features &&
+                     lde >= (blocksize < in_features ? blocksize : in_features),
+                 "vlmc_sparsegpt_prune_blocks: bad shape (blocksize <= %d)", kSgBlock);
+    VLMC_REQUIRE(prune_n != 0 || (select_workspace && scope_rows && scope_sparsity && n_scopes >= 1 && n_scopes <= kSelScopes),
+                 "vlmc_sparsegpt_prune_blocks: the unstructured mode needs 1..%d scopes, their sparsities and the select workspace", kSelScopes);
+    for (int64_t i1 = 0; i1 < in_features; i1 += blocksize) {
+        const int64_t i2 = i1 + blocksize < in_features ? i1 + blocksize : in_features, count = i2 - i1;
+        int rc;
+        if (prune_n != 0) {
+            rc = vlmc_sparsegpt_sweep(W + i1, out_features, count, ldw, U + i1 * ldu + i1, ldu, nullptr, 0, prune_n, prune_m, err, lde,
+                                      mask_out ? mask_out + i1 : nullptr, ldmo, stream);
+        } else {
+            int64_t ranks[kSelScopes];
+            for (int q = 0; q < n_scopes; ++q) {
+                const int64_t numel = scope_rows[q] * count;
+                const int64_t r = int64_t(double(numel) * scope_sparsity[q]);        // int(rows * (i2 - i1) * sparsity), as the reference's index (:184)
+                ranks[q] = r < numel - 1 ? (r < 0 ? 0 : r) : numel - 1;
+            }
+            rc = vlmc_sparsegpt_select_sweep(W + i1, count, ldw, U + i1 * ldu + i1, ldu, n_scopes, scope_rows, ranks, err, lde,
+                                             mask_out ? mask_out + i1 : nullptr, ldmo, select_workspace, stream);
+        }
+        if (rc != VLMC_OK) return rc;
+        if (i2 < in_features) {
+            rc = vlmc_sparsegpt_trailing_update(W + i2, out_features, in_features - i2, ldw, err, lde, U + i1 * ldu + i2, ldu, count, stream);
+            if (rc != VLMC_OK) return rc;
+        }
+    }
     return VLMC_OK;
 }

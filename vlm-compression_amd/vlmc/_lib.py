@@ -94,6 +94,7 @@ SIGNATURES = {
     "vlmc_sparsegpt_sweep": (_i, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i, _i, _p, _i64, _p, _i64, _p]),
     "vlmc_sparsegpt_trailing_update": (_i, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i64, _p]),
     "vlmc_sparsegpt_select_workspace_bytes": (_i64, []),
+    "vlmc_sparsegpt_prune_blocks": (_i, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _p, _p, _p, _i64, _p, _i64, _p, _p]),
     "vlmc_sparsegpt_select_sweep": (_i, [_p, _i64, _i64, _p, _i64, _i, _p, _p, _p, _i64, _p, _i64, _p, _p]),
     "vlmc_score_select_workspace": (_sz, [_i, _i]),
     "vlmc_score_select": (_i, [_p, _i, _p, _i, _i, _i, _p, _sz, _p]),

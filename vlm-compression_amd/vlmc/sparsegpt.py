@@ -582,69 +582,33 @@ def trailing_update(W: torch.Tensor, c0: int, c1: int, err: torch.Tensor, U: tor
         U.data_ptr() + (i1 * U.stride(0) + c0) * el, U.stride(0), i2 - i1, _stream()))
 
 
-_LOOKAHEAD = __import__("os").environ.get("VLMC_SGPT_LOOKAHEAD", "1") != "0"
-_LOOKAHEAD_STREAMS = {}       # (device index, the stream the sweeps run on) -> the side stream of their trailing updates
+_BLOCK_LOOP = __import__("os").environ.get("VLMC_SGPT_BLOCK_LOOP", "1") != "0"     # 0: the block loop issued from Python, launch by launch (the cross-check)
 
 
-class BlockedSweep:
-    """The 128-column block loop of `fasterprune` (:167-212) with the trailing update LOOKING AHEAD.
-
-    The reference sweeps a block and then updates every column to its right before it sweeps the next block.  The next sweep only
-    needs ITS OWN 128 columns updated: those are updated first, on the sweeps' stream; the rest of the trailing update runs on a side
-    stream beside the next sweep (a sweep is a latency chain of 128 dependent column steps that leaves the matrix cores idle).
-    Orders that must hold, and how: the wide update of block b and the narrow update of block b + 1 write the same columns --
-    the narrow one waits for the wide one's event; wide updates follow each other on the one side stream; a block's error matrix is
-    read by its wide update while the next sweep writes its own -- two error buffers, and buffer b % 2 is rewritten by sweep b + 2, which
-    the narrow update of block b + 1 (behind the wide update of block b) precedes.  Every element sees the same operations in the same
-    order as with one trailing launch per block: the same bits (tests/test_sparsegpt_gpu.py).  `VLMC_SGPT_LOOKAHEAD=0`: one launch per
-    block on the sweeps' stream."""
-
-    def __init__(self, W, U, blocksize):
-        self.W, self.U, self.bs = W, U, blocksize
-        rows, cols = W.shape
-        self.cols = cols
-        n = min(blocksize, cols)
-        self.errs = [torch.empty((rows, n), dtype=torch.float32, device=W.device) for _ in range(2 if _LOOKAHEAD and cols > 2 * blocksize else 1)]
-        self.main = torch.cuda.current_stream(W.device)
-        self.side = None
-        if len(self.errs) == 2:
-            key = (W.device.index, self.main.cuda_stream)
-            self.side = _LOOKAHEAD_STREAMS.get(key)
-            if self.side is None:
-                self.side = _LOOKAHEAD_STREAMS[key] = torch.cuda.Stream(device=W.device)
-        self.wide_done = None
-        self.b = 0
-
-    def err(self):
-        """the error buffer the sweep of the current block writes"""
-        return self.errs[self.b % len(self.errs)]
-
-    def after_sweep(self, i1, i2):
-        """the trailing update of block [i1, i2) -- call once its sweep has been issued"""
-        W, U, cols = self.W, self.U, self.cols
-        err = self.err()
-        self.b += 1
-        if i2 >= cols:
-            return
-        if self.side is None:
-            trailing_update(W, i2, cols, err, U, i1, i2)
-            return
-        n2 = min(i2 + self.bs, cols)
-        swept = torch.cuda.Event()
-        swept.record(self.main)                                   # err is complete
-        if self.wide_done is not None:
-            self.main.wait_event(self.wide_done)                   # the previous block's wide update wrote columns i2 .. too
-        trailing_update(W, i2, n2, err, U, i1, i2)                 # the next block's own columns: on the critical path
-        if n2 < cols:
-            self.side.wait_event(swept)
-            with torch.cuda.stream(self.side):
-                trailing_update(W, n2, cols, err, U, i1, i2)       # everything further right: beside the next sweep
-                self.wide_done = torch.cuda.Event()
-                self.wide_done.record(self.side)
-
-    def finish(self):
-        if self.side is not None:
-            self.main.wait_stream(self.side)                       # (every tensor used on the side stream outlives it)
+def prune_blocks(W: torch.Tensor, U: torch.Tensor, blocksize: int, prune_n: int, prune_m: int, rows_per_scope=None, sparsities=None,
+                 mask_out: torch.Tensor | None = None):
+    """The whole 128-column block loop of `fasterprune` (:167-212) issued by ONE call of the library (include/vlmc.h:
+    vlmc_sparsegpt_prune_blocks): sweep + trailing update per block."""
+    import ctypes
+    _need_gpu(W, U, mask_out)
+    assert W.dtype == torch.float32 and U.dtype == torch.float32 and W.stride(1) == 1 and U.stride(1) == 1
+    rows, cols = W.shape
+    err = torch.empty((rows, min(blocksize, cols)), dtype=torch.float32, device=W.device)
+    lib = _lib.load()
+    ws, rows_c, sp_c, n = None, None, None, 0
+    if prune_n == 0:
+        n = len(rows_per_scope)
+        assert sum(rows_per_scope) == rows and len(sparsities) == n
+        wkey = (W.device.index, torch.cuda.current_stream(W.device).cuda_stream)
+        ws = _select_ws.get(wkey)
+        if ws is None:
+            ws = _select_ws[wkey] = torch.zeros(int(lib.vlmc_sparsegpt_select_workspace_bytes()) // 4, dtype=torch.int32, device=W.device)
+        rows_c = (ctypes.c_int64 * n)(*[int(r) for r in rows_per_scope])
+        sp_c = (ctypes.c_double * n)(*[float(x) for x in sparsities])
+    _lib.check(lib.vlmc_sparsegpt_prune_blocks(
+        W.data_ptr(), rows, cols, W.stride(0), U.data_ptr(), U.stride(0), int(blocksize), int(prune_n), int(prune_m), n, rows_c, sp_c,
+        err.data_ptr(), err.stride(0), mask_out.data_ptr() if mask_out is not None else None,
+        mask_out.stride(0) if mask_out is not None else 0, ws.data_ptr() if ws is not None else None, _stream()))
 
 
 _SELECT_SWEEP = __import__("os").environ.get("VLMC_SGPT_SELECT_SWEEP", "1") != "0"
@@ -710,17 +674,19 @@ def fasterprune(layer, H: torch.Tensor, sparsity, prune_n=0, prune_m=0, blocksiz
     diag = torch.diag(U)
     score_mean = (W ** 2 / diag.reshape(1, -1) ** 2).abs().mean()
     rows, cols = W.shape
-    blocks = BlockedSweep(W, U, blocksize)
     pruned = torch.zeros((rows, cols), dtype=torch.bool, device=W.device) if return_mask else None
     fused = prune_n == 0 and _SELECT_THRESHOLD and select_sweep_usable([rows], W.device)
-    for i1 in range(0, cols, blocksize):
+    whole = _BLOCK_LOOP and (prune_n != 0 or fused)
+    if whole:                                                                              # :167-212, every block, from one call
+        prune_blocks(W, U, blocksize, prune_n, prune_m, [rows], [sparsity], pruned)
+    err = None if whole else torch.empty((rows, min(blocksize, cols)), dtype=torch.float32, device=W.device)
+    for i1 in (() if whole else range(0, cols, blocksize)):
         i2 = min(i1 + blocksize, cols)
         mask1 = None
-        err = blocks.err()
         if fused:                                                                          # :183-205 in one launch
             rank = min(int(rows * (i2 - i1) * sparsity), rows * (i2 - i1) - 1)
             select_sweep_block(W, i1, i2, U, [rows], [rank], err, pruned)
-            blocks.after_sweep(i1, i2)                                                     # :210
+            trailing_update(W, i2, cols, err, U, i1, i2)                                   # :210
             continue
         if prune_n == 0:
             tmp = W[:, i1:i2] ** 2 / diag[i1:i2].reshape(1, -1) ** 2                       # :183
@@ -734,8 +700,7 @@ def fasterprune(layer, H: torch.Tensor, sparsity, prune_n=0, prune_m=0, blocksiz
                 thresh = torch.sort(tmp.flatten())[0][int(tmp.numel() * sparsity)]         # :184
                 mask1 = (tmp <= thresh).contiguous()                                        # :185
         sweep_block(W, i1, i2, U, mask1, prune_n, prune_m, err, pruned)
-        blocks.after_sweep(i1, i2)                                                         # :210
-    blocks.finish()
+        trailing_update(W, i2, cols, err, U, i1, i2)                                       # :210
     if score_sink is None:
         setattr(layer.weight, "importance_score", score_mean.item())                       # :165
     else:
@@ -769,17 +734,19 @@ def fasterprune_group(layers, sparsities, factor_cache, prune_n=0, prune_m=0, bl
     for r in rows:
         bounds.append(bounds[-1] + r)
     means = [(W[bounds[i]:bounds[i + 1]] ** 2 / dsq).abs().mean() for i in range(len(layers))]
-    blocks = BlockedSweep(W, U, blocksize)
-    keep = torch.empty((W.shape[0], min(blocksize, cols)), dtype=torch.bool, device=W.device) if prune_n == 0 else None
     fused = prune_n == 0 and _SELECT_THRESHOLD and select_sweep_usable(rows, W.device)
-    for i1 in range(0, cols, blocksize):
+    whole = _BLOCK_LOOP and (prune_n != 0 or fused)
+    if whole:                                                                              # :167-212, every block, from one call
+        prune_blocks(W, U, blocksize, prune_n, prune_m, rows, sparsities, None)
+    keep = torch.empty((W.shape[0], min(blocksize, cols)), dtype=torch.bool, device=W.device) if (prune_n == 0 and not whole) else None
+    err = None if whole else torch.empty((W.shape[0], min(blocksize, cols)), dtype=torch.float32, device=W.device)
+    for i1 in (() if whole else range(0, cols, blocksize)):
         i2 = min(i1 + blocksize, cols)
         mask1 = None
-        err = blocks.err()
         if fused:                                                                          # :183-205 in one launch, a scope per linear
             ranks = [min(int(r * (i2 - i1) * sp), r * (i2 - i1) - 1) for r, sp in zip(rows, sparsities)]
             select_sweep_block(W, i1, i2, U, rows, ranks, err, None)
-            blocks.after_sweep(i1, i2)                                                     # :210
+            trailing_update(W, i2, cols, err, U, i1, i2)                                   # :210
             continue
         if prune_n == 0:
             tmp = W[:, i1:i2] ** 2 / dsq[:, i1:i2]                                          # :183
@@ -790,8 +757,7 @@ def fasterprune_group(layers, sparsities, factor_cache, prune_n=0, prune_m=0, bl
                              apply_weights=False, keeps=[kb[bounds[i]:bounds[i + 1]] for i in range(len(layers))])
             mask1 = torch.logical_not(kb)
         sweep_block(W, i1, i2, U, mask1, prune_n, prune_m, err, None)
-        blocks.after_sweep(i1, i2)                                                         # :210
-    blocks.finish()
+        trailing_update(W, i2, cols, err, U, i1, i2)                                       # :210
     for i, layer in enumerate(layers):
         if score_sink is None:
             setattr(layer.weight, "importance_score", means[i].item())                     # :165
