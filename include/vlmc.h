@@ -233,7 +233,10 @@ int vlmc_unpack_24(const void *values, const uint8_t *meta, int dtype, int64_t o
  * Y [M, N] (row stride ldy).  K, ldx, ldw multiples of 8 elements; X, W 16-byte aligned.
  * Batch-invariant: every output element is ONE accumulator fed the K-steps in ascending order by one
  * matrix-core instruction shape (v_mfma_f32_16x16x32), whatever M is -- replaying 1 or 128 calibration
- * samples per call, or any share of them on another GPU, yields identical rows.                     */
+ * samples per call, or any share of them on another GPU, yields identical rows.
+ * dtype VLMC_F32 (round 6: the reference's Q-Former, `ln_vision` and `t5_proj` stay in fp32 outside autocast, blip2_t5_instruct.py:76-95,
+ * :143-175): fp32 operands and output on v_mfma_f32_32x32x2_f32, one accumulator per element over k in ascending pairs -- the same
+ * invariance; no alignment requirement beyond 4 bytes.  (vlmc_linear_fwd_group / _rows / _post are 16-bit only.)                    */
 int vlmc_linear_fwd(const void *X, const void *W, const void *bias, int dtype, int64_t M, int64_t N, int64_t K, int64_t ldx,
                     int64_t ldw, void *Y, int64_t ldy, void *stream);
 
@@ -286,7 +289,9 @@ int vlmc_linear_fwd_post(const void *X, const void *W, const void *bias, int dty
  * sc_* for C, whose n stride is 1).  A batch stride of 0 broadcasts.  Rows need not be 16-byte aligned (2-byte aligned
  * pointers suffice).  Batch-invariant like vlmc_linear_fwd: every output element is ONE accumulator fed the K-steps of 32
  * in ascending order (tail zero-padded) by v_mfma_f32_16x16x32, whatever batch0 x batch1, M and N are -- the products of
- * one calibration sample have the same bits alone, in a group of 128, or on another GPU.                     */
+ * one calibration sample have the same bits alone, in a group of 128, or on another GPU.
+ * dtype VLMC_F32 (the fp32 Q-Former's `torch.matmul(query_layer, key_layer.transpose(-1, -2))` / `torch.matmul(attention_probs,
+ * value_layer)`, Qformer.py:201,246): fp32 operands and output on v_mfma_f32_32x32x2_f32, k in ascending pairs; batch0 * batch1 <= 65535. */
 int vlmc_attn_matmul(const void *A, const void *B, void *C, int dtype, int64_t batch0, int64_t batch1, int64_t M, int64_t N,
                      int64_t K, int64_t sa_b0, int64_t sa_b1, int64_t sa_m, int64_t sb_b0, int64_t sb_b1, int64_t sb_k,
                      int64_t sb_n, int64_t sc_b0, int64_t sc_b1, int64_t sc_m, void *stream);
@@ -325,7 +330,8 @@ int vlmc_row_mean(const float *x, int64_t rows, int64_t n, int64_t ldx, float *o
  * code than its body (hipcc contracts x/2 * (1 + erf) into an fma there: ~20 % of all 16-bit inputs differ in the last bit), so which
  * rows of a batch get which bits depends on how many samples share the forward.  This kernel uses the body's arithmetic everywhere:
  * equal to torch's body for all 65 536 fp16 / bf16 inputs, batch-invariant.  tanh_approx: 0 = erf form, 1 = `approximate="tanh"`.
- * x, y: n contiguous 16-bit elements (y may be x).                                                                            */
+ * x, y: n contiguous 16-bit elements (y may be x); dtype VLMC_F32 (the fp32 Q-Former's feed-forward): the same arithmetic on fp32
+ * elements, nothing rounded to 16 bits.                                                                                          */
 int vlmc_gelu(const void *x, void *y, int64_t n, int dtype, int tanh_approx, void *stream);
 
 /* Row-wise softmax over the last dimension, PADDING-invariant: `F.softmax(scores.float(), dim=-1)` (modeling_t5.py:604-606),

@@ -286,7 +286,7 @@ def test_stand_in_attention_modules_give_the_same_bits_on_the_lazy_route(kind, m
         x = torch.randn(3, 45, 256, device=DEV).half()
         mask = torch.zeros(3, 1, 1, 45, device=DEV, dtype=torch.float16)
         mask[1, ..., 40:] = torch.finfo(torch.float16).min
-        call = lambda: mod(x, attention_mask=mask)
+        call = lambda: mod(x, mask, None, None, None, None, False)[0]          # (Qformer.py:176-185: positional, returns (context, (key, value)))
     linears = [m for m in mod.modules() if isinstance(m, torch.nn.Linear)]
     forward._FUSED_OK.clear()
     with torch.no_grad(), forward.invariant_linears(linears, roots=[mod]):

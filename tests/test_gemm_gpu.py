@@ -420,3 +420,57 @@ def test_linear_fwd_rows_refuses_bad_maps():
     job = (_lib.LinearJob * 1)(_lib.LinearJob(w.data_ptr(), None, x.data_ptr(), 8, 64, 8))
     assert lib.vlmc_linear_fwd_rows(x.data_ptr(), job, 1, _lib.F16, 8, 64, 64, None, 4, None) == _lib.VLMC_EINVAL
     assert lib.vlmc_linear_fwd_rows(x.data_ptr(), job, 1, _lib.F16, 8, 64, 64, rm.data_ptr(), 9, None) == _lib.VLMC_EINVAL
+
+
+# ---- fp32 on fp32 matrix cores (round 6): the reference's Q-Former stays in fp32 (blip2_t5_instruct.py:76-95, :143-175) -------------
+@pytest.mark.parametrize("M,N,K,bias", [(1, 8, 8, False), (5, 24, 40, True), (300, 768, 768, True), (257 * 3, 768, 1408, True),
+                                        (130, 3072, 768, True), (64, 768, 3072, False), (127, 129, 65, True), (33, 2048, 768, True)])
+def test_linear_fwd_fp32_matches_fp64_and_is_batch_invariant(M, N, K, bias):
+    from vlmc import ops
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g, device=DEV) * 0.5 + 0.1
+    w = torch.randn(N, K, generator=g, device=DEV) * 0.05
+    b = torch.randn(N, generator=g, device=DEV) * 0.1 if bias else None
+    y = ops.linear_fwd(x, w, b)
+    assert y.shape == (M, N) and y.dtype == torch.float32
+    ref = _ref64(x, w, b)
+    scale = x.double().abs() @ w.double().abs().t() + (b.double().abs() if b is not None else 0)
+    assert bool(((y.double() - ref).abs() <= 1e-6 * scale + 1e-30).all())
+    # rows do not depend on what else is in the launch; a 3-D strided input is read through its strides
+    for r in sorted({0, M // 2, M - 1}):
+        assert torch.equal(ops.linear_fwd(x[r:r + 1], w, b)[0], y[r]), r
+    if M >= 6:
+        x3 = torch.cat([x, x], dim=1)[:, :K].reshape(2, M // 2, K) if M % 2 == 0 else None
+        if x3 is not None:
+            assert torch.equal(ops.linear_fwd(x3, w, b).reshape(M, N), y)
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,d", [(3, 12, 45, 45, 64), (2, 12, 32, 257, 64), (1, 4, 7, 5, 16), (5, 12, 160, 160, 64)])
+def test_attn_matmul_fp32_both_products_match_fp64_and_are_batch_invariant(B, H, Tq, Tk, d):
+    """`torch.matmul(q, k.transpose(-1, -2))` and `torch.matmul(probs, v)` of the fp32 Q-Former (Qformer.py:201,246) through permuted views."""
+    from vlmc import ops
+    g = torch.Generator(device=DEV).manual_seed(B + Tq + Tk)
+    q = torch.randn(B, Tq, H, d, generator=g, device=DEV).permute(0, 2, 1, 3)            # `transpose_for_scores`: a permuted view
+    k = torch.randn(B, Tk, H, d, generator=g, device=DEV).permute(0, 2, 1, 3)
+    v = torch.randn(B, Tk, H, d, generator=g, device=DEV).permute(0, 2, 1, 3)
+    s = ops.attn_matmul(q, k.transpose(-1, -2))
+    assert s.shape == (B, H, Tq, Tk) and s.dtype == torch.float32
+    ref = q.double() @ k.double().transpose(-1, -2)
+    assert bool(((s.double() - ref).abs() <= 1e-6 * (q.double().abs() @ k.double().abs().transpose(-1, -2)) + 1e-30).all())
+    p = torch.softmax(s / 8.0, dim=-1)
+    o = ops.attn_matmul(p, v)
+    assert bool(((o.double() - p.double() @ v.double()).abs() <= 1e-6 * (p.double().abs() @ v.double().abs()) + 1e-30).all())
+    for bi in (0, B - 1):                                                                 # one sample alone: the same bits
+        assert torch.equal(ops.attn_matmul(q[bi:bi + 1], k[bi:bi + 1].transpose(-1, -2))[0], s[bi])
+        assert torch.equal(ops.attn_matmul(p[bi:bi + 1], v[bi:bi + 1])[0], o[bi])
+
+
+def test_gelu_fp32_is_torchs_body_arithmetic_everywhere():
+    from vlmc import ops
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(4097 * 3 + 5, generator=g, device=DEV) * 3
+    y = ops.gelu(x)
+    ref = torch.nn.functional.gelu(x[:4096 * 3].double()).float()
+    assert torch.allclose(y[:4096 * 3], ref, rtol=2e-6, atol=1e-7)
+    assert torch.equal(ops.gelu(x[100:]), y[100:])                                          # position in the tensor does not matter
+    assert torch.allclose(ops.gelu(x, "tanh"), torch.nn.functional.gelu(x, approximate="tanh"), rtol=1e-5, atol=1e-6)

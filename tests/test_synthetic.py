@@ -108,3 +108,51 @@ def test_small_synthetic_vicuna_through_the_dsnot_pruner():
                                            t5_model_prefix="llm_model", max_cycle_time=8)
     assert info["linears"] == 2 * 4 + 2 * 7
     assert abs(info["pruned_fraction"] - 0.5) < 0.01
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ragged", [False, True])
+def test_q_former_with_the_references_call_contract_takes_the_stacked_routes(ragged, monkeypatch):
+    """ The reference-op stand-in calls its Q-Former as the reference does -- fp32 weights outside autocast, layers called
+    POSITIONALLY with tensor extended masks, `(layer_output, (key, value))` coming back (Qformer.py:470-474, :541-550, :795-801) -- and the
+    engine still runs it like a finished tower: stacked over the samples (fp32 linears, attention products and GELU on the
+    batch-invariant fp32 kernels), remembered from the encoder's phase to the decoder's (nested-tuple outputs handed on as
+    `(hidden_states, ..)`), merged capture forwards checked bit for bit.  Masks and weights of the whole prune equal the route in
+    which every calibration sample goes through everything alone."""
+    from vlmc import forward, synthetic
+    from lavis.compression.pruners import calibration
+    dev = torch.device("cuda:0")
+    monkeypatch.setattr(calibration, "MERGED_CAPTURE_MIN", 2)
+
+    def run(per_sample):
+        monkeypatch.setenv("VLMC_BATCH_REPLAY", "1" if per_sample else "128")
+        monkeypatch.setenv("VLMC_TOWER_BATCH", "0" if per_sample else "1")
+        torch.manual_seed(0)
+        model = synthetic.InstructBlipT5(vit_dim=64, vit_hidden=128, vit_heads=4, vit_depth=2, d_model=64, d_ff=128, heads=4, d_kv=16,
+                                         enc_depth=2, dec_depth=2, vocab=100, query_tokens=4, qformer_dim=64, qformer_heads=4, qformer_hidden=128,
+                                         qformer_depth=4, qformer_vocab=50, reference_ops=True).to(dev).eval()
+        layer = model.Qformer.bert.encoder.layer[0]
+        assert layer.attention.self.query.weight.dtype == torch.float32 and model.t5_proj.weight.dtype == torch.float32
+        out = layer(torch.zeros(1, 6, 64, device=dev), torch.zeros(1, 1, 1, 6, device=dev), None, torch.zeros(1, 9, 64, device=dev),
+                    torch.zeros(1, 1, 1, 9, device=dev), None, False, 4)
+        assert isinstance(out, tuple) and len(out) == 2 and isinstance(out[1], tuple) and len(out[1]) == 2 and out[1][0].shape == (1, 4, 6, 16)
+        batches = synthetic.calibration_batches(12, dev, vit_tokens=9, vit_dim=64, text_len=5, out_len=3, vocab=100, ragged=ragged)
+        before = dict(calibration.graph_stats)
+        lib0 = forward.stats["library"]
+        synthetic.time_prune(dev, n_samples=12, model=model, batches=batches)
+        delta = {k: v - before.get(k, 0) for k, v in calibration.graph_stats.items() if isinstance(v, (int, float))}
+        delta["library_linears"] = forward.stats["library"] - lib0
+        return {n: (m.weight.detach().clone(), m.mask.clone()) for n, m in model.named_modules() if isinstance(m, nn.Linear) and hasattr(m, "mask")}, delta
+
+    got, stats = run(False)
+    ref, _ = run(True)
+    print("graph_stats of the stacked route:", {k: v for k, v in stats.items() if v})
+    # the fp32 Q-Former ran stacked -- inside the merged capture forwards (equal lengths), or as a finished tower per group of equal
+    # shapes / one padded pass (ragged) -- and was remembered for the decoder's phase; nothing fell back, every linear on an invariant kernel
+    assert stats.get("merged_forwards", 0) >= 2 or stats.get("tower_batches", 0) >= 2, stats
+    assert stats.get("memo_recorded", 0) >= 12 and stats.get("memo_hits", 0) >= 1, stats
+    assert stats.get("merged_capture_mismatch", 0) == 0 and stats.get("merged_capture_errors", 0) == 0 and stats.get("fallbacks", 0) == 0, stats
+    assert stats["library_linears"] == 0, stats
+    assert got.keys() == ref.keys() and len(got) == 2 * 4 + 2 * 7 + 2 * 11
+    for k in got:
+        assert torch.equal(got[k][0], ref[k][0]) and torch.equal(got[k][1], ref[k][1]), k

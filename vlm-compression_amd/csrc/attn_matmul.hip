@@ -269,9 +269,18 @@ __global__ __launch_bounds__(NT_) void attn_matmul_kernel(const BmmArgs a) {
 
 using namespace vlmc;
 
+namespace vlmc {
+int attn_matmul_f32(const void *A, const void *B, void *C, int64_t batch0, int64_t batch1, int64_t M, int64_t N, int64_t K, int64_t sa_b0,
+                    int64_t sa_b1, int64_t sa_m, int64_t sa_k, int64_t sb_b0, int64_t sb_b1, int64_t sb_k, int64_t sb_n, int64_t sc_b0,
+                    int64_t sc_b1, int64_t sc_m, hipStream_t s);                  // gemm_f32.hip
+}
+
 extern "C" int vlmc_attn_matmul(const void *A, const void *B, void *C, int dtype, int64_t batch0, int64_t batch1, int64_t M, int64_t N,
                                 int64_t K, int64_t sa_b0, int64_t sa_b1, int64_t sa_m, int64_t sb_b0, int64_t sb_b1, int64_t sb_k,
                                 int64_t sb_n, int64_t sc_b0, int64_t sc_b1, int64_t sc_m, void *stream) {
+    if (dtype == VLMC_F32)                                            // (the fp32 Q-Former's attention products: fp32 matrix cores)
+        return attn_matmul_f32(A, B, C, batch0, batch1, M, N, K, sa_b0, sa_b1, sa_m, 1, sb_b0, sb_b1, sb_k, sb_n, sc_b0, sc_b1, sc_m,
+                               as_stream(stream));
     VLMC_REQUIRE(dtype == VLMC_F16 || dtype == VLMC_BF16, "vlmc_attn_matmul: dtype must be VLMC_F16 or VLMC_BF16");
     VLMC_REQUIRE(A && B && C, "vlmc_attn_matmul: null pointer");
     VLMC_REQUIRE(batch0 > 0 && batch1 > 0 && M > 0 && N > 0 && K > 0, "vlmc_attn_matmul: empty product");

@@ -145,6 +145,13 @@ LaunchEvents take_launch_events();                 // returns the pending pair (
         else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                \
     } while (0)
 
+#define VLMC_LAUNCH_TIMED_LDS(kernel, grid, block, lds, stream, ...)                                          \
+    do {                                                                                                     \
+        const ::vlmc::LaunchEvents ev_ = ::vlmc::take_launch_events();                                       \
+        if (ev_.start || ev_.stop) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ev_.start, ev_.stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                              \
+    } while (0)
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 __device__ __forceinline__ bool aligned16_dev(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -49,12 +49,49 @@ __global__ __launch_bounds__(256) void gelu_kernel(const uint16_t *__restrict__ 
     }
 }
 
+// fp32 tensors (the reference's Q-Former stays in fp32, blip2_t5_instruct.py:76-95): the same body arithmetic, nothing to round
+template <int TANH>
+__global__ __launch_bounds__(256) void gelu_f32_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n, int vec) {
+    const int64_t chunks = (n + 3) / 4;
+    for (int64_t c = int64_t(blockIdx.x) * 256 + threadIdx.x; c < chunks; c += int64_t(gridDim.x) * 256) {
+        const int64_t e0 = c * 4;
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool whole = vec && e0 + 4 <= n;
+        if (whole) {
+            const u32x4_t v = *reinterpret_cast<const u32x4_t *>(x + e0);
+            __builtin_memcpy(e, &v, 16);
+        } else {
+            for (int j = 0; j < 4 && e0 + j < n; ++j) e[j] = x[e0 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = e[j];
+            float r;
+            if (TANH) {
+                constexpr float kBeta = 1.41421356237309504880f * 1.12837916709551257390f * 0.5f, kKappa = 0.044715f;
+                const float x3 = ieee_mul(ieee_mul(v, v), v);
+                r = ieee_mul(ieee_mul(0.5f, v), ieee_add(1.0f, tanhf(ieee_mul(kBeta, ieee_add(v, ieee_mul(kKappa, x3))))));
+            } else {
+                r = ieee_mul(ieee_mul(v, 0.5f), ieee_add(1.0f, erff(ieee_mul(v, 0.70710678118654752440f))));
+            }
+            e[j] = r;
+        }
+        if (whole) {
+            u32x4_t o;
+            __builtin_memcpy(&o, e, 16);
+            *reinterpret_cast<u32x4_t *>(y + e0) = o;
+        } else {
+            for (int j = 0; j < 4 && e0 + j < n; ++j) y[e0 + j] = e[j];
+        }
+    }
+}
+
 }  // namespace vlmc
 
 using namespace vlmc;
 
 extern "C" int vlmc_gelu(const void *x, void *y, int64_t n, int dtype, int tanh_approx, void *stream) {
-    VLMC_REQUIRE(dtype == VLMC_F16 || dtype == VLMC_BF16, "vlmc_gelu: dtype must be VLMC_F16 or VLMC_BF16");
+    VLMC_REQUIRE(dtype == VLMC_F16 || dtype == VLMC_BF16 || dtype == VLMC_F32, "vlmc_gelu: dtype must be VLMC_F16, VLMC_BF16 or VLMC_F32");
     VLMC_REQUIRE(x && y && n >= 0, "vlmc_gelu: null pointer or negative size");
     VLMC_REQUIRE(tanh_approx == 0 || tanh_approx == 1, "vlmc_gelu: tanh_approx must be 0 (erf) or 1 (tanh)");
     if (n == 0) return VLMC_OK;
@@ -63,6 +100,12 @@ extern "C" int vlmc_gelu(const void *x, void *y, int64_t n, int dtype, int tanh_
     if (blocks > 256 * 16) blocks = 256 * 16;
     const dim3 grid{unsigned(blocks)}, block{256};
     hipStream_t s = as_stream(stream);
+    if (dtype == VLMC_F32) {
+        if (tanh_approx) hipLaunchKernelGGL((gelu_f32_kernel<1>), grid, block, 0, s, static_cast<const float *>(x), static_cast<float *>(y), n, vec);
+        else hipLaunchKernelGGL((gelu_f32_kernel<0>), grid, block, 0, s, static_cast<const float *>(x), static_cast<float *>(y), n, vec);
+        VLMC_HIP_CHECK_LAUNCH("vlmc_gelu");
+        return VLMC_OK;
+    }
     const uint16_t *xi = static_cast<const uint16_t *>(x);
     uint16_t *yo = static_cast<uint16_t *>(y);
     if (dtype == VLMC_F16) {

@@ -1477,8 +1477,14 @@ static int linear_group_launch(const char *what, const void *X, const vlmc_linea
     return VLMC_OK;
 }
 
+namespace vlmc {
+int linear_fwd_f32(const void *X, const void *W, const void *bias, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, void *Y,
+                   int64_t ldy, hipStream_t s);                                  // gemm_f32.hip
+}
+
 extern "C" int vlmc_linear_fwd(const void *X, const void *W, const void *bias, int dtype, int64_t M, int64_t N, int64_t K,
                                int64_t ldx, int64_t ldw, void *Y, int64_t ldy, void *stream) {
+    if (dtype == VLMC_F32) return linear_fwd_f32(X, W, bias, M, N, K, ldx, ldw, Y, ldy, as_stream(stream));   // (the fp32 Q-Former: fp32 matrix cores)
     const vlmc_linear_job job{W, bias, Y, N, ldw, ldy};
     return linear_group_launch("vlmc_linear_fwd", X, &job, 1, dtype, M, K, ldx, stream);
 }

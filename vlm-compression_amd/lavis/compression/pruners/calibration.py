@@ -173,6 +173,35 @@ def tower_memo_enabled():
     return os.environ.get("VLMC_TOWER_MEMO", "1") != "0"
 
 
+class _HiddenOnly(tuple):
+    """What a block of a REMEMBERED tower returns when the tower's blocks return `(hidden_states, more..)` -- a BERT layer's
+    `(layer_output, present_key_value)` (Qformer.py:470-474): element 0 is the hidden states; the other outputs were never computed
+    (the block did not run), so reading them raises instead of handing the model a stand-in value."""
+
+    def __new__(cls, hidden, n):
+        return super().__new__(cls, (hidden,) + (None,) * (n - 1))
+
+    def __getitem__(self, i):
+        if isinstance(i, int) and (i == 0 or i == -len(self)):
+            return tuple.__getitem__(self, 0)
+        raise RuntimeError("tower memo: only the hidden states (element 0) of a remembered block exist; the model reads another of the "
+                           "block's outputs -- set VLMC_TOWER_MEMO=0")
+
+    def __iter__(self):
+        raise RuntimeError("tower memo: only the hidden states (element 0) of a remembered block exist; the model unpacks the block's "
+                           "outputs -- set VLMC_TOWER_MEMO=0")
+
+
+def _memo_kind(result):
+    """How a block hands on its hidden states: None = the tensor itself; (tuple | list, n) = element 0 of a sequence of n outputs
+    (n = 1: transformers' `(hidden_states,)`; n > 1: a BERT layer's `(layer_output, present_key_value)`); False = neither."""
+    if isinstance(result, torch.Tensor):
+        return None
+    if type(result) in (tuple, list) and len(result) >= 1 and isinstance(result[0], torch.Tensor):
+        return (type(result), len(result))
+    return False
+
+
 class TowerMemo:
     """What a FINISHED tower produced for each calibration forward of one capture phase, for the next phase.
 
@@ -192,8 +221,8 @@ class TowerMemo:
         self.entries, self.mode, self.ok = {}, "record", True        # entries: index of the calibration forward -> record
         self.cursor, self.hit, self.pending, self.expect, self.bytes = 0, None, None, 0, 0
         self.current = 0
-        self.wrap = False            # how the blocks return their hidden states: None = the tensor itself, tuple / list = a sequence
-                                     # of that ONE tensor (BERT-style layers: `layer(...)[0]`); False = not seen yet
+        self.wrap = False            # how the blocks return their hidden states (_memo_kind): None = the tensor itself, (tuple | list, n) =
+                                     # element 0 of a sequence of n outputs (BERT-style layers: `layer(...)[0]`); False = not seen yet
 
     @staticmethod
     def fingerprint(blocks):
@@ -228,6 +257,13 @@ class TowerMemo:
         self.mode, self.cursor, self.hit, self.pending, self.expect = mode, 0, None, None, 0
         if mode == "record":
             self.entries, self.bytes = {}, 0
+
+    def hand(self, t):
+        """hidden states `t` in the form the tower's blocks return them"""
+        if not self.wrap:
+            return t
+        kind, n = self.wrap
+        return kind((t,)) if n == 1 else _HiddenOnly(t, n)
 
     @staticmethod
     def context():
@@ -269,14 +305,32 @@ class TowerMemo:
         if ctx0 != self.context() or len(rargs0) != len(args) or sorted(rkw0) != sorted(kwargs) or x.shape[0] != b * len(group) or \
                 x.shape[1:] != rargs0[0].shape[1:]:
             return None
-        for r, v in list(zip(rargs0[1:], args[1:])) + [(rkw0[k], kwargs[k]) for k in rkw0]:
-            if isinstance(r, torch.Tensor) or isinstance(v, torch.Tensor) or (r is not v and r != v):
-                return None                                         # (only towers whose blocks get nothing but the hidden states and plain values)
-        parts = x.split(b, dim=0)
-        for (rec, _out), part in zip(ents, parts):
-            rargs, rkw, ctx = rec
-            if ctx != ctx0 or len(rargs) != len(args) or not _bits_equal(rargs[0], part):
+        # the other arguments: plain values as remembered; tensors either carry the batch (a BERT layer's extended masks, the image
+        # states of its cross-attention: cut per sample and held against each sample's record) or are one tensor for every sample
+        others = []
+        for pos, (r, v) in enumerate(list(zip(rargs0[1:], args[1:])) + [(rkw0[k], kwargs[k]) for k in sorted(rkw0)]):
+            if isinstance(r, torch.Tensor) != isinstance(v, torch.Tensor):
                 return None
+            if not isinstance(v, torch.Tensor):
+                if r is not v and r != v:
+                    return None
+                others.append(None)
+            elif v.dim() >= 2 and v.shape[0] == b * len(group) and r.shape[0] == b and v.shape[1:] == r.shape[1:]:
+                others.append(v.split(b, dim=0))
+            elif v.shape == r.shape:
+                others.append(v)
+            else:
+                return None
+        parts = x.split(b, dim=0)
+        for t, ((rec, _out), part) in enumerate(zip(ents, parts)):
+            rargs, rkw, ctx = rec
+            if ctx != ctx0 or len(rargs) != len(args) or sorted(rkw) != sorted(rkw0) or not _bits_equal(rargs[0], part):
+                return None
+            for o, r in zip(others, list(rargs[1:]) + [rkw[k] for k in sorted(rkw0)]):
+                if o is None:
+                    continue
+                if not isinstance(r, torch.Tensor) or not _bits_equal(r, o[t] if isinstance(o, tuple) else o):
+                    return None
         return torch.cat([e[1] for e in ents], dim=0)
 
     def enter(self, index, args, kwargs):
@@ -336,8 +390,8 @@ class TowerMemo:
             return False, None
         if index == self.n - 1:
             out, self.hit = (self.hit if self.hit_fresh else self.hit.clone()), None
-            return True, (self.wrap((out,)) if self.wrap else out)
-        return True, (self.wrap((args[0],)) if self.wrap else args[0])
+            return True, self.hand(out)
+        return True, self.hand(args[0])
 
     def leave(self, index, result):
         if _CTX.capture_group is not None:
@@ -345,9 +399,8 @@ class TowerMemo:
                     and self.expect == self.n:
                 _tag, group, b, snaps = self.pending
                 self.pending = None
-                kind = None if isinstance(result, torch.Tensor) else \
-                    (type(result) if type(result) in (tuple, list) and len(result) == 1 and isinstance(result[0], torch.Tensor) else False)
-                if kind is False or (self.wrap is not False and self.wrap is not kind):
+                kind = _memo_kind(result)
+                if kind is False or (self.wrap is not False and self.wrap != kind):
                     return
                 self.wrap = kind
                 out = result if kind is None else result[0]
@@ -363,9 +416,8 @@ class TowerMemo:
             return
         if self.ok and self.mode == "record":
             # every block must hand its hidden states on the same way: the tensor, or a 1-tuple / 1-list of it
-            kind = None if isinstance(result, torch.Tensor) else \
-                (type(result) if type(result) in (tuple, list) and len(result) == 1 and isinstance(result[0], torch.Tensor) else False)
-            if kind is False or (self.wrap is not False and self.wrap is not kind):
+            kind = _memo_kind(result)
+            if kind is False or (self.wrap is not False and self.wrap != kind):
                 self._drop()
                 return
             self.wrap = kind
@@ -567,7 +619,35 @@ class TowerGraph:
     # -- helpers ---------------------------------------------------------------------------------------------------
     @staticmethod
     def _flat(out):
-        return list(out) if isinstance(out, (tuple, list)) else [out]
+        """The leaves of a block's output in order: the output itself, or the entries of a (nested) tuple / list of outputs --
+        a BERT layer returns `(hidden_states, (key, value))` (Qformer.py:470-474), a T5 block `(hidden, position_bias, ..)`."""
+        if not isinstance(out, (tuple, list)):
+            return [out]
+        flat = []
+        for o in out:
+            if isinstance(o, (tuple, list)):
+                flat += TowerGraph._flat(o)
+            else:
+                flat.append(o)
+        return flat
+
+    @staticmethod
+    def _like(out, flat):
+        """`flat` (as many leaves as `_flat(out)` has) in the nesting of `out`."""
+        it = iter(flat)
+
+        def build(o):
+            if isinstance(o, (tuple, list)):
+                return type(o)(build(e) for e in o) if type(o) in (tuple, list) else tuple(build(e) for e in o)
+            return next(it)
+        return build(out)
+
+    @staticmethod
+    def _shape_of(out):
+        """the nesting of an output without its leaves (what a traced call is compared by)"""
+        if isinstance(out, (tuple, list)):
+            return ("L" if isinstance(out, list) else "T",) + tuple(TowerGraph._shape_of(o) for o in out)
+        return None
 
     def _key0(self, args, kwargs, ctx=None):
         """What decides the tower's kernels and the wiring, from block 0's arguments (the stream slot is not part of it)."""
@@ -713,7 +793,7 @@ class TowerGraph:
                             flat.append(torch.cat([self._flat(r["outs"][i])[pos] for r in recs], dim=0) if g > 1 else o0)
                         else:
                             flat.append(o0)
-                    outs.append(tuple(flat) if isinstance(firsts, tuple) else flat if isinstance(firsts, list) else flat[0])
+                    outs.append(self._like(firsts, flat))
                 given, k, seen = {}, 0, set()
                 for v in list(args) + [kwargs[kk] for kk in sorted(kwargs)]:
                     if isinstance(v, torch.Tensor) and id(v) not in seen:
@@ -812,7 +892,7 @@ class TowerGraph:
             if isinstance(o, torch.Tensor):
                 tr["known"][id(o)] = (o, ("out", index, pos))
                 bt["ver"][id(o)] = o._version
-        tr["calls"].append((tuple(wires), tuple(sorted(kwires.items())), isinstance(out, tuple), isinstance(out, list),
+        tr["calls"].append((tuple(wires), tuple(sorted(kwires.items())), self._shape_of(out), False,
                             tuple(o is None for o in flat)))
         tr["shapes"].append(tuple(tuple(o.shape) if isinstance(o, torch.Tensor) else None for o in mine))
         tr["next"] = index + 1
@@ -827,13 +907,13 @@ class TowerGraph:
                     outs2 = []
                     for o_, pp in zip(bt["outs"], bt["parts"]):
                         fl = [(sp[t2] if sp is not None else o) for o, sp in zip(self._flat(o_), pp)]
-                        outs2.append(tuple(fl) if isinstance(o_, tuple) else fl if isinstance(o_, list) else fl[0])
+                        outs2.append(self._like(o_, fl))
                     self.ready[rec["j"]] = {"outs": outs2, "args": rec["args"], "kwargs": rec["kwargs"], "key": tr["key"]}
                 graph_stats["tower_predicted"] = graph_stats.get("tower_predicted", 0) + len(bt["chunk"]) - 1
                 graph_stats["tower_batches"] = graph_stats.get("tower_batches", 0) + 1
                 graph_stats["batched_traces"] = graph_stats.get("batched_traces", 0) + 1
             self.trace = self.btrace = None
-        return True, (tuple(mine) if isinstance(out, tuple) else mine if isinstance(out, list) else mine[0])
+        return True, self._like(out, mine)
 
     def leave(self, index, args, kwargs, out):
         tr = self.trace
@@ -854,7 +934,7 @@ class TowerGraph:
         for pos, o in enumerate(flat):
             if isinstance(o, torch.Tensor):
                 tr["known"][id(o)] = (o, ("out", index, pos))
-        tr["calls"].append((tuple(wires), tuple(sorted(kwires.items())), isinstance(out, tuple), isinstance(out, list),
+        tr["calls"].append((tuple(wires), tuple(sorted(kwires.items())), self._shape_of(out), False,
                             tuple(o is None for o in flat)))
         tr["shapes"].append(tuple(tuple(o.shape) if isinstance(o, torch.Tensor) else None for o in flat))
         if index == self.n - 1:
@@ -913,11 +993,7 @@ class TowerGraph:
         for pos, o in enumerate(flat):
             if isinstance(o, torch.Tensor):
                 live["given"][("out", index, pos)] = (o, o._version)
-        if isinstance(out, tuple):
-            return tuple(flat)
-        if isinstance(out, list):
-            return flat
-        return flat[0]
+        return self._like(out, flat)
 
     def _replay(self, plan, args, kwargs):
         given = {}
@@ -979,8 +1055,9 @@ class TowerGraph:
             ok = True
             for m in self.linears:
                 w = getattr(m, "weight", None)
-                if type(m) is not nn.Linear or w is None or w.dtype not in (torch.float16, torch.bfloat16) or w.shape[1] % 8 or \
-                        (ctx[0] and ctx[1] != w.dtype):
+                # 16-bit weights (the kernel's K % 8), or fp32 weights outside autocast (the reference's Q-Former: the fp32 kernel)
+                if type(m) is not nn.Linear or w is None or (ctx[0] and ctx[1] != w.dtype) or \
+                        not ((w.dtype in (torch.float16, torch.bfloat16) and w.shape[1] % 8 == 0) or w.dtype is torch.float32):
                     ok = False
                     break
             self._linears_ok[ctx] = ok
@@ -1146,7 +1223,7 @@ class TowerGraph:
                             for d in c_[1]:
                                 v = v.narrow(d, 0, n_t)
                             flat.append(v)
-                        mine.append(tuple(flat) if isinstance(out, tuple) else flat if isinstance(out, list) else flat[0])
+                        mine.append(self._like(out, flat))
                     done[rec["j"]] = {"outs": mine, "args": rec["args"], "kwargs": rec["kwargs"], "key": rec["key"]}
                 graph_stats["tower_batches"] = graph_stats.get("tower_batches", 0) + 1
                 graph_stats["tower_padded_passes"] = graph_stats.get("tower_padded_passes", 0) + 1
@@ -1199,7 +1276,7 @@ class TowerGraph:
                     mine = []
                     for out, pp in zip(outs, parts):
                         flat = [(sp[t] if sp is not None else o) for o, sp in zip(self._flat(out), pp)]
-                        mine.append(tuple(flat) if isinstance(out, tuple) else flat if isinstance(out, list) else flat[0])
+                        mine.append(self._like(out, flat))
                     self.ready[rec["j"]] = {"outs": mine, "args": rec["args"], "kwargs": rec["kwargs"], "key": key}
                 graph_stats["tower_batches"] = graph_stats.get("tower_batches", 0) + 1
         return [rec["j"] for rec in todo]
@@ -1231,7 +1308,7 @@ class GraphedModule(nn.Module):
             m, index = memo
             if m.hit is not None and m.ok and 0 < index == m.expect < m.n - 1:
                 m.expect = index + 1
-                return m.wrap((args[0],)) if m.wrap else args[0]
+                return m.hand(args[0])
         return self.forward(*args, **kwargs)
 
     @staticmethod

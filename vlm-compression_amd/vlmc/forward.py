@@ -868,7 +868,8 @@ def _make_gelu(orig):
             if type(x) is LazyLinear:
                 r = _ll_gelu(orig, (x,) + args, kw)
                 return r if r is not NotImplemented else gelu(x._realize(), *args, **kw)
-            if type(x) is Tensor and x.is_cuda and x.dtype in ops._16BIT and not torch.is_grad_enabled() and not args and \
+            if type(x) is Tensor and x.is_cuda and (x.dtype in ops._16BIT or (x.dtype is torch.float32 and not torch.is_autocast_enabled())) and \
+                    not torch.is_grad_enabled() and not args and \
                     not (set(kw) - {"approximate"}) and kw.get("approximate", "none") in ("none", "tanh") and x.numel() > 0:
                 stats["gelu_kernel"] += 1
                 return ops.gelu(x, kw.get("approximate", "none"))

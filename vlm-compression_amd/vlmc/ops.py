@@ -99,8 +99,28 @@ def _load_fast():
 _fast = _load_fast()
 
 
+def linear_f32_supported(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> bool:
+    """Whether `linear_fwd` takes this call on its fp32 kernel: fp32 activations, weights (and bias) on the GPU, weight rows contiguous."""
+    f32 = torch.float32
+    return (x.is_cuda and weight.is_cuda and x.dtype is f32 and weight.dtype is f32 and weight.dim() == 2 and x.dim() >= 1
+            and x.shape[-1] == weight.shape[1] and weight.stride(1) == 1 and weight.shape[1] > 0
+            and (bias is None or (bias.is_cuda and bias.dtype is f32 and bias.is_contiguous())))
+
+
+def _linear_fwd_f32(x, weight, bias):
+    N, K = weight.shape
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < K):
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().vlmc_linear_fwd(x2.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None, _lib.F32, M, N, K,
+                                           x2.stride(0) if M > 1 else K, weight.stride(0), y.data_ptr(), N, _stream()))
+    return y.reshape(*x.shape[:-1], N)
+
+
 def linear_fwd_supported(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> bool:
-    """Whether `linear_fwd` takes this call: 16-bit activations and weights of one dtype on the GPU, K a multiple of 8."""
+    """Whether `linear_fwd` takes this call on its 16-bit kernels: 16-bit activations and weights of one dtype on the GPU, K a multiple of 8."""
     return (x.is_cuda and weight.is_cuda and x.dtype == weight.dtype and x.dtype in (torch.float16, torch.bfloat16)
             and weight.dim() == 2 and x.shape[-1] == weight.shape[1] and weight.shape[1] % 8 == 0 and weight.stride(1) == 1
             and weight.stride(0) % 8 == 0 and weight.data_ptr() % 16 == 0
@@ -111,7 +131,10 @@ def linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None 
                _try: bool = False) -> torch.Tensor:
     """y = x @ weight.T + bias on the batch-invariant MFMA kernel (`F.linear` inside the calibration replay's block
     forwards, wanda_pruner.py:308-311,343-346): a row of y depends on its row of x only, whatever else is in the call.
-    `_try`: return None instead of raising when the call is not one the kernel takes."""
+    `_try`: return None instead of raising when the call is not one the kernel takes.  fp32 tensors (the reference's Q-Former): the
+    fp32 matrix-core kernel, the same invariance."""
+    if weight.dtype is torch.float32 and linear_f32_supported(x, weight, bias):
+        return _linear_fwd_f32(x, weight, bias)
     if _fast is not None:
         if not x.is_cuda:
             _need_gpu(x, weight, bias)
@@ -260,7 +283,7 @@ def attn_matmul_plan(a: torch.Tensor, b: torch.Tensor, _cuda_only: bool = True):
     4-D CUDA tensors of one 16-bit dtype, equal (or broadcast) batch dimensions, `a` contiguous along its last dimension,
     `b` along its last (attn @ v) or its second to last (q @ k.transpose(-2, -1)) -- read in place through their strides."""
     nd = a.dim()
-    if nd != b.dim() or nd < 3 or nd > 4 or a.dtype != b.dtype or a.dtype not in _16BIT or \
+    if nd != b.dim() or nd < 3 or nd > 4 or a.dtype != b.dtype or (a.dtype not in _16BIT and a.dtype is not torch.float32) or \
             (_cuda_only and not (a.is_cuda and b.is_cuda)):
         return None
     ash, bsh = a.shape, b.shape
@@ -297,7 +320,22 @@ def attn_matmul_plan(a: torch.Tensor, b: torch.Tensor, _cuda_only: bool = True):
 def attn_matmul(a: torch.Tensor, b: torch.Tensor, _plan=None, _try: bool = False) -> torch.Tensor:
     """`torch.matmul(a, b)` for the batched products of attention (q @ k^T, attn @ v: eva_vit.py:147,164;
     modeling_t5.py:590,638) on the batch-invariant MFMA kernel: an output element has the same bits whatever the batch
-    count, M or N (include/vlmc.h: vlmc_attn_matmul).  `_try`: None instead of an error for a call the kernel does not take."""
+    count, M or N (include/vlmc.h: vlmc_attn_matmul).  `_try`: None instead of an error for a call the kernel does not take.
+    fp32 operands (the reference's Q-Former): the fp32 matrix-core kernel, at most 65535 matrices per call."""
+    if a.dtype is torch.float32:
+        plan = _plan if _plan is not None else attn_matmul_plan(a, b)
+        if plan is not None and plan[0][0] * plan[0][1] > 65535:
+            plan = None
+        if plan is None:
+            if _try:
+                return None
+            _need_gpu(a, b)
+            raise TypeError("vlmc.attn_matmul: 3-D / 4-D tensors of one dtype expected, a contiguous along k, b along k or n")
+        batch, M, N, K, sa0, sa1, sam, sb0, sb1, sbk, sbn = plan
+        out = torch.empty((*(batch if a.dim() == 4 else batch[1:]), M, N), dtype=a.dtype, device=a.device)
+        _lib.check(_lib.load().vlmc_attn_matmul(a.data_ptr(), b.data_ptr(), out.data_ptr(), _lib.F32, batch[0], batch[1], M, N, K, sa0, sa1, sam,
+                                                sb0, sb1, sbk, sbn, batch[1] * M * N, M * N, N, _stream()))
+        return out
     if _fast is not None:
         if not a.is_cuda:
             if _try:
@@ -426,8 +464,8 @@ def gelu(x: torch.Tensor, approximate: str = "none") -> torch.Tensor:
     """`F.gelu(x, approximate=...)` for 16-bit CUDA tensors with one instruction sequence for every element (include/vlmc.h:
     vlmc_gelu): torch's body arithmetic also where torch itself switches to another (its kernels' last partial block)."""
     _need_gpu(x)
-    if x.dtype not in _16BIT or approximate not in ("none", "tanh"):
-        raise TypeError("vlmc.gelu: an fp16 / bf16 tensor and approximate 'none' or 'tanh' expected")
+    if (x.dtype not in _16BIT and x.dtype != torch.float32) or approximate not in ("none", "tanh"):
+        raise TypeError("vlmc.gelu: an fp16 / bf16 / fp32 tensor and approximate 'none' or 'tanh' expected")
     xc = x if x.is_contiguous() else x.contiguous()
     y = torch.empty_like(xc)
     _lib.check(_lib.load().vlmc_gelu(xc.data_ptr(), y.data_ptr(), xc.numel(), _DT[x.dtype], 1 if approximate == "tanh" else 0, _stream()))

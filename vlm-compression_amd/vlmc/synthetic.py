@@ -233,33 +233,49 @@ class T5Block(nn.Module):
 
 
 # ---- the Q-Former between the vision tower and the language model (never pruned) ----------------------------------------------
-# lavis/models/blip2_models/Qformer.py (BertLayer :378-470, BertSelfAttention :111-260) as blip2_t5_instruct.py:146-175 drives it:
-# 12 BERT-base layers (hidden 768, 12 heads, FFN 3072) over [32 learned queries | instruction text]; every second layer the queries
-# cross-attend to the image tokens (encoder width 1408); queries and text have their own feed-forward halves; the first 32 rows
-# of the last layer go to `t5_proj`.  The reference keeps its weights in fp32 and runs it under the model's fp16 autocast; the
-# stand-in holds them in fp16.  Module names are the reference's (`.attention.self.{query,key,value}`, `.attention.output.dense`,
-# `.crossattention...`, `.intermediate[_query].dense`, `.output[_query].dense`: the targets of `qformer_lora_target_modules`).
+# lavis/models/blip2_models/Qformer.py (BertLayer :378-470, BertSelfAttention :111-260, BertEncoder :490-580, BertModel :713-803 /
+# :866-930) as blip2_t5_instruct.py:143-175 drives it: 12 BERT-base layers (hidden 768, 12 heads, FFN 3072) over [32 learned queries |
+# instruction text]; every second layer the queries cross-attend to the image tokens (encoder width 1408); queries and text have their
+# own feed-forward halves; the first 32 rows of the last layer go to `t5_proj`.  The call CONTRACT is the reference's:
+#   * a layer is called POSITIONALLY -- `layer(hidden_states, attention_mask, head_mask, encoder_hidden_states,
+#     encoder_attention_mask, past_key_value, output_attentions, query_length)` (:541-550) -- with TENSOR extended masks,
+#     `(1 - mask[:, None, None, :]) * -10000.0` in the module's dtype (:795-801), head_mask / past_key_value None;
+#   * a layer returns `(layer_output, present_key_value)` with present_key_value = the self-attention's `(key_layer, value_layer)`
+#     (:470-474, :200): a nested tuple, of which the encoder reads element 0 (use_cache is off for a non-decoder);
+#   * the reference keeps the Q-Former, `ln_vision` and `t5_proj` in fp32 and calls them OUTSIDE `maybe_autocast`
+#     (blip2_t5_instruct.py:144 closes the autocast block before `self.Qformer.bert(...)`; under it `ln_vision` returns fp32):
+#     `qformer_dtype=torch.float32` (the default of the reference-op stand-in) does the same; the fp16 form is kept for the
+#     rounds 2-5 stand-in (`reference_ops=False`).
+# Module names are the reference's (`.attention.self.{query,key,value}`, `.attention.output.dense`, `.crossattention...`,
+# `.intermediate[_query].dense`, `.output[_query].dense`: the targets of `qformer_lora_target_modules`).
 class _QfSelfAttention(nn.Module):
     def __init__(self, dim, heads, kv_dim, reference_ops):
         super().__init__()
         self.heads, self.reference_ops = heads, reference_ops
         self.query, self.key, self.value = nn.Linear(dim, dim), nn.Linear(kv_dim, dim), nn.Linear(kv_dim, dim)
 
-    def forward(self, x, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None):
-        src, mask = (x, attention_mask) if encoder_hidden_states is None else (encoder_hidden_states, encoder_attention_mask)
-        B, T, D = x.shape
-        h = self.heads
-        q = self.query(x).view(B, T, h, D // h).permute(0, 2, 1, 3)
-        k = self.key(src).view(B, -1, h, D // h).permute(0, 2, 1, 3)
-        v = self.value(src).view(B, -1, h, D // h).permute(0, 2, 1, 3)
-        if self.reference_ops or mask is not None:                        # Qformer.py:205-246: scores, + mask, softmax, probs @ v
-            scores = torch.matmul(q, k.transpose(-1, -2)) / (D // h) ** 0.5
-            if mask is not None:
-                scores = scores + mask
-            y = torch.matmul(torch.softmax(scores, dim=-1), v)
+    def transpose_for_scores(self, x):
+        return x.view(*x.shape[:-1], self.heads, -1).permute(0, 2, 1, 3)
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                past_key_value=None, output_attentions=False):
+        cross = encoder_hidden_states is not None
+        src = encoder_hidden_states if cross else hidden_states
+        if cross:
+            attention_mask = encoder_attention_mask
+        k = self.transpose_for_scores(self.key(src))
+        v = self.transpose_for_scores(self.value(src))
+        q = self.transpose_for_scores(self.query(hidden_states))
+        B, T, D = hidden_states.shape
+        if self.reference_ops or attention_mask is not None:              # Qformer.py:205-246: scores, / sqrt(d), + mask, softmax, probs @ v
+            scores = torch.matmul(q, k.transpose(-1, -2))
+            scores = scores / (D // self.heads) ** 0.5
+            if attention_mask is not None:
+                scores = scores + attention_mask
+            y = torch.matmul(nn.functional.softmax(scores, dim=-1), v)
         else:
             y = F.scaled_dot_product_attention(q, k, v)
-        return y.permute(0, 2, 1, 3).reshape(B, T, D)
+        return y.permute(0, 2, 1, 3).reshape(B, T, D), (k, v)
 
 
 class _QfOutput(nn.Module):                         # BertSelfOutput / BertOutput: dense, (dropout,) LayerNorm(dense + residual)
@@ -278,8 +294,11 @@ class _QfAttention(nn.Module):
         self.self = _QfSelfAttention(dim, heads, kv_dim, reference_ops)
         self.output = _QfOutput(dim, dim)
 
-    def forward(self, x, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None):
-        return self.output(self.self(x, attention_mask, encoder_hidden_states, encoder_attention_mask), x)
+    def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                past_key_value=None, output_attentions=False):
+        ctx, present = self.self(hidden_states, attention_mask, head_mask, encoder_hidden_states, encoder_attention_mask, past_key_value,
+                                 output_attentions)
+        return self.output(ctx, hidden_states), present
 
 
 class _QfIntermediate(nn.Module):
@@ -301,24 +320,29 @@ class QFormerLayer(nn.Module):
         self.intermediate, self.output = _QfIntermediate(dim, hidden), _QfOutput(hidden, dim)
         self.intermediate_query, self.output_query = _QfIntermediate(dim, hidden), _QfOutput(hidden, dim)
 
-    def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None, query_length=0):
-        a = self.attention(hidden_states, attention_mask)
+    def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                past_key_value=None, output_attentions=False, query_length=0):
+        a, present_key_value = self.attention(hidden_states, attention_mask, head_mask, output_attentions=output_attentions,
+                                              past_key_value=past_key_value[:2] if past_key_value is not None else None)
         if query_length > 0:
-            qa = a[:, :query_length]
+            qa = a[:, :query_length, :]
             if self.has_cross_attention:
-                qa = self.crossattention(qa, attention_mask, encoder_hidden_states, encoder_attention_mask)
+                assert encoder_hidden_states is not None, "encoder_hidden_states must be given for cross-attention layers"
+                qa, _ = self.crossattention(qa, attention_mask, head_mask, encoder_hidden_states, encoder_attention_mask,
+                                            output_attentions=output_attentions)
             out = self.output_query(self.intermediate_query(qa), qa)
             if a.shape[1] > query_length:
-                ta = a[:, query_length:]
+                ta = a[:, query_length:, :]
                 out = torch.cat([out, self.output(self.intermediate(ta), ta)], dim=1)
         else:
             out = self.output(self.intermediate(a), a)
-        return (out,)
+        return (out,) + (present_key_value,)                 # (layer_output, present_key_value): Qformer.py:470-474
 
 
 class QFormer(nn.Module):
-    """`Qformer.bert(input_ids, attention_mask, query_embeds, encoder_hidden_states, encoder_attention_mask)` of the reference,
-    reduced to what the forward of blip2_t5_instruct.py:146-175 uses: `.bert.embeddings`, `.bert.encoder.layer[i]`."""
+    """`Qformer.bert(input_ids, attention_mask=, query_embeds=, encoder_hidden_states=, encoder_attention_mask=)` of the reference,
+    reduced to what the forward of blip2_t5_instruct.py:146-175 uses: `.bert.embeddings`, the extended masks of BertModel.forward
+    (:713-803, :889-921), `.bert.encoder.layer[i]` called as BertEncoder.forward calls them (:541-550)."""
 
     def __init__(self, dim=768, heads=12, hidden=3072, depth=12, encoder_width=1408, vocab=30523, cross_attention_freq=2, reference_ops=False):
         super().__init__()
@@ -332,7 +356,7 @@ class QFormer(nn.Module):
                                                  for i in range(depth)])
         self.vocab = vocab
 
-    def forward(self, input_ids, query_embeds, encoder_hidden_states):
+    def forward(self, input_ids, attention_mask=None, query_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None):
         emb = self.bert.embeddings
         B, Q = query_embeds.shape[:2]
         if input_ids is not None:
@@ -341,8 +365,15 @@ class QFormer(nn.Module):
         else:
             x = query_embeds
         x = emb.LayerNorm(x)
-        for layer in self.bert.encoder.layer:
-            x = layer(x, None, encoder_hidden_states, None, query_length=Q)[0]
+        dtype = x.dtype
+        ext = enc_ext = None
+        if attention_mask is not None:                                    # get_extended_attention_mask (:795-801)
+            ext = (1.0 - attention_mask[:, None, None, :].to(dtype)) * -10000.0
+        if encoder_attention_mask is not None:                            # invert_attention_mask of the image tokens (:906-916)
+            enc_ext = (1.0 - encoder_attention_mask[:, None, None, :].to(dtype)) * -10000.0
+        for layer in self.bert.encoder.layer:                             # BertEncoder.forward :541-550: positional, use_cache off
+            layer_outputs = layer(x, ext, None, encoder_hidden_states, enc_ext, None, False, Q)
+            x = layer_outputs[0]
         return x
 
 
@@ -350,7 +381,7 @@ class InstructBlipT5(nn.Module):
     def __init__(self, vit_dim=1408, vit_hidden=6144, vit_heads=16, vit_depth=39, d_model=2048, d_ff=5120, heads=32, d_kv=64,
                  enc_depth=24, dec_depth=24, vocab=32128, query_tokens=32, vit_dtype=torch.float16, t5_dtype=torch.bfloat16,
                  reference_ops=False, qformer=True, qformer_dim=768, qformer_heads=12, qformer_hidden=3072, qformer_depth=12,
-                 qformer_vocab=30523):
+                 qformer_vocab=30523, qformer_dtype=None):
         """reference_ops=True: the blocks' attention follows the reference's model files op for op -- EVA attention as
         eva_vit.py:129-168 (q / v bias, explicit `q @ k^T`, softmax, `attn @ v`), T5 attention as modeling_t5.py:520-640
         (`torch.matmul` scores, bucketed position bias in block 0 handed on by the stack, fp32 softmax, extended masks) --
@@ -361,11 +392,15 @@ class InstructBlipT5(nn.Module):
         self.visual_encoder.blocks = nn.ModuleList([ViTBlock(vit_dim, vit_hidden, vit_heads, reference_ops) for _ in range(vit_depth)])
         self.visual_encoder.to(vit_dtype)
         # qformer=False: rounds 1-4's stand-in (the first 32 image tokens projected straight to the language model's width)
+        # the reference keeps ln_vision, the Q-Former, its query tokens and t5_proj in fp32 and runs them outside autocast
+        # (blip2_t5_instruct.py:76-95, :143-175); the friendlier stand-in of rounds 2-5 held them in the towers' 16-bit dtypes
+        qdt = qformer_dtype if qformer_dtype is not None else (torch.float32 if reference_ops else vit_dtype)
+        self.qformer_dtype = qdt
         if qformer:
-            self.ln_vision = nn.LayerNorm(vit_dim).to(vit_dtype)
-            self.Qformer = QFormer(qformer_dim, qformer_heads, qformer_hidden, qformer_depth, vit_dim, qformer_vocab, 2, reference_ops).to(vit_dtype)
-            self.query_embeds = nn.Parameter(torch.zeros(1, query_tokens, qformer_dim, dtype=vit_dtype))
-            self.t5_proj = nn.Linear(qformer_dim, d_model).to(t5_dtype)
+            self.ln_vision = nn.LayerNorm(vit_dim).to(qdt)
+            self.Qformer = QFormer(qformer_dim, qformer_heads, qformer_hidden, qformer_depth, vit_dim, qformer_vocab, 2, reference_ops).to(qdt)
+            self.query_embeds = nn.Parameter(torch.zeros(1, query_tokens, qformer_dim, dtype=qdt))
+            self.t5_proj = nn.Linear(qformer_dim, d_model).to(torch.float32 if qdt == torch.float32 else t5_dtype)
         else:
             self.Qformer = None
             self.t5_proj = nn.Linear(vit_dim, d_model).to(t5_dtype)
@@ -396,10 +431,22 @@ class InstructBlipT5(nn.Module):
         if self.Qformer is not None:
             # blip2_t5_instruct.py:144-175: ln_vision, [queries | instruction text] through the Q-Former, its first 32 rows to t5_proj
             # (the Q-Former has its own tokenizer: the synthetic prompt's ids are folded into its vocabulary)
-            img_embeds = self.ln_vision(x)
+            # (under the reference's fp16 autocast `ln_vision` computes and returns fp32: the same values as the fp32 module on x.float())
+            img_embeds = self.ln_vision(x.to(self.qformer_dtype))
             ids = samples["text_input"] % self.Qformer.vocab
-            qout = self.Qformer(ids, self.query_embeds.expand(x.shape[0], -1, -1), img_embeds)
-            img = self.t5_proj(qout[:, :self.query_tokens].to(self.t5_dtype))
+            B = x.shape[0]
+            if self.reference_ops:
+                # blip2_t5_instruct.py:145-165: attention masks of ones (batch 1: the tokenizer's `padding="longest"` pads nothing),
+                # queries | text; the image tokens' mask
+                image_atts = torch.ones(img_embeds.shape[:-1], dtype=torch.long, device=x.device)
+                atts = torch.ones((B, self.query_tokens + ids.shape[1]), dtype=torch.long, device=x.device)
+                qout = self.Qformer(ids, attention_mask=atts, query_embeds=self.query_embeds.expand(B, -1, -1),
+                                    encoder_hidden_states=img_embeds, encoder_attention_mask=image_atts)
+            else:
+                qout = self.Qformer(ids, query_embeds=self.query_embeds.expand(B, -1, -1), encoder_hidden_states=img_embeds)
+            # (the reference's bf16 autocast `torch.cat` would carry the fp32 projection on as fp32 hidden states; the stand-in's T5
+            # stack is bf16 throughout: the projection is rounded to it here)
+            img = self.t5_proj(qout[:, :self.query_tokens].to(self.t5_proj.weight.dtype)).to(self.t5_dtype)
         else:
             img = self.t5_proj(x[:, :self.query_tokens].to(self.t5_dtype))      # stands in for the Q-Former's 32 queries
         h = torch.cat([img, t5.shared(samples["text_input"])], dim=1)
