@@ -235,7 +235,7 @@ int vlmc_unpack_24(const void *values, const uint8_t *meta, int dtype, int64_t o
  * matrix-core instruction shape (v_mfma_f32_16x16x32), whatever M is -- replaying 1 or 128 calibration
  * samples per call, or any share of them on another GPU, yields identical rows.
  * dtype VLMC_F32 (round 6: the reference's Q-Former, `ln_vision` and `t5_proj` stay in fp32 outside autocast, blip2_t5_instruct.py:76-95,
- * :143-175): fp32 operands and output on v_mfma_f32_32x32x2_f32, one accumulator per element over k in ascending pairs -- the same
+ * :143-175): fp32 operands and output on v_mfma_f32_16x16x4_f32, one accumulator per element over k in ascending groups of four -- the same
  * invariance; no alignment requirement beyond 4 bytes.  (vlmc_linear_fwd_group / _rows / _post are 16-bit only.)                    */
 int vlmc_linear_fwd(const void *X, const void *W, const void *bias, int dtype, int64_t M, int64_t N, int64_t K, int64_t ldx,
                     int64_t ldw, void *Y, int64_t ldy, void *stream);
@@ -291,7 +291,7 @@ int vlmc_linear_fwd_post(const void *X, const void *W, const void *bias, int dty
  * in ascending order (tail zero-padded) by v_mfma_f32_16x16x32, whatever batch0 x batch1, M and N are -- the products of
  * one calibration sample have the same bits alone, in a group of 128, or on another GPU.
  * dtype VLMC_F32 (the fp32 Q-Former's `torch.matmul(query_layer, key_layer.transpose(-1, -2))` / `torch.matmul(attention_probs,
- * value_layer)`, Qformer.py:201,246): fp32 operands and output on v_mfma_f32_32x32x2_f32, k in ascending pairs; batch0 * batch1 <= 65535. */
+ * value_layer)`, Qformer.py:201,246): fp32 operands and output on v_mfma_f32_16x16x4_f32, k in ascending groups of four; batch0 * batch1 <= 65535. */
 int vlmc_attn_matmul(const void *A, const void *B, void *C, int dtype, int64_t batch0, int64_t batch1, int64_t M, int64_t N,
                      int64_t K, int64_t sa_b0, int64_t sa_b1, int64_t sa_m, int64_t sb_b0, int64_t sb_b1, int64_t sb_k,
                      int64_t sb_n, int64_t sc_b0, int64_t sc_b1, int64_t sc_m, void *stream);

@@ -121,7 +121,7 @@ def test_a_product_has_the_same_bits_in_any_batch():
 
 def test_replayed_blocks_route_their_batched_matmuls_to_the_kernel():
     """Inside `forward.invariant_linears` (the replay of a block) `@`, `torch.matmul` and `torch.bmm` on 16-bit 3-D / 4-D
-    tensors run on vlmc_attn_matmul; fp32 operands, 2-D products and calls with gradients stay with the library."""
+    tensors (and, since round 6, fp32 ones) run on vlmc_attn_matmul; 2-D products and calls with gradients stay with the library."""
     from vlmc import forward, ops
     g = torch.Generator(device=DEV).manual_seed(2)
     q, k, v = _t5(2, 9, 11, 4, 64, g)
@@ -130,18 +130,18 @@ def test_replayed_blocks_route_their_batched_matmuls_to_the_kernel():
         s1 = q @ k.transpose(3, 2)
         s2 = torch.matmul(q, k.transpose(3, 2))
         s3 = torch.bmm(q.reshape(8, 9, 64), k.reshape(8, 11, 64).transpose(1, 2)).view(2, 4, 9, 11)
-        s4 = q.float() @ k.float().transpose(3, 2)                       # library
+        s4 = q.float() @ k.float().transpose(3, 2)                       # fp32: the fp32 kernel (round 6: the reference's fp32 Q-Former)
         w = torch.randn(64, 64, device=DEV).bfloat16()
         s5 = q @ w                                                       # 4-D @ 2-D: library
-    assert forward.stats["attn_kernel"] - before["attn_kernel"] == 3
-    assert forward.stats["attn_library"] - before["attn_library"] == 2
+    assert forward.stats["attn_kernel"] - before["attn_kernel"] == 4
+    assert forward.stats["attn_library"] - before["attn_library"] == 1
     want = ops.attn_matmul(q, k.transpose(3, 2))
     assert torch.equal(s1, want) and torch.equal(s2, want) and torch.equal(s3, want)
     assert s4.dtype == torch.float32 and s5.shape == (2, 4, 9, 64)
     with forward.invariant_linears([]):                                  # gradients enabled: untouched
         qq = q.clone().requires_grad_()
         (qq @ k.transpose(3, 2)).sum().backward()
-    assert forward.stats["attn_kernel"] - before["attn_kernel"] == 3 and qq.grad is not None
+    assert forward.stats["attn_kernel"] - before["attn_kernel"] == 4 and qq.grad is not None
     assert "__matmul__" not in torch.Tensor.__dict__
 
 
@@ -149,9 +149,13 @@ def test_bad_arguments_fail_loudly():
     from vlmc import _lib, ops
     a = torch.randn(2, 2, 4, 8, device=DEV).half()
     with pytest.raises(TypeError):
-        ops.attn_matmul(a.float(), a.float().transpose(-1, -2))
+        ops.attn_matmul(a.double(), a.double().transpose(-1, -2))             # (fp32 is taken since round 6; fp64 is not)
+    with pytest.raises(TypeError):
+        ops.attn_matmul(a, a.float().transpose(-1, -2))                      # mixed dtypes
     lib = _lib.load()
     rc = lib.vlmc_attn_matmul(a.data_ptr(), a.data_ptr(), a.data_ptr(), _lib.F16, 1, 1, 4, 4, 8, 0, 0, 8, 0, 0, 2, 2, 0, 0, 4, None)
     assert rc == _lib.VLMC_EINVAL and b"contiguous" in lib.vlmc_last_error()
-    rc = lib.vlmc_attn_matmul(a.data_ptr(), a.data_ptr(), a.data_ptr(), _lib.F32, 1, 1, 4, 4, 8, 0, 0, 8, 0, 0, 1, 8, 0, 0, 4, None)
-    assert rc == _lib.VLMC_EINVAL
+    rc = lib.vlmc_attn_matmul(a.data_ptr(), a.data_ptr(), a.data_ptr(), _lib.F32, 1, 1, 4, 4, 8, 0, 0, 8, 0, 0, 2, 2, 0, 0, 4, None)
+    assert rc == _lib.VLMC_EINVAL and b"contiguous" in lib.vlmc_last_error()      # fp32: B neither k- nor n-contiguous
+    rc = lib.vlmc_attn_matmul(a.data_ptr(), a.data_ptr(), a.data_ptr(), 7, 1, 1, 4, 4, 8, 0, 0, 8, 0, 0, 1, 8, 0, 0, 4, None)
+    assert rc == _lib.VLMC_EINVAL                                                 # unknown dtype

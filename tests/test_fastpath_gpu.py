@@ -62,9 +62,12 @@ def test_both_routes_refuse_the_same_calls(monkeypatch):
     for fast in (True, False):
         if not fast:
             monkeypatch.setattr(ops, "_fast", None)
+        assert ops.linear_fwd(x, w).dtype == torch.float32               # fp32: taken since round 6 (the fp32 kernel, both routes)
         with pytest.raises(TypeError):
-            ops.linear_fwd(x, w)                                         # fp32
-        assert ops.linear_fwd(x, w, _try=True) is None
+            ops.linear_fwd(x.double(), w.double())                       # fp64
+        with pytest.raises(TypeError):
+            ops.linear_fwd(x.half(), w)                                  # mixed dtypes
+        assert ops.linear_fwd(x.half(), w, _try=True) is None
         with pytest.raises(TypeError):
             ops.linear_fwd_group(x.half(), [w.half(), w])                # mixed dtypes
         with pytest.raises(ValueError):

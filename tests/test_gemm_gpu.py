@@ -153,9 +153,10 @@ def test_linear_fwd_refuses_what_it_cannot_do():
     from vlmc import ops
     x = torch.randn(4, 16, device=DEV)
     w = torch.randn(8, 16, device=DEV)
-    assert not ops.linear_fwd_supported(x, w)                              # fp32: the library GEMM stays in charge
+    assert not ops.linear_fwd_supported(x, w) and ops.linear_f32_supported(x, w)   # fp32: its own kernel since round 6 (not the 16-bit family)
+    assert ops.linear_fwd(x, w).dtype == torch.float32
     with pytest.raises(TypeError):
-        ops.linear_fwd(x, w)
+        ops.linear_fwd(x.double(), w.double())                            # fp64: nobody's
     assert not ops.linear_fwd_supported(x.half(), w.bfloat16())
     assert not ops.linear_fwd_supported(torch.randn(4, 12, device=DEV).half(), torch.randn(8, 12, device=DEV).half())  # K % 8
     with pytest.raises(RuntimeError):

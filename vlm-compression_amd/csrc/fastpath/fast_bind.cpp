@@ -56,7 +56,25 @@ std::vector<int64_t> lead_shape(const at::Tensor &x, int64_t N) {
     return s;
 }
 
+// fp32 (the reference's Q-Former: vlmc/ops.py: linear_f32_supported): the fp32 matrix-core kernel behind the same entry point
+py::object linear_fwd_f32(const at::Tensor &x, const at::Tensor &w, const c10::optional<at::Tensor> &b, int64_t stream) {
+    if (!x.is_cuda() || !w.is_cuda() || x.scalar_type() != at::kFloat || w.dim() != 2 || x.dim() < 1 || x.size(-1) != w.size(1) || w.size(1) == 0 ||
+        w.stride(1) != 1)
+        return py::none();
+    const bool has_b = b.has_value() && b->defined();
+    if (has_b && (!b->is_cuda() || b->scalar_type() != at::kFloat || !b->is_contiguous())) return py::none();
+    const int64_t N = w.size(0), K = w.size(1);
+    at::Tensor x2 = x.reshape({-1, K});
+    if (x2.stride(1) != 1 || (x2.size(0) > 1 && x2.stride(0) < K)) x2 = x2.contiguous();
+    const int64_t M = x2.size(0);
+    at::Tensor y = at::empty({M, N}, x.options());
+    check(vlmc_linear_fwd(x2.data_ptr(), w.data_ptr(), has_b ? b->data_ptr() : nullptr, VLMC_F32, M, N, K, M > 1 ? x2.stride(0) : K, w.stride(0),
+                          y.data_ptr(), N, reinterpret_cast<void *>(stream)));
+    return py::cast(y.reshape(lead_shape(x, N)));
+}
+
 py::object linear_fwd(const at::Tensor &x, const at::Tensor &w, const c10::optional<at::Tensor> &b, int64_t stream) {
+    if (w.scalar_type() == at::kFloat) return linear_fwd_f32(x, w, b, stream);
     if (!linear_ok(x, w, b)) return py::none();
     const int64_t N = w.size(0), K = w.size(1);
     const at::Tensor x2 = rows_of(x, K);
@@ -100,7 +118,8 @@ py::object linear_fwd_group(const at::Tensor &x, const std::vector<at::Tensor> &
 // (the conditions of vlmc/ops.py: attn_matmul_plan)
 py::object attn_matmul(const at::Tensor &a, const at::Tensor &b, int64_t stream) {
     const int64_t nd = a.dim();
-    if (nd != b.dim() || nd < 3 || nd > 4 || a.scalar_type() != b.scalar_type() || dtype_code(a.scalar_type()) < 0 || !a.is_cuda() ||
+    const bool f32 = a.scalar_type() == at::kFloat;                       // (the fp32 Q-Former's products: the fp32 kernel, <= 65535 matrices)
+    if (nd != b.dim() || nd < 3 || nd > 4 || a.scalar_type() != b.scalar_type() || (!f32 && dtype_code(a.scalar_type()) < 0) || !a.is_cuda() ||
         !b.is_cuda())
         return py::none();
     const int64_t M = a.size(-2), K = a.size(-1), N = b.size(-1);
@@ -132,8 +151,9 @@ py::object attn_matmul(const at::Tensor &a, const at::Tensor &b, int64_t stream)
     }
     oshape.push_back(M);
     oshape.push_back(N);
+    if (f32 && batch[0] * batch[1] > 65535) return py::none();
     at::Tensor out = at::empty(oshape, a.options());
-    check(vlmc_attn_matmul(a.data_ptr(), b.data_ptr(), out.data_ptr(), dtype_code(a.scalar_type()), batch[0], batch[1], M, N, K, sa[0], sa[1],
+    check(vlmc_attn_matmul(a.data_ptr(), b.data_ptr(), out.data_ptr(), f32 ? VLMC_F32 : dtype_code(a.scalar_type()), batch[0], batch[1], M, N, K, sa[0], sa[1],
                            a.stride(-2), sb[0], sb[1], sbk, sbn, batch[1] * M * N, M * N, N, reinterpret_cast<void *>(stream)));
     return py::cast(out);
 }

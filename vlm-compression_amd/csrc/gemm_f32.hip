@@ -1,17 +1,17 @@
-// fp32 products of a replayed forward on fp32 matrix cores (v_mfma_f32_32x32x2_f32), BATCH-INVARIANT like their 16-bit siblings.
+// fp32 products of a replayed forward on fp32 matrix cores (v_mfma_f32_16x16x4_f32), BATCH-INVARIANT like their 16-bit siblings.
 //
 // The reference keeps the Q-Former (and `ln_vision`, `t5_proj`) in fp32 and calls them outside autocast (blip2_t5_instruct.py:76-95,
 // :143-175): its linears and the two batched products of its attention (Qformer.py:201-246) are fp32 GEMMs.  A GEMM library picks its
 // kernel by problem size, so a calibration sample forwarded alone and inside a stacked batch would get other last bits -- and the
 // stacked capture of vlm-compression_amd/lavis/compression/pruners/calibration.py is only taken when it reproduces a sample's own forward
-// bit for bit.  Here an output element is ONE fp32 accumulator that takes k in ascending pairs through one MFMA shape, whatever else
+// bit for bit.  Here an output element is ONE fp32 accumulator that takes k in ascending groups of four through one MFMA shape, whatever else
 // shares the launch:
 //   * vlmc_linear_fwd (dtype VLMC_F32)   Y[m][n] = sum_k X[m][k] W[n][k] + bias[n]          ("NT": both operands k-contiguous)
 //   * vlmc_attn_matmul (dtype VLMC_F32)  C[b][h] = A[b][h] @ B[b][h]  through element strides (q @ k^T: B's rows are keys, k-contiguous;
 //                                         probs @ v: B's rows are k, n-contiguous)
-// One skeleton: a workgroup owns a 128 x 128 tile of the output, each of its four waves 64 x 64 of it (2 x 2 MFMA tiles); K goes through
-// LDS in chunks of 32, double buffered (the next chunk's global loads are in flight during this chunk's 64 MFMAs per wave); both
-// operand chunks lie in LDS as [row][k] with an odd pitch (the MFMA operand of a lane is one float: row = lane % 32, k = lane / 32).
+// One skeleton: a workgroup owns a square tile of the output, each of its four waves a quarter of it (TW x TW tiles of v_mfma_f32_16x16x4);
+// K goes through LDS in chunks of 32-128 (the next chunk's global loads are in flight, in registers, during this chunk's products); both
+// operand chunks lie in LDS as [row][k] (the MFMA operand of a lane is one float: row = lane % 16, k = lane / 16).
 // fp32 matrix peak is 157 TFLOP/s (1 / 16 of the 16-bit rate): these products are a few TFLOP per prune, not its hot path.
 #include "common.hpp"
 
@@ -19,8 +19,7 @@ namespace vlmc {
 namespace {
 
 typedef float f32x4v_t __attribute__((ext_vector_type(4)));
-typedef float f32x16v_t __attribute__((ext_vector_type(16)));
-constexpr int kFT = 128, kFK = 32, kFLd = kFK + 1, kFBuf = 2 * kFT * kFLd;            // floats per LDS buffer: [A chunk | B chunk]
+// (K chunk and LDS pitch are per tile size: see gemm_f32_kernel)
 
 struct F32Gemm {
     const float *A, *B;          // A [M, K]: element (m, k) at A[m * lda + k * ska]; B: element (n, k) at B[n * sbn + k * sbk]
@@ -32,15 +31,28 @@ struct F32Gemm {
     int M, N, K;
 };
 
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const F32Gemm g) {
+// TW = MFMA tiles (16 x 16) per wave along m and along n: the workgroup's tile is 32 TW x 32 TW (four waves, 2 x 2).  An output element
+// is one accumulator of v_mfma_f32_16x16x4_f32 over k in ascending groups of four -- a serial chain of K / 4 steps of 32 cycles.  With
+// few tiles what a launch costs is ONE wave's chain, so the smallest tile that still gives every SIMD a chain is taken: TW = 4
+// (128 x 128) once such a tile per CU exists, else TW = 2 (64 x 64), else TW = 1 (32 x 32: M = 512, N = 768, K = 3072 is 384 chains of
+// 41 us on 32 x 32 x 2 tiles of 32 x 32, 1536 chains of 10 us here).  The same MFMA shape and k order per element for every TW: the
+// same bits, whatever the launch's size -- which is what makes a calibration sample's rows independent of its company.
+template <int TW>
+__global__ __launch_bounds__(256, (TW == 4 ? 3 : 4)) void gemm_f32_kernel(const F32Gemm g) {
+    // K chunk: 128 / TW -- every thread stages four 16-byte pieces of each operand per chunk whatever the tile, so a small tile takes a long
+    // chunk: what a 32 x 32 tile costs is not its products (0.1 us per 32 k) but the round trip of every chunk's loads (~1.5 us), and a
+    // chunk of 128 k makes 4 x fewer of them.  LDS pitch kFK + 2: (pitch r + k) mod 32 is distinct over the 16 rows x 2 k of a half wave.
+    // ONE LDS buffer (33-35 KB: four workgroups per CU -- other workgroups' products cover this one's load round trips); the next
+    // chunk waits in registers while this one is multiplied, and goes to LDS between two barriers.
+    constexpr int kFT = 32 * TW, kFK = 128 / TW, kFLd = kFK + 2;
+    constexpr int TPR = kFK / 4, RSTEP = 256 / TPR;                               // k-contiguous operand: threads per row, rows per pass (4 passes)
+    constexpr int NQ4 = kFT / 4, KSTEP = 256 / NQ4;                                // n-contiguous B: threads per k row, k rows per pass (4 passes)
     extern __shared__ float fsh[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * kFT, n0 = blockIdx.x * kFT;
     const int64_t z0 = blockIdx.z / g.b1, z1 = blockIdx.z - z0 * g.b1;
     const float *A = g.A + z0 * g.batchA + z1 * g.batchA1, *B = g.B + z0 * g.batchB + z1 * g.batchB1;
     float *C = g.C + z0 * g.batchC + z1 * g.batchC1;
-    // staging: thread t takes, of each operand chunk, rows (t >> 3) + 32 i (i = 0..3), k = 4 (t & 7) .. + 3 when the operand is
-    // k-contiguous (16-byte loads), or -- B of probs @ v: n-contiguous -- k = (t >> 5) + 8 i, rows 4 (t & 31) .. + 3
     const bool a_vec = g.ska == 1 && (g.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15u) == 0;
     const bool b_kcontig = g.sbk == 1;
     const bool b_vec = (b_kcontig ? (g.sbn & 3) == 0 : (g.sbk & 3) == 0 && g.sbn == 1) && (reinterpret_cast<uintptr_t>(B) & 15u) == 0;
@@ -49,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const F32Gemm g) {
         const int k0 = q * kFK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = m0 + (tid >> 3) + 32 * i, k = k0 + 4 * (tid & 7);
+            const int row = m0 + (tid / TPR) + RSTEP * i, k = k0 + 4 * (tid % TPR);
             f32x4v_t v = {0.f, 0.f, 0.f, 0.f};
             if (row < g.M && k < g.K) {
                 const float *src = A + int64_t(row) * g.lda + int64_t(k) * g.ska;
@@ -62,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const F32Gemm g) {
         if (b_kcontig) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = n0 + (tid >> 3) + 32 * i, k = k0 + 4 * (tid & 7);
+                const int row = n0 + (tid / TPR) + RSTEP * i, k = k0 + 4 * (tid % TPR);
                 f32x4v_t v = {0.f, 0.f, 0.f, 0.f};
                 if (row < g.N && k < g.K) {
                     const float *src = B + int64_t(row) * g.sbn + k;
@@ -75,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const F32Gemm g) {
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int k = k0 + (tid >> 5) + 8 * i, row = n0 + 4 * (tid & 31);
+                const int k = k0 + (tid / NQ4) + KSTEP * i, row = n0 + 4 * (tid % NQ4);
                 f32x4v_t v = {0.f, 0.f, 0.f, 0.f};
                 if (k < g.K && row < g.N) {
                     const float *src = B + int64_t(k) * g.sbk + int64_t(row) * g.sbn;
@@ -87,93 +99,99 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const F32Gemm g) {
             }
         }
     };
-    auto stash = [&](int buf) {
-        float *pa = fsh + buf * kFBuf, *pb = pa + kFT * kFLd;
+    auto stash = [&]() {
+        float *pa = fsh, *pb = pa + kFT * kFLd;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float *d = pa + ((tid >> 3) + 32 * i) * kFLd + 4 * (tid & 7);
+            float *d = pa + ((tid / TPR) + RSTEP * i) * kFLd + 4 * (tid % TPR);
             d[0] = sa[i][0], d[1] = sa[i][1], d[2] = sa[i][2], d[3] = sa[i][3];
         }
         if (b_kcontig) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float *d = pb + ((tid >> 3) + 32 * i) * kFLd + 4 * (tid & 7);
+                float *d = pb + ((tid / TPR) + RSTEP * i) * kFLd + 4 * (tid % TPR);
                 d[0] = sb[i][0], d[1] = sb[i][1], d[2] = sb[i][2], d[3] = sb[i][3];
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float *d = pb + (4 * (tid & 31)) * kFLd + (tid >> 5) + 8 * i;                 // rows n, column k
+                float *d = pb + (4 * (tid % NQ4)) * kFLd + (tid / NQ4) + KSTEP * i;             // rows n, column k
                 d[0] = sb[i][0], d[kFLd] = sb[i][1], d[2 * kFLd] = sb[i][2], d[3 * kFLd] = sb[i][3];
             }
         }
     };
     const int rb = wave >> 1, cb = wave & 1;
-    f32x16v_t acc[2][2];
+    f32x4v_t acc[TW][TW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < TW; ++j) acc[i][j] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
     const int nq = (g.K + kFK - 1) / kFK;
     fetch(0);
-    stash(0);
+    stash();
     __syncthreads();
     for (int q = 0; q < nq; ++q) {
         if (q + 1 < nq) fetch(q + 1);
-        const float *pa = fsh + (q & 1) * kFBuf, *pb = pa + kFT * kFLd;
-        const float *ap0 = pa + (rb * 64 + (lane & 31)) * kFLd + (lane >> 5), *ap1 = ap0 + 32 * kFLd;
-        const float *bp0 = pb + (cb * 64 + (lane & 31)) * kFLd + (lane >> 5), *bp1 = bp0 + 32 * kFLd;
+        const float *pa = fsh, *pb = pa + kFT * kFLd;
+        // operand of a lane: row lane % 16, k = lane / 16 (of the step's four)
+        const float *ap = pa + (rb * 16 * TW + (lane & 15)) * kFLd + (lane >> 4);
+        const float *bp = pb + (cb * 16 * TW + (lane & 15)) * kFLd + (lane >> 4);
+#pragma unroll 8
+        for (int k = 0; k < kFK; k += 4) {
+            float a[TW], b[TW];
 #pragma unroll
-        for (int k = 0; k < kFK; k += 2) {
-            const float a0 = ap0[k], a1 = ap1[k], b0 = bp0[k], b1 = bp1[k];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            for (int i = 0; i < TW; ++i) a[i] = ap[i * 16 * kFLd + k], b[i] = bp[i * 16 * kFLd + k];
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int j = 0; j < TW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (q + 1 < nq) {
-            stash((q + 1) & 1);
+            __syncthreads();                                                  // every wave has read chunk q
+            stash();
             __syncthreads();
         }
     }
-    // register r of a tile: row 8 (r / 4) + 4 (lane / 32) + r % 4 of A's rows (m), column lane % 32 of B's rows (n)
+    // register r of a tile: row 4 (lane / 16) + r of A's rows (m), column lane % 16 of B's rows (n)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + cb * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < TW; ++j) {
+            const int n = n0 + (cb * TW + j) * 16 + (lane & 15);
             if (n >= g.N) continue;
             const float bv = g.bias != nullptr ? g.bias[n] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + rb * 64 + i * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + (rb * TW + i) * 16 + 4 * (lane >> 4) + r;
                 if (m < g.M) C[int64_t(m) * g.ldc + n] = g.bias != nullptr ? ieee_add(acc[i][j][r], bv) : acc[i][j][r];
             }
         }
 }
 
+template <int TW> int launch_f32_tw(const char *what, const F32Gemm &g, int64_t batches, hipStream_t s) {
+    constexpr int kFT = 32 * TW, kFLd = 128 / TW + 2;
+    const size_t lds = size_t(2 * kFT * kFLd) * sizeof(float);          // 33-35 KB
+    const dim3 grid{unsigned((g.N + kFT - 1) / kFT), unsigned((g.M + kFT - 1) / kFT), unsigned(batches)};
+    VLMC_LAUNCH_TIMED_LDS(gemm_f32_kernel<TW>, grid, dim3(256), lds, s, g);
+    VLMC_HIP_CHECK_LAUNCH(what);
+    return VLMC_OK;
+}
+
 int launch_f32(const char *what, const F32Gemm &g, int64_t batches, hipStream_t s) {
     if (g.M == 0 || g.N == 0 || batches == 0) return VLMC_OK;
-    const size_t lds = size_t(2) * kFBuf * sizeof(float);
-    static PerDeviceOnce once;
-    int dev;
-    if (once.needed(&dev)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) {
-            set_error("%s: cannot reserve %zu bytes of LDS", what, lds);
-            return VLMC_EHIP;
-        }
-        once.mark(dev);
-    }
     if (batches > 65535) {
         set_error("%s: more than 65535 matrices in a batch", what);
         return VLMC_EINVAL;
     }
-    const dim3 grid{unsigned((g.N + kFT - 1) / kFT), unsigned((g.M + kFT - 1) / kFT), unsigned(batches)};
-    VLMC_LAUNCH_TIMED_LDS(gemm_f32_kernel, grid, dim3(256), lds, s, g);
-    VLMC_HIP_CHECK_LAUNCH(what);
-    return VLMC_OK;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    auto tiles = [&](int t) { return int64_t((g.N + t - 1) / t) * ((g.M + t - 1) / t) * batches; };
+    if (tiles(128) >= cus) return launch_f32_tw<4>(what, g, batches, s);
+    if (tiles(64) >= cus) return launch_f32_tw<2>(what, g, batches, s);
+    return launch_f32_tw<1>(what, g, batches, s);
 }
 
 }  // namespace

@@ -133,8 +133,16 @@ def linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None 
     forwards, wanda_pruner.py:308-311,343-346): a row of y depends on its row of x only, whatever else is in the call.
     `_try`: return None instead of raising when the call is not one the kernel takes.  fp32 tensors (the reference's Q-Former): the
     fp32 matrix-core kernel, the same invariance."""
-    if weight.dtype is torch.float32 and linear_f32_supported(x, weight, bias):
-        return _linear_fwd_f32(x, weight, bias)
+    if weight.dtype is torch.float32 and x.dtype is torch.float32:
+        y = None
+        if _fast is not None and x.is_cuda:
+            y = _fast.linear_fwd(x, weight, bias, _stream())
+        elif linear_f32_supported(x, weight, bias):
+            y = _linear_fwd_f32(x, weight, bias)
+        if y is None and not _try:
+            _need_gpu(x, weight, bias)
+            raise TypeError("vlmc.linear_fwd: fp32 x [.., K], weight [N, K] with contiguous rows and a contiguous fp32 bias expected")
+        return y
     if _fast is not None:
         if not x.is_cuda:
             _need_gpu(x, weight, bias)
@@ -322,7 +330,7 @@ def attn_matmul(a: torch.Tensor, b: torch.Tensor, _plan=None, _try: bool = False
     modeling_t5.py:590,638) on the batch-invariant MFMA kernel: an output element has the same bits whatever the batch
     count, M or N (include/vlmc.h: vlmc_attn_matmul).  `_try`: None instead of an error for a call the kernel does not take.
     fp32 operands (the reference's Q-Former): the fp32 matrix-core kernel, at most 65535 matrices per call."""
-    if a.dtype is torch.float32:
+    if a.dtype is torch.float32 and _fast is None:
         plan = _plan if _plan is not None else attn_matmul_plan(a, b)
         if plan is not None and plan[0][0] * plan[0][1] > 65535:
             plan = None
