@@ -320,6 +320,7 @@ def test_tower_memo_hands_over_recorded_outputs_only_when_inputs_and_weights_are
 
 def test_tower_memo_in_a_whole_prune_is_bit_identical(monkeypatch):
     """Decoder capture of the toy InstructBLIP with the ViT's outputs taken from the encoder capture's record."""
+    monkeypatch.setenv("VLMC_LINEAR_F32", "0")      # (the toy is fp32: this test is about the graph / memo route of towers that are NOT stacked)
     from lavis.compression.pruners import calibration as cal
 
     def state(model):
@@ -344,6 +345,7 @@ def test_capture_phase_runs_again_when_a_remembered_input_was_not_the_one_fed(mo
     """The comparisons of remembered inputs are answered at the end of a capture phase (`_LaterEqual`); when one of them
     fails -- here the record of forward 0 is tampered with -- the records are dropped and the phase runs again comparing at
     once: same pruned model as without any memo, and `later_failed` counts the event."""
+    monkeypatch.setenv("VLMC_LINEAR_F32", "0")      # (the toy is fp32: this test is about the graph / memo route of towers that are NOT stacked)
     from lavis.compression.pruners import calibration as cal
 
     def state(model):
@@ -380,9 +382,10 @@ def test_capture_phase_runs_again_when_a_remembered_input_was_not_the_one_fed(mo
     assert all(torch.equal(want[k], got[k]) for k in want)
 
 
-def test_graphed_module_proxy_replays_identically_and_falls_back():
+def test_graphed_module_proxy_replays_identically_and_falls_back(monkeypatch):
     """calibration.GraphedModule (stand-in for already pruned blocks during capture): eager first call, captured second,
     replayed afterwards, one graph per argument signature; gradients / odd arguments go straight to the module."""
+    monkeypatch.setenv("VLMC_LINEAR_F32", "0")      # (the toy is fp32: with its linears on the fp32 kernel the finished tower is stacked, not graphed)
     import toy_models
     from lavis.compression.pruners import calibration as cal
     torch.manual_seed(0)
@@ -459,6 +462,7 @@ def _capture_decoder_inputs(model, batches, **env):
 def test_tower_graph_gives_the_eager_forward_bit_for_bit(streams, monkeypatch):
     """calibration.TowerGraph: the finished towers run as ONE graph per calibration forward (traced twice, then captured per
     stream slot); the captured decoder inputs equal those of the plain eager forward, on one stream and on three."""
+    monkeypatch.setenv("VLMC_LINEAR_F32", "0")      # (the toy is fp32: this test is about the graph / memo route of towers that are NOT stacked)
     import toy_models
     from lavis.compression.pruners import calibration as cal
     model = toy_models.init_toy(toy_models.ToyBlipT5(), seed=7).eval().to("cuda:0")

@@ -1057,7 +1057,7 @@ class TowerGraph:
                 w = getattr(m, "weight", None)
                 # 16-bit weights (the kernel's K % 8), or fp32 weights outside autocast (the reference's Q-Former: the fp32 kernel)
                 if type(m) is not nn.Linear or w is None or (ctx[0] and ctx[1] != w.dtype) or \
-                        not ((w.dtype in (torch.float16, torch.bfloat16) and w.shape[1] % 8 == 0) or w.dtype is torch.float32):
+                        not ((w.dtype in (torch.float16, torch.bfloat16) and w.shape[1] % 8 == 0) or (w.dtype is torch.float32 and fw.f32_enabled())):
                     ok = False
                     break
             self._linears_ok[ctx] = ok
@@ -1530,7 +1530,10 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
     p0 = next(model.parameters(), None)
     if merged_capture_enabled() and p0 is not None and p0.is_cuda and _CTX.later is None:
         _CTX.later = _LaterEqual()                              # (remembered tower inputs against what the merged forward feeds them)
-        keys_before = set(proxy_cache) if proxy_cache is not None else set()
+        # (what the attempt finds in the cache: a memo whose `entries` dict is still the same object afterwards was only replayed
+        # from -- `begin("record")` starts a new dict; a memo seeded by the walk, seed_tower_memo, is in "record" mode without ever
+        # having been begun: the mode alone does not tell)
+        keys_before = {k: (id(v.entries) if isinstance(v, TowerMemo) else None) for k, v in proxy_cache.items()} if proxy_cache is not None else {}
         try:
             try:
                 res = _capture_merged(*args, **kw)
@@ -1553,15 +1556,16 @@ def _capture_block_inputs(model, dataloader, n_samples, module_to_process, forwa
             return res
         graph_stats["merged_capture_declined"] = graph_stats.get("merged_capture_declined", 0) + 1
         # Whatever the declined attempt left behind must not serve the per-sample route that follows: a TowerMemo it
-        # created -- or re-recorded: `_wrap_towers` begins a stale memo anew in "record" mode -- holds outputs cut out of the merged
+        # created -- or re-recorded: `_wrap_towers` begins a stale memo anew with an empty record -- holds outputs cut out of the merged
         # forward, the very values the comparison has just refused (or never checked); likewise the block-0 arguments / catcher
         # calls it noted for the next phase.  Memos that only REPLAYED during the attempt hold the previous phase's per-sample
         # records and stay, unless a remembered input was refuted (`bad`): then every record goes, as on the per-sample route.
         for key, val in list(proxy_cache.items() if proxy_cache is not None else []):
             if isinstance(val, TowerMemo):
-                if bad or key not in keys_before or val.mode == "record":
+                rewritten = key not in keys_before or keys_before[key] != id(val.entries)
+                if bad or rewritten:
                     val._drop()
-                    if key not in keys_before or val.mode == "record":
+                    if rewritten:
                         del proxy_cache[key]
             elif isinstance(key, tuple) and key and key[0] in ("calls", "block0") and (bad or key not in keys_before):
                 del proxy_cache[key]

@@ -24,6 +24,7 @@ ROUTES = {
     "gemm_shallow_ring": ({"VLMC_GEMM_WIDE_SLOTS": "2"}, "one double step of loads in flight also for the tiles of at most 64 x 64"),
     "linear_single": ({"VLMC_LINEAR_GROUP": "0"}, "every linear its own launch"),
     "linear_library": ({"VLMC_LINEAR_FWD": "0"}, "the GEMM library for the blocks' linears"),
+    "f32_library": ({"VLMC_LINEAR_F32": "0"}, "fp32 modules (the reference's Q-Former) left to the GEMM library and torch's GELU: run per sample, never stacked"),
     "select_multi": ({"VLMC_MATRIX_FUSED": "0", "VLMC_SELECT_MIXED": "0"}, "multi-launch matrix-wide / per-width row selects"),
     "dsnot_radix": ({"VLMC_DSNOT_RADIX_ONLY": "1"}, "DSnoT list heads by the exact radix route only"),
     "dsnot_simulate": ({"VLMC_DSNOT_LISTS": "0"}, "DSnoT by the per-cycle arg-min kernel"),

@@ -51,6 +51,12 @@ def grouping_enabled():
     return os.environ.get("VLMC_LINEAR_GROUP", "1") != "0"
 
 
+def f32_enabled():
+    """fp32 linears / attention products / GELU of a replayed forward on the batch-invariant fp32 kernels (the reference's fp32
+    Q-Former); `VLMC_LINEAR_F32=0`: fp32 modules stay with the library, as before round 6 (a finished fp32 tower is then not stacked)."""
+    return os.environ.get("VLMC_LINEAR_F32", "1") != "0"
+
+
 def _prepare(x, weight, bias):
     """What the kernel would be fed for `F.linear(x, weight, bias)`, or None if the call stays with the library."""
     if not (_active and not torch.is_grad_enabled() and weight.is_cuda):
@@ -128,7 +134,7 @@ def linear(x, weight, bias=None):
                     stats["kernel_rows"] += 1
                     return ops.linear_fwd_rows(p[0], [weight], [p[1]], rm[0], rm[1])[0]
         if not torch.is_autocast_enabled():
-            y = ops.linear_fwd(x, weight, bias, _try=True)           # (the entry point checks; None: not one it takes)
+            y = ops.linear_fwd(x, weight, bias, _try=True) if (weight.dtype is not torch.float32 or f32_enabled()) else None   # (None: not one it takes)
             if y is not None:
                 stats["kernel"] += 1
                 return y
@@ -755,8 +761,9 @@ def _lazy_matmul(a, b, matmul):
 
 
 def _make_matmul(orig):
-    Tensor = torch.Tensor
+    Tensor, f32 = torch.Tensor, torch.float32
     lazy = attn_fused_enabled() and softmax_enabled()
+    f32_on = f32_enabled()
 
     def matmul(a, b, *args, **kw):
         if _ident() != _mm_owner:
@@ -768,7 +775,7 @@ def _make_matmul(orig):
         if type(b) is LazyScores:
             return orig(a, b._realize(), *args, **kw)
         if not args and not kw and type(a) is Tensor and type(b) is Tensor and a.dim() >= 3 and not torch.is_grad_enabled():
-            if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() != a.dtype:
+            if (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() != a.dtype) or (a.dtype is f32 and not f32_on):
                 return orig(a, b)                                   # (autocast would cast the operands: the library's call)
             if lazy and a.dim() == 4 and b.dim() == 4 and b.stride(2) == 1 and a.stride(3) == 1 and b.shape[3] > 1 and \
                     a.dtype is b.dtype and a.shape[:2] == b.shape[:2] and ops.attn_fused_plan(a, b.transpose(2, 3), b.transpose(2, 3)) is not None:
@@ -868,7 +875,7 @@ def _make_gelu(orig):
             if type(x) is LazyLinear:
                 r = _ll_gelu(orig, (x,) + args, kw)
                 return r if r is not NotImplemented else gelu(x._realize(), *args, **kw)
-            if type(x) is Tensor and x.is_cuda and (x.dtype in ops._16BIT or (x.dtype is torch.float32 and not torch.is_autocast_enabled())) and \
+            if type(x) is Tensor and x.is_cuda and (x.dtype in ops._16BIT or (x.dtype is torch.float32 and not torch.is_autocast_enabled() and f32_enabled())) and \
                     not torch.is_grad_enabled() and not args and \
                     not (set(kw) - {"approximate"}) and kw.get("approximate", "none") in ("none", "tanh") and x.numel() > 0:
                 stats["gelu_kernel"] += 1
