@@ -44,7 +44,8 @@ def test_plan_refuses_what_the_kernel_does_not_compute():
     h = torch.float16
     a, b = torch.randn(2, 3, 5, 8).to(h), torch.randn(2, 3, 8, 4).to(h)
     assert ops.attn_matmul_plan(a, b) is None                                            # CPU tensors
-    assert ops.attn_matmul_plan(a.float(), b.float(), _cuda_only=False) is None          # fp32 stays with the library
+    assert ops.attn_matmul_plan(a.float(), b.float(), _cuda_only=False) is not None      # fp32: its own kernel since round 6 (the fp32 Q-Former)
+    assert ops.attn_matmul_plan(a.double(), b.double(), _cuda_only=False) is None        # fp64 stays with the library
     assert ops.attn_matmul_plan(a, b.bfloat16(), _cuda_only=False) is None               # mixed dtypes
     assert ops.attn_matmul_plan(a[0, 0], b[0, 0], _cuda_only=False) is None              # 2-D: a linear, not attention
     assert ops.attn_matmul_plan(a, b[0], _cuda_only=False) is None                       # ranks differ
