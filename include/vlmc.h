@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLMC_ABI_VERSION 18
+#define VLMC_ABI_VERSION 19
 
 #define VLMC_OK 0
 #define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
@@ -236,7 +236,7 @@ int vlmc_unpack_24(const void *values, const uint8_t *meta, int dtype, int64_t o
  * samples per call, or any share of them on another GPU, yields identical rows.
  * dtype VLMC_F32 (round 6: the reference's Q-Former, `ln_vision` and `t5_proj` stay in fp32 outside autocast, blip2_t5_instruct.py:76-95,
  * :143-175): fp32 operands and output on v_mfma_f32_16x16x4_f32, one accumulator per element over k in ascending groups of four -- the same
- * invariance; no alignment requirement beyond 4 bytes.  (vlmc_linear_fwd_group / _rows / _post are 16-bit only.)                    */
+ * invariance; no alignment requirement beyond 4 bytes.  (vlmc_linear_fwd_group / _rows are 16-bit only.)                    */
 int vlmc_linear_fwd(const void *X, const void *W, const void *bias, int dtype, int64_t M, int64_t N, int64_t K, int64_t ldx,
                     int64_t ldw, void *Y, int64_t ldy, void *stream);
 
@@ -266,18 +266,6 @@ int vlmc_linear_fwd_group(const void *X, const vlmc_linear_job *jobs /* host arr
 int vlmc_linear_fwd_rows(const void *X, const vlmc_linear_job *jobs /* host array */, int n_jobs /* 1..4 */, int dtype, int64_t M,
                          int64_t K, int64_t ldx, const int32_t *rowmap, int64_t n_real, void *stream);
 
-/* vlmc_linear_fwd with the elementwise op(s) the model applies to a linear's output folded into the epilogue -- each still rounding
- * to the dtype where the tensor op rounds, so the result has the BITS of `vlmc_linear_fwd` followed by the torch op(s):
- *     y = wd(X W^T + bias)                                   the module's own output (nn.Linear.forward)
- *     [y = wd(y + post_bias[n])]                             `self.qkv(x) + qkv_bias`            eva_vit.py:137-142
- *     [y = wd(gelu(y))]  act = 1: erf form, nn.GELU()        `self.act(self.fc1(x))`             eva_vit.py:62-64
- *     [y = wd(residual[m][n] + y)]                           `x + self.drop_path(self.mlp(..))`  eva_vit.py:216-221,
- *                                                            `hidden_states + self.dropout(..)`  modeling_t5.py:675, :710, :346
- * in this order.  Saves one HBM pass over [M, N] per op (GELU on the ViT-g fc1 output: 808 MB per block and pass).  post_bias [N],
- * residual [M, N] (row stride ldr): the operand dtype, or NULL.  Batch-invariant like vlmc_linear_fwd.                        */
-int vlmc_linear_fwd_post(const void *X, const void *W, const void *bias, int dtype, int64_t M, int64_t N, int64_t K, int64_t ldx,
-                         int64_t ldw, void *Y, int64_t ldy, const void *post_bias, int act, const void *residual, int64_t ldr,
-                         void *stream);
 
 /* ---- batched attention products of the calibration forward (MFMA) ---------------------------------
  * Replaces the batched matmuls inside the attention of a replayed block -- `attn = q @ k.transpose(-2, -1)` and `attn @ v`

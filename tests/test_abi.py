@@ -59,3 +59,29 @@ def test_crosscheck_list_turns_into_the_individual_switches():
     import pytest
     with pytest.raises(ValueError):
         crosscheck.apply({"VLMC_CROSSCHECK": "gemm_stagd"})
+
+
+def test_every_environment_switch_is_registered():
+    """vlmc/config.py is the ONE list of `VLMC_*` environment variables: at most ten public ones, every other one a named cross-check
+    route or an internal aid.  A variable read anywhere in the tree (os.environ / getenv) that is not listed there fails here."""
+    import glob
+    import os
+    import re
+
+    from vlmc import config, crosscheck
+    assert len(config.PUBLIC) <= 10
+    routed = {k for vars_, _doc in crosscheck.ROUTES.values() for k in vars_}
+    assert routed <= config.CROSSCHECK | set(config.PUBLIC), sorted(routed - config.CROSSCHECK)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    read = set()
+    pats = [re.compile(r"""environ(?:\.get|\.setdefault|\.pop)?\(\s*["'](VLMC_[A-Z0-9_]+)"""), re.compile(r"""environ\[\s*["'](VLMC_[A-Z0-9_]+)"""),
+            re.compile(r"""getenv\(\s*["'](VLMC_[A-Z0-9_]+)"""), re.compile(r"""setenv\(\s*["'](VLMC_[A-Z0-9_]+)""")]
+    files = glob.glob(os.path.join(root, "vlm-compression_amd", "**", "*.py"), recursive=True) + \
+        glob.glob(os.path.join(root, "vlm-compression_amd", "csrc", "**", "*.h*"), recursive=True) + \
+        glob.glob(os.path.join(root, "vlm-compression_amd", "csrc", "**", "*.cpp"), recursive=True) + [os.path.join(root, "bench.py")]
+    for f in files:
+        src = open(f, errors="ignore").read()
+        for p in pats:
+            read |= set(p.findall(src))
+    unknown = sorted(read - config.all_names())
+    assert not unknown, f"VLMC_* variables read but not registered in vlmc/config.py: {unknown}"

@@ -69,11 +69,6 @@ struct GemmArgs {
     uint16_t *Y[MAXG];            // [NQ, NP[g]]
     int64_t ldy[MAXG];
     const void *bias[MAXG];       // [NP[g]] in the operand dtype, or NULL
-    // post-ops on the ROUNDED output, in this order, each rounding to the dtype like the tensor op it stands for (vlmc_linear_fwd_post):
-    const void *post_bias[MAXG];  // y = wd(y + post_bias[n])        `self.qkv(x) + qkv_bias` (eva_vit.py:137-142)
-    int act[MAXG];                // 1: y = wd(gelu_erf(y))          `self.act(self.fc1(x))`, nn.GELU() (eva_vit.py:62-64)
-    const void *res[MAXG];        // y = wd(res[m][n] + y)           `x + self.drop_path(self.mlp(..))`, `hidden_states + self.dropout(..)`
-    int64_t ldr[MAXG];
     // Panels of BP rows of P, numbered over all groups: the npf full ones first (fstart[g] .. fstart[g + 1] belong to
     // group g), then the nph "half" ones -- a group's last panel when at most BP / 2 of its rows exist (hgroup[h] = its
     // group).  Likewise nqf full blocks of BQ rows of Q, plus one half block if q_half.  The persistent kernel runs the
@@ -113,10 +108,6 @@ struct Panel {
     int64_t ldy;
     const void *bias;
     int p0;                       // first row of the panel inside its group
-    const void *post_bias;
-    const void *res;
-    int64_t ldr;
-    int act;
 };
 __device__ __forceinline__ Panel locate_panel(const GemmArgs &a, int bp, int BP) {
     int g = 0, local;
@@ -127,7 +118,7 @@ __device__ __forceinline__ Panel locate_panel(const GemmArgs &a, int bp, int BP)
         g = a.hgroup[bp - a.npf];
         local = a.fstart[g + 1] - a.fstart[g];
     }
-    return Panel{a.P[g], a.ldp[g], a.NP[g], a.Y[g], a.ldy[g], a.bias[g], local * BP, a.post_bias[g], a.res[g], a.ldr[g], a.act[g]};
+    return Panel{a.P[g], a.ldp[g], a.NP[g], a.Y[g], a.ldy[g], a.bias[g], local * BP};
 }
 
 // byte offset of 16-B chunk `ch` (0..7) of tile row `row` in an LDS operand tile
@@ -166,48 +157,6 @@ __device__ __forceinline__ void zero_pad_rows(const GemmArgs &a, const Panel &pn
 // (32 B per row and instruction: the epilogue of a 256 x 256 tile took about as long as 20 K-steps).  The wave's tile
 // goes through its own piece of the (now idle) LDS instead -- 16 or 32 rows of q at a time, the 16-B chunk index XOR-ed with
 // the row so the 8-B writes of 16 rows spread over the banks -- and leaves as 16 B per lane, 256 B contiguous per row.
-// Post-ops of vlmc_linear_fwd_post on 8 consecutive outputs of row q (columns p .. p + 7), each a tensor op of the model's code that
-// rounds to the dtype: an fp32 result is kept a value of its own (the empty asm) so that hipcc cannot fold arithmetic and
-// conversion into one rounding.  (Inlined: a call would give every kernel a scratch frame; the register peak stays the K loop's.)
-template <typename T>
-__device__ __forceinline__ u32x4_t linear_post(const Panel &pn, u32x4_t v, int q, int p) {
-    uint16_t e[8];
-    __builtin_memcpy(e, &v, 16);
-    const int n = pn.NP - p < 8 ? pn.NP - p : 8;
-    if (pn.post_bias != nullptr) {
-        const uint16_t *b = static_cast<const uint16_t *>(pn.post_bias) + p;
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-            if (r < n) {
-                float t = ieee_add(to_f32<T>(e[r]), to_f32<T>(b[r]));
-                asm volatile("" : "+v"(t));
-                e[r] = from_f32<T>(t);
-            }
-    }
-    if (pn.act == 1) {
-        // at::native::GeluCUDAKernelImpl, approximate = none:  x * 0.5 * (1 + erf(x * M_SQRT1_2))  in fp32
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const float x = to_f32<T>(e[r]);
-            float t = ieee_mul(ieee_mul(x, 0.5f), ieee_add(1.0f, erff(ieee_mul(x, 0.70710678118654752440f))));
-            asm volatile("" : "+v"(t));
-            e[r] = from_f32<T>(t);
-        }
-    }
-    if (pn.res != nullptr) {
-        const uint16_t *rr = static_cast<const uint16_t *>(pn.res) + int64_t(q) * pn.ldr + p;
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-            if (r < n) {
-                float t = ieee_add(to_f32<T>(rr[r]), to_f32<T>(e[r]));
-                asm volatile("" : "+v"(t));
-                e[r] = from_f32<T>(t);
-            }
-    }
-    __builtin_memcpy(&v, e, 16);
-    return v;
-}
-
 template <typename T, int EPI, typename S, int ROWS = (S::TQ >= 2 ? 32 : 16), bool BARRIER = true>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, const Panel &pn, f32x4_t (&acc)[S::TP][S::TQ], int q0, int wp,
                                               int wq, int lane, unsigned char *lds, int wave) {
@@ -257,7 +206,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, const Panel &pn
                 const int q = q0 + wq * (TQ * 16) + pass * ROWS + row, p = p0 + wp * PW + ch * 8;
                 if (q >= a.NQ || p >= pn.NP) continue;
                 const int qp = q_phys(a, q);                                // (row-mapped launch: where row q of the product lives)
-                if (pn.post_bias != nullptr || pn.act != 0 || pn.res != nullptr) v = linear_post<T>(pn, v, qp, p);    // (uniform: rare)
                 uint16_t *dst = pn.Y + int64_t(qp) * pn.ldy + p;
                 if (vec_ok && p + 7 < pn.NP) {
 #ifndef VLMC_GEMM_PLAIN_STORES
@@ -1421,16 +1369,8 @@ static int dtype_ok16(int dtype) { return dtype == VLMC_F16 || dtype == VLMC_BF1
 
 using namespace vlmc;
 
-struct LinearPost {
-    const void *post_bias = nullptr;
-    int act = 0;
-    const void *res = nullptr;
-    int64_t ldr = 0;
-};
-
 static int linear_group_launch(const char *what, const void *X, const vlmc_linear_job *jobs, int n_jobs, int dtype, int64_t M,
-                               int64_t K, int64_t ldx, void *stream, const LinearPost *post = nullptr, const int32_t *rowmap = nullptr,
-                               int64_t n_real = 0) {
+                               int64_t K, int64_t ldx, void *stream, const int32_t *rowmap = nullptr, int64_t n_real = 0) {
     VLMC_REQUIRE(dtype_ok16(dtype), "%s: dtype must be VLMC_F16 or VLMC_BF16", what);
     VLMC_REQUIRE(X && jobs && n_jobs >= 1 && n_jobs <= MAXG, "%s: null pointer or bad job count (1..%d)", what, MAXG);
     VLMC_REQUIRE(M >= 0 && K > 0 && M < (int64_t(1) << 31) && K < (int64_t(1) << 31), "%s: bad shape", what);
@@ -1455,12 +1395,6 @@ static int linear_group_launch(const char *what, const void *X, const vlmc_linea
         a.Y[g] = static_cast<uint16_t *>(j.Y);
         a.ldy[g] = j.ldy;
         a.bias[g] = j.bias;
-        if (post) {
-            VLMC_REQUIRE(post->act == 0 || post->act == 1, "%s: act must be 0 (none) or 1 (erf GELU)", what);
-            VLMC_REQUIRE(!post->res || post->ldr >= j.N, "%s: the residual's row stride must be >= N", what);
-            VLMC_REQUIRE(((reinterpret_cast<uintptr_t>(post->res) | reinterpret_cast<uintptr_t>(post->post_bias)) & 1u) == 0, "%s: unaligned post operand", what);
-            a.post_bias[g] = post->post_bias, a.act[g] = post->act, a.res[g] = post->res, a.ldr[g] = post->ldr;
-        }
         total += j.N;
     }
     VLMC_REQUIRE(total < (int64_t(1) << 31), "%s: too many output features", what);
@@ -1489,15 +1423,6 @@ extern "C" int vlmc_linear_fwd(const void *X, const void *W, const void *bias, i
     return linear_group_launch("vlmc_linear_fwd", X, &job, 1, dtype, M, K, ldx, stream);
 }
 
-extern "C" int vlmc_linear_fwd_post(const void *X, const void *W, const void *bias, int dtype, int64_t M, int64_t N, int64_t K, int64_t ldx,
-                                    int64_t ldw, void *Y, int64_t ldy, const void *post_bias, int act, const void *residual, int64_t ldr,
-                                    void *stream) {
-    const vlmc_linear_job job{W, bias, Y, N, ldw, ldy};
-    LinearPost post;
-    post.post_bias = post_bias, post.act = act, post.res = residual, post.ldr = ldr;
-    return linear_group_launch("vlmc_linear_fwd_post", X, &job, 1, dtype, M, K, ldx, stream, &post);
-}
-
 extern "C" int vlmc_linear_fwd_group(const void *X, const vlmc_linear_job *jobs, int n_jobs, int dtype, int64_t M, int64_t K,
                                      int64_t ldx, void *stream) {
     return linear_group_launch("vlmc_linear_fwd_group", X, jobs, n_jobs, dtype, M, K, ldx, stream);
@@ -1506,7 +1431,7 @@ extern "C" int vlmc_linear_fwd_group(const void *X, const vlmc_linear_job *jobs,
 extern "C" int vlmc_linear_fwd_rows(const void *X, const vlmc_linear_job *jobs, int n_jobs, int dtype, int64_t M, int64_t K, int64_t ldx,
                                     const int32_t *rowmap, int64_t n_real, void *stream) {
     VLMC_REQUIRE(rowmap != nullptr, "vlmc_linear_fwd_rows: null row map");
-    return linear_group_launch("vlmc_linear_fwd_rows", X, jobs, n_jobs, dtype, M, K, ldx, stream, nullptr, rowmap, n_real);
+    return linear_group_launch("vlmc_linear_fwd_rows", X, jobs, n_jobs, dtype, M, K, ldx, stream, rowmap, n_real);
 }
 
 // Split of the SYRK along the rows of X.  A Hessian of 1408 columns is 66 tiles of 128 x 128 (21 of 256 x 256) on a 256-CU

@@ -2169,34 +2169,6 @@ def pad_ragged_enabled():
     return os.environ.get("VLMC_PAD_RAGGED", "1") != "0" and fw.enabled() and fw.attn_matmul_enabled() and fw.softmax_enabled()
 
 
-def _length_buckets(L, min_size=16, max_buckets=3, gain=0.88):
-    """Samples 0 .. len(L) - 1 in at most `max_buckets` groups of similar length L (each sorted by sample index), minimising
-    sum(len(group) * max L in group); one group unless the best split needs at most `gain` of its rows."""
-    n = len(L)
-    order = sorted(range(n), key=lambda j: (L[j], j))
-    lens = [L[j] for j in order]
-    one = n * lens[-1]
-    best, cuts = one, ()
-    if n >= 2 * min_size:
-        for a in range(min_size, n - min_size + 1):
-            if lens[a - 1] == lens[a]:
-                continue                                          # (equal lengths stay together)
-            c2 = a * lens[a - 1] + (n - a) * lens[-1]
-            if c2 < best:
-                best, cuts = c2, (a,)
-            if max_buckets >= 3:
-                for b in range(a + min_size, n - min_size + 1):
-                    if lens[b - 1] == lens[b]:
-                        continue
-                    c3 = a * lens[a - 1] + (b - a) * lens[b - 1] + (n - b) * lens[-1]
-                    if c3 < best:
-                        best, cuts = c3, (a, b)
-    if not cuts or best > gain * one:
-        return [list(range(n))]
-    edges = (0,) + cuts + (n,)
-    return [sorted(order[edges[i]:edges[i + 1]]) for i in range(len(edges) - 1)]
-
-
 def plan_padded(cur_in, caches, n_samples, group_max):
     """[(chunk, spec)] covering samples 0 .. n_samples - 1 with PADDED groups, or None when the samples are not ragged or cannot be
     padded (no mask kwarg to hide the padding behind, tensors this function does not know how to pad, mixed dtypes / widths)."""
@@ -2246,18 +2218,10 @@ def plan_padded(cur_in, caches, n_samples, group_max):
         budget = max(1, int(os.environ.get("VLMC_REPLAY_TOKENS", str(REPLAY_TOKEN_BUDGET))))
     except ValueError:
         budget = REPLAY_TOKEN_BUDGET
-    # Which samples share a padded forward.  One group for all pads every sample to the longest: with prompts of 8..128 tokens the
-    # T5 blocks compute 160 rows per sample where the mean is 100.  Buckets of similar length (`VLMC_PAD_BUCKETS=2|3`: at most that
-    # many, at least 16 samples each, taken only if they save 12 % of the rows) trade a forward or two more per block for those
-    # rows -- measured (tools/ragged_time.py): 478 ms with one group, 486 with two buckets (-26 % rows), 541 with three (-34 %): the
-    # T5 towers' ~45 launches per block forward cost more than the rows save, so ONE group is the default.  (A sample's bits do not
-    # depend on the company it is padded in: that is what padding invariance means; the buckets are under the same tests.)
-    L = [S[j] if (ragged_s and S[j] is not None) else T[j] for j in range(n_samples)]
-    try:
-        nb = int(os.environ.get("VLMC_PAD_BUCKETS", "1"))
-    except ValueError:
-        nb = 1
-    buckets = _length_buckets(L, max_buckets=min(3, nb)) if nb >= 2 else [list(range(n_samples))]
+    # Which samples share a padded forward: ONE group.  (Buckets of similar length -- up to three, 26-34 % fewer rows -- were measured
+    # slower in round 5, 486 / 541 against 478 ms: a T5 block forward is ~45 launches whatever its rows; since round 6 the linears skip
+    # the padding rows and the fused attention the padding keys, so the rows buckets would save are hardly computed any more.  Removed.)
+    buckets = [list(range(n_samples))]
     out = []
     chunks = []
     for bucket in buckets:

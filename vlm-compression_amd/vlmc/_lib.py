@@ -72,7 +72,6 @@ SIGNATURES = {
     "vlmc_pack_24": (_i, [_p, _i, _i64, _i64, _i64, _p, _i64, _p, _p, _p, _p]),
     "vlmc_unpack_24": (_i, [_p, _p, _i, _i64, _i64, _p, _i64, _p, _i64, _p, _p]),
     "vlmc_linear_fwd": (_i, [_p, _p, _p, _i, _i64, _i64, _i64, _i64, _i64, _p, _i64, _p]),
-    "vlmc_linear_fwd_post": (_i, [_p, _p, _p, _i, _i64, _i64, _i64, _i64, _i64, _p, _i64, _p, _i, _p, _i64, _p]),
     "vlmc_linear_fwd_group": (_i, [_p, _p, _i, _i, _i64, _i64, _i64, _p]),
     "vlmc_linear_fwd_rows": (_i, [_p, _p, _i, _i, _i64, _i64, _i64, _p, _i64, _p]),
     "vlmc_attn_matmul": (_i, [_p, _p, _p, _i] + [_i64] * 15 + [_p]),

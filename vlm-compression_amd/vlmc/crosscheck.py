@@ -47,7 +47,6 @@ ROUTES = {
     "attn_library": ({"VLMC_ATTN_MATMUL": "0", "VLMC_ROW_MEAN": "0"}, "the blocks' batched matmuls and the norms' mean left to torch during the replay"),
     "attn_transposing_write": ({"VLMC_ATTN_TR": "0"}, "attn @ v with the operand transposed while writing LDS (no ds_read_b64_tr_b16)"),
     "lora_unfused": ({"VLMC_LORA_FUSED": "0"}, "SparseLoRA through a materialised W_eff, library GEMMs and a G = dY^T x in memory"),
-    "linear_epilogue_ops": ({"VLMC_LINEAR_POST": "1", "VLMC_LINEAR_POST_ADD": "1"}, "GELU / residual / bias after a linear folded into its GEMM epilogue (vlmc_linear_fwd_post; off by default: measured level)"),
     "gelu_torch": ({"VLMC_GELU": "0"}, "torch's GELU kernel (another instruction sequence in a tensor's last partial block)"),
     "attn_unfused": ({"VLMC_ATTN_FUSED": "0"}, "an attention written op by op runs op by op (vlmc_attn_matmul, torch elementwise, vlmc_softmax_rows) instead of vlmc_attn_fwd"),
     "replay_equal_shapes": ({"VLMC_PAD_RAGGED": "0", "VLMC_TOWER_PAD": "0"}, "ragged samples forwarded in groups of equal shape, never padded"),

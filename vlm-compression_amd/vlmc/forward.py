@@ -36,8 +36,7 @@ from . import ops
 _active = 0
 stats = {"kernel": 0, "library": 0, "grouped_launches": 0, "served_from_group": 0, "stash_dropped": 0, "attn_kernel": 0,
          "attn_library": 0, "mean_kernel": 0, "sdpa_kernel": 0, "sdpa_library": 0, "norm_kernel": 0, "softmax_kernel": 0,
-         "attn_fused": 0, "attn_chain_unfused": 0, "attn_fused_checks": 0, "linear_post": 0, "linear_lazy_unfused": 0,
-         "linear_post_checks": 0, "gelu_kernel": 0, "kernel_rows": 0, "attn_fused_lens": 0}
+         "attn_fused": 0, "attn_chain_unfused": 0, "attn_fused_checks": 0, "gelu_kernel": 0, "kernel_rows": 0, "attn_fused_lens": 0}
 
 # first member of a learned sibling group -> tuple of weak references to all members, in call order
 _SIBLINGS = weakref.WeakKeyDictionary()
@@ -195,9 +194,6 @@ class _Tracker:
         self.run, self.run_x, self.run_key = [], None, None      # consecutive calls on one tensor (the tensor kept alive)
         self.stash = {}                                          # id(module) -> (x, key, y)
         self.grouping = grouping_enabled()
-        self.post = linear_post_enabled()
-        global _post_add
-        _post_add = os.environ.get("VLMC_LINEAR_POST_ADD", "0") == "1"
 
     def _close_run(self):
         if len(self.run) >= 2 and len({id(m) for m in self.run}) == len(self.run) and self.run[0] not in _SIBLINGS:
@@ -205,7 +201,7 @@ class _Tracker:
         self.run, self.run_x, self.run_key = [], None, None
 
     def call(self, mod, x):
-        if type(x) is LazyLinear or type(x) is LazyScores:
+        if type(x) is LazyScores:
             x = x._realize()
         if not isinstance(x, torch.Tensor):
             return linear(x, mod.weight, mod.bias)
@@ -269,15 +265,7 @@ class _Tracker:
         return self.single(mod, x)
 
     def single(self, mod, x):
-        """A linear on its own: answered lazily when the op that follows may fold into its epilogue (LazyLinear)."""
-        if self.post and _POST.get(mod) is not False and not torch.is_grad_enabled() and mod.weight.is_cuda and \
-                (_ROW_MAPS is None or _rows_for(x) is None):
-            if torch.is_autocast_enabled():
-                p = _prepare(x, mod.weight, mod.bias)
-            else:
-                p = (x, mod.bias) if x.is_cuda and ops.linear_fwd_supported(x, mod.weight, mod.bias) else None
-            if p is not None:
-                return LazyLinear(p[0], mod.weight, p[1], mod)
+        """A linear on its own."""
         return linear(x, mod.weight, mod.bias)
 
     def close(self):
@@ -308,145 +296,6 @@ _ident = threading.get_ident
 
 def attn_matmul_enabled():
     return os.environ.get("VLMC_ATTN_MATMUL", "1") != "0"
-
-
-# ---- the elementwise op after a linear, folded into its epilogue ---------------------------------------------------------------
-# `self.act(self.fc1(x))`, `x + self.drop_path(self.mlp(..))`, `hidden_states + self.dropout(attention_output)`,
-# `self.qkv(x) + qkv_bias` (eva_vit.py:62-64, :216-221, :137-142; modeling_t5.py:346, :675, :710): the op that follows a linear is a
-# whole HBM pass over its output (GELU on the ViT-g fc1 output: 808 MB per block and pass, as long as a third of the GEMM itself).
-# `vlmc_linear_fwd_post` folds it into the GEMM's epilogue with the rounding of the separate op.  Like the attention chain below, it
-# is spliced under model code by answering LAZILY: a linear that is not part of a sibling group returns a `LazyLinear` (shape and
-# dtype, no storage); GELU (erf form), `+` a tensor of the output's shape (residual) or of shape [out_features], and dropout in
-# eval mode are the ops it knows (the adds only with `VLMC_LINEAR_POST_ADD=1`: measured, they do not pay); the first other op
-# computes the plain product and runs on it.  A module whose output was once
-# consumed by another op is never answered lazily again (`_POST`), so the wrapper costs nothing where nothing folds.  A
-# signature (dtype, kind of op) is trusted after one bitwise comparison with the unfused sequence -- for GELU on everything but the
-# last 4096 elements: torch's vectorized elementwise kernel runs a tensor's last partial block through another instruction
-# sequence (hipcc contracts `x/2 * (1 + erf)` into an fma there: gelu(-6.7) is +0.0 in the tail and -0.0 everywhere else;
-# tools/micro/gelu_variants.py), the epilogue uses the body's arithmetic for every element.  `VLMC_LINEAR_POST=1` switches it ON:
-# it is off by default because it was measured not to pay (see `linear_post_enabled`).
-_POST = weakref.WeakKeyDictionary()      # module -> True (an op folded into its epilogue) | False (its output went to another op)
-_POST_OK = {}
-_post_add = False
-
-
-def linear_post_enabled():
-    """OFF unless `VLMC_LINEAR_POST=1`: built, bit-exact, and measured not to pay inside a prune -- the GELU fold
-    saves 78 us of a 763-us fc1 + GELU pair in isolation, the whole prune is level within run-to-run noise (289.7 vs 283.9 ms)."""
-    return os.environ.get("VLMC_LINEAR_POST", "0") == "1"
-
-
-class LazyLinear(torch.Tensor):
-    """`F.linear(x, weight, bias)` not computed yet (see above)."""
-
-    @staticmethod
-    def __new__(cls, x, weight, bias, mod):
-        r = torch.Tensor._make_wrapper_subclass(cls, (*x.shape[:-1], weight.shape[0]), dtype=weight.dtype, device=weight.device)
-        r._x, r._w, r._b, r._mod, r._real, r._consumed = x, weight, bias, weakref.ref(mod), None, False
-        _LAZY_LIVE.add(r)
-        return r
-
-    def _realize(self):
-        if self._real is None:
-            self._real = ops.linear_fwd(self._x, self._w, self._b, _checked=True)
-            stats["kernel"] += 1
-            stats["linear_lazy_unfused"] += 1
-            m = self._mod()
-            if m is not None and _POST.get(m) is None:
-                _POST[m] = False                                          # its output feeds an op that does not fold: plain from now on
-            self._x = None
-        return self._real
-
-    @classmethod
-    def __torch_function__(cls, func, types, args=(), kwargs=None):
-        kwargs = kwargs or {}
-        h = _LINEAR_HANDLERS.get(func)
-        if h is not None:
-            r = h(func, args, kwargs)
-            if r is not NotImplemented:
-                return r
-        elif func in _LAZY_META_FUNCS or (getattr(func, "__name__", None) == "__get__" and
-                                         getattr(getattr(func, "__self__", None), "__name__", None) in _LAZY_META_PROPS):
-            with torch._C.DisableTorchFunctionSubclass():
-                return func(*args, **kwargs)
-        return func(*_real_args(args), **{k_: _real_arg(v_) for k_, v_ in kwargs.items()})
-
-
-def _fold(lazy, kind, other=None):
-    """The product with `kind` folded into the epilogue, once that has reproduced the separate op bit for bit; else None."""
-    if lazy._real is not None:
-        return None
-    key = (lazy._w.dtype, kind)
-    ok = _POST_OK.get(key)
-    if ok is False or (ok is None and torch.cuda.is_current_stream_capturing()):
-        return None
-    x, w, b = lazy._x, lazy._w, lazy._b
-    y = ops.linear_fwd_post(x, w, b, post_bias=other if kind == "bias" else None, act=1 if kind == "gelu" else 0,
-                            residual=other if kind == "res" else None)
-    if ok is None:
-        plain = ops.linear_fwd(x, w, b, _checked=True)
-        ref = F.gelu(plain) if kind == "gelu" else other + plain if kind == "res" else plain + other
-        a_, b_ = y.contiguous().view(torch.int16).flatten(), ref.contiguous().view(torch.int16).flatten()
-        body = a_.numel() - 4096 if kind == "gelu" else a_.numel()
-        ok = y.shape == ref.shape and torch.equal(a_[:max(0, body)], b_[:max(0, body)])
-        if ok and kind == "gelu":
-            t = max(0, body)
-            ok = bool((((a_[t:].int() - b_[t:].int()).abs() <= 1) | ((y.flatten()[t:] == 0) & (ref.flatten()[t:] == 0))).all())
-        _POST_OK[key] = bool(ok)
-        stats["linear_post_checks"] += 1
-        if not ok:
-            import warnings
-            warnings.warn(f"vlmc.forward: the {kind} epilogue does not reproduce the separate op for {w.dtype}; it stays unfused", RuntimeWarning)
-            return ref
-    stats["kernel"] += 1
-    stats["linear_post"] += 1
-    m = lazy._mod()
-    if m is not None:
-        _POST[m] = True
-    lazy._consumed = True
-    return y
-
-
-def _ll_gelu(func, args, kw):
-    if len(args) != 1 or type(args[0]) is not LazyLinear or kw.get("approximate", "none") != "none" or (set(kw) - {"approximate"}):
-        return NotImplemented
-    r = _fold(args[0], "gelu")
-    return NotImplemented if r is None else r
-
-
-def _ll_add(func, args, kw):
-    # Measured (tools/bench_linear_post.py): folding the residual / bias add does NOT pay -- the epilogue's extra loads are not
-    # overlapped with anything (vit.proj 185 -> 213 us, t5 wo / o +2-3 us, vit.fc2 and qkv level) while the separate add runs at
-    # HBM speed -- so only GELU folds by default (vit.fc1 763 -> 685 us); `VLMC_LINEAR_POST_ADD=1` folds the adds too.
-    if kw or len(args) != 2 or not _post_add:
-        return NotImplemented
-    a, b = args
-    if type(a) is not LazyLinear:
-        a, b = b, a
-    if type(a) is not LazyLinear or type(b) is not torch.Tensor or b.dtype != a._w.dtype or b.device != a._w.device or b.requires_grad:
-        return NotImplemented
-    shape = (*a._x.shape[:-1], a._w.shape[0]) if a._x is not None else None
-    if shape is None:
-        return NotImplemented
-    if tuple(b.shape) == shape:
-        r = _fold(a, "res", b)
-    elif b.dim() == 1 and b.shape[0] == shape[-1] and b.is_contiguous():
-        r = _fold(a, "bias", b)
-    else:
-        return NotImplemented
-    return NotImplemented if r is None else r
-
-
-def _ll_dropout(func, args, kw):
-    if not args or type(args[0]) is not LazyLinear:
-        return NotImplemented
-    names = ("p", "training", "inplace") if func is F.dropout else ("p", "train")
-    vals = dict(zip(names, args[1:]))
-    vals.update(kw)
-    training = vals.get("training", vals.get("train", True))
-    if set(vals) - set(names) or (training and vals.get("p", 0.5) != 0):
-        return NotImplemented
-    return args[0]
 
 
 # ---- the reference-op attention chain in ONE launch ---------------------------------------------------------------------------
@@ -530,7 +379,6 @@ def _lazy_dispatch(cls, func, types, args=(), kwargs=None):
 
 
 LazyScores.__torch_dispatch__ = classmethod(_lazy_dispatch)
-LazyLinear.__torch_dispatch__ = classmethod(_lazy_dispatch)
 
 
 def _realize_escaped():
@@ -542,7 +390,7 @@ def _realize_escaped():
 
 
 def _real_arg(v):
-    if type(v) is LazyScores or type(v) is LazyLinear:
+    if type(v) is LazyScores:
         return v._realize()
     if type(v) in (tuple, list):
         return type(v)(_real_arg(e) for e in v)
@@ -710,9 +558,6 @@ def _lazy_handlers():
 
 
 _LAZY_HANDLERS = _lazy_handlers()
-_LINEAR_HANDLERS = {F.gelu: _ll_gelu, torch.Tensor.__add__: _ll_add, torch.Tensor.__radd__: _ll_add, torch.Tensor.add: _ll_add,
-                    torch.add: _ll_add, F.dropout: _ll_dropout, torch.dropout: _ll_dropout}
-
 
 def _chain_signature(a, v):
     q = a._q
@@ -872,9 +717,6 @@ def _make_gelu(orig):
 
     def gelu(x, *args, **kw):
         if _ident() == _mm_owner:
-            if type(x) is LazyLinear:
-                r = _ll_gelu(orig, (x,) + args, kw)
-                return r if r is not NotImplemented else gelu(x._realize(), *args, **kw)
             if type(x) is Tensor and x.is_cuda and (x.dtype in ops._16BIT or (x.dtype is torch.float32 and not torch.is_autocast_enabled() and f32_enabled())) and \
                     not torch.is_grad_enabled() and not args and \
                     not (set(kw) - {"approximate"}) and kw.get("approximate", "none") in ("none", "tanh") and x.numel() > 0:

@@ -167,35 +167,6 @@ def linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None 
     return y.reshape(*x.shape[:-1], N)
 
 
-def linear_fwd_post(x: torch.Tensor, weight: torch.Tensor, bias=None, post_bias=None, act: int = 0, residual=None) -> torch.Tensor:
-    """`linear_fwd` with the op(s) the model applies to the linear's output folded into the epilogue, each rounding to the dtype
-    where the tensor op rounds (include/vlmc.h: vlmc_linear_fwd_post): `y + post_bias` (1-D [N]), `gelu(y)` (act = 1: erf form),
-    `residual + y` ([.., N], the output's shape) -- the bits of `linear_fwd` followed by those torch ops, one HBM pass fewer each."""
-    _need_gpu(x, weight, bias, post_bias, residual)
-    if not linear_fwd_supported(x, weight, bias):
-        raise TypeError("vlmc.linear_fwd_post: fp16/bf16 tensors of one dtype with in_features % 8 == 0 expected")
-    N, K = weight.shape
-    x2 = x.reshape(-1, K)
-    if x2.stride(1) != 1 or x2.stride(0) % 8 != 0 or x2.stride(0) < K or x2.data_ptr() % 16 != 0:
-        x2 = x2.contiguous()
-    M = x2.shape[0]
-    if post_bias is not None and (post_bias.dtype != x.dtype or post_bias.shape != (N,) or not post_bias.is_contiguous()):
-        raise TypeError("vlmc.linear_fwd_post: post_bias must be a contiguous [out_features] tensor of the operand dtype")
-    r2 = None
-    if residual is not None:
-        if residual.dtype != x.dtype or residual.shape != (*x.shape[:-1], N):
-            raise TypeError("vlmc.linear_fwd_post: the residual must have the output's shape and dtype")
-        r2 = residual.reshape(-1, N)
-        if r2.stride(1) != 1 or (M > 1 and r2.stride(0) < N):
-            r2 = r2.contiguous()
-    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
-    _lib.check(_lib.load().vlmc_linear_fwd_post(
-        x2.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None, _dtype_code(x), M, N, K, x2.stride(0),
-        weight.stride(0), y.data_ptr(), N, post_bias.data_ptr() if post_bias is not None else None, int(act),
-        r2.data_ptr() if r2 is not None else None, (r2.stride(0) if M > 1 else N) if r2 is not None else 0, _stream()))
-    return y.reshape(*x.shape[:-1], N)
-
-
 LINEAR_GROUP_MAX = 4
 
 
