@@ -49,6 +49,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2 / 16x16x4)
 N_CALIB = 128
 RATIO = 0.5
 PRUNER = "blipt5_wanda_pruner"
@@ -228,7 +229,29 @@ def install_probes(probe):
 
     probe.wrap(ops, "act_sqnorm_batch", "stat", sq_bytes)
     probe.wrap(ops, "wanda_select_batch", "rows", sel_bytes, sel_single)
-    probe.wrap(ops, "linear_fwd", "gemm", gemm_flops)
+    # one entry point, two kernels: 16-bit operands -> gemm_nt_* (2.5 PFLOP/s peak); fp32 (the Q-Former) -> gemm_f32_kernel (157 TFLOP/s peak)
+    calls32 = {"n": 0}
+
+    def linear_fwd_kind(*a, **k):
+        return len(a) < 2 or a[1].dtype != torch.float32
+    real_linear = ops.linear_fwd
+    probe.wrap(ops, "linear_fwd", "gemm", gemm_flops, linear_fwd_kind)
+    wrapped16 = ops.linear_fwd
+
+    def linear_fwd_both(x, weight, *a, **k):                            # (fp32 calls: their own kind, timed like the others)
+        if weight.dtype != torch.float32 or not probe.active or torch.cuda.is_current_stream_capturing():
+            return wrapped16(x, weight, *a, **k)
+        n = probe.calls["gemm32"] = probe.calls.get("gemm32", 0) + 1
+        if n % probe.stride:
+            return real_linear(x, weight, *a, **k)
+        e0, e1 = probe.hipev.new(), probe.hipev.new()
+        probe.arm(e0, e1)
+        out = real_linear(x, weight, *a, **k)
+        if out is not None:
+            probe.records.setdefault("gemm32", []).append((e0, e1, gemm_flops(x, weight), 1))
+        return out
+    ops.linear_fwd = linear_fwd_both
+    probe._undo.append((ops, "linear_fwd", real_linear))
     probe.wrap(ops, "linear_fwd_group", "gemm", group_flops)          # q / k / v, wi_0 / wi_1: one launch (vlmc/forward.py)
     probe.wrap(ops, "linear_fwd_rows", "gemm", rows_flops)            # the same products over a row map (padding rows skipped)
 
@@ -638,12 +661,11 @@ def main():
     cal.plan_groups, cal.plan_padded = real_plan, real_padded
     rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        every = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(every, t)
-        rank_ms = [round(float(e.item()) / args.steps * 1e3, 3) for e in every]
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        every = torch.zeros(world, dtype=torch.float64, device=dev)       # (a sum of one-hot vectors: all_reduce is what both backends carry)
+        every[rank] = elapsed
+        dist.all_reduce(every, op=dist.ReduceOp.SUM)
+        rank_ms = [round(float(e) / args.steps * 1e3, 3) for e in every.tolist()]
+        elapsed = max(every.tolist())
     pruned_fraction = job.pruned_fraction()
     per_tower = {}
     if groups and args.steps:
@@ -681,10 +703,11 @@ def main():
                   "gpu_ms_per_step": round(avg_us * calls / args.steps * 1e-3, 2), "traffic": traffic.get(tkey),
                   "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload taken when "
                                     "the profiles were collected (static; NOT measured in this run)", "timed": timed}
-        if bound == "mfma":
+        if bound in ("mfma", "mfma32"):
+            peak = MFMA_PEAK_TFLOPS if bound == "mfma" else MFMA_F32_PEAK_TFLOPS
             ach = units / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            return dict(common, bound="mfma", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / MFMA_PEAK_TFLOPS, 4), flops_per_launch=round(units / max(1, n)))
+            return dict(common, bound="mfma", achieved=round(ach, 1), peak=peak, unit="TFLOP/s",
+                        frac=round(ach / peak, 4), flops_per_launch=round(units / max(1, n)))
         ach = units / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         return dict(common, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
                     bytes_per_launch=round(units / max(1, n)))
@@ -696,6 +719,8 @@ def main():
                          "launch per group of calibration samples)", "act_sqnorm_kernel_bytes_per_launch"),
             roof("rows", "vlmc::select_rows_mixed_kernel (score+select+apply, per-row rule; all linears of a T5 block in one "
                          "launch)", "select_rows_mixed_kernel_bytes_per_launch"),
+            roof("gemm32", "vlmc::gemm_f32_kernel (vlmc_linear_fwd, fp32: the linears of the reference's fp32 Q-Former, ln_vision / t5_proj side, on "
+                           "v_mfma_f32_16x16x4_f32, batch-invariant; peak = the fp32 matrix rate)", "gemm_f32_bytes_per_launch", "mfma32"),
             roof("attnf", "vlmc::attn_fused_kernel (vlmc_attn_fwd: scores, scaling, position bias / mask addends, fp32 softmax and probs @ v "
                           "of a replayed block's attention in one launch, every intermediate rounded like the tensor op it replaces; "
                           "algorithmic flops = 4 B H Tq Tk d; what paces it is the softmax's VALU work and LDS fragment reads, not the "
