@@ -15,7 +15,7 @@ def load(d, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter and "vlmc::" in r["Kernel_Name"]:
-            acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+            acc[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
     return acc
 
 
