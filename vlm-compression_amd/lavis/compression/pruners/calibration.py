@@ -118,6 +118,7 @@ class _PruneContext(threading.local):
         self.stacked_lengths = None
         self.capture_group = None          # merged capture: the samples (indices) of the calibration forward that is running
         self.group_defer = False           # .. and finished towers are left for ONE (padded) stacked pass over all groups (ragged batches)
+        self.keep_ready = False            # .. and a tower's outputs for the sample forwarded alone stay for the group it belongs to
         self.capture_side = {}
         self.stream_set = ()
 
@@ -723,7 +724,8 @@ class TowerGraph:
                     return self._batched_step(0, args, kwargs)
                 return False, None
             if _CTX.capture_sample is not None and tower_batch_enabled():
-                r = self.ready.pop(_CTX.capture_sample, None)
+                # (the merged route forwards its scout alone AND in its group: the record serves both)
+                r = self.ready.get(_CTX.capture_sample) if _CTX.keep_ready else self.ready.pop(_CTX.capture_sample, None)
                 if r is not None:
                     if r.get("key", key) == key and self._same_inputs(r, args, kwargs):
                         given, k, seen = {}, 0, set()
@@ -783,14 +785,20 @@ class TowerGraph:
         if all(j in self.ready for j in grp):
             recs = [self.ready.pop(j) for j in grp]
             if all(self._same_inputs(r, a_, k_) for r, (a_, k_) in zip(recs, per)):
-                outs = []
+                outs, stacked = [], {}
                 for i in range(self.n):
                     firsts = recs[0]["outs"][i]
-                    flat0 = self._flat(firsts)
+                    flats = [self._flat(r["outs"][i]) for r in recs]
                     flat = []
-                    for pos, o0 in enumerate(flat0):
-                        if isinstance(o0, torch.Tensor):
-                            flat.append(torch.cat([self._flat(r["outs"][i])[pos] for r in recs], dim=0) if g > 1 else o0)
+                    for pos, o0 in enumerate(flats[0]):
+                        if isinstance(o0, torch.Tensor) and g > 1:
+                            # (the samples' pieces of one tensor -- the position bias every T5 block hands on -- are stacked once)
+                            parts = [fl[pos] for fl in flats]
+                            ids = tuple(id(p_) for p_ in parts)
+                            hit = stacked.get(ids)
+                            if hit is None:
+                                hit = stacked[ids] = (parts, torch.cat(parts, dim=0))
+                            flat.append(hit[1])
                         else:
                             flat.append(o0)
                     outs.append(self._like(firsts, flat))
@@ -1180,12 +1188,12 @@ class TowerGraph:
                 with torch.autocast(device_type="cuda", dtype=ctx[1], enabled=ctx[0]) if ctx[0] else contextlib.nullcontext(), \
                         fw.invariant_linears(self.linears, roots=self.mods), \
                         fw.padded_rows({(len(crecs), tp): row_map(spec["T"], tp, x.device)},
-                                       {tp: torch.tensor(spec["T"], dtype=torch.int32, device=x.device)}):   # linears and attention skip the padding rows
+                                       {tp: int32_on(spec["T"], x.device)}):   # linears and attention skip the padding rows
                     for i, (wires, kwires, _t, _l, _n) in enumerate(calls):
                         outs.append(self.mods[i](*[resolve(w) for w in wires], **{k: resolve(w) for k, w in kwires}))
                 g, lens = len(crecs), spec["T"]
                 # per block output: which dimensions carry the token count, and the per-sample pieces
-                cut = []
+                cut, views = [], {}
                 for out, sh in zip(outs, shapes):
                     flat = self._flat(out)
                     if len(flat) != len(sh):
@@ -1211,17 +1219,25 @@ class TowerGraph:
                     cut.append(row)
                 if not ok:
                     break
+                flats = [self._flat(out) for out in outs]
                 for t, rec in enumerate(crecs):
                     n_t, mine = lens[t], []
-                    for out, row in zip(outs, cut):
+                    for out, fl, row in zip(outs, flats, cut):
                         flat = []
-                        for o, c_ in zip(self._flat(out), row):
+                        for o, c_ in zip(fl, row):
                             if c_ is None:
                                 flat.append(o)
+                                continue
+                            # a tensor that several blocks return (T5: every block hands the position bias on) is cut ONCE per sample,
+                            # and the sample is handed the same view each time: enter_group stacks it once per group for the same reason
+                            hit = views.get((id(o), t))
+                            if hit is not None and hit[0] is o and hit[2] == c_[1]:
+                                flat.append(hit[1])
                                 continue
                             v = c_[0][t] if c_[0] is not None else o
                             for d in c_[1]:
                                 v = v.narrow(d, 0, n_t)
+                            views[(id(o), t)] = (o, v, c_[1])
                             flat.append(v)
                         mine.append(self._like(out, flat))
                     done[rec["j"]] = {"outs": mine, "args": rec["args"], "kwargs": rec["kwargs"], "key": rec["key"]}
@@ -1747,14 +1763,23 @@ def _capture_merged(model, batches, module_to_process, forward_to_cache, lora_mo
             # the preceding walk -- but with the linears skipping the padding rows that tail is shorter and the host shows: 479 -> 463 ms,
             # same box, tools/ragged_prof.py)
             return None
-        if defer and any(not t.memo_serves and t.path not in FROZEN_TOWERS for t in towers):
-            # ragged batches and a PRUNED tower on the way whose outputs are not remembered (the decoder's phase: 24 encoder blocks):
-            # handing the groups their blocks' outputs means cutting the padded pass per sample and stacking per group again, per
-            # block and output -- measured 145-173 ms for that phase against 87 on the per-sample route.  A frozen tower alone (the
-            # encoder's phase: the Q-Former's 12 single-output layers) is the case that pays: 55-59 against 100 ms.
+        pruned_on_the_way = [t for t in towers if not t.memo_serves and t.path not in FROZEN_TOWERS]
+        if defer and pruned_on_the_way and (os.environ.get("VLMC_CAPTURE_MERGED_PRUNED", "1") == "0" or
+                                            not all(t.predicted for t in pruned_on_the_way)):
+            # ragged batches and a PRUNED tower on the way whose outputs are not remembered (the decoder's phase: 24 encoder blocks).
+            # Round 5 measured 145-173 ms for that phase on this route against 87 per sample: every group's forward ran twice (postponed
+            # at the tower, repeated), and handing a group its blocks' outputs stacked the samples' pieces per block and output -- the
+            # position bias 24 times.  Since round 6 the tower runs BEFORE the forwards on its remembered block-0 arguments
+            # (run_predicted, as on the per-sample route) and a tensor several blocks hand on is cut and stacked once.  Without
+            # remembered arguments (a tower whose own phase did not run through this module): the per-sample route.
             return None
         flags = []                                               # device-side verdicts, read once at the end (no wait per forward)
         with torch.no_grad(), forward.invariant_linears(all_linears(model, proxy_cache), roots=[b for t in towers for b in t.mods]):
+            everyone = list(range(len(mine)))
+            if defer:
+                for t in pruned_on_the_way:
+                    t.run_predicted(everyone)                   # (towers whose wiring a previous prune traced: now; else after the scout has traced it)
+            _CTX.keep_ready = defer
             one = run([scout], alone=defer)                     # one sample alone: the shapes of a batch-1 call, and the bits to hold the merge to
             for _ in range(len(towers) + 1):                     # (a tower whose wiring an earlier phase traced postpones this forward too)
                 if one != "later":
@@ -1763,8 +1788,12 @@ def _capture_merged(model, batches, module_to_process, forward_to_cache, lora_mo
                     if t.deferred:
                         t.run_deferred()
                 one = run([scout], alone=True)
+            _CTX.keep_ready = False
             if one is None or one == "later" or not isinstance(one[0], torch.Tensor) or one[0].dim() < 2:
                 return None
+            if defer:
+                for t in pruned_on_the_way:
+                    t.run_predicted(everyone)                   # (no-op for the samples that have their outputs)
             names1 = tensors_of(one)
             batched = None                                       # name -> the per-sample batch extent of a tensor that carries the batch dimension, else 0
             rows = max(1, one[0].numel() // max(1, one[0].shape[-1]))
@@ -1857,7 +1886,7 @@ def _capture_merged(model, batches, module_to_process, forward_to_cache, lora_mo
         return None                                             # (a kwarg the reference's key list names is missing: its path)
     finally:
         _CTX.capture_group = _CTX.capture_sample = None
-        _CTX.group_defer = False
+        _CTX.group_defer = _CTX.keep_ready = False
         layers[0] = layers[0].module
         for blocks, i, orig in undo:
             tg = blocks[i].__dict__.get("_tower")
@@ -2233,14 +2262,26 @@ def plan_padded(cur_in, caches, n_samples, group_max):
         if sp is not None and sp == tp:
             sp += 8                                                   # the hooks tell the two kinds of input apart by their padded length
         dev = x0.device
-        lengths = {tp: torch.tensor([T[j] for j in chunk], dtype=torch.int32, device=dev)}
+        lengths = {tp: int32_on([T[j] for j in chunk], dev)}
         rows = {(len(chunk), tp): row_map([T[j] for j in chunk], tp, dev)}
         if sp is not None:
-            lengths[sp] = torch.tensor([S[j] for j in chunk], dtype=torch.int32, device=dev)
+            lengths[sp] = int32_on([S[j] for j in chunk], dev)
             rows[(len(chunk), sp)] = row_map([S[j] for j in chunk], sp, dev)
         out.append((chunk, {"T": [T[j] for j in chunk], "S": [S[j] for j in chunk], "tp": tp, "sp": sp, "lengths": lengths,
                             "rows": rows}))
     return out
+
+
+def int32_on(values, device):
+    """A small host list (token counts, a row map) as an int32 tensor on `device` WITHOUT draining the GPU: `torch.tensor(.., device=)`
+    copies from pageable memory and synchronises the stream -- in the middle of a capture phase the host then waits for the whole walk
+    before it and issues the rest of the phase against an idle GPU (tools/find_syncs.py, tools/phase_timeline.py).  Pinned staging
+    buffer, asynchronous copy; the caching host allocator keeps the buffer until the copy has run."""
+    t = torch.as_tensor(values, dtype=torch.int32)
+    device = torch.device(device)
+    if device.type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
 
 
 def row_map(lengths, padded, device):
@@ -2253,7 +2294,7 @@ def row_map(lengths, padded, device):
     real = tok < ln[:, None]
     flat = (np.arange(len(ln), dtype=np.int64)[:, None] * padded + tok)
     order = np.concatenate([flat[real], flat[~real]]).astype(np.int32)
-    return torch.from_numpy(order).to(device), int(real.sum())
+    return int32_on(order, device), int(real.sum())
 
 
 def _pad_inputs(xs, tp):
