@@ -193,7 +193,7 @@ class LaunchProbe:
     def summary(self, kind):
         evs = self.records.get(kind, [])
         ms = sum(self.hipev.elapsed_ms(a, b) for a, b, _, _ in evs)
-        return ms, sum(u for _, _, u, _ in evs), sum(n for _, _, _, n in evs)
+        return ms, sum(float(u) for _, _, u, _ in evs), sum(n for _, _, _, n in evs)
 
 
 def install_probes(probe):
@@ -203,7 +203,9 @@ def install_probes(probe):
 
     def sq_bytes(xs, outs=None, call_tokens=None):
         if call_tokens is not None and any(ct is not None for ct in call_tokens):     # a padded group of ragged samples: only a sample's own rows are read
-            return sum((int(ct.sum()) if ct is not None else x.shape[0] * x.shape[1]) * x.shape[-1] * x.element_size() + x.shape[0] * x.shape[-1] * 4
+            # (the token counts live on the device: summed THERE and read after the timed region -- `int(ct.sum())` here made the host
+            # wait for the GPU at every probed launch of a walk, and the capture phase behind it started without the host's lead)
+            return sum((ct.sum(dtype=torch.float64) if ct is not None else x.shape[0] * x.shape[1]) * (x.shape[-1] * x.element_size()) + x.shape[0] * x.shape[-1] * 4
                        for x, ct in zip(xs, call_tokens))
         return sum(x.numel() * x.element_size() + x.shape[0] * x.shape[-1] * 4 for x in xs)
 

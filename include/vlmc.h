@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VLMC_ABI_VERSION 19
+#define VLMC_ABI_VERSION 20
 
 #define VLMC_OK 0
 #define VLMC_EINVAL (-1)     /* bad argument (shape, dtype, alignment, null pointer) */
@@ -265,6 +265,17 @@ int vlmc_linear_fwd_group(const void *X, const vlmc_linear_job *jobs /* host arr
  * Padding rows of X are neither loaded nor multiplied; the tiles are cut from the n_real compacted rows.  1 <= n_real <= M. */
 int vlmc_linear_fwd_rows(const void *X, const vlmc_linear_job *jobs /* host array */, int n_jobs /* 1..4 */, int dtype, int64_t M,
                          int64_t K, int64_t ldx, const int32_t *rowmap, int64_t n_real, void *stream);
+
+/* The same, fp32 only (the reference's fp32 Q-Former, blip2_t5_instruct.py:143-175), with SEPARATE row lists for X and Y: the input is a
+ * token slice of a padded stack -- `attention_output[:, query_length:, :]` of a BERT layer, Qformer.py:434-466 -- read in place through its
+ * base rows, the output a compact [samples, slice tokens, N] tensor:
+ *     Y[y_rows[i], :] = X[x_rows[i], :] W^T + bias   for i < n_real   (accumulated exactly as by vlmc_linear_fwd with VLMC_F32: same bits)
+ *     Y[y_rows[i], :] = 0                             for n_real <= i < n_real + n_zero
+ * x_rows: device int32 [n_real] (row stride ldx); y_rows: device int32 [n_real + n_zero] (row stride ldy).  vlmc_linear_fwd_rows takes
+ * VLMC_F32 as well (x_rows == y_rows == rowmap, one launch per job). */
+int vlmc_linear_fwd_gather(const void *X, const void *W, const void *bias, int dtype /* VLMC_F32 */, int64_t N, int64_t K, int64_t ldx,
+                           int64_t ldw, void *Y, int64_t ldy, const int32_t *x_rows, const int32_t *y_rows, int64_t n_real, int64_t n_zero,
+                           void *stream);
 
 
 /* ---- batched attention products of the calibration forward (MFMA) ---------------------------------

@@ -446,6 +446,98 @@ def test_linear_fwd_fp32_matches_fp64_and_is_batch_invariant(M, N, K, bias):
             assert torch.equal(ops.linear_fwd(x3, w, b).reshape(M, N), y)
 
 
+@pytest.mark.parametrize("lengths,tpad,K,N", [([5, 1, 9, 3], 9, 64, 48), ([40, 104, 7, 160, 33, 99, 128, 61], 160, 768, 768),
+                                               ([100] * 3 + [17] * 40 + [160], 161, 768, 3072), ([3, 2], 4, 3072, 768)])
+def test_linear_fwd_rows_fp32_has_the_bits_of_each_samples_own_forward(lengths, tpad, K, N):
+    """The fp32 row-mapped launch (the Q-Former's padded stack, blip2_t5_instruct.py:143-175) == `linear_fwd` of every sample alone
+    on its own rows, bit for bit; padding rows of Y are +0 whatever the padding rows of x hold."""
+    from vlmc import ops
+    x, rowmap, n_real = _ragged_case(torch.float32, lengths, tpad, K, seed=len(lengths) + K)
+    g = torch.Generator(device=DEV).manual_seed(N)
+    w = torch.randn(N, K, generator=g, device=DEV) * 0.05
+    b = torch.randn(N, generator=g, device=DEV) * 0.1
+    for bias in (b, None):
+        y = ops.linear_fwd_rows(x, [w], [bias], rowmap, n_real)[0]
+        assert y.shape == (len(lengths), tpad, N) and y.dtype == torch.float32
+        for s_ in sorted(set(range(0, len(lengths), max(1, len(lengths) // 7))) | {len(lengths) - 1}):
+            t = lengths[s_]
+            alone = ops.linear_fwd(x[s_:s_ + 1, :t].contiguous(), w, bias)
+            assert torch.equal(y[s_, :t].view(torch.int32), alone[0].view(torch.int32)), s_
+            assert bool((y[s_, t:].view(torch.int32) == 0).all()), "a padding row of Y is not +0"
+    two = ops.linear_fwd_rows(x, [w, w[: N // 2]], [b, None], rowmap, n_real)
+    assert torch.equal(two[0], ops.linear_fwd_rows(x, [w], [b], rowmap, n_real)[0]) and two[1].shape[-1] == N // 2
+
+
+@pytest.mark.parametrize("lengths,P,a,L,K,N", [([40, 104, 39, 160, 33, 99, 128, 61], 160, 32, 128, 768, 3072), ([40, 104, 39, 160, 33], 160, 0, 32, 768, 768),
+                                                ([5, 1, 9, 3], 9, 2, 7, 64, 48), ([2, 2, 2], 8, 4, 3, 40, 24)])
+def test_linear_fwd_gather_reads_a_token_slice_in_place(lengths, P, a, L, K, N):
+    """`attention_output[:, a:a + L]` of a padded stack (a BERT layer's text / query halves, Qformer.py:434-466) through
+    vlmc_linear_fwd_gather: every sample's real rows of the slice have the bits of `linear_fwd` on them alone, the compact output's other
+    rows are +0, NaN in the stack's padding rows reaches nothing; an empty slice (no real row at all) is all zeros."""
+    import numpy as np
+    from vlmc import ops
+    n = len(lengths)
+    g = torch.Generator(device=DEV).manual_seed(P + a + L)
+    base = torch.randn(n, P, K, generator=g, device=DEV) * 0.5 + 0.1
+    for j, t in enumerate(lengths):
+        base[j, t:] = float("nan")
+    w = torch.randn(N, K, generator=g, device=DEV) * 0.05
+    b = torch.randn(N, generator=g, device=DEV) * 0.1
+    x = base[:, a:a + L]
+    ln = np.clip(np.asarray(lengths) - a, 0, L)
+    tok = np.arange(L)[None, :]
+    real = tok < ln[:, None]
+    xi, yi = np.arange(n)[:, None] * P + tok, np.arange(n)[:, None] * L + tok
+    x_rows = torch.from_numpy(xi[real].astype(np.int32)).to(DEV)
+    y_rows = torch.from_numpy(np.concatenate([yi[real], yi[~real]]).astype(np.int32)).to(DEV)
+    y = ops.linear_fwd_gather(x, w, b, x_rows, y_rows, int(real.sum()), n * L, K).view(n, L, N)
+    for j in range(n):
+        t = int(ln[j])
+        if t:
+            alone = ops.linear_fwd(base[j:j + 1, a:a + t].contiguous(), w, b)
+            assert torch.equal(y[j, :t].view(torch.int32), alone[0].view(torch.int32)), j
+        assert bool((y[j, t:].view(torch.int32) == 0).all())
+    assert bool(torch.isfinite(y).all())
+
+
+def test_fp32_linears_of_a_padded_stack_take_their_real_rows_only():
+    """vlmc/forward.py inside `padded_rows`: the contiguous stack by its leading shape, a token slice by what it is a view of, the
+    slice's output and its GELU by the map they carry -- each equal to the full computation on the real rows, zero on the others."""
+    import torch.nn.functional as F
+    from vlmc import forward
+    lengths, P, q = [40, 104, 39, 160, 33, 99, 128, 61], 160, 32
+    n, d, h = len(lengths), 768, 3072
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(n, P, d, generator=g, device=DEV) * 0.5
+    for j, t in enumerate(lengths):
+        x[j, t:] = 0
+    lin = [torch.nn.Linear(d, d).to(DEV), torch.nn.Linear(d, h).to(DEV), torch.nn.Linear(h, d).to(DEV)]
+    import numpy as np
+    ln = np.asarray(lengths)
+    tok = np.arange(P)[None, :]
+    real = tok < ln[:, None]
+    flat = np.arange(n)[:, None] * P + tok
+    rowmap = torch.from_numpy(np.concatenate([flat[real], flat[~real]]).astype(np.int32)).to(DEV)
+
+    def block(x):
+        a = lin[0](x)                                     # the whole stack
+        text = lin[2](F.gelu(lin[1](a[:, q:, :])))        # intermediate / output of the text half
+        query = lin[2](F.gelu(lin[1](a[:, :q, :])))       # .. of the query half (no padding)
+        return a, text, query
+    before = dict(forward.stats)
+    with torch.no_grad(), forward.invariant_linears(lin):
+        full = block(x)
+        with forward.padded_rows({(n, P): (rowmap, int(real.sum()))}, None, {(n, P): tuple(lengths)}):
+            part = block(x)
+    assert forward.stats["kernel_slices"] - before["kernel_slices"] == 2
+    assert forward.stats["kernel_rows"] - before["kernel_rows"] == 4        # the stack, two slices, the text half's tagged output (the query half's: all rows)
+    for j, t in enumerate(lengths):
+        assert torch.equal(part[0][j, :t], full[0][j, :t]) and bool((part[0][j, t:] == 0).all())
+        tt = max(0, min(t - q, P - q))
+        assert torch.equal(part[1][j, :tt], full[1][j, :tt]) and bool((part[1][j, tt:] == 0).all())
+    assert torch.equal(part[2], full[2])
+
+
 @pytest.mark.parametrize("B,H,Tq,Tk,d", [(3, 12, 45, 45, 64), (2, 12, 32, 257, 64), (1, 4, 7, 5, 16), (5, 12, 160, 160, 64)])
 def test_attn_matmul_fp32_both_products_match_fp64_and_are_batch_invariant(B, H, Tq, Tk, d):
     """`torch.matmul(q, k.transpose(-1, -2))` and `torch.matmul(probs, v)` of the fp32 Q-Former (Qformer.py:201,246) through permuted views."""

@@ -24,7 +24,7 @@ phase = ["-"]
 def show(message, category, filename, lineno, file=None, line=None):
     if "synchroniz" not in str(message):
         return
-    st = [f for f in traceback.extract_stack()[:-1] if "vlm-compression_amd" in f.filename or "tools/" in f.filename]
+    st = [f for f in traceback.extract_stack()[:-1] if "vlm-compression_amd" in f.filename or "tools/" in f.filename or f.filename.endswith("bench.py")]
     key = " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}({f.name})" for f in reversed(st[-5:]))
     sites[(phase[0], key)] += 1
 
@@ -46,8 +46,22 @@ def wrap(name, fn, pos):
 
 cal.capture_block_inputs = wrap("capture", orig_capture, 3)
 cal.walk_blocks = wrap("walk", orig_walk, 4)
-torch.cuda.set_sync_debug_mode("warn")
-dt, model, _ = synthetic.time_prune(dev, n_samples=128, model=model, batches=batches)
-torch.cuda.set_sync_debug_mode("default")
+if len(sys.argv) > 1 and sys.argv[1] == "bench":          # the bench's own step, with its launch probes armed
+    sys.path.insert(0, ROOT)
+    import bench
+    del model
+    job = bench.PruneJob(dev, reference_ops=True, ragged=True)
+    probe = bench.LaunchProbe(4)
+    bench.install_probes(probe)
+    for _ in range(2):
+        job.step()
+    probe.active = True
+    torch.cuda.set_sync_debug_mode("warn")
+    job.step()
+    torch.cuda.set_sync_debug_mode("default")
+else:
+    torch.cuda.set_sync_debug_mode("warn")
+    dt, model, _ = synthetic.time_prune(dev, n_samples=128, model=model, batches=batches)
+    torch.cuda.set_sync_debug_mode("default")
 for (ph, key), n in sorted(sites.items()):
     print(f"{ph:36s} x{n:4d}  {key}")

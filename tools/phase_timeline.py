@@ -52,3 +52,4 @@ for rep in range(3):
         gp = g - (prev if prev is not None else 0.0)
         print(f"{name:42s} {(t0 - h0) * 1e3:8.1f} {(t1 - h0) * 1e3:9.1f} {(t1 - t0) * 1e3:8.1f} {g:9.1f} {gp:7.1f} {g - (t1 - h0) * 1e3:16.1f}")
         prev = g
+    print("graph_stats", {k: v for k, v in cal.graph_stats.items() if v})

@@ -29,6 +29,10 @@ struct F32Gemm {
     int64_t batchA, batchB, batchC;                  // element strides between the matrices of a batch (grid z)
     int64_t b1, batchA1, batchB1, batchC1;           // z = z0 * b1 + z1: second batch level (heads): strides of z1; b1 = 1: none
     int M, N, K;
+    // a ROW MAP (vlmc_linear_fwd_rows / vlmc_linear_fwd_gather, one matrix): row m of the product (m < M) is row xrows[m] of A and row
+    // yrows[m] of C; rows yrows[M .. M + n_zero) of C are written as zeros by gridDim.y's extra blocks.  NULL: row m is row m.
+    const int32_t *xrows, *yrows;
+    int n_zero, my;              // my: blocks along y that own products (the rest clear rows)
 };
 
 // TW = MFMA tiles (16 x 16) per wave along m and along n: the workgroup's tile is 32 TW x 32 TW (four waves, 2 x 2).  An output element
@@ -50,6 +54,18 @@ __global__ __launch_bounds__(256, (TW == 4 ? 3 : 4)) void gemm_f32_kernel(const 
     extern __shared__ float fsh[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * kFT, n0 = blockIdx.x * kFT;
+    if (g.yrows != nullptr && int(blockIdx.y) >= g.my) {
+        // the padding rows of Y: zeros (a padded group of ragged samples -- they stay zero through the block's row-wise ops)
+        const int z0r = (int(blockIdx.y) - g.my) * kFT;
+        constexpr int TPZ = kFT / 4;                                           // threads per row, four columns each
+        for (int r = threadIdx.x / TPZ; r < kFT; r += 256 / TPZ) {
+            const int z = z0r + r, n = n0 + 4 * (threadIdx.x % TPZ);
+            if (z >= g.n_zero || n >= g.N) continue;
+            float *dst = g.C + int64_t(g.yrows[g.M + z]) * g.ldc + n;
+            for (int t = 0; t < 4 && n + t < g.N; ++t) dst[t] = 0.f;
+        }
+        return;
+    }
     const int64_t z0 = blockIdx.z / g.b1, z1 = blockIdx.z - z0 * g.b1;
     const float *A = g.A + z0 * g.batchA + z1 * g.batchA1, *B = g.B + z0 * g.batchB + z1 * g.batchB1;
     float *C = g.C + z0 * g.batchC + z1 * g.batchC1;
@@ -57,14 +73,20 @@ __global__ __launch_bounds__(256, (TW == 4 ? 3 : 4)) void gemm_f32_kernel(const 
     const bool b_kcontig = g.sbk == 1;
     const bool b_vec = (b_kcontig ? (g.sbn & 3) == 0 : (g.sbk & 3) == 0 && g.sbn == 1) && (reinterpret_cast<uintptr_t>(B) & 15u) == 0;
     f32x4v_t sa[4], sb[4];
+    int64_t arow[4];                                                           // this thread's four rows of A (through the row map)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + (tid / TPR) + RSTEP * i;
+        arow[i] = row < g.M ? (g.xrows != nullptr ? int64_t(g.xrows[row]) : int64_t(row)) : -1;
+    }
     auto fetch = [&](int q) {
         const int k0 = q * kFK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = m0 + (tid / TPR) + RSTEP * i, k = k0 + 4 * (tid % TPR);
+            const int k = k0 + 4 * (tid % TPR);
             f32x4v_t v = {0.f, 0.f, 0.f, 0.f};
-            if (row < g.M && k < g.K) {
-                const float *src = A + int64_t(row) * g.lda + int64_t(k) * g.ska;
+            if (arow[i] >= 0 && k < g.K) {
+                const float *src = A + arow[i] * g.lda + int64_t(k) * g.ska;
                 if (a_vec && k + 3 < g.K) v = *reinterpret_cast<const f32x4v_t *>(src);
                 else
                     for (int t = 0; t < 4 && k + t < g.K; ++t) v[t] = src[int64_t(t) * g.ska];
@@ -163,7 +185,10 @@ __global__ __launch_bounds__(256, (TW == 4 ? 3 : 4)) void gemm_f32_kernel(const 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + (rb * TW + i) * 16 + 4 * (lane >> 4) + r;
-                if (m < g.M) C[int64_t(m) * g.ldc + n] = g.bias != nullptr ? ieee_add(acc[i][j][r], bv) : acc[i][j][r];
+                if (m < g.M) {
+                    const int64_t mp = g.yrows != nullptr ? int64_t(g.yrows[m]) : int64_t(m);
+                    C[mp * g.ldc + n] = g.bias != nullptr ? ieee_add(acc[i][j][r], bv) : acc[i][j][r];
+                }
             }
         }
 }
@@ -171,14 +196,17 @@ __global__ __launch_bounds__(256, (TW == 4 ? 3 : 4)) void gemm_f32_kernel(const 
 template <int TW> int launch_f32_tw(const char *what, const F32Gemm &g, int64_t batches, hipStream_t s) {
     constexpr int kFT = 32 * TW, kFLd = 128 / TW + 2;
     const size_t lds = size_t(2 * kFT * kFLd) * sizeof(float);          // 33-35 KB
-    const dim3 grid{unsigned((g.N + kFT - 1) / kFT), unsigned((g.M + kFT - 1) / kFT), unsigned(batches)};
-    VLMC_LAUNCH_TIMED_LDS(gemm_f32_kernel<TW>, grid, dim3(256), lds, s, g);
+    F32Gemm a = g;
+    a.my = (g.M + kFT - 1) / kFT;
+    const int zy = g.yrows != nullptr ? (g.n_zero + kFT - 1) / kFT : 0;
+    const dim3 grid{unsigned((g.N + kFT - 1) / kFT), unsigned(a.my + zy), unsigned(batches)};
+    VLMC_LAUNCH_TIMED_LDS(gemm_f32_kernel<TW>, grid, dim3(256), lds, s, a);
     VLMC_HIP_CHECK_LAUNCH(what);
     return VLMC_OK;
 }
 
 int launch_f32(const char *what, const F32Gemm &g, int64_t batches, hipStream_t s) {
-    if (g.M == 0 || g.N == 0 || batches == 0) return VLMC_OK;
+    if ((g.M == 0 && g.n_zero == 0) || g.N == 0 || batches == 0) return VLMC_OK;
     if (batches > 65535) {
         set_error("%s: more than 65535 matrices in a batch", what);
         return VLMC_EINVAL;
@@ -211,6 +239,24 @@ int linear_fwd_f32(const void *X, const void *W, const void *bias, int64_t M, in
     return launch_f32("vlmc_linear_fwd", g, 1, s);
 }
 
+// rows xrows[i] of X times W^T (+ bias) into rows yrows[i] of Y for i < n_real; rows yrows[n_real .. n_real + n_zero) of Y cleared
+// (called by vlmc_linear_fwd_rows for VLMC_F32 with xrows == yrows, and by vlmc_linear_fwd_gather)
+int linear_gather_f32(const void *X, const void *W, const void *bias, int64_t N, int64_t K, int64_t ldx, int64_t ldw, void *Y, int64_t ldy,
+                      const int32_t *xrows, const int32_t *yrows, int64_t n_real, int64_t n_zero, hipStream_t s) {
+    VLMC_REQUIRE(X && W && Y && yrows && (xrows || n_real == 0), "vlmc_linear_fwd_gather: null pointer");
+    VLMC_REQUIRE(n_real >= 0 && n_zero >= 0 && n_real + n_zero >= 1 && n_real + n_zero < (int64_t(1) << 31) && N > 0 && K > 0 &&
+                 N < (int64_t(1) << 31) && K < (int64_t(1) << 31), "vlmc_linear_fwd_gather: bad shape");
+    VLMC_REQUIRE(ldx >= K && ldw >= K && ldy >= N, "vlmc_linear_fwd_gather: a row stride is shorter than its row");
+    F32Gemm g{};
+    g.A = static_cast<const float *>(X), g.B = static_cast<const float *>(W), g.C = static_cast<float *>(Y);
+    g.bias = static_cast<const float *>(bias);
+    g.lda = ldx, g.ska = 1, g.sbn = ldw, g.sbk = 1, g.ldc = ldy;
+    g.b1 = 1;
+    g.M = int(n_real), g.N = int(N), g.K = int(K);
+    g.xrows = xrows, g.yrows = yrows, g.n_zero = int(n_zero);
+    return launch_f32("vlmc_linear_fwd_gather", g, 1, s);
+}
+
 // C[b0][b1] = A[b0][b1] @ B[b0][b1], fp32, operands through element strides (called by vlmc_attn_matmul for VLMC_F32)
 int attn_matmul_f32(const void *A, const void *B, void *C, int64_t batch0, int64_t batch1, int64_t M, int64_t N, int64_t K, int64_t sa_b0,
                     int64_t sa_b1, int64_t sa_m, int64_t sa_k, int64_t sb_b0, int64_t sb_b1, int64_t sb_k, int64_t sb_n, int64_t sc_b0,
@@ -230,3 +276,12 @@ int attn_matmul_f32(const void *A, const void *B, void *C, int64_t batch0, int64
 }
 
 }  // namespace vlmc
+
+using namespace vlmc;
+
+extern "C" int vlmc_linear_fwd_gather(const void *X, const void *W, const void *bias, int dtype, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
+                                      void *Y, int64_t ldy, const int32_t *x_rows, const int32_t *y_rows, int64_t n_real, int64_t n_zero,
+                                      void *stream) {
+    VLMC_REQUIRE(dtype == VLMC_F32, "vlmc_linear_fwd_gather: dtype must be VLMC_F32");
+    return linear_gather_f32(X, W, bias, N, K, ldx, ldw, Y, ldy, x_rows, y_rows, n_real, n_zero, as_stream(stream));
+}

@@ -1414,6 +1414,8 @@ static int linear_group_launch(const char *what, const void *X, const vlmc_linea
 namespace vlmc {
 int linear_fwd_f32(const void *X, const void *W, const void *bias, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, void *Y,
                    int64_t ldy, hipStream_t s);                                  // gemm_f32.hip
+int linear_gather_f32(const void *X, const void *W, const void *bias, int64_t N, int64_t K, int64_t ldx, int64_t ldw, void *Y, int64_t ldy,
+                      const int32_t *xrows, const int32_t *yrows, int64_t n_real, int64_t n_zero, hipStream_t s);
 }
 
 extern "C" int vlmc_linear_fwd(const void *X, const void *W, const void *bias, int dtype, int64_t M, int64_t N, int64_t K,
@@ -1431,6 +1433,16 @@ extern "C" int vlmc_linear_fwd_group(const void *X, const vlmc_linear_job *jobs,
 extern "C" int vlmc_linear_fwd_rows(const void *X, const vlmc_linear_job *jobs, int n_jobs, int dtype, int64_t M, int64_t K, int64_t ldx,
                                     const int32_t *rowmap, int64_t n_real, void *stream) {
     VLMC_REQUIRE(rowmap != nullptr, "vlmc_linear_fwd_rows: null row map");
+    if (dtype == VLMC_F32) {                                                      // (the fp32 Q-Former: one launch per member on fp32 matrix cores)
+        VLMC_REQUIRE(X && jobs && n_jobs >= 1 && n_jobs <= MAXG, "vlmc_linear_fwd_rows: null pointer or bad job count (1..%d)", MAXG);
+        VLMC_REQUIRE(M >= 1 && n_real >= 1 && n_real <= M, "vlmc_linear_fwd_rows: n_real must be in 1..M");
+        for (int g = 0; g < n_jobs; ++g) {
+            const vlmc_linear_job &j = jobs[g];
+            const int rc = linear_gather_f32(X, j.W, j.bias, j.N, K, ldx, j.ldw, j.Y, j.ldy, rowmap, rowmap, n_real, M - n_real, as_stream(stream));
+            if (rc != VLMC_OK) return rc;
+        }
+        return VLMC_OK;
+    }
     return linear_group_launch("vlmc_linear_fwd_rows", X, jobs, n_jobs, dtype, M, K, ldx, stream, rowmap, n_real);
 }
 

@@ -1043,6 +1043,26 @@ class TowerGraph:
         return True, out
 
     # -- tower batching ----------------------------------------------------------------------------------------------------
+    def _positional_names(self, n_args):
+        """Names of the parameters that arguments 1 .. n_args - 1 of a block call bind to (argument 0: the hidden states), or
+        None when the block's forward does not say (`*args`)."""
+        if n_args <= 1:
+            return ()
+        names = self.__dict__.get("_pos_names")
+        if names is None:
+            import inspect
+            try:
+                ps = list(inspect.signature(self.mods[0].forward).parameters.values())
+            except (TypeError, ValueError):
+                ps = []
+            names = []
+            for p_ in ps:
+                if p_.kind not in (p_.POSITIONAL_ONLY, p_.POSITIONAL_OR_KEYWORD):
+                    break
+                names.append(p_.name)
+            self.__dict__["_pos_names"] = names = tuple(names)
+        return names[1:n_args] if len(names) >= n_args else None
+
     @staticmethod
     def _ext(args, kwargs):
         out, seen = [], set()
@@ -1161,19 +1181,26 @@ class TowerGraph:
                 continue
             recs = sorted((r for k in keys for r in groups[k]), key=lambda r: r["j"])
             ctx = recs[0]["ctx"]
-            if any(len(r["args"]) != 1 or r["ctx"] != ctx for r in recs):
+            # arguments behind the hidden states that the model passes POSITIONALLY (a BERT layer of the Q-Former: Qformer.py:541-550)
+            # are padded under the names the block's forward gives them -- the names plan_padded knows masks and states by
+            n_pos = len(recs[0]["args"])
+            pos_names = self._positional_names(n_pos)
+            if pos_names is None or any(len(r["args"]) != n_pos or r["ctx"] != ctx or any(nm in r["kwargs"] for nm in pos_names) for r in recs):
                 continue
-            plan = plan_padded([r["args"][0] for r in recs], [r["kwargs"] for r in recs], len(recs), replay_group_size())
+            named = [dict(r["kwargs"], **dict(zip(pos_names, r["args"][1:]))) for r in recs]
+            plan = plan_padded([r["args"][0] for r in recs], named, len(recs), replay_group_size())
             n_ext = len(self._ext(recs[0]["args"], recs[0]["kwargs"]))
-            if plan is None or any(spec["sp"] is not None for _c, spec in plan):
-                continue                                                 # (a second ragged length -- cross-attention states -- is not handled here)
+            if plan is None or any(spec["sp"] is not None and len(set(spec["S"])) > 1 for _c, spec in plan):
+                continue                                                 # (a second RAGGED length -- cross-attention states -- is not handled here)
             done, ok = {}, True
             for chunk, spec in plan:
                 crecs = [recs[i] for i in chunk]
                 tp = spec["tp"] + 1 if spec["tp"] == t_s else spec["tp"]
                 x = _pad_inputs([r["args"][0] for r in crecs], tp)
-                kw = _pad_caches([r["kwargs"] for r in crecs], dict(spec, tp=tp))
-                ext = self._ext((x,), kw)
+                padded = _pad_caches([named[i] for i in chunk], dict(spec, tp=tp))
+                dev_ = x.device
+                kw = {k: padded[k] for k in crecs[0]["kwargs"]}
+                ext = self._ext((x,) + tuple(padded[nm] for nm in pos_names), kw)
                 if len(ext) != n_ext:
                     ok = False
                     break
@@ -1187,8 +1214,9 @@ class TowerGraph:
                     return w[1]
                 with torch.autocast(device_type="cuda", dtype=ctx[1], enabled=ctx[0]) if ctx[0] else contextlib.nullcontext(), \
                         fw.invariant_linears(self.linears, roots=self.mods), \
-                        fw.padded_rows({(len(crecs), tp): row_map(spec["T"], tp, x.device)},
-                                       {tp: int32_on(spec["T"], x.device)}):   # linears and attention skip the padding rows
+                        fw.padded_rows({(len(crecs), tp): row_map(spec["T"], tp, dev_)},
+                                       {tp: int32_on(spec["T"], dev_)},    # linears and attention skip the padding rows
+                                       {(len(crecs), tp): tuple(spec["T"])}):
                     for i, (wires, kwires, _t, _l, _n) in enumerate(calls):
                         outs.append(self.mods[i](*[resolve(w) for w in wires], **{k: resolve(w) for k, w in kwires}))
                 g, lens = len(crecs), spec["T"]
@@ -2273,15 +2301,8 @@ def plan_padded(cur_in, caches, n_samples, group_max):
 
 
 def int32_on(values, device):
-    """A small host list (token counts, a row map) as an int32 tensor on `device` WITHOUT draining the GPU: `torch.tensor(.., device=)`
-    copies from pageable memory and synchronises the stream -- in the middle of a capture phase the host then waits for the whole walk
-    before it and issues the rest of the phase against an idle GPU (tools/find_syncs.py, tools/phase_timeline.py).  Pinned staging
-    buffer, asynchronous copy; the caching host allocator keeps the buffer until the copy has run."""
-    t = torch.as_tensor(values, dtype=torch.int32)
-    device = torch.device(device)
-    if device.type != "cuda":
-        return t.to(device)
-    return t.pin_memory().to(device, non_blocking=True)
+    """A small host list (token counts, a row map) as an int32 device tensor without draining the GPU (vlmc/forward.py: int32_on)."""
+    return forward.int32_on(values, device)
 
 
 def row_map(lengths, padded, device):

@@ -74,6 +74,7 @@ SIGNATURES = {
     "vlmc_linear_fwd": (_i, [_p, _p, _p, _i, _i64, _i64, _i64, _i64, _i64, _p, _i64, _p]),
     "vlmc_linear_fwd_group": (_i, [_p, _p, _i, _i, _i64, _i64, _i64, _p]),
     "vlmc_linear_fwd_rows": (_i, [_p, _p, _i, _i, _i64, _i64, _i64, _p, _i64, _p]),
+    "vlmc_linear_fwd_gather": (_i, [_p, _p, _p, _i, _i64, _i64, _i64, _i64, _p, _i64, _p, _p, _i64, _i64, _p]),
     "vlmc_attn_matmul": (_i, [_p, _p, _p, _i] + [_i64] * 15 + [_p]),
     "vlmc_gelu": (_i, [_p, _p, _i64, _i, _i, _p]),
     "vlmc_row_mean": (_i, [_p, _i64, _i64, _i64, _p, _p]),

@@ -52,6 +52,8 @@ ROUTES = {
     "replay_equal_shapes": ({"VLMC_PAD_RAGGED": "0", "VLMC_TOWER_PAD": "0"}, "ragged samples forwarded in groups of equal shape, never padded"),
     "towers_per_length": ({"VLMC_TOWER_PAD": "0"}, "a finished tower runs one stacked pass per token count"),
     "wiring_per_signature": ({"VLMC_TOWER_SHARE_WIRING": "0"}, "a finished tower is traced once per exact argument signature"),
+    "capture_per_sample_behind_pruned": ({"VLMC_CAPTURE_MERGED_PRUNED": "0"}, "ragged batches with a pruned tower on the way (the decoder's phase) are captured one forward per sample"),
+    "rows_no_slices": ({"VLMC_ROW_SLICES": "0"}, "a token slice of a padded fp32 stack (the Q-Former's query / text halves) is multiplied with its padding rows"),
     "host_ctypes": ({"VLMC_FAST": "0"}, "every launch through the ctypes route (no compiled host path)"),
 }
 

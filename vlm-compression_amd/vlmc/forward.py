@@ -36,7 +36,8 @@ from . import ops
 _active = 0
 stats = {"kernel": 0, "library": 0, "grouped_launches": 0, "served_from_group": 0, "stash_dropped": 0, "attn_kernel": 0,
          "attn_library": 0, "mean_kernel": 0, "sdpa_kernel": 0, "sdpa_library": 0, "norm_kernel": 0, "softmax_kernel": 0,
-         "attn_fused": 0, "attn_chain_unfused": 0, "attn_fused_checks": 0, "gelu_kernel": 0, "kernel_rows": 0, "attn_fused_lens": 0}
+         "attn_fused": 0, "attn_chain_unfused": 0, "attn_fused_checks": 0, "gelu_kernel": 0, "kernel_rows": 0, "attn_fused_lens": 0,
+         "kernel_slices": 0}
 
 # first member of a learned sibling group -> tuple of weak references to all members, in call order
 _SIBLINGS = weakref.WeakKeyDictionary()
@@ -88,21 +89,73 @@ def row_map_enabled():
 
 
 _PAD_LENGTHS = None           # {padded tokens: int32 device tensor [samples]}: each sample's own token rows (the fused attention skips the rest)
+# fp32 blocks (the reference's Q-Former) that SLICE the padded stack along its tokens -- a BERT layer of the Q-Former sends
+# `attention_output[:, :query_length]` and `attention_output[:, query_length:]` through feed-forward halves of their own
+# (Qformer.py:434-466): `_PAD_HOST` {(samples, padded tokens): each sample's own token rows, on the host} lets a linear fed such a
+# view (recognised by what it is a view OF: `_slice_rows`) read the slice's real rows in place and write a compact
+# [samples, slice tokens, N] output, whose rows carry their map as an attribute of the tensor (`_vlmc_rows`) -- through `F.gelu`
+# too -- for the next linear: nothing is inferred from the shape of a derived tensor.
+_PAD_HOST = None
+_SLICES = None                # (samples, padded tokens, first token, slice tokens) -> (x_rows, y_rows, n_real, out_rows) of this context
+
+
+def int32_on(values, device):
+    """A small host array (token counts, a row map) as an int32 tensor on `device` WITHOUT draining the GPU: `torch.tensor(.., device=)`
+    copies from pageable memory and synchronises the stream -- in the middle of a capture phase the host then waits for the whole walk
+    before it and issues the rest of the phase against an idle GPU (tools/find_syncs.py, tools/phase_timeline.py).  Pinned staging
+    buffer, asynchronous copy; the caching host allocator keeps the buffer until the copy has run."""
+    t = torch.as_tensor(values, dtype=torch.int32)
+    device = torch.device(device)
+    if device.type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
 
 
 @contextlib.contextmanager
-def padded_rows(maps, lengths=None):
+def padded_rows(maps, lengths=None, host=None):
     """`maps`: {(samples, padded tokens): (int32 device tensor [samples * padded tokens], number of real rows)} or None;
-    `lengths`: {padded tokens: int32 device tensor [samples]} or None -- what the fused attention takes as q_len / k_len."""
-    global _ROW_MAPS, _PAD_LENGTHS
-    prev = _ROW_MAPS, _PAD_LENGTHS
+    `lengths`: {padded tokens: int32 device tensor [samples]} or None -- what the fused attention takes as q_len / k_len;
+    `host`: {(samples, padded tokens): sequence of each sample's own token rows} or None -- for token slices of the stack (fp32)."""
+    global _ROW_MAPS, _PAD_LENGTHS, _PAD_HOST, _SLICES
+    prev = _ROW_MAPS, _PAD_LENGTHS, _PAD_HOST, _SLICES
     on = row_map_enabled()
     _ROW_MAPS = maps if (maps and on) else None
     _PAD_LENGTHS = lengths if (lengths and on) else None
+    _PAD_HOST = host if (host and on and os.environ.get("VLMC_ROW_SLICES", "1") != "0") else None
+    _SLICES = {}
     try:
         yield
     finally:
-        _ROW_MAPS, _PAD_LENGTHS = prev
+        _ROW_MAPS, _PAD_LENGTHS, _PAD_HOST, _SLICES = prev
+
+
+def _slice_rows(x, K):
+    """(x_rows, y_rows, n_real, out_rows) for a [samples, L, K] view that IS rows [a, a + L) of every sample of a contiguous
+    [samples, P, K] tensor whose samples own their first T_j token rows (`_PAD_HOST[(samples, P)]`): sample j's rows a .. min(T_j, a + L)
+    of the base -- relative to the view's first element, pitch K -- and the compact output's rows; else None."""
+    base = x._base
+    if base is None or x.dim() != 3 or not base.is_contiguous() or x.stride(2) != 1 or x.stride(1) != K or x.stride(0) % K:
+        return None
+    n, L, _ = x.shape
+    P = x.stride(0) // K                                   # token rows per sample of what x is a view of: n * P rows of K in all
+    T = _PAD_HOST.get((n, P))
+    if T is None or L >= P or base.numel() != n * P * K:
+        return None
+    off = x.storage_offset() - base.storage_offset()
+    if off < 0 or off % K or off // K + L > P:
+        return None
+    a = off // K
+    ent = _SLICES.get((n, P, a, L))
+    if ent is None:
+        import numpy as np
+        ln = np.clip(np.asarray(T, dtype=np.int64) - a, 0, L)
+        tok = np.arange(L, dtype=np.int64)[None, :]
+        real = tok < ln[:, None]
+        xi = np.arange(n, dtype=np.int64)[:, None] * P + tok
+        yi = np.arange(n, dtype=np.int64)[:, None] * L + tok
+        ent = _SLICES[(n, P, a, L)] = (int32_on(xi[real].astype(np.int32), x.device),
+                                       int32_on(np.concatenate([yi[real], yi[~real]]).astype(np.int32), x.device), int(real.sum()), n * L)
+    return ent
 
 
 def _pad_lengths(q, k, adds):
@@ -121,17 +174,54 @@ def _rows_for(x):
     return _ROW_MAPS.get((x.shape[0], x.shape[1])) if x.dim() == 3 else None
 
 
+def _linear_rows_f32(x, weight, bias):
+    """An fp32 linear inside a padded group, over the real rows only: the input carries its row map (the output of a slice's linear, or
+    its GELU), has a padded leading shape (`_ROW_MAPS`), or is a token slice of a padded stack (`_slice_rows`); else None."""
+    if torch.is_autocast_enabled() or not f32_enabled() or type(x) is not torch.Tensor or not ops.linear_f32_supported(x, weight, bias):
+        return None
+    tag = getattr(x, "_vlmc_rows", None)
+    if tag is not None and x.dim() == 3 and x.is_contiguous() and tag[0].shape[0] == x.shape[0] * x.shape[1]:
+        rm = tag
+    else:
+        rm = _rows_for(x) if (tag is None and x.is_contiguous()) else None
+    if rm is not None:
+        y = ops.linear_fwd_rows(x, [weight], [bias], rm[0], rm[1])[0]
+        if tag is not None:
+            y._vlmc_rows = tag
+        stats["kernel"] += 1
+        stats["kernel_rows"] += 1
+        return y
+    if _PAD_HOST is None or tag is not None:
+        return None
+    sl = _slice_rows(x, weight.shape[1])
+    if sl is None:
+        return None
+    x_rows, y_rows, n_real, out_rows = sl
+    y = ops.linear_fwd_gather(x, weight, bias, x_rows, y_rows, n_real, out_rows, weight.shape[1]).view(x.shape[0], x.shape[1], weight.shape[0])
+    if n_real < out_rows:
+        y._vlmc_rows = (y_rows, n_real)              # (a compact [samples, L, N] stack: its row map IS y_rows -- real rows first)
+    stats["kernel"] += 1
+    stats["kernel_rows"] += 1
+    stats["kernel_slices"] += 1
+    return y
+
+
 def linear(x, weight, bias=None):
     """`F.linear` for a calibration forward: the invariant kernel when the replay engine asked for it and the call fits."""
     if _active and not torch.is_grad_enabled() and weight.is_cuda:
         if _ROW_MAPS is not None:
-            rm = _rows_for(x)
-            if rm is not None:
-                p = _prepare(x, weight, bias)
-                if p is not None:
-                    stats["kernel"] += 1
-                    stats["kernel_rows"] += 1
-                    return ops.linear_fwd_rows(p[0], [weight], [p[1]], rm[0], rm[1])[0]
+            if weight.dtype is torch.float32:
+                y = _linear_rows_f32(x, weight, bias)
+                if y is not None:
+                    return y
+            else:
+                rm = _rows_for(x)
+                if rm is not None:
+                    p = _prepare(x, weight, bias)
+                    if p is not None:
+                        stats["kernel"] += 1
+                        stats["kernel_rows"] += 1
+                        return ops.linear_fwd_rows(p[0], [weight], [p[1]], rm[0], rm[1])[0]
         if not torch.is_autocast_enabled():
             y = ops.linear_fwd(x, weight, bias, _try=True) if (weight.dtype is not torch.float32 or f32_enabled()) else None   # (None: not one it takes)
             if y is not None:
@@ -721,7 +811,11 @@ def _make_gelu(orig):
                     not torch.is_grad_enabled() and not args and \
                     not (set(kw) - {"approximate"}) and kw.get("approximate", "none") in ("none", "tanh") and x.numel() > 0:
                 stats["gelu_kernel"] += 1
-                return ops.gelu(x, kw.get("approximate", "none"))
+                y = ops.gelu(x, kw.get("approximate", "none"))
+                tag = getattr(x, "_vlmc_rows", None)
+                if tag is not None and y.shape == x.shape:           # (a compact slice's output: GELU keeps rows, gelu(0) = 0)
+                    y._vlmc_rows = tag
+                return y
         return orig(x, *args, **kw)
     return gelu
 

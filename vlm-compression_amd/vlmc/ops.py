@@ -232,12 +232,13 @@ def linear_fwd_rows(x: torch.Tensor, weights, biases, rowmap: torch.Tensor, n_re
     if not 1 <= n <= LINEAR_GROUP_MAX or len(biases) != n:
         raise ValueError(f"linear_fwd_rows takes 1..{LINEAR_GROUP_MAX} weights and as many biases")
     _need_gpu(x, rowmap, *weights, *[b for b in biases if b is not None])
+    f32 = x.dtype is torch.float32
     for w, b in zip(weights, biases):
-        if not linear_fwd_supported(x, w, b):
-            raise TypeError("vlmc.linear_fwd_rows: fp16/bf16 tensors of one dtype with in_features % 8 == 0 expected")
+        if not (linear_f32_supported(x, w, b) if f32 else linear_fwd_supported(x, w, b)):
+            raise TypeError("vlmc.linear_fwd_rows: fp16/bf16 tensors of one dtype with in_features % 8 == 0, or fp32 tensors, expected")
     K = weights[0].shape[1]
     x2 = x.reshape(-1, K)
-    if x2.stride(1) != 1 or x2.stride(0) % 8 != 0 or x2.stride(0) < K or x2.data_ptr() % 16 != 0:
+    if x2.stride(1) != 1 or x2.stride(0) < K or (not f32 and (x2.stride(0) % 8 != 0 or x2.data_ptr() % 16 != 0)):
         x2 = x2.contiguous()
     M = x2.shape[0]
     if rowmap.dtype != torch.int32 or rowmap.dim() != 1 or rowmap.shape[0] != M or not rowmap.is_contiguous() or not 1 <= n_real <= M:
@@ -252,6 +253,29 @@ def linear_fwd_rows(x: torch.Tensor, weights, biases, rowmap: torch.Tensor, n_re
                                                 _stream()))
     lead = x.shape[:-1]
     return [y.reshape(*lead, y.shape[1]) for y in outs]
+
+
+def linear_fwd_gather(x: torch.Tensor, weight: torch.Tensor, bias, x_rows: torch.Tensor, y_rows: torch.Tensor, n_real: int, out_rows: int,
+                      pitch: int) -> torch.Tensor:
+    """fp32: y[y_rows[i]] = x_base[x_rows[i]] @ weight.T + bias for i < n_real, y[y_rows[i]] = 0 for the other entries of y_rows;
+    y is a fresh [out_rows, N] tensor every row of which y_rows names once.  `x` is any fp32 CUDA tensor whose element (row r, k) lies
+    at x.data_ptr() + (r * pitch + k) * 4 for the rows x_rows names -- a token slice of a padded stack, read in place
+    (include/vlmc.h: vlmc_linear_fwd_gather).  A computed row has the bits `linear_fwd` gives it."""
+    _need_gpu(x, weight, x_rows, y_rows, *([bias] if bias is not None else []))
+    N, K = weight.shape
+    if x.dtype is not torch.float32 or weight.dtype is not torch.float32 or weight.stride(1) != 1 or weight.stride(0) < K or pitch < K or \
+            (bias is not None and (bias.dtype is not torch.float32 or not bias.is_contiguous() or bias.shape != (N,))):
+        raise TypeError("vlmc.linear_fwd_gather: fp32 x, weight [N, K] with contiguous rows and a contiguous fp32 bias expected")
+    for t, n_ in ((x_rows, n_real), (y_rows, out_rows)):
+        if t.dtype != torch.int32 or t.dim() != 1 or not t.is_contiguous() or t.shape[0] != n_:
+            raise ValueError("vlmc.linear_fwd_gather: x_rows int32 [n_real], y_rows int32 [out_rows], contiguous")
+    if not 0 <= n_real <= out_rows or out_rows < 1:
+        raise ValueError("vlmc.linear_fwd_gather: 0 <= n_real <= out_rows")
+    y = torch.empty((out_rows, N), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().vlmc_linear_fwd_gather(x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None, _lib.F32, N, K,
+                                                  pitch, weight.stride(0), y.data_ptr(), N, x_rows.data_ptr(), y_rows.data_ptr(), int(n_real),
+                                                  int(out_rows - n_real), _stream()))
+    return y
 
 
 _16BIT = (torch.float16, torch.bfloat16)
