@@ -64,9 +64,10 @@ def parse():
     ap.add_argument("--kernel-pass", default="auto", choices=["auto", "0", "1"],
                     help="also time the statistics + select kernels alone on resident activations (auto: only at N=1)")
     ap.add_argument("--kernel-steps", type=int, default=10)
-    ap.add_argument("--event-stride", type=int, default=4,
+    ap.add_argument("--event-stride", type=int, default=5,
                     help="HIP events on every N-th launch of a timed kernel (1 = every launch; a timed launch idles the "
-                         "GPU for ~10 us)")
+                         "GPU for ~10 us).  Not 3, 4 or 7: a block pass is 3 (statistics pass, its tail skipped) + 4 GEMM launches of four "
+                         "shapes, and a stride that divides the period samples ONE shape of the four all through a tower")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds before self-launched ranks are killed")
     ap.add_argument("--invariance", default="auto", choices=["auto", "0", "1"],
                     help="also run the headline's prune once as the reference's one-sample-per-forward loop and count the mask bits "

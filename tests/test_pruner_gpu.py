@@ -366,7 +366,7 @@ def test_capture_phase_runs_again_when_a_remembered_input_was_not_the_one_fed(mo
         real_begin(self, mode)
         if mode == "replay" and self.entries and not tampered:
             first = self.entries[min(self.entries)]
-            first[0][0][0].add_(1)                      # the remembered block-0 input of forward 0
+            first[0][0][0] = first[0][0][0] + 1         # the remembered block-0 input of forward 0 is another tensor than the one fed
             tampered.append(self)
     monkeypatch.setattr(cal.TowerMemo, "begin", begin)
     before = cal.graph_stats.get("later_failed", 0)
@@ -380,6 +380,19 @@ def test_capture_phase_runs_again_when_a_remembered_input_was_not_the_one_fed(mo
     got = state(H.run_pruner("fp32_r50", "cuda:0")[0])
     assert tampered and cal.graph_stats.get("later_failed", 0) == before + 1 and cal.graph_stats["memo_misses"] > m0
     assert all(torch.equal(want[k], got[k]) for k in want)
+    # the memo keeps the tensors themselves, not copies (TowerMemo.keep): one that was written into since is refused at once
+    # (not tampered with here through a whole prune: the toy's block-0 input IS the calibration image, and writing into the record
+    # would write into the data)
+    t = torch.randn(4, 8, device="cuda:0")
+    kept = cal.TowerMemo.keep(t[1:3])
+    rec = cal.TowerMemo._snapshot([t], {"m": t[0]})
+    assert kept.data_ptr() == t[1:3].data_ptr() and cal.TowerMemo.fresh(kept) and cal.TowerMemo._same(rec, [t.clone()], {"m": t[0].clone()})
+    t[0].add_(1)                                        # (a view shares its base's version counter)
+    assert not cal.TowerMemo.fresh(kept) and not cal.TowerMemo._same(rec, [t.clone()], {"m": t[0].clone()})
+    monkeypatch.setenv("VLMC_MEMO_COPY", "1")
+    kept = cal.TowerMemo.keep(t)
+    t.add_(1)
+    assert cal.TowerMemo.fresh(kept) and kept.data_ptr() != t.data_ptr()
 
 
 def test_graphed_module_proxy_replays_identically_and_falls_back(monkeypatch):

@@ -273,8 +273,23 @@ class TowerMemo:
         return on, (torch.get_autocast_gpu_dtype() if on else None)
 
     @staticmethod
+    def keep(v):
+        """A tensor the memo remembers: the tensor ITSELF with the version it has now (`fresh` refuses it once somebody wrote into it),
+        not a copy -- the copies were 1 700 launches and 190 MB of traffic per prune for the Q-Former's arguments alone (every sample's
+        image states), and the walk's inputs / a seeded tower's outputs have always been kept this way.  `VLMC_MEMO_COPY=1`: copies."""
+        d = v.detach()
+        if os.environ.get("VLMC_MEMO_COPY", "0") == "1":
+            return d.clone()
+        d._vlmc_version = d._version                      # (the alias shares the version counter of what it was detached from)
+        return d
+
+    @staticmethod
+    def fresh(t):
+        return getattr(t, "_vlmc_version", None) in (None, t._version)
+
+    @staticmethod
     def _snapshot(args, kwargs):
-        snap = lambda v: v.detach().clone() if isinstance(v, torch.Tensor) else v
+        snap = lambda v: TowerMemo.keep(v) if isinstance(v, torch.Tensor) else v
         return [snap(a) for a in args], {k: snap(v) for k, v in kwargs.items()}, TowerMemo.context()
 
     @staticmethod
@@ -286,7 +301,7 @@ class TowerMemo:
             if isinstance(r, torch.Tensor) != isinstance(v, torch.Tensor):
                 return False
             if isinstance(r, torch.Tensor):
-                if not _bits_equal(r, v):
+                if not TowerMemo.fresh(r) or not _bits_equal(r, v):
                     return False
             elif r is not v and r != v:
                 return False
@@ -325,12 +340,13 @@ class TowerMemo:
         parts = x.split(b, dim=0)
         for t, ((rec, _out), part) in enumerate(zip(ents, parts)):
             rargs, rkw, ctx = rec
-            if ctx != ctx0 or len(rargs) != len(args) or sorted(rkw) != sorted(rkw0) or not _bits_equal(rargs[0], part):
+            if ctx != ctx0 or len(rargs) != len(args) or sorted(rkw) != sorted(rkw0) or not self.fresh(rargs[0]) or not self.fresh(_out) or \
+                    not _bits_equal(rargs[0], part):
                 return None
             for o, r in zip(others, list(rargs[1:]) + [rkw[k] for k in sorted(rkw0)]):
                 if o is None:
                     continue
-                if not isinstance(r, torch.Tensor) or not _bits_equal(r, o[t] if isinstance(o, tuple) else o):
+                if not isinstance(r, torch.Tensor) or not self.fresh(r) or not _bits_equal(r, o[t] if isinstance(o, tuple) else o):
                     return None
         return torch.cat([e[1] for e in ents], dim=0)
 
@@ -382,7 +398,7 @@ class TowerMemo:
             graph_stats["memo_hits" if self.hit is not None else "memo_misses"] += 1
         elif index == 0:
             ent = self.entries.get(self.current)
-            if ent is not None and self._same(ent[0], args, kwargs):
+            if ent is not None and self.fresh(ent[1]) and self._same(ent[0], args, kwargs):
                 self.hit = ent[1]
                 graph_stats["memo_hits"] += 1
             else:
@@ -408,7 +424,7 @@ class TowerMemo:
                 if out.shape[0] != b * len(group):
                     return
                 for j, snap, o in zip(group, snaps, out.split(b, dim=0)):
-                    self.entries[j] = (snap, o.detach().clone())
+                    self.entries[j] = (snap, self.keep(o))
                     self.bytes += o.numel() * o.element_size() + sum(v.numel() * v.element_size() for v in list(snap[0]) + list(snap[1].values())
                                                                      if isinstance(v, torch.Tensor))
                     graph_stats["memo_recorded"] += 1
@@ -426,7 +442,7 @@ class TowerMemo:
                 result = result[0]
         if self.ok and self.mode == "record" and index == self.n - 1:
             if isinstance(result, torch.Tensor) and self.pending is not None and self.expect == self.n:
-                self.entries[self.current] = (self.pending, result.detach().clone())
+                self.entries[self.current] = (self.pending, self.keep(result))
                 self.bytes += result.numel() * result.element_size() + sum(
                     v.numel() * v.element_size() for v in list(self.pending[0]) + list(self.pending[1].values())
                     if isinstance(v, torch.Tensor))

@@ -54,6 +54,7 @@ ROUTES = {
     "wiring_per_signature": ({"VLMC_TOWER_SHARE_WIRING": "0"}, "a finished tower is traced once per exact argument signature"),
     "capture_per_sample_behind_pruned": ({"VLMC_CAPTURE_MERGED_PRUNED": "0"}, "ragged batches with a pruned tower on the way (the decoder's phase) are captured one forward per sample"),
     "rows_no_slices": ({"VLMC_ROW_SLICES": "0"}, "a token slice of a padded fp32 stack (the Q-Former's query / text halves) is multiplied with its padding rows"),
+    "memo_copies": ({"VLMC_MEMO_COPY": "1"}, "what a finished tower remembers of a capture phase (its block-0 arguments, its outputs) is copied instead of kept with its version"),
     "host_ctypes": ({"VLMC_FAST": "0"}, "every launch through the ctypes route (no compiled host path)"),
 }
 
