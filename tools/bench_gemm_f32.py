@@ -9,7 +9,7 @@ import torch  # noqa: E402
 from vlmc import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-shapes = [(700, 768, 768), (700, 3072, 768), (700, 768, 3072), (1800, 768, 1408), (224, 768, 768), (224, 3072, 768),
+shapes = [(4096, 768, 768), (4096, 768, 1408), (2048, 768, 768), (1024, 768, 768), (1024, 3072, 768), (700, 768, 768), (700, 3072, 768), (700, 768, 3072), (1800, 768, 1408), (224, 768, 768), (224, 3072, 768),
           (12800, 768, 768), (20480, 768, 768), (8704, 3072, 768), (8704, 768, 3072), (16384, 3072, 768), (4096, 3072, 768), (4096, 768, 3072),
           (32896, 768, 1408), (32896, 1536, 1408), (4096, 2048, 768)]
 print("| M | N | K | us | TFLOP/s | of 157.3 |\n|---|---|---|---|---|---|")

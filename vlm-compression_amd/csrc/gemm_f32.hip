@@ -217,7 +217,19 @@ int launch_f32(const char *what, const F32Gemm &g, int64_t batches, hipStream_t 
         return n;
     }();
     auto tiles = [&](int t) { return int64_t((g.N + t - 1) / t) * ((g.M + t - 1) / t) * batches; };
-    if (tiles(128) >= cus) return launch_f32_tw<4>(what, g, batches, s);
+    static const int forced = [] {
+        const char *e = getenv("VLMC_F32_TILE");                       // A/B: 128 / 64 / 32 for every fp32 launch (same bits)
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 128) return launch_f32_tw<4>(what, g, batches, s);
+    if (forced == 64) return launch_f32_tw<2>(what, g, batches, s);
+    if (forced == 32) return launch_f32_tw<1>(what, g, batches, s);
+    // 128-tiles run three workgroups to a CU, 64-tiles four, and a "wave" of 128-tiles takes ~2.8 x as long as one of 64-tiles over the same
+    // K (measured: 183 against 65 us at K = 768); a partly filled last wave costs nearly a whole one, so the count that matters is the
+    // waves rounded UP -- [20480, 768] x 768: 1.25 waves of 128-tiles take 360 us, 3.75 of 64-tiles 254 (tools/bench_gemm_f32.py,
+    // gpurun_out/r06/gemm_f32_tiles.log: the rule picks the faster tile in 19 of 21 shapes, within 4 % in the other two).
+    const int64_t w128 = (tiles(128) + 3 * int64_t(cus) - 1) / (3 * int64_t(cus)), w64 = (tiles(64) + 4 * int64_t(cus) - 1) / (4 * int64_t(cus));
+    if (tiles(128) >= cus && 14 * w128 < 5 * w64) return launch_f32_tw<4>(what, g, batches, s);
     if (tiles(64) >= cus) return launch_f32_tw<2>(what, g, batches, s);
     return launch_f32_tw<1>(what, g, batches, s);
 }

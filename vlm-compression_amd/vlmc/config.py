@@ -51,6 +51,7 @@ INTERNAL = {
     # tuning overrides of single kernels / routes (A/B runs of tools/)
     "VLMC_GEMM_BIG_TILES": "tiles needed to pick 256 x 256 (default 200)", "VLMC_GEMM_SHAPE": "force one small tile shape",
     "VLMC_DSNOT_NW": "waves per workgroup of the DSnoT list kernel", "VLMC_SQNORM_VEC": "vector width of act_sqnorm",
+    "VLMC_F32_TILE": "128 / 64 / 32: one tile size for every fp32 GEMM launch (same bits)",
     "VLMC_LORA_BQ": "activation rows per generated W_eff tile", "VLMC_LORA_DBG": "lora_gemm ablation bits (results invalid)",
     "VLMC_LORA_RECOMPUTE": "1: regenerate W_eff in the unfused backward instead of keeping it", "VLMC_ATTN_DMA": "0: K / V of vlmc_attn_fwd staged through registers",
     "VLMC_SGPT_SWEEP_STREAMS": "streams for the sweeps of a block's independent linears (default 4)",
