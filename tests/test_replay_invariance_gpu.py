@@ -196,7 +196,7 @@ def test_ragged_samples_padded_into_one_group_keep_their_bits(lora_model, monkey
     base = {"VLMC_BATCH_REPLAY": "128", "VLMC_TOWER_BATCH": "1", "VLMC_PAD_RAGGED": "1", "VLMC_TOWER_PAD": "1", "VLMC_CAPTURE_MERGED": "0"}
     seen = {}
     before_m = calibration.graph_stats.get("merged_forwards", 0)
-    monkeypatch.setattr(calibration, "MERGED_CAPTURE_MIN", 2)
+    monkeypatch.setattr(calibration.replay_capture, "MERGED_CAPTURE_MIN", 2)
     merged, n_m, _ = run({**base, "VLMC_CAPTURE_MERGED": "1", "VLMC_CAPTURE_MERGED_RAGGED": "1"})      # merged forwards per shape, towers deferred (opt-in)
     monkeypatch.delenv("VLMC_CAPTURE_MERGED_RAGGED")
     # (ragged batches: the groups' merged forwards are postponed at the finished towers, which run once, padded, for all samples)
@@ -252,7 +252,7 @@ def test_merged_capture_forwards_give_the_per_sample_routes_bits(n_shapes, monke
                for n, m in model.named_modules() if isinstance(m, torch.nn.Linear) and (".block." in n or ".blocks." in n)}
         return out, calibration.graph_stats.get("merged_forwards", 0) - m0, calibration.graph_stats.get("merged_capture_declined", 0) - d0
 
-    monkeypatch.setattr(calibration, "MERGED_CAPTURE_MIN", 2)             # (16 samples here; the default asks for 24)
+    monkeypatch.setattr(calibration.replay_capture, "MERGED_CAPTURE_MIN", 2)             # (16 samples here; the default asks for 24)
     merged, n_merged, declined = run({"VLMC_CAPTURE_MERGED": "1", "VLMC_BATCH_REPLAY": "128", "VLMC_TOWER_BATCH": "1"})
     assert n_merged == 3 * n_shapes and declined == 0                      # one stacked model forward per tower, capture phase and shape
     per_sample, n0, _ = run({"VLMC_CAPTURE_MERGED": "0"})
@@ -271,7 +271,7 @@ def test_a_model_that_cannot_take_the_merged_batch_is_forwarded_per_sample(monke
     from vlmc import synthetic
     from lavis.compression.pruners import calibration
     dev = torch.device(DEV)
-    monkeypatch.setattr(calibration, "MERGED_CAPTURE_MIN", 2)
+    monkeypatch.setattr(calibration.replay_capture, "MERGED_CAPTURE_MIN", 2)
 
     def run(picky):
         torch.manual_seed(0)

@@ -59,7 +59,7 @@ def test_q_former_run_as_a_finished_tower_gives_the_per_sample_forwards_result(r
     dev = torch.device("cuda:0")
 
     def run(frozen, per_sample):
-        monkeypatch.setattr(calibration, "FROZEN_TOWERS", frozen)
+        monkeypatch.setattr(calibration.replay_towers, "FROZEN_TOWERS", frozen)
         monkeypatch.setenv("VLMC_BATCH_REPLAY", "1" if per_sample else "128")
         monkeypatch.setenv("VLMC_TOWER_BATCH", "0" if per_sample else "1")
         torch.manual_seed(0)                                           # (biases and norm weights keep torch's default, RNG-drawn init)
@@ -122,7 +122,7 @@ def test_q_former_with_the_references_call_contract_takes_the_stacked_routes(rag
     from vlmc import forward, synthetic
     from lavis.compression.pruners import calibration
     dev = torch.device("cuda:0")
-    monkeypatch.setattr(calibration, "MERGED_CAPTURE_MIN", 2)
+    monkeypatch.setattr(calibration.replay_capture, "MERGED_CAPTURE_MIN", 2)
 
     def run(per_sample):
         monkeypatch.setenv("VLMC_BATCH_REPLAY", "1" if per_sample else "128")
