@@ -197,7 +197,21 @@ def test_ragged_samples_padded_into_one_group_keep_their_bits(lora_model, monkey
     seen = {}
     before_m = calibration.graph_stats.get("merged_forwards", 0)
     monkeypatch.setattr(calibration.replay_capture, "MERGED_CAPTURE_MIN", 2)
+    declined0, slices0 = calibration.graph_stats.get("merged_capture_declined", 0), forward.stats["kernel_slices"]
     merged, n_m, _ = run({**base, "VLMC_CAPTURE_MERGED": "1", "VLMC_CAPTURE_MERGED_RAGGED": "1"})      # merged forwards per shape, towers deferred (opt-in)
+    # (round 6, second half) no phase declined -- the decoder's phase runs merged although the pruned encoder lies on the way -- and the
+    # fp32 Q-Former ran as a padded pass whose token slices (its query / text feed-forward halves) were read in place
+    assert calibration.graph_stats.get("merged_capture_declined", 0) == declined0 and forward.stats["kernel_slices"] > slices0, \
+        (calibration.graph_stats, forward.stats)
+    variants = {}
+    for env_, name_ in (({"VLMC_CAPTURE_MERGED_PRUNED": "0"}, "decoder's capture per sample"), ({"VLMC_ROW_SLICES": "0"}, "slices with their padding rows"),
+                        ({"VLMC_MEMO_COPY": "1"}, "memo copies")):
+        d_ = calibration.graph_stats.get("merged_capture_declined", 0)
+        variants[name_], _, _ = run({**base, "VLMC_CAPTURE_MERGED": "1", "VLMC_CAPTURE_MERGED_RAGGED": "1", **env_})
+        if "VLMC_CAPTURE_MERGED_PRUNED" in env_:
+            assert calibration.graph_stats.get("merged_capture_declined", 0) == d_ + 1           # the decoder's phase, and only it
+        for k_ in env_:
+            monkeypatch.delenv(k_)
     monkeypatch.delenv("VLMC_CAPTURE_MERGED_RAGGED")
     # (ragged batches: the groups' merged forwards are postponed at the finished towers, which run once, padded, for all samples)
     assert calibration.graph_stats.get("merged_forwards", 0) > before_m and n_m == 2 * 2 * 3, calibration.graph_stats
@@ -220,7 +234,7 @@ def test_ragged_samples_padded_into_one_group_keep_their_bits(lora_model, monkey
     assert padded.keys() == shaped.keys() == single.keys() and len(padded) == 2 * 4 + 3 * 7 + 3 * 11
     for k in padded:
         for other, name in ((shaped, "groups of equal shapes"), (single, "per-sample loop"), (towers_per_length, "towers per token count"),
-                            (merged, "merged capture forwards"), (every_row, "padding rows computed")):
+                            (merged, "merged capture forwards"), (every_row, "padding rows computed")) + tuple((v_, n_) for n_, v_ in variants.items()):
             assert torch.equal(padded[k][0], other[k][0]), (k, name)
             assert (padded[k][1] is None and other[k][1] is None) or torch.equal(padded[k][1], other[k][1]), (k, name)
 
