@@ -166,12 +166,26 @@ def row_map(lengths, padded, device):
     return int32_on(order, device), int(real.sum())
 
 
+def _ragged_to_padded(pieces, padded, fill):
+    """[T_j, ...] tensors -> [n, padded, ...], `fill` behind each sample's own rows: ONE concatenation and ONE scatter of the real rows (a copy per
+    sample -- `pad_sequence`, or a Python loop of slice assignments -- was ~550 copy launches at the start of every T5 walk)."""
+    import numpy as np
+    n, lengths = len(pieces), [int(p_.shape[0]) for p_ in pieces]
+    flat = torch.cat(pieces, dim=0)
+    shape = (n * padded,) + tuple(flat.shape[1:])
+    out = flat.new_zeros(shape) if fill == 0 else torch.full(shape, fill, dtype=flat.dtype, device=flat.device)
+    ln = np.asarray(lengths, dtype=np.int64)
+    tok = np.arange(padded, dtype=np.int64)[None, :]
+    rows = (np.arange(n, dtype=np.int64)[:, None] * padded + tok)[tok < ln[:, None]]
+    idx = torch.from_numpy(rows)
+    idx = idx.pin_memory().to(flat.device, non_blocking=True) if flat.is_cuda else idx
+    out.index_copy_(0, idx, flat)
+    return out.view((n, padded) + tuple(flat.shape[1:]))
+
+
 def _pad_inputs(xs, tp):
     """[1, T_j, d] tensors -> [n, tp, d], zero rows behind each sample's own"""
-    x = torch.nn.utils.rnn.pad_sequence([x_[0] for x_ in xs], batch_first=True)
-    if x.shape[1] < tp:
-        x = torch.nn.functional.pad(x, (0, 0, 0, tp - x.shape[1]))
-    return x
+    return _ragged_to_padded([x_[0] for x_ in xs], tp, 0)
 
 
 def _pad_caches(group, spec):
@@ -183,12 +197,15 @@ def _pad_caches(group, spec):
         if not isinstance(v0, torch.Tensor):
             out[k] = v0
         elif k in PAD_STATE_KEYS:
-            x = torch.nn.utils.rnn.pad_sequence([c[k][0] for c in group], batch_first=True)
-            out[k] = torch.nn.functional.pad(x, (0, 0, 0, sp - x.shape[1])) if x.shape[1] < sp else x
+            out[k] = _ragged_to_padded([c[k][0] for c in group], sp, 0)
         else:
             keys = tp if PAD_MASK_KEYS[k] == "self" else sp
             q = tp if v0.shape[2] != 1 else 1
-            m = torch.full((n, 1, q, keys), torch.finfo(v0.dtype).min, dtype=v0.dtype, device=v0.device)
+            lowest = torch.finfo(v0.dtype).min
+            if q == 1:                                               # [1, 1, 1, keys_j]: one row of keys per sample
+                out[k] = _ragged_to_padded([c[k].reshape(-1) for c in group], keys, lowest).view(n, 1, 1, keys)
+                continue
+            m = torch.full((n, 1, q, keys), lowest, dtype=v0.dtype, device=v0.device)
             for t, c in enumerate(group):
                 v = c[k]
                 m[t, :, :v.shape[2], :v.shape[3]] = v[0]
