@@ -120,3 +120,29 @@ def test_other_threads_see_the_original_functions_through_the_patches():
         assert forward.stats["attn_library"] == before + 1                             # and still routing it
     assert seen == {"eq": True, "eq2": True, "counted": 0}
     assert "__matmul__" not in torch.Tensor.__dict__
+
+
+def test_function_mode_routes_the_same_calls_without_assigning_anything(monkeypatch):
+    """`VLMC_TORCH_FUNCTION_MODE=1` (the cross-check route VERDICT r5 item 8 asked to be tried): the routing through a scoped
+    TorchFunctionMode -- no attribute of torch is touched, the same calls are counted, an exception leaves nothing behind."""
+    monkeypatch.setenv("VLMC_TORCH_FUNCTION_MODE", "1")
+    orig = (torch.matmul, torch.bmm, torch.softmax, torch.mean)
+    x, y = torch.randn(2, 3, 4), torch.randn(2, 4, 5)
+    want = x @ y
+    before = dict(forward.stats)
+    with pytest.raises(ZeroDivisionError):
+        with forward.invariant_matmuls():
+            assert (torch.matmul, torch.bmm, torch.softmax, torch.mean) == orig and "__matmul__" not in torch.Tensor.__dict__
+            with torch.no_grad():
+                for got in (x @ y, torch.matmul(x, y), torch.bmm(x, y), x.matmul(y), x.bmm(y)):
+                    assert torch.equal(got, want)
+                assert torch.equal(torch.softmax(x, -1), x.softmax(-1)) and torch.equal(x.mean(-1), torch.mean(x, -1))
+            with forward.invariant_matmuls():                        # nests
+                with torch.no_grad():
+                    x @ y
+            1 / 0
+    assert forward.stats["attn_library"] - before["attn_library"] == 6 and forward.stats["attn_kernel"] == before["attn_kernel"]
+    with torch.no_grad():
+        x @ y                                                       # outside: not routed, not counted
+    assert forward.stats["attn_library"] - before["attn_library"] == 6
+

@@ -55,6 +55,7 @@ ROUTES = {
     "capture_per_sample_behind_pruned": ({"VLMC_CAPTURE_MERGED_PRUNED": "0"}, "ragged batches with a pruned tower on the way (the decoder's phase) are captured one forward per sample"),
     "rows_no_slices": ({"VLMC_ROW_SLICES": "0"}, "a token slice of a padded fp32 stack (the Q-Former's query / text halves) is multiplied with its padding rows"),
     "memo_copies": ({"VLMC_MEMO_COPY": "1"}, "what a finished tower remembers of a capture phase (its block-0 arguments, its outputs) is copied instead of kept with its version"),
+    "patches_as_function_mode": ({"VLMC_TORCH_FUNCTION_MODE": "1"}, "the replay's routing of matmul / softmax / gelu / mean / sdpa through a scoped TorchFunctionMode instead of attribute patches"),
     "host_ctypes": ({"VLMC_FAST": "0"}, "every launch through the ctypes route (no compiled host path)"),
 }
 

@@ -820,6 +820,46 @@ def _make_gelu(orig):
     return gelu
 
 
+def function_mode_enabled():
+    return os.environ.get("VLMC_TORCH_FUNCTION_MODE", "0") == "1"
+
+
+class _ReplayMode(torch.overrides.TorchFunctionMode):
+    """The replay's routing as a torch-function mode: a call of one of the table's functions goes to its handler (the closures the
+    attribute patches install), every other call straight through."""
+
+    def __init__(self, table):
+        super().__init__()
+        self.table = table
+
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        h = self.table.get(func)
+        if h is None:
+            return func(*args, **kwargs) if kwargs else func(*args)
+        return h(*args, **kwargs) if kwargs else h(*args)
+
+
+def _function_table():
+    """function object -> handler, for the switches in force (built per context: the closures read the switches when made)"""
+    import torch.nn.functional as F_
+    base = torch._C.TensorBase
+    t = {}
+    for f in (torch.matmul, torch.bmm, base.__matmul__, base.matmul, base.bmm):
+        t[f] = _make_matmul(f)
+    if os.environ.get("VLMC_SDPA", "1") != "0":
+        t[F_.scaled_dot_product_attention] = _make_sdpa(F_.scaled_dot_product_attention)
+    if softmax_enabled():
+        t[F_.softmax] = _make_softmax(F_.softmax, True)
+        t[torch.softmax] = _make_softmax(torch.softmax, False)
+        t[base.softmax] = _make_softmax(base.softmax, False)
+    if os.environ.get("VLMC_GELU", "1") != "0":
+        t[F_.gelu] = _make_gelu(F_.gelu)
+    if os.environ.get("VLMC_ROW_MEAN", "1") != "0":
+        t[torch.mean] = _make_mean(torch.mean)
+        t[base.mean] = _make_mean(base.mean)
+    return t
+
+
 @contextlib.contextmanager
 def invariant_matmuls():
     """Batched 16-bit `matmul`s run on `vlmc_attn_matmul`, fp32 means over the last dimension on `vlmc_row_mean`, for the
@@ -827,6 +867,24 @@ def invariant_matmuls():
     global _mm_depth, _mm_owner
     if not (enabled() and attn_matmul_enabled()) or (_mm_depth > 0 and _mm_owner != _ident()):
         yield
+        return
+    if function_mode_enabled():
+        # the same routing through a scoped `torch.overrides.TorchFunctionMode` instead of attribute patches: nothing
+        # global is assigned, nothing to restore.  Measured slower -- every torch call of the forward then goes through Python once more
+        # (profiles/r06_phase_timeline.md 6) -- so it is the cross-check route, not the default.
+        _mm_depth += 1
+        try:
+            if _mm_depth > 1:                                    # nested: the outer context's mode is in force
+                yield
+            else:
+                _mm_owner = _ident()
+                with _ReplayMode(_function_table()):
+                    yield
+        finally:
+            _mm_depth -= 1
+            if _mm_depth == 0:
+                _realize_escaped()
+                _mm_owner = None
         return
     if _mm_depth == 0:
         _mm_owner = _ident()
