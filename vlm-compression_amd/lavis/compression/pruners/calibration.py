@@ -280,8 +280,24 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                 with statistics_only(subset, tail_learned) as so:
                     _run_pass(before_sample, so, False)
 
+    def materialise(lst):
+        """the per-sample views of a padded pass's output that were not cut when it ran (below)"""
+        pend = lazy.pop(id(lst), None)
+        for key_, (y_, lens_) in (pend or {}).items():
+            slices_ = [y_[t:t + 1, :tj] for t, tj in enumerate(lens_)]
+            slices_[0]._vlmc_stack = (y_, key_, slices_)
+            for t, j in enumerate(key_):
+                lst[j] = slices_[t]
+
     def _run_pass(before_sample, so, outputs):
         cur_in, cur_out = state["inps"], state["outs"]
+        if outputs:
+            lazy.pop(id(cur_out), None)                               # (whatever an earlier pass left pending there is overwritten now)
+        pend_in = lazy.get(id(cur_in))
+        if pend_in is not None and (group_max == 1 or "chunks" not in plan or {tuple(c) for c in plan["chunks"]} != set(pend_in)
+                                     or any(plan["pad"].get(k_) is None for k_ in pend_in)):
+            materialise(cur_in)                                       # (another route than the padded groups the outputs were left stacked for)
+            pend_in = None
         keys = None
         sig = None
         for k_ in [k_ for k_, g_ in graphs.items() if g_ is not False]:     # the first pass's graphs, if the block's
@@ -320,7 +336,8 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                 j += 1
             return
         # blocks of a tower map [.., T, d] to [.., T, d]: the plan of the first pass holds while the shapes do
-        shapes = [tuple(cur_in[j].shape) for j in range(n_samples)]
+        # (inputs that are still one stacked tensor per padded group: the shapes are the plan's -- a block maps [.., T, d] to [.., T, d])
+        shapes = plan["shapes"] if pend_in is not None else [tuple(cur_in[j].shape) for j in range(n_samples)]
         if plan.get("shapes") != shapes:
             plan["shapes"] = shapes
             padded = plan_padded(cur_in, caches, n_samples, group_max) if (pad_ragged and group_max > 1) else None
@@ -351,8 +368,10 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                     # a PADDED group of ragged samples: one forward; the outputs are handed on padded (the next block takes
                     # the same tensor), every sample sees its own rows of it
                     key, spec = tuple(chunk), plan["pad"][tuple(chunk)]
-                    prev = getattr(cur_in[chunk[0]], "_vlmc_stack", None)
-                    if prev is not None and prev[1] == key and all(cur_in[j] is prev[2][t] for t, j in enumerate(chunk)):
+                    prev = getattr(cur_in[chunk[0]], "_vlmc_stack", None) if pend_in is None else None
+                    if pend_in is not None:
+                        x = pend_in[key][0]                           # the previous block's stacked output, never cut per sample
+                    elif prev is not None and prev[1] == key and all(cur_in[j] is prev[2][t] for t, j in enumerate(chunk)):
                         x = prev[0]
                     else:
                         x = _pad_inputs([cur_in[j] for j in chunk], spec["tp"])
@@ -371,10 +390,9 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                     if so is not None:
                         so.end_forward(True)
                     y = y[0] if tuple_output else y
-                    slices = [y[t:t + 1, :tj] for t, tj in enumerate(spec["T"])]
-                    slices[0]._vlmc_stack = (y, key, slices)
-                    for t, j in enumerate(chunk):
-                        cur_out[j] = slices[t]
+                    # the next block takes the stacked tensor itself; the samples' own views of it (128 x 2 indexing calls: 0.25 ms per
+                    # block of a host-paced tower) are cut when somebody wants them -- another route, or the end of the walk
+                    lazy.setdefault(id(cur_out), {})[key] = (y, spec["T"])
                 else:
                     b0 = cur_in[chunk[0]].shape[0]
                     _CTX.stacked = (len(chunk), b0, tuple(chunk))
@@ -419,7 +437,7 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
                     for t, j in enumerate(chunk):
                         cur_out[j] = slices[t]
 
-    graphs, plan, stacked_kwargs, tail_learned = {}, {}, {}, {}
+    graphs, plan, stacked_kwargs, tail_learned, lazy = {}, {}, {}, {}, {}
     sibling_names = []
     for i in range(len(layers)):
         layer = layers[i]
@@ -440,6 +458,8 @@ def walk_blocks(model, inps, outs, caches, module_to_process, n_samples, autocas
             sibling_names = [tuple(by_id[id(m)] for m in g) for g in forward.sibling_groups(subset.values())
                              if all(id(m) in by_id for m in g)]
         state["inps"], state["outs"] = state["outs"], state["inps"]
+    materialise(state["inps"])
+    materialise(state["outs"])
     if memo_cache is not None and not tuple_output:
         seed_tower_memo(memo_cache, module_to_process, layers, state["inps"][:n_samples], autocast)
     return model
