@@ -1,5 +1,5 @@
 // Compiled host path for the entry points a calibration replay calls thousands of times: vlmc_linear_fwd,
-// vlmc_linear_fwd_group, vlmc_attn_matmul, vlmc_row_mean, vlmc_sdpa_fwd and vlmc_rms_norm (include/vlmc.h).
+// vlmc_linear_fwd_group, vlmc_linear_fwd_rows, vlmc_attn_matmul, vlmc_row_mean, vlmc_sdpa_fwd and vlmc_rms_norm (include/vlmc.h).
 //
 // The replay of the reference's per-sample block forwards (wanda_pruner.py:308-311, :343-346) issues 1 000 - 15 000 of these
 // launches per prune, most of them on a few hundred rows when the calibration text is ragged or the samples are sharded over
@@ -114,6 +114,50 @@ py::object linear_fwd_group(const at::Tensor &x, const std::vector<at::Tensor> &
     return std::move(out);
 }
 
+// the same over a ROW MAP (a padded group of ragged calibration samples; vlmc/ops.py: linear_fwd_rows): 16-bit or fp32; None when the
+// call is not one the kernel takes (the caller's ctypes route then raises with the reason)
+py::object linear_fwd_rows(const at::Tensor &x, const std::vector<at::Tensor> &ws, const std::vector<c10::optional<at::Tensor>> &bs,
+                           const at::Tensor &rowmap, int64_t n_real, int64_t stream) {
+    const size_t n = ws.size();
+    if (n < 1 || n > 4 || bs.size() != n || !x.is_cuda()) return py::none();
+    const bool f32 = x.scalar_type() == at::kFloat;
+    for (size_t g = 0; g < n; ++g) {
+        if (ws[g].dim() != 2 || ws[g].size(1) != ws[0].size(1)) return py::none();
+        if (f32) {
+            const at::Tensor &w = ws[g];
+            if (!w.is_cuda() || w.scalar_type() != at::kFloat || x.dim() < 1 || x.size(-1) != w.size(1) || w.size(1) == 0 || w.stride(1) != 1) return py::none();
+            if (bs[g].has_value() && bs[g]->defined() && (!bs[g]->is_cuda() || bs[g]->scalar_type() != at::kFloat || !bs[g]->is_contiguous())) return py::none();
+        } else if (!linear_ok(x, ws[g], bs[g])) {
+            return py::none();
+        }
+    }
+    const int64_t K = ws[0].size(1);
+    at::Tensor x2 = x.reshape({-1, K});
+    if (x2.stride(1) != 1 || x2.stride(0) < K || (!f32 && (x2.stride(0) % 8 != 0 || !aligned16(x2.data_ptr())))) x2 = x2.contiguous();
+    const int64_t M = x2.size(0);
+    if (!rowmap.is_cuda() || rowmap.scalar_type() != at::kInt || rowmap.dim() != 1 || rowmap.size(0) != M || !rowmap.is_contiguous() || n_real < 1 ||
+        n_real > M)
+        return py::none();
+    vlmc_linear_job jobs[4];
+    std::vector<at::Tensor> ys;
+    ys.reserve(n);
+    for (size_t g = 0; g < n; ++g) {
+        const int64_t N = ws[g].size(0);
+        ys.push_back(at::empty({M, N}, x.options()));
+        jobs[g].W = ws[g].data_ptr();
+        jobs[g].bias = (bs[g].has_value() && bs[g]->defined()) ? bs[g]->data_ptr() : nullptr;
+        jobs[g].Y = ys.back().data_ptr();
+        jobs[g].N = N;
+        jobs[g].ldw = ws[g].stride(0);
+        jobs[g].ldy = N;
+    }
+    check(vlmc_linear_fwd_rows(x2.data_ptr(), jobs, int(n), f32 ? VLMC_F32 : dtype_code(x.scalar_type()), M, K, x2.stride(0),
+                               static_cast<const int32_t *>(rowmap.data_ptr()), n_real, reinterpret_cast<void *>(stream)));
+    py::list out;
+    for (size_t g = 0; g < n; ++g) out.append(py::cast(ys[g].reshape(lead_shape(x, ws[g].size(0)))));
+    return std::move(out);
+}
+
 // torch.matmul(a, b) for the batched products of attention; None when vlmc_attn_matmul does not compute the call
 // (the conditions of vlmc/ops.py: attn_matmul_plan)
 py::object attn_matmul(const at::Tensor &a, const at::Tensor &b, int64_t stream) {
@@ -216,5 +260,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("row_mean", &row_mean, py::arg("x"), py::arg("keepdim"), py::arg("stream"));
     m.def("sdpa", &sdpa, py::arg("q"), py::arg("k"), py::arg("v"), py::arg("scale"), py::arg("causal"), py::arg("stream"));
     m.def("rms_norm", &rms_norm, py::arg("x"), py::arg("weight"), py::arg("eps"), py::arg("rsqrt_mode"), py::arg("stream"));
+    m.def("linear_fwd_rows", &linear_fwd_rows);
     m.def("abi_version", []() { return vlmc_abi_version(); });
 }

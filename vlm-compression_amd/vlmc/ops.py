@@ -229,6 +229,10 @@ def linear_fwd_rows(x: torch.Tensor, weights, biases, rowmap: torch.Tensor, n_re
     n = len(weights)
     if biases is None:
         biases = [None] * n
+    if _fast is not None and x.is_cuda and hasattr(_fast, "linear_fwd_rows"):
+        outs = _fast.linear_fwd_rows(x, list(weights), list(biases), rowmap, int(n_real), _stream())
+        if outs is not None:
+            return outs                                               # (None: not a call the kernel takes -- the checks below say why)
     if not 1 <= n <= LINEAR_GROUP_MAX or len(biases) != n:
         raise ValueError(f"linear_fwd_rows takes 1..{LINEAR_GROUP_MAX} weights and as many biases")
     _need_gpu(x, rowmap, *weights, *[b for b in biases if b is not None])
