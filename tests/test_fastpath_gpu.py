@@ -39,6 +39,25 @@ def test_linear_routes_agree(dtype, monkeypatch):
     assert torch.equal(a, c)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+def test_row_mapped_linear_routes_agree(dtype, monkeypatch):
+    """vlmc_linear_fwd_rows through vlmc/_fast and through ctypes: same outputs (16-bit group launch; fp32 one launch per member), and
+    the calls the kernel does not take fall through to the ctypes route's checks."""
+    from vlmc import ops
+    g = torch.Generator(device=DEV).manual_seed(3)
+    lengths, tp, K = [9, 3, 12, 1, 7], 12, 256
+    x = (torch.randn(len(lengths), tp, K, generator=g, device=DEV) * 0.5).to(dtype)
+    real = [j * tp + t for j, n in enumerate(lengths) for t in range(n)]
+    pad = [j * tp + t for j, n in enumerate(lengths) for t in range(n, tp)]
+    rowmap = torch.tensor(real + pad, dtype=torch.int32, device=DEV)
+    ws = [(torch.randn(n, K, generator=g, device=DEV) * 0.05).to(dtype) for n in (64, 200)]
+    bs = [(torch.randn(64, generator=g, device=DEV) * 0.1).to(dtype), None]
+    a, c = _both(monkeypatch, lambda: ops.linear_fwd_rows(x, ws, bs, rowmap, len(real)))
+    assert len(a) == 2 and all(p.shape == (len(lengths), tp, w.shape[0]) and torch.equal(p, q) for p, q, w in zip(a, c, ws))
+    with pytest.raises(ValueError):
+        ops.linear_fwd_rows(x, ws, bs, rowmap[:-1].contiguous(), len(real))          # (the compiled path answers None, the ctypes route says why)
+
+
 def test_attention_products_routes_agree(monkeypatch):
     from vlmc import ops
     g = torch.Generator(device=DEV).manual_seed(1)
