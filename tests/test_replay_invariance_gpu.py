@@ -205,7 +205,7 @@ def test_ragged_samples_padded_into_one_group_keep_their_bits(lora_model, monkey
         (calibration.graph_stats, forward.stats)
     variants = {}
     for env_, name_ in (({"VLMC_CAPTURE_MERGED_PRUNED": "0"}, "decoder's capture per sample"), ({"VLMC_ROW_SLICES": "0"}, "slices with their padding rows"),
-                        ({"VLMC_MEMO_COPY": "1"}, "memo copies")):
+                        ({"VLMC_MEMO_COPY": "1"}, "memo copies"), ({"VLMC_REPLAY_TOKENS": "40"}, "several padded chunks per block pass")):
         d_ = calibration.graph_stats.get("merged_capture_declined", 0)
         variants[name_], _, _ = run({**base, "VLMC_CAPTURE_MERGED": "1", "VLMC_CAPTURE_MERGED_RAGGED": "1", **env_})
         if "VLMC_CAPTURE_MERGED_PRUNED" in env_:
