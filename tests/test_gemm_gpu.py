@@ -500,6 +500,32 @@ def test_linear_fwd_gather_reads_a_token_slice_in_place(lengths, P, a, L, K, N):
     assert bool(torch.isfinite(y).all())
 
 
+def test_linear_fwd_gather_refuses_what_it_does_not_compute():
+    from vlmc import _lib, ops
+    x = torch.zeros(2, 4, 64, device=DEV)
+    w = torch.zeros(8, 64, device=DEV)
+    xr = torch.arange(4, dtype=torch.int32, device=DEV)
+    yr = torch.arange(8, dtype=torch.int32, device=DEV)
+    with pytest.raises(TypeError):
+        ops.linear_fwd_gather(x.half(), w.half(), None, xr, yr, 4, 8, 64)            # fp32 only
+    with pytest.raises(ValueError):
+        ops.linear_fwd_gather(x, w, None, xr, yr[:7].contiguous(), 4, 8, 64)         # y_rows must name every output row
+    with pytest.raises(ValueError):
+        ops.linear_fwd_gather(x, w, None, xr.long(), yr, 4, 8, 64)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.linear_fwd_gather(x.cpu(), w.cpu(), None, xr.cpu(), yr.cpu(), 4, 8, 64)
+    lib = _lib.load()
+    y = torch.empty(8, 8, device=DEV)
+    args = (x.data_ptr(), w.data_ptr(), None)
+    assert lib.vlmc_linear_fwd_gather(*args, _lib.F16, 8, 64, 64, 64, y.data_ptr(), 8, xr.data_ptr(), yr.data_ptr(), 4, 4, None) == _lib.VLMC_EINVAL
+    assert b"VLMC_F32" in lib.vlmc_last_error()
+    assert lib.vlmc_linear_fwd_gather(*args, _lib.F32, 8, 64, 32, 64, y.data_ptr(), 8, xr.data_ptr(), yr.data_ptr(), 4, 4, None) == _lib.VLMC_EINVAL   # ldx < K
+    assert lib.vlmc_linear_fwd_gather(*args, _lib.F32, 8, 64, 64, 64, y.data_ptr(), 8, None, yr.data_ptr(), 4, 4, None) == _lib.VLMC_EINVAL          # rows without x_rows
+    assert lib.vlmc_linear_fwd_gather(*args, _lib.F32, 8, 64, 64, 64, y.data_ptr(), 8, None, yr.data_ptr(), 0, 8, None) == _lib.VLMC_OK              # nothing real: y cleared
+    torch.cuda.synchronize()
+    assert bool((y == 0).all())
+
+
 def test_fp32_linears_of_a_padded_stack_take_their_real_rows_only():
     """vlmc/forward.py inside `padded_rows`: the contiguous stack by its leading shape, a token slice by what it is a view of, the
     slice's output and its GELU by the map they carry -- each equal to the full computation on the real rows, zero on the others."""
