@@ -697,10 +697,10 @@ def test_a_wrong_prediction_is_noticed_and_the_phase_runs_again(batched_trace, m
         tampered.append(j)
     real_run, real_begin = cal.TowerGraph.run_predicted, cal.TowerGraph._begin_batched_trace
 
-    def run_predicted(self, samples):
+    def run_predicted(self, samples, *more):
         if batched_trace == "0" and self.predicted and not self.memo_serves and not tampered and any(w for w in self.wirings.values()):
             tamper(self)
-        return real_run(self, samples)
+        return real_run(self, samples, *more)
 
     def begin(self, key, args, kwargs, ext):
         if batched_trace == "1" and self.predicted and not self.memo_serves and not tampered:

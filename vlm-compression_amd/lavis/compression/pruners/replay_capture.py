@@ -309,9 +309,10 @@ def _capture_merged(model, batches, module_to_process, forward_to_cache, lora_mo
         flags = []                                               # device-side verdicts, read once at the end (no wait per forward)
         with torch.no_grad(), forward.invariant_linears(all_linears(model, proxy_cache), roots=[b for t in towers for b in t.mods]):
             everyone = list(range(len(mine)))
+            group_of = {j: groups[s_][0] for s_ in order for j in groups[s_]}     # (the samples of a group stay neighbours in a tower's padded stack)
             if defer:
                 for t in pruned_on_the_way:
-                    t.run_predicted(everyone)                   # (towers whose wiring a previous prune traced: now; else after the scout has traced it)
+                    t.run_predicted(everyone, group_of)         # (towers whose wiring a previous prune traced: now; else after the scout has traced it)
             _CTX.keep_ready = defer
             one = run([scout], alone=defer)                     # one sample alone: the shapes of a batch-1 call, and the bits to hold the merge to
             for _ in range(len(towers) + 1):                     # (a tower whose wiring an earlier phase traced postpones this forward too)
@@ -326,7 +327,7 @@ def _capture_merged(model, batches, module_to_process, forward_to_cache, lora_mo
                 return None
             if defer:
                 for t in pruned_on_the_way:
-                    t.run_predicted(everyone)                   # (no-op for the samples that have their outputs)
+                    t.run_predicted(everyone, group_of)         # (no-op for the samples that have their outputs)
             names1 = tensors_of(one)
             batched = None                                       # name -> the per-sample batch extent of a tensor that carries the batch dimension, else 0
             rows = max(1, one[0].numel() // max(1, one[0].shape[-1]))

@@ -609,7 +609,34 @@ class TowerGraph:
             recs = [self.ready.pop(j) for j in grp]
             if all(self._same_inputs(r, a_, k_) for r, (a_, k_) in zip(recs, per)):
                 outs, stacked = [], {}
-                for i in range(self.n):
+                # neighbours of one length in ONE padded pass (its stack is sorted by length): what the blocks before the last hand the
+                # group is a VIEW of the pass's outputs -- nobody computes on it (the model passes it to the next block, which is served);
+                # the last block's outputs, which the model does compute on, are stacked into tensors of their own as before
+                ps, t0 = recs[0].get("pass"), recs[0].get("t")
+                near = ps is not None and all(r.get("pass") is ps and r.get("t") == t0 + k_ for k_, r in enumerate(recs)) and \
+                    len({ps["lens"][r["t"]] for r in recs}) == 1 and os.environ.get("VLMC_GROUP_VIEWS", "1") != "0"
+                n_views = self.n - 1 if near else 0
+                whole = len(ps["lens"]) if near else 0
+                for i in range(n_views):
+                    flat = []
+                    for o, c_ in zip(ps["flats"][i], ps["cut"][i]):
+                        if c_ is None:
+                            flat.append(o)
+                            continue
+                        hit = stacked.get(id(o))
+                        if hit is None or hit[0] is not o:
+                            v = o
+                            if c_[0] is not None:                        # carries the batch: the group's rows of the stack
+                                b0_ = o.shape[0] // whole
+                                v = v.narrow(0, t0 * b0_, g * b0_)
+                            for d in c_[1]:
+                                v = v.narrow(d, 0, ps["lens"][t0])
+                            hit = stacked[id(o)] = (o, v)
+                        flat.append(hit[1])
+                    outs.append(self._like(ps["outs"][i], flat))
+                if n_views:
+                    graph_stats["group_views"] = graph_stats.get("group_views", 0) + 1
+                for i in range(n_views, self.n):
                     firsts = recs[0]["outs"][i]
                     flats = [self._flat(r["outs"][i]) for r in recs]
                     flat = []
@@ -636,7 +663,7 @@ class TowerGraph:
             return False, None
         ctx = TowerMemo.context()
         for j, key_j, (a_, k_) in zip(grp, keys, per):
-            self.deferred.append({"j": j, "key": key_j, "args": a_, "kwargs": k_, "ctx": ctx})
+            self.deferred.append({"j": j, "key": key_j, "args": a_, "kwargs": k_, "ctx": ctx, "group": grp[0]})   # (groups of one length stay together in the padded stack)
         raise _Defer
 
     # -- tracing the wiring WHILE the tower runs stacked ---------------------------------------------------------------------
@@ -946,7 +973,7 @@ class TowerGraph:
                 count[ckey] = have + 1
         return out
 
-    def run_predicted(self, samples):
+    def run_predicted(self, samples, group_of=None):
         """The stacked tower pass BEFORE the forwards that will ask for it.
 
         A finished tower normally learns a sample's block-0 arguments by running the model's forward up to block 0 and
@@ -971,7 +998,7 @@ class TowerGraph:
             wiring = self._wiring(key) if key is not None else None
             if not wiring or not self._batchable(args, kwargs, ctx):
                 continue
-            recs.append({"j": j, "key": key, "args": args, "kwargs": kwargs, "ctx": ctx})
+            recs.append({"j": j, "key": key, "args": args, "kwargs": kwargs, "ctx": ctx, "group": (group_of or {}).get(j, -1)})
         if recs:
             held, self.deferred = self.deferred, recs
             try:
@@ -1002,7 +1029,11 @@ class TowerGraph:
             t_s, shapes = self.shapes.get(base, (None, None))
             if len(keys) < 2 or not calls or t_s is None or len(shapes) != len(calls):
                 continue
-            recs = sorted((r for k in keys for r in groups[k]), key=lambda r: r["j"])
+            # by token count, then by sample: the samples of one length -- a group of the merged capture -- are then NEIGHBOURS in the
+            # padded stack, and their stacked outputs are views of it (enter_group)
+            recs = sorted((r for k in keys for r in groups[k]),
+                          key=lambda r: (r["args"][0].shape[1] if isinstance(r["args"][0], torch.Tensor) and r["args"][0].dim() >= 2 else 0,
+                                         r.get("group", -1), r["j"]))
             ctx = recs[0]["ctx"]
             # arguments behind the hidden states that the model passes POSITIONALLY (a BERT layer of the Q-Former: Qformer.py:541-550)
             # are padded under the names the block's forward gives them -- the names plan_padded knows masks and states by
@@ -1071,6 +1102,7 @@ class TowerGraph:
                 if not ok:
                     break
                 flats = [self._flat(out) for out in outs]
+                this_pass = {"outs": outs, "flats": flats, "cut": cut, "lens": lens}
                 for t, rec in enumerate(crecs):
                     n_t, mine = lens[t], []
                     for out, fl, row in zip(outs, flats, cut):
@@ -1091,7 +1123,7 @@ class TowerGraph:
                             views[(id(o), t)] = (o, v, c_[1])
                             flat.append(v)
                         mine.append(self._like(out, flat))
-                    done[rec["j"]] = {"outs": mine, "args": rec["args"], "kwargs": rec["kwargs"], "key": rec["key"]}
+                    done[rec["j"]] = {"outs": mine, "args": rec["args"], "kwargs": rec["kwargs"], "key": rec["key"], "pass": this_pass, "t": t}
                 graph_stats["tower_batches"] = graph_stats.get("tower_batches", 0) + 1
                 graph_stats["tower_padded_passes"] = graph_stats.get("tower_padded_passes", 0) + 1
             if not ok:

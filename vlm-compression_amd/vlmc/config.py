@@ -37,7 +37,7 @@ CROSSCHECK = {
     "VLMC_SGPT_DIRECT_FACTOR", "VLMC_CHOL_GRAPH", "VLMC_SGPT_DEFER", "VLMC_SGPT_PERSISTENT", "VLMC_RMS_NORM", "VLMC_SDPA_DMA", "VLMC_SDPA",
     "VLMC_ATTN_MATMUL", "VLMC_ROW_MEAN", "VLMC_ATTN_TR", "VLMC_LORA_FUSED", "VLMC_GELU", "VLMC_ATTN_FUSED", "VLMC_PAD_RAGGED", "VLMC_TOWER_PAD",
     "VLMC_TOWER_SHARE_WIRING", "VLMC_SGPT_BLOCK_LOOP", "VLMC_ROW_MAP", "VLMC_CAPTURE_MERGED", "VLMC_CAPTURE_MERGED_RAGGED", "VLMC_SOFTMAX",
-    "VLMC_CAPTURE_MERGED_PRUNED", "VLMC_ROW_SLICES", "VLMC_MEMO_COPY", "VLMC_TORCH_FUNCTION_MODE",
+    "VLMC_CAPTURE_MERGED_PRUNED", "VLMC_ROW_SLICES", "VLMC_MEMO_COPY", "VLMC_TORCH_FUNCTION_MODE", "VLMC_GROUP_VIEWS",
 }
 
 INTERNAL = {

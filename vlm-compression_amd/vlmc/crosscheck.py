@@ -56,6 +56,7 @@ ROUTES = {
     "rows_no_slices": ({"VLMC_ROW_SLICES": "0"}, "a token slice of a padded fp32 stack (the Q-Former's query / text halves) is multiplied with its padding rows"),
     "memo_copies": ({"VLMC_MEMO_COPY": "1"}, "what a finished tower remembers of a capture phase (its block-0 arguments, its outputs) is copied instead of kept with its version"),
     "patches_as_function_mode": ({"VLMC_TORCH_FUNCTION_MODE": "1"}, "the replay's routing of matmul / softmax / gelu / mean / sdpa through a scoped TorchFunctionMode instead of attribute patches"),
+    "group_stacks": ({"VLMC_GROUP_VIEWS": "0"}, "a merged forward's group is handed copies (torch.cat) of every block output of a finished tower, not views of the padded pass"),
     "host_ctypes": ({"VLMC_FAST": "0"}, "every launch through the ctypes route (no compiled host path)"),
 }
 
