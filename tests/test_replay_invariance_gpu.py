@@ -198,14 +198,17 @@ def test_ragged_samples_padded_into_one_group_keep_their_bits(lora_model, monkey
     before_m = calibration.graph_stats.get("merged_forwards", 0)
     monkeypatch.setattr(calibration.replay_capture, "MERGED_CAPTURE_MIN", 2)
     declined0, slices0 = calibration.graph_stats.get("merged_capture_declined", 0), forward.stats["kernel_slices"]
+    views0 = calibration.graph_stats.get("group_views", 0)
     merged, n_m, _ = run({**base, "VLMC_CAPTURE_MERGED": "1", "VLMC_CAPTURE_MERGED_RAGGED": "1"})      # merged forwards per shape, towers deferred (opt-in)
     # (round 6, second half) no phase declined -- the decoder's phase runs merged although the pruned encoder lies on the way -- and the
     # fp32 Q-Former ran as a padded pass whose token slices (its query / text feed-forward halves) were read in place
     assert calibration.graph_stats.get("merged_capture_declined", 0) == declined0 and forward.stats["kernel_slices"] > slices0, \
         (calibration.graph_stats, forward.stats)
+    assert calibration.graph_stats.get("group_views", 0) > views0              # .. whose groups were handed views of the padded pass
     variants = {}
     for env_, name_ in (({"VLMC_CAPTURE_MERGED_PRUNED": "0"}, "decoder's capture per sample"), ({"VLMC_ROW_SLICES": "0"}, "slices with their padding rows"),
-                        ({"VLMC_MEMO_COPY": "1"}, "memo copies"), ({"VLMC_REPLAY_TOKENS": "40"}, "several padded chunks per block pass")):
+                        ({"VLMC_MEMO_COPY": "1"}, "memo copies"), ({"VLMC_REPLAY_TOKENS": "40"}, "several padded chunks per block pass"),
+                        ({"VLMC_GROUP_VIEWS": "0"}, "groups handed copies, not views of the padded pass")):
         d_ = calibration.graph_stats.get("merged_capture_declined", 0)
         variants[name_], _, _ = run({**base, "VLMC_CAPTURE_MERGED": "1", "VLMC_CAPTURE_MERGED_RAGGED": "1", **env_})
         if "VLMC_CAPTURE_MERGED_PRUNED" in env_:
